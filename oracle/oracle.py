@@ -1,0 +1,323 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes loaders for the two CPU checkers.
+
+  * ``Oracle``  -> oracle/liblora_oracle.so   plain-C restatement (lora_oracle.c)
+  * ``Ref``     -> oracle/_ref/libloraref.so  the real reference sources compiled in
+                   place by oracle/Makefile (present only where /root/reference was)
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import
+this module. The product package ``lora_sdr_amd`` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liblora_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libloraref.so")
+
+_f32p = C.POINTER(C.c_float)
+_i16p = C.POINTER(C.c_int16)
+_u16p = C.POINTER(C.c_uint16)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+def build(quiet=True):
+    """(Re)build the checkers with oracle/Makefile (gcc/g++ only)."""
+    subprocess.run(["make", "-C", HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def _ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(ty)
+
+
+def _cf(a):
+    """complex64 array -> contiguous complex64"""
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+class WorkResult(C.Structure):
+    _fields_ = [("consumed", C.c_int64), ("stateBefore", C.c_int32), ("value", C.c_int32),
+                ("power", C.c_float), ("powerAvg", C.c_float), ("snr", C.c_float), ("fIndex", C.c_float),
+                ("packetPosted", C.c_int32), ("packetLen", C.c_int32), ("signalsEmitted", C.c_int32),
+                ("sigError", C.c_int32), ("sigPower", C.c_float), ("sigSnr", C.c_float),
+                ("label", C.c_char * 48)]
+
+
+class Oracle:
+    """The plain-C restatement."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = self.L = C.CDLL(ORACLE_SO)
+        L.lo_fft_new.restype = C.c_void_p
+        L.lo_fft_new.argtypes = [C.c_int]
+        L.lo_fft_free.argtypes = [C.c_void_p]
+        L.lo_fft_twiddles.restype = _f32p
+        L.lo_fft_twiddles.argtypes = [C.c_void_p]
+        L.lo_fft_stages.argtypes = [C.c_void_p, _i32p, _i32p]
+        L.lo_fft_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_detect.restype = C.c_size_t
+        L.lo_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p]
+        L.lo_demod_tables.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_dechirp.restype = C.c_int
+        L.lo_dechirp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.lo_detect_batch.argtypes = [C.c_int, C.c_void_p, C.c_size_t, _i64p, _i32p, _i32p, _f32p,
+                                      _u16p, _f32p, _f32p, _f32p, _i32p, C.c_void_p, C.c_void_p, C.c_int]
+        L.lo_genchirp.restype = C.c_int
+        L.lo_genchirp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, _f32p]
+        L.lo_mod_frame.restype = C.c_size_t
+        L.lo_mod_frame.argtypes = [C.c_int, C.c_ubyte, C.c_float, C.c_size_t, _u16p, C.c_size_t, C.c_void_p, _f32p]
+        L.lo_mod_frame_len.restype = C.c_size_t
+        L.lo_mod_frame_len.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
+        L.lo_demod_new.restype = C.c_void_p
+        L.lo_demod_new.argtypes = [C.c_int]
+        L.lo_demod_free.argtypes = [C.c_void_p]
+        L.lo_demod_set_sync.argtypes = [C.c_void_p, C.c_ubyte]
+        L.lo_demod_set_threshold.argtypes = [C.c_void_p, C.c_double]
+        L.lo_demod_set_mtu.argtypes = [C.c_void_p, C.c_size_t]
+        L.lo_demod_activate.argtypes = [C.c_void_p]
+        L.lo_demod_work.restype = C.c_int
+        L.lo_demod_work.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(WorkResult),
+                                    C.c_void_p, C.c_void_p, _i16p]
+        L.lo_demod_bench.restype = C.c_int64
+        L.lo_demod_bench.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+
+    # -- kissfft ---------------------------------------------------------
+    def twiddles(self, N):
+        f = self.L.lo_fft_new(N)
+        p = self.L.lo_fft_twiddles(f)
+        tw = np.ctypeslib.as_array(p, shape=(2 * N,)).copy().view(np.complex64)
+        self.L.lo_fft_free(f)
+        return tw
+
+    def stages(self, N):
+        f = self.L.lo_fft_new(N)
+        r = np.zeros(32, np.int32)
+        m = np.zeros(32, np.int32)
+        n = self.L.lo_fft_stages(f, _ptr(r, _i32p), _ptr(m, _i32p))
+        self.L.lo_fft_free(f)
+        return list(zip(r[:n].tolist(), m[:n].tolist()))
+
+    def fft(self, x):
+        x = _cf(x)
+        f = self.L.lo_fft_new(x.size)
+        out = np.empty_like(x)
+        self.L.lo_fft_transform(f, x.ctypes.data, out.ctypes.data)
+        self.L.lo_fft_free(f)
+        return out
+
+    def detect(self, x):
+        """LoRaDetector feed+detect on one window -> (index, power, powerAvg, fIndex, fft)"""
+        x = _cf(x)
+        f = self.L.lo_fft_new(x.size)
+        out = np.empty_like(x)
+        p, pa, fi = C.c_float(), C.c_float(), C.c_float()
+        idx = self.L.lo_detect(f, x.ctypes.data, out.ctypes.data, C.byref(p), C.byref(pa), C.byref(fi))
+        self.L.lo_fft_free(f)
+        return int(idx), p.value, pa.value, fi.value, out
+
+    # -- demod -----------------------------------------------------------
+    def tables(self, sf, fine=True):
+        N = 1 << sf
+        up = np.empty(N, np.complex64)
+        down = np.empty(N, np.complex64)
+        fi = np.empty(N * 128, np.complex64) if fine else None
+        self.L.lo_demod_tables(sf, up.ctypes.data, down.ctypes.data, fi.ctypes.data if fine else None)
+        return up, down, fi
+
+    def dechirp(self, x, chirp, fine, idx, err):
+        x = _cf(x)
+        out = np.empty_like(x)
+        idx1 = self.L.lo_dechirp(x.size, x.ctypes.data, _cf(chirp).ctypes.data, _cf(fine).ctypes.data,
+                                 int(idx), float(err), out.ctypes.data)
+        return out, idx1
+
+    def detect_batch(self, sf, iq, n_windows=None, offsets=None, chirp_sel=None, fine_idx0=None,
+                     fine_err=None, want_fft=False, want_dec=False, nthreads=1):
+        N = 1 << sf
+        iq = _cf(iq).reshape(-1)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, np.int64)
+            n = offsets.size
+        else:
+            n = iq.size // N if n_windows is None else n_windows
+        cs = None if chirp_sel is None else np.ascontiguousarray(np.broadcast_to(chirp_sel, (n,)), np.int32)
+        i0 = None if fine_idx0 is None else np.ascontiguousarray(np.broadcast_to(fine_idx0, (n,)), np.int32)
+        fe = None if fine_err is None else np.ascontiguousarray(np.broadcast_to(fine_err, (n,)), np.float32)
+        sym = np.empty(n, np.uint16)
+        power = np.empty(n, np.float32)
+        pavg = np.empty(n, np.float32)
+        fidx = np.empty(n, np.float32)
+        idx1 = np.empty(n, np.int32)
+        fft = np.empty((n, N), np.complex64) if want_fft else None
+        dec = np.empty((n, N), np.complex64) if want_dec else None
+        self.L.lo_detect_batch(sf, iq.ctypes.data, n, _ptr(offsets, _i64p), _ptr(cs, _i32p), _ptr(i0, _i32p),
+                               _ptr(fe, _f32p), _ptr(sym, _u16p), _ptr(power, _f32p), _ptr(pavg, _f32p),
+                               _ptr(fidx, _f32p), _ptr(idx1, _i32p),
+                               fft.ctypes.data if want_fft else None, dec.ctypes.data if want_dec else None,
+                               int(nthreads))
+        return dict(sym=sym, power=power, powerAvg=pavg, fIndex=fidx, fineIdxOut=idx1, fft=fft, dec=dec)
+
+    # -- chirps / frames -------------------------------------------------
+    def genchirp(self, N, ovs, NN, f0, down, ampl, phase):
+        out = np.empty(NN, np.complex64)
+        ph = C.c_float(phase)
+        self.L.lo_genchirp(out.ctypes.data, N, ovs, NN, float(f0), int(bool(down)), float(ampl), C.byref(ph))
+        return out, ph.value
+
+    def mod_frame(self, sf, syms, sync=0x12, ampl=1.0, padding=1):
+        syms = np.ascontiguousarray(syms, np.uint16)
+        n = self.L.lo_mod_frame_len(sf, padding, syms.size)
+        out = np.empty(n, np.complex64)
+        ph = C.c_float(0)
+        w = self.L.lo_mod_frame(sf, sync, float(ampl), padding, _ptr(syms, _u16p), syms.size, out.ctypes.data, C.byref(ph))
+        assert w == n
+        return out
+
+    # -- the LoRaDemod block --------------------------------------------
+    def demod_run(self, sf, iq, sync=0x12, thresh=-30.0, mtu=256, keep=True):
+        """Run the restated block over a stream -> dict of per-call logs + packets"""
+        N = 1 << sf
+        iq = _cf(iq)
+        d = self.L.lo_demod_new(sf)
+        self.L.lo_demod_set_sync(d, sync)
+        self.L.lo_demod_set_threshold(d, thresh)
+        self.L.lo_demod_set_mtu(d, mtu)
+        pos = 0
+        res = WorkResult()
+        dec = np.zeros(2 * N, np.complex64)
+        fft = np.zeros(N, np.complex64)
+        pkt = np.zeros(max(mtu, 1), np.int16)
+        calls, packets, signals, ffts, decs = [], [], [], [], []
+        while self.L.lo_demod_work(d, iq.ctypes.data + 8 * pos, iq.size - pos, C.byref(res),
+                                   dec.ctypes.data, fft.ctypes.data, _ptr(pkt, _i16p)):
+            calls.append(dict(consumed=res.consumed, state=res.stateBefore, value=res.value, power=res.power,
+                              powerAvg=res.powerAvg, snr=res.snr, fIndex=res.fIndex, label=res.label.decode()))
+            if keep:
+                ffts.append(fft.copy())
+                decs.append(dec.copy())
+            if res.packetPosted:
+                packets.append((len(calls) - 1, pkt[:res.packetLen].copy()))
+            if res.signalsEmitted:
+                signals.append((res.sigError, res.sigPower, res.sigSnr))
+            pos += res.consumed
+            if res.consumed == 0:
+                break
+        self.L.lo_demod_free(d)
+        return dict(calls=calls, packets=packets, signals=signals, fft=ffts, dec=decs)
+
+    def demod_bench(self, sf, iq, samples_per_stream, n_streams, nthreads):
+        iq = _cf(iq)
+        return int(self.L.lo_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads))
+
+
+class Ref:
+    """The real reference code (LoRaDetector.hpp, kissfft.hh, ChirpGenerator.hpp, LoRaDemod.cpp)."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def __init__(self):
+        L = self.L = C.CDLL(REF_SO)
+        L.loraref_detector_new.restype = C.c_void_p
+        L.loraref_detector_new.argtypes = [C.c_size_t]
+        L.loraref_detector_free.argtypes = [C.c_void_p]
+        L.loraref_detector_detect.restype = C.c_size_t
+        L.loraref_detector_detect.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]
+        L.loraref_detect_windows.argtypes = [C.c_size_t, C.c_void_p, C.c_size_t, _u16p, _f32p, _f32p, _f32p,
+                                             C.c_void_p, C.c_int]
+        L.loraref_genchirp.restype = C.c_int
+        L.loraref_genchirp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, _f32p]
+        L.loraref_demod_new.restype = C.c_void_p
+        L.loraref_demod_new.argtypes = [C.c_size_t, C.c_int]
+        L.loraref_demod_free.argtypes = [C.c_void_p]
+        L.loraref_demod_set.restype = C.c_int
+        L.loraref_demod_set.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.loraref_demod_run.restype = C.c_int64
+        L.loraref_demod_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        for n in ("num_calls", "num_packets", "num_signals"):
+            getattr(L, "loraref_demod_" + n).restype = C.c_size_t
+            getattr(L, "loraref_demod_" + n).argtypes = [C.c_void_p]
+        L.loraref_demod_get_calls.argtypes = [C.c_void_p, _i64p, C.c_void_p, C.c_void_p]
+        L.loraref_demod_get_label.restype = C.c_size_t
+        L.loraref_demod_get_label.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.loraref_demod_packet_len.restype = C.c_size_t
+        L.loraref_demod_packet_len.argtypes = [C.c_void_p, C.c_size_t]
+        L.loraref_demod_packet_call.restype = C.c_int64
+        L.loraref_demod_packet_call.argtypes = [C.c_void_p, C.c_size_t]
+        L.loraref_demod_get_packet.argtypes = [C.c_void_p, C.c_size_t, _i16p]
+        L.loraref_demod_get_signal.restype = C.c_double
+        L.loraref_demod_get_signal.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.loraref_demod_bench.restype = C.c_int64
+        L.loraref_demod_bench.argtypes = [C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+
+    def detect(self, x):
+        x = _cf(x)
+        d = self.L.loraref_detector_new(x.size)
+        out = np.empty_like(x)
+        p, pa, fi = C.c_float(), C.c_float(), C.c_float()
+        idx = self.L.loraref_detector_detect(d, x.size, x.ctypes.data, C.byref(p), C.byref(pa), C.byref(fi),
+                                             out.ctypes.data)
+        self.L.loraref_detector_free(d)
+        return int(idx), p.value, pa.value, fi.value, out
+
+    def detect_windows(self, N, iq, want_fft=False, nthreads=1):
+        iq = _cf(iq).reshape(-1)
+        n = iq.size // N
+        sym = np.empty(n, np.uint16)
+        power = np.empty(n, np.float32)
+        pavg = np.empty(n, np.float32)
+        fidx = np.empty(n, np.float32)
+        fft = np.empty((n, N), np.complex64) if want_fft else None
+        self.L.loraref_detect_windows(N, iq.ctypes.data, n, _ptr(sym, _u16p), _ptr(power, _f32p),
+                                      _ptr(pavg, _f32p), _ptr(fidx, _f32p),
+                                      fft.ctypes.data if want_fft else None, int(nthreads))
+        return dict(sym=sym, power=power, powerAvg=pavg, fIndex=fidx, fft=fft)
+
+    def genchirp(self, N, ovs, NN, f0, down, ampl, phase):
+        out = np.empty(NN, np.complex64)
+        ph = C.c_float(phase)
+        self.L.loraref_genchirp(out.ctypes.data, N, ovs, NN, float(f0), int(bool(down)), float(ampl), C.byref(ph))
+        return out, ph.value
+
+    def demod_run(self, sf, iq, sync=0x12, thresh=-30.0, mtu=256):
+        N = 1 << sf
+        iq = _cf(iq)
+        h = self.L.loraref_demod_new(sf, 1)
+        assert h, "registry has no /lora/lora_demod"
+        self.L.loraref_demod_set(h, b"setSync", float(sync))
+        self.L.loraref_demod_set(h, b"setThreshold", float(thresh))
+        self.L.loraref_demod_set(h, b"setMTU", float(mtu))
+        self.L.loraref_demod_run(h, iq.ctypes.data, iq.size)
+        n = self.L.loraref_demod_num_calls(h)
+        consumed = np.zeros(n, np.int64)
+        fft = np.zeros((n, N), np.complex64)
+        dec = np.zeros((n, 2 * N), np.complex64)
+        self.L.loraref_demod_get_calls(h, _ptr(consumed, _i64p), fft.ctypes.data, dec.ctypes.data)
+        buf = C.create_string_buffer(64)
+        labels = []
+        for i in range(n):
+            self.L.loraref_demod_get_label(h, i, buf, 64)
+            labels.append(buf.value.decode())
+        packets = []
+        for i in range(self.L.loraref_demod_num_packets(h)):
+            ln = self.L.loraref_demod_packet_len(h, i)
+            p = np.zeros(ln, np.int16)
+            self.L.loraref_demod_get_packet(h, i, _ptr(p, _i16p))
+            packets.append((int(self.L.loraref_demod_packet_call(h, i)), p))
+        signals = []
+        for i in range(self.L.loraref_demod_num_signals(h)):
+            v = self.L.loraref_demod_get_signal(h, i, buf, 64)
+            signals.append((buf.value.decode(), v))
+        self.L.loraref_demod_free(h)
+        return dict(consumed=consumed, labels=labels, fft=fft, dec=dec, packets=packets, signals=signals)
+
+    def demod_bench(self, sf, iq, samples_per_stream, n_streams, nthreads):
+        iq = _cf(iq)
+        return int(self.L.loraref_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads))

@@ -1,0 +1,250 @@
+// TEST INFRASTRUCTURE ONLY (oracle/) -- never linked or called by the product path.
+//
+// Thin extern "C" driver around the REAL reference code, compiled in place from
+// /root/reference (see oracle/Makefile; output goes to oracle/_ref/ only):
+//   * LoRaDetector.hpp + kissfft.hh      (framework-free, included below verbatim)
+//   * ChirpGenerator.hpp                 (needs only the empty stub Pothos/Config.hpp)
+//   * LoRaDemod.cpp                      (separate TU, verbatim, against the recording
+//                                          fake in oracle/stub/Pothos/Framework.hpp)
+// It exists to (1) pin the plain-C restatement in oracle/lora_oracle.c, (2) generate the
+// golden vectors in tests/golden/, (3) serve as the "reference" CPU baseline in bench.py.
+//
+// The reference leaves LoRaDemod::_finefreqError/_freqError/_prevValue uninitialised
+// (LoRaDemod.cpp:68-74 vs :160,:183). This library replaces operator new
+// with a zero-filling one (linked -Bsymbolic so only this .so is affected) so that the
+// block starts from the all-zero state the restatement and the HIP path define.
+#include <Pothos/Framework.hpp>
+#include <cstdlib>
+#include <new>
+#include <thread>
+#include "LoRaDetector.hpp"
+#include "ChirpGenerator.hpp"
+
+void *operator new(std::size_t n)
+{
+    void *p = std::calloc(n ? n : 1, 1);
+    if (p == nullptr) throw std::bad_alloc();
+    return p;
+}
+void *operator new[](std::size_t n) { return operator new(n); }
+void operator delete(void *p) noexcept { std::free(p); }
+void operator delete[](void *p) noexcept { std::free(p); }
+void operator delete(void *p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
+
+typedef std::complex<float> cf32;
+
+namespace {
+
+struct DemodHandle
+{
+    Pothos::Block *block;
+    size_t N;
+    std::vector<cf32> raw, dec, fft;
+    //logs across work() calls
+    std::vector<int64_t> consumed;      // per call
+    std::vector<std::string> labels;    // per call: label posted on "raw" this call ("" if none)
+    std::vector<float> fftLog;          // N floats*2 per call
+    std::vector<float> decLog;          // 2N floats*2 per call (full port buffer snapshot)
+    std::vector<std::vector<int16_t>> packets;
+    std::vector<int64_t> packetCall;    // call index that posted each packet
+    std::vector<Pothos::SignalRecord> signals;
+    bool keepBuffers;
+};
+
+} // namespace
+
+extern "C" {
+
+/***********************************************************************
+ * LoRaDetector<float> (LoRaDetector.hpp:8-72)
+ **********************************************************************/
+void *loraref_detector_new(const size_t N) { return new LoRaDetector<float>(N); }
+void loraref_detector_free(void *d) { delete reinterpret_cast<LoRaDetector<float> *>(d); }
+
+size_t loraref_detector_detect(void *d, const size_t N, const float *iq,
+                               float *power, float *powerAvg, float *fIndex, float *fftOut)
+{
+    auto det = reinterpret_cast<LoRaDetector<float> *>(d);
+    auto in = reinterpret_cast<const cf32 *>(iq);
+    for (size_t i = 0; i < N; i++) det->feed(i, in[i]);
+    return det->detect(*power, *powerAvg, *fIndex, reinterpret_cast<cf32 *>(fftOut));
+}
+
+//! n independent windows of already-dechirped samples, split over nthreads
+void loraref_detect_windows(const size_t N, const float *iq, const size_t nWindows,
+                            uint16_t *sym, float *power, float *powerAvg, float *fIndex,
+                            float *fftOut, const int nthreads)
+{
+    auto body = [=](const size_t lo, const size_t hi)
+    {
+        LoRaDetector<float> det(N);
+        auto in = reinterpret_cast<const cf32 *>(iq);
+        for (size_t w = lo; w < hi; w++)
+        {
+            for (size_t i = 0; i < N; i++) det.feed(i, in[w * N + i]);
+            cf32 *out = fftOut ? reinterpret_cast<cf32 *>(fftOut) + w * N : nullptr;
+            sym[w] = uint16_t(det.detect(power[w], powerAvg[w], fIndex[w], out));
+        }
+    };
+    const size_t T = nthreads > 1 ? size_t(nthreads) : 1;
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < T; t++)
+        pool.emplace_back(body, nWindows * t / T, nWindows * (t + 1) / T);
+    for (auto &th : pool) th.join();
+}
+
+/***********************************************************************
+ * genChirp<float> (ChirpGenerator.hpp:22-47)
+ **********************************************************************/
+int loraref_genchirp(float *samps, const int N, const int ovs, const int NN, const float f0,
+                     const int down, const float ampl, float *phaseAccum)
+{
+    return genChirp(reinterpret_cast<cf32 *>(samps), N, ovs, NN, f0, down != 0, ampl, *phaseAccum);
+}
+
+/***********************************************************************
+ * LoRaDemod block (LoRaDemod.cpp, through the registry like a topology would)
+ **********************************************************************/
+void *loraref_demod_new(const size_t sf, const int keepBuffers)
+{
+    auto it = Pothos::BlockRegistry::table().find("/lora/lora_demod");
+    if (it == Pothos::BlockRegistry::table().end()) return nullptr;
+    auto h = new DemodHandle();
+    h->block = it->second(sf);
+    h->N = size_t(1) << sf;
+    h->keepBuffers = keepBuffers != 0;
+    //the buffer-manager hooks set the reserves (LoRaDemod.cpp:330-358)
+    h->block->getInputBufferManager("0", "");
+    h->block->getOutputBufferManager("raw", "");
+    h->block->getOutputBufferManager("dec", "");
+    h->block->getOutputBufferManager("fft", "");
+    h->raw.resize(2 * h->N); h->dec.resize(2 * h->N); h->fft.resize(h->N);
+    h->block->output("raw")->_buff = Pothos::BufferChunk::view(h->raw.data(), 2 * h->N * sizeof(cf32));
+    h->block->output("dec")->_buff = Pothos::BufferChunk::view(h->dec.data(), 2 * h->N * sizeof(cf32));
+    h->block->output("fft")->_buff = Pothos::BufferChunk::view(h->fft.data(), h->N * sizeof(cf32));
+    h->block->activate();
+    return h;
+}
+
+void loraref_demod_free(void *p)
+{
+    auto h = reinterpret_cast<DemodHandle *>(p);
+    delete h->block;
+    delete h;
+}
+
+int loraref_demod_set(void *p, const char *name, const double v)
+{
+    auto h = reinterpret_cast<DemodHandle *>(p);
+    auto it = h->block->calls.find(name);
+    if (it == h->block->calls.end()) return -1;
+    it->second(v);
+    return 0;
+}
+
+//! Feed a whole stream: call work() until fewer than 2N elements remain (LoRaDemod.cpp:148).
+//! Returns the number of work() calls made; logs are appended to the handle.
+int64_t loraref_demod_run(void *p, const float *iq, const size_t nSamples)
+{
+    auto h = reinterpret_cast<DemodHandle *>(p);
+    auto in = h->block->input(0);
+    auto raw = h->block->output("raw"), dec = h->block->output("dec"), fft = h->block->output("fft");
+    auto out0 = h->block->output(0);
+    size_t pos = 0;
+    int64_t calls = 0;
+    while (true)
+    {
+        in->_elems = nSamples - pos;
+        in->_buff = Pothos::BufferChunk::view(const_cast<float *>(iq) + 2 * pos, (nSamples - pos) * sizeof(cf32));
+        in->consumed = 0;
+        if (in->_elems < 2 * h->N) break;
+        const size_t nLabels = raw->labels.size();
+        const size_t nMsgs = out0->messages.size();
+        h->block->work();
+        calls++;
+        if (h->keepBuffers)
+        {
+            h->consumed.push_back(int64_t(in->consumed));
+            h->labels.push_back(raw->labels.size() > nLabels ? raw->labels.back().id : std::string());
+            auto f = reinterpret_cast<const float *>(h->fft.data());
+            h->fftLog.insert(h->fftLog.end(), f, f + 2 * h->N);
+            auto d = reinterpret_cast<const float *>(h->dec.data());
+            h->decLog.insert(h->decLog.end(), d, d + 4 * h->N);
+        }
+        for (size_t m = nMsgs; m < out0->messages.size(); m++)
+        {
+            const auto &bytes = out0->messages[m];
+            std::vector<int16_t> syms(bytes.size() / sizeof(int16_t));
+            if (!syms.empty()) std::memcpy(syms.data(), bytes.data(), syms.size() * sizeof(int16_t));
+            h->packets.push_back(syms);
+            h->packetCall.push_back(int64_t(h->consumed.size()) - 1);
+        }
+        if (!h->keepBuffers) { out0->messages.clear(); raw->labels.clear(); dec->labels.clear(); fft->labels.clear(); }
+        pos += in->consumed;
+        if (in->consumed == 0) break; //cannot happen in the reference; guards the loop
+    }
+    return calls;
+}
+
+size_t loraref_demod_num_calls(void *p) { return reinterpret_cast<DemodHandle *>(p)->consumed.size(); }
+size_t loraref_demod_num_packets(void *p) { return reinterpret_cast<DemodHandle *>(p)->packets.size(); }
+size_t loraref_demod_num_signals(void *p) { return reinterpret_cast<DemodHandle *>(p)->block->signals.size(); }
+
+void loraref_demod_get_calls(void *p, int64_t *consumed, float *fftLog, float *decLog)
+{
+    auto h = reinterpret_cast<DemodHandle *>(p);
+    if (consumed) std::memcpy(consumed, h->consumed.data(), h->consumed.size() * sizeof(int64_t));
+    if (fftLog) std::memcpy(fftLog, h->fftLog.data(), h->fftLog.size() * sizeof(float));
+    if (decLog) std::memcpy(decLog, h->decLog.data(), h->decLog.size() * sizeof(float));
+}
+
+//! copies label i (NUL terminated, truncated to cap) and returns its length
+size_t loraref_demod_get_label(void *p, const size_t i, char *buf, const size_t cap)
+{
+    auto h = reinterpret_cast<DemodHandle *>(p);
+    const std::string &s = h->labels.at(i);
+    if (cap) { std::strncpy(buf, s.c_str(), cap - 1); buf[cap - 1] = 0; }
+    return s.size();
+}
+
+size_t loraref_demod_packet_len(void *p, const size_t i) { return reinterpret_cast<DemodHandle *>(p)->packets.at(i).size(); }
+int64_t loraref_demod_packet_call(void *p, const size_t i) { return reinterpret_cast<DemodHandle *>(p)->packetCall.at(i); }
+void loraref_demod_get_packet(void *p, const size_t i, int16_t *out)
+{
+    const auto &s = reinterpret_cast<DemodHandle *>(p)->packets.at(i);
+    if (!s.empty()) std::memcpy(out, s.data(), s.size() * sizeof(int16_t));
+}
+
+//! signal i: name into buf, value returned
+double loraref_demod_get_signal(void *p, const size_t i, char *buf, const size_t cap)
+{
+    const auto &r = reinterpret_cast<DemodHandle *>(p)->block->signals.at(i);
+    if (cap) { std::strncpy(buf, r.name.c_str(), cap - 1); buf[cap - 1] = 0; }
+    return r.value;
+}
+
+//! CPU baseline: nthreads blocks, each runs its own contiguous stream; returns total work() calls
+int64_t loraref_demod_bench(const size_t sf, const float *iq, const size_t samplesPerStream,
+                            const int nStreams, const int nthreads)
+{
+    std::vector<int64_t> calls(size_t(nStreams), 0);
+    auto body = [&](const int lo, const int hi)
+    {
+        for (int s = lo; s < hi; s++)
+        {
+            void *h = loraref_demod_new(sf, 0);
+            calls[size_t(s)] = loraref_demod_run(h, iq + 2 * size_t(s) * samplesPerStream, samplesPerStream);
+            loraref_demod_free(h);
+        }
+    };
+    const int T = nthreads > 1 ? nthreads : 1;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; t++) pool.emplace_back(body, nStreams * t / T, nStreams * (t + 1) / T);
+    for (auto &th : pool) th.join();
+    int64_t total = 0;
+    for (auto c : calls) total += c;
+    return total;
+}
+
+} // extern "C"

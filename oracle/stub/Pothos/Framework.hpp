@@ -1,0 +1,203 @@
+// TEST INFRASTRUCTURE ONLY (oracle/): a minimal stand-in for <Pothos/Framework.hpp>.
+//
+// Pothos is not installed in this image, so the reference's LoRaDemod.cpp cannot be
+// built against the real framework. This header provides just enough of the Pothos
+// surface that LoRaDemod.cpp touches (SURVEY.md §8b symbol list; LoRaDemod.cpp:76-94,
+// 147-154, 295-298, 316-324, 330-358, 395) for the file to compile VERBATIM from
+// /root/reference and be driven by oracle/ref_driver.cpp. It is a recording fake:
+// ports are plain host buffers owned by the driver, labels / messages / signals are
+// appended to per-block logs. Nothing here is product code.
+#pragma once
+#include <complex>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <typeinfo>
+#include <vector>
+
+namespace Pothos {
+
+struct DType
+{
+    DType(void) : size(1) {}
+    DType(const std::type_info &t) : size(1)
+    {
+        if (t == typeid(std::complex<float>)) size = sizeof(std::complex<float>);
+        else if (t == typeid(int16_t)) size = sizeof(int16_t);
+        else if (t == typeid(float)) size = sizeof(float);
+    }
+    size_t size;
+};
+
+struct Object
+{
+    Object(void) {}
+};
+
+struct Label
+{
+    template <typename IdT>
+    Label(const IdT &id, const Object &, const size_t index) : id(id), index(index) {}
+    std::string id;
+    size_t index;
+};
+
+//! shared-ownership buffer, copy = alias (same as the real BufferChunk)
+struct BufferChunk
+{
+    BufferChunk(void) : address(0), length(0) {}
+    BufferChunk(const DType &dtype, const size_t numElems) :
+        address(0), length(dtype.size * numElems), _mem(new char[dtype.size * numElems + 16], std::default_delete<char[]>())
+    {
+        std::memset(_mem.get(), 0, length + 16);
+        address = size_t(_mem.get());
+    }
+    //! view of externally owned memory (driver side)
+    static BufferChunk view(void *p, const size_t bytes)
+    {
+        BufferChunk b;
+        b.address = size_t(p);
+        b.length = bytes;
+        return b;
+    }
+    template <typename T> T as(void) const { return reinterpret_cast<T>(address); }
+    size_t address;
+    size_t length;
+    std::shared_ptr<char> _mem;
+};
+
+struct Packet
+{
+    BufferChunk payload;
+};
+
+struct BufferManagerArgs
+{
+    BufferManagerArgs(void) : numBuffers(4), bufferSize(8192), nodeAffinity(-1) {}
+    size_t numBuffers;
+    size_t bufferSize;
+    long nodeAffinity;
+};
+
+struct BufferManager
+{
+    typedef std::shared_ptr<BufferManager> Sptr;
+    static Sptr make(const std::string &name, const BufferManagerArgs &args)
+    {
+        Sptr m(new BufferManager());
+        m->name = name;
+        m->args = args;
+        return m;
+    }
+    std::string name;
+    BufferManagerArgs args;
+};
+
+struct InputPort
+{
+    InputPort(void) : reserve(0), _elems(0), consumed(0) {}
+    void setReserve(const size_t n) { reserve = n; }
+    size_t elements(void) const { return _elems; }
+    const BufferChunk &buffer(void) const { return _buff; }
+    void consume(const size_t n) { consumed += n; }
+    size_t reserve;
+    size_t _elems;
+    BufferChunk _buff;
+    size_t consumed;
+};
+
+struct OutputPort
+{
+    OutputPort(void) : reserve(0), produced(0) {}
+    void setReserve(const size_t n) { reserve = n; }
+    const BufferChunk &buffer(void) const { return _buff; }
+    void produce(const size_t n) { produced += n; }
+    void postLabel(const Label &l) { labels.push_back(l); }
+    template <typename T> void postMessage(const T &m) { _post(m); }
+    void _post(const Packet &p)
+    {
+        //deep-copy at post time: the block may keep writing to the shared chunk
+        std::vector<char> bytes(p.payload.length);
+        if (p.payload.length) std::memcpy(bytes.data(), p.payload.as<const char *>(), p.payload.length);
+        messages.push_back(bytes);
+    }
+    size_t reserve;
+    BufferChunk _buff;
+    size_t produced;
+    std::vector<Label> labels;
+    std::vector<std::vector<char>> messages;
+};
+
+struct SignalRecord
+{
+    std::string name;
+    double value;
+};
+
+class Block
+{
+public:
+    virtual ~Block(void) {}
+    virtual void activate(void) {}
+    virtual void deactivate(void) {}
+    virtual void work(void) {}
+
+    //! setters become name -> callable(double) so the driver can reach non-virtual members
+    template <typename C, typename A>
+    void registerCall(C *obj, const char *name, void (C::*m)(A))
+    {
+        calls[name] = [obj, m](const double v) { (obj->*m)(static_cast<A>(v)); };
+    }
+    void registerSignal(const std::string &name) { signalNames.push_back(name); }
+    template <typename T>
+    void emitSignal(const std::string &name, const T &v)
+    {
+        SignalRecord r; r.name = name; r.value = double(v);
+        signals.push_back(r);
+    }
+
+    void setupInput(const int i, const DType & = DType()) { inputs[std::to_string(i)]; }
+    void setupInput(const std::string &n, const DType & = DType()) { inputs[n]; }
+    void setupOutput(const int i, const DType & = DType()) { outputs[std::to_string(i)]; }
+    void setupOutput(const std::string &n, const DType & = DType()) { outputs[n]; }
+    void setupOutput(const char *n, const DType &d = DType()) { setupOutput(std::string(n), d); }
+
+    InputPort *input(const int i) { return &inputs.at(std::to_string(i)); }
+    InputPort *input(const std::string &n) { return &inputs.at(n); }
+    OutputPort *output(const int i) { return &outputs.at(std::to_string(i)); }
+    OutputPort *output(const std::string &n) { return &outputs.at(n); }
+    OutputPort *output(const char *n) { return &outputs.at(std::string(n)); }
+
+    virtual BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &) { return BufferManager::Sptr(); }
+    virtual BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &) { return BufferManager::Sptr(); }
+
+    //recording state, read by the driver
+    std::map<std::string, InputPort> inputs;
+    std::map<std::string, OutputPort> outputs;
+    std::map<std::string, std::function<void(double)>> calls;
+    std::vector<std::string> signalNames;
+    std::vector<SignalRecord> signals;
+};
+
+//! registry fake: remembers factories of signature Block*(size_t) by path
+class BlockRegistry
+{
+public:
+    typedef Block *(*FactorySizeT)(const size_t);
+    static std::map<std::string, FactorySizeT> &table(void)
+    {
+        static std::map<std::string, FactorySizeT> t;
+        return t;
+    }
+    BlockRegistry(const std::string &path, FactorySizeT f) { table()[path] = f; }
+};
+
+} // namespace Pothos
+
+#define POTHOS_FCN_TUPLE(classPath, functionName) \
+    #functionName, &classPath::functionName
