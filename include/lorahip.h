@@ -1,0 +1,199 @@
+/* lorahip.h -- C ABI of the MI355X-native LoRa demodulation hot path.
+ *
+ * Drop-in boundary for the part of myriadrf/LoRa-SDR that BASELINE.json's north_star
+ * names: dechirp multiply -> 2^SF-point complex FFT -> |.|^2 arg-max / power / fractional
+ * bin. Everything here is plain pointers and sizes; no exceptions cross the boundary,
+ * every entry point returns LORAHIP_OK (0) or a negative LORAHIP_E_* code.
+ * File:line citations are relative to the LoRa-SDR tree.
+ *
+ * Three levels, from the inner seam outwards:
+ *
+ *   1. lorahip_detector_*   one window, host buffers: exactly the semantics of
+ *      `template<T> class LoRaDetector` (LoRaDetector.hpp:8-72) so LoRaDemod.cpp can
+ *      swap `LoRaDetector<float> _detector` for a thin wrapper.
+ *
+ *   2. lorahip_detect_batch   many independent symbol windows per call (the data-parallel
+ *      axis: channels x windows), device pointers, asynchronous on the context's stream.
+ *      Per window it performs LoRaDemod.cpp:157-166 (dechirp with the chirp table and the
+ *      fine-tune table, including the int<-float index recurrence) followed by
+ *      LoRaDetector::detect (LoRaDetector.hpp:29-64 on kissfft.hh:77-157).
+ *
+ *   3. lorahip_demod_*   B channels of the `LoRaDemod` block (LoRaDemod.cpp:68-143 setters,
+ *      :145-327 work()): same parameters (sf, sync, thresh, mtu), same 5-state frame
+ *      machine, same int16 symbol packets, driven in lock-step over all channels with one
+ *      batch launch per work() round.
+ *
+ * Results: symbol indices and FFT bins are bit-identical to the reference CPU path
+ * compiled without FMA contraction (the kernels evaluate kissfft's radix-4/2 DIT graph
+ * with kissfft's own float twiddles, op for op); power / powerAvg / fIndex agree to
+ * float rounding of log10/hypot (tolerances in tests/).
+ */
+#ifndef LORAHIP_H
+#define LORAHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LORAHIP_OK             0
+#define LORAHIP_E_INVALID     -1  /* bad argument (NULL, sf out of range, size mismatch)   */
+#define LORAHIP_E_NODEVICE    -2  /* no HIP device / device index out of range             */
+#define LORAHIP_E_HIP         -3  /* a HIP runtime call failed; see lorahip_last_error()    */
+#define LORAHIP_E_NOMEM       -4  /* host or device allocation failed                       */
+#define LORAHIP_E_ARCH        -5  /* device is not gfx950 (kernels are built for it only)   */
+
+#define LORAHIP_SF_MIN  6
+#define LORAHIP_SF_MAX 12
+#define LORAHIP_FINE_STEPS 128     /* LoRaDemod.cpp:69 _fineSteps */
+
+/* chirp selection per window */
+#define LORAHIP_CHIRP_UP    0      /* _upChirpTable  = conj(entry)  LoRaDemod.cpp:103 (FRAMESYNC, DATASYMBOLS) */
+#define LORAHIP_CHIRP_DOWN  1      /* _downChirpTable = entry       LoRaDemod.cpp:104 (DOWNCHIRP0/1)           */
+#define LORAHIP_CHIRP_NONE  2      /* input is already dechirped: the LoRaDetector::feed seam                 */
+
+const char *lorahip_strerror(int code);
+const char *lorahip_last_error(void);       /* thread-local text of the last LORAHIP_E_HIP */
+int lorahip_version(void);                  /* ABI version, currently 1 */
+int lorahip_device_count(void);             /* number of usable gfx950 devices, 0 if none */
+
+/* -------------------------------------------------------------------------------------
+ * Host-side tables, exactly the reference's expressions (no device needed):
+ *   up/down : N cf32       LoRaDemod.cpp:97-107
+ *   fine    : 128*N cf32   LoRaDemod.cpp:108-114
+ *   twiddle : N cf32       kissfft.hh:17-22
+ * Any pointer may be NULL. Buffers are interleaved (re,im) floats.
+ * ------------------------------------------------------------------------------------- */
+int lorahip_host_tables(int sf, float *up, float *down, float *fine, float *twiddle);
+
+/* -------------------------------------------------------------------------------------
+ * Level 2: batch context. One per (device, SF); not thread-safe (one host thread per
+ * context, like one Pothos actor per block). Replaces: LoRaDemod ctor tables
+ * (LoRaDemod.cpp:97-116) + LoRaDetector ctor (LoRaDetector.hpp:12-20) + kissfft ctor
+ * (kissfft.hh:71-75).
+ * ------------------------------------------------------------------------------------- */
+typedef struct lorahip_ctx lorahip_ctx;
+
+int lorahip_create(lorahip_ctx **ctx, int device, int sf);
+void lorahip_destroy(lorahip_ctx *ctx);
+int lorahip_sf(const lorahip_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) for all launches; NULL = the
+ * context's own stream. */
+int lorahip_set_stream(lorahip_ctx *ctx, void *hip_stream);
+int lorahip_synchronize(lorahip_ctx *ctx);
+
+/* Kernel variant: 0 = auto (fastest validated for this SF), 1 = generic LDS kernel.
+ * All variants produce identical symbol indices and FFT bins. */
+int lorahip_set_variant(lorahip_ctx *ctx, int variant);
+
+/* One batch of independent windows. All pointers are DEVICE pointers for
+ * lorahip_detect_batch and HOST pointers for lorahip_detect_batch_host.
+ *
+ * Window w reads N = 2^sf cf32 samples starting at sample index
+ *     offsets ? offsets[w] : w * window_stride
+ * of `iq` (window_stride 0 means N: back-to-back windows).
+ */
+typedef struct lorahip_batch {
+    size_t struct_size;          /* = sizeof(lorahip_batch), for ABI growth                      */
+    /* inputs */
+    const float *iq;             /* interleaved cf32 samples                                      */
+    size_t n_windows;
+    const int64_t *offsets;      /* optional per-window start sample                              */
+    size_t window_stride;        /* used when offsets == NULL                                     */
+    const int32_t *chirp_sel;    /* optional per-window LORAHIP_CHIRP_*; NULL -> chirp_sel_all    */
+    int32_t chirp_sel_all;
+    const int32_t *fine_idx0;    /* optional per-window _fineTuneIndex on entry (NULL -> 0)       */
+    const float *fine_err;       /* optional per-window _finefreqError (NULL -> 0)                */
+    /* outputs (sym/power/power_avg/f_index required, the rest optional) */
+    uint16_t *sym;               /* detect() return value                LoRaDetector.hpp:63      */
+    float *power;                /*                                      LoRaDetector.hpp:54      */
+    float *power_avg;            /*                                      LoRaDetector.hpp:53      */
+    float *f_index;              /*                                      LoRaDetector.hpp:56-61   */
+    int32_t *fine_idx_out;       /* _fineTuneIndex after the N steps     LoRaDemod.cpp:160-162    */
+    float *fft_out;              /* n_windows*N cf32, the "fft" port     LoRaDemod.cpp:154,172    */
+    float *dec_out;              /* n_windows*N cf32, the "dec" port     LoRaDemod.cpp:164        */
+} lorahip_batch;
+
+int lorahip_detect_batch(lorahip_ctx *ctx, const lorahip_batch *b);       /* async, device ptrs */
+int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b);  /* sync, host ptrs;
+                                   iq must hold max(offset)+N samples: pass iq_len via window_stride
+                                   semantics or offsets; see lorahip_api.cpp */
+
+/* Time the last `n` launches made through this context between two internal HIP events
+ * recorded on the launch stream (bench.py uses this for the roofline line). */
+int lorahip_timer_start(lorahip_ctx *ctx);
+int lorahip_timer_stop(lorahip_ctx *ctx, float *elapsed_ms);
+
+/* -------------------------------------------------------------------------------------
+ * Level 1: LoRaDetector<float> shim (LoRaDetector.hpp:8-72). N must be 2^sf with sf in
+ * [LORAHIP_SF_MIN, LORAHIP_SF_MAX].
+ * ------------------------------------------------------------------------------------- */
+typedef struct lorahip_detector lorahip_detector;
+
+int lorahip_detector_create(lorahip_detector **det, int device, size_t N);   /* LoRaDetector(N)  :12 */
+void lorahip_detector_destroy(lorahip_detector *det);
+int lorahip_detector_feed(lorahip_detector *det, size_t i, float re, float im); /* feed()       :23 */
+/* detect(): returns the arg-max bin through *index; fft_out may be NULL (:29-64) */
+int lorahip_detector_detect(lorahip_detector *det, size_t *index, float *power, float *power_avg,
+                            float *f_index, float *fft_out);
+
+/* -------------------------------------------------------------------------------------
+ * Level 3: B channels of the LoRaDemod block (declared here, see lorahip_demod.cpp).
+ * ------------------------------------------------------------------------------------- */
+typedef struct lorahip_demod lorahip_demod;
+
+int lorahip_demod_create(lorahip_demod **d, int device, int sf, size_t n_channels); /* make(sf) LoRaDemod.cpp:119 */
+void lorahip_demod_destroy(lorahip_demod *d);
+int lorahip_demod_set_sync(lorahip_demod *d, unsigned char sync);        /* setSync       :124 */
+int lorahip_demod_set_threshold(lorahip_demod *d, double thresh_dB);     /* setThreshold  :129 */
+int lorahip_demod_set_mtu(lorahip_demod *d, size_t mtu);                 /* setMTU        :134 */
+int lorahip_demod_activate(lorahip_demod *d);                            /* activate()    :139 */
+
+/* Per-channel outcome of one work() round (what the block would have done on its ports). */
+typedef struct lorahip_work_result {
+    int64_t consumed;       /* inPort->consume(total)                          :320 */
+    int32_t state_before;   /* 0 FRAMESYNC 1 DOWNCHIRP0 2 DOWNCHIRP1 3 QUARTERCHIRP 4 DATASYMBOLS */
+    int32_t value;          /* detect() of window 0                            :172 */
+    float power, power_avg, snr, f_index;
+    int32_t worked;         /* 0 if fewer than 2N samples were available       :148 */
+    int32_t packet_len;     /* >0: a packet of that many int16 symbols was posted this round :295-298 */
+    int32_t signals;        /* 1 at DOWNCHIRP1: error/power/snr emitted        :267-269 */
+    int32_t sig_error;
+    float sig_power, sig_snr;
+} lorahip_work_result;
+
+/* Feed every channel's whole stream (host memory, cf32, n_samples[c] samples each) and run
+ * work() rounds in lock-step until no channel has 2N samples left. Packets are appended to
+ * the demod's queue. Returns the number of rounds through *rounds (may be NULL). */
+int lorahip_demod_run(lorahip_demod *d, const float *const *streams, const size_t *n_samples,
+                      int64_t *rounds);
+/* Same, but `iq` is one DEVICE buffer holding n_channels streams of samples_per_channel each. */
+int lorahip_demod_run_device(lorahip_demod *d, const float *iq_dev, size_t samples_per_channel,
+                             int64_t *rounds);
+
+size_t lorahip_demod_num_packets(const lorahip_demod *d);
+/* packet i: channel, round index it was posted in, and length; symbols copied if out != NULL */
+int lorahip_demod_get_packet(const lorahip_demod *d, size_t i, int32_t *channel, int64_t *round,
+                             size_t *len, int16_t *out, size_t cap);
+void lorahip_demod_clear_packets(lorahip_demod *d);
+/* total work() calls made (sum over channels) since create/activate */
+int64_t lorahip_demod_work_calls(const lorahip_demod *d);
+/* optional trace of every work() call: enable before run, then read back */
+int lorahip_demod_set_trace(lorahip_demod *d, int enable);
+size_t lorahip_demod_trace_len(const lorahip_demod *d, size_t channel);
+int lorahip_demod_get_trace(const lorahip_demod *d, size_t channel, lorahip_work_result *out, size_t cap);
+
+/* -------------------------------------------------------------------------------------
+ * Synthetic IQ directly in HBM (bench / tests input; ChirpGenerator.hpp:22-47 semantics in
+ * closed form): window w of channel c = ampl * upchirp(sym[c*S+w]) (+ AWGN of per-component
+ * sigma `noise_sigma`, counter-based RNG keyed by seed). iq_dev: B*S*N cf32.
+ * ------------------------------------------------------------------------------------- */
+int lorahip_synth_symbols(lorahip_ctx *ctx, float *iq_dev, const uint16_t *sym_dev,
+                          size_t n_windows, float ampl, float noise_sigma, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LORAHIP_H */

@@ -1,0 +1,343 @@
+"""Host-side mirror of the reference's operator interface for the demod hot path, on top of
+the C ABI (include/lorahip.h). Names and argument meaning follow the reference:
+
+  LoRaDetector(N).feed(i, samp) / .detect()      LoRaDetector.hpp:8-72
+  LoRaDemod(sf).setSync/.setThreshold/.setMTU    LoRaDemod.cpp:119-137   (factory /lora/lora_demod)
+  LoRaDemod.activate() / .work(...)              LoRaDemod.cpp:139-327
+  Context(sf).detect_batch(...)                  the batched form of LoRaDemod.cpp:157-172
+
+torch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Batch, WorkResult, check, load, CHIRP_UP, CHIRP_DOWN, CHIRP_NONE  # noqa: F401
+
+
+def host_tables(sf, fine=True):
+    """(up, down, fine, twiddle) exactly as the reference builds them -- pure host code."""
+    lib = load()
+    N = 1 << sf
+    up = np.empty(N, np.complex64)
+    down = np.empty(N, np.complex64)
+    fi = np.empty(N * _lib.FINE_STEPS, np.complex64) if fine else None
+    tw = np.empty(N, np.complex64)
+    check(lib.lorahip_host_tables(sf, up.ctypes.data, down.ctypes.data, fi.ctypes.data if fine else None,
+                                  tw.ctypes.data), "lorahip_host_tables")
+    return up, down, fi, tw
+
+
+def device_count():
+    return load().lorahip_device_count()
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _dptr(t, dtype=None):
+    """device pointer of a torch tensor (must be contiguous, on a HIP device)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("expected a device tensor")
+    if not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError("expected dtype %s, got %s" % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+class Context:
+    """One (device, SF) batch context: chirp / fine-tune / twiddle tables resident in HBM."""
+
+    def __init__(self, sf, device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        check(self._lib.lorahip_create(C.byref(self._h), int(device), int(sf)), "lorahip_create")
+        self.sf = int(sf)
+        self.N = 1 << self.sf
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.lorahip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        """stream_handle: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None"""
+        check(self._lib.lorahip_set_stream(self._h, C.c_void_p(stream_handle) if stream_handle else None),
+              "lorahip_set_stream")
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_variant(self, v):
+        check(self._lib.lorahip_set_variant(self._h, int(v)), "lorahip_set_variant")
+
+    def synchronize(self):
+        check(self._lib.lorahip_synchronize(self._h), "lorahip_synchronize")
+
+    def timer_start(self):
+        check(self._lib.lorahip_timer_start(self._h), "lorahip_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self._lib.lorahip_timer_stop(self._h, C.byref(ms)), "lorahip_timer_stop")
+        return ms.value
+
+    # ------------------------------------------------------------------
+    def detect_batch_raw(self, batch):
+        """Launch with a prepared struct lorahip_batch of DEVICE pointers (asynchronous)."""
+        check(self._lib.lorahip_detect_batch(self._h, C.byref(batch)), "lorahip_detect_batch")
+
+    def make_batch(self, iq, n_windows, sym, power, power_avg, f_index, offsets=None, window_stride=0,
+                   chirp_sel=None, chirp_sel_all=CHIRP_UP, fine_idx0=None, fine_err=None, fine_idx_out=None,
+                   fft_out=None, dec_out=None):
+        """Build a struct lorahip_batch from torch device tensors (kept alive by the caller)."""
+        import torch
+        b = Batch()
+        b.struct_size = C.sizeof(Batch)
+        b.iq = _dptr(iq)
+        b.n_windows = int(n_windows)
+        b.offsets = _dptr(offsets, torch.int64)
+        b.window_stride = int(window_stride)
+        b.chirp_sel = _dptr(chirp_sel, torch.int32)
+        b.chirp_sel_all = int(chirp_sel_all)
+        b.fine_idx0 = _dptr(fine_idx0, torch.int32)
+        b.fine_err = _dptr(fine_err, torch.float32)
+        b.sym = _dptr(sym)
+        b.power = _dptr(power, torch.float32)
+        b.power_avg = _dptr(power_avg, torch.float32)
+        b.f_index = _dptr(f_index, torch.float32)
+        b.fine_idx_out = _dptr(fine_idx_out, torch.int32)
+        b.fft_out = _dptr(fft_out)
+        b.dec_out = _dptr(dec_out)
+        return b
+
+    def detect_batch(self, iq, n_windows=None, offsets=None, window_stride=0, chirp_sel=None,
+                     chirp_sel_all=CHIRP_UP, fine_idx0=None, fine_err=None, want_fft=False, want_dec=False,
+                     want_fine_idx=False):
+        """Demodulate a batch of independent windows.
+
+        iq: torch complex64 device tensor (flat stream) or numpy complex64 array (host; staged
+        through the context). Returns a dict of arrays of the same kind as the input:
+        sym (uint16 as int16-viewed tensor for torch), power, powerAvg, fIndex [, fineIdxOut, fft, dec].
+        """
+        if _is_torch(iq):
+            return self._detect_torch(iq, n_windows, offsets, window_stride, chirp_sel, chirp_sel_all,
+                                      fine_idx0, fine_err, want_fft, want_dec, want_fine_idx)
+        return self._detect_numpy(iq, n_windows, offsets, window_stride, chirp_sel, chirp_sel_all,
+                                  fine_idx0, fine_err, want_fft, want_dec, want_fine_idx)
+
+    def _count(self, n_samples, n_windows, offsets, window_stride):
+        if offsets is not None:
+            return int(offsets.shape[0])
+        if n_windows is not None:
+            return int(n_windows)
+        stride = window_stride or self.N
+        return 0 if n_samples < self.N else (n_samples - self.N) // stride + 1
+
+    def _detect_torch(self, iq, n_windows, offsets, window_stride, chirp_sel, chirp_sel_all, fine_idx0, fine_err,
+                      want_fft, want_dec, want_fine_idx):
+        import torch
+        iq = iq.reshape(-1)
+        dev = iq.device
+        W = self._count(iq.numel(), n_windows, offsets, window_stride)
+        out = dict(sym=torch.empty(W, dtype=torch.int16, device=dev),       # uint16 payload
+                   power=torch.empty(W, dtype=torch.float32, device=dev),
+                   powerAvg=torch.empty(W, dtype=torch.float32, device=dev),
+                   fIndex=torch.empty(W, dtype=torch.float32, device=dev))
+        if want_fine_idx:
+            out["fineIdxOut"] = torch.empty(W, dtype=torch.int32, device=dev)
+        if want_fft:
+            out["fft"] = torch.empty((W, self.N), dtype=torch.complex64, device=dev)
+        if want_dec:
+            out["dec"] = torch.empty((W, self.N), dtype=torch.complex64, device=dev)
+        b = self.make_batch(iq, W, out["sym"], out["power"], out["powerAvg"], out["fIndex"], offsets=offsets,
+                            window_stride=window_stride, chirp_sel=chirp_sel, chirp_sel_all=chirp_sel_all,
+                            fine_idx0=fine_idx0, fine_err=fine_err, fine_idx_out=out.get("fineIdxOut"),
+                            fft_out=out.get("fft"), dec_out=out.get("dec"))
+        self.use_torch_stream()
+        self.detect_batch_raw(b)
+        return out
+
+    def _detect_numpy(self, iq, n_windows, offsets, window_stride, chirp_sel, chirp_sel_all, fine_idx0, fine_err,
+                      want_fft, want_dec, want_fine_idx):
+        iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, np.int64)
+        W = self._count(iq.size, n_windows, offsets, window_stride)
+        cs = None if chirp_sel is None else np.ascontiguousarray(np.broadcast_to(chirp_sel, (W,)), np.int32)
+        i0 = None if fine_idx0 is None else np.ascontiguousarray(np.broadcast_to(fine_idx0, (W,)), np.int32)
+        fe = None if fine_err is None else np.ascontiguousarray(np.broadcast_to(fine_err, (W,)), np.float32)
+        out = dict(sym=np.empty(W, np.uint16), power=np.empty(W, np.float32), powerAvg=np.empty(W, np.float32),
+                   fIndex=np.empty(W, np.float32))
+        if want_fine_idx:
+            out["fineIdxOut"] = np.empty(W, np.int32)
+        if want_fft:
+            out["fft"] = np.empty((W, self.N), np.complex64)
+        if want_dec:
+            out["dec"] = np.empty((W, self.N), np.complex64)
+        need = (int(offsets.max()) + self.N) if (offsets is not None and W) else ((W - 1) * (window_stride or self.N) + self.N if W else 0)
+        if need > iq.size:
+            raise ValueError("iq holds %d samples, the batch reads up to %d" % (iq.size, need))
+
+        def p(a):
+            return None if a is None else a.ctypes.data
+        b = Batch()
+        b.struct_size = C.sizeof(Batch)
+        b.iq = p(iq)
+        b.n_windows = W
+        b.offsets = p(offsets)
+        b.window_stride = int(window_stride)
+        b.chirp_sel = p(cs)
+        b.chirp_sel_all = int(chirp_sel_all)
+        b.fine_idx0 = p(i0)
+        b.fine_err = p(fe)
+        b.sym = p(out["sym"]); b.power = p(out["power"]); b.power_avg = p(out["powerAvg"]); b.f_index = p(out["fIndex"])
+        b.fine_idx_out = p(out.get("fineIdxOut"))
+        b.fft_out = p(out.get("fft"))
+        b.dec_out = p(out.get("dec"))
+        check(self._lib.lorahip_detect_batch_host(self._h, C.byref(b)), "lorahip_detect_batch_host")
+        return out
+
+    def synth_symbols(self, sym, ampl=1.0, noise_sigma=0.0, seed=0):
+        """IQ of len(sym) back-to-back up-chirp symbols generated in HBM -> complex64 device tensor."""
+        import torch
+        sym = sym.reshape(-1)
+        if sym.dtype not in (torch.int16, torch.uint16):
+            raise ValueError("sym must be a 16-bit integer device tensor")
+        iq = torch.empty(sym.numel() * self.N, dtype=torch.complex64, device=sym.device)
+        self.use_torch_stream()
+        check(self._lib.lorahip_synth_symbols(self._h, _dptr(iq), _dptr(sym), sym.numel(), float(ampl),
+                                              float(noise_sigma), int(seed) & (2 ** 64 - 1)), "lorahip_synth_symbols")
+        return iq
+
+
+class LoRaDetector:
+    """`LoRaDetector<float>` (LoRaDetector.hpp:8-72): feed N samples, detect() -> arg-max bin."""
+
+    def __init__(self, N, device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        check(self._lib.lorahip_detector_create(C.byref(self._h), int(device), int(N)), "lorahip_detector_create")
+        self.N = int(N)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.lorahip_detector_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def feed(self, i, samp):
+        samp = complex(samp)
+        check(self._lib.lorahip_detector_feed(self._h, int(i), samp.real, samp.imag), "lorahip_detector_feed")
+
+    def detect(self, fft_output=None):
+        """returns (index, power, powerAvg, fIndex); fills fft_output (complex64[N]) if given"""
+        idx = C.c_size_t()
+        p, pa, fi = C.c_float(), C.c_float(), C.c_float()
+        out = None
+        if fft_output is not None:
+            if fft_output.dtype != np.complex64 or fft_output.size != self.N or not fft_output.flags.c_contiguous:
+                raise ValueError("fft_output must be a contiguous complex64[N] array")
+            out = fft_output.ctypes.data
+        check(self._lib.lorahip_detector_detect(self._h, C.byref(idx), C.byref(p), C.byref(pa), C.byref(fi), out),
+              "lorahip_detector_detect")
+        return idx.value, p.value, pa.value, fi.value
+
+
+class LoRaDemod:
+    """B channels of the `/lora/lora_demod` block (LoRaDemod.cpp), same parameters and defaults."""
+
+    STATES = ("FRAMESYNC", "DOWNCHIRP0", "DOWNCHIRP1", "QUARTERCHIRP", "DATASYMBOLS")
+
+    def __init__(self, sf=10, n_channels=1, device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        check(self._lib.lorahip_demod_create(C.byref(self._h), int(device), int(sf), int(n_channels)),
+              "lorahip_demod_create")
+        self.sf, self.N, self.n_channels = int(sf), 1 << int(sf), int(n_channels)
+
+    @staticmethod
+    def make(sf):
+        return LoRaDemod(sf)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.lorahip_demod_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def setSync(self, sync):
+        check(self._lib.lorahip_demod_set_sync(self._h, int(sync) & 0xff), "lorahip_demod_set_sync")
+
+    def setThreshold(self, thresh_dB):
+        check(self._lib.lorahip_demod_set_threshold(self._h, float(thresh_dB)), "lorahip_demod_set_threshold")
+
+    def setMTU(self, mtu):
+        check(self._lib.lorahip_demod_set_mtu(self._h, int(mtu)), "lorahip_demod_set_mtu")
+
+    def activate(self):
+        check(self._lib.lorahip_demod_activate(self._h), "lorahip_demod_activate")
+
+    def set_trace(self, on=True):
+        check(self._lib.lorahip_demod_set_trace(self._h, int(bool(on))), "lorahip_demod_set_trace")
+
+    def work(self, streams):
+        """Feed one complete input stream per channel and run work() until < 2N samples remain
+        everywhere. streams: list of complex64 numpy arrays, or ONE torch complex64 device tensor
+        of shape (n_channels, samples). Returns the number of lock-step rounds."""
+        rounds = C.c_int64()
+        if _is_torch(streams):
+            if streams.dim() != 2 or streams.shape[0] != self.n_channels:
+                raise ValueError("expected a (n_channels, samples) tensor")
+            check(self._lib.lorahip_demod_run_device(self._h, _dptr(streams), int(streams.shape[1]),
+                                                     C.byref(rounds)), "lorahip_demod_run_device")
+            return rounds.value
+        if len(streams) != self.n_channels:
+            raise ValueError("expected %d streams" % self.n_channels)
+        keep = [np.ascontiguousarray(s, np.complex64).reshape(-1) for s in streams]
+        ptrs = (C.c_void_p * self.n_channels)(*[k.ctypes.data for k in keep])
+        lens = (C.c_size_t * self.n_channels)(*[k.size for k in keep])
+        check(self._lib.lorahip_demod_run(self._h, ptrs, lens, C.byref(rounds)), "lorahip_demod_run")
+        return rounds.value
+
+    def packets(self, clear=True):
+        """[(channel, round, int16 symbols)] -- the Pothos::Packet payloads of output port 0"""
+        out = []
+        for i in range(self._lib.lorahip_demod_num_packets(self._h)):
+            ch, rd, ln = C.c_int32(), C.c_int64(), C.c_size_t()
+            check(self._lib.lorahip_demod_get_packet(self._h, i, C.byref(ch), C.byref(rd), C.byref(ln), None, 0),
+                  "lorahip_demod_get_packet")
+            syms = np.empty(ln.value, np.int16)
+            check(self._lib.lorahip_demod_get_packet(self._h, i, None, None, None, syms.ctypes.data, syms.size),
+                  "lorahip_demod_get_packet")
+            out.append((ch.value, rd.value, syms))
+        if clear:
+            self._lib.lorahip_demod_clear_packets(self._h)
+        return out
+
+    def work_calls(self):
+        return int(self._lib.lorahip_demod_work_calls(self._h))
+
+    def trace(self, channel):
+        n = self._lib.lorahip_demod_trace_len(self._h, int(channel))
+        arr = (WorkResult * n)()
+        if n:
+            check(self._lib.lorahip_demod_get_trace(self._h, int(channel), arr, n), "lorahip_demod_get_trace")
+        return [dict((f, getattr(r, f)) for f, _ in WorkResult._fields_) for r in arr]

@@ -1,0 +1,376 @@
+// C ABI of liblorahip.so: context management, the batch entry points and the
+// LoRaDetector shim (include/lorahip.h). Host-side only; kernels are in lorahip_kernels.hip.
+#include "lorahip_internal.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace lorahip {
+
+static thread_local std::string g_lastError;
+
+void setLastError(const std::string &s) { g_lastError = s; }
+
+int hipFail(const hipError_t e, const char *what)
+{
+    g_lastError = std::string(what) + ": " + hipGetErrorString(e);
+    if (e == hipErrorOutOfMemory) return LORAHIP_E_NOMEM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return LORAHIP_E_NODEVICE;
+    return LORAHIP_E_HIP;
+}
+
+static bool isGfx950(const int device)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+    return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+static int growStage(lorahip_ctx *ctx, const size_t bytes)
+{
+    if (bytes <= ctx->dStageBytes) return LORAHIP_OK;
+    if (ctx->dStage) { (void)hipFree(ctx->dStage); ctx->dStage = nullptr; ctx->dStageBytes = 0; }
+    if (ctx->hStage) { (void)hipHostFree(ctx->hStage); ctx->hStage = nullptr; ctx->hStageBytes = 0; }
+    const size_t cap = bytes + bytes / 4;
+    LORAHIP_TRY(hipMalloc(&ctx->dStage, cap));
+    ctx->dStageBytes = cap;
+    LORAHIP_TRY(hipHostMalloc(&ctx->hStage, cap, hipHostMallocDefault));
+    ctx->hStageBytes = cap;
+    return LORAHIP_OK;
+}
+
+} // namespace lorahip
+
+using namespace lorahip;
+
+extern "C" {
+
+const char *lorahip_strerror(const int code)
+{
+    switch (code)
+    {
+    case LORAHIP_OK: return "ok";
+    case LORAHIP_E_INVALID: return "invalid argument";
+    case LORAHIP_E_NODEVICE: return "no usable HIP device";
+    case LORAHIP_E_HIP: return "HIP runtime error";
+    case LORAHIP_E_NOMEM: return "out of memory";
+    case LORAHIP_E_ARCH: return "device is not gfx950";
+    default: return "unknown error";
+    }
+}
+
+const char *lorahip_last_error(void) { return g_lastError.c_str(); }
+
+int lorahip_version(void) { return 1; }
+
+int lorahip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int d = 0; d < n; d++) if (isGfx950(d)) ok++;
+    return ok;
+}
+
+int lorahip_create(lorahip_ctx **out, const int device, const int sf)
+{
+    if (out == nullptr) return LORAHIP_E_INVALID;
+    *out = nullptr;
+    if (sf < LORAHIP_SF_MIN || sf > LORAHIP_SF_MAX) return LORAHIP_E_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); setLastError("no HIP device"); return LORAHIP_E_NODEVICE; }
+    if (device < 0 || device >= n) return LORAHIP_E_NODEVICE;
+    if (!isGfx950(device)) return LORAHIP_E_ARCH;
+    LORAHIP_TRY(hipSetDevice(device));
+
+    lorahip_ctx *ctx = new (std::nothrow) lorahip_ctx();
+    if (ctx == nullptr) return LORAHIP_E_NOMEM;
+    std::memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device;
+    ctx->sf = sf;
+    ctx->N = size_t(1) << sf;
+    ctx->powerScale = float(20 * std::log10(double(ctx->N)));   // LoRaDetector.hpp:18
+
+    HostTables t;
+    buildHostTables(sf, t, true);
+    const size_t nb = ctx->N * sizeof(cf32);
+    int rc = LORAHIP_OK;
+    do
+    {
+#define LORAHIP_CK(expr) { hipError_t _e = (expr); if (_e != hipSuccess) { rc = hipFail(_e, #expr); break; } }
+        LORAHIP_CK(hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking));
+        ctx->stream = ctx->ownStream;
+        LORAHIP_CK(hipEventCreate(&ctx->ev0));
+        LORAHIP_CK(hipEventCreate(&ctx->ev1));
+        LORAHIP_CK(hipMalloc((void **)&ctx->dUp, nb));
+        LORAHIP_CK(hipMalloc((void **)&ctx->dDown, nb));
+        LORAHIP_CK(hipMalloc((void **)&ctx->dTw, nb));
+        LORAHIP_CK(hipMalloc((void **)&ctx->dFine, nb * LORAHIP_FINE_STEPS));
+        LORAHIP_CK(hipMemcpy(ctx->dUp, t.up.data(), nb, hipMemcpyHostToDevice));
+        LORAHIP_CK(hipMemcpy(ctx->dDown, t.down.data(), nb, hipMemcpyHostToDevice));
+        LORAHIP_CK(hipMemcpy(ctx->dTw, t.twiddle.data(), nb, hipMemcpyHostToDevice));
+        LORAHIP_CK(hipMemcpy(ctx->dFine, t.fine.data(), nb * LORAHIP_FINE_STEPS, hipMemcpyHostToDevice));
+#undef LORAHIP_CK
+    } while (false);
+    if (rc != LORAHIP_OK) { lorahip_destroy(ctx); return rc; }
+    *out = ctx;
+    return LORAHIP_OK;
+}
+
+void lorahip_destroy(lorahip_ctx *ctx)
+{
+    if (ctx == nullptr) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->ownStream) (void)hipStreamSynchronize(ctx->ownStream);
+    if (ctx->dUp) (void)hipFree(ctx->dUp);
+    if (ctx->dDown) (void)hipFree(ctx->dDown);
+    if (ctx->dTw) (void)hipFree(ctx->dTw);
+    if (ctx->dFine) (void)hipFree(ctx->dFine);
+    if (ctx->dStage) (void)hipFree(ctx->dStage);
+    if (ctx->hStage) (void)hipHostFree(ctx->hStage);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
+    delete ctx;
+}
+
+int lorahip_sf(const lorahip_ctx *ctx) { return ctx ? ctx->sf : LORAHIP_E_INVALID; }
+
+int lorahip_set_stream(lorahip_ctx *ctx, void *hip_stream)
+{
+    if (ctx == nullptr) return LORAHIP_E_INVALID;
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->ownStream;
+    return LORAHIP_OK;
+}
+
+int lorahip_synchronize(lorahip_ctx *ctx)
+{
+    if (ctx == nullptr) return LORAHIP_E_INVALID;
+    LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LORAHIP_OK;
+}
+
+int lorahip_set_variant(lorahip_ctx *ctx, const int variant)
+{
+    if (ctx == nullptr || variant < 0 || variant > 2) return LORAHIP_E_INVALID;
+    ctx->variant = variant;
+    return LORAHIP_OK;
+}
+
+static int checkBatch(const lorahip_ctx *ctx, const lorahip_batch *b)
+{
+    if (ctx == nullptr || b == nullptr) return LORAHIP_E_INVALID;
+    if (b->struct_size != sizeof(lorahip_batch)) return LORAHIP_E_INVALID;
+    if (b->n_windows > 0xffffffffu) return LORAHIP_E_INVALID;
+    if (b->n_windows == 0) return LORAHIP_OK;
+    if (!b->iq || !b->sym || !b->power || !b->power_avg || !b->f_index) return LORAHIP_E_INVALID;
+    if (!b->chirp_sel && (b->chirp_sel_all < 0 || b->chirp_sel_all > LORAHIP_CHIRP_NONE)) return LORAHIP_E_INVALID;
+    return LORAHIP_OK;
+}
+
+static void fillArgs(const lorahip_ctx *ctx, const lorahip_batch *b, DetectArgs &a)
+{
+    a.iq = reinterpret_cast<const float2 *>(b->iq);
+    a.offsets = reinterpret_cast<const long long *>(b->offsets);
+    a.stride = (long long)(b->window_stride ? b->window_stride : ctx->N);
+    a.chirpSel = b->chirp_sel;
+    a.chirpSelAll = b->chirp_sel_all;
+    a.fineIdx0 = b->fine_idx0;
+    a.fineErr = b->fine_err;
+    a.sym = b->sym;
+    a.power = b->power;
+    a.powerAvg = b->power_avg;
+    a.fIndex = b->f_index;
+    a.fineIdxOut = b->fine_idx_out;
+    a.fftOut = reinterpret_cast<float2 *>(b->fft_out);
+    a.decOut = reinterpret_cast<float2 *>(b->dec_out);
+    a.up = ctx->dUp;
+    a.down = ctx->dDown;
+    a.fine = ctx->dFine;
+    a.tw = ctx->dTw;
+    a.nWindows = unsigned(b->n_windows);
+    a.powerScale = ctx->powerScale;
+}
+
+int lorahip_detect_batch(lorahip_ctx *ctx, const lorahip_batch *b)
+{
+    const int rc = checkBatch(ctx, b);
+    if (rc != LORAHIP_OK || b->n_windows == 0) return rc;
+    DetectArgs a;
+    fillArgs(ctx, b, a);
+    LORAHIP_TRY(launchDetect(ctx->sf, ctx->variant, a, ctx->stream));
+    return LORAHIP_OK;
+}
+
+// Host-pointer convenience: stage through context-owned pinned + device buffers.
+int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b)
+{
+    int rc = checkBatch(ctx, b);
+    if (rc != LORAHIP_OK || b->n_windows == 0) return rc;
+    LORAHIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = ctx->N, W = b->n_windows;
+    const size_t stride = b->window_stride ? b->window_stride : N;
+    size_t iqLen = 0;
+    if (b->offsets)
+    {
+        for (size_t w = 0; w < W; w++)
+        {
+            if (b->offsets[w] < 0) return LORAHIP_E_INVALID;
+            if (size_t(b->offsets[w]) + N > iqLen) iqLen = size_t(b->offsets[w]) + N;
+        }
+    }
+    else iqLen = (W - 1) * stride + N;
+
+    // carve one staging block: inputs first, then outputs (256 B aligned pieces)
+    struct Piece { size_t off, bytes; };
+    size_t cur = 0;
+    auto carve = [&cur](const size_t bytes) { Piece p = { cur, bytes }; cur += (bytes + 255) & ~size_t(255); return p; };
+    const Piece pIq = carve(iqLen * sizeof(cf32));
+    const Piece pOff = carve(b->offsets ? W * sizeof(int64_t) : 0);
+    const Piece pSel = carve(b->chirp_sel ? W * sizeof(int32_t) : 0);
+    const Piece pIdx = carve(b->fine_idx0 ? W * sizeof(int32_t) : 0);
+    const Piece pErr = carve(b->fine_err ? W * sizeof(float) : 0);
+    const size_t inBytes = cur;
+    const Piece pSym = carve(W * sizeof(uint16_t));
+    const Piece pPow = carve(W * sizeof(float));
+    const Piece pAvg = carve(W * sizeof(float));
+    const Piece pFi = carve(W * sizeof(float));
+    const Piece pIdxOut = carve(b->fine_idx_out ? W * sizeof(int32_t) : 0);
+    const Piece pFft = carve(b->fft_out ? W * N * sizeof(cf32) : 0);
+    const Piece pDec = carve(b->dec_out ? W * N * sizeof(cf32) : 0);
+    rc = growStage(ctx, cur);
+    if (rc != LORAHIP_OK) return rc;
+
+    char *h = static_cast<char *>(ctx->hStage), *d = static_cast<char *>(ctx->dStage);
+    std::memcpy(h + pIq.off, b->iq, pIq.bytes);
+    if (b->offsets) std::memcpy(h + pOff.off, b->offsets, pOff.bytes);
+    if (b->chirp_sel) std::memcpy(h + pSel.off, b->chirp_sel, pSel.bytes);
+    if (b->fine_idx0) std::memcpy(h + pIdx.off, b->fine_idx0, pIdx.bytes);
+    if (b->fine_err) std::memcpy(h + pErr.off, b->fine_err, pErr.bytes);
+    LORAHIP_TRY(hipMemcpyAsync(d, h, inBytes, hipMemcpyHostToDevice, ctx->stream));
+
+    lorahip_batch db = *b;
+    db.iq = reinterpret_cast<const float *>(d + pIq.off);
+    db.offsets = b->offsets ? reinterpret_cast<const int64_t *>(d + pOff.off) : nullptr;
+    db.chirp_sel = b->chirp_sel ? reinterpret_cast<const int32_t *>(d + pSel.off) : nullptr;
+    db.fine_idx0 = b->fine_idx0 ? reinterpret_cast<const int32_t *>(d + pIdx.off) : nullptr;
+    db.fine_err = b->fine_err ? reinterpret_cast<const float *>(d + pErr.off) : nullptr;
+    db.sym = reinterpret_cast<uint16_t *>(d + pSym.off);
+    db.power = reinterpret_cast<float *>(d + pPow.off);
+    db.power_avg = reinterpret_cast<float *>(d + pAvg.off);
+    db.f_index = reinterpret_cast<float *>(d + pFi.off);
+    db.fine_idx_out = b->fine_idx_out ? reinterpret_cast<int32_t *>(d + pIdxOut.off) : nullptr;
+    db.fft_out = b->fft_out ? reinterpret_cast<float *>(d + pFft.off) : nullptr;
+    db.dec_out = b->dec_out ? reinterpret_cast<float *>(d + pDec.off) : nullptr;
+    rc = lorahip_detect_batch(ctx, &db);
+    if (rc != LORAHIP_OK) return rc;
+
+    LORAHIP_TRY(hipMemcpyAsync(h + inBytes, d + inBytes, cur - inBytes, hipMemcpyDeviceToHost, ctx->stream));
+    LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::memcpy(b->sym, h + pSym.off, pSym.bytes);
+    std::memcpy(b->power, h + pPow.off, pPow.bytes);
+    std::memcpy(b->power_avg, h + pAvg.off, pAvg.bytes);
+    std::memcpy(b->f_index, h + pFi.off, pFi.bytes);
+    if (b->fine_idx_out) std::memcpy(b->fine_idx_out, h + pIdxOut.off, pIdxOut.bytes);
+    if (b->fft_out) std::memcpy(b->fft_out, h + pFft.off, pFft.bytes);
+    if (b->dec_out) std::memcpy(b->dec_out, h + pDec.off, pDec.bytes);
+    return LORAHIP_OK;
+}
+
+int lorahip_timer_start(lorahip_ctx *ctx)
+{
+    if (ctx == nullptr) return LORAHIP_E_INVALID;
+    LORAHIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    return LORAHIP_OK;
+}
+
+int lorahip_timer_stop(lorahip_ctx *ctx, float *elapsed_ms)
+{
+    if (ctx == nullptr || elapsed_ms == nullptr) return LORAHIP_E_INVALID;
+    LORAHIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    LORAHIP_TRY(hipEventSynchronize(ctx->ev1));
+    LORAHIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return LORAHIP_OK;
+}
+
+int lorahip_synth_symbols(lorahip_ctx *ctx, float *iq_dev, const uint16_t *sym_dev, const size_t n_windows,
+                          const float ampl, const float noise_sigma, const uint64_t seed)
+{
+    if (ctx == nullptr || (n_windows && (!iq_dev || !sym_dev))) return LORAHIP_E_INVALID;
+    LORAHIP_TRY(launchSynth(ctx->sf, reinterpret_cast<float2 *>(iq_dev), sym_dev, n_windows, ampl, noise_sigma,
+                            (unsigned long long)seed, ctx->stream));
+    return LORAHIP_OK;
+}
+
+/***********************************************************************
+ * LoRaDetector<float> shim
+ **********************************************************************/
+} // extern "C"
+
+struct lorahip_detector
+{
+    lorahip_ctx *ctx;
+    size_t N;
+    std::vector<cf32> input;     // _fftInput  LoRaDetector.hpp:68
+    std::vector<cf32> output;    // _fftOutput LoRaDetector.hpp:69
+};
+
+extern "C" {
+
+int lorahip_detector_create(lorahip_detector **out, const int device, const size_t N)
+{
+    if (out == nullptr) return LORAHIP_E_INVALID;
+    *out = nullptr;
+    int sf = -1;
+    for (int s = LORAHIP_SF_MIN; s <= LORAHIP_SF_MAX; s++) if ((size_t(1) << s) == N) sf = s;
+    if (sf < 0) return LORAHIP_E_INVALID;
+    lorahip_detector *det = new (std::nothrow) lorahip_detector();
+    if (det == nullptr) return LORAHIP_E_NOMEM;
+    det->ctx = nullptr;
+    det->N = N;
+    const int rc = lorahip_create(&det->ctx, device, sf);
+    if (rc != LORAHIP_OK) { delete det; return rc; }
+    det->input.assign(N, cf32(0, 0));
+    det->output.assign(N, cf32(0, 0));
+    *out = det;
+    return LORAHIP_OK;
+}
+
+void lorahip_detector_destroy(lorahip_detector *det)
+{
+    if (det == nullptr) return;
+    lorahip_destroy(det->ctx);
+    delete det;
+}
+
+int lorahip_detector_feed(lorahip_detector *det, const size_t i, const float re, const float im)
+{
+    if (det == nullptr || i >= det->N) return LORAHIP_E_INVALID;
+    det->input[i] = cf32(re, im);
+    return LORAHIP_OK;
+}
+
+int lorahip_detector_detect(lorahip_detector *det, size_t *index, float *power, float *power_avg,
+                            float *f_index, float *fft_out)
+{
+    if (det == nullptr || !index || !power || !power_avg || !f_index) return LORAHIP_E_INVALID;
+    uint16_t sym = 0;
+    lorahip_batch b;
+    std::memset(&b, 0, sizeof(b));
+    b.struct_size = sizeof(b);
+    b.iq = reinterpret_cast<const float *>(det->input.data());
+    b.n_windows = 1;
+    b.chirp_sel_all = LORAHIP_CHIRP_NONE;
+    b.sym = &sym;
+    b.power = power;
+    b.power_avg = power_avg;
+    b.f_index = f_index;
+    b.fft_out = fft_out ? fft_out : reinterpret_cast<float *>(det->output.data());
+    const int rc = lorahip_detect_batch_host(det->ctx, &b);
+    if (rc != LORAHIP_OK) return rc;
+    *index = sym;
+    return LORAHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,439 @@
+// Level 3 of the C ABI: B channels of the LoRaDemod block driven in lock-step.
+//
+// Mirrors LoRaDemod.cpp: parameters and defaults (:68-74), setters (:124-137), activate()
+// (:139-143) and work() (:145-327). One work() "round" = every channel that has >= 2N
+// samples left performs one work() call. The dechirp+FFT+detect of all those calls is ONE
+// batch launch (lorahip_detect_batch); the frame state machine -- a handful of integer
+// operations per call whose only coupling is the per-channel window offset -- runs on the
+// host between launches. Channels that hit "syncd and match0" (:189) get their second
+// window in a second, compacted launch, exactly like the reference's nested loop (:189-206).
+//
+// The three members the reference leaves uninitialised (_finefreqError, _freqError,
+// _prevValue) start at zero here.
+#include "lorahip_internal.h"
+#include <cstring>
+#include <new>
+
+using namespace lorahip;
+
+namespace {
+
+enum State { ST_FRAMESYNC = 0, ST_DOWNCHIRP0, ST_DOWNCHIRP1, ST_QUARTERCHIRP, ST_DATASYMBOLS };
+
+struct Channel
+{
+    int state;
+    bool downTable;         // _chirpTable == _downChirpTable
+    short prevValue;
+    int freqError;
+    int fineTuneIndex;
+    float finefreqError;
+    size_t symCount;
+    std::vector<int16_t> outSymbols;
+    size_t base, len, pos;  // stream placement in the device buffer, read position
+    std::vector<lorahip_work_result> trace;
+};
+
+struct Packet
+{
+    int32_t channel;
+    int64_t round;
+    std::vector<int16_t> syms;
+};
+
+} // namespace
+
+struct lorahip_demod
+{
+    lorahip_ctx *ctx;
+    size_t N, B;
+    unsigned char sync;
+    float thresh;
+    size_t mtu;
+    bool tracing;
+    int64_t workCalls;
+    std::vector<Channel> ch;
+    std::vector<Packet> packets;
+    // per-round staging (host pinned + device), sized for B windows
+    char *h, *d;
+    size_t stageBytes;
+    float *dIq; size_t dIqSamples;   // owned upload buffer for lorahip_demod_run
+};
+
+namespace {
+
+struct Round
+{
+    int64_t *off; int32_t *sel; int32_t *idx0; float *err;                  // inputs
+    uint16_t *sym; float *power; float *pavg; float *fidx; int32_t *idxOut; // outputs
+    size_t inBytes, total;
+};
+
+static size_t align256(const size_t x) { return (x + 255) & ~size_t(255); }
+
+static Round carve(char *p, const size_t B)
+{
+    Round r;
+    size_t cur = 0;
+    r.off = reinterpret_cast<int64_t *>(p + cur); cur += align256(B * sizeof(int64_t));
+    r.sel = reinterpret_cast<int32_t *>(p + cur); cur += align256(B * sizeof(int32_t));
+    r.idx0 = reinterpret_cast<int32_t *>(p + cur); cur += align256(B * sizeof(int32_t));
+    r.err = reinterpret_cast<float *>(p + cur); cur += align256(B * sizeof(float));
+    r.inBytes = cur;
+    r.sym = reinterpret_cast<uint16_t *>(p + cur); cur += align256(B * sizeof(uint16_t));
+    r.power = reinterpret_cast<float *>(p + cur); cur += align256(B * sizeof(float));
+    r.pavg = reinterpret_cast<float *>(p + cur); cur += align256(B * sizeof(float));
+    r.fidx = reinterpret_cast<float *>(p + cur); cur += align256(B * sizeof(float));
+    r.idxOut = reinterpret_cast<int32_t *>(p + cur); cur += align256(B * sizeof(int32_t));
+    r.total = cur;
+    return r;
+}
+
+//! one compacted launch over `n` windows described in the host staging block
+static int launchRound(lorahip_demod *dm, const float *iqDev, const size_t n)
+{
+    lorahip_ctx *ctx = dm->ctx;
+    const Round hr = carve(dm->h, dm->B), dr = carve(dm->d, dm->B);
+    LORAHIP_TRY(hipMemcpyAsync(dm->d, dm->h, hr.inBytes, hipMemcpyHostToDevice, ctx->stream));
+    lorahip_batch b;
+    std::memset(&b, 0, sizeof(b));
+    b.struct_size = sizeof(b);
+    b.iq = iqDev;
+    b.n_windows = n;
+    b.offsets = dr.off;
+    b.chirp_sel = dr.sel;
+    b.fine_idx0 = dr.idx0;
+    b.fine_err = dr.err;
+    b.sym = dr.sym; b.power = dr.power; b.power_avg = dr.pavg; b.f_index = dr.fidx;
+    b.fine_idx_out = dr.idxOut;
+    const int rc = lorahip_detect_batch(ctx, &b);
+    if (rc != LORAHIP_OK) return rc;
+    LORAHIP_TRY(hipMemcpyAsync(dm->h + hr.inBytes, dm->d + hr.inBytes, hr.total - hr.inBytes,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LORAHIP_OK;
+}
+
+static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
+{
+    const size_t N = dm->N, B = dm->B;
+    LORAHIP_TRY(hipSetDevice(dm->ctx->device));
+    const Round hr = carve(dm->h, B);
+    std::vector<uint32_t> live, second;
+    std::vector<lorahip_work_result> res(B);
+    int64_t rounds = 0;
+    while (true)
+    {
+        // ---- who can work this round (LoRaDemod.cpp:148) ----
+        live.clear();
+        for (size_t c = 0; c < B; c++)
+        {
+            Channel &k = dm->ch[c];
+            if (k.len - k.pos < 2 * N) continue;
+            const size_t i = live.size();
+            live.push_back(uint32_t(c));
+            hr.off[i] = int64_t(k.base + k.pos);
+            hr.sel[i] = k.downTable ? LORAHIP_CHIRP_DOWN : LORAHIP_CHIRP_UP;
+            hr.idx0[i] = k.fineTuneIndex;
+            hr.err[i] = k.finefreqError;
+        }
+        if (live.empty()) break;
+        int rc = launchRound(dm, iqDev, live.size());       // loop A + detect (:157-172)
+        if (rc != LORAHIP_OK) return rc;
+
+        // ---- first pass: commit the index, find channels needing window 1 ----
+        second.clear();
+        for (size_t i = 0; i < live.size(); i++)
+        {
+            Channel &k = dm->ch[live[i]];
+            lorahip_work_result &r = res[live[i]];
+            std::memset(&r, 0, sizeof(r));
+            r.worked = 1;
+            r.state_before = k.state;
+            r.value = hr.sym[i];
+            r.power = hr.power[i]; r.power_avg = hr.pavg[i]; r.f_index = hr.fidx[i];
+            r.snr = r.power - r.power_avg;                                      // :173
+            k.fineTuneIndex = hr.idxOut[i];
+            if (k.state == ST_FRAMESYNC)
+            {
+                const bool squelched = r.snr < dm->thresh;                      // :174
+                const bool syncd = !squelched && (k.prevValue + 4) / 8 == 0;    // :183
+                const bool match0 = (size_t(r.value) + 4) / 8 == unsigned(dm->sync >> 4); // :184
+                if (syncd && match0) second.push_back(live[i]);
+            }
+        }
+        std::vector<uint16_t> value1(second.size());
+        if (!second.empty())
+        {
+            for (size_t i = 0; i < second.size(); i++)
+            {
+                Channel &k = dm->ch[second[i]];
+                hr.off[i] = int64_t(k.base + k.pos + N);                         // inBuff[i + N]  :194
+                hr.sel[i] = k.downTable ? LORAHIP_CHIRP_DOWN : LORAHIP_CHIRP_UP;
+                hr.idx0[i] = k.fineTuneIndex;                                    // int ft = _fineTuneIndex  :191
+                hr.err[i] = k.finefreqError;
+            }
+            rc = launchRound(dm, iqDev, second.size());
+            if (rc != LORAHIP_OK) return rc;
+            for (size_t i = 0; i < second.size(); i++)
+            {
+                lorahip_work_result &r = res[second[i]];
+                value1[i] = hr.sym[i];
+                // detect(power,powerAvg,fIndex) of window 1 overwrites the locals (:203); snr is not recomputed
+                r.power = hr.power[i]; r.power_avg = hr.pavg[i]; r.f_index = hr.fidx[i];
+            }
+        }
+
+        // ---- second pass: the state machine (:176-312) ----
+        size_t si = 0;
+        for (size_t i = 0; i < live.size(); i++)
+        {
+            const uint32_t c = live[i];
+            Channel &k = dm->ch[c];
+            lorahip_work_result &r = res[c];
+            const size_t value = size_t(r.value);
+            const bool squelched = r.snr < dm->thresh;
+            size_t total = 0;
+            switch (k.state)
+            {
+            case ST_FRAMESYNC:
+            {
+                const bool syncd = !squelched && (k.prevValue + 4) / 8 == 0;
+                const bool match0 = (value + 4) / 8 == unsigned(dm->sync >> 4);
+                bool match1 = false;
+                if (syncd && match0)
+                {
+                    match1 = (size_t(value1[si]) + 4) / 8 == unsigned(dm->sync & 0xf);   // :205
+                    si++;
+                }
+                if (syncd && match0 && match1)
+                {
+                    total = 2 * N;
+                    k.state = ST_DOWNCHIRP0;
+                    k.downTable = true;
+                }
+                else if (!squelched)
+                {
+                    total = N - value;
+                    k.finefreqError += r.f_index;
+                }
+                else
+                {
+                    total = N;
+                    k.finefreqError = 0;
+                    k.fineTuneIndex = 0;
+                }
+            } break;
+            case ST_DOWNCHIRP0:
+            {
+                k.state = ST_DOWNCHIRP1;
+                total = N;
+                int error = int(value);
+                if (value > N / 2) error -= int(N);
+                k.freqError = error;
+            } break;
+            case ST_DOWNCHIRP1:
+            {
+                k.state = ST_QUARTERCHIRP;
+                total = N;
+                k.downTable = false;
+                k.outSymbols.assign(dm->mtu ? dm->mtu : 1, 0);
+                int error = int(value);
+                if (value > N / 2) error -= int(N);
+                k.freqError = (k.freqError + error) / 2;
+                r.signals = 1;
+                r.sig_error = k.freqError; r.sig_power = r.power; r.sig_snr = r.snr;
+            } break;
+            case ST_QUARTERCHIRP:
+            {
+                k.state = ST_DATASYMBOLS;
+                total = N / 4 + size_t(k.freqError / 2);
+                k.finefreqError += float(k.freqError / 2);
+                k.symCount = 0;
+            } break;
+            case ST_DATASYMBOLS:
+            {
+                total = N;
+                k.outSymbols[k.symCount++] = int16_t(value);
+                if (k.symCount >= dm->mtu || squelched)
+                {
+                    Packet p;
+                    p.channel = int32_t(c);
+                    p.round = rounds;
+                    p.syms.assign(k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
+                    dm->packets.push_back(p);
+                    r.packet_len = int32_t(k.symCount);
+                    k.finefreqError = 0;
+                    k.state = ST_FRAMESYNC;
+                }
+            } break;
+            }
+            k.prevValue = short(value);                                          // :326
+            r.consumed = int64_t(total);
+            k.pos += total;                                                      // consume(total)  :320
+            dm->workCalls++;
+            if (dm->tracing) k.trace.push_back(r);
+        }
+        rounds++;
+    }
+    if (roundsOut) *roundsOut = rounds;
+    return LORAHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, const size_t n_channels)
+{
+    if (out == nullptr || n_channels == 0 || n_channels > 0x7fffffffu) return LORAHIP_E_INVALID;
+    *out = nullptr;
+    lorahip_demod *dm = new (std::nothrow) lorahip_demod();
+    if (dm == nullptr) return LORAHIP_E_NOMEM;
+    dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
+    int rc = lorahip_create(&dm->ctx, device, sf);
+    if (rc != LORAHIP_OK) { delete dm; return rc; }
+    dm->N = size_t(1) << sf;
+    dm->B = n_channels;
+    dm->sync = 0x12; dm->thresh = -30.0f; dm->mtu = 256;        // LoRaDemod.cpp:71-73
+    dm->tracing = false;
+    dm->workCalls = 0;
+    dm->ch.resize(n_channels);
+    dm->stageBytes = carve(nullptr, n_channels).total;
+    if (hipMalloc((void **)&dm->d, dm->stageBytes) != hipSuccess ||
+        hipHostMalloc((void **)&dm->h, dm->stageBytes, hipHostMallocDefault) != hipSuccess)
+    {
+        lorahip_demod_destroy(dm);
+        return LORAHIP_E_NOMEM;
+    }
+    lorahip_demod_activate(dm);
+    *out = dm;
+    return LORAHIP_OK;
+}
+
+void lorahip_demod_destroy(lorahip_demod *dm)
+{
+    if (dm == nullptr) return;
+    if (dm->ctx) (void)hipSetDevice(dm->ctx->device);
+    if (dm->d) (void)hipFree(dm->d);
+    if (dm->h) (void)hipHostFree(dm->h);
+    if (dm->dIq) (void)hipFree(dm->dIq);
+    lorahip_destroy(dm->ctx);
+    delete dm;
+}
+
+int lorahip_demod_set_sync(lorahip_demod *dm, const unsigned char sync)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    dm->sync = sync;
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_set_threshold(lorahip_demod *dm, const double thresh_dB)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    dm->thresh = float(thresh_dB);
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_set_mtu(lorahip_demod *dm, const size_t mtu)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    dm->mtu = mtu;
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_activate(lorahip_demod *dm)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    // activate() resets only _state and _chirpTable (:139-143); everything else keeps the
+    // constructor / zero state, or whatever the previous activation left
+    for (auto &k : dm->ch) { k.state = ST_FRAMESYNC; k.downTable = false; }
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_run_device(lorahip_demod *dm, const float *iq_dev, const size_t samples_per_channel, int64_t *rounds)
+{
+    if (dm == nullptr || iq_dev == nullptr) return LORAHIP_E_INVALID;
+    for (size_t c = 0; c < dm->B; c++)
+    {
+        dm->ch[c].base = c * samples_per_channel;
+        dm->ch[c].len = samples_per_channel;
+        dm->ch[c].pos = 0;
+    }
+    return runRounds(dm, iq_dev, rounds);
+}
+
+int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size_t *n_samples, int64_t *rounds)
+{
+    if (dm == nullptr || streams == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
+    LORAHIP_TRY(hipSetDevice(dm->ctx->device));
+    size_t total = 0;
+    for (size_t c = 0; c < dm->B; c++)
+    {
+        if (n_samples[c] && streams[c] == nullptr) return LORAHIP_E_INVALID;
+        dm->ch[c].base = total;
+        dm->ch[c].len = n_samples[c];
+        dm->ch[c].pos = 0;
+        total += n_samples[c];
+    }
+    if (total > dm->dIqSamples)
+    {
+        if (dm->dIq) { (void)hipFree(dm->dIq); dm->dIq = nullptr; dm->dIqSamples = 0; }
+        LORAHIP_TRY(hipMalloc((void **)&dm->dIq, (total ? total : 1) * sizeof(cf32)));
+        dm->dIqSamples = total;
+    }
+    for (size_t c = 0; c < dm->B; c++)
+        if (n_samples[c])
+            LORAHIP_TRY(hipMemcpyAsync(dm->dIq + 2 * dm->ch[c].base, streams[c], n_samples[c] * sizeof(cf32),
+                                       hipMemcpyHostToDevice, dm->ctx->stream));
+    LORAHIP_TRY(hipStreamSynchronize(dm->ctx->stream));
+    return runRounds(dm, dm->dIq, rounds);
+}
+
+size_t lorahip_demod_num_packets(const lorahip_demod *dm) { return dm ? dm->packets.size() : 0; }
+
+int lorahip_demod_get_packet(const lorahip_demod *dm, const size_t i, int32_t *channel, int64_t *round,
+                             size_t *len, int16_t *out, const size_t cap)
+{
+    if (dm == nullptr || i >= dm->packets.size()) return LORAHIP_E_INVALID;
+    const Packet &p = dm->packets[i];
+    if (channel) *channel = p.channel;
+    if (round) *round = p.round;
+    if (len) *len = p.syms.size();
+    if (out)
+    {
+        if (cap < p.syms.size()) return LORAHIP_E_INVALID;
+        std::memcpy(out, p.syms.data(), p.syms.size() * sizeof(int16_t));
+    }
+    return LORAHIP_OK;
+}
+
+void lorahip_demod_clear_packets(lorahip_demod *dm) { if (dm) dm->packets.clear(); }
+
+int64_t lorahip_demod_work_calls(const lorahip_demod *dm) { return dm ? dm->workCalls : 0; }
+
+int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    dm->tracing = enable != 0;
+    if (!dm->tracing) for (auto &k : dm->ch) k.trace.clear();
+    return LORAHIP_OK;
+}
+
+size_t lorahip_demod_trace_len(const lorahip_demod *dm, const size_t channel)
+{
+    if (dm == nullptr || channel >= dm->B) return 0;
+    return dm->ch[channel].trace.size();
+}
+
+int lorahip_demod_get_trace(const lorahip_demod *dm, const size_t channel, lorahip_work_result *out, const size_t cap)
+{
+    if (dm == nullptr || channel >= dm->B || out == nullptr) return LORAHIP_E_INVALID;
+    const auto &t = dm->ch[channel].trace;
+    if (cap < t.size()) return LORAHIP_E_INVALID;
+    if (!t.empty()) std::memcpy(out, t.data(), t.size() * sizeof(lorahip_work_result));
+    return LORAHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,73 @@
+// Internal declarations shared by the host-side translation units of liblorahip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <complex>
+#include <string>
+#include <vector>
+#include "../../include/lorahip.h"
+
+namespace lorahip {
+
+typedef std::complex<float> cf32;
+
+//! host tables, built with the reference's own expressions (lorahip_tables.cpp)
+struct HostTables
+{
+    std::vector<cf32> up, down, fine, twiddle;
+};
+void buildHostTables(int sf, HostTables &t, bool wantFine);
+
+//! kernel argument block (device pointers), one launch = nWindows independent windows
+struct DetectArgs
+{
+    const float2 *iq;
+    const long long *offsets;   // nullable
+    long long stride;           // samples between windows when offsets == nullptr
+    const int *chirpSel;        // nullable
+    int chirpSelAll;
+    const int *fineIdx0;        // nullable
+    const float *fineErr;       // nullable
+    unsigned short *sym;
+    float *power;
+    float *powerAvg;
+    float *fIndex;
+    int *fineIdxOut;            // nullable
+    float2 *fftOut;             // nullable
+    float2 *decOut;             // nullable
+    const float2 *up;
+    const float2 *down;
+    const float2 *fine;
+    const float2 *tw;
+    unsigned nWindows;
+    float powerScale;           // float(20*log10(double(N)))  LoRaDetector.hpp:18
+};
+
+//! launchers (lorahip_kernels.hip)
+hipError_t launchDetect(int sf, int variant, const DetectArgs &a, hipStream_t stream);
+hipError_t launchSynth(int sf, float2 *iq, const unsigned short *sym, size_t nWindows,
+                       float ampl, float sigma, unsigned long long seed, hipStream_t stream);
+
+void setLastError(const std::string &s);
+int hipFail(hipError_t e, const char *what);
+
+#define LORAHIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return ::lorahip::hipFail(_e, #expr); } while (0)
+
+} // namespace lorahip
+
+struct lorahip_ctx
+{
+    int device;
+    int sf;
+    size_t N;
+    int variant;
+    hipStream_t ownStream;
+    hipStream_t stream;
+    float2 *dUp, *dDown, *dFine, *dTw;
+    hipEvent_t ev0, ev1;
+    float powerScale;
+    // staging for the host-pointer entry point (grown on demand)
+    void *dStage; size_t dStageBytes;
+    void *hStage; size_t hStageBytes;
+};

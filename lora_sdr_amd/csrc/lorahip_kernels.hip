@@ -1,0 +1,378 @@
+// CDNA4 (gfx950) kernels of the LoRa demod hot path: dechirp -> 2^SF-point FFT -> detect.
+//
+// Numerics contract: the FFT evaluates the SAME dataflow graph as the
+// reference's kissfft for N = 2^SF -- decimation-in-time, radix-4 stages outermost and one
+// radix-2 stage innermost for odd SF (kissfft.hh:34-51 factorisation), every butterfly with
+// kissfft's operation order (kissfft.hh:128-157) and kissfft's own float twiddle table
+// (kissfft.hh:17-22, uploaded from the host) -- in strict IEEE fp32 with NO fused
+// multiply-add. This translation unit is therefore compiled with -ffp-contract=off and the
+// pragma below; the FFT bins and the arg-max index are bit-identical to the CPU reference
+// built without FMA. That is a property of the arithmetic graph, not of the schedule: which
+// lane holds which point, what goes through LDS or DPP, and the order butterflies of one
+// stage are issued in are free, and are chosen for the machine.
+#pragma clang fp contract(off)
+
+#include "lorahip_internal.h"
+
+namespace lorahip {
+
+/***********************************************************************
+ * complex helpers -- (ac - bd, ad + bc), products and sums rounded separately,
+ * which is what std::complex<float>::operator* evaluates for finite operands
+ **********************************************************************/
+__device__ __forceinline__ float2 cmul(const float2 a, const float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(const float2 a, const float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(const float2 a, const float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+//! kf_bfly4 body for one k (kissfft.hh:143-155), forward transform
+__device__ __forceinline__ void bfly4(float2 &f0, float2 &f1, float2 &f2, float2 &f3,
+                                      const float2 t1, const float2 t2, const float2 t3)
+{
+    const float2 s0 = cmul(f1, t1);
+    const float2 s1 = cmul(f2, t2);
+    const float2 s2 = cmul(f3, t3);
+    const float2 s5 = csub(f0, s1);
+    f0 = cadd(f0, s1);
+    const float2 s3 = cadd(s0, s2);
+    float2 s4 = csub(s0, s2);
+    s4 = make_float2(s4.y, -s4.x);
+    f2 = csub(f0, s3);
+    f0 = cadd(f0, s3);
+    f1 = cadd(s5, s4);
+    f3 = csub(s5, s4);
+}
+
+//! kf_bfly2 body for one k (kissfft.hh:131-133)
+__device__ __forceinline__ void bfly2(float2 &f0, float2 &f1, const float2 t)
+{
+    const float2 v = cmul(f1, t);
+    f1 = csub(f0, v);
+    f0 = cadd(f0, v);
+}
+
+/***********************************************************************
+ * kissfft's plan for N = 2^LOG2N as compile-time constants.
+ * Stage s (0 = outermost) has radix p_s and remainder m_s; input digit q_s has weight
+ * fstride_s = p_0..p_{s-1} in the sample index n and weight m_s in the work-array
+ * position (kf_work recursion, kissfft.hh:83-104).
+ **********************************************************************/
+template <int LOG2N> struct Plan
+{
+    static constexpr int N = 1 << LOG2N;
+    static constexpr int R4 = LOG2N / 2;          // number of radix-4 stages
+    static constexpr bool HAS_R2 = (LOG2N & 1);   // innermost radix-2 stage (m = 1)
+    //! work-array position of input sample n (digit reversal of the mixed-radix index)
+    __host__ __device__ static constexpr int pos(int n)
+    {
+        int p = 0, m = N;
+        for (int s = 0; s < R4; s++) { m >>= 2; p += (n & 3) * m; n >>= 2; }
+        if (HAS_R2) p += (n & 1);
+        return p;
+    }
+};
+
+/***********************************************************************
+ * fine-tune index recurrence, one step (LoRaDemod.cpp:160-162)
+ *   _fineTuneIndex -= _finefreqError * _fineSteps   (int -= float: float subtract, truncate)
+ **********************************************************************/
+__device__ __forceinline__ int fineStep(const int idx, const float d /* = err*128 */, const int M)
+{
+    int n = (int)((float)idx - d);
+    if (n < 0) n += M;
+    else if (n >= M) n -= M;
+    return n;
+}
+
+/***********************************************************************
+ * detect() tail for one window, executed by one lane (LoRaDetector.hpp:50-61)
+ **********************************************************************/
+__device__ __forceinline__ void detectTail(const DetectArgs &a, const unsigned w, const int maxIndex,
+                                           const float maxValue, const double total,
+                                           const float2 leftBin, const float2 rightBin)
+{
+    const float noise = sqrtf((float)(total - (double)maxValue));
+    const float fundamental = sqrtf(maxValue);
+    // log10 evaluated in double and rounded once: within an ulp of a correctly rounded log10f
+    const float powerAvg = 20 * (float)log10((double)noise) - a.powerScale;
+    const float power = 20 * (float)log10((double)fundamental) - a.powerScale;
+    // std::abs(complex<float>) = hypotf; the double form is its correctly rounded value
+    const float left = (float)sqrt((double)leftBin.x * (double)leftBin.x + (double)leftBin.y * (double)leftBin.y);
+    const float right = (float)sqrt((double)rightBin.x * (double)rightBin.x + (double)rightBin.y * (double)rightBin.y);
+    const double demon = (2.0 * (double)fundamental) - (double)right - (double)left;
+    float fIndex = 0.0f;
+    if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
+    a.sym[w] = (unsigned short)maxIndex;
+    a.power[w] = power;
+    a.powerAvg[w] = powerAvg;
+    a.fIndex[w] = fIndex;
+}
+
+//! arg-max combine with the reference's tie-break: strict '>' scanning upwards keeps the
+//! LOWEST index among equal maxima (LoRaDetector.hpp:43)
+__device__ __forceinline__ void argmaxCombine(float &v, int &i, const float ov, const int oi)
+{
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+/***********************************************************************
+ * Variant 1: generic LDS kernel. N/4 threads per window, every stage through LDS.
+ * Correct for every SF; the tuned per-SF kernels below are validated against it.
+ **********************************************************************/
+template <int LOG2N>
+__global__ void __launch_bounds__((1 << LOG2N) / 4 < 256 ? 256 : (1 << LOG2N) / 4)
+detectGeneric(const DetectArgs a)
+{
+    typedef Plan<LOG2N> P;
+    constexpr int N = P::N;
+    constexpr int TW = N / 4;                        // threads per window
+    constexpr int BLOCK = TW < 256 ? 256 : TW;
+    constexpr int WPB = BLOCK / TW;                  // windows per block
+    constexpr int WAVES_PER_WIN = TW >= 64 ? TW / 64 : 1;
+    constexpr int M = N * LORAHIP_FINE_STEPS;
+
+    __shared__ float2 sA[WPB][N];
+    __shared__ int sIdx[WPB][N];
+    __shared__ float sRedV[WPB][WAVES_PER_WIN];
+    __shared__ int sRedI[WPB][WAVES_PER_WIN];
+    __shared__ double sRedT[WPB][WAVES_PER_WIN];
+
+    const int lw = threadIdx.x / TW;                 // local window
+    const int t = threadIdx.x % TW;
+    const unsigned w = blockIdx.x * WPB + lw;
+    const bool active = w < a.nWindows;
+    float2 *A = sA[lw];
+
+    int sel = LORAHIP_CHIRP_NONE;
+    int idx0 = 0;
+    float err = 0.0f;
+    const float2 *in = nullptr;
+    if (active)
+    {
+        sel = a.chirpSel ? a.chirpSel[w] : a.chirpSelAll;
+        idx0 = a.fineIdx0 ? a.fineIdx0[w] : 0;
+        err = a.fineErr ? a.fineErr[w] : 0.0f;
+        in = a.iq + (a.offsets ? a.offsets[w] : (long long)w * a.stride);
+    }
+    const bool dechirp = sel != LORAHIP_CHIRP_NONE;
+    const float d = err * (float)LORAHIP_FINE_STEPS;
+    const bool moving = dechirp && d != 0.0f;        // index changes from sample to sample
+
+    // fine-tune index chain (sequential by definition; one lane walks it)
+    if (moving && t == 0)
+    {
+        int idx = idx0;
+        for (int i = 0; i < N; i++) { sIdx[lw][i] = idx; idx = fineStep(idx, d, M); }
+        if (a.fineIdxOut) a.fineIdxOut[w] = idx;
+    }
+    if (active && !moving && t == 0 && a.fineIdxOut) a.fineIdxOut[w] = idx0;
+    __syncthreads();
+
+    // load + dechirp (LoRaDemod.cpp:158-159), scatter to the DIT work-array order
+    if (active)
+    {
+        const float2 *chirp = sel == LORAHIP_CHIRP_DOWN ? a.down : a.up;
+        const float2 fconst = a.fine[idx0];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const int n = t + j * TW;
+            float2 x = in[n];
+            if (dechirp)
+            {
+                x = cmul(x, chirp[n]);
+                x = cmul(x, moving ? a.fine[sIdx[lw][n]] : fconst);
+            }
+            if (a.decOut) a.decOut[(size_t)w * N + n] = x;
+            A[P::pos(n)] = x;
+        }
+    }
+    __syncthreads();
+
+    // innermost radix-2 stage: m = 1, fstride = N/2, twiddle(0)
+    if (P::HAS_R2)
+    {
+        if (active)
+        {
+            const float2 t0 = a.tw[0];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+            {
+                const int b = t + j * TW;
+                float2 f0 = A[2 * b], f1 = A[2 * b + 1];
+                bfly2(f0, f1, t0);
+                A[2 * b] = f0; A[2 * b + 1] = f1;
+            }
+        }
+        __syncthreads();
+    }
+
+    // radix-4 stages, innermost (smallest m) first
+#pragma unroll
+    for (int s = P::R4 - 1; s >= 0; s--)
+    {
+        const int m = N >> (2 * (s + 1));            // remainder of stage s
+        const int fstride = 1 << (2 * s);            // 4^s
+        if (active)
+        {
+            const int k = t & (m - 1);
+            const int base = ((t / m) * 4 * m) + k;
+            float2 f0 = A[base], f1 = A[base + m], f2 = A[base + 2 * m], f3 = A[base + 3 * m];
+            bfly4(f0, f1, f2, f3, a.tw[k * fstride], a.tw[k * fstride * 2], a.tw[k * fstride * 3]);
+            A[base] = f0; A[base + m] = f1; A[base + 2 * m] = f2; A[base + 3 * m] = f3;
+        }
+        __syncthreads();
+    }
+
+    // scan (LoRaDetector.hpp:36-48): per-lane partials over 4 bins, then tree
+    float bestV = 0.0f;
+    int bestI = 0;
+    double tot = 0.0;
+    if (active)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const int i = t + j * TW;
+            const float2 b = A[i];
+            if (a.fftOut) a.fftOut[(size_t)w * N + i] = b;
+            const float mag2 = b.x * b.x + b.y * b.y;
+            tot += (double)mag2;
+            if (mag2 > bestV) { bestV = mag2; bestI = i; }
+        }
+        if (!(bestV > 0.0f)) bestI = 0;
+    }
+    constexpr int SEG = TW < 64 ? TW : 64;
+#pragma unroll
+    for (int off = SEG / 2; off > 0; off >>= 1)
+    {
+        const float ov = __shfl_xor(bestV, off, 64);
+        const int oi = __shfl_xor(bestI, off, 64);
+        const double ot = __shfl_xor(tot, off, 64);
+        argmaxCombine(bestV, bestI, ov, oi);
+        tot += ot;
+    }
+    if (WAVES_PER_WIN > 1)
+    {
+        const int wv = t / 64;
+        if ((t & 63) == 0) { sRedV[lw][wv] = bestV; sRedI[lw][wv] = bestI; sRedT[lw][wv] = tot; }
+        __syncthreads();
+        if (t == 0)
+        {
+            bestV = sRedV[lw][0]; bestI = sRedI[lw][0]; tot = sRedT[lw][0];
+            for (int k = 1; k < WAVES_PER_WIN; k++)
+            {
+                argmaxCombine(bestV, bestI, sRedV[lw][k], sRedI[lw][k]);
+                tot += sRedT[lw][k];
+            }
+        }
+    }
+    if (active && t == 0)
+    {
+        const float2 l = A[bestI > 0 ? bestI - 1 : N - 1];
+        const float2 r = A[bestI < N - 1 ? bestI + 1 : 0];
+        detectTail(a, w, bestI, bestV, tot, l, r);
+    }
+}
+
+template <int LOG2N>
+static hipError_t launchGeneric(const DetectArgs &a, hipStream_t stream)
+{
+    constexpr int N = 1 << LOG2N;
+    constexpr int TW = N / 4;
+    constexpr int BLOCK = TW < 256 ? 256 : TW;
+    constexpr int WPB = BLOCK / TW;
+    const unsigned grid = (a.nWindows + WPB - 1) / WPB;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(detectGeneric<LOG2N>, dim3(grid), dim3(BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launchDetect(const int sf, const int variant, const DetectArgs &a, hipStream_t stream)
+{
+    (void)variant;
+    switch (sf)
+    {
+    case 6: return launchGeneric<6>(a, stream);
+    case 7: return launchGeneric<7>(a, stream);
+    case 8: return launchGeneric<8>(a, stream);
+    case 9: return launchGeneric<9>(a, stream);
+    case 10: return launchGeneric<10>(a, stream);
+    case 11: return launchGeneric<11>(a, stream);
+    case 12: return launchGeneric<12>(a, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+/***********************************************************************
+ * Synthetic up-chirp symbols + AWGN, generated in HBM (bench / test input).
+ * Window w = ampl * exp(j*phi_i), phi following ChirpGenerator.hpp:22-47 for an up-chirp
+ * with f0 = 2*pi*sym/N and ovs = 1 in closed form (per-window phase origin 0):
+ *   f_i = -pi + f0 + (i+1)*2pi/N, wrapped by -2pi once it exceeds +pi
+ *   phi_i = sum_{j<=i} f_j
+ * evaluated in fp64 then rounded; noise: counter-based splitmix64 -> Box-Muller.
+ **********************************************************************/
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <int LOG2N>
+__global__ void synthSymbols(float2 *iq, const unsigned short *sym, const size_t nWindows,
+                             const float ampl, const float sigma, const unsigned long long seed)
+{
+    constexpr int N = 1 << LOG2N;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = nWindows * (size_t)N;
+    for (size_t e = gid; e < total; e += (size_t)gridDim.x * blockDim.x)
+    {
+        const size_t w = e >> LOG2N;
+        const int i = (int)(e & (N - 1));
+        const int s = sym[w] & (N - 1);
+        // number of samples j<=i whose instantaneous frequency has already wrapped: j+1+s > N  <=>  j >= N-s
+        const double twoPiN = 6.283185307179586476925 / N;
+        const double n1 = (double)(i + 1);
+        double phi = n1 * (-3.14159265358979323846 + twoPiN * s) + twoPiN * 0.5 * n1 * (n1 + 1.0);
+        const int wrapped = i - (N - s) + 1;     // count of wrapped samples among 0..i
+        if (wrapped > 0) phi -= 6.283185307179586476925 * (double)wrapped;
+        phi -= 6.283185307179586476925 * floor(phi / 6.283185307179586476925);
+        double sn, cs;
+        sincos(phi, &sn, &cs);
+        float re = ampl * (float)cs, im = ampl * (float)sn;
+        if (sigma > 0.0f)
+        {
+            const unsigned long long r = splitmix64(seed ^ (e * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull));
+            const double u1 = ((double)(r >> 32) + 1.0) * (1.0 / 4294967296.0);
+            const double u2 = (double)(r & 0xffffffffu) * (1.0 / 4294967296.0);
+            const double rad = sqrt(-2.0 * log(u1));
+            double s2, c2;
+            sincos(6.283185307179586476925 * u2, &s2, &c2);
+            re += sigma * (float)(rad * c2);
+            im += sigma * (float)(rad * s2);
+        }
+        iq[e] = make_float2(re, im);
+    }
+}
+
+hipError_t launchSynth(const int sf, float2 *iq, const unsigned short *sym, const size_t nWindows,
+                       const float ampl, const float sigma, const unsigned long long seed, hipStream_t stream)
+{
+    if (nWindows == 0) return hipSuccess;
+    const dim3 block(256), grid(2048);
+    switch (sf)
+    {
+#define LORAHIP_SYNTH_CASE(SF) case SF: hipLaunchKernelGGL(synthSymbols<SF>, grid, block, 0, stream, iq, sym, nWindows, ampl, sigma, seed); break;
+    LORAHIP_SYNTH_CASE(6) LORAHIP_SYNTH_CASE(7) LORAHIP_SYNTH_CASE(8) LORAHIP_SYNTH_CASE(9)
+    LORAHIP_SYNTH_CASE(10) LORAHIP_SYNTH_CASE(11) LORAHIP_SYNTH_CASE(12)
+#undef LORAHIP_SYNTH_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace lorahip

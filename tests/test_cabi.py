@@ -1,0 +1,82 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/lorahip.h declares, its
+host-side tables are bit-identical to the oracle's, and it fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits
+
+import lora_sdr_amd as L
+from lora_sdr_amd import _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lorahip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lorahip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "liblorahip.so does not export %s" % n
+    # and the Python binding knows all of them
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_struct_layout_matches_header():
+    # struct lorahip_batch: 16 pointer-sized fields incl. one int32 padded to 8
+    assert C.sizeof(_lib.Batch) == 16 * 8
+    assert C.sizeof(_lib.WorkResult) == 56
+
+
+def test_version_and_errors():
+    lib = L.load()
+    assert lib.lorahip_version() == 1
+    assert lib.lorahip_strerror(0) == b"ok"
+    assert lib.lorahip_strerror(-5) == b"device is not gfx950"
+    assert lib.lorahip_host_tables(0, None, None, None, None) == -1
+    assert lib.lorahip_host_tables(13, None, None, None, None) == -1
+    assert lib.lorahip_create(None, 0, 7) == -1
+    assert lib.lorahip_detect_batch(None, None) == -1
+
+
+@pytest.mark.parametrize("sf", range(6, 13))
+def test_host_tables_match_oracle(oracle, sf):
+    up, down, fine, tw = L.host_tables(sf)
+    ou, od, of = oracle.tables(sf)
+    ot = oracle.twiddles(1 << sf)
+    assert np.array_equal(bits(up), bits(ou))
+    assert np.array_equal(bits(down), bits(od))
+    assert np.array_equal(bits(fine), bits(of))
+    assert np.array_equal(bits(tw), bits(ot))
+    assert fine[0] != 1.0          # accumulator is pre-incremented (LoRaDemod.cpp:111): fine[0] != 1
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert L.device_count() == 0
+    with pytest.raises(L.LoraHipError):
+        L.Context(7)
+    with pytest.raises(L.LoraHipError):
+        L.LoRaDetector(1024)
+    with pytest.raises(L.LoraHipError):
+        L.LoRaDemod(10)
+
+
+def test_product_never_touches_oracle():
+    """the product package must not import / link / call anything under oracle/"""
+    pkg = os.path.join(ROOT, "lora_sdr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU", ""), "%s mentions oracle" % f
+                assert "/root/reference" not in src

@@ -1,0 +1,253 @@
+"""GPU: the HIP path (through the C ABI) against the CPU oracle on identical IQ.
+
+Bar (BASELINE.json north_star): symbol indices bit-exact; FFT bins within 1e-4 relative --
+the kernels do better: bins are compared for exact equality (same fp32 operation graph as
+kissfft, no FMA). power / powerAvg / fIndex go through log10 / hypot whose device and glibc
+implementations may differ in the last float ulp, and powerAvg through an fp64 sum taken in
+tree order instead of sequentially: tolerances below are absolute, in dB / bins.
+"""
+import numpy as np
+import pytest
+
+from conftest import same_values
+
+pytestmark = pytest.mark.gpu
+
+TOL_DB = 2e-5       # power, powerAvg [dB]: <= ~3 float ulp at 60 dB
+TOL_FIDX = 2e-6     # fIndex [bins]
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def sym_np(t):
+    return to_np(t).view(np.uint16)
+
+
+def check(o, g, fft=True, dec=False, where=""):
+    assert np.array_equal(sym_np(g["sym"]), o["sym"]), "symbol index mismatch " + where
+    if fft:
+        assert same_values(to_np(g["fft"]), o["fft"]), "FFT bins differ " + where
+    if dec:
+        assert same_values(to_np(g["dec"]), o["dec"]), "dechirped samples differ " + where
+    with np.errstate(invalid="ignore"):
+        for k, tol in (("power", TOL_DB), ("powerAvg", TOL_DB), ("fIndex", TOL_FIDX)):
+            a, b = to_np(g[k]).astype(np.float64), o[k].astype(np.float64)
+            fin = np.isfinite(b)
+            assert np.array_equal(np.isfinite(a), fin), k + " finiteness " + where
+            assert np.array_equal(a[~fin], b[~fin]) or np.all(np.isnan(a[~fin]) == np.isnan(b[~fin])), k
+            err = np.abs(a[fin] - b[fin]).max() if fin.any() else 0.0
+            assert err <= tol, "%s differs by %g %s" % (k, err, where)
+
+
+def make_iq(rng, sf, W, snr_db=None, kind="chirp"):
+    """W windows of random symbols plus AWGN.
+    chirp:   down-chirp table x tone -> dechirps to exactly bin sym
+    halfbin: analytic up-chirp whose dechirped tone sits at sym - 0.5: two near-equal bins
+    noise:   no signal at all"""
+    import lora_sdr_amd as L
+    N = 1 << sf
+    t = np.arange(N)
+    sym = rng.integers(0, N, W)
+    if kind == "chirp":
+        down = L.host_tables(sf, fine=False)[1].astype(np.complex128)
+        x = down[None, :] * np.exp(2j * np.pi * sym[:, None] * t[None, :] / N)
+    elif kind == "halfbin":
+        ph = np.pi * t * t / N - np.pi * t
+        x = np.exp(1j * (ph[None, :] + 2 * np.pi * sym[:, None] * t[None, :] / N))
+    else:
+        x = np.zeros((W, N), np.complex128)
+        snr_db = 0.0
+    if snr_db is not None:
+        sigma = np.sqrt(10 ** (-snr_db / 10) / 2)
+        x = x + sigma * (rng.standard_normal((W, N)) + 1j * rng.standard_normal((W, N)))
+    return x.astype(np.complex64), sym
+
+
+@pytest.mark.parametrize("sf", range(6, 13))
+def test_random_symbols_awgn(gpu, oracle, sf):
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(sf)
+    W = {6: 700, 7: 515, 8: 300, 9: 130, 10: 70, 11: 33, 12: 19}[sf]   # ragged: not a multiple of windows/block
+    iq, _ = make_iq(rng, sf, W, snr_db=-5.0)
+    _ = _.astype(np.uint16)
+    ctx = L.Context(sf)
+    g = ctx.detect_batch(gpu.from_numpy(iq).cuda(), want_fft=True, want_dec=True, want_fine_idx=True)
+    gpu.cuda.synchronize()
+    o = oracle.detect_batch(sf, iq, want_fft=True, want_dec=True)
+    check(o, g, dec=True, where="sf%d" % sf)
+    assert np.array_equal(to_np(g["fineIdxOut"]), o["fineIdxOut"])
+    # and the sanity of the test itself: at -5 dB per sample every symbol is recovered
+    assert np.array_equal(o["sym"], _)
+
+
+@pytest.mark.parametrize("sf", [7, 9, 11])
+def test_half_bin_offset_near_ties(gpu, oracle, sf):
+    """tone exactly between two bins: the two candidates differ by rounding only"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(30 + sf)
+    W = 257
+    iq, _ = make_iq(rng, sf, W, snr_db=None, kind="halfbin")
+    ctx = L.Context(sf)
+    g = ctx.detect_batch(gpu.from_numpy(iq).cuda(), want_fft=True)
+    o = oracle.detect_batch(sf, iq, want_fft=True)
+    check(o, g, where="halfbin sf%d" % sf)
+
+
+@pytest.mark.parametrize("sf", [7, 10, 12])
+def test_noise_only_windows_bit_exact_argmax(gpu, oracle, sf):
+    """no peak at all: near-equal maxima everywhere; only an identical FFT gives identical indices"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(50 + sf)
+    W = {7: 4096, 10: 512, 12: 128}[sf]
+    iq, _ = make_iq(rng, sf, W, kind="noise")
+    ctx = L.Context(sf)
+    g = ctx.detect_batch(gpu.from_numpy(iq).cuda(), want_fft=True)
+    o = oracle.detect_batch(sf, iq, want_fft=True, nthreads=4)
+    check(o, g, where="noise sf%d" % sf)
+
+
+@pytest.mark.parametrize("sf", [7, 9, 12])
+def test_chirp_tables_and_none(gpu, oracle, sf):
+    """per-window chirp_sel: up / down / none (the LoRaDetector::feed seam)"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(70 + sf)
+    W = 96
+    iq, _ = make_iq(rng, sf, W, snr_db=3.0)
+    sel = rng.integers(0, 3, W).astype(np.int32)
+    ctx = L.Context(sf)
+    g = ctx.detect_batch(gpu.from_numpy(iq).cuda(), chirp_sel=gpu.from_numpy(sel).cuda(), want_fft=True, want_dec=True)
+    o = oracle.detect_batch(sf, iq, chirp_sel=sel, want_fft=True, want_dec=True)
+    check(o, g, dec=True, where="sel sf%d" % sf)
+    for s in (0, 1, 2):
+        g = ctx.detect_batch(gpu.from_numpy(iq).cuda(), chirp_sel_all=s, want_fft=True)
+        o = oracle.detect_batch(sf, iq, chirp_sel=s, want_fft=True)
+        check(o, g, where="sel_all=%d sf%d" % (s, sf))
+
+
+@pytest.mark.parametrize("sf", [7, 8, 10, 12])
+def test_fine_tune_recurrence(gpu, oracle, sf):
+    """LoRaDemod.cpp:160-162: the int<-float index recurrence for many (idx0, err) pairs,
+    including wrap in both directions, integer and tiny steps, and large indices where
+    float(idx) - d rounds differently"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(90 + sf)
+    N = 1 << sf
+    M = 128 * N
+    errs = np.array([0.0, 0.3, -0.3, 1.0, -1.0, 0.0078125, -0.0078125, 0.01, 1e-4, -1e-4, 2.5, -7.25, 0.4999, 17.3,
+                     -33.7, N / 4 + 0.37, -(N / 4) - 0.12], np.float32)
+    idx0 = np.array([0, 1, M - 1, M // 2, 5, M - 5, 12345 % M, M // 3], np.int32)
+    E, I = np.meshgrid(errs, idx0)
+    E, I = E.reshape(-1).astype(np.float32), I.reshape(-1).astype(np.int32)
+    extra = 40
+    E = np.concatenate([E, rng.uniform(-3, 3, extra).astype(np.float32)])
+    I = np.concatenate([I, rng.integers(0, M, extra).astype(np.int32)])
+    W = E.size
+    iq, _ = make_iq(rng, sf, W, snr_db=10.0)
+    sel = (np.arange(W) % 2).astype(np.int32)
+    ctx = L.Context(sf)
+    g = ctx.detect_batch(gpu.from_numpy(iq).cuda(), chirp_sel=gpu.from_numpy(sel).cuda(),
+                         fine_idx0=gpu.from_numpy(I).cuda(), fine_err=gpu.from_numpy(E).cuda(),
+                         want_fft=True, want_dec=True, want_fine_idx=True)
+    o = oracle.detect_batch(sf, iq, chirp_sel=sel, fine_idx0=I, fine_err=E, want_fft=True, want_dec=True)
+    assert np.array_equal(to_np(g["fineIdxOut"]), o["fineIdxOut"]), "index recurrence end state"
+    check(o, g, dec=True, where="fine sf%d" % sf)
+
+
+def test_offsets_stride_and_overlap(gpu, oracle):
+    """windows at arbitrary sample offsets (the sync machine consumes N-value, N/4+err, 2N ...)"""
+    import lora_sdr_amd as L
+    sf, N = 8, 256
+    rng = np.random.default_rng(5)
+    stream = (rng.standard_normal(50 * N) + 1j * rng.standard_normal(50 * N)).astype(np.complex64)
+    off = np.sort(rng.integers(0, 49 * N, 333)).astype(np.int64)
+    ctx = L.Context(sf)
+    d = gpu.from_numpy(stream).cuda()
+    g = ctx.detect_batch(d, offsets=gpu.from_numpy(off).cuda(), want_fft=True)
+    o = oracle.detect_batch(sf, stream, offsets=off, want_fft=True)
+    check(o, g, where="offsets")
+    g = ctx.detect_batch(d, n_windows=97, window_stride=N // 2, want_fft=True)      # 50% overlapped
+    o = oracle.detect_batch(sf, stream, offsets=np.arange(97, dtype=np.int64) * (N // 2), want_fft=True)
+    check(o, g, where="stride")
+
+
+def test_edge_batches(gpu, oracle):
+    import lora_sdr_amd as L
+    sf, N = 7, 128
+    ctx = L.Context(sf)
+    # empty batch: no launch, no error
+    g = ctx.detect_batch(gpu.zeros(0, dtype=gpu.complex64, device="cuda"))
+    assert g["sym"].numel() == 0
+    # one window; all-zero input -> index 0, -inf powers (log10(0)), fIndex 0 (demon == 0)
+    z = np.zeros((1, N), np.complex64)
+    g = ctx.detect_batch(gpu.from_numpy(z).cuda(), chirp_sel_all=L.CHIRP_NONE, want_fft=True)
+    o = oracle.detect_batch(sf, z, chirp_sel=2, want_fft=True)
+    check(o, g, where="zeros")
+    assert sym_np(g["sym"])[0] == 0 and to_np(g["fIndex"])[0] == 0.0
+    # exact tie between two bins: the lowest index wins (strict '>')
+    t = np.arange(N)
+    x = (np.exp(2j * np.pi * 5 * t / N) + np.exp(2j * np.pi * 69 * t / N)).astype(np.complex64)[None]
+    g = ctx.detect_batch(gpu.from_numpy(x).cuda(), chirp_sel_all=L.CHIRP_NONE, want_fft=True)
+    o = oracle.detect_batch(sf, x, chirp_sel=2, want_fft=True)
+    check(o, g, where="tie")
+
+
+def test_host_pointer_entry(gpu, oracle):
+    """lorahip_detect_batch_host: numpy in, numpy out, staged through the context"""
+    import lora_sdr_amd as L
+    sf = 9
+    rng = np.random.default_rng(11)
+    iq, _ = make_iq(rng, sf, 77, snr_db=0.0)
+    ctx = L.Context(sf)
+    g = ctx.detect_batch(iq, want_fft=True, want_dec=True, want_fine_idx=True, fine_err=0.25)
+    o = oracle.detect_batch(sf, iq, want_fft=True, want_dec=True, fine_err=0.25)
+    assert np.array_equal(g["sym"], o["sym"]) and same_values(g["fft"], o["fft"]) and same_values(g["dec"], o["dec"])
+    assert np.array_equal(g["fineIdxOut"], o["fineIdxOut"])
+    assert np.abs(g["power"] - o["power"]).max() <= TOL_DB
+
+
+def test_detector_shim_test_detector(gpu, oracle, golden):
+    """TestDetector.cpp:9-35 through the LoRaDetector shim (feed/detect), a sample of symbols,
+    and the full 1024-symbol sweep through the batch entry, against the reference's own values"""
+    import lora_sdr_amd as L
+    g = golden("test_detector_n1024.npz")
+    N = 1024
+    down, _ = oracle.genchirp(N, 1, N, 0.0, True, 1.0, 0.0)
+    det = L.LoRaDetector(N)
+    wins = np.empty((N, N), np.complex64)
+    for sym in range(N):
+        ch, _ = oracle.genchirp(N, 1, N, np.float32(2 * np.pi * sym) / N, False, 1.0, np.float32(np.pi / 4))
+        wins[sym] = down * ch
+    for sym in (0, 1, 511, 777, 1023):
+        for i in range(N):
+            det.feed(i, wins[sym, i])
+        fft = np.empty(N, np.complex64)
+        index, power, powerAvg, fIndex = det.detect(fft)
+        assert index == sym and power > -10.0
+        assert abs(power - g["power"][sym]) <= TOL_DB and abs(fIndex - g["fIndex"][sym]) <= TOL_FIDX
+        assert same_values(fft, oracle.detect(wins[sym])[4])
+    ctx = L.Context(10)
+    r = ctx.detect_batch(gpu.from_numpy(wins).cuda(), chirp_sel_all=L.CHIRP_NONE)
+    assert np.array_equal(sym_np(r["sym"]), np.arange(N))
+    assert (to_np(r["power"]) > -10.0).all()
+    assert np.abs(to_np(r["power"]) - g["power"]).max() <= TOL_DB
+    assert np.abs(to_np(r["powerAvg"]) - g["powerAvg"]).max() <= 1e-3   # -140 dB floor of a clean tone: ulp-level noise sum
+    assert np.abs(to_np(r["fIndex"]) - g["fIndex"]).max() <= TOL_FIDX
+
+
+@pytest.mark.parametrize("sf", range(6, 13))
+def test_golden_detector_kat(gpu, golden, sf):
+    """committed vectors from the real reference: chirp+noise, noise, zeros, last bin, twin peaks, off-bin tone"""
+    import lora_sdr_amd as L
+    g = golden("detector_kat.npz")
+    ctx = L.Context(sf)
+    r = ctx.detect_batch(gpu.from_numpy(g["in_%d" % sf]).cuda(), chirp_sel_all=L.CHIRP_NONE, want_fft=True)
+    assert np.array_equal(sym_np(r["sym"]), g["sym_%d" % sf])
+    assert same_values(to_np(r["fft"]), g["fft_%d" % sf])
+    ref_p, ref_a, ref_f = g["power_%d" % sf], g["powerAvg_%d" % sf], g["fIndex_%d" % sf]
+    fin = np.isfinite(ref_p)
+    assert np.abs(to_np(r["power"])[fin] - ref_p[fin]).max() <= TOL_DB
+    fin = np.isfinite(ref_a)
+    assert np.abs(to_np(r["powerAvg"])[fin] - ref_a[fin]).max() <= 1e-3
+    assert np.abs(to_np(r["fIndex"]) - ref_f).max() <= TOL_FIDX

@@ -1,0 +1,95 @@
+"""CPU: pin the plain-C restatement (oracle/lora_oracle.c) against the REAL reference code
+compiled in place (oracle/_ref). Skipped where oracle/_ref was never built."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+
+@pytest.mark.parametrize("sf", range(1, 13))
+def test_detect_bit_exact(oracle, ref, sf):
+    rng = np.random.default_rng(sf)
+    N = 1 << sf
+    for kind in range(3):
+        x = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+        if kind == 1:
+            x += (4 * np.exp(2j * np.pi * (N // 3) * np.arange(N) / N)).astype(np.complex64)
+        if kind == 2:
+            x[:] = 0
+        a, b = oracle.detect(x), ref.detect(x)
+        assert a[0] == b[0]
+        assert np.array_equal(bits(np.float32(a[1:4])), bits(np.float32(b[1:4])))
+        assert np.array_equal(bits(a[4]), bits(b[4]))
+
+
+def test_kissfft_plan_matches_survey(oracle):
+    # SF7 [4,4,4,2], SF8 [4^4], SF12 [4^6]; radix-2 stage innermost
+    assert [p for p, _ in oracle.stages(128)] == [4, 4, 4, 2]
+    assert [p for p, _ in oracle.stages(256)] == [4, 4, 4, 4]
+    assert [p for p, _ in oracle.stages(2048)] == [4, 4, 4, 4, 4, 2]
+    assert oracle.stages(4096) == [(4, 1024), (4, 256), (4, 64), (4, 16), (4, 4), (4, 1)]
+
+
+@pytest.mark.parametrize("args", [(128, 1, 128, 0.0, 0, 1.0, 0.0), (1024, 1, 1024, 0.3, 1, 0.7, 0.25),
+                                  (4096, 1, 1024, 2.0, 0, 0.3, 6.0), (256, 4, 1024, 1.0, 1, 1.0, 0.1)])
+def test_genchirp_bit_exact(oracle, ref, args):
+    a, b = oracle.genchirp(*args), ref.genchirp(*args)
+    assert np.array_equal(bits(a[0]), bits(b[0])) and a[1] == b[1]
+
+
+def test_detector_sweep_n1024(oracle, ref):
+    """TestDetector.cpp:9-35 through both implementations"""
+    N = 1024
+    down, _ = ref.genchirp(N, 1, N, 0.0, True, 1.0, 0.0)
+    wins = np.empty((N, N), np.complex64)
+    for sym in range(N):
+        ch, _ = ref.genchirp(N, 1, N, np.float32(2 * np.pi * sym) / N, False, 1.0, np.float32(np.pi / 4))
+        wins[sym] = down * ch
+    r = ref.detect_windows(N, wins)
+    o = oracle.detect_batch(10, wins, chirp_sel=2)
+    assert np.array_equal(r["sym"], np.arange(N)) and (r["power"] > -10).all()
+    for k in ("sym", "power", "powerAvg", "fIndex"):
+        assert np.array_equal(o[k], r[k]), k
+
+
+@pytest.mark.parametrize("sf,off", [(7, 0.3), (8, -0.4), (10, 0.25)])
+def test_demod_block_identical(oracle, ref, sf, off):
+    """whole LoRaDemod.cpp (verbatim, fake Pothos) vs the restated state machine on a stream with
+    two frames, a fractional frequency offset (fine-tune recurrence active) and noise"""
+    rng = np.random.default_rng(100 + sf)
+    N = 1 << sf
+    syms = rng.integers(0, N, 20).astype(np.uint16)
+    fr = oracle.mod_frame(sf, syms, padding=3)
+    st = np.concatenate([np.zeros(N // 2 + 5, np.complex64), fr, fr, np.zeros(3 * N, np.complex64)])
+    st = (st * np.exp(2j * np.pi * off / N * np.arange(st.size))).astype(np.complex64)
+    st += (0.05 * (rng.standard_normal(st.size) + 1j * rng.standard_normal(st.size))).astype(np.complex64)
+    A, B = oracle.demod_run(sf, st, mtu=20), ref.demod_run(sf, st, mtu=20)
+    assert [c["consumed"] for c in A["calls"]] == B["consumed"].tolist()
+    assert [c["label"] for c in A["calls"]] == B["labels"]
+    assert any(c["label"].startswith("P ") for c in A["calls"])
+    for fa, fb in zip(A["fft"], B["fft"]):
+        assert np.array_equal(bits(fa), bits(fb))
+    for da, db in zip(A["dec"], B["dec"]):
+        assert np.array_equal(bits(da[:N]), bits(db[:N]))
+    assert len(A["packets"]) == len(B["packets"]) == 2
+    for (ca, pa), (cb, pb) in zip(A["packets"], B["packets"]):
+        assert ca == cb and np.array_equal(pa, pb) and np.array_equal(pa, syms.astype(np.int16))
+    sig = [v for _, v in B["signals"]]
+    assert np.allclose(np.array(A["signals"]).reshape(-1), sig, rtol=0, atol=0)
+
+
+def test_demod_sync_word_and_squelch(oracle, ref):
+    """non-default sync word, small MTU, frame ending by squelch (padding) -- still identical"""
+    rng = np.random.default_rng(7)
+    sf, N = 8, 256
+    syms = rng.integers(0, N, 9).astype(np.uint16)
+    fr = oracle.mod_frame(sf, syms, sync=0x34, padding=4)
+    st = np.concatenate([fr, fr, np.zeros(2 * N, np.complex64)])
+    st += (0.01 * (rng.standard_normal(st.size) + 1j * rng.standard_normal(st.size))).astype(np.complex64)
+    for sync, mtu in ((0x34, 64), (0x34, 4), (0x12, 64)):
+        A = oracle.demod_run(sf, st, sync=sync, mtu=mtu, thresh=10.0)
+        B = ref.demod_run(sf, st, sync=sync, mtu=mtu, thresh=10.0)
+        assert [c["consumed"] for c in A["calls"]] == B["consumed"].tolist()
+        assert len(A["packets"]) == len(B["packets"])
+        for (ca, pa), (cb, pb) in zip(A["packets"], B["packets"]):
+            assert ca == cb and np.array_equal(pa, pb)
