@@ -65,10 +65,13 @@ def gather_symbols(local_sym, local_channels, n_channels, group=None):
     pad_sym[:local_sym.shape[0]] = local_sym
     pad_ch = torch.full((cap,), -1, dtype=torch.int64, device=dev)
     pad_ch[:local_sym.shape[0]] = torch.as_tensor(local_channels, dtype=torch.int64, device=dev)
-    all_sym = [torch.empty_like(pad_sym) for _ in range(world)]
+    # 16-bit integers are not a collective dtype in RCCL/gloo: ship the payload as bytes
+    raw = pad_sym.contiguous().view(torch.uint8)
+    all_raw = [torch.empty_like(raw) for _ in range(world)]
     all_ch = [torch.empty_like(pad_ch) for _ in range(world)]
-    dist.all_gather(all_sym, pad_sym, group=group)
+    dist.all_gather(all_raw, raw, group=group)
     dist.all_gather(all_ch, pad_ch, group=group)
+    all_sym = [r.view(local_sym.dtype).reshape(cap, S) for r in all_raw]
     out = torch.zeros((n_channels, S), dtype=local_sym.dtype, device=dev)
     for r in range(world):
         k = counts[r]

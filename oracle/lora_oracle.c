@@ -490,7 +490,7 @@ int lo_demod_work(lo_demod *d, const lo_cf32 *in, size_t avail, lo_work_result *
 /***********************************************************************
  * CPU baseline driver
  **********************************************************************/
-typedef struct { int sf; const lo_cf32 *iq; size_t sps; int lo, hi; int64_t calls; } bench_job;
+typedef struct { int sf; const lo_cf32 *iq; size_t sps; int lo, hi; int repeat; int64_t calls; } bench_job;
 
 static void *bench_body(void *arg)
 {
@@ -498,26 +498,29 @@ static void *bench_body(void *arg)
     const size_t N = (size_t)1 << j->sf;
     lo_cf32 *dec = (lo_cf32 *)malloc(sizeof(lo_cf32) * 2 * N);
     lo_cf32 *fft = (lo_cf32 *)malloc(sizeof(lo_cf32) * N);
+    /* one block per worker (its constructor builds the 128*N fine table), re-activated per stream */
+    lo_demod *d = lo_demod_new(j->sf);
+    for (int rep = 0; rep < (j->repeat > 1 ? j->repeat : 1); rep++)
     for (int s = j->lo; s < j->hi; s++) {
-        lo_demod *d = lo_demod_new(j->sf);
+        lo_demod_activate(d);
         const lo_cf32 *in = j->iq + (size_t)s * j->sps;
         size_t pos = 0;
         lo_work_result r;
         /* like the block, also fill the dec/fft debug buffers (LoRaDemod.cpp:163-164) */
         while (lo_demod_work(d, in + pos, j->sps - pos, &r, dec, fft, NULL)) { pos += (size_t)r.consumed; j->calls++; if (!r.consumed) break; }
-        lo_demod_free(d);
     }
+    lo_demod_free(d);
     free(dec); free(fft);
     return NULL;
 }
 
-int64_t lo_demod_bench(int sf, const lo_cf32 *iq, size_t samplesPerStream, int nStreams, int nthreads)
+int64_t lo_demod_bench(int sf, const lo_cf32 *iq, size_t samplesPerStream, int nStreams, int nthreads, int repeat)
 {
     const int T = nthreads > 1 ? nthreads : 1;
     bench_job *jobs = (bench_job *)calloc((size_t)T, sizeof(bench_job));
     pthread_t *th = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
     for (int t = 0; t < T; t++) {
-        bench_job j = { sf, iq, samplesPerStream, nStreams * t / T, nStreams * (t + 1) / T, 0 };
+        bench_job j = { sf, iq, samplesPerStream, nStreams * t / T, nStreams * (t + 1) / T, repeat, 0 };
         jobs[t] = j;
         if (T == 1) bench_body(&jobs[t]); else pthread_create(&th[t], NULL, bench_body, &jobs[t]);
     }

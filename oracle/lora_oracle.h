@@ -88,8 +88,9 @@ int lo_demod_work(lo_demod *d, const lo_cf32 *in, size_t avail, lo_work_result *
                   lo_cf32 *dec, lo_cf32 *fft, int16_t *packet);
 
 /* CPU baseline: nStreams independent blocks over contiguous streams, nthreads workers;
- * returns the total number of work() calls (= windows dechirped+FFT'd+scanned). */
-int64_t lo_demod_bench(int sf, const lo_cf32 *iq, size_t samplesPerStream, int nStreams, int nthreads);
+ * every stream is processed `repeat` times (fresh block each time); returns the total number
+ * of work() calls (= windows dechirped+FFT'd+scanned). */
+int64_t lo_demod_bench(int sf, const lo_cf32 *iq, size_t samplesPerStream, int nStreams, int nthreads, int repeat);
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,7 @@ class Oracle:
         L.lo_demod_work.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(WorkResult),
                                     C.c_void_p, C.c_void_p, _i16p]
         L.lo_demod_bench.restype = C.c_int64
-        L.lo_demod_bench.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        L.lo_demod_bench.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
 
     # -- kissfft ---------------------------------------------------------
     def twiddles(self, N):
@@ -211,9 +211,9 @@ class Oracle:
         self.L.lo_demod_free(d)
         return dict(calls=calls, packets=packets, signals=signals, fft=ffts, dec=decs)
 
-    def demod_bench(self, sf, iq, samples_per_stream, n_streams, nthreads):
+    def demod_bench(self, sf, iq, samples_per_stream, n_streams, nthreads, repeat=1):
         iq = _cf(iq)
-        return int(self.L.lo_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads))
+        return int(self.L.lo_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads, repeat))
 
 
 class Ref:
@@ -255,7 +255,7 @@ class Ref:
         L.loraref_demod_get_signal.restype = C.c_double
         L.loraref_demod_get_signal.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.loraref_demod_bench.restype = C.c_int64
-        L.loraref_demod_bench.argtypes = [C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        L.loraref_demod_bench.argtypes = [C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
 
     def detect(self, x):
         x = _cf(x)
@@ -318,6 +318,6 @@ class Ref:
         self.L.loraref_demod_free(h)
         return dict(consumed=consumed, labels=labels, fft=fft, dec=dec, packets=packets, signals=signals)
 
-    def demod_bench(self, sf, iq, samples_per_stream, n_streams, nthreads):
+    def demod_bench(self, sf, iq, samples_per_stream, n_streams, nthreads, repeat=1):
         iq = _cf(iq)
-        return int(self.L.loraref_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads))
+        return int(self.L.loraref_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads, repeat))

@@ -226,17 +226,21 @@ double loraref_demod_get_signal(void *p, const size_t i, char *buf, const size_t
 
 //! CPU baseline: nthreads blocks, each runs its own contiguous stream; returns total work() calls
 int64_t loraref_demod_bench(const size_t sf, const float *iq, const size_t samplesPerStream,
-                            const int nStreams, const int nthreads)
+                            const int nStreams, const int nthreads, const int repeat)
 {
     std::vector<int64_t> calls(size_t(nStreams), 0);
     auto body = [&](const int lo, const int hi)
     {
+        // one block per worker (the constructor builds a 128*N-entry table: LoRaDemod.cpp:108-114),
+        // re-activated for every stream
+        void *h = loraref_demod_new(sf, 0);
+        for (int rep = 0; rep < (repeat > 1 ? repeat : 1); rep++)
         for (int s = lo; s < hi; s++)
         {
-            void *h = loraref_demod_new(sf, 0);
-            calls[size_t(s)] = loraref_demod_run(h, iq + 2 * size_t(s) * samplesPerStream, samplesPerStream);
-            loraref_demod_free(h);
+            reinterpret_cast<DemodHandle *>(h)->block->activate();
+            calls[size_t(s)] += loraref_demod_run(h, iq + 2 * size_t(s) * samplesPerStream, samplesPerStream);
         }
+        loraref_demod_free(h);
     };
     const int T = nthreads > 1 ? nthreads : 1;
     std::vector<std::thread> pool;

@@ -70,16 +70,16 @@ def test_random_symbols_awgn(gpu, oracle, sf):
     import lora_sdr_amd as L
     rng = np.random.default_rng(sf)
     W = {6: 700, 7: 515, 8: 300, 9: 130, 10: 70, 11: 33, 12: 19}[sf]   # ragged: not a multiple of windows/block
-    iq, _ = make_iq(rng, sf, W, snr_db=-5.0)
-    _ = _.astype(np.uint16)
+    snr = -5.0 if sf >= 9 else 5.0       # keep the post-FFT SNR comfortably above the error floor
+    iq, sent = make_iq(rng, sf, W, snr_db=snr)
     ctx = L.Context(sf)
     g = ctx.detect_batch(gpu.from_numpy(iq).cuda(), want_fft=True, want_dec=True, want_fine_idx=True)
     gpu.cuda.synchronize()
     o = oracle.detect_batch(sf, iq, want_fft=True, want_dec=True)
     check(o, g, dec=True, where="sf%d" % sf)
     assert np.array_equal(to_np(g["fineIdxOut"]), o["fineIdxOut"])
-    # and the sanity of the test itself: at -5 dB per sample every symbol is recovered
-    assert np.array_equal(o["sym"], _)
+    # and the sanity of the test itself: every symbol is recovered
+    assert np.array_equal(o["sym"], sent.astype(np.uint16))
 
 
 @pytest.mark.parametrize("sf", [7, 9, 11])
