@@ -79,8 +79,8 @@ typedef struct lorahip_ctx lorahip_ctx;
 int lorahip_create(lorahip_ctx **ctx, int device, int sf);
 void lorahip_destroy(lorahip_ctx *ctx);
 int lorahip_sf(const lorahip_ctx *ctx);
-/* Use an existing hipStream_t (e.g. torch's current stream) for all launches; NULL = the
- * context's own stream. */
+/* Launch on an existing hipStream_t (e.g. torch's current stream) from now on. NULL is HIP's
+ * null stream. Until this is called the context uses a private non-blocking stream. */
 int lorahip_set_stream(lorahip_ctx *ctx, void *hip_stream);
 int lorahip_synchronize(lorahip_ctx *ctx);
 

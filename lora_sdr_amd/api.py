@@ -75,9 +75,9 @@ class Context:
         self.close()
 
     def set_stream(self, stream_handle):
-        """stream_handle: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None"""
-        check(self._lib.lorahip_set_stream(self._h, C.c_void_p(stream_handle) if stream_handle else None),
-              "lorahip_set_stream")
+        """stream_handle: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0/None is
+        HIP's null stream, which is torch's default stream"""
+        check(self._lib.lorahip_set_stream(self._h, C.c_void_p(stream_handle or 0)), "lorahip_set_stream")
 
     def use_torch_stream(self):
         import torch

@@ -140,7 +140,8 @@ int lorahip_sf(const lorahip_ctx *ctx) { return ctx ? ctx->sf : LORAHIP_E_INVALI
 int lorahip_set_stream(lorahip_ctx *ctx, void *hip_stream)
 {
     if (ctx == nullptr) return LORAHIP_E_INVALID;
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->ownStream;
+    // NULL is HIP's null stream (what torch calls its default stream), not "no stream"
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return LORAHIP_OK;
 }
 
