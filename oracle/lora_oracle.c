@@ -503,6 +503,8 @@ static void *bench_body(void *arg)
     for (int rep = 0; rep < (j->repeat > 1 ? j->repeat : 1); rep++)
     for (int s = j->lo; s < j->hi; s++) {
         lo_demod_activate(d);
+        /* same start state for every stream (the reference only resets these in its noise branch) */
+        d->prevValue = 0; d->freqError = 0; d->fineTuneIndex = 0; d->finefreqError = 0; d->symCount = 0;
         const lo_cf32 *in = j->iq + (size_t)s * j->sps;
         size_t pos = 0;
         lo_work_result r;

