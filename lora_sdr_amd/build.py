@@ -13,8 +13,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblorahip.so")
-SOURCES = ["lorahip_kernels.hip", "lorahip_api.cpp", "lorahip_tables.cpp", "lorahip_demod.cpp"]
-HEADERS = ["lorahip_internal.h", os.path.join("..", "..", "include", "lorahip.h")]
+SOURCES = ["lorahip_kernels.hip", "lorahip_fast.hip", "lorahip_api.cpp", "lorahip_tables.cpp", "lorahip_demod.cpp"]
+HEADERS = ["lorahip_internal.h", "lorahip_device.h", os.path.join("..", "..", "include", "lorahip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result", "-x", "hip"]
 

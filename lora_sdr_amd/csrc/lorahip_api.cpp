@@ -111,6 +111,12 @@ int lorahip_create(lorahip_ctx **out, const int device, const int sf)
         LORAHIP_CK(hipMemcpy(ctx->dDown, t.down.data(), nb, hipMemcpyHostToDevice));
         LORAHIP_CK(hipMemcpy(ctx->dTw, t.twiddle.data(), nb, hipMemcpyHostToDevice));
         LORAHIP_CK(hipMemcpy(ctx->dFine, t.fine.data(), nb * LORAHIP_FINE_STEPS, hipMemcpyHostToDevice));
+        const std::vector<cf32> st = buildStageTwiddles(sf, t.twiddle);
+        LORAHIP_CK(hipMalloc((void **)&ctx->dTwStage, (st.size() + 1) * sizeof(cf32)));
+        LORAHIP_CK(hipMemcpy(ctx->dTwStage, st.data(), st.size() * sizeof(cf32), hipMemcpyHostToDevice));
+        hipDeviceProp_t prop;
+        LORAHIP_CK(hipGetDeviceProperties(&prop, device));
+        ctx->cuCount = prop.multiProcessorCount;
 #undef LORAHIP_CK
     } while (false);
     if (rc != LORAHIP_OK) { lorahip_destroy(ctx); return rc; }
@@ -127,6 +133,7 @@ void lorahip_destroy(lorahip_ctx *ctx)
     if (ctx->dDown) (void)hipFree(ctx->dDown);
     if (ctx->dTw) (void)hipFree(ctx->dTw);
     if (ctx->dFine) (void)hipFree(ctx->dFine);
+    if (ctx->dTwStage) (void)hipFree(ctx->dTwStage);
     if (ctx->dStage) (void)hipFree(ctx->dStage);
     if (ctx->hStage) (void)hipHostFree(ctx->hStage);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -200,7 +207,10 @@ int lorahip_detect_batch(lorahip_ctx *ctx, const lorahip_batch *b)
     if (rc != LORAHIP_OK || b->n_windows == 0) return rc;
     DetectArgs a;
     fillArgs(ctx, b, a);
-    LORAHIP_TRY(launchDetect(ctx->sf, ctx->variant, a, ctx->stream));
+    FastTables ft;
+    ft.twStage = ctx->dTwStage;
+    ft.nBlocksHint = ctx->cuCount;
+    LORAHIP_TRY(launchDetect(ctx->sf, ctx->variant, a, ft, ctx->stream));
     return LORAHIP_OK;
 }
 

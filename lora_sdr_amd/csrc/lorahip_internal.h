@@ -44,8 +44,20 @@ struct DetectArgs
     float powerScale;           // float(20*log10(double(N)))  LoRaDetector.hpp:18
 };
 
-//! launchers (lorahip_kernels.hip)
-hipError_t launchDetect(int sf, int variant, const DetectArgs &a, hipStream_t stream);
+//! tables of the tuned kernels (device pointers, built at context creation)
+struct FastTables
+{
+    const float2 *twStage;      // stage-major twiddles: for each radix-4 stage with remainder m = 2^b,
+                                // [q-1][k] = twiddle(k * fstride_b * q), k < m  (values of kissfft's table)
+    int nBlocksHint;            // multiprocessor count of the device
+};
+//! host: stage-major twiddle table from kissfft's table (lorahip_fast.hip)
+std::vector<cf32> buildStageTwiddles(int sf, const std::vector<cf32> &tw);
+
+//! launchers (lorahip_kernels.hip / lorahip_fast.hip)
+hipError_t launchDetect(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
+bool fastAvailable(int sf);
+hipError_t launchFast(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
 hipError_t launchSynth(int sf, float2 *iq, const unsigned short *sym, size_t nWindows,
                        float ampl, float sigma, unsigned long long seed, hipStream_t stream);
 
@@ -64,7 +76,8 @@ struct lorahip_ctx
     int variant;
     hipStream_t ownStream;
     hipStream_t stream;
-    float2 *dUp, *dDown, *dFine, *dTw;
+    float2 *dUp, *dDown, *dFine, *dTw, *dTwStage;
+    int cuCount;
     hipEvent_t ev0, ev1;
     float powerScale;
     // staging for the host-pointer entry point (grown on demand)

@@ -1,121 +1,10 @@
 // CDNA4 (gfx950) kernels of the LoRa demod hot path: dechirp -> 2^SF-point FFT -> detect.
-//
-// Numerics contract: the FFT evaluates the SAME dataflow graph as the
-// reference's kissfft for N = 2^SF -- decimation-in-time, radix-4 stages outermost and one
-// radix-2 stage innermost for odd SF (kissfft.hh:34-51 factorisation), every butterfly with
-// kissfft's operation order (kissfft.hh:128-157) and kissfft's own float twiddle table
-// (kissfft.hh:17-22, uploaded from the host) -- in strict IEEE fp32 with NO fused
-// multiply-add. This translation unit is therefore compiled with -ffp-contract=off and the
-// pragma below; the FFT bins and the arg-max index are bit-identical to the CPU reference
-// built without FMA. That is a property of the arithmetic graph, not of the schedule: which
-// lane holds which point, what goes through LDS or DPP, and the order butterflies of one
-// stage are issued in are free, and are chosen for the machine.
-#pragma clang fp contract(off)
-
-#include "lorahip_internal.h"
+// This TU: the generic LDS kernel (variant 1, every SF), the synthetic-IQ generator and the
+// launch dispatch. The tuned register/LDS-phase kernels live in lorahip_fast.hip.
+// Numerics contract and shared helpers: lorahip_device.h.
+#include "lorahip_device.h"
 
 namespace lorahip {
-
-/***********************************************************************
- * complex helpers -- (ac - bd, ad + bc), products and sums rounded separately,
- * which is what std::complex<float>::operator* evaluates for finite operands
- **********************************************************************/
-__device__ __forceinline__ float2 cmul(const float2 a, const float2 b)
-{
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 cadd(const float2 a, const float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(const float2 a, const float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-
-//! kf_bfly4 body for one k (kissfft.hh:143-155), forward transform
-__device__ __forceinline__ void bfly4(float2 &f0, float2 &f1, float2 &f2, float2 &f3,
-                                      const float2 t1, const float2 t2, const float2 t3)
-{
-    const float2 s0 = cmul(f1, t1);
-    const float2 s1 = cmul(f2, t2);
-    const float2 s2 = cmul(f3, t3);
-    const float2 s5 = csub(f0, s1);
-    f0 = cadd(f0, s1);
-    const float2 s3 = cadd(s0, s2);
-    float2 s4 = csub(s0, s2);
-    s4 = make_float2(s4.y, -s4.x);
-    f2 = csub(f0, s3);
-    f0 = cadd(f0, s3);
-    f1 = cadd(s5, s4);
-    f3 = csub(s5, s4);
-}
-
-//! kf_bfly2 body for one k (kissfft.hh:131-133)
-__device__ __forceinline__ void bfly2(float2 &f0, float2 &f1, const float2 t)
-{
-    const float2 v = cmul(f1, t);
-    f1 = csub(f0, v);
-    f0 = cadd(f0, v);
-}
-
-/***********************************************************************
- * kissfft's plan for N = 2^LOG2N as compile-time constants.
- * Stage s (0 = outermost) has radix p_s and remainder m_s; input digit q_s has weight
- * fstride_s = p_0..p_{s-1} in the sample index n and weight m_s in the work-array
- * position (kf_work recursion, kissfft.hh:83-104).
- **********************************************************************/
-template <int LOG2N> struct Plan
-{
-    static constexpr int N = 1 << LOG2N;
-    static constexpr int R4 = LOG2N / 2;          // number of radix-4 stages
-    static constexpr bool HAS_R2 = (LOG2N & 1);   // innermost radix-2 stage (m = 1)
-    //! work-array position of input sample n (digit reversal of the mixed-radix index)
-    __host__ __device__ static constexpr int pos(int n)
-    {
-        int p = 0, m = N;
-        for (int s = 0; s < R4; s++) { m >>= 2; p += (n & 3) * m; n >>= 2; }
-        if (HAS_R2) p += (n & 1);
-        return p;
-    }
-};
-
-/***********************************************************************
- * fine-tune index recurrence, one step (LoRaDemod.cpp:160-162)
- *   _fineTuneIndex -= _finefreqError * _fineSteps   (int -= float: float subtract, truncate)
- **********************************************************************/
-__device__ __forceinline__ int fineStep(const int idx, const float d /* = err*128 */, const int M)
-{
-    int n = (int)((float)idx - d);
-    if (n < 0) n += M;
-    else if (n >= M) n -= M;
-    return n;
-}
-
-/***********************************************************************
- * detect() tail for one window, executed by one lane (LoRaDetector.hpp:50-61)
- **********************************************************************/
-__device__ __forceinline__ void detectTail(const DetectArgs &a, const unsigned w, const int maxIndex,
-                                           const float maxValue, const double total,
-                                           const float2 leftBin, const float2 rightBin)
-{
-    const float noise = sqrtf((float)(total - (double)maxValue));
-    const float fundamental = sqrtf(maxValue);
-    // log10 evaluated in double and rounded once: within an ulp of a correctly rounded log10f
-    const float powerAvg = 20 * (float)log10((double)noise) - a.powerScale;
-    const float power = 20 * (float)log10((double)fundamental) - a.powerScale;
-    // std::abs(complex<float>) = hypotf; the double form is its correctly rounded value
-    const float left = (float)sqrt((double)leftBin.x * (double)leftBin.x + (double)leftBin.y * (double)leftBin.y);
-    const float right = (float)sqrt((double)rightBin.x * (double)rightBin.x + (double)rightBin.y * (double)rightBin.y);
-    const double demon = (2.0 * (double)fundamental) - (double)right - (double)left;
-    float fIndex = 0.0f;
-    if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
-    a.sym[w] = (unsigned short)maxIndex;
-    a.power[w] = power;
-    a.powerAvg[w] = powerAvg;
-    a.fIndex[w] = fIndex;
-}
-
-//! arg-max combine with the reference's tie-break: strict '>' scanning upwards keeps the
-//! LOWEST index among equal maxima (LoRaDetector.hpp:43)
-__device__ __forceinline__ void argmaxCombine(float &v, int &i, const float ov, const int oi)
-{
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-}
 
 /***********************************************************************
  * Variant 1: generic LDS kernel. N/4 threads per window, every stage through LDS.
@@ -290,9 +179,9 @@ static hipError_t launchGeneric(const DetectArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launchDetect(const int sf, const int variant, const DetectArgs &a, hipStream_t stream)
+hipError_t launchDetect(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
-    (void)variant;
+    if (variant != 1 && fastAvailable(sf)) return launchFast(sf, variant, a, ft, stream);
     switch (sf)
     {
     case 6: return launchGeneric<6>(a, stream);
