@@ -193,6 +193,11 @@ int lorahip_demod_get_trace(const lorahip_demod *d, size_t channel, lorahip_work
 int lorahip_synth_symbols(lorahip_ctx *ctx, float *iq_dev, const uint16_t *sym_dev,
                           size_t n_windows, float ampl, float noise_sigma, uint64_t seed);
 
+/* Measurement aid: one read-only streaming pass over n_bytes of device memory (pattern 0: linear
+ * 16 B per lane; 1: the access shape of the tuned SF7 kernel). Time it with lorahip_timer_*; the
+ * result is the practical HBM ceiling the roofline fraction can be compared with. */
+int lorahip_membw_probe(lorahip_ctx *ctx, const float *buf_dev, size_t n_bytes, int pattern, int blocks_per_cu);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,7 @@ SIGNATURES = {
     "lorahip_demod_set_trace": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_trace_len": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "lorahip_demod_get_trace": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(WorkResult), C.c_size_t]),
+    "lorahip_membw_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "lorahip_synth_symbols": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                         C.c_uint64]),
 }

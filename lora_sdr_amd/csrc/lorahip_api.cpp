@@ -161,7 +161,7 @@ int lorahip_synchronize(lorahip_ctx *ctx)
 
 int lorahip_set_variant(lorahip_ctx *ctx, const int variant)
 {
-    if (ctx == nullptr || variant < 0 || variant > 2) return LORAHIP_E_INVALID;
+    if (ctx == nullptr || variant < 0 || variant > 9) return LORAHIP_E_INVALID;
     ctx->variant = variant;
     return LORAHIP_OK;
 }
@@ -302,6 +302,14 @@ int lorahip_timer_stop(lorahip_ctx *ctx, float *elapsed_ms)
     LORAHIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     LORAHIP_TRY(hipEventSynchronize(ctx->ev1));
     LORAHIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return LORAHIP_OK;
+}
+
+int lorahip_membw_probe(lorahip_ctx *ctx, const float *buf_dev, const size_t n_bytes, const int pattern, const int blocks_per_cu)
+{
+    if (ctx == nullptr || buf_dev == nullptr || blocks_per_cu < 1) return LORAHIP_E_INVALID;
+    LORAHIP_TRY(launchMembw(reinterpret_cast<const float2 *>(buf_dev), n_bytes, pattern, ctx->cuCount * blocks_per_cu,
+                            reinterpret_cast<float *>(ctx->dTwStage), ctx->stream));
     return LORAHIP_OK;
 }
 

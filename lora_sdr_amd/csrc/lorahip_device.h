@@ -99,7 +99,9 @@ __device__ __forceinline__ int fineStep(const int idx, const float d /* = err*12
 //! LOWEST index among equal maxima (LoRaDetector.hpp:43)
 __device__ __forceinline__ void argmaxCombine(float &v, int &i, const float ov, const int oi)
 {
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    const bool take = (ov > v) | ((ov == v) & (oi < i));   // branch-free: two selects
+    v = take ? ov : v;
+    i = take ? oi : i;
 }
 
 /***********************************************************************

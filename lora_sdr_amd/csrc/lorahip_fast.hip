@@ -52,10 +52,18 @@ std::vector<cf32> buildStageTwiddles(const int sf, const std::vector<cf32> &tw)
 
 /***********************************************************************
  * compile-time configuration of one kernel instance
+ *   X0ROT/X0PAD/X0S/X0D: exchange-0 LDS layout (found with tools/lds_conflicts.py): a row per low sample
+ *   index n_low = VEC*t+u at element offset rotr(n_low, X0ROT)*(WPW*R+X0PAD) + ((n_low>>X0S)&1)*X0D,
+ *   the WPW windows of a wave side by side inside the row (stride R), so that the writers' ds_write_b64
+ *   groups and the readers' ds_read_b64 groups each tile the LDS banks exactly once.
  **********************************************************************/
-template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_>
+template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_,
+          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, bool PREFETCH_>
 struct FastCfg
 {
+    static constexpr bool PREFETCH = PREFETCH_;       // issue the next window set's loads right after the dechirp of this one
+    static constexpr bool CH_LDS = CH_LDS_;           // chirp table read from LDS per window (else loop-invariant registers)
+    static constexpr bool TW_ALL_LDS = TW_ALL_LDS_;   // last-phase twiddles from the LDS table too (else registers)
     static constexpr int LOG2N = LOG2N_, N = 1 << LOG2N_;
     static constexpr int LOG2T = LOG2T_, T = 1 << LOG2T_;     // lanes per window (<= 64)
     static constexpr int VEC = VEC_;                            // consecutive samples per lane per load
@@ -65,27 +73,31 @@ struct FastCfg
     static constexpr int WPW = 64 / T;                          // windows per wave iteration
     static constexpr int WAVES_PER_SIMD = WAVES_PER_SIMD_;
     static constexpr bool HAS_R2 = (LOG2N_ & 1);
+    static constexpr int NL = VEC * T;                          // distinct n_low
+    static constexpr int LOG2NL = LOG2N_ - PB1_;
     __host__ __device__ static constexpr int bound(const int j)
     {
         return j <= 0 ? 0 : (j == 1 ? PB1_ : (j == 2 ? (NPH_ == 2 ? LOG2N_ : PB2_) : LOG2N_));
     }
     static_assert((1 << PB1_) == R, "phase 0 must cover exactly the bits a lane loads");
     static_assert(((LOG2N_ - PB1_) & 1) == 0, "the low sample digits must be whole radix-4 digits");
-    static_assert(T <= 64 && T >= 2, "a window lives inside one wavefront");
-    //! LDS elements (float2) one window needs for its exchanges: rows of G_j (+1 pad) elements
-    __host__ __device__ static constexpr int exchElems()
+    static_assert(T <= 64 && T >= 4, "a window lives inside one wavefront");
+    // exchange 0
+    static constexpr int RS0 = WPW * R + X0PAD_;
+    __host__ __device__ static constexpr int x0off(const int nlow)
     {
-        int best = 0;
-        for (int j = 0; j + 1 < NPH_; j++)
-        {
-            const int g = 1 << (bound(j + 1) - bound(j));
-            const int e = (N / g) * (g + 1);
-            best = e > best ? e : best;
-        }
-        return best;
+        const int rot = ((nlow >> X0ROT_) | (nlow << (LOG2NL - X0ROT_))) & (NL - 1);
+        return rot * RS0 + ((nlow >> X0S_) & 1) * X0D_;
     }
-    //! twiddle entries staged in LDS: all stages below the last phase
-    static constexpr int TW_LDS = twStageOffset(LOG2N_, bound(NPH_ - 1));
+    static constexpr int X0ELEMS = NL * RS0 + X0D_;             // per wave
+    // exchange 1 (3 phases): per window, element (rl, rh, col) at rh*X1 + col*R + rl
+    static constexpr int G1 = 1 << (bound(2) - bound(1));
+    static constexpr int X1 = G1 * R + 8;
+    static constexpr int X1ELEMS = NPH_ == 3 ? WPW * (N / (G1 * R)) * X1 : 0;   // per wave
+    static constexpr int XELEMS = (X0ELEMS > X1ELEMS ? X0ELEMS : X1ELEMS) + (N > X0ELEMS ? N - X0ELEMS : 0) / 2 * 0;
+    //! twiddle entries staged in LDS: all stages below the last phase, or every stage
+    static constexpr int TW_LDS = twStageOffset(LOG2N_, TW_ALL_LDS_ ? LOG2N_ : bound(NPH_ - 1));
+    static constexpr int CH_ELEMS = CH_LDS_ ? N : 0;
 };
 
 //! reverse the radix-4 digits of an even-width bit string
@@ -159,15 +171,24 @@ __host__ __device__ constexpr int lastPhaseSlots()
     return s;
 }
 
-//! select v[idx] for a runtime idx in [0, CNT) with a cndmask tree (CNT a power of two)
-template <int CNT>
-__device__ __forceinline__ float2 selectReg(const float2 (&v)[CNT], const int idx)
+//! select element (e, g) with flat index idx = e*NG + g out of v[g][e] for a runtime idx: cndmask tree
+template <int NG, int G>
+__device__ __forceinline__ float2 selectReg(const float2 (&v)[NG][G], const int idx)
 {
-    float2 cur[CNT];
+    constexpr int CNT = NG * G;
+    float2 cur[CNT / 2];
+    {
+        const bool hi = idx & 1;
 #pragma unroll
-    for (int i = 0; i < CNT; i++) cur[i] = v[i];
+        for (int i = 0; i < CNT / 2; i++)
+        {
+            const float2 lo2 = v[(2 * i) % NG][(2 * i) / NG], hi2 = v[(2 * i + 1) % NG][(2 * i + 1) / NG];
+            cur[i].x = hi ? hi2.x : lo2.x;
+            cur[i].y = hi ? hi2.y : lo2.y;
+        }
+    }
 #pragma unroll
-    for (int w = CNT / 2, bit = 0; w >= 1; w >>= 1, bit++)
+    for (int w = CNT / 4, bit = 1; w >= 1; w >>= 1, bit++)
     {
         const bool hi = (idx >> bit) & 1;
 #pragma unroll
@@ -180,10 +201,15 @@ __device__ __forceinline__ float2 selectReg(const float2 (&v)[CNT], const int id
     return cur[0];
 }
 
+struct TailRec { unsigned w[64]; int idx[64]; float val[64]; double tot[64]; float2 l[64]; float2 r[64]; };
+
 /***********************************************************************
- * the kernel: one wave = WPW windows per iteration, persistent over window sets
+ * the kernel: one wave = WPW windows per iteration, persistent over window sets.
+ * DBG = the optional "dec" / "fft" debug outputs are wanted (LoRaDemod.cpp:164, :154).
+ * UNI = launch-uniform batch: one chirp selection for all windows and no moving fine-tune index
+ *       (chirp_sel == NULL, fine_err == NULL): the steady-state shape, compiled without the rare paths.
  **********************************************************************/
-template <class C>
+template <class C, bool DBG, bool UNI>
 __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD)
 detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 {
@@ -194,35 +220,32 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     constexpr int GL = 1 << (LOG2N - BL);                 // last-phase group size
     constexpr int NGL = P / GL;                           // last-phase groups per lane
     constexpr int SLOTS = lastPhaseSlots<LOG2N, BL, LOG2N>();
-    constexpr int EXCH = C::exchElems();                  // float2 per window
-    constexpr int WS = EXCH + 4;                          // window stride in LDS (float2), de-phases windows
+    constexpr int XE = (C::X0ELEMS > C::X1ELEMS ? C::X0ELEMS : C::X1ELEMS);
+    constexpr int XW = (XE * 2 > WPW * N ? XE : (WPW * N + 1) / 2) + 2;   // float2 per wave; also holds WPW*N ints
     constexpr int M = N * LORAHIP_FINE_STEPS;
     constexpr int WAVES = 4;
 
     extern __shared__ __attribute__((aligned(16))) char smemRaw[];
     float2 *sTw = reinterpret_cast<float2 *>(smemRaw);                                   // [TW_LDS]
-    float2 *sX = sTw + ((C::TW_LDS + 1) & ~1);                                           // [WAVES][WPW][WS]
-    char *sTail = reinterpret_cast<char *>(sX + WAVES * WPW * WS);                       // [WAVES] tail records
+    float2 *sCh = sTw + ((C::TW_LDS + 1) & ~1);                                          // [CH_ELEMS]
+    float2 *sX = sCh + C::CH_ELEMS;                                                      // [WAVES][XW]
+    TailRec *sTail = reinterpret_cast<TailRec *>(sX + WAVES * XW);                       // [WAVES]
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int wsub = lane >> LOG2T;                       // window inside the wave iteration
     const int t = lane & (T - 1);
-    float2 *X = sX + (wave * WPW + wsub) * WS;            // this window's exchange region
-
-    // tail records of this wave (one slot per lane)
-    struct TailRec { unsigned w[64]; int idx[64]; float val[64]; double tot[64]; float2 l[64]; float2 r[64]; };
-    TailRec &tr = reinterpret_cast<TailRec *>(sTail)[wave];
+    float2 *X = sX + wave * XW;                           // this wave's exchange region
+    TailRec &tr = sTail[wave];
 
     // ---- one-time set-up -------------------------------------------------------------
-    tr.w[lane] = 0xffffffffu;                              // empty tail slots
+    tr.w[lane] = 0xffffffffu;                             // empty tail slots
     for (int i = threadIdx.x; i < C::TW_LDS; i += blockDim.x) sTw[i] = ft.twStage[i];
 
-    // register twiddles of the last phase: group g has klow = (t + T*g) mod 2^BL ... for the last
-    // phase BL bits are all below -> klow = ci
-    float2 twR[NGL][SLOTS];
+    // register twiddles of the last phase: in the last phase klow = ci = t + T*g
+    float2 twR[C::TW_ALL_LDS ? 1 : NGL][C::TW_ALL_LDS ? 1 : SLOTS];
 #pragma unroll
-    for (int g = 0; g < NGL; g++)
+    for (int g = 0; g < (C::TW_ALL_LDS ? 0 : NGL); g++)
     {
         const int ci = t + T * g;
         int slot = 0;
@@ -240,49 +263,83 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             }
     }
 
-    // chirp table values of this lane's sample positions (down table; up = conj, LoRaDemod.cpp:103-104)
-    float2 ch[R][VEC];
+    // chirp table values of this lane's sample positions. One table serves both selections:
+    // _upChirpTable = conj(_downChirpTable) entry by entry (LoRaDemod.cpp:103-104)
+    const bool perWindowSel = !UNI && a.chirpSel != nullptr;
+    const float s0 = (!perWindowSel && a.chirpSelAll == LORAHIP_CHIRP_UP) ? -1.0f : 1.0f;
+    float2 ch[C::CH_LDS ? 1 : R][C::CH_LDS ? 1 : VEC];
+    if (C::CH_LDS)
+    {
+        for (int i = threadIdx.x; i < N; i += blockDim.x)
+        {
+            const float2 c = a.down[i];
+            sCh[i] = make_float2(c.x, s0 * c.y);
+        }
+    }
+    else
+    {
 #pragma unroll
-    for (int r = 0; r < R; r++)
+        for (int r = 0; r < (C::CH_LDS ? 0 : R); r++)
 #pragma unroll
-        for (int u = 0; u < VEC; u++) ch[r][u] = a.down[VEC * t + u + VEC * T * r];
+            for (int u = 0; u < VEC; u++)
+            {
+                const float2 c = a.down[VEC * t + u + VEC * T * r];
+                ch[r][u] = make_float2(c.x, s0 * c.y);
+            }
+    }
     __syncthreads();
 
     const unsigned waveId = blockIdx.x * WAVES + wave;
     const unsigned waveCount = gridDim.x * WAVES;
     int pending = 0;                                       // tail records waiting in tr
 
+    // coalesced window load: VEC*8 bytes per lane, the T lanes of a window contiguous, R rows
+    float2 xn[R][VEC];
+    auto issueLoads = [&](const unsigned set_)
+    {
+        const unsigned w_ = set_ * WPW + wsub;
+        const unsigned wc_ = w_ < a.nWindows ? w_ : a.nWindows - 1;
+        const float2 *in_ = a.iq + (a.offsets ? a.offsets[wc_] : (long long)wc_ * a.stride);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+        {
+            const float2 *p = in_ + VEC * t + VEC * T * r;
+            if (VEC == 2)
+            {
+                const float4 q = *reinterpret_cast<const float4 *>(p);
+                xn[r][0] = make_float2(q.x, q.y);
+                xn[r][VEC - 1] = make_float2(q.z, q.w);
+            }
+            else xn[r][0] = *p;
+        }
+    };
+    if (C::PREFETCH && waveId < nSets) issueLoads(waveId);
+    const float2 fconst0 = a.fine[0];
+
     for (unsigned set = waveId; set < nSets; set += waveCount)
     {
         const unsigned w = set * WPW + wsub;
         const bool active = w < a.nWindows;
-        const unsigned wc = active ? w : a.nWindows - 1;  // clamp: inactive lanes redo the last window, results dropped
-        const int sel = a.chirpSel ? a.chirpSel[wc] : a.chirpSelAll;
+        const unsigned wc = active ? w : a.nWindows - 1;  // inactive lanes redo the last window, results dropped
+        const int sel = perWindowSel ? a.chirpSel[wc] : a.chirpSelAll;
         const int idx0 = a.fineIdx0 ? a.fineIdx0[wc] : 0;
-        const float err = a.fineErr ? a.fineErr[wc] : 0.0f;
-        const float2 *in = a.iq + (a.offsets ? a.offsets[wc] : (long long)wc * a.stride);
+        const float err = (!UNI && a.fineErr) ? a.fineErr[wc] : 0.0f;
         const bool dechirp = sel != LORAHIP_CHIRP_NONE;
         const float d = err * (float)LORAHIP_FINE_STEPS;
         const bool moving = dechirp && d != 0.0f;
+        const bool anyMoving = !UNI && __any(moving);
 
-        // ---- load (coalesced: VEC*8 bytes per lane, T lanes contiguous) ---------------------
+        // ---- samples of this set: loaded here, or already in flight since the previous iteration ---
         float2 x[R][VEC];
+        if (!C::PREFETCH) issueLoads(set);
 #pragma unroll
         for (int r = 0; r < R; r++)
-        {
-            const float2 *p = in + VEC * t + VEC * T * r;
-            if (VEC == 2)
-            {
-                const float4 q = *reinterpret_cast<const float4 *>(p);
-                x[r][0] = make_float2(q.x, q.y);
-                x[r][VEC - 1] = make_float2(q.z, q.w);
-            }
-            else x[r][0] = *p;
-        }
+#pragma unroll
+            for (int u = 0; u < VEC; u++) x[r][u] = xn[r][u];
 
         // ---- fine-tune index chain for windows whose index moves (rare path) -----------------
-        int *sIdx = reinterpret_cast<int *>(X);            // aliases the exchange region (free until phase 0 ends)
-        if (__any(moving))
+        int *sIdx = reinterpret_cast<int *>(X) + wsub * N;   // aliases the exchange region (free until phase 0 ends)
+        if (!UNI && anyMoving)
         {
             if (moving && t == 0)
             {
@@ -296,36 +353,58 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         if (!moving && t == 0 && active && a.fineIdxOut) a.fineIdxOut[w] = idx0;
 
         // ---- dechirp: (samp * chirp) * fine   (LoRaDemod.cpp:159) ---------------------------
-        const float2 fconst = a.fine[idx0];
-        const float sgn = sel == LORAHIP_CHIRP_UP ? -1.0f : 1.0f;   // up table = conj(down table)
-        if (__any(moving))
+        // fine-tune entry of this window: constant over the launch when no per-window index is given
+        const float2 fconst = a.fineIdx0 ? a.fine[idx0] : fconst0;
+        float2 cw[R][VEC];                                 // chirp values of this lane's samples
+#pragma unroll
+        for (int r = 0; r < R; r++)
         {
+            if (C::CH_LDS)
+            {
+                const float2 *p = sCh + VEC * t + VEC * T * r;
+                if (VEC == 2)
+                {
+                    const float4 q = *reinterpret_cast<const float4 *>(p);
+                    cw[r][0] = make_float2(q.x, q.y);
+                    cw[r][VEC - 1] = make_float2(q.z, q.w);
+                }
+                else cw[r][0] = *p;
+            }
+            else
+            {
+#pragma unroll
+                for (int u = 0; u < VEC; u++) cw[r][u] = ch[C::CH_LDS ? 0 : r][C::CH_LDS ? 0 : u];
+            }
+        }
+        if (UNI || (!perWindowSel && !anyMoving))
+        {
+            // launch-uniform table selection, constant fine-tune entry: the hot path
+            if (a.chirpSelAll != LORAHIP_CHIRP_NONE)
+            {
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int u = 0; u < VEC; u++) x[r][u] = cmul(cmul(x[r][u], cw[r][u]), fconst);
+            }
+        }
+        else
+        {
+            const float sgn = (perWindowSel && sel == LORAHIP_CHIRP_UP) ? -1.0f : 1.0f;
 #pragma unroll
             for (int r = 0; r < R; r++)
 #pragma unroll
                 for (int u = 0; u < VEC; u++)
                 {
-                    const float2 c = make_float2(ch[r][u].x, sgn * ch[r][u].y);
-                    const float2 f = moving ? a.fine[sIdx[VEC * t + u + VEC * T * r]] : fconst;
+                    const float2 c = make_float2(cw[r][u].x, sgn * cw[r][u].y);
+                    float2 f = fconst;
+                    if (anyMoving && moving) f = a.fine[sIdx[VEC * t + u + VEC * T * r]];
                     const float2 y = cmul(cmul(x[r][u], c), f);
                     x[r][u] = dechirp ? y : x[r][u];
                 }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        else
-        {
-#pragma unroll
-            for (int r = 0; r < R; r++)
-#pragma unroll
-                for (int u = 0; u < VEC; u++)
-                {
-                    const float2 c = make_float2(ch[r][u].x, sgn * ch[r][u].y);
-                    const float2 y = cmul(cmul(x[r][u], c), fconst);
-                    x[r][u] = dechirp ? y : x[r][u];
-                }
-        }
-        if (a.decOut && active)
+        if (DBG && a.decOut && active)
         {
 #pragma unroll
             for (int r = 0; r < R; r++)
@@ -340,67 +419,84 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int u = 0; u < VEC; u++) v0[u][Plan<LOG2N>::pos(VEC * T * r) & (R - 1)] = x[r][u];
+        // next set's samples go in flight now and land while this set is transformed (past the end:
+        // re-read the last set, harmless and branch-free)
+        if (C::PREFETCH) issueLoads(set + waveCount < nSets ? set + waveCount : nSets - 1);
 #pragma unroll
         for (int u = 0; u < VEC; u++) runPhase<LOG2N, 0, B1, false>(v0[u], 0, sTw, nullptr);
 
-        // ---- exchange 0: rows = n_low = VEC*t+u (writer order), R (+1 pad) columns ------------
+        // ---- exchange 0: one row per n_low = VEC*t+u, the wave's windows side by side ----------
+        {
+            float2 *Xw = X + wsub * R;
 #pragma unroll
-        for (int u = 0; u < VEC; u++)
+            for (int u = 0; u < VEC; u++)
+            {
+                float2 *row = Xw + C::x0off(VEC * t + u);
 #pragma unroll
-            for (int e = 0; e < R; e++) X[(VEC * t + u) * (R + 1) + e] = v0[u][e];
+                for (int e = 0; e < R; e++) row[e] = v0[u][e];
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
         float2 vl[NGL][GL];                                // last-phase registers
         if (NPH == 2)
         {
-            // phase 1 = last: group g has klow = ci = t + T*g (< R), elements e <-> hp = e, row = rev4(hp)
+            // phase 1 = last: group g has klow = ci = t + T*g (< R), element e <-> hp = e, n_low = rev4(hp)
+            const float2 *Xr = X + wsub * R;
 #pragma unroll
             for (int g = 0; g < NGL; g++)
 #pragma unroll
-                for (int e = 0; e < GL; e++) vl[g][e] = X[rev4(e, LOG2N - B1) * (R + 1) + (t + T * g)];
+                for (int e = 0; e < GL; e++) vl[g][e] = Xr[C::x0off(rev4(e, LOG2N - B1)) + (t + T * g)];
         }
         else
         {
             // phase 1 (middle): bits [B1, B2); ci = t + T*g; klow = ci mod R; high = ci >> B1
-            constexpr int G1 = 1 << (B2 - B1);
+            constexpr int G1 = C::G1;
             constexpr int NG1 = P / G1;
             constexpr int HB = LOG2N - B2;                 // bits of `high`
             float2 v1[NG1][G1];
+            const float2 *Xr = X + wsub * R;
 #pragma unroll
             for (int g = 0; g < NG1; g++)
             {
                 const int ci = t + T * g;
                 const int klow = ci & (R - 1), high = ci >> B1;
-                // hp = e + G1*high; row = rev4(hp) = rev4(e) << HB | rev4(high)
                 const int rhigh = rev4(high, HB);
+                // hp = e + G1*high; n_low = rev4(hp) = rev4(e) << HB | rev4(high)
 #pragma unroll
-                for (int e = 0; e < G1; e++) v1[g][e] = X[((rev4(e, B2 - B1) << HB) | rhigh) * (R + 1) + klow];
+                for (int e = 0; e < G1; e++) v1[g][e] = Xr[C::x0off((rev4(e, B2 - B1) << HB) | rhigh) + klow];
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int g = 0; g < NG1; g++) runPhase<LOG2N, B1, B2, false>(v1[g], (t + T * g) & (R - 1), sTw, nullptr);
-            // exchange 1: rows = ci (writer order), G1 (+1) columns
+            // exchange 1: element (rl, rh, col) of this window at rh*X1 + col*R + rl
+            float2 *X1w = X + wsub * (GL * C::X1);
 #pragma unroll
             for (int g = 0; g < NG1; g++)
-#pragma unroll
-                for (int e = 0; e < G1; e++) X[(t + T * g) * (G1 + 1) + e] = v1[g][e];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // phase 2 = last: ci' = t + T*g < 2^B2; element e2 <-> writer row (ci' mod R) + R*e2, column ci' >> B1
-#pragma unroll
-            for (int g = 0; g < NGL; g++)
             {
                 const int ci = t + T * g;
+                float2 *base = X1w + (ci >> B1) * C::X1 + (ci & (R - 1));
 #pragma unroll
-                for (int e = 0; e < GL; e++) vl[g][e] = X[((ci & (R - 1)) + R * e) * (G1 + 1) + (ci >> B1)];
+                for (int e = 0; e < G1; e++) base[e * R] = v1[g][e];
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // phase 2 = last: ci' = t + T*g = col*R + rl, element e2 = rh
+#pragma unroll
+            for (int g = 0; g < NGL; g++)
+#pragma unroll
+                for (int e = 0; e < GL; e++) vl[g][e] = X1w[e * C::X1 + (t + T * g)];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int g = 0; g < NGL; g++) runPhase<LOG2N, BL, LOG2N, true>(vl[g], 0, nullptr, twR[g]);
+        for (int g = 0; g < NGL; g++)
+        {
+            if (C::TW_ALL_LDS) runPhase<LOG2N, BL, LOG2N, false>(vl[g], t + T * g, sTw, nullptr);
+            else runPhase<LOG2N, BL, LOG2N, true>(vl[g], 0, nullptr, twR[C::TW_ALL_LDS ? 0 : g]);
+        }
 
         // ---- scan (LoRaDetector.hpp:36-48): bin = ci + 2^BL * e, ascending in (e, g) -----------
         float bestV = 0.0f;
@@ -413,7 +509,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             {
                 const float2 bin = vl[g][e];
                 const int i = (t + T * g) + (e << BL);
-                if (a.fftOut && active) a.fftOut[(size_t)w * N + i] = bin;
+                if (DBG && a.fftOut && active) a.fftOut[(size_t)w * N + i] = bin;
                 const float mag2 = bin.x * bin.x + bin.y * bin.y;
                 tot += (double)mag2;
                 if (mag2 > bestV) { bestV = mag2; bestI = i; }
@@ -436,12 +532,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         const int cil = bl & ((1 << BL) - 1), cir = br & ((1 << BL) - 1);
         const bool ownL = (cil & (T - 1)) == t;
         const int req = ownL ? ((bl >> BL) * NGL + (cil >> LOG2T)) : ((br >> BL) * NGL + (cir >> LOG2T));
-        float2 flat[P];
-#pragma unroll
-        for (int e = 0; e < GL; e++)
-#pragma unroll
-            for (int g = 0; g < NGL; g++) flat[e * NGL + g] = vl[g][e];
-        const float2 mine = selectReg<P>(flat, req);
+        const float2 mine = selectReg<NGL, GL>(vl, req);
         const int base = lane & ~(T - 1);
         const float2 leftBin = make_float2(__shfl(mine.x, base + (cil & (T - 1)), 64), __shfl(mine.y, base + (cil & (T - 1)), 64));
         const float2 rightBin = make_float2(__shfl(mine.x, base + (cir & (T - 1)), 64), __shfl(mine.y, base + (cir & (T - 1)), 64));
@@ -457,10 +548,8 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         __builtin_amdgcn_wave_barrier();
         if (pending == 64)
         {
-            const int sl = lane;
-            const unsigned ww = tr.w[sl];
-            // slots of inactive windows were never written this round: mark by w >= nWindows
-            if (ww < a.nWindows) detectTail(a, ww, tr.idx[sl], tr.val[sl], tr.tot[sl], tr.l[sl], tr.r[sl]);
+            const unsigned ww = tr.w[lane];
+            if (ww < a.nWindows) detectTail(a, ww, tr.idx[lane], tr.val[lane], tr.tot[lane], tr.l[lane], tr.r[lane]);
             pending = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -481,16 +570,23 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
  * launch
  **********************************************************************/
 template <class C>
-static hipError_t launchCfg(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
+static size_t smemBytes()
 {
     constexpr int WAVES = 4;
-    constexpr int WS = C::exchElems() + 4;
-    const size_t smem = size_t((C::TW_LDS + 1) & ~1) * sizeof(float2) + size_t(WAVES) * C::WPW * WS * sizeof(float2)
-                      + size_t(WAVES) * (64 * (4 + 4 + 4 + 8 + 8 + 8));
+    constexpr int XE = (C::X0ELEMS > C::X1ELEMS ? C::X0ELEMS : C::X1ELEMS);
+    constexpr int XW = (XE * 2 > C::WPW * C::N ? XE : (C::WPW * C::N + 1) / 2) + 2;
+    return size_t(((C::TW_LDS + 1) & ~1) + C::CH_ELEMS) * sizeof(float2) + size_t(WAVES) * XW * sizeof(float2) + size_t(WAVES) * sizeof(TailRec);
+}
+
+template <class C, bool DBG, bool UNI>
+static hipError_t launchOne(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
+{
+    constexpr int WAVES = 4;
+    const size_t smem = smemBytes<C>();
     static bool attrSet = false;
     if (!attrSet)
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(detectFast<C>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(detectFast<C, DBG, UNI>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
         if (e != hipSuccess) return e;
         attrSet = true;
@@ -501,24 +597,43 @@ static hipError_t launchCfg(const DetectArgs &a, const FastTables &ft, hipStream
     unsigned grid = (nSets + WAVES - 1) / WAVES;
     if (grid > resident) grid = resident;
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(detectFast<C>, dim3(grid), dim3(WAVES * 64), smem, stream, a, ft, nSets);
+    hipLaunchKernelGGL((detectFast<C, DBG, UNI>), dim3(grid), dim3(WAVES * 64), smem, stream, a, ft, nSets);
     return hipGetLastError();
 }
 
-//                LOG2N T   VEC NPH PB1 PB2 waves/SIMD
-typedef FastCfg<7,  3,  2,  2,  3,  7,  2> Cfg7;      // 8 lanes x 16 points : [R2,4] X [4,4]
-typedef FastCfg<8,  3,  2,  2,  4,  8,  2> Cfg8;      // 8 lanes x 32 points : [4,4] X [4,4]
-typedef FastCfg<9,  5,  2,  3,  3,  7,  2> Cfg9;      // 32 lanes x 16 points: [R2,4] X [4,4] X [4]
-typedef FastCfg<10, 5,  2,  3,  4,  8,  2> Cfg10;     // 32 lanes x 32 points: [4,4] X [4,4] X [4]
+template <class C>
+static hipError_t launchCfg(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
+{
+    const bool uni = a.chirpSel == nullptr && a.fineErr == nullptr;
+    if (a.decOut || a.fftOut) return launchOne<C, true, false>(a, ft, stream);
+    return uni ? launchOne<C, false, true>(a, ft, stream) : launchOne<C, false, false>(a, ft, stream);
+}
+
+//              LOG2N T VEC NPH PB1 PB2 w/SIMD  X0: ROT PAD S  D   chLDS twLDS prefetch
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  false> Cfg7a;   // 8 lanes x 16 pts: [R2,4] X [4,4]
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  true>  Cfg7b;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  true,  true,  true>  Cfg7c;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  4,          1,  1,  0, 0,  true,  true,  false> Cfg7d;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  false, false, true>  Cfg7e;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg8;    // 16 lanes x 16 pts: [4,4] X [4,4]
+typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  true>  Cfg9;    // 32 lanes x 16 pts: [R2,4] X [4,4] X [4]
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg10;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
 
 bool fastAvailable(const int sf) { return sf >= 7 && sf <= 10; }
 
 hipError_t launchFast(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
-    (void)variant;
     switch (sf)
     {
-    case 7: return launchCfg<Cfg7>(a, ft, stream);
+    case 7:
+        switch (variant)
+        {
+        case 2: return launchCfg<Cfg7a>(a, ft, stream);
+        case 3: return launchCfg<Cfg7c>(a, ft, stream);
+        case 4: return launchCfg<Cfg7d>(a, ft, stream);
+        case 5: return launchCfg<Cfg7e>(a, ft, stream);
+        default: return launchCfg<Cfg7b>(a, ft, stream);
+        }
     case 8: return launchCfg<Cfg8>(a, ft, stream);
     case 9: return launchCfg<Cfg9>(a, ft, stream);
     case 10: return launchCfg<Cfg10>(a, ft, stream);

@@ -61,6 +61,8 @@ hipError_t launchFast(int sf, int variant, const DetectArgs &a, const FastTables
 hipError_t launchSynth(int sf, float2 *iq, const unsigned short *sym, size_t nWindows,
                        float ampl, float sigma, unsigned long long seed, hipStream_t stream);
 
+hipError_t launchMembw(const float2 *iq, size_t nBytes, int pattern, int blocks, float *scratch, hipStream_t stream);
+
 void setLastError(const std::string &s);
 int hipFail(hipError_t e, const char *what);
 

@@ -1,0 +1,132 @@
+"""LDS bank-conflict model for the exchange layouts of lorahip_fast.hip (MI355X_MICROARCH.md §LDS).
+
+ds_write_b64: contiguous 16-lane groups, bank = (addr/4) % 32;  ds_read_b64: two 32-lane groups,
+bank = (addr/4) % 64. Cost of one wave-instruction = sum over groups of the largest number of DISTINCT
+8-byte words that map onto one bank pair. Usage: python tools/lds_conflicts.py
+"""
+import itertools
+
+
+def rev4(x, bits):
+    r = 0
+    for _ in range(0, bits, 2):
+        r = (r << 2) | (x & 3)
+        x >>= 2
+    return r
+
+
+def cost(addrs, kind):
+    """addrs: list of 64 byte addresses (8-byte accesses)"""
+    if kind == "w":
+        groups, nb = [range(g * 16, g * 16 + 16) for g in range(4)], 32
+    else:
+        groups, nb = [range(0, 32), range(32, 64)], 64
+    tot = 0
+    for g in groups:
+        per = {}
+        for l in g:
+            a = addrs[l]
+            for b in ((a // 4) % nb, (a // 4 + 1) % nb):
+                per.setdefault(b, set()).add(a // 8)
+        tot += max(len(v) for v in per.values())
+    return tot, len(groups)
+
+
+def exch0(LOG2N, LOG2T, VEC, B1, B2, rowmap, rowlen_pad=1, verbose=False):
+    """exchange 0 of a config; rowmap(t,u)->row. layout [row][ws][col]"""
+    N, T = 1 << LOG2N, 1 << LOG2T
+    R = 1 << B1
+    WPW = 64 // T
+    rowlen = WPW * R + rowlen_pad
+    wr = []
+    for u in range(VEC):
+        for e in range(R):
+            addrs = [8 * (rowmap(l % T, u) * rowlen + (l // T) * R + e) for l in range(64)]
+            wr.append(cost(addrs, "w"))
+    rd = []
+    GL = 1 << (B2 - B1)
+    HB = LOG2N - B2
+    P = N // T
+    NG1 = P // GL
+    for g in range(NG1):
+        for e in range(GL):
+            addrs = []
+            for l in range(64):
+                t, ws = l % T, l // T
+                ci = t + T * g
+                klow, high = ci & (R - 1), ci >> B1
+                nlow = (rev4(e, B2 - B1) << HB) | rev4(high, HB)
+                tt, uu = (nlow // VEC, nlow % VEC)
+                addrs.append(8 * (rowmap(tt, uu) * rowlen + ws * R + klow))
+            rd.append(cost(addrs, "r"))
+    w = sum(c for c, _ in wr) / sum(n for _, n in wr)
+    r = sum(c for c, _ in rd) / sum(n for _, n in rd)
+    return w, r
+
+
+if __name__ == "__main__":
+    cfgs = {"sf7": (7, 3, 2, 3, 7), "sf8": (8, 3, 2, 4, 8), "sf9": (9, 5, 2, 3, 7), "sf10": (10, 5, 2, 4, 8)}
+    for name, (n, t, vec, b1, b2) in cfgs.items():
+        T = 1 << t
+        for rm_name, rm in (("n_low", lambda tt, uu: vec * tt + uu), ("u-major", lambda tt, uu: tt + T * uu),
+                            ("u-major+1", lambda tt, uu: tt + (T + 1) * uu)):
+            for pad in (0, 1, 2, 3):
+                w, r = exch0(n, t, vec, b1, b2, rm, pad)
+                print("%-5s rows=%-10s pad=%d  write x%.2f  read x%.2f" % (name, rm_name, pad, w, r))
+
+
+def exch0_general(LOG2N, LOG2T, VEC, B1, B2, off, wsstride):
+    """off(n_low) -> element offset of the row start; element addr = off + ws*wsstride + col"""
+    N, T = 1 << LOG2N, 1 << LOG2T
+    R = 1 << B1
+    wr = []
+    for u in range(VEC):
+        for e in range(R):
+            addrs = [8 * (off(VEC * (l % T) + u) + (l // T) * wsstride + e) for l in range(64)]
+            wr.append(cost(addrs, "w"))
+    rd = []
+    GL = 1 << (B2 - B1)
+    HB = LOG2N - B2
+    NG1 = (N // T) // GL
+    for g in range(NG1):
+        for e in range(GL):
+            addrs = []
+            for l in range(64):
+                t, ws = l % T, l // T
+                ci = t + T * g
+                klow, high = ci & (R - 1), ci >> B1
+                nlow = (rev4(e, B2 - B1) << HB) | rev4(high, HB)
+                addrs.append(8 * (off(nlow) + ws * wsstride + klow))
+            rd.append(cost(addrs, "r"))
+    return (sum(c for c, _ in wr) / sum(n for _, n in wr), sum(c for c, _ in rd) / sum(n for _, n in rd))
+
+
+def search(name, n, t, vec, b1, b2):
+    T, R = 1 << t, 1 << b1
+    WPW = 64 // T
+    NL = vec * T
+    best = []
+    # off(n_low) = perm(n_low) * RS where perm swaps/rotates bit fields, RS = WPW*R + pad; ws stride R
+    import itertools
+    nb = NL.bit_length() - 1
+    for rot in range(nb):
+        for pad in range(0, 9):
+            for extra_s in range(nb):
+                for extra_d in (0, 1, 2, 4, 8, 16, 32):
+                    RS = WPW * R + pad
+
+                    def off(x, rot=rot, RS=RS, extra_s=extra_s, extra_d=extra_d):
+                        p = ((x >> rot) | (x << (nb - rot))) & (NL - 1)
+                        return p * RS + ((x >> extra_s) & 1) * extra_d
+                    w, r = exch0_general(n, t, vec, b1, b2, off, R)
+                    size = NL * RS + 64
+                    best.append((w + r, w, r, rot, pad, extra_s, extra_d, size))
+    best.sort()
+    print(name, "best (sum, w, r, rot, pad, extra_s, extra_d, size):")
+    for b in best[:5]:
+        print("   ", b)
+
+
+if __name__ == "__main__":
+    for name, c in {"sf7": (7, 3, 2, 3, 7), "sf8": (8, 3, 2, 4, 8), "sf9": (9, 5, 2, 3, 7), "sf10": (10, 5, 2, 4, 8)}.items():
+        search(name, *c)
