@@ -65,6 +65,73 @@ __device__ __forceinline__ void bfly2unit(float2 &f0, float2 &f1)
 }
 
 /***********************************************************************
+ * Packed-pair forms for the tuned kernels. A complex value is one 64-bit VGPR pair and every
+ * operation below is the SAME IEEE multiply / add as the scalar form above, two at a time:
+ * v_pk_mul_f32 / v_pk_add_f32 round each half exactly like v_mul_f32 / v_add_f32, op_sel picks
+ * which half of a source feeds which half of the result and neg_lo/neg_hi flip a sign (exact),
+ * so no fused operation and no re-association enters. hipcc does not find the half-negated add
+ * or the rotate-by(-j) forms on its own (it falls back to v_mov shuffles), hence the asm.
+ **********************************************************************/
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+//! (a.x*b.x - a.y*b.y, a.y*b.x + a.x*b.y): 3 instructions
+__device__ __forceinline__ v2f cmulv(const v2f a, const v2f b)
+{
+    v2f p, q, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));   // (a.x*b.x, a.y*b.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(q) : "v"(a), "v"(b));   // (a.y*b.y, a.x*b.y)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));                   // (p.x-q.x, p.y+q.y)
+    return r;
+}
+//! same with b conjugated: a * (b.x, -b.y) -- the up-chirp table is conj(down-chirp table)
+__device__ __forceinline__ v2f cmulConjv(const v2f a, const v2f b)
+{
+    v2f p, q, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));   // (a.x*b.x, a.y*b.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(q) : "v"(a), "v"(b));   // (a.y*b.y, a.x*b.y)
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(p), "v"(q));                   // (p.x+q.x, p.y-q.y)
+    return r;
+}
+//! s5 + (s4.y, -s4.x)  and  s5 - (s4.y, -s4.x): kissfft.hh:150,153-154 without materialising the rotation
+__device__ __forceinline__ v2f addRotv(const v2f s5, const v2f s4)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(s5), "v"(s4));
+    return r;
+}
+__device__ __forceinline__ v2f subRotv(const v2f s5, const v2f s4)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(s5), "v"(s4));
+    return r;
+}
+
+//! kf_bfly4 for one k (kissfft.hh:143-155), forward; s0..s2 are the three twiddled inputs
+__device__ __forceinline__ void bfly4corev(v2f &f0, v2f &f1, v2f &f2, v2f &f3, const v2f s0, const v2f s1, const v2f s2)
+{
+    const v2f s5 = f0 - s1;
+    f0 = f0 + s1;
+    const v2f s3 = s0 + s2;
+    const v2f s4 = s0 - s2;
+    f2 = f0 - s3;
+    f0 = f0 + s3;
+    f1 = addRotv(s5, s4);
+    f3 = subRotv(s5, s4);
+}
+__device__ __forceinline__ void bfly4v(v2f &f0, v2f &f1, v2f &f2, v2f &f3, const v2f t1, const v2f t2, const v2f t3)
+{
+    bfly4corev(f0, f1, f2, f3, cmulv(f1, t1), cmulv(f2, t2), cmulv(f3, t3));
+}
+__device__ __forceinline__ void bfly4unitv(v2f &f0, v2f &f1, v2f &f2, v2f &f3) { bfly4corev(f0, f1, f2, f3, f1, f2, f3); }
+__device__ __forceinline__ void bfly2unitv(v2f &f0, v2f &f1)
+{
+    const v2f v = f1;
+    f1 = f0 - v;
+    f0 = f0 + v;
+}
+
+/***********************************************************************
  * kissfft's plan for N = 2^LOG2N as compile-time constants.
  * Stage s (0 = outermost) has radix p_s and remainder m_s; input digit q_s has weight
  * fstride_s = p_0..p_{s-1} in the sample index n and weight m_s in the work-array position
@@ -107,9 +174,10 @@ __device__ __forceinline__ void argmaxCombine(float &v, int &i, const float ov, 
 /***********************************************************************
  * detect() tail for one window, executed by one lane (LoRaDetector.hpp:50-61)
  **********************************************************************/
+template <class CPX>
 __device__ __forceinline__ void detectTail(const DetectArgs &a, const unsigned w, const int maxIndex,
                                            const float maxValue, const double total,
-                                           const float2 leftBin, const float2 rightBin)
+                                           const CPX leftBin, const CPX rightBin)
 {
     const float noise = sqrtf((float)(total - (double)maxValue));
     const float fundamental = sqrtf(maxValue);

@@ -115,8 +115,8 @@ __host__ __device__ constexpr int rev4(int x, const int bits)
  *   klow : position bits below LO of this group (0 in phase 0)
  **********************************************************************/
 template <int LOG2N, int LO, int HI, bool LAST>
-__device__ __forceinline__ void runPhase(float2 (&v)[1 << (HI - LO)], const int klow,
-                                         const float2 *__restrict__ TWL, const float2 *twR)
+__device__ __forceinline__ void runPhase(v2f (&v)[1 << (HI - LO)], const int klow,
+                                         const v2f *__restrict__ TWL, const v2f *twR)
 {
     constexpr int G = 1 << (HI - LO);
     constexpr bool R2 = (LO == 0) && (LOG2N & 1);
@@ -124,7 +124,7 @@ __device__ __forceinline__ void runPhase(float2 (&v)[1 << (HI - LO)], const int 
     {
         // innermost radix-2 stage, m = 1: twiddle(0) = (1,0)
 #pragma unroll
-        for (int i = 0; i < G / 2; i++) bfly2unit(v[2 * i], v[2 * i + 1]);
+        for (int i = 0; i < G / 2; i++) bfly2unitv(v[2 * i], v[2 * i + 1]);
     }
     int slot = 0;
 #pragma unroll
@@ -135,7 +135,7 @@ __device__ __forceinline__ void runPhase(float2 (&v)[1 << (HI - LO)], const int 
 #pragma unroll
         for (int kl = 0; kl < nkl; kl++)
         {
-            float2 t1, t2, t3;
+            v2f t1, t2, t3;
             const bool unit = (LO == 0) && (kl == 0);
             if (!unit)
             {
@@ -155,14 +155,14 @@ __device__ __forceinline__ void runPhase(float2 (&v)[1 << (HI - LO)], const int 
             for (int hi = 0; hi < (G >> (sh + 2)); hi++)
             {
                 const int e0 = kl + (hi << (sh + 2));
-                if (unit) bfly4unit(v[e0], v[e0 + nkl], v[e0 + 2 * nkl], v[e0 + 3 * nkl]);
-                else bfly4(v[e0], v[e0 + nkl], v[e0 + 2 * nkl], v[e0 + 3 * nkl], t1, t2, t3);
+                if (unit) bfly4unitv(v[e0], v[e0 + nkl], v[e0 + 2 * nkl], v[e0 + 3 * nkl]);
+                else bfly4v(v[e0], v[e0 + nkl], v[e0 + 2 * nkl], v[e0 + 3 * nkl], t1, t2, t3);
             }
         }
     }
 }
 
-//! number of register twiddles (float2) of the last phase for one group
+//! number of register twiddles (v2f) of the last phase for one group
 template <int LOG2N, int LO, int HI>
 __host__ __device__ constexpr int lastPhaseSlots()
 {
@@ -173,16 +173,16 @@ __host__ __device__ constexpr int lastPhaseSlots()
 
 //! select element (e, g) with flat index idx = e*NG + g out of v[g][e] for a runtime idx: cndmask tree
 template <int NG, int G>
-__device__ __forceinline__ float2 selectReg(const float2 (&v)[NG][G], const int idx)
+__device__ __forceinline__ v2f selectReg(const v2f (&v)[NG][G], const int idx)
 {
     constexpr int CNT = NG * G;
-    float2 cur[CNT / 2];
+    v2f cur[CNT / 2];
     {
         const bool hi = idx & 1;
 #pragma unroll
         for (int i = 0; i < CNT / 2; i++)
         {
-            const float2 lo2 = v[(2 * i) % NG][(2 * i) / NG], hi2 = v[(2 * i + 1) % NG][(2 * i + 1) / NG];
+            const v2f lo2 = v[(2 * i) % NG][(2 * i) / NG], hi2 = v[(2 * i + 1) % NG][(2 * i + 1) / NG];
             cur[i].x = hi ? hi2.x : lo2.x;
             cur[i].y = hi ? hi2.y : lo2.y;
         }
@@ -201,7 +201,9 @@ __device__ __forceinline__ float2 selectReg(const float2 (&v)[NG][G], const int 
     return cur[0];
 }
 
-struct TailRec { unsigned w[64]; int idx[64]; float val[64]; double tot[64]; float2 l[64]; float2 r[64]; };
+#define MAKE2(X, Y) (v2f{(X), (Y)})
+
+struct TailRec { unsigned w[64]; int idx[64]; float val[64]; double tot[64]; v2f l[64]; v2f r[64]; };
 
 /***********************************************************************
  * the kernel: one wave = WPW windows per iteration, persistent over window sets.
@@ -221,29 +223,33 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     constexpr int NGL = P / GL;                           // last-phase groups per lane
     constexpr int SLOTS = lastPhaseSlots<LOG2N, BL, LOG2N>();
     constexpr int XE = (C::X0ELEMS > C::X1ELEMS ? C::X0ELEMS : C::X1ELEMS);
-    constexpr int XW = (XE * 2 > WPW * N ? XE : (WPW * N + 1) / 2) + 2;   // float2 per wave; also holds WPW*N ints
+    constexpr int XW = (XE * 2 > WPW * N ? XE : (WPW * N + 1) / 2) + 2;   // v2f per wave; also holds WPW*N ints
     constexpr int M = N * LORAHIP_FINE_STEPS;
     constexpr int WAVES = 4;
 
     extern __shared__ __attribute__((aligned(16))) char smemRaw[];
-    float2 *sTw = reinterpret_cast<float2 *>(smemRaw);                                   // [TW_LDS]
-    float2 *sCh = sTw + ((C::TW_LDS + 1) & ~1);                                          // [CH_ELEMS]
-    float2 *sX = sCh + C::CH_ELEMS;                                                      // [WAVES][XW]
+    v2f *sTw = reinterpret_cast<v2f *>(smemRaw);                                   // [TW_LDS]
+    v2f *sCh = sTw + ((C::TW_LDS + 1) & ~1);                                          // [CH_ELEMS]
+    v2f *sX = sCh + C::CH_ELEMS;                                                      // [WAVES][XW]
     TailRec *sTail = reinterpret_cast<TailRec *>(sX + WAVES * XW);                       // [WAVES]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int wsub = lane >> LOG2T;                       // window inside the wave iteration
     const int t = lane & (T - 1);
-    float2 *X = sX + wave * XW;                           // this wave's exchange region
+    v2f *X = sX + wave * XW;                           // this wave's exchange region
     TailRec &tr = sTail[wave];
+
+    const v2f *gIq = reinterpret_cast<const v2f *>(a.iq), *gDown = reinterpret_cast<const v2f *>(a.down);
+    const v2f *gFine = reinterpret_cast<const v2f *>(a.fine);
+    v2f *gDec = reinterpret_cast<v2f *>(a.decOut), *gFft = reinterpret_cast<v2f *>(a.fftOut);
 
     // ---- one-time set-up -------------------------------------------------------------
     tr.w[lane] = 0xffffffffu;                             // empty tail slots
-    for (int i = threadIdx.x; i < C::TW_LDS; i += blockDim.x) sTw[i] = ft.twStage[i];
+    for (int i = threadIdx.x; i < C::TW_LDS; i += blockDim.x) sTw[i] = reinterpret_cast<const v2f *>(ft.twStage)[i];
 
     // register twiddles of the last phase: in the last phase klow = ci = t + T*g
-    float2 twR[C::TW_ALL_LDS ? 1 : NGL][C::TW_ALL_LDS ? 1 : SLOTS];
+    v2f twR[C::TW_ALL_LDS ? 1 : NGL][C::TW_ALL_LDS ? 1 : SLOTS];
 #pragma unroll
     for (int g = 0; g < (C::TW_ALL_LDS ? 0 : NGL); g++)
     {
@@ -256,9 +262,9 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             {
                 const int k = ci + (kl << BL);
                 const int base = twStageOffset(LOG2N, b) + k;
-                twR[g][slot] = ft.twStage[base];
-                twR[g][slot + 1] = ft.twStage[base + (1 << b)];
-                twR[g][slot + 2] = ft.twStage[base + (2 << b)];
+                twR[g][slot] = reinterpret_cast<const v2f *>(ft.twStage)[base];
+                twR[g][slot + 1] = reinterpret_cast<const v2f *>(ft.twStage)[base + (1 << b)];
+                twR[g][slot + 2] = reinterpret_cast<const v2f *>(ft.twStage)[base + (2 << b)];
                 slot += 3;
             }
     }
@@ -267,13 +273,13 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     // _upChirpTable = conj(_downChirpTable) entry by entry (LoRaDemod.cpp:103-104)
     const bool perWindowSel = !UNI && a.chirpSel != nullptr;
     const float s0 = (!perWindowSel && a.chirpSelAll == LORAHIP_CHIRP_UP) ? -1.0f : 1.0f;
-    float2 ch[C::CH_LDS ? 1 : R][C::CH_LDS ? 1 : VEC];
+    v2f ch[C::CH_LDS ? 1 : R][C::CH_LDS ? 1 : VEC];
     if (C::CH_LDS)
     {
         for (int i = threadIdx.x; i < N; i += blockDim.x)
         {
-            const float2 c = a.down[i];
-            sCh[i] = make_float2(c.x, s0 * c.y);
+            const v2f c = gDown[i];
+            sCh[i] = MAKE2(c.x, s0 * c.y);
         }
     }
     else
@@ -283,8 +289,8 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 #pragma unroll
             for (int u = 0; u < VEC; u++)
             {
-                const float2 c = a.down[VEC * t + u + VEC * T * r];
-                ch[r][u] = make_float2(c.x, s0 * c.y);
+                const v2f c = gDown[VEC * t + u + VEC * T * r];
+                ch[r][u] = MAKE2(c.x, s0 * c.y);
             }
     }
     __syncthreads();
@@ -294,27 +300,27 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     int pending = 0;                                       // tail records waiting in tr
 
     // coalesced window load: VEC*8 bytes per lane, the T lanes of a window contiguous, R rows
-    float2 xn[R][VEC];
+    v2f xn[R][VEC];
     auto issueLoads = [&](const unsigned set_)
     {
         const unsigned w_ = set_ * WPW + wsub;
         const unsigned wc_ = w_ < a.nWindows ? w_ : a.nWindows - 1;
-        const float2 *in_ = a.iq + (a.offsets ? a.offsets[wc_] : (long long)wc_ * a.stride);
+        const v2f *in_ = gIq + (a.offsets ? a.offsets[wc_] : (long long)wc_ * a.stride);
 #pragma unroll
         for (int r = 0; r < R; r++)
         {
-            const float2 *p = in_ + VEC * t + VEC * T * r;
+            const v2f *p = in_ + VEC * t + VEC * T * r;
             if (VEC == 2)
             {
-                const float4 q = *reinterpret_cast<const float4 *>(p);
-                xn[r][0] = make_float2(q.x, q.y);
-                xn[r][VEC - 1] = make_float2(q.z, q.w);
+                const v4f q = *reinterpret_cast<const v4f *>(p);
+                xn[r][0] = MAKE2(q.x, q.y);
+                xn[r][VEC - 1] = MAKE2(q.z, q.w);
             }
             else xn[r][0] = *p;
         }
     };
     if (C::PREFETCH && waveId < nSets) issueLoads(waveId);
-    const float2 fconst0 = a.fine[0];
+    const v2f fconst0 = gFine[0];
 
     for (unsigned set = waveId; set < nSets; set += waveCount)
     {
@@ -330,7 +336,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         const bool anyMoving = !UNI && __any(moving);
 
         // ---- samples of this set: loaded here, or already in flight since the previous iteration ---
-        float2 x[R][VEC];
+        v2f x[R][VEC];
         if (!C::PREFETCH) issueLoads(set);
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -354,19 +360,19 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 
         // ---- dechirp: (samp * chirp) * fine   (LoRaDemod.cpp:159) ---------------------------
         // fine-tune entry of this window: constant over the launch when no per-window index is given
-        const float2 fconst = a.fineIdx0 ? a.fine[idx0] : fconst0;
-        float2 cw[R][VEC];                                 // chirp values of this lane's samples
+        const v2f fconst = a.fineIdx0 ? gFine[idx0] : fconst0;
+        v2f cw[R][VEC];                                 // chirp values of this lane's samples
 #pragma unroll
         for (int r = 0; r < R; r++)
         {
             if (C::CH_LDS)
             {
-                const float2 *p = sCh + VEC * t + VEC * T * r;
+                const v2f *p = sCh + VEC * t + VEC * T * r;
                 if (VEC == 2)
                 {
-                    const float4 q = *reinterpret_cast<const float4 *>(p);
-                    cw[r][0] = make_float2(q.x, q.y);
-                    cw[r][VEC - 1] = make_float2(q.z, q.w);
+                    const v4f q = *reinterpret_cast<const v4f *>(p);
+                    cw[r][0] = MAKE2(q.x, q.y);
+                    cw[r][VEC - 1] = MAKE2(q.z, q.w);
                 }
                 else cw[r][0] = *p;
             }
@@ -384,7 +390,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 #pragma unroll
                 for (int r = 0; r < R; r++)
 #pragma unroll
-                    for (int u = 0; u < VEC; u++) x[r][u] = cmul(cmul(x[r][u], cw[r][u]), fconst);
+                    for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulv(x[r][u], cw[r][u]), fconst);
             }
         }
         else
@@ -395,10 +401,10 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 #pragma unroll
                 for (int u = 0; u < VEC; u++)
                 {
-                    const float2 c = make_float2(cw[r][u].x, sgn * cw[r][u].y);
-                    float2 f = fconst;
-                    if (anyMoving && moving) f = a.fine[sIdx[VEC * t + u + VEC * T * r]];
-                    const float2 y = cmul(cmul(x[r][u], c), f);
+                    const v2f c = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
+                    v2f f = fconst;
+                    if (anyMoving && moving) f = gFine[sIdx[VEC * t + u + VEC * T * r]];
+                    const v2f y = cmulv(cmulv(x[r][u], c), f);
                     x[r][u] = dechirp ? y : x[r][u];
                 }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -409,12 +415,12 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 #pragma unroll
             for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int u = 0; u < VEC; u++) a.decOut[(size_t)w * N + VEC * t + u + VEC * T * r] = x[r][u];
+                for (int u = 0; u < VEC; u++) gDec[(size_t)w * N + VEC * t + u + VEC * T * r] = x[r][u];
         }
 
         // ---- phase 0: bits [0, B1) in registers, one group per u -----------------------------
         // register r holds sample index high part a = r; its work-array position low bits are rev(a)
-        float2 v0[VEC][R];
+        v2f v0[VEC][R];
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
@@ -427,11 +433,11 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 
         // ---- exchange 0: one row per n_low = VEC*t+u, the wave's windows side by side ----------
         {
-            float2 *Xw = X + wsub * R;
+            v2f *Xw = X + wsub * R;
 #pragma unroll
             for (int u = 0; u < VEC; u++)
             {
-                float2 *row = Xw + C::x0off(VEC * t + u);
+                v2f *row = Xw + C::x0off(VEC * t + u);
 #pragma unroll
                 for (int e = 0; e < R; e++) row[e] = v0[u][e];
             }
@@ -439,11 +445,11 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        float2 vl[NGL][GL];                                // last-phase registers
+        v2f vl[NGL][GL];                                // last-phase registers
         if (NPH == 2)
         {
             // phase 1 = last: group g has klow = ci = t + T*g (< R), element e <-> hp = e, n_low = rev4(hp)
-            const float2 *Xr = X + wsub * R;
+            const v2f *Xr = X + wsub * R;
 #pragma unroll
             for (int g = 0; g < NGL; g++)
 #pragma unroll
@@ -455,8 +461,8 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             constexpr int G1 = C::G1;
             constexpr int NG1 = P / G1;
             constexpr int HB = LOG2N - B2;                 // bits of `high`
-            float2 v1[NG1][G1];
-            const float2 *Xr = X + wsub * R;
+            v2f v1[NG1][G1];
+            const v2f *Xr = X + wsub * R;
 #pragma unroll
             for (int g = 0; g < NG1; g++)
             {
@@ -472,12 +478,12 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 #pragma unroll
             for (int g = 0; g < NG1; g++) runPhase<LOG2N, B1, B2, false>(v1[g], (t + T * g) & (R - 1), sTw, nullptr);
             // exchange 1: element (rl, rh, col) of this window at rh*X1 + col*R + rl
-            float2 *X1w = X + wsub * (GL * C::X1);
+            v2f *X1w = X + wsub * (GL * C::X1);
 #pragma unroll
             for (int g = 0; g < NG1; g++)
             {
                 const int ci = t + T * g;
-                float2 *base = X1w + (ci >> B1) * C::X1 + (ci & (R - 1));
+                v2f *base = X1w + (ci >> B1) * C::X1 + (ci & (R - 1));
 #pragma unroll
                 for (int e = 0; e < G1; e++) base[e * R] = v1[g][e];
             }
@@ -507,9 +513,9 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 #pragma unroll
             for (int g = 0; g < NGL; g++)
             {
-                const float2 bin = vl[g][e];
+                const v2f bin = vl[g][e];
                 const int i = (t + T * g) + (e << BL);
-                if (DBG && a.fftOut && active) a.fftOut[(size_t)w * N + i] = bin;
+                if (DBG && a.fftOut && active) gFft[(size_t)w * N + i] = bin;
                 const float mag2 = bin.x * bin.x + bin.y * bin.y;
                 tot += (double)mag2;
                 if (mag2 > bestV) { bestV = mag2; bestI = i; }
@@ -532,10 +538,10 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         const int cil = bl & ((1 << BL) - 1), cir = br & ((1 << BL) - 1);
         const bool ownL = (cil & (T - 1)) == t;
         const int req = ownL ? ((bl >> BL) * NGL + (cil >> LOG2T)) : ((br >> BL) * NGL + (cir >> LOG2T));
-        const float2 mine = selectReg<NGL, GL>(vl, req);
+        const v2f mine = selectReg<NGL, GL>(vl, req);
         const int base = lane & ~(T - 1);
-        const float2 leftBin = make_float2(__shfl(mine.x, base + (cil & (T - 1)), 64), __shfl(mine.y, base + (cil & (T - 1)), 64));
-        const float2 rightBin = make_float2(__shfl(mine.x, base + (cir & (T - 1)), 64), __shfl(mine.y, base + (cir & (T - 1)), 64));
+        const v2f leftBin = MAKE2(__shfl(mine.x, base + (cil & (T - 1)), 64), __shfl(mine.y, base + (cil & (T - 1)), 64));
+        const v2f rightBin = MAKE2(__shfl(mine.x, base + (cir & (T - 1)), 64), __shfl(mine.y, base + (cir & (T - 1)), 64));
 
         // ---- defer the log/sqrt tail: one record per window, flushed 64 at a time ---------------
         if (t == 0 && active)
