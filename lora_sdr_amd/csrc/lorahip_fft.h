@@ -1,0 +1,125 @@
+// FFT building blocks shared by the tuned kernels (lorahip_fast.hip: a window inside one wavefront;
+// lorahip_wide.hip: a window across the wavefronts of a workgroup). Numerics contract: lorahip_device.h.
+#pragma once
+#include "lorahip_device.h"
+
+namespace lorahip {
+
+/***********************************************************************
+ * stage-major twiddle table: for every radix-4 stage with remainder m = 2^b,
+ * [q-1][k] = kissfft twiddle(k * (N/(4m)) * q), k < m. Same VALUES as kissfft's table,
+ * re-indexed so that lanes with consecutive k read consecutive LDS words.
+ **********************************************************************/
+__host__ __device__ constexpr int twStageOffset(const int log2n, const int b)
+{
+    int off = 0;
+    for (int bb = (log2n & 1); bb < b; bb += 2) off += 3 << bb;
+    return off;
+}
+
+//! reverse the radix-4 digits of an even-width bit string
+__host__ __device__ constexpr int rev4(int x, const int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i += 2) { r = (r << 2) | (x & 3); x >>= 2; }
+    return r;
+}
+
+/***********************************************************************
+ * one phase over one register group v[0..G): stages at bits [LO, HI)
+ *   TWL  : LDS stage-major table (stages below the last phase)
+ *   twR  : register twiddles of the last phase (slot order = stage, kl, q)
+ *   klow : position bits below LO of this group (0 in phase 0)
+ **********************************************************************/
+template <int LOG2N, int LO, int HI, bool LAST>
+__device__ __forceinline__ void runPhase(v2f (&v)[1 << (HI - LO)], const int klow,
+                                         const v2f *__restrict__ TWL, const v2f *twR)
+{
+    constexpr int G = 1 << (HI - LO);
+    constexpr bool R2 = (LO == 0) && (LOG2N & 1);
+    if (R2)
+    {
+        // innermost radix-2 stage, m = 1: twiddle(0) = (1,0)
+#pragma unroll
+        for (int i = 0; i < G / 2; i++) bfly2unitv(v[2 * i], v[2 * i + 1]);
+    }
+    int slot = 0;
+#pragma unroll
+    for (int b = LO + (R2 ? 1 : 0); b < HI; b += 2)
+    {
+        const int sh = b - LO;                       // bit position of q inside the group index
+        const int nkl = 1 << sh;                     // distinct k inside the group
+#pragma unroll
+        for (int kl = 0; kl < nkl; kl++)
+        {
+            v2f t1, t2, t3;
+            const bool unit = (LO == 0) && (kl == 0);
+            if (!unit)
+            {
+                if (LAST)
+                {
+                    t1 = twR[slot]; t2 = twR[slot + 1]; t3 = twR[slot + 2];
+                }
+                else
+                {
+                    const int k = klow + (kl << LO);
+                    const int base = twStageOffset(LOG2N, b) + k;
+                    t1 = TWL[base]; t2 = TWL[base + (1 << b)]; t3 = TWL[base + (2 << b)];
+                }
+            }
+            slot += 3;
+#pragma unroll
+            for (int hi = 0; hi < (G >> (sh + 2)); hi++)
+            {
+                const int e0 = kl + (hi << (sh + 2));
+                if (unit) bfly4unitv(v[e0], v[e0 + nkl], v[e0 + 2 * nkl], v[e0 + 3 * nkl]);
+                else bfly4v(v[e0], v[e0 + nkl], v[e0 + 2 * nkl], v[e0 + 3 * nkl], t1, t2, t3);
+            }
+        }
+    }
+}
+
+//! number of register twiddles (v2f) of the last phase for one group
+template <int LOG2N, int LO, int HI>
+__host__ __device__ constexpr int lastPhaseSlots()
+{
+    int s = 0;
+    for (int b = LO; b < HI; b += 2) s += 3 << (b - LO);
+    return s;
+}
+
+//! select element (e, g) with flat index idx = e*NG + g out of v[g][e] for a runtime idx: cndmask tree
+template <int NG, int G>
+__device__ __forceinline__ v2f selectReg(const v2f (&v)[NG][G], const int idx)
+{
+    constexpr int CNT = NG * G;
+    v2f cur[CNT / 2];
+    {
+        const bool hi = idx & 1;
+#pragma unroll
+        for (int i = 0; i < CNT / 2; i++)
+        {
+            const v2f lo2 = v[(2 * i) % NG][(2 * i) / NG], hi2 = v[(2 * i + 1) % NG][(2 * i + 1) / NG];
+            cur[i].x = hi ? hi2.x : lo2.x;
+            cur[i].y = hi ? hi2.y : lo2.y;
+        }
+    }
+#pragma unroll
+    for (int w = CNT / 4, bit = 1; w >= 1; w >>= 1, bit++)
+    {
+        const bool hi = (idx >> bit) & 1;
+#pragma unroll
+        for (int i = 0; i < w; i++)
+        {
+            cur[i].x = hi ? cur[2 * i + 1].x : cur[2 * i].x;
+            cur[i].y = hi ? cur[2 * i + 1].y : cur[2 * i].y;
+        }
+    }
+    return cur[0];
+}
+
+#define MAKE2(X, Y) (v2f{(X), (Y)})
+
+struct TailRec { unsigned w[64]; int idx[64]; float val[64]; double tot[64]; v2f l[64]; v2f r[64]; };
+
+} // namespace lorahip

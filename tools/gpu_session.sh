@@ -1,0 +1,57 @@
+#!/bin/bash
+# One gpurun call: GPU parity tests, bench per SF, rocprofv3 kernel stats and PMC passes.
+# Everything lands under gpurun_out/ (scratch); summaries worth judging are copied to profiles/.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session.sh [tests] [bench] [prof] [pmc] [membw]'
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+what="${*:-tests bench prof pmc membw}"
+export TMPDIR=/tmp
+
+if [[ $what == *tests* ]]; then
+  timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> $O/pytest_gpu.log
+  tail -5 $O/pytest_gpu.log
+fi
+
+if [[ $what == *bench* ]]; then
+  timeout 600 python bench.py > $O/bench_sf7.json 2> $O/bench_sf7.err
+  tail -c 2500 $O/bench_sf7.json
+  for sf in 8 9 10 11 12; do
+    timeout 300 python bench.py --sf $sf --steps 10 --warmup 2 --cpu-seconds 3 > $O/bench_sf$sf.json 2> $O/bench_sf$sf.err
+    python - <<EOF
+import json
+try:
+    d = json.loads(open("$O/bench_sf$sf.json").read().strip().splitlines()[-1])
+    print("SF$sf", round(d["value"], 1), "Msym/s frac", round(d["roofline"]["frac"], 3), "cpu", d.get("cpu_baseline", {}).get("value"))
+except Exception as e:
+    print("SF$sf bench failed", e)
+EOF
+  done
+fi
+
+if [[ $what == *membw* ]]; then
+  timeout 300 python tools/membw.py > $O/membw.log 2>&1
+  cat $O/membw.log
+fi
+
+if [[ $what == *prof* ]]; then
+  for sf in 7 12; do
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_sf$sf -o sf$sf --output-format csv -- \
+        python $R/bench.py --sf $sf --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_sf$sf.log 2>&1 )
+    find $O/prof_sf$sf -name '*kernel_stats.csv' | head -1 | xargs -r head -4
+  done
+fi
+
+if [[ $what == *pmc* ]]; then
+  for sf in 7 12; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && timeout 600 rocprofv3 --pmc $c -d $O/pmc_${c}_sf$sf -o pmc --output-format csv -- \
+          python $R/bench.py --sf $sf --steps 5 --warmup 1 --no-cpu-baseline > $O/pmc_${c}_sf$sf.log 2>&1 )
+    done
+  done
+  python tools/pmc_summary.py $O > $O/pmc_summary.txt 2>&1
+  cat $O/pmc_summary.txt
+fi
