@@ -58,6 +58,8 @@ std::vector<cf32> buildStageTwiddles(int sf, const std::vector<cf32> &tw);
 hipError_t launchDetect(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
 bool fastAvailable(int sf);
 hipError_t launchFast(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
+bool wideAvailable(int sf);
+hipError_t launchWide(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
 hipError_t launchSynth(int sf, float2 *iq, const unsigned short *sym, size_t nWindows,
                        float ampl, float sigma, unsigned long long seed, hipStream_t stream);
 

@@ -1,0 +1,474 @@
+// Tuned CDNA4 kernels for the long windows (SF11, SF12): one window spread over the wavefronts of a
+// 256-thread workgroup, 16 points per lane.
+//
+// Same algebra as lorahip_fast.hip (three register phases of kissfft's DIT graph, two transpositions
+// through LDS), but T = N/16 lanes per window is 128 (SF11: two windows per workgroup) or 256 (SF12: one),
+// so the exchanges are fenced with workgroup barriers and the |X|^2 arg-max / fp64 total is finished across
+// wavefronts through LDS. Barrier budget per window set: 4 (after each exchange write, and before the
+// region is overwritten by the next exchange); the cross-wave reduction shares the last one and the
+// read-back of the peak's neighbours is deferred behind the first barrier of the NEXT set, as is the
+// sqrt/log tail (queued in LDS, executed 64 windows at a time by wave 0 with all lanes busy).
+//
+//   phase 0  bits [0,B1)      lane t holds samples n = VEC*t+u + (N/R)*r, r < R = 16/VEC     (registers)
+//   exch 0   row per n_low = VEC*t+u (R elements, padded/rotated so writes and reads tile the banks)
+//   phase 1  bits [B1,B1+4)   lane t: klow = t mod R, high = t / R, element e = position bits [B1,B1+4)
+//   exch 1   natural position order, 8 elements of padding per 2^(B1+4) block
+//   phase 2  bits [B1+4,LOG2N) lane t holds bins t + T*e                                       (registers)
+#include "lorahip_fft.h"
+
+namespace lorahip {
+
+template <int LOG2N_, int VEC_, int MINW_, int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_>
+struct WideCfg
+{
+    static constexpr int LOG2N = LOG2N_, N = 1 << LOG2N_;
+    static constexpr int P = 16;                               // points per lane
+    static constexpr int LOG2T = LOG2N_ - 4, T = 1 << LOG2T;    // lanes per window
+    static constexpr int VEC = VEC_, R = P / VEC_;
+    static constexpr int B1 = (VEC_ == 1 ? 4 : 3), B2 = B1 + 4;
+    static constexpr int WPB = 256 / T;                         // windows per workgroup iteration
+    static constexpr int WPWIN = T / 64;                        // wavefronts per window
+    static constexpr int MINW = MINW_;
+    static constexpr bool CH_LDS = CH_LDS_, TW_ALL_LDS = TW_ALL_LDS_;
+    static constexpr int HB = LOG2N_ - B2;                      // = 4: position bits of the last phase
+    static constexpr int NL = VEC_ * T, LOG2NL = LOG2N_ - B1;   // rows of exchange 0
+    static_assert(B2 + 4 == LOG2N_, "VEC 1 <-> SF12, VEC 2 <-> SF11");
+    static_assert(T >= 64 && T <= 256, "a window is 1..4 wavefronts");
+    static constexpr int RS0 = R + X0PAD_;
+    __host__ __device__ static constexpr int x0off(const int nlow)
+    {
+        const int rot = ((nlow >> X0ROT_) | (nlow << (LOG2NL - X0ROT_))) & (NL - 1);
+        return rot * RS0 + ((nlow >> X0S_) & 1) * X0D_;
+    }
+    static constexpr int X0ELEMS = NL * RS0 + X0D_;
+    static constexpr int X1 = 16 * R + 8;                       // one block of `high` in exchange 1
+    static constexpr int X1ELEMS = 16 * X1;
+    static constexpr int XE = X0ELEMS > X1ELEMS ? X0ELEMS : X1ELEMS;
+    static constexpr int XW = ((XE * 2 > N ? XE : (N + 1) / 2) + 1) & ~1;   // v2f per window; also holds N ints
+    static constexpr int TW_LDS = twStageOffset(LOG2N_, TW_ALL_LDS_ ? LOG2N_ : B2);
+    static constexpr int TWN = (TW_LDS + 1) & ~1;
+    static constexpr int CH_ELEMS = CH_LDS_ ? N : 0;
+};
+
+struct RedRec { float v; int i; double tot; };
+
+template <class C>
+struct WideSmem
+{
+    static constexpr size_t bytes()
+    {
+        return size_t(C::TWN + C::CH_ELEMS + C::WPB * C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + size_t(C::WPB) * 2 * sizeof(float2) + sizeof(TailRec);
+    }
+};
+
+template <class C, bool DBG, bool UNI>
+__global__ void __launch_bounds__(256, C::MINW)
+detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
+{
+    constexpr int N = C::N, T = C::T, VEC = C::VEC, R = C::R, WPB = C::WPB, WPWIN = C::WPWIN;
+    constexpr int LOG2N = C::LOG2N, LOG2T = C::LOG2T, B1 = C::B1, B2 = C::B2, HB = C::HB;
+    constexpr int SLOTS = lastPhaseSlots<LOG2N, B2, LOG2N>();
+    constexpr int M = N * LORAHIP_FINE_STEPS;
+
+    extern __shared__ __attribute__((aligned(16))) char smemRaw[];
+    v2f *sTw = reinterpret_cast<v2f *>(smemRaw);                         // [TWN]
+    v2f *sCh = sTw + C::TWN;                                             // [CH_ELEMS]
+    v2f *sX = sCh + C::CH_ELEMS;                                         // [WPB][XW]
+    RedRec *sRed = reinterpret_cast<RedRec *>(sX + WPB * C::XW);         // [4]: one per wavefront
+    v2f *sNb = reinterpret_cast<v2f *>(sRed + 4);                        // [WPB][2]: bins left/right of the peak
+    TailRec &tr = *reinterpret_cast<TailRec *>(sNb + WPB * 2);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wsub = tid >> LOG2T;                        // window inside the workgroup iteration
+    const int t = tid & (T - 1);
+    v2f *X = sX + wsub * C::XW;
+
+    const v2f *gIq = reinterpret_cast<const v2f *>(a.iq), *gDown = reinterpret_cast<const v2f *>(a.down);
+    const v2f *gFine = reinterpret_cast<const v2f *>(a.fine);
+    v2f *gDec = reinterpret_cast<v2f *>(a.decOut), *gFft = reinterpret_cast<v2f *>(a.fftOut);
+
+    // ---- one-time set-up -------------------------------------------------------------
+    if (tid < 64) tr.w[tid] = 0xffffffffu;                // empty tail slots
+    for (int i = tid; i < C::TW_LDS; i += 256) sTw[i] = reinterpret_cast<const v2f *>(ft.twStage)[i];
+
+    // register twiddles of the last phase (klow = t there)
+    v2f twR[C::TW_ALL_LDS ? 1 : SLOTS];
+    if (!C::TW_ALL_LDS)
+    {
+        int slot = 0;
+#pragma unroll
+        for (int b = B2; b < LOG2N; b += 2)
+#pragma unroll
+            for (int kl = 0; kl < (1 << (b - B2)); kl++)
+            {
+                const int k = t + (kl << B2);
+                const int base = twStageOffset(LOG2N, b) + k;
+                twR[C::TW_ALL_LDS ? 0 : slot] = reinterpret_cast<const v2f *>(ft.twStage)[base];
+                twR[C::TW_ALL_LDS ? 0 : slot + 1] = reinterpret_cast<const v2f *>(ft.twStage)[base + (1 << b)];
+                twR[C::TW_ALL_LDS ? 0 : slot + 2] = reinterpret_cast<const v2f *>(ft.twStage)[base + (2 << b)];
+                slot += 3;
+            }
+    }
+
+    // chirp table values of this lane's sample positions: _upChirpTable = conj(_downChirpTable) (LoRaDemod.cpp:103-104)
+    const bool perWindowSel = !UNI && a.chirpSel != nullptr;
+    const float s0 = (!perWindowSel && a.chirpSelAll == LORAHIP_CHIRP_UP) ? -1.0f : 1.0f;
+    v2f ch[C::CH_LDS ? 1 : R][C::CH_LDS ? 1 : VEC];
+    if (C::CH_LDS)
+    {
+        for (int i = tid; i < N; i += 256)
+        {
+            const v2f c = gDown[i];
+            sCh[i] = MAKE2(c.x, s0 * c.y);
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int r = 0; r < (C::CH_LDS ? 0 : R); r++)
+#pragma unroll
+            for (int u = 0; u < VEC; u++)
+            {
+                const v2f c = gDown[VEC * t + u + VEC * T * r];
+                ch[C::CH_LDS ? 0 : r][C::CH_LDS ? 0 : u] = MAKE2(c.x, s0 * c.y);
+            }
+    }
+    __syncthreads();
+
+    // coalesced window load: VEC*8 bytes per lane, a wavefront covers 512 or 1024 contiguous bytes, R rows
+    v2f xn[R][VEC];
+    auto issueLoads = [&](const unsigned set_)
+    {
+        const unsigned w_ = set_ * WPB + wsub;
+        const unsigned wc_ = w_ < a.nWindows ? w_ : a.nWindows - 1;
+        const v2f *in_ = gIq + (a.offsets ? a.offsets[wc_] : (long long)wc_ * a.stride);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+        {
+            const v2f *p = in_ + VEC * t + VEC * T * r;
+            if (VEC == 2)
+            {
+                const v4f q = *reinterpret_cast<const v4f *>(p);
+                xn[r][0] = MAKE2(q.x, q.y);
+                xn[r][VEC - 1] = MAKE2(q.z, q.w);
+            }
+            else xn[r][0] = *p;
+        }
+    };
+    issueLoads(blockIdx.x);
+    const v2f fconst0 = gFine[0];
+
+    // result of the previous set, waiting for its neighbours / tail record
+    bool havePrev = false, pActive = false;
+    unsigned pW = 0, cnt = 0;
+    int pI = 0;
+    float pV = 0.0f;
+    double pTot = 0.0;
+
+    auto recordPrev = [&]()
+    {
+        if (havePrev && pActive && t == 0)
+        {
+            const int s = (cnt + wsub) & 63;
+            tr.w[s] = pW; tr.idx[s] = pI; tr.val[s] = pV; tr.tot[s] = pTot;
+            tr.l[s] = sNb[wsub * 2]; tr.r[s] = sNb[wsub * 2 + 1];
+        }
+    };
+    auto flushIfFull = [&]()
+    {
+        if (havePrev)
+        {
+            cnt += WPB;
+            if ((cnt & 63) == 0 && wave == 0)
+            {
+                const unsigned ww = tr.w[lane];
+                if (ww < a.nWindows) detectTail(a, ww, tr.idx[lane], tr.val[lane], tr.tot[lane], tr.l[lane], tr.r[lane]);
+                tr.w[lane] = 0xffffffffu;
+            }
+        }
+    };
+
+    for (unsigned set = blockIdx.x; set < nSets; set += gridDim.x)
+    {
+        const unsigned w = set * WPB + wsub;
+        const bool active = w < a.nWindows;
+        const unsigned wc = active ? w : a.nWindows - 1;  // an inactive half redoes the last window, results dropped
+        const int sel = perWindowSel ? a.chirpSel[wc] : a.chirpSelAll;
+        const int idx0 = a.fineIdx0 ? a.fineIdx0[wc] : 0;
+        const float err = (!UNI && a.fineErr) ? a.fineErr[wc] : 0.0f;
+        const bool dechirp = sel != LORAHIP_CHIRP_NONE;
+        const float d = err * (float)LORAHIP_FINE_STEPS;
+        const bool moving = dechirp && d != 0.0f;
+
+        v2f x[R][VEC];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int u = 0; u < VEC; u++) x[r][u] = xn[r][u];
+
+        // ---- fine-tune index chain for windows whose index moves (LoRaDemod.cpp:160-162) ------
+        int *sIdx = reinterpret_cast<int *>(X);             // aliases the exchange region (free until phase 0 ends)
+        bool anyMoving = false;
+        if (!UNI)
+        {
+            anyMoving = __syncthreads_or(moving);
+            if (anyMoving)
+            {
+                if (moving && t == 0)
+                {
+                    int idx = idx0;
+                    for (int i = 0; i < N; i++) { sIdx[i] = idx; idx = fineStep(idx, d, M); }
+                    if (a.fineIdxOut && active) a.fineIdxOut[w] = idx;
+                }
+                __syncthreads();
+            }
+        }
+        if (!moving && t == 0 && active && a.fineIdxOut) a.fineIdxOut[w] = idx0;
+
+        // ---- dechirp: (samp * chirp) * fine   (LoRaDemod.cpp:159) ---------------------------
+        const v2f fconst = a.fineIdx0 ? gFine[idx0] : fconst0;
+        v2f cw[R][VEC];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+        {
+            if (C::CH_LDS)
+            {
+                const v2f *p = sCh + VEC * t + VEC * T * r;
+                if (VEC == 2)
+                {
+                    const v4f q = *reinterpret_cast<const v4f *>(p);
+                    cw[r][0] = MAKE2(q.x, q.y);
+                    cw[r][VEC - 1] = MAKE2(q.z, q.w);
+                }
+                else cw[r][0] = *p;
+            }
+            else
+            {
+#pragma unroll
+                for (int u = 0; u < VEC; u++) cw[r][u] = ch[C::CH_LDS ? 0 : r][C::CH_LDS ? 0 : u];
+            }
+        }
+        if (UNI || (!perWindowSel && !anyMoving))
+        {
+            if (a.chirpSelAll != LORAHIP_CHIRP_NONE)
+            {
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulv(x[r][u], cw[r][u]), fconst);
+            }
+        }
+        else
+        {
+            const float sgn = (perWindowSel && sel == LORAHIP_CHIRP_UP) ? -1.0f : 1.0f;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int u = 0; u < VEC; u++)
+                {
+                    const v2f c = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
+                    v2f f = fconst;
+                    if (anyMoving && moving) f = gFine[sIdx[VEC * t + u + VEC * T * r]];
+                    const v2f y = cmulv(cmulv(x[r][u], c), f);
+                    x[r][u] = dechirp ? y : x[r][u];
+                }
+            if (anyMoving) __syncthreads();               // sIdx is about to be overwritten by exchange 0
+        }
+        if (DBG && a.decOut && active)
+        {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int u = 0; u < VEC; u++) gDec[(size_t)w * N + VEC * t + u + VEC * T * r] = x[r][u];
+        }
+
+        // ---- phase 0: bits [0, B1) in registers, one group per u -----------------------------
+        v2f v0[VEC][R];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int u = 0; u < VEC; u++) v0[u][Plan<LOG2N>::pos(VEC * T * r) & (R - 1)] = x[r][u];
+        // next set's samples go in flight now (past the end: re-read the last set, harmless and branch-free)
+        issueLoads(set + gridDim.x < nSets ? set + gridDim.x : nSets - 1);
+#pragma unroll
+        for (int u = 0; u < VEC; u++) runPhase<LOG2N, 0, B1, false>(v0[u], 0, sTw, nullptr);
+
+        // ---- exchange 0 ----------------------------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < VEC; u++)
+        {
+            v2f *row = X + C::x0off(VEC * t + u);
+#pragma unroll
+            for (int e = 0; e < R; e++) row[e] = v0[u][e];
+        }
+        __syncthreads();                                                                      // B1
+        recordPrev();                                   // previous set: its neighbours are visible now
+
+        // phase 1 (middle): bits [B1, B2); klow = t mod R, high = t / R
+        v2f v1[16];
+        {
+            const int klow = t & (R - 1), high = t >> B1;
+            const int rhigh = rev4(high, HB);
+#pragma unroll
+            for (int e = 0; e < 16; e++) v1[e] = X[C::x0off((rev4(e, 4) << HB) | rhigh) + klow];
+        }
+        __syncthreads();                                                                      // B2
+        flushIfFull();                                  // wave 0, once per 64 windows
+        runPhase<LOG2N, B1, B2, false>(v1, t & (R - 1), sTw, nullptr);
+        // exchange 1: position klow + R*e + 16R*high, 8 elements of padding per `high`
+        {
+            v2f *base = X + (t >> B1) * C::X1 + (t & (R - 1));
+#pragma unroll
+            for (int e = 0; e < 16; e++) base[e * R] = v1[e];
+        }
+        __syncthreads();                                                                      // B3
+        // phase 2 = last: lane t holds positions t + T*e
+        v2f vl[1][16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) vl[0][e] = X[e * C::X1 + t];
+        if (C::TW_ALL_LDS) runPhase<LOG2N, B2, LOG2N, false>(vl[0], t, sTw, nullptr);
+        else runPhase<LOG2N, B2, LOG2N, true>(vl[0], 0, nullptr, twR);
+
+        // ---- scan (LoRaDetector.hpp:36-48): bin = t + T*e, ascending in e ----------------------
+        float bestV = 0.0f;
+        int bestI = 0;
+        double tot = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+        {
+            const v2f bin = vl[0][e];
+            const int i = t + (e << LOG2T);
+            if (DBG && a.fftOut && active) gFft[(size_t)w * N + i] = bin;
+            const float mag2 = bin.x * bin.x + bin.y * bin.y;
+            tot += (double)mag2;
+            if (mag2 > bestV) { bestV = mag2; bestI = i; }
+        }
+        if (!(bestV > 0.0f)) bestI = 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            const float ov = __shfl_xor(bestV, off, 64);
+            const int oi = __shfl_xor(bestI, off, 64);
+            const double ot = __shfl_xor(tot, off, 64);
+            argmaxCombine(bestV, bestI, ov, oi);
+            tot += ot;
+        }
+        if (lane == 0) { sRed[wave].v = bestV; sRed[wave].i = bestI; sRed[wave].tot = tot; }
+        __syncthreads();                                                                      // B4
+        // every lane combines the window's wavefronts in the same order: identical results on all of them
+        {
+            const RedRec r0 = sRed[wsub * WPWIN];
+            bestV = r0.v; bestI = r0.i; tot = r0.tot;
+#pragma unroll
+            for (int k = 1; k < WPWIN; k++)
+            {
+                const RedRec rk = sRed[wsub * WPWIN + k];
+                argmaxCombine(bestV, bestI, rk.v, rk.i);
+                tot += rk.tot;
+            }
+        }
+
+        // ---- neighbours of the peak for fIndex (LoRaDetector.hpp:56-57): the owners post them ---
+        {
+            const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
+            const bool ownL = (bl & (T - 1)) == t, ownR = (br & (T - 1)) == t;
+            if (ownL || ownR)
+            {
+                const v2f mine = selectReg<1, 16>(vl, ownL ? (bl >> LOG2T) : (br >> LOG2T));
+                sNb[wsub * 2 + (ownL ? 0 : 1)] = mine;
+            }
+        }
+        havePrev = true; pActive = active; pW = w; pI = bestI; pV = bestV; pTot = tot;
+    }
+
+    // ---- drain: last set's record, then whatever is queued --------------------------------------
+    __syncthreads();
+    recordPrev();
+    __syncthreads();
+    if (wave == 0)
+    {
+        const unsigned ww = tr.w[lane];
+        if (ww < a.nWindows) detectTail(a, ww, tr.idx[lane], tr.val[lane], tr.tot[lane], tr.l[lane], tr.r[lane]);
+    }
+}
+
+/***********************************************************************
+ * launch
+ **********************************************************************/
+template <class C, bool DBG, bool UNI>
+static hipError_t launchOneWide(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
+{
+    const size_t smem = WideSmem<C>::bytes();
+    static bool attrSet = false;
+    if (!attrSet)
+    {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(detectWide<C, DBG, UNI>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        if (e != hipSuccess) return e;
+        attrSet = true;
+    }
+    const unsigned nSets = (a.nWindows + C::WPB - 1) / C::WPB;
+    // persistent: as many workgroups as stay resident, never more than there are sets of work
+    unsigned perCu = unsigned((160u * 1024u) / smem);
+    if (perCu > unsigned(C::MINW)) perCu = unsigned(C::MINW);
+    if (perCu < 1) perCu = 1;
+    unsigned grid = unsigned(ft.nBlocksHint > 0 ? ft.nBlocksHint : 256) * perCu;
+    if (grid > nSets) grid = nSets;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL((detectWide<C, DBG, UNI>), dim3(grid), dim3(256), smem, stream, a, ft, nSets);
+    return hipGetLastError();
+}
+
+template <class C>
+static hipError_t launchCfgWide(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
+{
+    const bool uni = a.chirpSel == nullptr && a.fineErr == nullptr;
+    if (a.decOut || a.fftOut) return launchOneWide<C, true, false>(a, ft, stream);
+    return uni ? launchOneWide<C, false, true>(a, ft, stream) : launchOneWide<C, false, false>(a, ft, stream);
+}
+
+//              LOG2N VEC w/SIMD X0: ROT PAD S  D   chLDS twLDS
+// 128 lanes x 16 pts: [R2,4] X [4,4] X [4,4]
+typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  false, false> Cfg11a;
+typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false> Cfg11b;
+typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  true,  false> Cfg11c;
+typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  false, true>  Cfg11d;
+typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  true,  true>  Cfg11e;
+// 256 lanes x 16 pts: [4,4] X [4,4] X [4,4]
+typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  false, false> Cfg12a;
+typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false> Cfg12b;
+typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  true,  false> Cfg12c;
+typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  false, true>  Cfg12d;
+typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  true,  true>  Cfg12e;
+
+bool wideAvailable(const int sf) { return sf == 11 || sf == 12; }
+
+hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
+{
+    switch (sf)
+    {
+    case 11:
+        switch (variant)
+        {
+        case 2: return launchCfgWide<Cfg11b>(a, ft, stream);
+        case 3: return launchCfgWide<Cfg11c>(a, ft, stream);
+        case 4: return launchCfgWide<Cfg11d>(a, ft, stream);
+        case 5: return launchCfgWide<Cfg11e>(a, ft, stream);
+        default: return launchCfgWide<Cfg11a>(a, ft, stream);
+        }
+    case 12:
+        switch (variant)
+        {
+        case 2: return launchCfgWide<Cfg12a>(a, ft, stream);
+        case 3: return launchCfgWide<Cfg12c>(a, ft, stream);
+        case 4: return launchCfgWide<Cfg12d>(a, ft, stream);
+        case 5: return launchCfgWide<Cfg12e>(a, ft, stream);
+        default: return launchCfgWide<Cfg12b>(a, ft, stream);   // measured best (profiles/r01)
+        }
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace lorahip

@@ -268,3 +268,35 @@ def test_golden_detector_kat(gpu, golden, sf):
     assert np.abs(to_np(r["power"])[fin] - ref_p[fin]).max() <= TOL_DB
     assert pavg_err_ok(to_np(r["powerAvg"]), ref_a, ref_p)[0]
     assert np.abs(to_np(r["fIndex"]) - ref_f).max() <= TOL_FIDX
+
+
+# every selectable kernel variant per SF (lorahip_kernels.hip / lorahip_fast.hip / lorahip_wide.hip); 1 = generic
+VARIANTS = {6: [0], 7: [0, 1, 2, 3, 4, 5], 8: [0, 1], 9: [0, 1], 10: [0, 1], 11: [0, 1, 2, 3, 4, 5], 12: [0, 1, 2, 3, 4, 5]}
+
+
+@pytest.mark.parametrize("sf", range(6, 13))
+def test_steady_state_kernels_all_variants(gpu, oracle, sf):
+    """The launch-uniform, no-debug-output kernels (the shape bench.py times), batches large enough that every
+    persistent workgroup runs several window sets and the deferred tails are flushed mid-loop and at the end;
+    every variant against the oracle, and the debug-output kernel against the same."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(200 + sf)
+    W = {6: 70001, 7: 70001, 8: 30011, 9: 16001, 10: 9001, 11: 4099, 12: 2051}[sf]
+    snr = -5.0 if sf >= 9 else 5.0
+    iq, sent = make_iq(rng, sf, W, snr_db=snr)
+    # sprinkle degenerate windows: all-zero, and pure noise
+    iq[17] = 0
+    iq[W - 1] = (rng.standard_normal(1 << sf) + 1j * rng.standard_normal(1 << sf)).astype(np.complex64)
+    o = oracle.detect_batch(sf, iq, want_fft=False, nthreads=8)
+    d = gpu.from_numpy(iq).cuda()
+    ctx = L.Context(sf)
+    for v in VARIANTS[sf]:
+        ctx.set_variant(v)
+        for sel in (L.CHIRP_UP,):
+            g = ctx.detect_batch(d, chirp_sel_all=sel)
+            gpu.cuda.synchronize()
+            check(o, g, fft=False, where="steady sf%d variant %d" % (sf, v))
+    ctx.set_variant(0)
+    o2 = oracle.detect_batch(sf, iq[:1500], chirp_sel=1, want_fft=True, nthreads=8)
+    g2 = ctx.detect_batch(d[:1500], chirp_sel_all=L.CHIRP_DOWN, want_fft=True)
+    check(o2, g2, where="steady-dbg sf%d" % sf)

@@ -55,3 +55,35 @@ if [[ $what == *pmc* ]]; then
   python tools/pmc_summary.py $O > $O/pmc_summary.txt 2>&1
   cat $O/pmc_summary.txt
 fi
+
+if [[ $what == *variants* ]]; then
+  for sf in ${VSF:-11 12}; do
+    for v in ${VARS:-0 2 3 4 5}; do
+      timeout 200 python bench.py --sf $sf --variant $v --steps 10 --warmup 2 --no-cpu-baseline > $O/var_sf${sf}_v$v.json 2> $O/var_sf${sf}_v$v.err
+      python - <<EOF2
+import json
+try:
+    d = json.loads(open("$O/var_sf${sf}_v$v.json").read().strip().splitlines()[-1])
+    print("SF$sf variant $v:", round(d["value"], 1), "Msym/s frac", round(d["roofline"]["frac"], 3), "ser", d["symbol_error_rate_vs_sent"])
+except Exception as e:
+    print("SF$sf variant $v failed", e)
+EOF2
+    done
+  done
+fi
+
+if [[ $what == *sq* ]]; then
+  rocprofv3 -L > $O/counters_list.txt 2>&1
+  for sf in ${SQSF:-7 12}; do
+    i=0
+    for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" \
+               "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
+               "GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG"; do
+      i=$((i+1))
+      ( cd /tmp && timeout 300 rocprofv3 --pmc $set -d $O/pmc_SQ${i}_sf$sf -o pmc --output-format csv -- \
+          python $R/bench.py --sf $sf --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_SQ${i}_sf$sf.log 2>&1 )
+    done
+  done
+  python tools/pmc_summary.py $O > $O/pmc_summary_sq.txt 2>&1
+  cat $O/pmc_summary_sq.txt
+fi

@@ -130,3 +130,56 @@ def search(name, n, t, vec, b1, b2):
 if __name__ == "__main__":
     for name, c in {"sf7": (7, 3, 2, 3, 7), "sf8": (8, 3, 2, 4, 8), "sf9": (9, 5, 2, 3, 7), "sf10": (10, 5, 2, 4, 8)}.items():
         search(name, *c)
+
+
+def exch0_wide(LOG2N, VEC, off):
+    """wide kernels (lorahip_wide.hip): T = N/16 lanes per window (whole wavefronts), one X region per window.
+    off(n_low) -> element offset of the row start."""
+    N = 1 << LOG2N
+    T = N // 16
+    R = 16 // VEC
+    B1 = 4 if VEC == 1 else 3
+    HB = 4
+    wr, rd = [], []
+    for wv in range(T // 64):
+        for u in range(VEC):
+            for e in range(R):
+                wr.append(cost([8 * (off(VEC * (64 * wv + l) + u) + e) for l in range(64)], "w"))
+        for e in range(16):
+            addrs = []
+            for l in range(64):
+                t = 64 * wv + l
+                klow, high = t & (R - 1), t >> B1
+                nlow = (rev4(e, 4) << HB) | rev4(high, HB)
+                addrs.append(8 * (off(nlow) + klow))
+            rd.append(cost(addrs, "r"))
+    return (sum(c for c, _ in wr) / sum(n for _, n in wr), sum(c for c, _ in rd) / sum(n for _, n in rd))
+
+
+def search_wide(name, LOG2N, VEC):
+    N = 1 << LOG2N
+    T = N // 16
+    R = 16 // VEC
+    NL = VEC * T
+    nb = NL.bit_length() - 1
+    best = []
+    for rot in range(nb):
+        for pad in range(0, 9):
+            for extra_s in range(nb):
+                for extra_d in (0, 1, 2, 4, 8, 16, 32):
+                    RS = R + pad
+
+                    def off(x, rot=rot, RS=RS, extra_s=extra_s, extra_d=extra_d):
+                        p = ((x >> rot) | (x << (nb - rot))) & (NL - 1)
+                        return p * RS + ((x >> extra_s) & 1) * extra_d
+                    w, r = exch0_wide(LOG2N, VEC, off)
+                    best.append((w + r, w, r, rot, pad, extra_s, extra_d, NL * RS + extra_d))
+    best.sort()
+    print(name, "best (sum, w, r, rot, pad, extra_s, extra_d, size):")
+    for b in best[:6]:
+        print("   ", b)
+
+
+if __name__ == "__main__":
+    search_wide("sf11-wide", 11, 2)
+    search_wide("sf12-wide", 12, 1)
