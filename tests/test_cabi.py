@@ -80,3 +80,39 @@ def test_product_never_touches_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU", ""), "%s mentions oracle" % f
                 assert "/root/reference" not in src
+
+
+def test_cpp_detector_shim_compiles_links_and_fails_loudly(tmp_path):
+    """include/LoRaDetectorHip.hpp (the LoRaDetector<float> drop-in of INTEGRATION.md §1) builds with a
+    plain host compiler against the C ABI; without a gfx950 device its constructor throws."""
+    import shutil
+    import subprocess
+    import torch
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    src = tmp_path / "shim.cpp"
+    src.write_text(r'''
+#include "LoRaDetectorHip.hpp"
+#include <cstdio>
+int main()
+{
+    try {
+        LoRaDetectorHip<float> det(1024);
+        for (size_t i = 0; i < 1024; i++) det.feed(i, std::complex<float>(1.0f, 0.0f));   // DC tone -> bin 0
+        float power, powerAvg, fIndex;
+        const size_t idx = det.detect(power, powerAvg, fIndex);
+        std::printf("index %zu power %g\n", idx, power);
+        return idx == 0 ? 0 : 2;
+    } catch (const std::exception &e) { std::printf("threw: %s\n", e.what()); return 3; }
+}
+''')
+    exe = tmp_path / "shim"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([cxx, "-std=c++11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-llorahip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "threw" in r.stdout, r.stdout + r.stderr
