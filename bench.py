@@ -36,8 +36,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--ramp-seconds", type=float, default=0.3,
+                    help="untimed launches before the warm-up steps until the GPU has left its idle clocks "
+                         "(a cold MI355X needs ~40 ms of load to ramp: tools/ramp.py, profiles/r01/s4_clock_ramp.txt)")
     ap.add_argument("--sf", type=int, default=7)
     ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default: 1 GiB of IQ per step)")
     ap.add_argument("--symbols", type=int, default=None, help="symbol windows per channel per step")
@@ -45,6 +48,8 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--alias-windows", action="store_true",
+                    help="diagnostic: every window reads window 0 (no HBM traffic): the compute-only time of the kernel")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
@@ -129,7 +134,9 @@ def main():
     iq = ctx.synth_symbols(sym, ampl=1.0, noise_sigma=a.noise_sigma, seed=0x5EED0000 + rank)
     out = dict(sym=torch.empty(W, dtype=torch.int16, device=dev), power=torch.empty(W, dtype=torch.float32, device=dev),
                powerAvg=torch.empty(W, dtype=torch.float32, device=dev), fIndex=torch.empty(W, dtype=torch.float32, device=dev))
-    batch = ctx.make_batch(iq, W, out["sym"], out["power"], out["powerAvg"], out["fIndex"], chirp_sel_all=L.CHIRP_UP)
+    offsets = torch.zeros(W, dtype=torch.int64, device=dev) if a.alias_windows else None
+    batch = ctx.make_batch(iq, W, out["sym"], out["power"], out["powerAvg"], out["fIndex"], chirp_sel_all=L.CHIRP_UP,
+                           offsets=offsets)
 
     def barrier():
         torch.cuda.synchronize()
@@ -137,6 +144,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock ramp: the first ~40 ms of load after idle run at reduced clocks (profiles/r01/s4_clock_ramp.txt);
+    # keep launching (untimed) until that is over, then the W warm-up steps, then the timed K steps
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < a.ramp_seconds:
+        for _ in range(10):
+            ctx.detect_batch_raw(batch)
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         ctx.detect_batch_raw(batch)
     barrier()
@@ -175,7 +189,8 @@ def main():
                                    % (B, sf, N, S), "sf": sf, "channels_per_gpu": B, "symbols_per_channel": S,
                        "iq_bytes_per_step_per_gpu": W * N * 8, "noise_sigma": a.noise_sigma,
                        "parallelism": "channels sharded, %d rank(s), no data-path collective" % world,
-                       "kernel_variant": a.variant},
+                       "kernel_variant": a.variant, "alias_windows": bool(a.alias_windows),
+                       "ramp_seconds": a.ramp_seconds},
             "symbol_error_rate_vs_sent": ser, "bin_offset": bin_offset,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": a.traffic,

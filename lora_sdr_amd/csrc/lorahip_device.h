@@ -172,8 +172,82 @@ __device__ __forceinline__ void argmaxCombine(float &v, int &i, const float ov, 
 }
 
 /***********************************************************************
- * detect() tail for one window, executed by one lane (LoRaDetector.hpp:50-61)
+ * group reductions without LDS: max / min of an unsigned over the aligned group of T lanes this lane
+ * belongs to, result in every lane. DPP row permutations up to 16 lanes, gfx950's v_permlane16/32_swap
+ * above. |X|^2 values are non-negative non-NaN floats, whose bit patterns order like unsigned integers,
+ * so the arg-max is: group max of the value, then group min of the index among the lanes that hold it
+ * (= the reference's lowest-index tie-break, LoRaDetector.hpp:43).
  **********************************************************************/
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+template <int T, bool MAX>
+__device__ __forceinline__ unsigned groupReduceU(unsigned v)
+{
+#define LORAHIP_RED_STEP(O) { const unsigned o_ = (O); v = MAX ? (v > o_ ? v : o_) : (v < o_ ? v : o_); }
+    if (T >= 2) LORAHIP_RED_STEP(__builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false))     // quad_perm [1,0,3,2]
+    if (T >= 4) LORAHIP_RED_STEP(__builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false))     // quad_perm [2,3,0,1]
+    if (T >= 8) LORAHIP_RED_STEP(__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false))    // row_half_mirror
+    if (T >= 16) LORAHIP_RED_STEP(__builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, false))   // row_mirror
+    if (T >= 32) { const v2u r = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = r.x; LORAHIP_RED_STEP(r.y) }
+    if (T >= 64) { const v2u r = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = r.x; LORAHIP_RED_STEP(r.y) }
+#undef LORAHIP_RED_STEP
+    return v;
+}
+template <int T>
+__device__ __forceinline__ void groupArgmax(float &bestV, int &bestI)
+{
+    const unsigned mine = __float_as_uint(bestV);
+    const unsigned gm = groupReduceU<T, true>(mine);
+    const unsigned cand = mine == gm ? (unsigned)bestI : 0x7fffffffu;
+    bestI = (int)groupReduceU<T, false>(cand);
+    bestV = __uint_as_float(gm);
+}
+
+/***********************************************************************
+ * detect() tail for one window, executed by one lane (LoRaDetector.hpp:50-61)
+ *
+ * The reference evaluates log10f / hypotf in glibc; OCML's fp64 log10 (double-double inside, ~200
+ * instructions) is far more than a float result needs. log10d / hypotd below are accurate to ~1e-14 /
+ * ~1e-13 relative, i.e. they round to the same float as the exact value except when that value lies
+ * within 2^-20 ulp of a float rounding boundary -- the same quality class as glibc's own float routines
+ * (tests/: |power - ref| <= 2e-5 dB, |fIndex - ref| <= 2e-6).
+ **********************************************************************/
+//! log10 of a non-negative double (a widened float): x = m*2^e, m in [sqrt(1/2), sqrt 2),
+//! ln m = 2 atanh f, f = (m-1)/(m+1), |f| <= 0.1716; series to f^15 (next term 3e-14 relative)
+__device__ __forceinline__ double log10d(const double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = (m - 1.0) / (m + 1.0);
+    const double s = f * f;
+    double p = 1.0 / 15.0;
+    p = __builtin_fma(p, s, 1.0 / 13.0);
+    p = __builtin_fma(p, s, 1.0 / 11.0);
+    p = __builtin_fma(p, s, 1.0 / 9.0);
+    p = __builtin_fma(p, s, 1.0 / 7.0);
+    p = __builtin_fma(p, s, 1.0 / 5.0);
+    p = __builtin_fma(p, s, 1.0 / 3.0);
+    p = __builtin_fma(p, s, 1.0);
+    const double lnm10 = (f * p) * 0.86858896380650365530;          // 2/ln(10)
+    double r = __builtin_fma((double)e, 0.30102999566398119521, lnm10);
+    r = x == 0.0 ? -__builtin_inf() : r;                                // log10(0) = -inf
+    r = (x < 0.0 || x != x) ? __builtin_nan("") : r;                    // negative (rounded total - max) or NaN
+    r = x == __builtin_inf() ? x : r;
+    return r;
+}
+//! sqrt(a*a + b*b) of two floats in fp64: products exact, one rounding in the sum, rsq + one Newton step
+__device__ __forceinline__ double hypotd(const float a, const float b)
+{
+    const double s = __builtin_fma((double)a, (double)a, (double)b * (double)b);
+    const double r = __builtin_amdgcn_rsq(s);
+    const double y0 = s * r;
+    const double y1 = __builtin_fma(__builtin_fma(-y0, y0, s), 0.5 * r, y0);
+    const double y2 = __builtin_fma(__builtin_fma(-y1, y1, s), 0.5 * r, y1);
+    return (s == 0.0 || s != s || s == __builtin_inf()) ? s : y2;
+}
+
 template <class CPX>
 __device__ __forceinline__ void detectTail(const DetectArgs &a, const unsigned w, const int maxIndex,
                                            const float maxValue, const double total,
@@ -181,12 +255,11 @@ __device__ __forceinline__ void detectTail(const DetectArgs &a, const unsigned w
 {
     const float noise = sqrtf((float)(total - (double)maxValue));
     const float fundamental = sqrtf(maxValue);
-    // log10 evaluated in double and rounded once: within an ulp of a correctly rounded log10f
-    const float powerAvg = 20 * (float)log10((double)noise) - a.powerScale;
-    const float power = 20 * (float)log10((double)fundamental) - a.powerScale;
-    // std::abs(complex<float>) = hypotf; the double form is its correctly rounded value
-    const float left = (float)sqrt((double)leftBin.x * (double)leftBin.x + (double)leftBin.y * (double)leftBin.y);
-    const float right = (float)sqrt((double)rightBin.x * (double)rightBin.x + (double)rightBin.y * (double)rightBin.y);
+    const float powerAvg = 20 * (float)log10d((double)noise) - a.powerScale;
+    const float power = 20 * (float)log10d((double)fundamental) - a.powerScale;
+    // std::abs(complex<float>) = hypotf
+    const float left = (float)hypotd(leftBin.x, leftBin.y);
+    const float right = (float)hypotd(rightBin.x, rightBin.y);
     const double demon = (2.0 * (double)fundamental) - (double)right - (double)left;
     float fIndex = 0.0f;
     if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);

@@ -106,7 +106,8 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     constexpr int NGL = P / GL;                           // last-phase groups per lane
     constexpr int SLOTS = lastPhaseSlots<LOG2N, BL, LOG2N>();
     constexpr int XE = (C::X0ELEMS > C::X1ELEMS ? C::X0ELEMS : C::X1ELEMS);
-    constexpr int XW = (XE * 2 > WPW * N ? XE : (WPW * N + 1) / 2) + 2;   // v2f per wave; also holds WPW*N ints
+    constexpr int FS = N + 8;                             // final-bin rows of the wave's windows (8 pad: 16-lane write groups tile the banks)
+    constexpr int XW = (XE > WPW * FS ? XE : WPW * FS) + 2;   // v2f per wave; also holds WPW*N ints
     constexpr int M = N * LORAHIP_FINE_STEPS;
     constexpr int WAVES = 4;
 
@@ -387,9 +388,16 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             else runPhase<LOG2N, BL, LOG2N, true>(vl[g], 0, nullptr, twR[C::TW_ALL_LDS ? 0 : g]);
         }
 
+        // ---- final bins into the (now free) exchange region: the peak's neighbours are fetched from there ----
+        v2f *F = X + wsub * FS;
+#pragma unroll
+        for (int e = 0; e < GL; e++)
+#pragma unroll
+            for (int g = 0; g < NGL; g++) F[(t + T * g) + (e << BL)] = vl[g][e];
+
         // ---- scan (LoRaDetector.hpp:36-48): bin = ci + 2^BL * e, ascending in (e, g) -----------
         float bestV = 0.0f;
-        int bestI = 0;
+        int bestJ = 0;                                     // element number e*NGL + g of the lane's best bin
         double tot = 0.0;
 #pragma unroll
         for (int e = 0; e < GL; e++)
@@ -397,40 +405,28 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             for (int g = 0; g < NGL; g++)
             {
                 const v2f bin = vl[g][e];
-                const int i = (t + T * g) + (e << BL);
-                if (DBG && a.fftOut && active) gFft[(size_t)w * N + i] = bin;
+                if (DBG && a.fftOut && active) gFft[(size_t)w * N + (t + T * g) + (e << BL)] = bin;
                 const float mag2 = bin.x * bin.x + bin.y * bin.y;
                 tot += (double)mag2;
-                if (mag2 > bestV) { bestV = mag2; bestI = i; }
+                if (mag2 > bestV) { bestV = mag2; bestJ = e * NGL + g; }
             }
+        int bestI = (t + T * (bestJ & (NGL - 1))) + ((bestJ / NGL) << BL);
         if (!(bestV > 0.0f)) bestI = 0;
+        groupArgmax<T>(bestV, bestI);
 #pragma unroll
-        for (int off = T / 2; off > 0; off >>= 1)
-        {
-            const float ov = __shfl_xor(bestV, off, 64);
-            const int oi = __shfl_xor(bestI, off, 64);
-            const double ot = __shfl_xor(tot, off, 64);
-            argmaxCombine(bestV, bestI, ov, oi);
-            tot += ot;
-        }
+        for (int off = T / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
         // every lane of the window now holds the window's (bestV, bestI); the xor tree adds the same
         // fp64 partials in the same pairing on all lanes, so tot is identical on all of them too
 
-        // ---- neighbours of the peak for fIndex (LoRaDetector.hpp:56-57) ------------------------
-        const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
-        const int cil = bl & ((1 << BL) - 1), cir = br & ((1 << BL) - 1);
-        const bool ownL = (cil & (T - 1)) == t;
-        const int req = ownL ? ((bl >> BL) * NGL + (cil >> LOG2T)) : ((br >> BL) * NGL + (cir >> LOG2T));
-        const v2f mine = selectReg<NGL, GL>(vl, req);
-        const int base = lane & ~(T - 1);
-        const v2f leftBin = MAKE2(__shfl(mine.x, base + (cil & (T - 1)), 64), __shfl(mine.y, base + (cil & (T - 1)), 64));
-        const v2f rightBin = MAKE2(__shfl(mine.x, base + (cir & (T - 1)), 64), __shfl(mine.y, base + (cir & (T - 1)), 64));
-
         // ---- defer the log/sqrt tail: one record per window, flushed 64 at a time ---------------
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (t == 0 && active)
         {
+            // neighbours of the peak for fIndex (LoRaDetector.hpp:56-57)
             const int s = pending + wsub;
-            tr.w[s] = w; tr.idx[s] = bestI; tr.val[s] = bestV; tr.tot[s] = tot; tr.l[s] = leftBin; tr.r[s] = rightBin;
+            tr.w[s] = w; tr.idx[s] = bestI; tr.val[s] = bestV; tr.tot[s] = tot;
+            tr.l[s] = F[(bestI + N - 1) & (N - 1)]; tr.r[s] = F[(bestI + 1) & (N - 1)];
         }
         pending += WPW;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -463,7 +459,7 @@ static size_t smemBytes()
 {
     constexpr int WAVES = 4;
     constexpr int XE = (C::X0ELEMS > C::X1ELEMS ? C::X0ELEMS : C::X1ELEMS);
-    constexpr int XW = (XE * 2 > C::WPW * C::N ? XE : (C::WPW * C::N + 1) / 2) + 2;
+    constexpr int XW = (XE > C::WPW * (C::N + 8) ? XE : C::WPW * (C::N + 8)) + 2;
     return size_t(((C::TW_LDS + 1) & ~1) + C::CH_ELEMS) * sizeof(float2) + size_t(WAVES) * XW * sizeof(float2) + size_t(WAVES) * sizeof(TailRec);
 }
 

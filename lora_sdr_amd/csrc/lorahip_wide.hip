@@ -52,6 +52,19 @@ struct WideCfg
 
 struct RedRec { float v; int i; double tot; };
 
+//! v[idx] for a wave-uniform idx: a scalar branch tree instead of 30 v_cndmask
+__device__ __forceinline__ v2f pickUniform16(const v2f (&v)[16], const int idx)
+{
+    switch (idx)
+    {
+#define LORAHIP_PICK(I) case I: return v[I];
+    LORAHIP_PICK(0) LORAHIP_PICK(1) LORAHIP_PICK(2) LORAHIP_PICK(3) LORAHIP_PICK(4) LORAHIP_PICK(5) LORAHIP_PICK(6) LORAHIP_PICK(7)
+    LORAHIP_PICK(8) LORAHIP_PICK(9) LORAHIP_PICK(10) LORAHIP_PICK(11) LORAHIP_PICK(12) LORAHIP_PICK(13) LORAHIP_PICK(14)
+#undef LORAHIP_PICK
+    default: return v[15];
+    }
+}
+
 template <class C>
 struct WideSmem
 {
@@ -325,36 +338,30 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         }
         __syncthreads();                                                                      // B3
         // phase 2 = last: lane t holds positions t + T*e
-        v2f vl[1][16];
+        v2f vl[16];
 #pragma unroll
-        for (int e = 0; e < 16; e++) vl[0][e] = X[e * C::X1 + t];
-        if (C::TW_ALL_LDS) runPhase<LOG2N, B2, LOG2N, false>(vl[0], t, sTw, nullptr);
-        else runPhase<LOG2N, B2, LOG2N, true>(vl[0], 0, nullptr, twR);
+        for (int e = 0; e < 16; e++) vl[e] = X[e * C::X1 + t];
+        if (C::TW_ALL_LDS) runPhase<LOG2N, B2, LOG2N, false>(vl, t, sTw, nullptr);
+        else runPhase<LOG2N, B2, LOG2N, true>(vl, 0, nullptr, twR);
 
         // ---- scan (LoRaDetector.hpp:36-48): bin = t + T*e, ascending in e ----------------------
         float bestV = 0.0f;
-        int bestI = 0;
+        int bestE = 0;
         double tot = 0.0;
 #pragma unroll
         for (int e = 0; e < 16; e++)
         {
-            const v2f bin = vl[0][e];
-            const int i = t + (e << LOG2T);
-            if (DBG && a.fftOut && active) gFft[(size_t)w * N + i] = bin;
+            const v2f bin = vl[e];
+            if (DBG && a.fftOut && active) gFft[(size_t)w * N + t + (e << LOG2T)] = bin;
             const float mag2 = bin.x * bin.x + bin.y * bin.y;
             tot += (double)mag2;
-            if (mag2 > bestV) { bestV = mag2; bestI = i; }
+            if (mag2 > bestV) { bestV = mag2; bestE = e; }
         }
+        int bestI = t + (bestE << LOG2T);
         if (!(bestV > 0.0f)) bestI = 0;
+        groupArgmax<64>(bestV, bestI);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-        {
-            const float ov = __shfl_xor(bestV, off, 64);
-            const int oi = __shfl_xor(bestI, off, 64);
-            const double ot = __shfl_xor(tot, off, 64);
-            argmaxCombine(bestV, bestI, ov, oi);
-            tot += ot;
-        }
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
         if (lane == 0) { sRed[wave].v = bestV; sRed[wave].i = bestI; sRed[wave].tot = tot; }
         __syncthreads();                                                                      // B4
         // every lane combines the window's wavefronts in the same order: identical results on all of them
@@ -370,15 +377,13 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
             }
         }
 
-        // ---- neighbours of the peak for fIndex (LoRaDetector.hpp:56-57): the owners post them ---
+        // ---- neighbours of the peak for fIndex (LoRaDetector.hpp:56-57): the owners post them. A wavefront
+        // belongs to one window, so the register number of a neighbour is wave-uniform: scalar select.
         {
             const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
             const bool ownL = (bl & (T - 1)) == t, ownR = (br & (T - 1)) == t;
-            if (ownL || ownR)
-            {
-                const v2f mine = selectReg<1, 16>(vl, ownL ? (bl >> LOG2T) : (br >> LOG2T));
-                sNb[wsub * 2 + (ownL ? 0 : 1)] = mine;
-            }
+            if (__any(ownL)) { const v2f c = pickUniform16(vl, __builtin_amdgcn_readfirstlane(bl >> LOG2T)); if (ownL) sNb[wsub * 2] = c; }
+            if (__any(ownR)) { const v2f c = pickUniform16(vl, __builtin_amdgcn_readfirstlane(br >> LOG2T)); if (ownR) sNb[wsub * 2 + 1] = c; }
         }
         havePrev = true; pActive = active; pW = w; pI = bestI; pV = bestV; pTot = tot;
     }

@@ -20,7 +20,7 @@ if [[ $what == *bench* ]]; then
   timeout 600 python bench.py > $O/bench_sf7.json 2> $O/bench_sf7.err
   tail -c 2500 $O/bench_sf7.json
   for sf in 8 9 10 11 12; do
-    timeout 300 python bench.py --sf $sf --steps 10 --warmup 2 --cpu-seconds 3 > $O/bench_sf$sf.json 2> $O/bench_sf$sf.err
+    timeout 300 python bench.py --sf $sf --cpu-seconds 3 > $O/bench_sf$sf.json 2> $O/bench_sf$sf.err
     python - <<EOF
 import json
 try:
@@ -38,10 +38,11 @@ if [[ $what == *membw* ]]; then
 fi
 
 if [[ $what == *prof* ]]; then
-  for sf in 7 12; do
+  for sf in ${PSF:-7 12}; do
     ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_sf$sf -o sf$sf --output-format csv -- \
-        python $R/bench.py --sf $sf --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_sf$sf.log 2>&1 )
-    find $O/prof_sf$sf -name '*kernel_stats.csv' | head -1 | xargs -r head -4
+        python $R/bench.py --sf $sf --steps 300 --warmup 20 --no-cpu-baseline > $O/prof_sf$sf.log 2>&1 )
+    find $O/prof_sf$sf -name '*kernel_stats.csv' | head -1 | xargs -r head -3
+    python tools/trace_tail.py $O/prof_sf$sf 300 | tee $O/prof_sf$sf.timed.txt; tail -c 600 $O/prof_sf$sf.log
   done
 fi
 
@@ -49,7 +50,7 @@ if [[ $what == *pmc* ]]; then
   for sf in 7 12; do
     for c in FETCH_SIZE WRITE_SIZE; do
       ( cd /tmp && timeout 600 rocprofv3 --pmc $c -d $O/pmc_${c}_sf$sf -o pmc --output-format csv -- \
-          python $R/bench.py --sf $sf --steps 5 --warmup 1 --no-cpu-baseline > $O/pmc_${c}_sf$sf.log 2>&1 )
+          python $R/bench.py --sf $sf --steps 5 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $O/pmc_${c}_sf$sf.log 2>&1 )
     done
   done
   python tools/pmc_summary.py $O > $O/pmc_summary.txt 2>&1
@@ -59,7 +60,7 @@ fi
 if [[ $what == *variants* ]]; then
   for sf in ${VSF:-11 12}; do
     for v in ${VARS:-0 2 3 4 5}; do
-      timeout 200 python bench.py --sf $sf --variant $v --steps 10 --warmup 2 --no-cpu-baseline > $O/var_sf${sf}_v$v.json 2> $O/var_sf${sf}_v$v.err
+      timeout 200 python bench.py --sf $sf --variant $v --no-cpu-baseline > $O/var_sf${sf}_v$v.json 2> $O/var_sf${sf}_v$v.err
       python - <<EOF2
 import json
 try:
@@ -81,9 +82,43 @@ if [[ $what == *sq* ]]; then
                "GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG"; do
       i=$((i+1))
       ( cd /tmp && timeout 300 rocprofv3 --pmc $set -d $O/pmc_SQ${i}_sf$sf -o pmc --output-format csv -- \
-          python $R/bench.py --sf $sf --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_SQ${i}_sf$sf.log 2>&1 )
+          python $R/bench.py --sf $sf --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $O/pmc_SQ${i}_sf$sf.log 2>&1 )
     done
   done
   python tools/pmc_summary.py $O > $O/pmc_summary_sq.txt 2>&1
   cat $O/pmc_summary_sq.txt
+fi
+
+if [[ $what == *tailtest* ]]; then
+  timeout 120 tools/tailtest.bin > $O/tailtest.log 2>&1; cat $O/tailtest.log
+fi
+
+if [[ $what == *quick* ]]; then
+  for sf in ${QSF:-7 8 9 10 11 12}; do
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline > $O/q_sf$sf.json 2> $O/q_sf$sf.err
+    python - <<EOF2
+import json
+try:
+    d = json.loads(open("$O/q_sf$sf.json").read().strip().splitlines()[-1])
+    print("SF$sf:", round(d["value"], 1), "Msym/s frac", round(d["roofline"]["frac"], 3), "launch_us", round(d["roofline"]["launch_us"],1), "ser", d["symbol_error_rate_vs_sent"])
+except Exception as e:
+    print("SF$sf failed", e); print(open("$O/q_sf$sf.err").read()[-800:])
+EOF2
+  done
+fi
+
+if [[ $what == *alias* ]]; then
+  for sf in ${QSF:-7 10 12}; do
+    for extra in "" "--alias-windows"; do
+      timeout 200 python bench.py --sf $sf --no-cpu-baseline $extra > $O/alias_sf$sf.json 2> $O/alias_sf$sf.err
+      python - <<EOF2
+import json
+try:
+    d = json.loads(open("$O/alias_sf$sf.json").read().strip().splitlines()[-1])
+    print("SF$sf $extra:", round(d["value"], 1), "Msym/s frac", round(d["roofline"]["frac"], 3), "launch_us", round(d["roofline"]["launch_us"],1))
+except Exception as e:
+    print("SF$sf failed", e); print(open("$O/alias_sf$sf.err").read()[-800:])
+EOF2
+    done
+  done
 fi
