@@ -118,6 +118,34 @@ __device__ __forceinline__ v2f selectReg(const v2f (&v)[NG][G], const int idx)
     return cur[0];
 }
 
+//! v[idx] for a runtime per-lane idx: cndmask tree over a flat register array
+template <int CNT>
+__device__ __forceinline__ v2f selectFlat(const v2f (&v)[CNT], const int idx)
+{
+    v2f cur[CNT / 2];
+    {
+        const bool hi = idx & 1;
+#pragma unroll
+        for (int i = 0; i < CNT / 2; i++)
+        {
+            cur[i].x = hi ? v[2 * i + 1].x : v[2 * i].x;
+            cur[i].y = hi ? v[2 * i + 1].y : v[2 * i].y;
+        }
+    }
+#pragma unroll
+    for (int w = CNT / 4, bit = 1; w >= 1; w >>= 1, bit++)
+    {
+        const bool hi = (idx >> bit) & 1;
+#pragma unroll
+        for (int i = 0; i < w; i++)
+        {
+            cur[i].x = hi ? cur[2 * i + 1].x : cur[2 * i].x;
+            cur[i].y = hi ? cur[2 * i + 1].y : cur[2 * i].y;
+        }
+    }
+    return cur[0];
+}
+
 #define MAKE2(X, Y) (v2f{(X), (Y)})
 
 struct TailRec { unsigned w[64]; int idx[64]; float val[64]; double tot[64]; v2f l[64]; v2f r[64]; };

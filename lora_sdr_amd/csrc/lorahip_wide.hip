@@ -18,7 +18,7 @@
 
 namespace lorahip {
 
-template <int LOG2N_, int VEC_, int MINW_, int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_>
+template <int LOG2N_, int VEC_, int MINW_, int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, bool PREFETCH_ = true>
 struct WideCfg
 {
     static constexpr int LOG2N = LOG2N_, N = 1 << LOG2N_;
@@ -30,6 +30,7 @@ struct WideCfg
     static constexpr int WPWIN = T / 64;                        // wavefronts per window
     static constexpr int MINW = MINW_;
     static constexpr bool CH_LDS = CH_LDS_, TW_ALL_LDS = TW_ALL_LDS_;
+    static constexpr bool PREFETCH = PREFETCH_;                 // next set's samples in registers during this set (else: loaded at the top, hidden by co-resident workgroups)
     static constexpr int HB = LOG2N_ - B2;                      // = 4: position bits of the last phase
     static constexpr int NL = VEC_ * T, LOG2NL = LOG2N_ - B1;   // rows of exchange 0
     static_assert(B2 + 4 == LOG2N_, "VEC 1 <-> SF12, VEC 2 <-> SF11");
@@ -51,19 +52,6 @@ struct WideCfg
 };
 
 struct RedRec { float v; int i; double tot; };
-
-//! v[idx] for a wave-uniform idx: a scalar branch tree instead of 30 v_cndmask
-__device__ __forceinline__ v2f pickUniform16(const v2f (&v)[16], const int idx)
-{
-    switch (idx)
-    {
-#define LORAHIP_PICK(I) case I: return v[I];
-    LORAHIP_PICK(0) LORAHIP_PICK(1) LORAHIP_PICK(2) LORAHIP_PICK(3) LORAHIP_PICK(4) LORAHIP_PICK(5) LORAHIP_PICK(6) LORAHIP_PICK(7)
-    LORAHIP_PICK(8) LORAHIP_PICK(9) LORAHIP_PICK(10) LORAHIP_PICK(11) LORAHIP_PICK(12) LORAHIP_PICK(13) LORAHIP_PICK(14)
-#undef LORAHIP_PICK
-    default: return v[15];
-    }
-}
 
 template <class C>
 struct WideSmem
@@ -170,7 +158,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
             else xn[r][0] = *p;
         }
     };
-    issueLoads(blockIdx.x);
+    if (C::PREFETCH) issueLoads(blockIdx.x);
     const v2f fconst0 = gFine[0];
 
     // result of the previous set, waiting for its neighbours / tail record
@@ -216,6 +204,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         const bool moving = dechirp && d != 0.0f;
 
         v2f x[R][VEC];
+        if (!C::PREFETCH) issueLoads(set);
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
@@ -304,7 +293,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
 #pragma unroll
             for (int u = 0; u < VEC; u++) v0[u][Plan<LOG2N>::pos(VEC * T * r) & (R - 1)] = x[r][u];
         // next set's samples go in flight now (past the end: re-read the last set, harmless and branch-free)
-        issueLoads(set + gridDim.x < nSets ? set + gridDim.x : nSets - 1);
+        if (C::PREFETCH) issueLoads(set + gridDim.x < nSets ? set + gridDim.x : nSets - 1);
 #pragma unroll
         for (int u = 0; u < VEC; u++) runPhase<LOG2N, 0, B1, false>(v0[u], 0, sTw, nullptr);
 
@@ -377,13 +366,17 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
             }
         }
 
-        // ---- neighbours of the peak for fIndex (LoRaDetector.hpp:56-57): the owners post them. A wavefront
-        // belongs to one window, so the register number of a neighbour is wave-uniform: scalar select.
+        // ---- neighbours of the peak for fIndex (LoRaDetector.hpp:56-57): the owners post them. Only the
+        // wavefront(s) that hold bin k-1 / k+1 walk the register-select tree.
         {
             const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
             const bool ownL = (bl & (T - 1)) == t, ownR = (br & (T - 1)) == t;
-            if (__any(ownL)) { const v2f c = pickUniform16(vl, __builtin_amdgcn_readfirstlane(bl >> LOG2T)); if (ownL) sNb[wsub * 2] = c; }
-            if (__any(ownR)) { const v2f c = pickUniform16(vl, __builtin_amdgcn_readfirstlane(br >> LOG2T)); if (ownR) sNb[wsub * 2 + 1] = c; }
+            if (__any(ownL | ownR))
+            {
+                const v2f mine = selectFlat<16>(vl, ownL ? (bl >> LOG2T) : (br >> LOG2T));
+                if (ownL) sNb[wsub * 2] = mine;
+                if (ownR) sNb[wsub * 2 + 1] = mine;
+            }
         }
         havePrev = true; pActive = active; pW = w; pI = bestI; pV = bestV; pTot = tot;
     }
@@ -441,12 +434,16 @@ typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false> Cfg11b;
 typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  true,  false> Cfg11c;
 typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  false, true>  Cfg11d;
 typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  true,  true>  Cfg11e;
+typedef WideCfg<11,  2,  4,         0,  1,  4, 1,  false, false, false> Cfg11f;   // no register prefetch: 4 workgroups per CU
+typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, false> Cfg11g;
 // 256 lanes x 16 pts: [4,4] X [4,4] X [4,4]
 typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  false, false> Cfg12a;
 typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false> Cfg12b;
 typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  true,  false> Cfg12c;
 typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  false, true>  Cfg12d;
 typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  true,  true>  Cfg12e;
+typedef WideCfg<12,  1,  4,         0,  1,  0, 0,  false, false, false> Cfg12f;
+typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, false> Cfg12g;
 
 bool wideAvailable(const int sf) { return sf == 11 || sf == 12; }
 
@@ -457,11 +454,13 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
     case 11:
         switch (variant)
         {
-        case 2: return launchCfgWide<Cfg11b>(a, ft, stream);
+        case 2: return launchCfgWide<Cfg11a>(a, ft, stream);
         case 3: return launchCfgWide<Cfg11c>(a, ft, stream);
         case 4: return launchCfgWide<Cfg11d>(a, ft, stream);
         case 5: return launchCfgWide<Cfg11e>(a, ft, stream);
-        default: return launchCfgWide<Cfg11a>(a, ft, stream);
+        case 6: return launchCfgWide<Cfg11f>(a, ft, stream);
+        case 7: return launchCfgWide<Cfg11g>(a, ft, stream);
+        default: return launchCfgWide<Cfg11b>(a, ft, stream);   // measured best (profiles/r01)
         }
     case 12:
         switch (variant)
@@ -470,6 +469,8 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
         case 3: return launchCfgWide<Cfg12c>(a, ft, stream);
         case 4: return launchCfgWide<Cfg12d>(a, ft, stream);
         case 5: return launchCfgWide<Cfg12e>(a, ft, stream);
+        case 6: return launchCfgWide<Cfg12f>(a, ft, stream);
+        case 7: return launchCfgWide<Cfg12g>(a, ft, stream);
         default: return launchCfgWide<Cfg12b>(a, ft, stream);   // measured best (profiles/r01)
         }
     default: return hipErrorInvalidValue;
