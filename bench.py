@@ -179,6 +179,14 @@ def main():
         total_syms = W * a.steps * world
         value = total_syms / elapsed / 1e6
         launch_s = kernel_ms / 1e3 / a.steps
+        traffic = a.traffic
+        if traffic is None and a.channels is None and a.symbols is None:
+            # measured in a separate rocprofv3 --pmc pass of this same command (tools/gpu_session.sh pmc), committed
+            try:
+                t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["per_sf"][str(sf)]
+                traffic = t.get("total_bytes")
+            except Exception:
+                traffic = None
         alg_bytes = W * bytes_per_symbol(sf)
         achieved = alg_bytes / launch_s / 1e9
         line = {
@@ -193,7 +201,7 @@ def main():
                        "ramp_seconds": a.ramp_seconds},
             "symbol_error_rate_vs_sent": ser, "bin_offset": bin_offset,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": a.traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "lorahip detect (dechirp+FFT+detect fused)", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_symbol": bytes_per_symbol(sf)},
         }

@@ -46,10 +46,10 @@ std::vector<cf32> buildStageTwiddles(const int sf, const std::vector<cf32> &tw)
  *   groups and the readers' ds_read_b64 groups each tile the LDS banks exactly once.
  **********************************************************************/
 template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_,
-          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, bool PREFETCH_>
+          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_>
 struct FastCfg
 {
-    static constexpr bool PREFETCH = PREFETCH_;       // issue the next window set's loads right after the dechirp of this one
+    static constexpr int PREFETCH = PREFETCH_;        // next window set's loads: 0 none (loaded at the top), 1 issued after the dechirp of this set, 2 at the top of this set
     static constexpr bool CH_LDS = CH_LDS_;           // chirp table read from LDS per window (else loop-invariant registers)
     static constexpr bool TW_ALL_LDS = TW_ALL_LDS_;   // last-phase twiddles from the LDS table too (else registers)
     static constexpr int LOG2N = LOG2N_, N = 1 << LOG2N_;
@@ -226,6 +226,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int u = 0; u < VEC; u++) x[r][u] = xn[r][u];
+        if (C::PREFETCH == 2) issueLoads(set + waveCount < nSets ? set + waveCount : nSets - 1);
 
         // ---- fine-tune index chain for windows whose index moves (rare path) -----------------
         int *sIdx = reinterpret_cast<int *>(X) + wsub * N;   // aliases the exchange region (free until phase 0 ends)
@@ -311,7 +312,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             for (int u = 0; u < VEC; u++) v0[u][Plan<LOG2N>::pos(VEC * T * r) & (R - 1)] = x[r][u];
         // next set's samples go in flight now and land while this set is transformed (past the end:
         // re-read the last set, harmless and branch-free)
-        if (C::PREFETCH) issueLoads(set + waveCount < nSets ? set + waveCount : nSets - 1);
+        if (C::PREFETCH == 1) issueLoads(set + waveCount < nSets ? set + waveCount : nSets - 1);
 #pragma unroll
         for (int u = 0; u < VEC; u++) runPhase<LOG2N, 0, B1, false>(v0[u], 0, sTw, nullptr);
 
@@ -500,9 +501,13 @@ typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  
 typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  true,  true,  true>  Cfg7c;
 typedef FastCfg<7,  3, 2,  2,  3,  7,  4,          1,  1,  0, 0,  true,  true,  false> Cfg7d;
 typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  false, false, true>  Cfg7e;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg8;    // 16 lanes x 16 pts: [4,4] X [4,4]
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  2>     Cfg7f;   // loads issued at the top of the set
+typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg8;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  2>     Cfg8f;    // 16 lanes x 16 pts: [4,4] X [4,4]
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  true>  Cfg9;    // 32 lanes x 16 pts: [R2,4] X [4,4] X [4]
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg10;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
+typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  2>     Cfg9f;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg10;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  2>     Cfg10f;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
 
 bool fastAvailable(const int sf) { return sf >= 7 && sf <= 10; }
 
@@ -517,11 +522,12 @@ hipError_t launchFast(const int sf, const int variant, const DetectArgs &a, cons
         case 3: return launchCfg<Cfg7c>(a, ft, stream);
         case 4: return launchCfg<Cfg7d>(a, ft, stream);
         case 5: return launchCfg<Cfg7e>(a, ft, stream);
+        case 6: return launchCfg<Cfg7f>(a, ft, stream);
         default: return launchCfg<Cfg7b>(a, ft, stream);
         }
-    case 8: return launchCfg<Cfg8>(a, ft, stream);
-    case 9: return launchCfg<Cfg9>(a, ft, stream);
-    case 10: return launchCfg<Cfg10>(a, ft, stream);
+    case 8: return variant == 6 ? launchCfg<Cfg8f>(a, ft, stream) : launchCfg<Cfg8>(a, ft, stream);
+    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : launchCfg<Cfg9>(a, ft, stream);
+    case 10: return variant == 6 ? launchCfg<Cfg10f>(a, ft, stream) : launchCfg<Cfg10>(a, ft, stream);
     default: return hipErrorInvalidValue;
     }
 }

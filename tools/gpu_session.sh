@@ -47,7 +47,7 @@ if [[ $what == *prof* ]]; then
 fi
 
 if [[ $what == *pmc* ]]; then
-  for sf in 7 12; do
+  for sf in ${PMCSF:-7 8 9 10 11 12}; do
     for c in FETCH_SIZE WRITE_SIZE; do
       ( cd /tmp && timeout 600 rocprofv3 --pmc $c -d $O/pmc_${c}_sf$sf -o pmc --output-format csv -- \
           python $R/bench.py --sf $sf --steps 5 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $O/pmc_${c}_sf$sf.log 2>&1 )

@@ -33,3 +33,35 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         elif c == "WRITE_SIZE":
             extra = "  -> %.3f MB/dispatch as counted" % (mean / 1024)
         print("  %-60s %-12s n=%d mean=%.1f%s" % (k, c, len(v), mean, extra))
+
+
+# ---- HBM traffic per launch of the detect kernel, for bench.py's roofline.traffic -----------------------
+# FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (gfx950 counts a wide coalesced streaming read at half
+# its bytes, MI355X_MICROARCH.md "HBM"); WRITE_SIZE is taken as counted (uncalibrated for 2..4-byte scattered stores).
+import json
+import re
+traffic = {}
+for d in sorted(glob.glob(os.path.join(root, "pmc_*_sf*"))):
+    m = re.match(r"pmc_(FETCH_SIZE|WRITE_SIZE)_sf(\d+)$", os.path.basename(d))
+    if not m:
+        continue
+    vals = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f, newline="")):
+            if "lorahip::detect" in row.get("Kernel_Name", "") and row.get("Counter_Name") == m.group(1):
+                vals.append(float(row["Counter_Value"]))
+    if vals:
+        kb = sum(vals) / len(vals)
+        t = traffic.setdefault(m.group(2), {})
+        if m.group(1) == "FETCH_SIZE":
+            t["fetch_bytes"] = 2 * kb * 1024
+        else:
+            t["write_bytes"] = kb * 1024
+for sf, t in traffic.items():
+    if "fetch_bytes" in t and "write_bytes" in t:
+        t["total_bytes"] = t["fetch_bytes"] + t["write_bytes"]
+if traffic:
+    out = os.path.join(root, "traffic.json")
+    json.dump({"note": "HBM bytes per launch of the detect kernel at bench.py's default geometry; rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate passes",
+               "per_sf": traffic}, open(out, "w"), indent=1, sort_keys=True)
+    print("wrote", out)
