@@ -146,6 +146,47 @@ __device__ __forceinline__ v2f selectFlat(const v2f (&v)[CNT], const int idx)
     return cur[0];
 }
 
+/*! The fine-tune index recurrence (LoRaDemod.cpp:160-162), idx_{i+1} = f(idx_i), over T*P consecutive samples,
+ * evaluated by a group of T lanes (T <= 64, aligned, inside one wavefront) and EXACTLY: lane t walks the P consecutive
+ * samples [P*t, P*t+P) with the true step function from a guessed start; the guesses are then checked against the
+ * predecessors' end values, corrected by the prefix sum of the mismatches (exact wherever f commutes with a shift, i.e.
+ * away from wraps and float-exponent boundaries) and re-walked until every lane's start equals its predecessor's end.
+ * The first lane with a wrong start is always repaired exactly, so T rounds bound the loop; 1-2 are typical. Every
+ * lane of the wavefront must call it (groups with d == 0 converge at once). Writes the index of sample P*t+i to
+ * sIdx[i*T + t] (lane-major: conflict-free) and returns the index after the T*P steps in every lane of the group. */
+template <int T, int P, int M>
+__device__ __forceinline__ int fineChainGroup(const int idx0, const float d, const int t, int *sIdx)
+{
+    const int first = fineStep(idx0, d, M);
+    int c = first - idx0;                               // nominal step, wrap removed
+    if (c > M / 2) c -= M;
+    else if (c < -M / 2) c += M;
+    int g = (idx0 + c * (P * t)) & (M - 1);            // |c*P*t| < 2^30; M is a power of two
+    int loc[P];
+    int e = 0;
+    for (int round = 0; round <= T; round++)
+    {
+        int idx = g;
+#pragma unroll
+        for (int i = 0; i < P; i++) { loc[i] = idx; idx = fineStep(idx, d, M); }
+        e = idx;
+        const int prevE = __shfl_up(e, 1, T);
+        int delta = t == 0 ? ((idx0 - g) & (M - 1)) : ((prevE - g) & (M - 1));
+        if (!__any(delta != 0)) break;
+        // inclusive prefix sum of the mismatches over the group's lanes (mod M)
+#pragma unroll
+        for (int off = 1; off < T; off <<= 1)
+        {
+            const int o = __shfl_up(delta, off, T);
+            if (t >= off) delta += o;
+        }
+        g = (g + delta) & (M - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) sIdx[i * T + t] = loc[i];
+    return __shfl(e, T - 1, T);
+}
+
 #define MAKE2(X, Y) (v2f{(X), (Y)})
 
 struct TailRec { unsigned w[64]; int idx[64]; float val[64]; double tot[64]; v2f l[64]; v2f r[64]; };

@@ -53,6 +53,9 @@ struct WideCfg
 
 struct RedRec { float v; int i; double tot; };
 
+//! where fineChainGroup<64,16> (1024-sample chunks) leaves the index of sample n
+__device__ __forceinline__ int chainSlot(const int n) { return (n & ~1023) + (n & 15) * 64 + ((n >> 4) & 63); }
+
 template <class C>
 struct WideSmem
 {
@@ -218,11 +221,13 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
             anyMoving = __syncthreads_or(moving);
             if (anyMoving)
             {
-                if (moving && t == 0)
+                // the window's first wavefront walks the chain, 1024 samples (64 lanes x 16) at a time
+                if (t < 64)
                 {
                     int idx = idx0;
-                    for (int i = 0; i < N; i++) { sIdx[i] = idx; idx = fineStep(idx, d, M); }
-                    if (a.fineIdxOut && active) a.fineIdxOut[w] = idx;
+                    for (int chunk = 0; chunk < N / 1024; chunk++)
+                        idx = fineChainGroup<64, 16, M>(idx, moving ? d : 0.0f, t, sIdx + chunk * 1024);
+                    if (moving && t == 0 && a.fineIdxOut && active) a.fineIdxOut[w] = idx;
                 }
                 __syncthreads();
             }
@@ -272,7 +277,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
                 {
                     const v2f c = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
                     v2f f = fconst;
-                    if (anyMoving && moving) f = gFine[sIdx[VEC * t + u + VEC * T * r]];
+                    if (anyMoving && moving) f = gFine[sIdx[chainSlot(VEC * t + u + VEC * T * r)]];
                     const v2f y = cmulv(cmulv(x[r][u], c), f);
                     x[r][u] = dechirp ? y : x[r][u];
                 }

@@ -144,7 +144,7 @@ def test_chirp_tables_and_none(gpu, oracle, sf):
         check(o, g, where="sel_all=%d sf%d" % (s, sf))
 
 
-@pytest.mark.parametrize("sf", [7, 8, 10, 12])
+@pytest.mark.parametrize("sf", [6, 7, 8, 9, 10, 11, 12])
 def test_fine_tune_recurrence(gpu, oracle, sf):
     """LoRaDemod.cpp:160-162: the int<-float index recurrence for many (idx0, err) pairs,
     including wrap in both directions, integer and tiny steps, and large indices where
