@@ -150,6 +150,12 @@ int lorahip_demod_set_sync(lorahip_demod *d, unsigned char sync);        /* setS
 int lorahip_demod_set_threshold(lorahip_demod *d, double thresh_dB);     /* setThreshold  :129 */
 int lorahip_demod_set_mtu(lorahip_demod *d, size_t mtu);                 /* setMTU        :134 */
 int lorahip_demod_activate(lorahip_demod *d);                            /* activate()    :139 */
+/* How work() rounds are driven: 0 = auto (1 where a streaming kernel exists for the SF, else 2),
+ * 1 = on the device: one streaming kernel walks every channel's stream window after window with the frame
+ *     machine (LoRaDemod.cpp:176-312) in registers; no host round trip between the windows of a channel,
+ * 2 = from the host: one batch launch per lock-step round, the frame machine on the host between launches.
+ * Both produce identical packets, traces and signals. */
+int lorahip_demod_set_mode(lorahip_demod *d, int mode);
 
 /* Per-channel outcome of one work() round (what the block would have done on its ports). */
 typedef struct lorahip_work_result {

@@ -295,6 +295,10 @@ class LoRaDemod:
     def activate(self):
         check(self._lib.lorahip_demod_activate(self._h), "lorahip_demod_activate")
 
+    def set_mode(self, mode):
+        """0 auto, 1 streaming kernel (frame machine on the device), 2 host-driven lock-step rounds"""
+        check(self._lib.lorahip_demod_set_mode(self._h, int(mode)), "lorahip_demod_set_mode")
+
     def set_trace(self, on=True):
         check(self._lib.lorahip_demod_set_trace(self._h, int(bool(on))), "lorahip_demod_set_trace")
 

@@ -11,6 +11,7 @@
 // The three members the reference leaves uninitialised (_finefreqError, _freqError,
 // _prevValue) start at zero here.
 #include "lorahip_internal.h"
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -58,6 +59,9 @@ struct lorahip_demod
     char *h, *d;
     size_t stageBytes;
     float *dIq; size_t dIqSamples;   // owned upload buffer for lorahip_demod_run
+    int mode;                        // 0 auto, 1 device streaming kernel, 2 host-driven rounds
+    // streaming path: device + pinned-host mirrors, grown on demand
+    char *sDev, *sHost; size_t sBytes;
 };
 
 namespace {
@@ -280,6 +284,132 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     return LORAHIP_OK;
 }
 
+
+/***********************************************************************
+ * Streaming path: the device walks every channel (lorahip_stream.hip); the host only drains the
+ * per-call records, assembles the packets and keeps the Channel mirrors in step.
+ **********************************************************************/
+static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
+{
+    lorahip_ctx *ctx = dm->ctx;
+    const size_t N = dm->N, B = dm->B;
+    LORAHIP_TRY(hipSetDevice(ctx->device));
+    size_t maxLen = 0;
+    for (size_t c = 0; c < B; c++) if (dm->ch[c].len - dm->ch[c].pos > maxLen) maxLen = dm->ch[c].len - dm->ch[c].pos;
+    // records per channel per launch: enough for a clean stream, bounded so that the buffer stays <= 256 MiB
+    size_t cap = maxLen / N + 16;
+    if (cap > 4096) cap = 4096;
+    const size_t capMem = (size_t(256) << 20) / (B * sizeof(lorahip_work_result));
+    if (cap > capMem) cap = capMem;
+    if (cap < 8) cap = 8;
+
+    size_t cur = 0;
+    auto carveS = [&cur](const size_t bytes) { const size_t o = cur; cur += align256(bytes); return o; };
+    const size_t oBase = carveS(B * sizeof(long long)), oLen = carveS(B * sizeof(long long));
+    const size_t oState = carveS(B * sizeof(StreamState)), oN = carveS(B * sizeof(int));
+    const size_t oCalls = carveS(B * cap * sizeof(lorahip_work_result));
+    if (cur > dm->sBytes)
+    {
+        if (dm->sDev) { (void)hipFree(dm->sDev); dm->sDev = nullptr; }
+        if (dm->sHost) { (void)hipHostFree(dm->sHost); dm->sHost = nullptr; }
+        dm->sBytes = 0;
+        LORAHIP_TRY(hipMalloc((void **)&dm->sDev, cur));
+        LORAHIP_TRY(hipHostMalloc((void **)&dm->sHost, cur, hipHostMallocDefault));
+        dm->sBytes = cur;
+    }
+    char *h = dm->sHost, *d = dm->sDev;
+    long long *hBase = reinterpret_cast<long long *>(h + oBase), *hLen = reinterpret_cast<long long *>(h + oLen);
+    StreamState *hState = reinterpret_cast<StreamState *>(h + oState);
+    int *hN = reinterpret_cast<int *>(h + oN);
+    lorahip_work_result *hCalls = reinterpret_cast<lorahip_work_result *>(h + oCalls);
+    for (size_t c = 0; c < B; c++)
+    {
+        const Channel &k = dm->ch[c];
+        hBase[c] = (long long)k.base;
+        hLen[c] = (long long)k.len;
+        StreamState &st = hState[c];
+        st.state = k.state; st.downTable = k.downTable ? 1 : 0; st.prevValue = k.prevValue; st.freqError = k.freqError;
+        st.fineTuneIndex = k.fineTuneIndex; st.finefreqError = k.finefreqError; st.symCount = int(k.symCount); st.pad = 0;
+        st.pos = (long long)k.pos;
+    }
+    LORAHIP_TRY(hipMemcpyAsync(d, h, oN, hipMemcpyHostToDevice, ctx->stream));       // base, len, state
+
+    StreamArgs a;
+    a.iq = reinterpret_cast<const float2 *>(iqDev);
+    a.base = reinterpret_cast<const long long *>(d + oBase);
+    a.len = reinterpret_cast<const long long *>(d + oLen);
+    a.state = reinterpret_cast<StreamState *>(d + oState);
+    a.nCalls = reinterpret_cast<int *>(d + oN);
+    a.calls = reinterpret_cast<lorahip_work_result *>(d + oCalls);
+    a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
+    a.nChannels = unsigned(B);
+    a.cap = int(cap);
+    a.powerScale = ctx->powerScale;
+    a.thresh = dm->thresh;
+    a.sync = dm->sync;
+    a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
+
+    std::vector<int64_t> callIndex(B, 0);
+    const size_t firstNewPacket = dm->packets.size();
+    while (true)
+    {
+        LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
+        LORAHIP_TRY(hipMemcpyAsync(h + oState, d + oState, cur - oState, hipMemcpyDeviceToHost, ctx->stream));   // state, nCalls, calls
+        LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+        bool more = false;
+        for (size_t c = 0; c < B; c++)
+        {
+            Channel &k = dm->ch[c];
+            const lorahip_work_result *rec = hCalls + c * cap;
+            for (int i = 0; i < hN[c]; i++)
+            {
+                const lorahip_work_result &r = rec[i];
+                if (r.state_before == ST_QUARTERCHIRP) k.symCount = 0;                // :279
+                else if (r.state_before == ST_DATASYMBOLS)
+                {
+                    if (k.outSymbols.size() <= k.symCount) k.outSymbols.resize(k.symCount + 1, 0);
+                    k.outSymbols[k.symCount++] = int16_t(r.value);                    // :290
+                    if (r.packet_len > 0)
+                    {
+                        Packet p;
+                        p.channel = int32_t(c);
+                        p.round = callIndex[c];
+                        p.syms.assign(k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
+                        dm->packets.push_back(p);
+                    }
+                }
+                callIndex[c]++;
+                dm->workCalls++;
+                if (dm->tracing) k.trace.push_back(r);
+            }
+            if (size_t(hN[c]) == cap) more = true;
+        }
+        if (!more) break;
+    }
+    int64_t rounds = 0;
+    for (size_t c = 0; c < B; c++)
+    {
+        Channel &k = dm->ch[c];
+        const StreamState &st = hState[c];
+        k.state = st.state; k.downTable = st.downTable != 0; k.prevValue = short(st.prevValue); k.freqError = st.freqError;
+        k.fineTuneIndex = st.fineTuneIndex; k.finefreqError = st.finefreqError; k.symCount = size_t(st.symCount);
+        k.pos = size_t(st.pos);
+        if (callIndex[c] > rounds) rounds = callIndex[c];
+    }
+    // the host-driven path posts packets round by round, channels in order inside a round
+    std::stable_sort(dm->packets.begin() + long(firstNewPacket), dm->packets.end(),
+                     [](const Packet &x, const Packet &y) { return x.round != y.round ? x.round < y.round : x.channel < y.channel; });
+    if (roundsOut) *roundsOut = rounds;
+    return LORAHIP_OK;
+}
+
+static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
+{
+    const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(dm->ctx->sf));
+    if (stream && !streamAvailable(dm->ctx->sf)) { setLastError("no streaming kernel for this SF"); return LORAHIP_E_INVALID; }
+    return stream ? runStream(dm, iqDev, roundsOut) : runRounds(dm, iqDev, roundsOut);
+}
+
 } // namespace
 
 extern "C" {
@@ -291,6 +421,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     lorahip_demod *dm = new (std::nothrow) lorahip_demod();
     if (dm == nullptr) return LORAHIP_E_NOMEM;
     dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
+    dm->mode = 0; dm->sDev = nullptr; dm->sHost = nullptr; dm->sBytes = 0;
     int rc = lorahip_create(&dm->ctx, device, sf);
     if (rc != LORAHIP_OK) { delete dm; return rc; }
     dm->N = size_t(1) << sf;
@@ -318,6 +449,8 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->d) (void)hipFree(dm->d);
     if (dm->h) (void)hipHostFree(dm->h);
     if (dm->dIq) (void)hipFree(dm->dIq);
+    if (dm->sDev) (void)hipFree(dm->sDev);
+    if (dm->sHost) (void)hipHostFree(dm->sHost);
     lorahip_destroy(dm->ctx);
     delete dm;
 }
@@ -343,6 +476,13 @@ int lorahip_demod_set_mtu(lorahip_demod *dm, const size_t mtu)
     return LORAHIP_OK;
 }
 
+int lorahip_demod_set_mode(lorahip_demod *dm, const int mode)
+{
+    if (dm == nullptr || mode < 0 || mode > 2) return LORAHIP_E_INVALID;
+    dm->mode = mode;
+    return LORAHIP_OK;
+}
+
 int lorahip_demod_activate(lorahip_demod *dm)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
@@ -361,7 +501,7 @@ int lorahip_demod_run_device(lorahip_demod *dm, const float *iq_dev, const size_
         dm->ch[c].len = samples_per_channel;
         dm->ch[c].pos = 0;
     }
-    return runRounds(dm, iq_dev, rounds);
+    return runAny(dm, iq_dev, rounds);
 }
 
 int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size_t *n_samples, int64_t *rounds)
@@ -388,7 +528,7 @@ int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size
             LORAHIP_TRY(hipMemcpyAsync(dm->dIq + 2 * dm->ch[c].base, streams[c], n_samples[c] * sizeof(cf32),
                                        hipMemcpyHostToDevice, dm->ctx->stream));
     LORAHIP_TRY(hipStreamSynchronize(dm->ctx->stream));
-    return runRounds(dm, dm->dIq, rounds);
+    return runAny(dm, dm->dIq, rounds);
 }
 
 size_t lorahip_demod_num_packets(const lorahip_demod *dm) { return dm ? dm->packets.size() : 0; }

@@ -248,21 +248,31 @@ __device__ __forceinline__ double hypotd(const float a, const float b)
     return (s == 0.0 || s != s || s == __builtin_inf()) ? s : y2;
 }
 
+//! LoRaDetector.hpp:50-61 for one window: power, powerAvg, fIndex from the peak, the fp64 total and the peak's neighbours
+template <class CPX>
+__device__ __forceinline__ void tailValues(const float powerScale, const float maxValue, const double total,
+                                           const CPX leftBin, const CPX rightBin,
+                                           float &power, float &powerAvg, float &fIndex)
+{
+    const float noise = sqrtf((float)(total - (double)maxValue));
+    const float fundamental = sqrtf(maxValue);
+    powerAvg = 20 * (float)log10d((double)noise) - powerScale;
+    power = 20 * (float)log10d((double)fundamental) - powerScale;
+    // std::abs(complex<float>) = hypotf
+    const float left = (float)hypotd(leftBin.x, leftBin.y);
+    const float right = (float)hypotd(rightBin.x, rightBin.y);
+    const double demon = (2.0 * (double)fundamental) - (double)right - (double)left;
+    fIndex = 0.0f;
+    if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
+}
+
 template <class CPX>
 __device__ __forceinline__ void detectTail(const DetectArgs &a, const unsigned w, const int maxIndex,
                                            const float maxValue, const double total,
                                            const CPX leftBin, const CPX rightBin)
 {
-    const float noise = sqrtf((float)(total - (double)maxValue));
-    const float fundamental = sqrtf(maxValue);
-    const float powerAvg = 20 * (float)log10d((double)noise) - a.powerScale;
-    const float power = 20 * (float)log10d((double)fundamental) - a.powerScale;
-    // std::abs(complex<float>) = hypotf
-    const float left = (float)hypotd(leftBin.x, leftBin.y);
-    const float right = (float)hypotd(rightBin.x, rightBin.y);
-    const double demon = (2.0 * (double)fundamental) - (double)right - (double)left;
-    float fIndex = 0.0f;
-    if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
+    float power, powerAvg, fIndex;
+    tailValues(a.powerScale, maxValue, total, leftBin, rightBin, power, powerAvg, fIndex);
     a.sym[w] = (unsigned short)maxIndex;
     a.power[w] = power;
     a.powerAvg[w] = powerAvg;

@@ -54,12 +54,46 @@ struct FastTables
 //! host: stage-major twiddle table from kissfft's table (lorahip_fast.hip)
 std::vector<cf32> buildStageTwiddles(int sf, const std::vector<cf32> &tw);
 
+//! per-channel state of the LoRaDemod block as the streaming kernel keeps it (LoRaDemod.cpp:385-392)
+struct StreamState
+{
+    int state;              // 0 FRAMESYNC .. 4 DATASYMBOLS
+    int downTable;          // _chirpTable == _downChirpTable
+    int prevValue;          // short _prevValue
+    int freqError;
+    int fineTuneIndex;
+    float finefreqError;
+    int symCount;
+    int pad;
+    long long pos;          // samples consumed so far
+};
+
+//! argument block of the streaming demod kernel (lorahip_stream.hip); all pointers are device pointers
+struct StreamArgs
+{
+    const float2 *iq;
+    const long long *base;      // [nChannels] first sample of the channel's stream in iq
+    const long long *len;       // [nChannels] samples available
+    StreamState *state;         // [nChannels] in/out
+    lorahip_work_result *calls; // [nChannels][cap] one record per work() call
+    int *nCalls;                // [nChannels] records written by this launch
+    const float2 *down, *fine, *twStage;
+    unsigned nChannels;
+    int cap;
+    float powerScale;
+    float thresh;
+    int sync;
+    unsigned mtu;
+};
+
 //! launchers (lorahip_kernels.hip / lorahip_fast.hip)
 hipError_t launchDetect(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
 bool fastAvailable(int sf);
 hipError_t launchFast(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
 bool wideAvailable(int sf);
 hipError_t launchWide(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
+bool streamAvailable(int sf);
+hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchSynth(int sf, float2 *iq, const unsigned short *sym, size_t nWindows,
                        float ampl, float sigma, unsigned long long seed, hipStream_t stream);
 

@@ -1,0 +1,255 @@
+// Streaming demodulator: the whole LoRaDemod::work() loop of a channel on the device.
+//
+// The batch kernels (lorahip_fast.hip) need the host between two windows of the same channel, because the
+// reference's frame machine decides from window k where window k+1 starts (LoRaDemod.cpp:219 `total = N - value`,
+// :278 `N/4 + freqError/2`, :209 two windows at once). Here a group of T lanes OWNS a channel and walks its stream
+// window after window: load -> fine-tune index chain -> dechirp -> FFT -> detect -> power/SNR/fIndex -> the
+// reference's 5-state machine (LoRaDemod.cpp:176-312) in registers -> one record per work() call. Channels are the
+// only parallel axis: a wavefront carries 64/T of them, a launch carries all of them, and nothing returns to the
+// host until every channel has fewer than 2N samples left (or has filled its record buffer: the launch is
+// resumable from the saved per-channel state).
+//
+// Numerics are those of the batch kernels (same FastCore, same tables); the state machine is the one of
+// lorahip_demod.cpp's host path, which tests pin against the verbatim LoRaDemod.cpp.
+#include "lorahip_fastcore.h"
+
+namespace lorahip {
+
+enum { ST_FRAMESYNC = 0, ST_DOWNCHIRP0, ST_DOWNCHIRP1, ST_QUARTERCHIRP, ST_DATASYMBOLS };
+
+template <class C>
+__global__ void __launch_bounds__(256, C::WAVES_PER_SIMD)
+demodStream(const StreamArgs s)
+{
+    typedef FastCore<C> K;
+    constexpr int N = C::N, T = C::T, VEC = C::VEC, R = C::R, WPW = C::WPW;
+    constexpr int LOG2T = C::LOG2T;
+    constexpr int NGL = C::NGL, GL = C::GL;
+    constexpr int FS = C::FS, XW = C::XW;
+    constexpr int WAVES = 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smemRaw[];
+    v2f *sTw = reinterpret_cast<v2f *>(smemRaw);          // [TWN]
+    v2f *sCh = sTw + C::TWN;                                // [N] down-chirp table (the up-chirp is its conjugate)
+    v2f *sX = sCh + N;                                      // [WAVES][XW]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wsub = lane >> LOG2T;                        // channel inside the wavefront
+    const int t = lane & (T - 1);
+    v2f *X = sX + wave * XW;
+
+    const v2f *gIq = reinterpret_cast<const v2f *>(s.iq), *gFine = reinterpret_cast<const v2f *>(s.fine);
+    for (int i = threadIdx.x; i < C::TW_LDS; i += blockDim.x) sTw[i] = reinterpret_cast<const v2f *>(s.twStage)[i];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) sCh[i] = reinterpret_cast<const v2f *>(s.down)[i];
+    typename K::TwR twR;
+    K::loadTwR(twR, reinterpret_cast<const v2f *>(s.twStage), t);
+    __syncthreads();
+
+    // ---- this lane group's channel and its state (replicated in the T lanes) ----------------------
+    const unsigned c = (blockIdx.x * WAVES + wave) * WPW + wsub;
+    const bool mine = c < s.nChannels;
+    const unsigned cc = mine ? c : 0;
+    StreamState st = s.state[cc];
+    const long long base = s.base[cc], len = mine ? s.len[cc] : 0;
+    int calls = 0;
+    lorahip_work_result *out = s.calls + (size_t)cc * s.cap;
+
+    // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
+    // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
+    auto detect = [&](const bool on, const long long off, const bool downTable, const int idx0, const float err,
+                      int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd)
+    {
+        v2f x[R][VEC];
+        K::load(x, gIq + (on ? off : 0), t);
+        const float d = err * (float)LORAHIP_FINE_STEPS;
+        const bool moving = on && d != 0.0f;
+        int *sIdx = reinterpret_cast<int *>(X) + wsub * N;
+        idxEnd = idx0;
+        const bool anyMoving = __any(moving);
+        if (anyMoving)
+        {
+            const int e = K::fineChain(idx0, moving ? d : 0.0f, t, sIdx);
+            if (moving) idxEnd = e;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        v2f cw[R][VEC];
+        K::chirpFromLds(cw, sCh, t);
+        const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
+        const v2f fconst = gFine[idx0];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int u = 0; u < VEC; u++)
+            {
+                const v2f cv = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
+                v2f f = fconst;
+                if (anyMoving && moving) f = gFine[sIdx[K::idxSlot(VEC * t + u + VEC * T * r)]];
+                x[r][u] = cmulv(cmulv(x[r][u], cv), f);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        v2f vl[NGL][GL];
+        K::fft(x, X, wsub, t, sTw, twR, vl, []() {});
+        v2f *F = X + wsub * FS;
+        float bestV;
+        int bestI;
+        double tot;
+        K::scan(vl, F, nullptr, t, bestV, bestI, tot);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const v2f l = F[(bestI + N - 1) & (N - 1)], r = F[(bestI + 1) & (N - 1)];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        tailValues(s.powerScale, bestV, tot, l, r, power, powerAvg, fIndex);
+        value = bestI;
+    };
+
+    while (true)
+    {
+        const bool live = mine && (len - st.pos >= 2 * N) && calls < s.cap;           // LoRaDemod.cpp:148
+        if (!__any(live)) break;
+
+        // ---- window 0 (:157-172) ----
+        int value, idxEnd;
+        float power, powerAvg, fIndex;
+        detect(live, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd);
+        const float snr = power - powerAvg;                                             // :173
+        const bool squelched = snr < s.thresh;                                          // :174
+        const int stateBefore = st.state;
+        if (live) st.fineTuneIndex = idxEnd;                                            // the loop commits the member (:160-162)
+
+        // ---- FRAMESYNC: second window when sync'd and the first sync word matches (:183-206) ----
+        const bool syncd = !squelched && (st.prevValue + 4) / 8 == 0;                  // :183
+        const bool match0 = (value + 4) / 8 == (s.sync >> 4);                          // :184
+        const bool need1 = live && st.state == ST_FRAMESYNC && syncd && match0;
+        bool match1 = false;
+        if (__any(need1))
+        {
+            int value1, idxEnd1;
+            float p1, pa1, fi1;
+            // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
+            detect(need1, base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, p1, pa1, fi1, idxEnd1);
+            if (need1)
+            {
+                match1 = (value1 + 4) / 8 == (s.sync & 0xf);                           // :205
+                power = p1; powerAvg = pa1; fIndex = fi1;                               // detect() overwrites the locals (:203); snr is not recomputed
+            }
+        }
+
+        // ---- the frame machine (:176-312) ----
+        int total = 0, packetLen = 0, signals = 0, sigError = 0;
+        if (live)
+        {
+            switch (st.state)
+            {
+            case ST_FRAMESYNC:
+                if (syncd && match0 && match1) { total = 2 * N; st.state = ST_DOWNCHIRP0; st.downTable = 1; }   // :209-213
+                else if (!squelched) { total = N - value; st.finefreqError += fIndex; }                          // :217-221
+                else { total = N; st.finefreqError = 0.0f; st.fineTuneIndex = 0; }                               // :228-233
+                break;
+            case ST_DOWNCHIRP0:
+            {
+                st.state = ST_DOWNCHIRP1;
+                total = N;
+                int error = value;
+                if (value > N / 2) error -= N;
+                st.freqError = error;                                                                            // :246-249
+            } break;
+            case ST_DOWNCHIRP1:
+            {
+                st.state = ST_QUARTERCHIRP;
+                total = N;
+                st.downTable = 0;
+                int error = value;
+                if (value > N / 2) error -= N;
+                st.freqError = (st.freqError + error) / 2;                                                       // :262-265
+                signals = 1; sigError = st.freqError;                                                            // :267-269
+            } break;
+            case ST_QUARTERCHIRP:
+                st.state = ST_DATASYMBOLS;
+                total = N / 4 + st.freqError / 2;                                                                // :278
+                st.finefreqError += (float)(st.freqError / 2);
+                st.symCount = 0;
+                break;
+            default: // ST_DATASYMBOLS
+                total = N;
+                st.symCount++;                                                                                   // out[_symCount++] = value  :290
+                if ((unsigned)st.symCount >= s.mtu || squelched)                                                 // :291
+                {
+                    packetLen = st.symCount;
+                    st.finefreqError = 0.0f;
+                    st.state = ST_FRAMESYNC;
+                }
+                break;
+            }
+            st.prevValue = (short)value;                                                                         // :326
+            st.pos += total;                                                                                     // consume(total)  :320
+            if (t == 0)
+            {
+                lorahip_work_result r;
+                r.consumed = total;
+                r.state_before = stateBefore;
+                r.value = value;
+                r.power = power; r.power_avg = powerAvg; r.snr = snr; r.f_index = fIndex;
+                r.worked = 1;
+                r.packet_len = packetLen;
+                r.signals = signals;
+                r.sig_error = sigError;
+                r.sig_power = signals ? power : 0.0f;
+                r.sig_snr = signals ? snr : 0.0f;
+                out[calls] = r;
+            }
+            calls++;
+        }
+    }
+    if (mine && t == 0)
+    {
+        s.state[c] = st;
+        s.nCalls[c] = calls;
+    }
+}
+
+template <class C>
+static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
+{
+    constexpr int WAVES = 4;
+    const size_t smem = size_t(C::TWN + C::N) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2);
+    static bool attrSet = false;
+    if (!attrSet)
+    {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(demodStream<C>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        if (e != hipSuccess) return e;
+        attrSet = true;
+    }
+    const unsigned perBlock = WAVES * C::WPW;
+    const unsigned grid = (s.nChannels + perBlock - 1) / perBlock;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL((demodStream<C>), dim3(grid), dim3(WAVES * 64), smem, stream, s);
+    return hipGetLastError();
+}
+
+//             LOG2N T VEC NPH PB1 PB2 w/SIMD  X0: ROT PAD S  D   chLDS twLDS prefetch
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  0> Stream7;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  0> Stream8;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  true,  true,  0> Stream9;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  true,  true,  0> Stream10;
+
+bool streamAvailable(const int sf) { return sf >= 7 && sf <= 10; }
+
+hipError_t launchStream(const int sf, const StreamArgs &s, hipStream_t stream)
+{
+    switch (sf)
+    {
+    case 7: return launchStreamCfg<Stream7>(s, stream);
+    case 8: return launchStreamCfg<Stream8>(s, stream);
+    case 9: return launchStreamCfg<Stream9>(s, stream);
+    case 10: return launchStreamCfg<Stream10>(s, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace lorahip

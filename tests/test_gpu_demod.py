@@ -33,12 +33,17 @@ def compare_channel(tr, ref_calls):
             assert abs(a["power"] - b["power"]) <= TOL_DB
 
 
-def test_config1_single_channel_sf7_loopback(gpu, oracle):
+MODES = [1, 2]     # 1 = streaming kernel (frame machine on the device), 2 = host-driven lock-step rounds
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_config1_single_channel_sf7_loopback(gpu, oracle, mode):
     """BASELINE configs[0]: single channel SF=7, modulator frame -> demod -> sent symbols (no noise)"""
     import lora_sdr_amd as L
     rng = np.random.default_rng(1)
     st, syms = frames(oracle, rng, 7, 1, 24, noise=0.0)
     d = L.LoRaDemod(7)
+    d.set_mode(mode)
     d.setMTU(24)
     d.set_trace(True)
     d.work([st])
@@ -49,12 +54,14 @@ def test_config1_single_channel_sf7_loopback(gpu, oracle):
     assert [p[1] for p in pk] == [c for c, _ in r["packets"]]
 
 
-def test_golden_stream_through_demod(gpu, golden):
+@pytest.mark.parametrize("mode", MODES)
+def test_golden_stream_through_demod(gpu, golden, mode):
     """the committed stream recorded from the verbatim LoRaDemod.cpp: same consumption, same packets"""
     import lora_sdr_amd as L
     g = golden("demod_stream.npz")
     for sf in (7, 9):
         d = L.LoRaDemod(sf)
+        d.set_mode(mode)
         d.setMTU(int(g["mtu_%d" % sf]))
         d.set_trace(True)
         d.work([g["iq_%d" % sf]])
@@ -67,8 +74,9 @@ def test_golden_stream_through_demod(gpu, golden):
         assert np.allclose(np.array(sig).reshape(-1), g["signals_%d" % sf], rtol=0, atol=TOL_DB)
 
 
-@pytest.mark.parametrize("sf", [7, 8, 10])
-def test_many_channels_lockstep(gpu, oracle, sf):
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sf", [7, 8, 9, 10])
+def test_many_channels_lockstep(gpu, oracle, sf, mode):
     """channels with different lengths, frequency offsets, sync alignment and noise, one of them pure
     noise and one too short to work at all: every channel must follow its own oracle block"""
     import lora_sdr_amd as L
@@ -88,6 +96,7 @@ def test_many_channels_lockstep(gpu, oracle, sf):
         streams.append(st)
         sent.append(sy)
     d = L.LoRaDemod(sf, n_channels=B)
+    d.set_mode(mode)
     d.setMTU(64)
     d.set_trace(True)
     d.work(streams)
@@ -105,7 +114,8 @@ def test_many_channels_lockstep(gpu, oracle, sf):
     assert len(d.trace(7)) == 0
 
 
-def test_device_resident_streams(gpu, oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_device_resident_streams(gpu, oracle, mode):
     """lorahip_demod_run_device: the streams are already one (B, samples) tensor in HBM"""
     import lora_sdr_amd as L
     sf, B = 8, 5
@@ -114,6 +124,7 @@ def test_device_resident_streams(gpu, oracle):
     n = min(len(s) for s in sts)
     arr = np.stack([s[:n] for s in sts])
     d = L.LoRaDemod(sf, n_channels=B)
+    d.set_mode(mode)
     d.setMTU(10)
     d.set_trace(True)
     d.work(gpu.from_numpy(arr).cuda())
