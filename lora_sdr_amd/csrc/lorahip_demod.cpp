@@ -258,6 +258,7 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
             case ST_DATASYMBOLS:
             {
                 total = N;
+                if (k.outSymbols.size() <= k.symCount) k.outSymbols.resize(k.symCount + 1, 0);   // a packet begun on the streaming path
                 k.outSymbols[k.symCount++] = int16_t(value);
                 if (k.symCount >= dm->mtu || squelched)
                 {
@@ -296,18 +297,24 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     LORAHIP_TRY(hipSetDevice(ctx->device));
     size_t maxLen = 0;
     for (size_t c = 0; c < B; c++) if (dm->ch[c].len - dm->ch[c].pos > maxLen) maxLen = dm->ch[c].len - dm->ch[c].pos;
-    // records per channel per launch: enough for a clean stream, bounded so that the buffer stays <= 256 MiB
-    size_t cap = maxLen / N + 16;
-    if (cap > 4096) cap = 4096;
-    const size_t capMem = (size_t(256) << 20) / (B * sizeof(lorahip_work_result));
+    // work() calls per channel per launch: enough for a clean stream in one launch, bounded so that the
+    // per-launch buffers stay moderate (the launch is resumable)
+    const size_t perCall = sizeof(short) + (dm->tracing ? sizeof(lorahip_work_result) : 0) + sizeof(StreamPacket) / 4 + 1;
+    size_t cap = maxLen / N + 64;
+    if (cap > 65536) cap = 65536;
+    const size_t capMem = (size_t(256) << 20) / (B * perCall);
     if (cap > capMem) cap = capMem;
     if (cap < 8) cap = 8;
+    const size_t capPkt = cap / 4 + 2;               // a packet costs at least 5 calls (3 sync, quarter, 1 symbol)
 
     size_t cur = 0;
     auto carveS = [&cur](const size_t bytes) { const size_t o = cur; cur += align256(bytes); return o; };
     const size_t oBase = carveS(B * sizeof(long long)), oLen = carveS(B * sizeof(long long));
-    const size_t oState = carveS(B * sizeof(StreamState)), oN = carveS(B * sizeof(int));
-    const size_t oCalls = carveS(B * cap * sizeof(lorahip_work_result));
+    const size_t oState = carveS(B * sizeof(StreamState));
+    const size_t oN = carveS(B * sizeof(int)), oNSym = carveS(B * sizeof(int)), oNPkt = carveS(B * sizeof(int));
+    const size_t oPkt = carveS(B * capPkt * sizeof(StreamPacket));
+    const size_t oSym = carveS(B * cap * sizeof(short));
+    const size_t oCalls = carveS(dm->tracing ? B * cap * sizeof(lorahip_work_result) : 0);
     if (cur > dm->sBytes)
     {
         if (dm->sDev) { (void)hipFree(dm->sDev); dm->sDev = nullptr; }
@@ -320,17 +327,20 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     char *h = dm->sHost, *d = dm->sDev;
     long long *hBase = reinterpret_cast<long long *>(h + oBase), *hLen = reinterpret_cast<long long *>(h + oLen);
     StreamState *hState = reinterpret_cast<StreamState *>(h + oState);
-    int *hN = reinterpret_cast<int *>(h + oN);
-    lorahip_work_result *hCalls = reinterpret_cast<lorahip_work_result *>(h + oCalls);
+    const int *hN = reinterpret_cast<int *>(h + oN), *hNSym = reinterpret_cast<int *>(h + oNSym), *hNPkt = reinterpret_cast<int *>(h + oNPkt);
+    const StreamPacket *hPkt = reinterpret_cast<StreamPacket *>(h + oPkt);
+    const short *hSym = reinterpret_cast<short *>(h + oSym);
+    const lorahip_work_result *hCalls = reinterpret_cast<lorahip_work_result *>(h + oCalls);
     for (size_t c = 0; c < B; c++)
     {
-        const Channel &k = dm->ch[c];
+        Channel &k = dm->ch[c];
         hBase[c] = (long long)k.base;
         hLen[c] = (long long)k.len;
         StreamState &st = hState[c];
         st.state = k.state; st.downTable = k.downTable ? 1 : 0; st.prevValue = k.prevValue; st.freqError = k.freqError;
-        st.fineTuneIndex = k.fineTuneIndex; st.finefreqError = k.finefreqError; st.symCount = int(k.symCount); st.pad = 0;
+        st.fineTuneIndex = k.fineTuneIndex; st.finefreqError = k.finefreqError; st.symCount = int(k.symCount); st.callCount = 0;
         st.pos = (long long)k.pos;
+        if (k.outSymbols.size() < k.symCount) k.outSymbols.resize(k.symCount, 0);
     }
     LORAHIP_TRY(hipMemcpyAsync(d, h, oN, hipMemcpyHostToDevice, ctx->stream));       // base, len, state
 
@@ -340,49 +350,57 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.len = reinterpret_cast<const long long *>(d + oLen);
     a.state = reinterpret_cast<StreamState *>(d + oState);
     a.nCalls = reinterpret_cast<int *>(d + oN);
-    a.calls = reinterpret_cast<lorahip_work_result *>(d + oCalls);
+    a.nSym = reinterpret_cast<int *>(d + oNSym);
+    a.nPkt = reinterpret_cast<int *>(d + oNPkt);
+    a.pktOut = reinterpret_cast<StreamPacket *>(d + oPkt);
+    a.symOut = reinterpret_cast<short *>(d + oSym);
+    a.calls = dm->tracing ? reinterpret_cast<lorahip_work_result *>(d + oCalls) : nullptr;
     a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
     a.nChannels = unsigned(B);
     a.cap = int(cap);
+    a.capPkt = int(capPkt);
     a.powerScale = ctx->powerScale;
     a.thresh = dm->thresh;
     a.sync = dm->sync;
     a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
 
-    std::vector<int64_t> callIndex(B, 0);
     const size_t firstNewPacket = dm->packets.size();
     while (true)
     {
         LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
-        LORAHIP_TRY(hipMemcpyAsync(h + oState, d + oState, cur - oState, hipMemcpyDeviceToHost, ctx->stream));   // state, nCalls, calls
+        LORAHIP_TRY(hipMemcpyAsync(h + oState, d + oState, cur - oState, hipMemcpyDeviceToHost, ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
         bool more = false;
         for (size_t c = 0; c < B; c++)
         {
             Channel &k = dm->ch[c];
-            const lorahip_work_result *rec = hCalls + c * cap;
-            for (int i = 0; i < hN[c]; i++)
+            // symbols of this launch continue the packet the previous launches left open (k.outSymbols[0..k.symCount))
+            const short *sy = hSym + c * cap;
+            size_t p = 0;
+            for (int j = 0; j < hNPkt[c]; j++)
             {
-                const lorahip_work_result &r = rec[i];
-                if (r.state_before == ST_QUARTERCHIRP) k.symCount = 0;                // :279
-                else if (r.state_before == ST_DATASYMBOLS)
-                {
-                    if (k.outSymbols.size() <= k.symCount) k.outSymbols.resize(k.symCount + 1, 0);
-                    k.outSymbols[k.symCount++] = int16_t(r.value);                    // :290
-                    if (r.packet_len > 0)
-                    {
-                        Packet p;
-                        p.channel = int32_t(c);
-                        p.round = callIndex[c];
-                        p.syms.assign(k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
-                        dm->packets.push_back(p);
-                    }
-                }
-                callIndex[c]++;
-                dm->workCalls++;
-                if (dm->tracing) k.trace.push_back(r);
+                const StreamPacket &q = hPkt[c * capPkt + size_t(j)];
+                Packet pk;
+                pk.channel = int32_t(c);
+                pk.round = q.callIndex;
+                pk.syms.assign(k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
+                const size_t fresh = size_t(q.len) - k.symCount;
+                pk.syms.insert(pk.syms.end(), sy + p, sy + p + fresh);
+                p += fresh;
+                k.symCount = 0;
+                dm->packets.push_back(std::move(pk));
             }
-            if (size_t(hN[c]) == cap) more = true;
+            // what is left belongs to a packet still being received
+            const size_t left = size_t(hNSym[c]) - p;
+            if (left)
+            {
+                if (k.outSymbols.size() < k.symCount + left) k.outSymbols.resize(k.symCount + left, 0);
+                for (size_t i = 0; i < left; i++) k.outSymbols[k.symCount + i] = sy[p + i];
+                k.symCount += left;
+            }
+            dm->workCalls += hN[c];
+            if (dm->tracing) k.trace.insert(k.trace.end(), hCalls + c * cap, hCalls + c * cap + hN[c]);
+            if (size_t(hN[c]) == cap || size_t(hNPkt[c]) == capPkt) more = true;
         }
         if (!more) break;
     }
@@ -394,7 +412,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         k.state = st.state; k.downTable = st.downTable != 0; k.prevValue = short(st.prevValue); k.freqError = st.freqError;
         k.fineTuneIndex = st.fineTuneIndex; k.finefreqError = st.finefreqError; k.symCount = size_t(st.symCount);
         k.pos = size_t(st.pos);
-        if (callIndex[c] > rounds) rounds = callIndex[c];
+        if (st.callCount > rounds) rounds = st.callCount;
     }
     // the host-driven path posts packets round by round, channels in order inside a round
     std::stable_sort(dm->packets.begin() + long(firstNewPacket), dm->packets.end(),

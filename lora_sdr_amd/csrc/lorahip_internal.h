@@ -64,9 +64,13 @@ struct StreamState
     int fineTuneIndex;
     float finefreqError;
     int symCount;
-    int pad;
+    int callCount;          // work() calls made since the run started (= the lock-step round index of the next call)
     long long pos;          // samples consumed so far
 };
+
+//! one posted packet: the call (round) it was posted in and its length; its symbols are the next `len` entries
+//! of the channel's symbol stream (after what earlier launches carried over)
+struct StreamPacket { int callIndex; int len; };
 
 //! argument block of the streaming demod kernel (lorahip_stream.hip); all pointers are device pointers
 struct StreamArgs
@@ -75,8 +79,13 @@ struct StreamArgs
     const long long *base;      // [nChannels] first sample of the channel's stream in iq
     const long long *len;       // [nChannels] samples available
     StreamState *state;         // [nChannels] in/out
-    lorahip_work_result *calls; // [nChannels][cap] one record per work() call
-    int *nCalls;                // [nChannels] records written by this launch
+    lorahip_work_result *calls; // [nChannels][cap] one record per work() call; nullptr unless tracing
+    int *nCalls;                // [nChannels] work() calls made by this launch
+    short *symOut;              // [nChannels][cap] the DATASYMBOLS values of this launch, in order
+    int *nSym;                  // [nChannels]
+    StreamPacket *pktOut;       // [nChannels][capPkt]
+    int *nPkt;                  // [nChannels]
+    int capPkt;
     const float2 *down, *fine, *twStage;
     unsigned nChannels;
     int cap;

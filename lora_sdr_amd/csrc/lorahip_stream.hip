@@ -52,8 +52,10 @@ demodStream(const StreamArgs s)
     const unsigned cc = mine ? c : 0;
     StreamState st = s.state[cc];
     const long long base = s.base[cc], len = mine ? s.len[cc] : 0;
-    int calls = 0;
-    lorahip_work_result *out = s.calls + (size_t)cc * s.cap;
+    int calls = 0, nSym = 0, nPkt = 0;
+    lorahip_work_result *out = s.calls ? s.calls + (size_t)cc * s.cap : nullptr;
+    short *symOut = s.symOut + (size_t)cc * s.cap;
+    StreamPacket *pktOut = s.pktOut + (size_t)cc * s.capPkt;
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
     // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
@@ -109,7 +111,7 @@ demodStream(const StreamArgs s)
 
     while (true)
     {
-        const bool live = mine && (len - st.pos >= 2 * N) && calls < s.cap;           // LoRaDemod.cpp:148
+        const bool live = mine && (len - st.pos >= 2 * N) && calls < s.cap && nPkt < s.capPkt;   // LoRaDemod.cpp:148
         if (!__any(live)) break;
 
         // ---- window 0 (:157-172) ----
@@ -176,10 +178,14 @@ demodStream(const StreamArgs s)
                 break;
             default: // ST_DATASYMBOLS
                 total = N;
-                st.symCount++;                                                                                   // out[_symCount++] = value  :290
+                if (t == 0) symOut[nSym] = (short)value;                                                         // out[_symCount++] = value  :290
+                nSym++;
+                st.symCount++;
                 if ((unsigned)st.symCount >= s.mtu || squelched)                                                 // :291
                 {
                     packetLen = st.symCount;
+                    if (t == 0) { pktOut[nPkt].callIndex = st.callCount; pktOut[nPkt].len = packetLen; }         // postMessage  :295-298
+                    nPkt++;
                     st.finefreqError = 0.0f;
                     st.state = ST_FRAMESYNC;
                 }
@@ -187,7 +193,7 @@ demodStream(const StreamArgs s)
             }
             st.prevValue = (short)value;                                                                         // :326
             st.pos += total;                                                                                     // consume(total)  :320
-            if (t == 0)
+            if (t == 0 && out)
             {
                 lorahip_work_result r;
                 r.consumed = total;
@@ -203,12 +209,15 @@ demodStream(const StreamArgs s)
                 out[calls] = r;
             }
             calls++;
+            st.callCount++;
         }
     }
     if (mine && t == 0)
     {
         s.state[c] = st;
         s.nCalls[c] = calls;
+        s.nSym[c] = nSym;
+        s.nPkt[c] = nPkt;
     }
 }
 
