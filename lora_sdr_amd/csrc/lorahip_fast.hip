@@ -293,12 +293,24 @@ typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  true,  true,  
 typedef FastCfg<7,  3, 2,  2,  3,  7,  4,          1,  1,  0, 0,  true,  true,  false> Cfg7d;
 typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  false, false, true>  Cfg7e;
 typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  2>     Cfg7f;   // loads issued at the top of the set
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  false, 1>     Cfg7g;   // last-phase twiddles in registers
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  1, true> Cfg7h;  // non-temporal IQ loads
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  false, 1, true> Cfg7i;
 typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg8;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1>     Cfg8g;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  1, true> Cfg8h;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1, true> Cfg8i;
 typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  2>     Cfg8f;    // 16 lanes x 16 pts: [4,4] X [4,4]
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  true>  Cfg9;    // 32 lanes x 16 pts: [R2,4] X [4,4] X [4]
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  2>     Cfg9f;
 typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg10;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  2>     Cfg10f;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  2>     Cfg10f;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1>     Cfg10g;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  1, true> Cfg10h;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  false, 1>     Cfg9g;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  1, true> Cfg9h;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  false, 1, true> Cfg9i;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1, true> Cfg10i;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
 
 bool fastAvailable(const int sf) { return sf >= 7 && sf <= 10; }
 
@@ -314,11 +326,15 @@ hipError_t launchFast(const int sf, const int variant, const DetectArgs &a, cons
         case 4: return launchCfg<Cfg7d>(a, ft, stream);
         case 5: return launchCfg<Cfg7e>(a, ft, stream);
         case 6: return launchCfg<Cfg7f>(a, ft, stream);
-        default: return launchCfg<Cfg7b>(a, ft, stream);
+        case 7: return launchCfg<Cfg7g>(a, ft, stream);
+        case 8: return launchCfg<Cfg7h>(a, ft, stream);
+        case 9: return launchCfg<Cfg7i>(a, ft, stream);
+        case 10: return launchCfg<Cfg7b>(a, ft, stream);
+        default: return launchCfg<Cfg7h>(a, ft, stream);      // measured best (profiles/r01/s8_variants.txt)
         }
-    case 8: return variant == 6 ? launchCfg<Cfg8f>(a, ft, stream) : launchCfg<Cfg8>(a, ft, stream);
-    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : launchCfg<Cfg9>(a, ft, stream);
-    case 10: return variant == 6 ? launchCfg<Cfg10f>(a, ft, stream) : launchCfg<Cfg10>(a, ft, stream);
+    case 8: return variant == 6 ? launchCfg<Cfg8f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg8g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg8h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg8>(a, ft, stream) : launchCfg<Cfg8i>(a, ft, stream);
+    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg9g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg9h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg9>(a, ft, stream) : launchCfg<Cfg9i>(a, ft, stream);
+    case 10: return variant == 6 ? launchCfg<Cfg10f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg10g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg10h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg10>(a, ft, stream) : launchCfg<Cfg10i>(a, ft, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -14,10 +14,11 @@ namespace lorahip {
  *   groups and the readers' ds_read_b64 groups each tile the LDS banks exactly once.
  **********************************************************************/
 template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_,
-          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_>
+          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false>
 struct FastCfg
 {
     static constexpr int PREFETCH = PREFETCH_;        // next window set's loads: 0 none (loaded at the top), 1 issued after the dechirp of this set, 2 at the top of this set
+    static constexpr bool NT = NT_;                   // non-temporal hint on the IQ loads (read once, never reused)
     static constexpr bool CH_LDS = CH_LDS_;           // chirp table read from LDS per window (else loop-invariant registers)
     static constexpr bool TW_ALL_LDS = TW_ALL_LDS_;   // last-phase twiddles from the LDS table too (else registers)
     static constexpr int LOG2N = LOG2N_, N = 1 << LOG2N_;
@@ -107,11 +108,11 @@ struct FastCore
             const v2f *p = in_ + VEC * t + VEC * T * r;
             if (VEC == 2)
             {
-                const v4f q = *reinterpret_cast<const v4f *>(p);
+                const v4f q = C::NT ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)) : *reinterpret_cast<const v4f *>(p);
                 xn[r][0] = MAKE2(q.x, q.y);
                 xn[r][VEC - 1] = MAKE2(q.z, q.w);
             }
-            else xn[r][0] = *p;
+            else xn[r][0] = C::NT ? __builtin_nontemporal_load(p) : *p;
         }
     }
 

@@ -18,7 +18,7 @@
 
 namespace lorahip {
 
-template <int LOG2N_, int VEC_, int MINW_, int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, bool PREFETCH_ = true>
+template <int LOG2N_, int VEC_, int MINW_, int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, bool PREFETCH_ = true, bool NT_ = false>
 struct WideCfg
 {
     static constexpr int LOG2N = LOG2N_, N = 1 << LOG2N_;
@@ -30,6 +30,7 @@ struct WideCfg
     static constexpr int WPWIN = T / 64;                        // wavefronts per window
     static constexpr int MINW = MINW_;
     static constexpr bool CH_LDS = CH_LDS_, TW_ALL_LDS = TW_ALL_LDS_;
+    static constexpr bool NT = NT_;                             // non-temporal hint on the IQ loads
     static constexpr bool PREFETCH = PREFETCH_;                 // next set's samples in registers during this set (else: loaded at the top, hidden by co-resident workgroups)
     static constexpr int HB = LOG2N_ - B2;                      // = 4: position bits of the last phase
     static constexpr int NL = VEC_ * T, LOG2NL = LOG2N_ - B1;   // rows of exchange 0
@@ -154,11 +155,11 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
             const v2f *p = in_ + VEC * t + VEC * T * r;
             if (VEC == 2)
             {
-                const v4f q = *reinterpret_cast<const v4f *>(p);
+                const v4f q = C::NT ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)) : *reinterpret_cast<const v4f *>(p);
                 xn[r][0] = MAKE2(q.x, q.y);
                 xn[r][VEC - 1] = MAKE2(q.z, q.w);
             }
-            else xn[r][0] = *p;
+            else xn[r][0] = C::NT ? __builtin_nontemporal_load(p) : *p;
         }
     };
     if (C::PREFETCH) issueLoads(blockIdx.x);
@@ -441,6 +442,8 @@ typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  false, true>  Cfg11d;
 typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  true,  true>  Cfg11e;
 typedef WideCfg<11,  2,  4,         0,  1,  4, 1,  false, false, false> Cfg11f;   // no register prefetch: 4 workgroups per CU
 typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, false> Cfg11g;
+typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, true, true> Cfg11h;   // non-temporal IQ loads
+typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, false, true> Cfg11i;
 // 256 lanes x 16 pts: [4,4] X [4,4] X [4,4]
 typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  false, false> Cfg12a;
 typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false> Cfg12b;
@@ -449,6 +452,8 @@ typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  false, true>  Cfg12d;
 typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  true,  true>  Cfg12e;
 typedef WideCfg<12,  1,  4,         0,  1,  0, 0,  false, false, false> Cfg12f;
 typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, false> Cfg12g;
+typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, true, true> Cfg12h;
+typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, false, true> Cfg12i;
 
 bool wideAvailable(const int sf) { return sf == 11 || sf == 12; }
 
@@ -465,7 +470,10 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
         case 5: return launchCfgWide<Cfg11e>(a, ft, stream);
         case 6: return launchCfgWide<Cfg11f>(a, ft, stream);
         case 7: return launchCfgWide<Cfg11g>(a, ft, stream);
-        default: return launchCfgWide<Cfg11b>(a, ft, stream);   // measured best (profiles/r01)
+        case 8: return launchCfgWide<Cfg11h>(a, ft, stream);
+        case 9: return launchCfgWide<Cfg11i>(a, ft, stream);
+        case 10: return launchCfgWide<Cfg11b>(a, ft, stream);
+        default: return launchCfgWide<Cfg11i>(a, ft, stream);   // measured best (profiles/r01/s8_variants.txt)
         }
     case 12:
         switch (variant)
@@ -476,7 +484,10 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
         case 5: return launchCfgWide<Cfg12e>(a, ft, stream);
         case 6: return launchCfgWide<Cfg12f>(a, ft, stream);
         case 7: return launchCfgWide<Cfg12g>(a, ft, stream);
-        default: return launchCfgWide<Cfg12b>(a, ft, stream);   // measured best (profiles/r01)
+        case 8: return launchCfgWide<Cfg12h>(a, ft, stream);
+        case 9: return launchCfgWide<Cfg12i>(a, ft, stream);
+        case 10: return launchCfgWide<Cfg12b>(a, ft, stream);
+        default: return launchCfgWide<Cfg12i>(a, ft, stream);   // measured best (profiles/r01/s8_variants.txt)
         }
     default: return hipErrorInvalidValue;
     }

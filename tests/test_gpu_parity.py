@@ -271,7 +271,8 @@ def test_golden_detector_kat(gpu, golden, sf):
 
 
 # every selectable kernel variant per SF (lorahip_kernels.hip / lorahip_fast.hip / lorahip_wide.hip); 1 = generic
-VARIANTS = {6: [0], 7: [0, 1, 2, 3, 4, 5, 6], 8: [0, 1, 6], 9: [0, 1, 6], 10: [0, 1, 6], 11: [0, 1, 2, 3, 4, 5, 6, 7], 12: [0, 1, 2, 3, 4, 5, 6, 7]}
+VARIANTS = {6: [0], 7: list(range(11)), 8: [0, 1, 6, 7, 8, 9, 10], 9: [0, 1, 6, 7, 8, 9, 10], 10: [0, 1, 6, 7, 8, 9, 10],
+            11: list(range(11)), 12: list(range(11))}
 
 
 @pytest.mark.parametrize("sf", range(6, 13))
