@@ -59,6 +59,7 @@ const char *lorahip_strerror(int code);
 const char *lorahip_last_error(void);       /* thread-local text of the last LORAHIP_E_HIP */
 int lorahip_version(void);                  /* ABI version, currently 1 */
 int lorahip_device_count(void);             /* number of usable gfx950 devices, 0 if none */
+int lorahip_selfcheck(void);                /* host-only: the kernels' compile-time LDS layouts are consistent; no device needed */
 
 /* -------------------------------------------------------------------------------------
  * Host-side tables, exactly the reference's expressions (no device needed):

@@ -46,6 +46,7 @@ SIGNATURES = {
     "lorahip_strerror": (C.c_char_p, [C.c_int]),
     "lorahip_last_error": (C.c_char_p, []),
     "lorahip_version": (C.c_int, []),
+    "lorahip_selfcheck": (C.c_int, []),
     "lorahip_device_count": (C.c_int, []),
     "lorahip_host_tables": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lorahip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),

@@ -64,6 +64,13 @@ const char *lorahip_last_error(void) { return g_lastError.c_str(); }
 
 int lorahip_version(void) { return 1; }
 
+int lorahip_selfcheck(void)
+{
+    if (!fastLayoutsOk()) { setLastError("an LDS exchange layout of lorahip_fast.hip is not injective"); return LORAHIP_E_INVALID; }
+    if (!wideLayoutsOk()) { setLastError("an LDS exchange layout of lorahip_wide.hip is not injective"); return LORAHIP_E_INVALID; }
+    return LORAHIP_OK;
+}
+
 int lorahip_device_count(void)
 {
     int n = 0;

@@ -314,6 +314,28 @@ typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  false, 
 
 bool fastAvailable(const int sf) { return sf >= 7 && sf <= 10; }
 
+//! host-side check of a configuration's exchange-0 layout: every (row, window, element) has its own word inside the
+//! wave's region
+template <class C>
+static bool layoutOk()
+{
+    std::vector<char> used(size_t(C::XW), 0);
+    for (int n = 0; n < C::NL; n++)
+        for (int ws = 0; ws < C::WPW; ws++)
+            for (int e = 0; e < C::R; e++)
+            {
+                const int a = C::x0off(n) + ws * C::R + e;
+                if (a < 0 || a >= C::XW || used[size_t(a)]) return false;
+                used[size_t(a)] = 1;
+            }
+    return true;
+}
+
+bool fastLayoutsOk()
+{
+    return layoutOk<Cfg7a>() && layoutOk<Cfg7e>() && layoutOk<Cfg8>() && layoutOk<Cfg9>() && layoutOk<Cfg10>();
+}
+
 hipError_t launchFast(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
     switch (sf)

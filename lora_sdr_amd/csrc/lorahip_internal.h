@@ -100,6 +100,8 @@ hipError_t launchDetect(int sf, int variant, const DetectArgs &a, const FastTabl
 bool fastAvailable(int sf);
 hipError_t launchFast(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
 bool wideAvailable(int sf);
+bool wideLayoutsOk();
+bool fastLayoutsOk();
 hipError_t launchWide(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
 bool streamAvailable(int sf);
 hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);

@@ -18,7 +18,8 @@
 
 namespace lorahip {
 
-template <int LOG2N_, int VEC_, int MINW_, int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, bool PREFETCH_ = true, bool NT_ = false>
+template <int LOG2N_, int VEC_, int MINW_, int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, bool PREFETCH_ = true, bool NT_ = false, int WPB_ = 0,
+          bool INPLACE_ = false, int X0S2_ = 0, int X0D2_ = 0>
 struct WideCfg
 {
     static constexpr int LOG2N = LOG2N_, N = 1 << LOG2N_;
@@ -26,11 +27,15 @@ struct WideCfg
     static constexpr int LOG2T = LOG2N_ - 4, T = 1 << LOG2T;    // lanes per window
     static constexpr int VEC = VEC_, R = P / VEC_;
     static constexpr int B1 = (VEC_ == 1 ? 4 : 3), B2 = B1 + 4;
-    static constexpr int WPB = 256 / T;                         // windows per workgroup iteration
+    static constexpr int WPB = WPB_ ? WPB_ : 256 / T;           // windows per workgroup iteration
+    static constexpr int BLOCK = WPB * T;                       // threads per workgroup (128 or 256)
+    static constexpr int BPC = MINW_ * 256 / BLOCK;             // workgroups per CU at MINW waves per SIMD
     static constexpr int WPWIN = T / 64;                        // wavefronts per window
     static constexpr int MINW = MINW_;
     static constexpr bool CH_LDS = CH_LDS_, TW_ALL_LDS = TW_ALL_LDS_;
     static constexpr bool NT = NT_;                             // non-temporal hint on the IQ loads
+    static constexpr bool INPLACE = INPLACE_;                   // the middle phase writes its results back where it read its inputs:
+                                                                // no barrier between the two, the last phase reads the exchange-0 layout
     static constexpr bool PREFETCH = PREFETCH_;                 // next set's samples in registers during this set (else: loaded at the top, hidden by co-resident workgroups)
     static constexpr int HB = LOG2N_ - B2;                      // = 4: position bits of the last phase
     static constexpr int NL = VEC_ * T, LOG2NL = LOG2N_ - B1;   // rows of exchange 0
@@ -40,11 +45,11 @@ struct WideCfg
     __host__ __device__ static constexpr int x0off(const int nlow)
     {
         const int rot = ((nlow >> X0ROT_) | (nlow << (LOG2NL - X0ROT_))) & (NL - 1);
-        return rot * RS0 + ((nlow >> X0S_) & 1) * X0D_;
+        return rot * RS0 + ((nlow >> X0S_) & 1) * X0D_ + ((nlow >> X0S2_) & 1) * X0D2_;
     }
-    static constexpr int X0ELEMS = NL * RS0 + X0D_;
+    static constexpr int X0ELEMS = NL * RS0 + X0D_ + X0D2_;
     static constexpr int X1 = 16 * R + 8;                       // one block of `high` in exchange 1
-    static constexpr int X1ELEMS = 16 * X1;
+    static constexpr int X1ELEMS = INPLACE_ ? 0 : 16 * X1;
     static constexpr int XE = X0ELEMS > X1ELEMS ? X0ELEMS : X1ELEMS;
     static constexpr int XW = ((XE * 2 > N ? XE : (N + 1) / 2) + 1) & ~1;   // v2f per window; also holds N ints
     static constexpr int TW_LDS = twStageOffset(LOG2N_, TW_ALL_LDS_ ? LOG2N_ : B2);
@@ -67,7 +72,7 @@ struct WideSmem
 };
 
 template <class C, bool DBG, bool UNI>
-__global__ void __launch_bounds__(256, C::MINW)
+__global__ void __launch_bounds__(C::BLOCK, C::MINW)
 detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
 {
     constexpr int N = C::N, T = C::T, VEC = C::VEC, R = C::R, WPB = C::WPB, WPWIN = C::WPWIN;
@@ -96,7 +101,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
 
     // ---- one-time set-up -------------------------------------------------------------
     if (tid < 64) tr.w[tid] = 0xffffffffu;                // empty tail slots
-    for (int i = tid; i < C::TW_LDS; i += 256) sTw[i] = reinterpret_cast<const v2f *>(ft.twStage)[i];
+    for (int i = tid; i < C::TW_LDS; i += C::BLOCK) sTw[i] = reinterpret_cast<const v2f *>(ft.twStage)[i];
 
     // register twiddles of the last phase (klow = t there)
     v2f twR[C::TW_ALL_LDS ? 1 : SLOTS];
@@ -123,7 +128,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
     v2f ch[C::CH_LDS ? 1 : R][C::CH_LDS ? 1 : VEC];
     if (C::CH_LDS)
     {
-        for (int i = tid; i < N; i += 256)
+        for (int i = tid; i < N; i += C::BLOCK)
         {
             const v2f c = gDown[i];
             sCh[i] = MAKE2(c.x, s0 * c.y);
@@ -322,20 +327,37 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
 #pragma unroll
             for (int e = 0; e < 16; e++) v1[e] = X[C::x0off((rev4(e, 4) << HB) | rhigh) + klow];
         }
-        __syncthreads();                                                                      // B2
-        flushIfFull();                                  // wave 0, once per 64 windows
-        runPhase<LOG2N, B1, B2, false>(v1, t & (R - 1), sTw, nullptr);
-        // exchange 1: position klow + R*e + 16R*high, 8 elements of padding per `high`
+        if (!C::INPLACE)
         {
+            __syncthreads();                                                                  // B2
+            flushIfFull();                              // wave 0, once per 64 windows
+        }
+        runPhase<LOG2N, B1, B2, false>(v1, t & (R - 1), sTw, nullptr);
+        v2f vl[16];
+        if (C::INPLACE)
+        {
+            // write-back in place: only this lane touches these 16 words between B1 and B3
+            const int klow = t & (R - 1), rhigh = rev4(t >> B1, HB);
+#pragma unroll
+            for (int e = 0; e < 16; e++) X[C::x0off((rev4(e, 4) << HB) | rhigh) + klow] = v1[e];
+            __syncthreads();                                                                  // B3
+            flushIfFull();
+            // last phase: lane t holds positions t + T*e2; t = klow + R*e_mid, e2 = high
+            const int rmid = rev4(t >> B1, 4) << HB;
+#pragma unroll
+            for (int e = 0; e < 16; e++) vl[e] = X[C::x0off(rmid | rev4(e, HB)) + klow];
+        }
+        else
+        {
+            // exchange 1: position klow + R*e + 16R*high, 8 elements of padding per `high`
             v2f *base = X + (t >> B1) * C::X1 + (t & (R - 1));
 #pragma unroll
             for (int e = 0; e < 16; e++) base[e * R] = v1[e];
-        }
-        __syncthreads();                                                                      // B3
-        // phase 2 = last: lane t holds positions t + T*e
-        v2f vl[16];
+            __syncthreads();                                                                  // B3
+            // phase 2 = last: lane t holds positions t + T*e
 #pragma unroll
-        for (int e = 0; e < 16; e++) vl[e] = X[e * C::X1 + t];
+            for (int e = 0; e < 16; e++) vl[e] = X[e * C::X1 + t];
+        }
         if (C::TW_ALL_LDS) runPhase<LOG2N, B2, LOG2N, false>(vl, t, sTw, nullptr);
         else runPhase<LOG2N, B2, LOG2N, true>(vl, 0, nullptr, twR);
 
@@ -416,12 +438,12 @@ static hipError_t launchOneWide(const DetectArgs &a, const FastTables &ft, hipSt
     const unsigned nSets = (a.nWindows + C::WPB - 1) / C::WPB;
     // persistent: as many workgroups as stay resident, never more than there are sets of work
     unsigned perCu = unsigned((160u * 1024u) / smem);
-    if (perCu > unsigned(C::MINW)) perCu = unsigned(C::MINW);
+    if (perCu > unsigned(C::BPC)) perCu = unsigned(C::BPC);
     if (perCu < 1) perCu = 1;
     unsigned grid = unsigned(ft.nBlocksHint > 0 ? ft.nBlocksHint : 256) * perCu;
     if (grid > nSets) grid = nSets;
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL((detectWide<C, DBG, UNI>), dim3(grid), dim3(256), smem, stream, a, ft, nSets);
+    hipLaunchKernelGGL((detectWide<C, DBG, UNI>), dim3(grid), dim3(C::BLOCK), smem, stream, a, ft, nSets);
     return hipGetLastError();
 }
 
@@ -444,6 +466,10 @@ typedef WideCfg<11,  2,  4,         0,  1,  4, 1,  false, false, false> Cfg11f; 
 typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, false> Cfg11g;
 typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, true, true> Cfg11h;   // non-temporal IQ loads
 typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, false, true> Cfg11i;
+typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, false, true, 1> Cfg11j;   // one window (2 wavefronts) per workgroup
+typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, true, true, 1> Cfg11k;
+typedef WideCfg<11,  2,  3,         3,  1,  1, 4,  false, false, false, true, 1, true, 2, 8> Cfg11l;   // in-place middle phase
+typedef WideCfg<11,  2,  3,         3,  1,  1, 4,  false, false, false, true, 0, true, 2, 8> Cfg11m;
 // 256 lanes x 16 pts: [4,4] X [4,4] X [4,4]
 typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  false, false> Cfg12a;
 typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false> Cfg12b;
@@ -454,8 +480,35 @@ typedef WideCfg<12,  1,  4,         0,  1,  0, 0,  false, false, false> Cfg12f;
 typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, false> Cfg12g;
 typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, true, true> Cfg12h;
 typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, false, true> Cfg12i;
+typedef WideCfg<12,  1,  3,         0,  1,  6, 16, false, false, false, true, 0, true, 7, 16> Cfg12l;   // in-place middle phase
+typedef WideCfg<12,  1,  3,         0,  1,  6, 16, false, false, true,  true, 0, true, 7, 16> Cfg12m;
 
 bool wideAvailable(const int sf) { return sf == 11 || sf == 12; }
+
+//! host-side check of a configuration's exchange-0 layout: every (row, element) has its own word inside the region
+template <class C>
+static bool layoutOk()
+{
+    std::vector<char> used(size_t(C::XW), 0);
+    for (int n = 0; n < C::NL; n++)
+        for (int e = 0; e < C::R; e++)
+        {
+            const int a = C::x0off(n) + e;
+            if (a < 0 || a >= C::XW || used[size_t(a)]) return false;
+            used[size_t(a)] = 1;
+        }
+    return true;
+}
+
+bool wideLayoutsOk()
+{
+    return layoutOk<Cfg11a>() && layoutOk<Cfg11b>() && layoutOk<Cfg11c>() && layoutOk<Cfg11d>() && layoutOk<Cfg11e>() &&
+           layoutOk<Cfg11f>() && layoutOk<Cfg11g>() && layoutOk<Cfg11h>() && layoutOk<Cfg11i>() && layoutOk<Cfg11j>() &&
+           layoutOk<Cfg11k>() && layoutOk<Cfg11l>() && layoutOk<Cfg11m>() &&
+           layoutOk<Cfg12a>() && layoutOk<Cfg12b>() && layoutOk<Cfg12c>() && layoutOk<Cfg12d>() && layoutOk<Cfg12e>() &&
+           layoutOk<Cfg12f>() && layoutOk<Cfg12g>() && layoutOk<Cfg12h>() && layoutOk<Cfg12i>() && layoutOk<Cfg12l>() &&
+           layoutOk<Cfg12m>();
+}
 
 hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
@@ -471,9 +524,13 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
         case 6: return launchCfgWide<Cfg11f>(a, ft, stream);
         case 7: return launchCfgWide<Cfg11g>(a, ft, stream);
         case 8: return launchCfgWide<Cfg11h>(a, ft, stream);
-        case 9: return launchCfgWide<Cfg11i>(a, ft, stream);
         case 10: return launchCfgWide<Cfg11b>(a, ft, stream);
-        default: return launchCfgWide<Cfg11i>(a, ft, stream);   // measured best (profiles/r01/s8_variants.txt)
+        case 11: return launchCfgWide<Cfg11j>(a, ft, stream);
+        case 12: return launchCfgWide<Cfg11k>(a, ft, stream);
+        case 13: return launchCfgWide<Cfg11l>(a, ft, stream);
+        case 14: return launchCfgWide<Cfg11m>(a, ft, stream);
+        case 9: return launchCfgWide<Cfg11i>(a, ft, stream);
+        default: return launchCfgWide<Cfg11l>(a, ft, stream);   // measured best (profiles/r01/s8_variants.txt)
         }
     case 12:
         switch (variant)
@@ -487,7 +544,9 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
         case 8: return launchCfgWide<Cfg12h>(a, ft, stream);
         case 9: return launchCfgWide<Cfg12i>(a, ft, stream);
         case 10: return launchCfgWide<Cfg12b>(a, ft, stream);
-        default: return launchCfgWide<Cfg12i>(a, ft, stream);   // measured best (profiles/r01/s8_variants.txt)
+        case 13: return launchCfgWide<Cfg12l>(a, ft, stream);
+        case 14: return launchCfgWide<Cfg12m>(a, ft, stream);
+        default: return launchCfgWide<Cfg12m>(a, ft, stream);   // measured best (profiles/r01/s8_variants.txt)
         }
     default: return hipErrorInvalidValue;
     }

@@ -183,3 +183,60 @@ def search_wide(name, LOG2N, VEC):
 if __name__ == "__main__":
     search_wide("sf11-wide", 11, 2)
     search_wide("sf12-wide", 12, 1)
+
+
+def inplace_wide(LOG2N, VEC, off):
+    """wide kernels with the in-place middle phase: exchange-0 write, exchange-0 read (= in-place write-back of
+    phase 1), and the last phase's read from the SAME layout. Returns (write, read1, read2) average cost factors."""
+    N = 1 << LOG2N
+    T = N // 16
+    R = 16 // VEC
+    B1 = 4 if VEC == 1 else 3
+    wr, rd1, wb, rd2 = [], [], [], []
+    for wv in range(T // 64):
+        for u in range(VEC):
+            for e in range(R):
+                wr.append(cost([8 * (off(VEC * (64 * wv + l) + u) + e) for l in range(64)], "w"))
+        for e in range(16):
+            addrs = []
+            for l in range(64):
+                t = 64 * wv + l
+                klow, high = t & (R - 1), t >> B1
+                addrs.append(8 * (off((rev4(e, 4) << 4) | rev4(high, 4)) + klow))
+            rd1.append(cost(addrs, "r"))
+            wb.append(cost(addrs, "w"))
+        for e2 in range(16):
+            addrs = []
+            for l in range(64):
+                t = 64 * wv + l
+                klow, e = t & (R - 1), t >> B1
+                addrs.append(8 * (off((rev4(e, 4) << 4) | rev4(e2, 4)) + klow))
+            rd2.append(cost(addrs, "r"))
+    f = lambda v: sum(c for c, _ in v) / sum(n for _, n in v)
+    return f(wr), f(rd1), f(wb), f(rd2)
+
+
+def search_inplace(name, LOG2N, VEC):
+    N = 1 << LOG2N
+    T = N // 16
+    R = 16 // VEC
+    NL = VEC * T
+    nb = NL.bit_length() - 1
+    best = []
+    for rot in range(nb):
+        for pad in range(0, 5):
+            for s1 in range(nb):
+                for d1 in (0, 1, 2, 4, 8, 16, 32):
+                    for s2 in range(s1 + 1, nb) if d1 else [0]:
+                        for d2 in ((0, 2, 4, 8, 16, 32) if d1 else (0,)):
+                            RS = R + pad
+
+                            def off(x, rot=rot, RS=RS, s1=s1, d1=d1, s2=s2, d2=d2):
+                                p = ((x >> rot) | (x << (nb - rot))) & (NL - 1)
+                                return p * RS + ((x >> s1) & 1) * d1 + ((x >> s2) & 1) * d2
+                            w, r1, wb, r2 = inplace_wide(LOG2N, VEC, off)
+                            best.append((w + r1 + wb + r2, w, r1, wb, r2, rot, pad, s1, d1, s2, d2, NL * RS + d1 + d2))
+    best.sort()
+    print(name, "in-place best (sum, w, r1, wb, r2, rot, pad, s1, d1, s2, d2, size):")
+    for b in best[:8]:
+        print("   ", b)
