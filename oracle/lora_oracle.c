@@ -310,6 +310,9 @@ int lo_genchirp(lo_cf32 *samps, int N, int ovs, int NN, float f0, int down, floa
 size_t lo_mod_frame_len(int sf, size_t padding, size_t nsyms)
 {
     const size_t N = (size_t)1 << sf;
+    /* STATE_PADSYMBOLS emits one zero symbol BEFORE it tests `_counter >= _padding` (LoRaMod.cpp:218-224):
+     * padding 0 still produces one */
+    if (padding == 0) padding = 1;
     return N * (10 + 2 + 2 + nsyms + padding) + N / 4;
 }
 
@@ -333,6 +336,7 @@ size_t lo_mod_frame(int sf, unsigned char sync, float ampl, size_t padding,
         const float freq = (2 * M_PI * sym) / NN;
         n += (size_t)lo_genchirp(out + n, N, 1, NN, freq, 0, ampl, phaseAccum);
     }
+    if (padding == 0) padding = 1;                                                                         /* :220-222: emit, then test */
     for (size_t p = 0; p < padding; p++)                                                                   /* :218-229 */
         for (int i = 0; i < NN; i++) { out[n].re = 0.0f; out[n].im = 0.0f; n++; }
     return n;

@@ -217,7 +217,7 @@ class Oracle:
 
 
 class Ref:
-    """The real reference code (LoRaDetector.hpp, kissfft.hh, ChirpGenerator.hpp, LoRaDemod.cpp)."""
+    """The real reference code (LoRaDetector.hpp, kissfft.hh, ChirpGenerator.hpp, LoRaDemod.cpp, LoRaMod.cpp)."""
 
     @staticmethod
     def available():
@@ -234,6 +234,8 @@ class Ref:
                                              C.c_void_p, C.c_int]
         L.loraref_genchirp.restype = C.c_int
         L.loraref_genchirp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, _f32p]
+        L.loraref_mod_frame.restype = C.c_size_t
+        L.loraref_mod_frame.argtypes = [C.c_size_t, C.c_int, C.c_float, C.c_size_t, _u16p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.loraref_demod_new.restype = C.c_void_p
         L.loraref_demod_new.argtypes = [C.c_size_t, C.c_int]
         L.loraref_demod_free.argtypes = [C.c_void_p]
@@ -256,6 +258,15 @@ class Ref:
         L.loraref_demod_get_signal.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.loraref_demod_bench.restype = C.c_int64
         L.loraref_demod_bench.argtypes = [C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+
+    def mod_frame(self, sf, syms, sync=0x12, ampl=1.0, padding=1):
+        """the verbatim LoRaMod block (LoRaMod.cpp:109-238): one packet of symbols -> its frame"""
+        syms = np.ascontiguousarray(syms, np.uint16)
+        cap = (1 << sf) * (syms.size + padding + 32)
+        out = np.empty(cap, np.complex64)
+        n = self.L.loraref_mod_frame(sf, sync, float(ampl), padding, _ptr(syms, _u16p), syms.size, out.ctypes.data, cap)
+        assert n > 0, "reference modulator produced nothing"
+        return out[:n].copy()
 
     def detect(self, x):
         x = _cf(x)

@@ -4,7 +4,7 @@
 // /root/reference (see oracle/Makefile; output goes to oracle/_ref/ only):
 //   * LoRaDetector.hpp + kissfft.hh      (framework-free, included below verbatim)
 //   * ChirpGenerator.hpp                 (needs only the empty stub Pothos/Config.hpp)
-//   * LoRaDemod.cpp                      (separate TU, verbatim, against the recording
+//   * LoRaDemod.cpp, LoRaMod.cpp         (separate TUs, verbatim, against the recording
 //                                          fake in oracle/stub/Pothos/Framework.hpp)
 // It exists to (1) pin the plain-C restatement in oracle/lora_oracle.c, (2) generate the
 // golden vectors in tests/golden/, (3) serve as the "reference" CPU baseline in bench.py.
@@ -264,3 +264,39 @@ int64_t loraref_demod_bench(const size_t sf, const float *iq, const size_t sampl
 }
 
 } // extern "C"
+
+/***********************************************************************
+ * LoRaMod block (LoRaMod.cpp:109-238): one packet of symbols -> the samples of its frame
+ **********************************************************************/
+extern "C" size_t loraref_mod_frame(const size_t sf, const int sync, const float ampl, const size_t padding,
+                                    const uint16_t *syms, const size_t nsyms, float *out, const size_t capSamples)
+{
+    auto it = Pothos::BlockRegistry::table().find("/lora/lora_mod");
+    if (it == Pothos::BlockRegistry::table().end()) return 0;
+    Pothos::Block *block = it->second(sf);
+    const size_t N = size_t(1) << sf;
+    block->calls.at("setSync")(double(sync));
+    block->calls.at("setPadding")(double(padding));
+    block->calls.at("setAmplitude")(double(ampl));
+    block->getOutputBufferManager("0", "");
+    std::vector<cf32> buf(N);
+    block->output(0)->_buff = Pothos::BufferChunk::view(buf.data(), N * sizeof(cf32));
+    block->activate();
+    Pothos::Packet pkt;
+    pkt.payload = Pothos::BufferChunk(typeid(uint16_t), nsyms);
+    for (size_t i = 0; i < nsyms; i++) pkt.payload.as<uint16_t *>()[i] = syms[i];
+    block->input(0)->_msgs.push_back(Pothos::Object(pkt));
+    size_t n = 0;
+    for (size_t call = 0; call < nsyms + padding + 64; call++)
+    {
+        const size_t before = block->output(0)->produced;
+        block->work();
+        const size_t got = block->output(0)->produced - before;
+        if (got == 0 && call > 0) break;           // back in STATE_WAITINPUT with nothing queued (LoRaMod.cpp:124-130)
+        if (n + got > capSamples) { n = 0; break; }
+        std::memcpy(reinterpret_cast<cf32 *>(out) + n, buf.data(), got * sizeof(cf32));
+        n += got;
+    }
+    delete block;
+    return n;
+}

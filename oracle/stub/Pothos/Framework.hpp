@@ -3,8 +3,9 @@
 // Pothos is not installed in this image, so the reference's LoRaDemod.cpp cannot be
 // built against the real framework. This header provides just enough of the Pothos
 // surface that LoRaDemod.cpp touches (SURVEY.md §8b symbol list; LoRaDemod.cpp:76-94,
-// 147-154, 295-298, 316-324, 330-358, 395) for the file to compile VERBATIM from
-// /root/reference and be driven by oracle/ref_driver.cpp. It is a recording fake:
+// 147-154, 295-298, 316-324, 330-358, 395) and that LoRaMod.cpp touches (LoRaMod.cpp:65-70, 97,
+// 111-132, 226-250) for the files to compile VERBATIM from /root/reference and be driven by
+// oracle/ref_driver.cpp. It is a recording fake:
 // ports are plain host buffers owned by the driver, labels / messages / signals are
 // appended to per-block logs. Nothing here is product code.
 #pragma once
@@ -15,7 +16,9 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <deque>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <typeinfo>
 #include <vector>
@@ -29,30 +32,18 @@ struct DType
     {
         if (t == typeid(std::complex<float>)) size = sizeof(std::complex<float>);
         else if (t == typeid(int16_t)) size = sizeof(int16_t);
+        else if (t == typeid(uint16_t)) size = sizeof(uint16_t);
         else if (t == typeid(float)) size = sizeof(float);
     }
     size_t size;
 };
 
-struct Object
-{
-    Object(void) {}
-};
-
-struct Label
-{
-    template <typename IdT>
-    Label(const IdT &id, const Object &, const size_t index) : id(id), index(index) {}
-    std::string id;
-    size_t index;
-};
-
 //! shared-ownership buffer, copy = alias (same as the real BufferChunk)
 struct BufferChunk
 {
-    BufferChunk(void) : address(0), length(0) {}
+    BufferChunk(void) : address(0), length(0), elemSize(1) {}
     BufferChunk(const DType &dtype, const size_t numElems) :
-        address(0), length(dtype.size * numElems), _mem(new char[dtype.size * numElems + 16], std::default_delete<char[]>())
+        address(0), length(dtype.size * numElems), elemSize(dtype.size), _mem(new char[dtype.size * numElems + 16], std::default_delete<char[]>())
     {
         std::memset(_mem.get(), 0, length + 16);
         address = size_t(_mem.get());
@@ -66,14 +57,38 @@ struct BufferChunk
         return b;
     }
     template <typename T> T as(void) const { return reinterpret_cast<T>(address); }
+    size_t elements(void) const { return length / elemSize; }
     size_t address;
     size_t length;
+    size_t elemSize;
     std::shared_ptr<char> _mem;
 };
 
 struct Packet
 {
     BufferChunk payload;
+};
+
+//! the only payload a message carries in these blocks is a Packet
+struct Object
+{
+    Object(void) {}
+    explicit Object(const Packet &p) : _pkt(p) {}
+    template <typename T> T extract(void) const { return _pkt; }
+    Packet _pkt;
+};
+
+struct Label
+{
+    template <typename IdT>
+    Label(const IdT &id, const Object &, const size_t index) : id(id), index(index) {}
+    std::string id;
+    size_t index;
+};
+
+struct InvalidArgumentException : public std::runtime_error
+{
+    InvalidArgumentException(const std::string &what, const std::string &why) : std::runtime_error(what + ": " + why) {}
 };
 
 struct BufferManagerArgs
@@ -105,6 +120,9 @@ struct InputPort
     size_t elements(void) const { return _elems; }
     const BufferChunk &buffer(void) const { return _buff; }
     void consume(const size_t n) { consumed += n; }
+    bool hasMessage(void) const { return !_msgs.empty(); }
+    Object popMessage(void) { Object o = _msgs.front(); _msgs.pop_front(); return o; }
+    std::deque<Object> _msgs;
     size_t reserve;
     size_t _elems;
     BufferChunk _buff;

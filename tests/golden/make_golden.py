@@ -91,6 +91,16 @@ def main():
         dm["packets_%d" % sf] = np.stack([p for _, p in r["packets"]])
         dm["signals_%d" % sf] = np.array([v for _, v in r["signals"]], np.float64)
     np.savez_compressed(os.path.join(HERE, "demod_stream.npz"), **dm)
+
+    # 5. the LoRaMod block (verbatim LoRaMod.cpp through the fake framework): frames for a few parameter sets
+    mf = {}
+    for i, (sf, nsym, sync, ampl, pad) in enumerate([(7, 11, 0x12, 1.0, 1), (8, 6, 0x34, 0.5, 3), (10, 5, 0x8e, 1.0, 0)]):
+        syms = rng.integers(0, 1 << sf, nsym).astype(np.uint16)
+        mf["args_%d" % i] = np.array([sf, sync, pad], np.int64)
+        mf["ampl_%d" % i] = np.float32(ampl)
+        mf["syms_%d" % i] = syms
+        mf["frame_%d" % i] = ref.mod_frame(sf, syms, sync=sync, ampl=ampl, padding=pad)
+    np.savez_compressed(os.path.join(HERE, "mod_frame.npz"), **mf)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

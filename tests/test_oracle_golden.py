@@ -62,3 +62,13 @@ def test_demod_stream(oracle, golden, sf):
     assert np.array_equal(np.stack([p for _, p in r["packets"]]), g["packets_%d" % sf])
     assert np.array_equal(g["packets_%d" % sf][0], g["syms_%d" % sf].astype(np.int16))
     assert np.array_equal(np.array(r["signals"], np.float64).reshape(-1), g["signals_%d" % sf])
+
+
+def test_mod_frame_kat(oracle, golden):
+    """frames recorded from the verbatim LoRaMod.cpp block (LoRaMod.cpp:109-238)"""
+    g = golden("mod_frame.npz")
+    for i in range(3):
+        sf, sync, pad = (int(v) for v in g["args_%d" % i])
+        fr = oracle.mod_frame(sf, g["syms_%d" % i], sync=sync, ampl=float(g["ampl_%d" % i]), padding=pad)
+        assert fr.size == g["frame_%d" % i].size
+        assert np.array_equal(bits(fr), bits(g["frame_%d" % i]))

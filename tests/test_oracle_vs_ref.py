@@ -93,3 +93,15 @@ def test_demod_sync_word_and_squelch(oracle, ref):
         assert len(A["packets"]) == len(B["packets"])
         for (ca, pa), (cb, pb) in zip(A["packets"], B["packets"]):
             assert ca == cb and np.array_equal(pa, pb)
+
+
+@pytest.mark.parametrize("sf,padding,sync,ampl", [(7, 1, 0x12, 1.0), (8, 3, 0x34, 0.5), (10, 2, 0x12, 1.0), (12, 1, 0x8e, 2.0), (7, 0, 0x12, 1.0)])
+def test_mod_frame_bit_exact(oracle, ref, sf, padding, sync, ampl):
+    """the restated frame layout against the verbatim LoRaMod.cpp block: 10 up-chirps, two sync chirps, 2 1/4
+    down-chirps, data chirps, padding (LoRaMod.cpp:135-229), one running float phase accumulator"""
+    rng = np.random.default_rng(sf * 10 + padding)
+    syms = rng.integers(0, 1 << sf, 9).astype(np.uint16)
+    a = oracle.mod_frame(sf, syms, sync=sync, ampl=ampl, padding=padding)
+    b = ref.mod_frame(sf, syms, sync=sync, ampl=ampl, padding=padding)
+    assert a.size == b.size
+    assert np.array_equal(bits(a), bits(b))
