@@ -201,6 +201,19 @@ int lorahip_demod_get_trace(const lorahip_demod *d, size_t channel, lorahip_work
 int lorahip_synth_symbols(lorahip_ctx *ctx, float *iq_dev, const uint16_t *sym_dev,
                           size_t n_windows, float ampl, float noise_sigma, uint64_t seed);
 
+/* -------------------------------------------------------------------------------------
+ * Batched modulator + channel (the step before the path: SURVEY.md section 8f #3). n_frames packets of nsyms
+ * uint16 symbols each -> the samples the LoRaMod block produces for them (LoRaMod.cpp:109-238 on
+ * ChirpGenerator.hpp:22-47, ovs = 1): 10 up-chirps, the two sync-word chirps, 2 1/4 down-chirps, one chirp
+ * per symbol, max(padding,1) zero symbols; one running float phase accumulator per frame. Frame f is written
+ * at iq_dev + f*frame_stride samples; frame_stride >= lorahip_mod_frame_len(sf, nsyms, padding).
+ * ------------------------------------------------------------------------------------- */
+size_t lorahip_mod_frame_len(int sf, size_t nsyms, size_t padding);
+int lorahip_mod_frames(lorahip_ctx *ctx, float *iq_dev, size_t frame_stride, const uint16_t *syms_dev,
+                       size_t n_frames, size_t nsyms, unsigned char sync, float ampl, size_t padding);
+/* complex AWGN of per-component standard deviation sigma added in place (counter-based generator keyed by seed) */
+int lorahip_add_awgn(lorahip_ctx *ctx, float *iq_dev, size_t n_samples, float sigma, uint64_t seed);
+
 /* Measurement aid: one read-only streaming pass over n_bytes of device memory (pattern 0: linear
  * 16 B per lane; 1: the access shape of the tuned SF7 kernel). Time it with lorahip_timer_*; the
  * result is the practical HBM ceiling the roofline fraction can be compared with. */

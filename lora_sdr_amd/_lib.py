@@ -68,6 +68,9 @@ SIGNATURES = {
     "lorahip_demod_set_sync": (C.c_int, [C.c_void_p, C.c_ubyte]),
     "lorahip_demod_set_threshold": (C.c_int, [C.c_void_p, C.c_double]),
     "lorahip_demod_set_mtu": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "lorahip_mod_frame_len": (C.c_size_t, [C.c_int, C.c_size_t, C.c_size_t]),
+    "lorahip_mod_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_ubyte, C.c_float, C.c_size_t]),
+    "lorahip_add_awgn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_uint64]),
     "lorahip_demod_activate": (C.c_int, [C.c_void_p]),
     "lorahip_demod_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),

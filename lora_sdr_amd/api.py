@@ -226,6 +226,35 @@ class Context:
         return iq
 
 
+    # ------------------------------------------------------------------
+    def mod_frame_len(self, nsyms, padding=1):
+        return int(self._lib.lorahip_mod_frame_len(self.sf, int(nsyms), int(padding)))
+
+    def mod_frames(self, syms, sync=0x12, ampl=1.0, padding=1, frame_stride=None, lead=0, tail=0):
+        """The LoRaMod block (LoRaMod.cpp:109-238) for a batch of packets: syms is a (n_frames, nsyms) 16-bit device
+        tensor; returns a (n_frames, lead + frame_stride + tail) complex64 device tensor, zero outside the frames."""
+        import torch
+        if syms.dim() != 2 or syms.dtype not in (torch.int16, torch.uint16):
+            raise ValueError("syms must be a (n_frames, nsyms) 16-bit integer device tensor")
+        syms = syms.contiguous()
+        F, S = int(syms.shape[0]), int(syms.shape[1])
+        flen = self.mod_frame_len(S, padding)
+        stride = int(frame_stride or flen)
+        row = lead + stride + tail
+        iq = torch.zeros((F, row), dtype=torch.complex64, device=syms.device)
+        self.use_torch_stream()
+        base = iq.data_ptr() + 8 * lead
+        check(self._lib.lorahip_mod_frames(self._h, C.c_void_p(base), row, _dptr(syms), F, S, int(sync) & 0xff, float(ampl),
+                                           int(padding)), "lorahip_mod_frames")
+        return iq
+
+    def add_awgn(self, iq, sigma, seed=0):
+        """complex AWGN (per-component sigma) added in place to a complex64 device tensor"""
+        self.use_torch_stream()
+        check(self._lib.lorahip_add_awgn(self._h, _dptr(iq), iq.numel(), float(sigma), int(seed) & (2 ** 64 - 1)), "lorahip_add_awgn")
+        return iq
+
+
 class LoRaDetector:
     """`LoRaDetector<float>` (LoRaDetector.hpp:8-72): feed N samples, detect() -> arg-max bin."""
 

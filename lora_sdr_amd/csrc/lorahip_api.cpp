@@ -329,6 +329,30 @@ int lorahip_synth_symbols(lorahip_ctx *ctx, float *iq_dev, const uint16_t *sym_d
     return LORAHIP_OK;
 }
 
+size_t lorahip_mod_frame_len(const int sf, const size_t nsyms, const size_t padding)
+{
+    if (sf < LORAHIP_SF_MIN || sf > LORAHIP_SF_MAX) return 0;
+    const size_t N = size_t(1) << sf;
+    return N * (10 + 2 + 2 + nsyms + (padding ? padding : 1)) + N / 4;      // LoRaMod.cpp:135-229
+}
+
+int lorahip_mod_frames(lorahip_ctx *ctx, float *iq_dev, const size_t frame_stride, const uint16_t *syms_dev,
+                       const size_t n_frames, const size_t nsyms, const unsigned char sync, const float ampl, const size_t padding)
+{
+    if (ctx == nullptr || (n_frames && (!iq_dev || !syms_dev)) || nsyms == 0 || nsyms > 0x7fffffu || padding > 0x7fffffu) return LORAHIP_E_INVALID;
+    if (n_frames > 0xffffffffu || frame_stride < lorahip_mod_frame_len(ctx->sf, nsyms, padding)) return LORAHIP_E_INVALID;
+    LORAHIP_TRY(launchModFrames(reinterpret_cast<float2 *>(iq_dev), (long long)frame_stride, syms_dev, n_frames, int(nsyms), int(sync), ampl,
+                                int(padding), ctx->sf, ctx->stream));
+    return LORAHIP_OK;
+}
+
+int lorahip_add_awgn(lorahip_ctx *ctx, float *iq_dev, const size_t n_samples, const float sigma, const uint64_t seed)
+{
+    if (ctx == nullptr || (n_samples && !iq_dev)) return LORAHIP_E_INVALID;
+    LORAHIP_TRY(launchAwgn(reinterpret_cast<float2 *>(iq_dev), n_samples, sigma, (unsigned long long)seed, ctx->stream));
+    return LORAHIP_OK;
+}
+
 /***********************************************************************
  * LoRaDetector<float> shim
  **********************************************************************/

@@ -108,6 +108,9 @@ hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchSynth(int sf, float2 *iq, const unsigned short *sym, size_t nWindows,
                        float ampl, float sigma, unsigned long long seed, hipStream_t stream);
 
+hipError_t launchModFrames(float2 *iq, long long frameStride, const unsigned short *syms, size_t nFrames, int nsyms, int sync,
+                           float ampl, int padding, int sf, hipStream_t stream);
+hipError_t launchAwgn(float2 *iq, size_t n, float sigma, unsigned long long seed, hipStream_t stream);
 hipError_t launchMembw(const float2 *iq, size_t nBytes, int pattern, int blocks, float *scratch, hipStream_t stream);
 
 void setLastError(const std::string &s);

@@ -267,6 +267,114 @@ hipError_t launchSynth(const int sf, float2 *iq, const unsigned short *sym, cons
 
 
 /***********************************************************************
+ * Batched modulator: the frame of the LoRaMod block (LoRaMod.cpp:109-238) for many packets at once,
+ * one lane per frame. genChirp<float> (ChirpGenerator.hpp:22-47) is a sequential float recurrence --
+ * `f += fStep` with wrap, `phaseAccum +-= f`, one running accumulator through the whole frame, reduced
+ * mod 2pi at the end of every chirp -- so a frame is walked by one lane exactly as the reference walks
+ * it, 64 frames per wavefront; 16 samples at a time go through LDS so that the stores are 128-byte
+ * rows. polar(ampl, phase) = (ampl*cosf, ampl*sinf): cos/sin are evaluated in fp64 and rounded once,
+ * i.e. correctly rounded; glibc's cosf/sinf agree with that except for rare last-ulp cases (tests/).
+ **********************************************************************/
+__global__ void __launch_bounds__(256) modFrames(float2 *__restrict__ iq, const long long frameStride,
+                                                 const unsigned short *__restrict__ syms, const unsigned nFrames,
+                                                 const int nsyms, const int sync, const float ampl, const int padding, const int N)
+{
+    __shared__ float2 stage[4][64][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned frame0 = (blockIdx.x * 4 + wave) * 64;
+    const unsigned frame = frame0 + lane;
+    const bool mine = frame < nFrames;
+    const unsigned short *mySyms = syms + (size_t)(mine ? frame : 0) * nsyms;
+    const float fMin = (float)(-M_PI), fMax = (float)M_PI;                 // ovs = 1   ChirpGenerator.hpp:25-26
+    const float fStep = (float)((2 * M_PI) / N);                           //           :27
+    float phaseAccum = 0.0f;                                               // LoRaMod.cpp:135
+    long long pos = 0;
+    const int pad = padding < 1 ? 1 : padding;                             // one zero symbol is emitted before the test (LoRaMod.cpp:218-224)
+    const int nChirps = 10 + 2 + 3 + nsyms + pad;
+    for (int c = 0; c < nChirps; c++)
+    {
+        // what this chirp is (LoRaMod.cpp:141-229); the structure is the same for every frame, only f0 differs
+        int NN = N;
+        bool down = false, zero = false;
+        float f0 = 0.0f;
+        if (c < 10) {}
+        else if (c == 10) f0 = (float)((2 * M_PI * ((sync >> 4) * 8)) / N);
+        else if (c == 11) f0 = (float)((2 * M_PI * ((sync & 0xf) * 8)) / N);
+        else if (c < 14) down = true;
+        else if (c == 14) { down = true; NN = N / 4; }
+        else if (c < 15 + nsyms) f0 = (float)((2 * M_PI * (int)mySyms[c - 15]) / N);
+        else zero = true;
+        float f = fMin + f0;                                               // ChirpGenerator.hpp:28
+        for (int i0 = 0; i0 < NN; i0 += 16)
+        {
+#pragma unroll 4
+            for (int i = 0; i < 16; i++)
+            {
+                float2 v = make_float2(0.0f, 0.0f);
+                if (!zero)
+                {
+                    f += fStep;                                            // :31 / :39
+                    if (f > fMax) f -= (fMax - fMin);
+                    phaseAccum = down ? phaseAccum - f : phaseAccum + f;
+                    double sn, cs;
+                    sincos((double)phaseAccum, &sn, &cs);
+                    v = make_float2(ampl * (float)cs, ampl * (float)sn);   // std::polar(ampl, phaseAccum)
+                }
+                stage[wave][lane][i] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int r = 0; r < 16; r++)
+            {
+                const int fr = r * 4 + (lane >> 4), sidx = lane & 15;
+                if (frame0 + fr < nFrames) iq[(size_t)(frame0 + fr) * frameStride + pos + i0 + sidx] = stage[wave][fr][sidx];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!zero) phaseAccum = (float)((double)phaseAccum - floor((double)phaseAccum / (2 * M_PI)) * 2 * M_PI);   // :45
+        pos += NN;
+    }
+}
+
+hipError_t launchModFrames(float2 *iq, const long long frameStride, const unsigned short *syms, const size_t nFrames,
+                           const int nsyms, const int sync, const float ampl, const int padding, const int sf, hipStream_t stream)
+{
+    if (nFrames == 0) return hipSuccess;
+    const unsigned grid = unsigned((nFrames + 255) / 256);
+    hipLaunchKernelGGL(modFrames, dim3(grid), dim3(256), 0, stream, iq, frameStride, syms, unsigned(nFrames), nsyms, sync, ampl, padding, 1 << sf);
+    return hipGetLastError();
+}
+
+//! complex AWGN added in place: the channel of the loopback test (TestLoopback.cpp:98-99 adds a noise source to the
+//! modulator output). Same counter-based generator as synthSymbols.
+__global__ void addAwgn(float2 *iq, const size_t n, const float sigma, const unsigned long long seed)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t e = gid; e < n; e += (size_t)gridDim.x * blockDim.x)
+    {
+        const unsigned long long r = splitmix64(seed ^ (e * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull));
+        const double u1 = ((double)(r >> 32) + 1.0) * (1.0 / 4294967296.0);
+        const double u2 = (double)(r & 0xffffffffu) * (1.0 / 4294967296.0);
+        const double rad = sqrt(-2.0 * log(u1));
+        double s2, c2;
+        sincos(6.283185307179586476925 * u2, &s2, &c2);
+        float2 v = iq[e];
+        v.x += sigma * (float)(rad * c2);
+        v.y += sigma * (float)(rad * s2);
+        iq[e] = v;
+    }
+}
+
+hipError_t launchAwgn(float2 *iq, const size_t n, const float sigma, const unsigned long long seed, hipStream_t stream)
+{
+    if (n == 0 || sigma == 0.0f) return hipSuccess;
+    hipLaunchKernelGGL(addAwgn, dim3(2048), dim3(256), 0, stream, iq, n, sigma, seed);
+    return hipGetLastError();
+}
+
+/***********************************************************************
  * HBM read probe (measurement aid, not part of the demod path): streams `n16` 16-byte words
  * and folds them into one checksum per lane. pattern 0: lane-linear float4 (the classic copy
  * shape); pattern 1: the tuned SF7 kernel's shape -- a wave owns 8 KB, reads it as 8 row loads in

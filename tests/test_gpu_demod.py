@@ -179,3 +179,75 @@ def test_config4_mixed_sf_sharded(gpu, oracle):
         r = ctx.detect_batch(iq)
         o = oracle.detect_batch(sf, iq.cpu().numpy(), nthreads=8)
         assert np.array_equal(r["sym"].cpu().numpy().view(np.uint16), o["sym"])
+
+
+def ulp_diff(a, b):
+    """distance in float32 ulps between two float arrays (same sign assumed where it matters)"""
+    ia = np.ascontiguousarray(a).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b).view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7fffffff), ia)
+    ib = np.where(ib < 0, -(ib & 0x7fffffff), ib)
+    return np.abs(ia - ib)
+
+
+@pytest.mark.parametrize("sf,nsyms,sync,ampl,padding", [(7, 11, 0x12, 1.0, 1), (8, 6, 0x34, 0.5, 3), (10, 5, 0x8e, 1.0, 0), (12, 3, 0x12, 2.0, 2)])
+def test_batched_modulator_matches_loramod(gpu, oracle, sf, nsyms, sync, ampl, padding):
+    """lorahip_mod_frames against the LoRaMod frame of the oracle (itself bit-exact with the verbatim LoRaMod.cpp):
+    same length, same zero padding, every sample within 1 float ulp. The float frequency / phase recurrence is reproduced
+    exactly (an error there would grow along the frame); what differs is polar()'s cosf/sinf: the reference takes them
+    from the platform's libm (glibc: up to 0.56 ulp), the kernel rounds the fp64 value once (<= 0.5 ulp), so a percent
+    or two of the samples sit one ulp apart."""
+    import lora_sdr_amd as L
+    torch = gpu
+    rng = np.random.default_rng(sf)
+    F = 70                                               # more than one wavefront, ragged
+    syms = rng.integers(0, 1 << sf, (F, nsyms)).astype(np.uint16)
+    ctx = L.Context(sf)
+    iq = ctx.mod_frames(torch.from_numpy(syms.view(np.int16)).cuda(), sync=sync, ampl=ampl, padding=padding, lead=5, tail=3)
+    torch.cuda.synchronize()
+    got = iq.cpu().numpy()
+    assert got.shape[1] == 5 + ctx.mod_frame_len(nsyms, padding) + 3
+    assert not got[:, :5].any() and not got[:, -3:].any()
+    worst, differ, total = 0, 0, 0
+    for f in (0, 1, 63, 64, F - 1):
+        ref = oracle.mod_frame(sf, syms[f], sync=sync, ampl=ampl, padding=padding)
+        mine = got[f, 5:-3]
+        assert mine.size == ref.size
+        d = ulp_diff(mine.view(np.float32), ref.view(np.float32))
+        small = np.abs(ref.view(np.float32)) < 1e-6 * ampl           # near a zero crossing an ulp is meaningless: absolute check
+        assert np.abs(mine.view(np.float32) - ref.view(np.float32))[small].max(initial=0) < 1e-7 * ampl
+        worst = max(worst, int(d[~small].max()))
+        differ += int((d[~small] > 0).sum())
+        total += int((~small).sum())
+    assert worst <= 1, "more than one ulp from the reference modulator: %d" % worst
+    assert differ <= 5e-2 * total, "%d of %d samples differ in the last ulp" % (differ, total)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sf", [7, 9, 10])
+def test_loopback_mod_noise_demod(gpu, sf, mode):
+    """TestLoopback.cpp's chain without the codec: symbols -> modulator -> AWGN -> demodulator -> the same symbols,
+    for many channels at once, everything on the device"""
+    import lora_sdr_amd as L
+    torch = gpu
+    N, B, nsyms, frames = 1 << sf, 300, 20, 2
+    g = torch.Generator(device="cuda")
+    g.manual_seed(sf)
+    syms = torch.randint(0, N, (B * frames, nsyms), generator=g, device="cuda", dtype=torch.int32).to(torch.int16)
+    ctx = L.Context(sf)
+    iq = ctx.mod_frames(syms, padding=2, lead=N // 2 + 7, tail=0)                 # (B*frames, row)
+    iq = iq.reshape(B, -1)
+    iq = torch.cat([iq, torch.zeros((B, 3 * N), dtype=torch.complex64, device="cuda")], dim=1).contiguous()
+    ctx.add_awgn(iq, sigma=0.2, seed=99)
+    d = L.LoRaDemod(sf, n_channels=B)
+    d.set_mode(mode)
+    d.setMTU(nsyms)
+    d.work(iq)
+    pk = d.packets()
+    assert len(pk) == B * frames
+    sent = syms.cpu().numpy().reshape(B, frames, nsyms)
+    seen = np.zeros(B, np.int64)
+    for ch, _, s in pk:
+        assert np.array_equal(s, sent[ch, seen[ch]]), "channel %d frame %d" % (ch, seen[ch])
+        seen[ch] += 1
+    assert (seen == frames).all()
