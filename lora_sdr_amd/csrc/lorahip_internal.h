@@ -105,6 +105,7 @@ bool fastLayoutsOk();
 hipError_t launchWide(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
 bool streamAvailable(int sf);
 hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);
+hipError_t launchStreamWide(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchSynth(int sf, float2 *iq, const unsigned short *sym, size_t nWindows,
                        float ampl, float sigma, unsigned long long seed, hipStream_t stream);
 

@@ -12,10 +12,9 @@
 // Numerics are those of the batch kernels (same FastCore, same tables); the state machine is the one of
 // lorahip_demod.cpp's host path, which tests pin against the verbatim LoRaDemod.cpp.
 #include "lorahip_fastcore.h"
+#include "lorahip_framemachine.h"
 
 namespace lorahip {
-
-enum { ST_FRAMESYNC = 0, ST_DOWNCHIRP0, ST_DOWNCHIRP1, ST_QUARTERCHIRP, ST_DATASYMBOLS };
 
 template <class C>
 __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD)
@@ -52,10 +51,8 @@ demodStream(const StreamArgs s)
     const unsigned cc = mine ? c : 0;
     StreamState st = s.state[cc];
     const long long base = s.base[cc], len = mine ? s.len[cc] : 0;
-    int calls = 0, nSym = 0, nPkt = 0;
-    lorahip_work_result *out = s.calls ? s.calls + (size_t)cc * s.cap : nullptr;
-    short *symOut = s.symOut + (size_t)cc * s.cap;
-    StreamPacket *pktOut = s.pktOut + (size_t)cc * s.capPkt;
+    StreamOut o;
+    o.init(s, cc);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
     // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
@@ -111,7 +108,7 @@ demodStream(const StreamArgs s)
 
     while (true)
     {
-        const bool live = mine && (len - st.pos >= 2 * N) && calls < s.cap && nPkt < s.capPkt;   // LoRaDemod.cpp:148
+        const bool live = mine && (len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt;   // LoRaDemod.cpp:148
         if (!__any(live)) break;
 
         // ---- window 0 (:157-172) ----
@@ -120,7 +117,6 @@ demodStream(const StreamArgs s)
         detect(live, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd);
         const float snr = power - powerAvg;                                             // :173
         const bool squelched = snr < s.thresh;                                          // :174
-        const int stateBefore = st.state;
         if (live) st.fineTuneIndex = idxEnd;                                            // the loop commits the member (:160-162)
 
         // ---- FRAMESYNC: second window when sync'd and the first sync word matches (:183-206) ----
@@ -142,82 +138,14 @@ demodStream(const StreamArgs s)
         }
 
         // ---- the frame machine (:176-312) ----
-        int total = 0, packetLen = 0, signals = 0, sigError = 0;
-        if (live)
-        {
-            switch (st.state)
-            {
-            case ST_FRAMESYNC:
-                if (syncd && match0 && match1) { total = 2 * N; st.state = ST_DOWNCHIRP0; st.downTable = 1; }   // :209-213
-                else if (!squelched) { total = N - value; st.finefreqError += fIndex; }                          // :217-221
-                else { total = N; st.finefreqError = 0.0f; st.fineTuneIndex = 0; }                               // :228-233
-                break;
-            case ST_DOWNCHIRP0:
-            {
-                st.state = ST_DOWNCHIRP1;
-                total = N;
-                int error = value;
-                if (value > N / 2) error -= N;
-                st.freqError = error;                                                                            // :246-249
-            } break;
-            case ST_DOWNCHIRP1:
-            {
-                st.state = ST_QUARTERCHIRP;
-                total = N;
-                st.downTable = 0;
-                int error = value;
-                if (value > N / 2) error -= N;
-                st.freqError = (st.freqError + error) / 2;                                                       // :262-265
-                signals = 1; sigError = st.freqError;                                                            // :267-269
-            } break;
-            case ST_QUARTERCHIRP:
-                st.state = ST_DATASYMBOLS;
-                total = N / 4 + st.freqError / 2;                                                                // :278
-                st.finefreqError += (float)(st.freqError / 2);
-                st.symCount = 0;
-                break;
-            default: // ST_DATASYMBOLS
-                total = N;
-                if (t == 0) symOut[nSym] = (short)value;                                                         // out[_symCount++] = value  :290
-                nSym++;
-                st.symCount++;
-                if ((unsigned)st.symCount >= s.mtu || squelched)                                                 // :291
-                {
-                    packetLen = st.symCount;
-                    if (t == 0) { pktOut[nPkt].callIndex = st.callCount; pktOut[nPkt].len = packetLen; }         // postMessage  :295-298
-                    nPkt++;
-                    st.finefreqError = 0.0f;
-                    st.state = ST_FRAMESYNC;
-                }
-                break;
-            }
-            st.prevValue = (short)value;                                                                         // :326
-            st.pos += total;                                                                                     // consume(total)  :320
-            if (t == 0 && out)
-            {
-                lorahip_work_result r;
-                r.consumed = total;
-                r.state_before = stateBefore;
-                r.value = value;
-                r.power = power; r.power_avg = powerAvg; r.snr = snr; r.f_index = fIndex;
-                r.worked = 1;
-                r.packet_len = packetLen;
-                r.signals = signals;
-                r.sig_error = sigError;
-                r.sig_power = signals ? power : 0.0f;
-                r.sig_snr = signals ? snr : 0.0f;
-                out[calls] = r;
-            }
-            calls++;
-            st.callCount++;
-        }
+        if (live) frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1);
     }
     if (mine && t == 0)
     {
         s.state[c] = st;
-        s.nCalls[c] = calls;
-        s.nSym[c] = nSym;
-        s.nPkt[c] = nPkt;
+        s.nCalls[c] = o.calls;
+        s.nSym[c] = o.nSym;
+        s.nPkt[c] = o.nPkt;
     }
 }
 
@@ -247,7 +175,7 @@ typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  
 typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  true,  true,  0> Stream9;
 typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  true,  true,  0> Stream10;
 
-bool streamAvailable(const int sf) { return sf >= 7 && sf <= 10; }
+bool streamAvailable(const int sf) { return sf >= 7 && sf <= 12; }
 
 hipError_t launchStream(const int sf, const StreamArgs &s, hipStream_t stream)
 {
@@ -257,6 +185,7 @@ hipError_t launchStream(const int sf, const StreamArgs &s, hipStream_t stream)
     case 8: return launchStreamCfg<Stream8>(s, stream);
     case 9: return launchStreamCfg<Stream9>(s, stream);
     case 10: return launchStreamCfg<Stream10>(s, stream);
+    case 11: case 12: return launchStreamWide(sf, s, stream);
     default: return hipErrorInvalidValue;
     }
 }

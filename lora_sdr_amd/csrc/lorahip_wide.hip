@@ -15,6 +15,7 @@
 //   exch 1   natural position order, 8 elements of padding per 2^(B1+4) block
 //   phase 2  bits [B1+4,LOG2N) lane t holds bins t + T*e                                       (registers)
 #include "lorahip_fft.h"
+#include "lorahip_framemachine.h"
 
 namespace lorahip {
 
@@ -483,6 +484,10 @@ typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, false, true> Cf
 typedef WideCfg<12,  1,  3,         0,  1,  6, 16, false, false, false, true, 0, true, 7, 16> Cfg12l;   // in-place middle phase
 typedef WideCfg<12,  1,  3,         0,  1,  6, 16, false, false, true,  true, 0, true, 7, 16> Cfg12m;
 
+// streaming demodulator configurations (demodStreamWide below): one channel per workgroup, in-place middle phase
+typedef WideCfg<11,  2,  2,         3,  1,  1, 4,  false, false, false, false, 1, true, 2, 8>  StreamWide11;
+typedef WideCfg<12,  1,  2,         0,  1,  6, 16, false, false, false, false, 0, true, 7, 16> StreamWide12;
+
 bool wideAvailable(const int sf) { return sf == 11 || sf == 12; }
 
 //! host-side check of a configuration's exchange-0 layout: every (row, element) has its own word inside the region
@@ -507,7 +512,7 @@ bool wideLayoutsOk()
            layoutOk<Cfg11k>() && layoutOk<Cfg11l>() && layoutOk<Cfg11m>() &&
            layoutOk<Cfg12a>() && layoutOk<Cfg12b>() && layoutOk<Cfg12c>() && layoutOk<Cfg12d>() && layoutOk<Cfg12e>() &&
            layoutOk<Cfg12f>() && layoutOk<Cfg12g>() && layoutOk<Cfg12h>() && layoutOk<Cfg12i>() && layoutOk<Cfg12l>() &&
-           layoutOk<Cfg12m>();
+           layoutOk<Cfg12m>() && layoutOk<StreamWide11>() && layoutOk<StreamWide12>();
 }
 
 hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
@@ -550,6 +555,237 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
         }
     default: return hipErrorInvalidValue;
     }
+}
+
+
+/***********************************************************************
+ * Streaming demodulator for the long windows: a workgroup OWNS a channel (T = 128 / 256 lanes) and walks its stream
+ * window after window -- the level-3 twin of lorahip_stream.hip, same frame machine (lorahip_framemachine.h), the
+ * in-place three-phase FFT of detectWide. Five workgroup barriers per window (two more while the fine-tune index moves).
+ **********************************************************************/
+template <class C>
+__global__ void __launch_bounds__(C::T, 2)
+demodStreamWide(const StreamArgs s)
+{
+    static_assert(C::INPLACE && C::WPB == 1 && !C::CH_LDS && !C::TW_ALL_LDS, "stream configs: one channel per workgroup, in-place middle phase");
+    constexpr int N = C::N, T = C::T, VEC = C::VEC, R = C::R, WPWIN = C::WPWIN;
+    constexpr int LOG2N = C::LOG2N, LOG2T = C::LOG2T, B1 = C::B1, B2 = C::B2, HB = C::HB;
+    constexpr int SLOTS = lastPhaseSlots<LOG2N, B2, LOG2N>();
+    constexpr int M = N * LORAHIP_FINE_STEPS;
+
+    extern __shared__ __attribute__((aligned(16))) char smemRaw[];
+    v2f *sTw = reinterpret_cast<v2f *>(smemRaw);                         // [TWN]
+    v2f *X = sTw + C::TWN;                                               // [XW]
+    RedRec *sRed = reinterpret_cast<RedRec *>(X + C::XW);                // [WPWIN]
+    v2f *sNb = reinterpret_cast<v2f *>(sRed + 4);                        // [2]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const v2f *gIq = reinterpret_cast<const v2f *>(s.iq), *gFine = reinterpret_cast<const v2f *>(s.fine);
+    for (int i = t; i < C::TW_LDS; i += T) sTw[i] = reinterpret_cast<const v2f *>(s.twStage)[i];
+    v2f twR[SLOTS];
+    {
+        int slot = 0;
+#pragma unroll
+        for (int b = B2; b < LOG2N; b += 2)
+#pragma unroll
+            for (int kl = 0; kl < (1 << (b - B2)); kl++)
+            {
+                const int base = twStageOffset(LOG2N, b) + t + (kl << B2);
+                twR[slot] = reinterpret_cast<const v2f *>(s.twStage)[base];
+                twR[slot + 1] = reinterpret_cast<const v2f *>(s.twStage)[base + (1 << b)];
+                twR[slot + 2] = reinterpret_cast<const v2f *>(s.twStage)[base + (2 << b)];
+                slot += 3;
+            }
+    }
+    v2f ch[R][VEC];                                        // down-chirp values of this lane's sample positions
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int u = 0; u < VEC; u++) ch[r][u] = reinterpret_cast<const v2f *>(s.down)[VEC * t + u + VEC * T * r];
+    __syncthreads();
+
+    const unsigned c = blockIdx.x;                         // one channel per workgroup
+    StreamState st = s.state[c];
+    const long long base = s.base[c], len = s.len[c];
+    StreamOut o;
+    o.init(s, c);
+
+    // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect; every argument is workgroup-uniform
+    auto detect = [&](const long long off, const bool downTable, const int idx0, const float err,
+                      int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd)
+    {
+        v2f x[R][VEC];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+        {
+            const v2f *p = gIq + off + VEC * t + VEC * T * r;
+            if (VEC == 2)
+            {
+                const v4f q = *reinterpret_cast<const v4f *>(p);
+                x[r][0] = MAKE2(q.x, q.y);
+                x[r][VEC - 1] = MAKE2(q.z, q.w);
+            }
+            else x[r][0] = *p;
+        }
+        const float d = err * (float)LORAHIP_FINE_STEPS;
+        const bool moving = d != 0.0f;
+        int *sIdx = reinterpret_cast<int *>(X);
+        idxEnd = idx0;
+        if (moving)
+        {
+            if (t < 64)
+            {
+                int idx = idx0;
+                for (int chunk = 0; chunk < N / 1024; chunk++) idx = fineChainGroup<64, 16, M>(idx, d, t, sIdx + chunk * 1024);
+                if (t == 0) sRed[0].i = idx;
+            }
+            __syncthreads();
+            idxEnd = sRed[0].i;
+        }
+        const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
+        const v2f fconst = gFine[idx0];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int u = 0; u < VEC; u++)
+            {
+                const v2f cv = MAKE2(ch[r][u].x, sgn * ch[r][u].y);
+                v2f f = fconst;
+                if (moving) f = gFine[sIdx[chainSlot(VEC * t + u + VEC * T * r)]];
+                x[r][u] = cmulv(cmulv(x[r][u], cv), f);
+            }
+        if (moving) __syncthreads();                       // sIdx is about to be overwritten by exchange 0
+
+        // phase 0 -> exchange 0
+        v2f v0[VEC][R];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int u = 0; u < VEC; u++) v0[u][Plan<LOG2N>::pos(VEC * T * r) & (R - 1)] = x[r][u];
+#pragma unroll
+        for (int u = 0; u < VEC; u++) runPhase<LOG2N, 0, B1, false>(v0[u], 0, sTw, nullptr);
+#pragma unroll
+        for (int u = 0; u < VEC; u++)
+        {
+            v2f *row = X + C::x0off(VEC * t + u);
+#pragma unroll
+            for (int e = 0; e < R; e++) row[e] = v0[u][e];
+        }
+        __syncthreads();                                                                      // B1
+        // phase 1 in place
+        v2f v1[16];
+        const int klow = t & (R - 1), rhigh = rev4(t >> B1, HB);
+#pragma unroll
+        for (int e = 0; e < 16; e++) v1[e] = X[C::x0off((rev4(e, 4) << HB) | rhigh) + klow];
+        runPhase<LOG2N, B1, B2, false>(v1, klow, sTw, nullptr);
+#pragma unroll
+        for (int e = 0; e < 16; e++) X[C::x0off((rev4(e, 4) << HB) | rhigh) + klow] = v1[e];
+        __syncthreads();                                                                      // B3
+        // last phase: lane t holds positions t + T*e
+        v2f vl[16];
+        const int rmid = rev4(t >> B1, 4) << HB;
+#pragma unroll
+        for (int e = 0; e < 16; e++) vl[e] = X[C::x0off(rmid | rev4(e, HB)) + klow];
+        runPhase<LOG2N, B2, LOG2N, true>(vl, 0, nullptr, twR);
+
+        // scan (LoRaDetector.hpp:36-48)
+        float bestV = 0.0f;
+        int bestE = 0;
+        double tot = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+        {
+            const v2f bin = vl[e];
+            const float mag2 = bin.x * bin.x + bin.y * bin.y;
+            tot += (double)mag2;
+            if (mag2 > bestV) { bestV = mag2; bestE = e; }
+        }
+        int bestI = t + (bestE << LOG2T);
+        if (!(bestV > 0.0f)) bestI = 0;
+        groupArgmax<64>(bestV, bestI);
+#pragma unroll
+        for (int off2 = 32; off2 > 0; off2 >>= 1) tot += __shfl_xor(tot, off2, 64);
+        if (lane == 0) { sRed[wave].v = bestV; sRed[wave].i = bestI; sRed[wave].tot = tot; }
+        __syncthreads();                                                                      // B4
+        {
+            const RedRec r0 = sRed[0];
+            bestV = r0.v; bestI = r0.i; tot = r0.tot;
+#pragma unroll
+            for (int k = 1; k < WPWIN; k++)
+            {
+                const RedRec rk = sRed[k];
+                argmaxCombine(bestV, bestI, rk.v, rk.i);
+                tot += rk.tot;
+            }
+        }
+        // neighbours of the peak (LoRaDetector.hpp:56-57)
+        {
+            const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
+            const bool ownL = (bl & (T - 1)) == t, ownR = (br & (T - 1)) == t;
+            if (__any(ownL | ownR))
+            {
+                const v2f mine = selectFlat<16>(vl, ownL ? (bl >> LOG2T) : (br >> LOG2T));
+                if (ownL) sNb[0] = mine;
+                if (ownR) sNb[1] = mine;
+            }
+        }
+        __syncthreads();                                                                      // B5
+        tailValues(s.powerScale, bestV, tot, sNb[0], sNb[1], power, powerAvg, fIndex);
+        value = bestI;
+    };
+
+    while ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt)                  // LoRaDemod.cpp:148
+    {
+        int value, idxEnd;
+        float power, powerAvg, fIndex;
+        detect(base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd);
+        const float snr = power - powerAvg;                                             // :173
+        const bool squelched = snr < s.thresh;                                          // :174
+        st.fineTuneIndex = idxEnd;                                                      // :160-162
+        const bool syncd = !squelched && (st.prevValue + 4) / 8 == 0;                  // :183
+        const bool match0 = (value + 4) / 8 == (s.sync >> 4);                          // :184
+        bool match1 = false;
+        if (st.state == ST_FRAMESYNC && syncd && match0)
+        {
+            int value1, idxEnd1;
+            // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
+            detect(base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, power, powerAvg, fIndex, idxEnd1);
+            match1 = (value1 + 4) / 8 == (s.sync & 0xf);                               // :205; snr is not recomputed
+        }
+        frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1);
+    }
+    if (t == 0)
+    {
+        s.state[c] = st;
+        s.nCalls[c] = o.calls;
+        s.nSym[c] = o.nSym;
+        s.nPkt[c] = o.nPkt;
+    }
+}
+
+
+template <class C>
+static hipError_t launchStreamWideCfg(const StreamArgs &s, hipStream_t stream)
+{
+    const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2);
+    static bool attrSet = false;
+    if (!attrSet)
+    {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(demodStreamWide<C>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        if (e != hipSuccess) return e;
+        attrSet = true;
+    }
+    if (s.nChannels == 0) return hipSuccess;
+    hipLaunchKernelGGL((demodStreamWide<C>), dim3(s.nChannels), dim3(C::T), smem, stream, s);
+    return hipGetLastError();
+}
+
+hipError_t launchStreamWide(const int sf, const StreamArgs &s, hipStream_t stream)
+{
+    return sf == 11 ? launchStreamWideCfg<StreamWide11>(s, stream) : launchStreamWideCfg<StreamWide12>(s, stream);
 }
 
 } // namespace lorahip

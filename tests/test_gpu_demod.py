@@ -75,7 +75,7 @@ def test_golden_stream_through_demod(gpu, golden, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("sf", [7, 8, 9, 10])
+@pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
 def test_many_channels_lockstep(gpu, oracle, sf, mode):
     """channels with different lengths, frequency offsets, sync alignment and noise, one of them pure
     noise and one too short to work at all: every channel must follow its own oracle block"""
@@ -224,13 +224,13 @@ def test_batched_modulator_matches_loramod(gpu, oracle, sf, nsyms, sync, ampl, p
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("sf", [7, 9, 10])
+@pytest.mark.parametrize("sf", [7, 9, 10, 11, 12])
 def test_loopback_mod_noise_demod(gpu, sf, mode):
     """TestLoopback.cpp's chain without the codec: symbols -> modulator -> AWGN -> demodulator -> the same symbols,
     for many channels at once, everything on the device"""
     import lora_sdr_amd as L
     torch = gpu
-    N, B, nsyms, frames = 1 << sf, 300, 20, 2
+    N, B, nsyms, frames = 1 << sf, (300 if sf <= 10 else 70), 20, 2
     g = torch.Generator(device="cuda")
     g.manual_seed(sf)
     syms = torch.randint(0, N, (B * frames, nsyms), generator=g, device="cuda", dtype=torch.int32).to(torch.int16)
