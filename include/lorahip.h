@@ -214,6 +214,32 @@ int lorahip_mod_frames(lorahip_ctx *ctx, float *iq_dev, size_t frame_stride, con
 /* complex AWGN of per-component standard deviation sigma added in place (counter-based generator keyed by seed) */
 int lorahip_add_awgn(lorahip_ctx *ctx, float *iq_dev, size_t n_samples, float sigma, uint64_t seed);
 
+/* -------------------------------------------------------------------------------------
+ * Batched decoder (the step after the path: SURVEY.md section 8f #2): what the LoRaDecoder block does with one symbol
+ * message (LoRaDecoder.cpp:196-397 on LoRaCodes.hpp), for n_packets messages at once. Parameters and defaults are the
+ * block's (LoRaDecoder.cpp:98-110, setters :134-191): coding rate "4/4".."4/8" = rdd 0..4.
+ *   packet p: nsyms_dev[p] symbols at syms_dev + p*sym_stride (sym_stride <= 512)
+ *   out_len_dev[p]: number of output elements posted at out_dev + p*out_stride -- bytes, or uint16 symbols when
+ *       interleaving is off --, -1 if the block posts nothing (fewer than 8 symbols, or dropped), -2 if the packet is
+ *       longer than this build supports; dropped_dev[p] = 1 where the block calls drop() (the "dropped" signal).
+ *   out_stride: even, >= 2*(sym_stride + 8). ctx supplies the device and the stream only (any SF).
+ * ------------------------------------------------------------------------------------- */
+typedef struct lorahip_decoder_cfg {
+    size_t struct_size;     /* = sizeof(lorahip_decoder_cfg) */
+    int32_t sf;             /* setSpreadFactor      default 10 */
+    int32_t ppm;            /* setSymbolSize        default 0 = sf */
+    int32_t rdd;            /* setCodingRate        default 4 ("4/8") */
+    int32_t crcc;           /* enableCrcc           default 0 */
+    int32_t interleaving;   /* enableInterleaving   default 1 */
+    int32_t error_check;    /* enableErrorCheck     default 0 */
+    int32_t explicit_hdr;   /* enableExplicit       default 1 */
+    int32_t hdr;            /* enableHdr            default 0 */
+    int32_t data_length;    /* setDataLength        default 8 */
+} lorahip_decoder_cfg;
+int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, const uint16_t *syms_dev, size_t sym_stride,
+                           const int32_t *nsyms_dev, size_t n_packets, uint8_t *out_dev, size_t out_stride,
+                           int32_t *out_len_dev, int32_t *dropped_dev);
+
 /* Measurement aid: one read-only streaming pass over n_bytes of device memory (pattern 0: linear
  * 16 B per lane; 1: the access shape of the tuned SF7 kernel). Time it with lorahip_timer_*; the
  * result is the practical HBM ceiling the roofline fraction can be compared with. */

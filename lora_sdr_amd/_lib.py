@@ -33,6 +33,11 @@ class Batch(C.Structure):
                 ("fine_idx_out", C.c_void_p), ("fft_out", C.c_void_p), ("dec_out", C.c_void_p)]
 
 
+class DecoderCfg(C.Structure):
+    _fields_ = [("struct_size", C.c_size_t)] + [(n, C.c_int32) for n in ("sf", "ppm", "rdd", "crcc", "interleaving", "error_check",
+                                                                          "explicit_hdr", "hdr", "data_length")]
+
+
 class WorkResult(C.Structure):
     """struct lorahip_work_result"""
     _fields_ = [("consumed", C.c_int64), ("state_before", C.c_int32), ("value", C.c_int32),
@@ -71,6 +76,8 @@ SIGNATURES = {
     "lorahip_mod_frame_len": (C.c_size_t, [C.c_int, C.c_size_t, C.c_size_t]),
     "lorahip_mod_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_ubyte, C.c_float, C.c_size_t]),
     "lorahip_add_awgn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_uint64]),
+    "lorahip_decode_packets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_void_p]),
     "lorahip_demod_activate": (C.c_int, [C.c_void_p]),
     "lorahip_demod_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Batch, WorkResult, check, load, CHIRP_UP, CHIRP_DOWN, CHIRP_NONE  # noqa: F401
+from ._lib import Batch, DecoderCfg, WorkResult, check, load, CHIRP_UP, CHIRP_DOWN, CHIRP_NONE  # noqa: F401
 
 
 def host_tables(sf, fine=True):
@@ -374,3 +374,83 @@ class LoRaDemod:
         if n:
             check(self._lib.lorahip_demod_get_trace(self._h, int(channel), arr, n), "lorahip_demod_get_trace")
         return [dict((f, getattr(r, f)) for f, _ in WorkResult._fields_) for r in arr]
+
+
+class LoRaDecoder:
+    """The `/lora/lora_decoder` block (LoRaDecoder.cpp), same setters and defaults, for batches of symbol packets.
+
+    work(packets): list of int16/uint16 symbol arrays (what LoRaDemod posts) -> list of bytes arrays (None where the
+    block posts nothing); decode_batch(): the same on device tensors."""
+
+    _CR = {"4/4": 0, "4/5": 1, "4/6": 2, "4/7": 3, "4/8": 4}
+
+    def __init__(self, device=0):
+        self._ctx = Context(7, device=device)             # device + stream only; the decoder has its own sf
+        self._cfg = DecoderCfg(C.sizeof(DecoderCfg), 10, 0, 4, 0, 1, 0, 1, 0, 8)   # LoRaDecoder.cpp:98-110
+        self._whitening = True
+        self._dropped = 0
+
+    @staticmethod
+    def make():
+        return LoRaDecoder()
+
+    def setSpreadFactor(self, sf): self._cfg.sf = int(sf)
+    def setSymbolSize(self, ppm): self._cfg.ppm = int(ppm)
+
+    def setCodingRate(self, cr):
+        if cr not in self._CR:
+            raise ValueError("LoRaDecoder::setCodingRate(%s): unknown coding rate" % cr)   # InvalidArgumentException :150
+        self._cfg.rdd = self._CR[cr]
+
+    def enableWhitening(self, on): self._whitening = bool(on)     # stored, never read by work() -- like the reference
+    def enableCrcc(self, on): self._cfg.crcc = int(bool(on))
+    def enableInterleaving(self, on): self._cfg.interleaving = int(bool(on))
+    def enableExplicit(self, on): self._cfg.explicit_hdr = int(bool(on))
+    def enableHdr(self, on): self._cfg.hdr = int(bool(on))
+    def enableErrorCheck(self, on): self._cfg.error_check = int(bool(on))
+    def setDataLength(self, n): self._cfg.data_length = int(n)
+    def getDropped(self): return self._dropped
+    def activate(self): self._dropped = 0
+
+    def decode_batch(self, syms, nsyms):
+        """syms: (P, stride) int16/uint16 device tensor, nsyms: (P,) int32 device tensor ->
+        (out uint8 (P, out_stride), out_len int32 (P,), dropped int32 (P,)) device tensors"""
+        import torch
+        if syms.dim() != 2 or syms.dtype not in (torch.int16, torch.uint16) or nsyms.dtype != torch.int32:
+            raise ValueError("syms must be (P, stride) 16-bit, nsyms (P,) int32 device tensors")
+        syms, nsyms = syms.contiguous(), nsyms.contiguous()
+        P, stride = int(syms.shape[0]), int(syms.shape[1])
+        out_stride = 2 * (stride + 8)
+        out = torch.zeros((P, out_stride), dtype=torch.uint8, device=syms.device)
+        out_len = torch.empty(P, dtype=torch.int32, device=syms.device)
+        dropped = torch.empty(P, dtype=torch.int32, device=syms.device)
+        self._ctx.use_torch_stream()
+        check(self._ctx._lib.lorahip_decode_packets(self._ctx._h, C.byref(self._cfg), _dptr(syms), stride, _dptr(nsyms), P,
+                                                    _dptr(out), out_stride, _dptr(out_len), _dptr(dropped)), "lorahip_decode_packets")
+        return out, out_len, dropped
+
+    def work(self, packets):
+        import torch
+        if self._cfg.ppm > self._cfg.sf:
+            raise ValueError("LoRaDecoder::work(): failed check: PPM <= SF")            # Pothos::Exception :202
+        P = len(packets)
+        if P == 0:
+            return []
+        stride = max(8, max(len(p) for p in packets))
+        host = np.zeros((P, stride), np.uint16)
+        for i, p in enumerate(packets):
+            host[i, :len(p)] = np.asarray(p).astype(np.uint16)
+        n = np.array([len(p) for p in packets], np.int32)
+        dev = torch.device("cuda", self._ctx.device)
+        out, out_len, dropped = self.decode_batch(torch.from_numpy(host.view(np.int16)).to(dev), torch.from_numpy(n).to(dev))
+        out, out_len, dropped = out.cpu().numpy(), out_len.cpu().numpy(), dropped.cpu().numpy()
+        self._dropped += int(dropped.sum())
+        res = []
+        for i in range(P):
+            if out_len[i] < 0:
+                res.append(None)
+            elif self._cfg.interleaving:
+                res.append(out[i, :out_len[i]].copy())
+            else:
+                res.append(out[i, :2 * out_len[i]].view(np.uint16).copy())
+        return res

@@ -353,6 +353,24 @@ int lorahip_add_awgn(lorahip_ctx *ctx, float *iq_dev, const size_t n_samples, co
     return LORAHIP_OK;
 }
 
+int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, const uint16_t *syms_dev, const size_t sym_stride,
+                           const int32_t *nsyms_dev, const size_t n_packets, uint8_t *out_dev, const size_t out_stride,
+                           int32_t *out_len_dev, int32_t *dropped_dev)
+{
+    if (ctx == nullptr || cfg == nullptr || cfg->struct_size != sizeof(lorahip_decoder_cfg)) return LORAHIP_E_INVALID;
+    if (n_packets == 0) return LORAHIP_OK;
+    if (!syms_dev || !nsyms_dev || !out_dev || !out_len_dev || !dropped_dev || n_packets > 0x7fffffffu) return LORAHIP_E_INVALID;
+    if (cfg->sf < 1 || cfg->sf > 16 || cfg->ppm < 0 || cfg->ppm > cfg->sf || cfg->rdd < 0 || cfg->rdd > 4 || cfg->data_length < 0) return LORAHIP_E_INVALID;
+    if (sym_stride == 0 || sym_stride > size_t(decodeMaxSymbols()) || (out_stride & 1) || out_stride < 2 * (sym_stride + 8)) return LORAHIP_E_INVALID;
+    DecodeArgs a;
+    a.syms = syms_dev; a.nsyms = nsyms_dev; a.out = out_dev; a.outLen = out_len_dev; a.dropped = dropped_dev;
+    a.nPackets = unsigned(n_packets); a.symStride = int(sym_stride); a.outStride = int(out_stride);
+    a.sf = cfg->sf; a.ppm = cfg->ppm; a.rdd = cfg->rdd; a.crcc = cfg->crcc; a.interleaving = cfg->interleaving;
+    a.errorCheck = cfg->error_check; a.explicitHdr = cfg->explicit_hdr; a.hdr = cfg->hdr; a.dataLength = cfg->data_length;
+    LORAHIP_TRY(launchDecode(a, ctx->stream));
+    return LORAHIP_OK;
+}
+
 /***********************************************************************
  * LoRaDetector<float> shim
  **********************************************************************/

@@ -95,6 +95,21 @@ struct StreamArgs
     unsigned mtu;
 };
 
+//! argument block of the batched decoder (lorahip_codec.hip); device pointers
+struct DecodeArgs
+{
+    const unsigned short *syms;     // [nPackets][symStride]
+    const int *nsyms;               // [nPackets]
+    unsigned char *out;             // [nPackets][outStride]
+    int *outLen;                    // [nPackets] elements posted, -1 nothing posted, -2 packet too long for this build
+    int *dropped;                   // [nPackets] the block called drop()
+    unsigned nPackets;
+    int symStride, outStride;
+    int sf, ppm, rdd, crcc, interleaving, errorCheck, explicitHdr, hdr, dataLength;
+};
+hipError_t launchDecode(const DecodeArgs &a, hipStream_t stream);
+int decodeMaxSymbols();
+
 //! launchers (lorahip_kernels.hip / lorahip_fast.hip)
 hipError_t launchDetect(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
 bool fastAvailable(int sf);

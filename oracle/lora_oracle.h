@@ -92,6 +92,21 @@ int lo_demod_work(lo_demod *d, const lo_cf32 *in, size_t avail, lo_work_result *
  * of work() calls (= windows dechirped+FFT'd+scanned). */
 int64_t lo_demod_bench(int sf, const lo_cf32 *iq, size_t samplesPerStream, int nStreams, int nthreads, int repeat);
 
+
+/* ---- receive-side codec (oracle/lora_codec.c): the LoRaDecoder block, LoRaDecoder.cpp:196-397 ---- */
+typedef struct lo_decoder_cfg {
+    int sf;             /* setSpreadFactor  */
+    int ppm;            /* setSymbolSize, 0 = sf */
+    int rdd;            /* setCodingRate: "4/4".."4/8" -> 0..4 */
+    int crcc;           /* enableCrcc */
+    int interleaving;   /* enableInterleaving */
+    int error_check;    /* enableErrorCheck */
+    int explicit_hdr;   /* enableExplicit */
+    int hdr;            /* enableHdr */
+    int data_length;    /* setDataLength */
+} lo_decoder_cfg;
+long lo_decode(const lo_decoder_cfg *c, const uint16_t *syms, size_t nsyms, void *out, int *dropped);
+
 #ifdef __cplusplus
 }
 #endif

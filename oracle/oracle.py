@@ -179,6 +179,23 @@ class Oracle:
         assert w == n
         return out
 
+    # -- the LoRaDecoder block (LoRaDecoder.cpp:196-397) ----------------
+    def decode(self, sf, syms, ppm=0, cr="4/8", crcc=False, interleaving=True, error_check=False, explicit=True, hdr=False,
+               data_length=8):
+        """-> (bytes, or uint16 symbols when interleaving is off, or None if nothing was posted; dropped flag)"""
+        syms = np.ascontiguousarray(syms, np.uint16)
+        cfg = DecoderCfg(sf, ppm, CR_TO_RDD[cr], int(crcc), int(interleaving), int(error_check), int(explicit), int(hdr), data_length)
+        out = np.zeros(4 * syms.size + 64, np.uint8)
+        dropped = C.c_int(0)
+        self.L.lo_decode.restype = C.c_long
+        self.L.lo_decode.argtypes = [C.POINTER(DecoderCfg), _u16p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int)]
+        n = self.L.lo_decode(C.byref(cfg), _ptr(syms, _u16p), syms.size, out.ctypes.data, C.byref(dropped))
+        if n < 0:
+            return None, int(dropped.value)
+        if not interleaving:
+            return out[:2 * n].view(np.uint16).copy(), int(dropped.value)
+        return out[:n].copy(), int(dropped.value)
+
     # -- the LoRaDemod block --------------------------------------------
     def demod_run(self, sf, iq, sync=0x12, thresh=-30.0, mtu=256, keep=True):
         """Run the restated block over a stream -> dict of per-call logs + packets"""
@@ -216,6 +233,13 @@ class Oracle:
         return int(self.L.lo_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads, repeat))
 
 
+CR_TO_RDD = {"4/4": 0, "4/5": 1, "4/6": 2, "4/7": 3, "4/8": 4}
+
+
+class DecoderCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("sf", "ppm", "rdd", "crcc", "interleaving", "error_check", "explicit_hdr", "hdr", "data_length")]
+
+
 class Ref:
     """The real reference code (LoRaDetector.hpp, kissfft.hh, ChirpGenerator.hpp, LoRaDemod.cpp, LoRaMod.cpp)."""
 
@@ -234,6 +258,14 @@ class Ref:
                                              C.c_void_p, C.c_int]
         L.loraref_genchirp.restype = C.c_int
         L.loraref_genchirp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, _f32p]
+        L.loraref_decode.restype = C.c_long
+        L.loraref_decode.argtypes = [C.c_size_t, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                     _u16p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_ulonglong)]
+        L.loraref_decode_bench.restype = C.c_double
+        L.loraref_decode_bench.argtypes = [C.c_size_t, C.c_size_t, C.c_char_p, C.c_int, C.c_int, _u16p, C.c_size_t, C.c_size_t]
+        L.loraref_encode.restype = C.c_long
+        L.loraref_encode.argtypes = [C.c_size_t, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                     _u16p, C.c_size_t]
         L.loraref_mod_frame.restype = C.c_size_t
         L.loraref_mod_frame.argtypes = [C.c_size_t, C.c_int, C.c_float, C.c_size_t, _u16p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.loraref_demod_new.restype = C.c_void_p
@@ -258,6 +290,34 @@ class Ref:
         L.loraref_demod_get_signal.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.loraref_demod_bench.restype = C.c_int64
         L.loraref_demod_bench.argtypes = [C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+
+    # -- the codec blocks (LoRaEncoder.cpp / LoRaDecoder.cpp, verbatim) --
+    def encode(self, sf, data, ppm=0, cr="4/8", explicit=True, crc=True, whitening=True):
+        data = np.ascontiguousarray(data, np.uint8)
+        out = np.zeros(16 + 4 * (data.size + 8), np.uint16)
+        n = self.L.loraref_encode(sf, ppm, cr.encode(), int(explicit), int(crc), int(whitening), data.ctypes.data, data.size,
+                                  _ptr(out, _u16p), out.size)
+        assert 0 <= n <= out.size
+        return out[:n].copy()
+
+    def decode_bench(self, sf, syms, reps, ppm=0, cr="4/8", crcc=True, error_check=False):
+        """seconds the verbatim block needs for `reps` messages (one host core)"""
+        syms = np.ascontiguousarray(syms, np.uint16)
+        return float(self.L.loraref_decode_bench(sf, ppm, cr.encode(), int(crcc), int(error_check), _ptr(syms, _u16p), syms.size, reps))
+
+    def decode(self, sf, syms, ppm=0, cr="4/8", crcc=False, interleaving=True, error_check=False, explicit=True, hdr=False,
+               data_length=8):
+        """-> (bytes or None if nothing was posted, dropped count)"""
+        syms = np.ascontiguousarray(syms, np.uint16)
+        out = np.zeros(4 * syms.size + 64, np.uint8)
+        dropped = C.c_ulonglong(0)
+        n = self.L.loraref_decode(sf, ppm, cr.encode(), int(crcc), int(interleaving), int(error_check), int(explicit), int(hdr),
+                                  data_length, _ptr(syms, _u16p), syms.size, out.ctypes.data, out.size, C.byref(dropped))
+        if n < 0:
+            return None, int(dropped.value)
+        if not interleaving:
+            return out[:2 * n].view(np.uint16).copy(), int(dropped.value)
+        return out[:n].copy(), int(dropped.value)
 
     def mod_frame(self, sf, syms, sync=0x12, ampl=1.0, padding=1):
         """the verbatim LoRaMod block (LoRaMod.cpp:109-238): one packet of symbols -> its frame"""

@@ -14,6 +14,7 @@
 // with a zero-filling one (linked -Bsymbolic so only this .so is affected) so that the
 // block starts from the all-zero state the restatement and the HIP path define.
 #include <Pothos/Framework.hpp>
+#include <chrono>
 #include <cstdlib>
 #include <new>
 #include <thread>
@@ -299,4 +300,114 @@ extern "C" size_t loraref_mod_frame(const size_t sf, const int sync, const float
     }
     delete block;
     return n;
+}
+
+/***********************************************************************
+ * The codec blocks, verbatim (LoRaEncoder.cpp:161-233, LoRaDecoder.cpp:196-397 on LoRaCodes.hpp)
+ **********************************************************************/
+static void setCodec(Pothos::Block *b, const char *name, const double v)
+{
+    auto it = b->calls.find(name);
+    if (it != b->calls.end()) it->second(v);
+}
+
+//! one packet of demodulated symbols -> bytes. Returns the payload length of the message the block posted
+//! (in elements: bytes, or uint16 symbols when interleaving is off), -1 if it posted nothing (too short / dropped).
+extern "C" long loraref_decode(const size_t sf, const size_t ppm, const char *cr, const int crcc, const int interleaving,
+                               const int errorCheck, const int explicitHdr, const int hdr, const size_t dataLength,
+                               const uint16_t *syms, const size_t nsyms, void *out, const size_t capBytes, unsigned long long *dropped)
+{
+    auto it = Pothos::BlockRegistry::tableVoid().find("/lora/lora_decoder");
+    if (it == Pothos::BlockRegistry::tableVoid().end()) return -2;
+    Pothos::Block *b = it->second();
+    setCodec(b, "setSpreadFactor", double(sf));
+    setCodec(b, "setSymbolSize", double(ppm));
+    b->stringCalls.at("setCodingRate")(cr);
+    setCodec(b, "enableCrcc", crcc);
+    setCodec(b, "enableInterleaving", interleaving);
+    setCodec(b, "enableErrorCheck", errorCheck);
+    setCodec(b, "enableExplicit", explicitHdr);
+    setCodec(b, "enableHdr", hdr);
+    setCodec(b, "setDataLength", double(dataLength));
+    b->activate();
+    Pothos::Packet pkt;
+    pkt.payload = Pothos::BufferChunk(typeid(uint16_t), nsyms);
+    if (nsyms) std::memcpy(pkt.payload.as<void *>(), syms, nsyms * sizeof(uint16_t));
+    b->input(0)->_msgs.push_back(Pothos::Object(pkt));
+    // the block can throw (Pothos::Exception for PPM > SF, std::bad_alloc / length_error when a header without the crc
+    // flag announces fewer than 2 bytes and `dataLength -= 5` wraps around, LoRaDecoder.cpp:377): nothing is posted then
+    try { b->work(); } catch (...) { delete b; if (dropped) *dropped = 0; return -1; }
+    long n = -1;
+    auto &msgs = b->output(0)->messages;
+    if (!msgs.empty())
+    {
+        n = long(msgs[0].size());
+        if (size_t(n) <= capBytes && n) std::memcpy(out, msgs[0].data(), size_t(n));
+        if (!interleaving) n /= 2;
+    }
+    if (dropped)
+    {
+        *dropped = 0;
+        for (const auto &sg : b->signals) if (sg.name == "dropped") *dropped = (unsigned long long)(sg.value);
+    }
+    delete b;
+    return n;
+}
+
+//! bytes -> the symbols the encoder block posts; returns their number
+extern "C" long loraref_encode(const size_t sf, const size_t ppm, const char *cr, const int explicitHdr, const int crc,
+                               const int whitening, const uint8_t *bytes, const size_t nbytes, uint16_t *out, const size_t capSyms)
+{
+    auto it = Pothos::BlockRegistry::tableVoid().find("/lora/lora_encoder");
+    if (it == Pothos::BlockRegistry::tableVoid().end()) return -2;
+    Pothos::Block *b = it->second();
+    setCodec(b, "setSpreadFactor", double(sf));
+    setCodec(b, "setSymbolSize", double(ppm));
+    b->stringCalls.at("setCodingRate")(cr);
+    setCodec(b, "enableExplicit", explicitHdr);
+    setCodec(b, "enableCrc", crc);
+    setCodec(b, "enableWhitening", whitening);
+    b->activate();
+    Pothos::Packet pkt;
+    pkt.payload = Pothos::BufferChunk(typeid(uint8_t), nbytes);
+    if (nbytes) std::memcpy(pkt.payload.as<void *>(), bytes, nbytes);
+    b->input(0)->_msgs.push_back(Pothos::Object(pkt));
+    b->work();
+    long n = -1;
+    auto &msgs = b->output(0)->messages;
+    if (!msgs.empty())
+    {
+        n = long(msgs[0].size() / 2);
+        if (size_t(n) <= capSyms && n) std::memcpy(out, msgs[0].data(), size_t(n) * 2);
+    }
+    delete b;
+    return n;
+}
+
+//! timing aid: the decoder block created once, `reps` messages decoded back to back; returns seconds
+extern "C" double loraref_decode_bench(const size_t sf, const size_t ppm, const char *cr, const int crcc, const int errorCheck,
+                                       const uint16_t *syms, const size_t nsyms, const size_t reps)
+{
+    auto it = Pothos::BlockRegistry::tableVoid().find("/lora/lora_decoder");
+    if (it == Pothos::BlockRegistry::tableVoid().end()) return -1.0;
+    Pothos::Block *b = it->second();
+    setCodec(b, "setSpreadFactor", double(sf));
+    setCodec(b, "setSymbolSize", double(ppm));
+    b->stringCalls.at("setCodingRate")(cr);
+    setCodec(b, "enableCrcc", crcc);
+    setCodec(b, "enableErrorCheck", errorCheck);
+    b->activate();
+    Pothos::Packet pkt;
+    pkt.payload = Pothos::BufferChunk(typeid(uint16_t), nsyms);
+    std::memcpy(pkt.payload.as<void *>(), syms, nsyms * sizeof(uint16_t));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t r = 0; r < reps; r++)
+    {
+        b->input(0)->_msgs.push_back(Pothos::Object(pkt));
+        b->work();
+        b->output(0)->messages.clear();
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    delete b;
+    return dt;
 }

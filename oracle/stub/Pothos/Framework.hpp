@@ -3,8 +3,8 @@
 // Pothos is not installed in this image, so the reference's LoRaDemod.cpp cannot be
 // built against the real framework. This header provides just enough of the Pothos
 // surface that LoRaDemod.cpp touches (SURVEY.md §8b symbol list; LoRaDemod.cpp:76-94,
-// 147-154, 295-298, 316-324, 330-358, 395) and that LoRaMod.cpp touches (LoRaMod.cpp:65-70, 97,
-// 111-132, 226-250) for the files to compile VERBATIM from /root/reference and be driven by
+// 147-154, 295-298, 316-324, 330-358, 395), LoRaMod.cpp (:65-70, 97, 111-132, 226-250) and the codec
+// blocks LoRaEncoder.cpp / LoRaDecoder.cpp (string / bool setters, message ports, Pothos::Exception) touch, for the files to compile VERBATIM from /root/reference and be driven by
 // oracle/ref_driver.cpp. It is a recording fake:
 // ports are plain host buffers owned by the driver, labels / messages / signals are
 // appended to per-block logs. Nothing here is product code.
@@ -16,6 +16,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <new>
 #include <deque>
 #include <sstream>
 #include <stdexcept>
@@ -33,6 +34,7 @@ struct DType
         if (t == typeid(std::complex<float>)) size = sizeof(std::complex<float>);
         else if (t == typeid(int16_t)) size = sizeof(int16_t);
         else if (t == typeid(uint16_t)) size = sizeof(uint16_t);
+        else if (t == typeid(uint8_t)) size = sizeof(uint8_t);
         else if (t == typeid(float)) size = sizeof(float);
     }
     size_t size;
@@ -43,10 +45,16 @@ struct BufferChunk
 {
     BufferChunk(void) : address(0), length(0), elemSize(1) {}
     BufferChunk(const DType &dtype, const size_t numElems) :
-        address(0), length(dtype.size * numElems), elemSize(dtype.size), _mem(new char[dtype.size * numElems + 16], std::default_delete<char[]>())
+        address(0), length(dtype.size * numElems), elemSize(dtype.size), _mem(alloc(dtype.size, numElems), std::default_delete<char[]>())
     {
         std::memset(_mem.get(), 0, length + 16);
         address = size_t(_mem.get());
+    }
+    //! a request the real framework could never satisfy (a size_t that wrapped around) must fail, not wrap again
+    static char *alloc(const size_t elemSize, const size_t numElems)
+    {
+        if (numElems > (size_t(1) << 40)) throw std::bad_alloc();
+        return new char[elemSize * numElems + 16];
     }
     //! view of externally owned memory (driver side)
     static BufferChunk view(void *p, const size_t bytes)
@@ -89,6 +97,11 @@ struct Label
 struct InvalidArgumentException : public std::runtime_error
 {
     InvalidArgumentException(const std::string &what, const std::string &why) : std::runtime_error(what + ": " + why) {}
+};
+
+struct Exception : public std::runtime_error
+{
+    Exception(const std::string &what, const std::string &why) : std::runtime_error(what + ": " + why) {}
 };
 
 struct BufferManagerArgs
@@ -171,6 +184,13 @@ public:
     {
         calls[name] = [obj, m](const double v) { (obj->*m)(static_cast<A>(v)); };
     }
+    template <typename C>
+    void registerCall(C *obj, const char *name, void (C::*m)(const std::string &))
+    {
+        stringCalls[name] = [obj, m](const std::string &v) { (obj->*m)(v); };
+    }
+    template <typename C, typename R>
+    void registerCall(C *, const char *, R (C::*)(void) const) {}     // getters are not driven
     void registerSignal(const std::string &name) { signalNames.push_back(name); }
     template <typename T>
     void emitSignal(const std::string &name, const T &v)
@@ -198,6 +218,7 @@ public:
     std::map<std::string, InputPort> inputs;
     std::map<std::string, OutputPort> outputs;
     std::map<std::string, std::function<void(double)>> calls;
+    std::map<std::string, std::function<void(const std::string &)>> stringCalls;
     std::vector<std::string> signalNames;
     std::vector<SignalRecord> signals;
 };
@@ -213,6 +234,13 @@ public:
         return t;
     }
     BlockRegistry(const std::string &path, FactorySizeT f) { table()[path] = f; }
+    typedef Block *(*FactoryVoid)(void);
+    static std::map<std::string, FactoryVoid> &tableVoid(void)
+    {
+        static std::map<std::string, FactoryVoid> t;
+        return t;
+    }
+    BlockRegistry(const std::string &path, FactoryVoid f) { tableVoid()[path] = f; }
 };
 
 } // namespace Pothos

@@ -101,6 +101,35 @@ def main():
         mf["syms_%d" % i] = syms
         mf["frame_%d" % i] = ref.mod_frame(sf, syms, sync=sync, ampl=ampl, padding=pad)
     np.savez_compressed(os.path.join(HERE, "mod_frame.npz"), **mf)
+
+    # 6. the codec blocks (verbatim LoRaEncoder.cpp -> symbols, verbatim LoRaDecoder.cpp -> bytes): clean and damaged
+    #    packets over coding rates, symbol sizes, header modes, crc, error checking
+    ck = {}
+    n = 0
+    rdd_of = {"4/4": 0, "4/5": 1, "4/6": 2, "4/7": 3, "4/8": 4}
+    for sf in (7, 9, 10, 12):
+        for cr in ("4/4", "4/5", "4/6", "4/7", "4/8"):
+            for ppm, explicit, crc in ((0, True, True), (sf - 2, True, False), (0, False, True), (sf - 2, False, False)):
+                nbytes = int(rng.integers(2, 48))
+                data = rng.integers(0, 256, nbytes).astype(np.uint8)
+                syms = ref.encode(sf, data, ppm=ppm, cr=cr, explicit=explicit, crc=crc)
+                for damage in (0, 1, 2):
+                    s = syms.copy()
+                    if damage == 1:
+                        k = int(rng.integers(0, s.size)); s[k] = (int(s[k]) + 1) % (1 << sf)
+                    elif damage == 2:
+                        for k in rng.integers(0, s.size, 3): s[int(k)] = int(rng.integers(0, 1 << sf))
+                    for hdr, ec in ((False, False), (True, True)):
+                        out, dropped = ref.decode(sf, s, ppm=ppm, cr=cr, crcc=crc, error_check=ec, explicit=explicit, hdr=hdr,
+                                                  data_length=nbytes)
+                        ck["cfg_%d" % n] = np.array([sf, ppm, rdd_of[cr], int(crc), 1, int(ec), int(explicit), int(hdr), nbytes], np.int32)
+                        ck["syms_%d" % n] = s
+                        ck["data_%d" % n] = data
+                        ck["out_%d" % n] = out if out is not None else np.zeros(0, np.uint8)
+                        ck["res_%d" % n] = np.array([-1 if out is None else out.size, dropped, damage], np.int32)
+                        n += 1
+    ck["count"] = np.int64(n)
+    np.savez_compressed(os.path.join(HERE, "codec_kat.npz"), **ck)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

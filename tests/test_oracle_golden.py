@@ -72,3 +72,25 @@ def test_mod_frame_kat(oracle, golden):
         fr = oracle.mod_frame(sf, g["syms_%d" % i], sync=sync, ampl=float(g["ampl_%d" % i]), padding=pad)
         assert fr.size == g["frame_%d" % i].size
         assert np.array_equal(bits(fr), bits(g["frame_%d" % i]))
+
+
+RDD_TO_CR = {0: "4/4", 1: "4/5", 2: "4/6", 3: "4/7", 4: "4/8"}
+
+
+def test_codec_kat(oracle, golden):
+    """symbol packets from the verbatim LoRaEncoder.cpp, clean and damaged, and what the verbatim LoRaDecoder.cpp posts
+    for them: the restated decoder must post the same bytes / nothing / drop"""
+    g = golden("codec_kat.npz")
+    clean_ok = 0
+    for i in range(int(g["count"])):
+        sf, ppm, rdd, crcc, inter, ec, explicit, hdr, dlen = (int(v) for v in g["cfg_%d" % i])
+        out, dropped = oracle.decode(sf, g["syms_%d" % i], ppm=ppm, cr=RDD_TO_CR[rdd], crcc=bool(crcc), interleaving=bool(inter),
+                                     error_check=bool(ec), explicit=bool(explicit), hdr=bool(hdr), data_length=dlen)
+        n, drp, damage = (int(v) for v in g["res_%d" % i])
+        assert (-1 if out is None else out.size) == n and bool(dropped) == bool(drp), i
+        if out is not None:
+            assert np.array_equal(out, g["out_%d" % i]), i
+        if damage == 0 and explicit and crcc and not hdr:
+            assert np.array_equal(out, g["data_%d" % i])
+            clean_ok += 1
+    assert clean_ok >= 20
