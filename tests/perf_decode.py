@@ -1,10 +1,10 @@
 """Batched decoder throughput (packets/s) against the verbatim LoRaDecoder.cpp on one host core.
-    python tools/bench_decode.py [--packets 262144]"""
+    python tests/perf_decode.py [--packets 262144]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import lora_sdr_amd as L
-from oracle.oracle import Ref, Oracle        # measurement baseline only
+from oracle.oracle import Ref                # CPU baseline (tests/ may use the oracle)
 
 ap = argparse.ArgumentParser(); ap.add_argument("--packets", type=int, default=262144); a = ap.parse_args()
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "codec_kat.npz"))
