@@ -213,14 +213,12 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         K::scan(vl, F, (DBG && a.fftOut && active) ? gFft + (size_t)w * N : nullptr, t, bestV, bestI, tot);
 
         // ---- defer the log/sqrt tail: one record per window, flushed 64 at a time ---------------
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        v2f leftBin, rightBin;
+        K::neighbours(vl, F, bestI, lane, t, leftBin, rightBin);
         if (t == 0 && active)
         {
-            // neighbours of the peak for fIndex (LoRaDetector.hpp:56-57)
             const int s = pending + wsub;
-            tr.w[s] = w; tr.idx[s] = bestI; tr.val[s] = bestV; tr.tot[s] = tot;
-            tr.l[s] = F[(bestI + N - 1) & (N - 1)]; tr.r[s] = F[(bestI + 1) & (N - 1)];
+            tr.w[s] = w; tr.idx[s] = bestI; tr.val[s] = bestV; tr.tot[s] = tot; tr.l[s] = leftBin; tr.r[s] = rightBin;
         }
         pending += WPW;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -310,7 +308,16 @@ typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  false, 1>     Cfg9g;
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  1, true> Cfg9h;
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  false, 1, true> Cfg9i;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1, true> Cfg10i;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1, true> Cfg10i;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true> Cfg10j;   // chirp values in registers too
+typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true> Cfg9j;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true> Cfg8j;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true> Cfg7j;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  false, false, 1, true> Cfg7k;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true, true> Cfg7l;   // neighbours by register select
+typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true> Cfg8l;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true, true> Cfg9l;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true> Cfg10l;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
 
 bool fastAvailable(const int sf) { return sf >= 7 && sf <= 10; }
 
@@ -352,11 +359,14 @@ hipError_t launchFast(const int sf, const int variant, const DetectArgs &a, cons
         case 8: return launchCfg<Cfg7h>(a, ft, stream);
         case 9: return launchCfg<Cfg7i>(a, ft, stream);
         case 10: return launchCfg<Cfg7b>(a, ft, stream);
-        default: return launchCfg<Cfg7h>(a, ft, stream);      // measured best (profiles/r01/s8_variants.txt)
+        case 11: return launchCfg<Cfg7j>(a, ft, stream);
+        case 12: return launchCfg<Cfg7k>(a, ft, stream);
+        case 13: return launchCfg<Cfg7l>(a, ft, stream);
+        default: return launchCfg<Cfg7j>(a, ft, stream);      // measured best (profiles/r01/s8_variants.txt)
         }
-    case 8: return variant == 6 ? launchCfg<Cfg8f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg8g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg8h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg8>(a, ft, stream) : launchCfg<Cfg8i>(a, ft, stream);
-    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg9g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg9h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg9>(a, ft, stream) : launchCfg<Cfg9i>(a, ft, stream);
-    case 10: return variant == 6 ? launchCfg<Cfg10f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg10g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg10h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg10>(a, ft, stream) : launchCfg<Cfg10i>(a, ft, stream);
+    case 8: return variant == 6 ? launchCfg<Cfg8f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg8g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg8h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg8>(a, ft, stream) : variant == 11 ? launchCfg<Cfg8j>(a, ft, stream) : variant == 13 ? launchCfg<Cfg8l>(a, ft, stream) : variant == 9 ? launchCfg<Cfg8i>(a, ft, stream) : launchCfg<Cfg8j>(a, ft, stream);
+    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg9g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg9h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg9>(a, ft, stream) : variant == 11 ? launchCfg<Cfg9j>(a, ft, stream) : variant == 13 ? launchCfg<Cfg9l>(a, ft, stream) : variant == 9 ? launchCfg<Cfg9i>(a, ft, stream) : launchCfg<Cfg9j>(a, ft, stream);
+    case 10: return variant == 6 ? launchCfg<Cfg10f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg10g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg10h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg10>(a, ft, stream) : variant == 11 ? launchCfg<Cfg10j>(a, ft, stream) : variant == 13 ? launchCfg<Cfg10l>(a, ft, stream) : variant == 9 ? launchCfg<Cfg10i>(a, ft, stream) : launchCfg<Cfg10j>(a, ft, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -14,10 +14,11 @@ namespace lorahip {
  *   groups and the readers' ds_read_b64 groups each tile the LDS banks exactly once.
  **********************************************************************/
 template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_,
-          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false>
+          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false>
 struct FastCfg
 {
     static constexpr int PREFETCH = PREFETCH_;        // next window set's loads: 0 none (loaded at the top), 1 issued after the dechirp of this set, 2 at the top of this set
+    static constexpr bool NB_SELECT = NB_SELECT_;     // peak's neighbours by register select + lane shuffle instead of staging all bins in LDS
     static constexpr bool NT = NT_;                   // non-temporal hint on the IQ loads (read once, never reused)
     static constexpr bool CH_LDS = CH_LDS_;           // chirp table read from LDS per window (else loop-invariant registers)
     static constexpr bool TW_ALL_LDS = TW_ALL_LDS_;   // last-phase twiddles from the LDS table too (else registers)
@@ -229,10 +230,13 @@ struct FastCore
     static __device__ __forceinline__ void scan(const v2f (&vl)[NGL][GL], v2f *F, v2f *fftOut, const int t,
                                                 float &bestV, int &bestI, double &tot)
     {
+        if (!C::NB_SELECT)
+        {
 #pragma unroll
-        for (int e = 0; e < GL; e++)
+            for (int e = 0; e < GL; e++)
 #pragma unroll
-            for (int g = 0; g < NGL; g++) F[(t + T * g) + (e << BL)] = vl[g][e];
+                for (int g = 0; g < NGL; g++) F[(t + T * g) + (e << BL)] = vl[g][e];
+        }
         bestV = 0.0f;
         int bestJ = 0;                                     // element number e*NGL + g of the lane's best bin
         tot = 0.0;
@@ -254,6 +258,30 @@ struct FastCore
         for (int off = T / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
         // every lane of the window now holds the window's (bestV, bestI); the xor tree adds the same
         // fp64 partials in the same pairing on all lanes, so tot is identical on all of them too
+    }
+
+    //! bins k-1 and k+1 of the window's peak k (LoRaDetector.hpp:56-57), valid in every lane of the window
+    static __device__ __forceinline__ void neighbours(const v2f (&vl)[NGL][GL], const v2f *F, const int bestI, const int lane, const int t,
+                                                      v2f &leftBin, v2f &rightBin)
+    {
+        const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
+        if (C::NB_SELECT)
+        {
+            const int cil = bl & ((1 << BL) - 1), cir = br & ((1 << BL) - 1);
+            const bool ownL = (cil & (T - 1)) == t;
+            const int req = ownL ? ((bl >> BL) * NGL + (cil >> LOG2T)) : ((br >> BL) * NGL + (cir >> LOG2T));
+            const v2f mine = selectReg<NGL, GL>(vl, req);
+            const int base = lane & ~(T - 1);
+            leftBin = MAKE2(__shfl(mine.x, base + (cil & (T - 1)), 64), __shfl(mine.y, base + (cil & (T - 1)), 64));
+            rightBin = MAKE2(__shfl(mine.x, base + (cir & (T - 1)), 64), __shfl(mine.y, base + (cir & (T - 1)), 64));
+        }
+        else
+        {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            leftBin = F[bl];
+            rightBin = F[br];
+        }
     }
 
     //! position of sample n's fine-tune index inside the window's sIdx array (lane-major transposed so that

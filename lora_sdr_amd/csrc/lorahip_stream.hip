@@ -97,9 +97,8 @@ demodStream(const StreamArgs s)
         int bestI;
         double tot;
         K::scan(vl, F, nullptr, t, bestV, bestI, tot);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const v2f l = F[(bestI + N - 1) & (N - 1)], r = F[(bestI + 1) & (N - 1)];
+        v2f l, r;
+        K::neighbours(vl, F, bestI, lane, t, l, r);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         tailValues(s.powerScale, bestV, tot, l, r, power, powerAvg, fIndex);
