@@ -300,6 +300,7 @@ class LoRaDemod:
         check(self._lib.lorahip_demod_create(C.byref(self._h), int(device), int(sf), int(n_channels)),
               "lorahip_demod_create")
         self.sf, self.N, self.n_channels = int(sf), 1 << int(sf), int(n_channels)
+        self._thresh = -30.0                                            # LoRaDemod.cpp:72
 
     @staticmethod
     def make(sf):
@@ -317,6 +318,7 @@ class LoRaDemod:
 
     def setThreshold(self, thresh_dB):
         check(self._lib.lorahip_demod_set_threshold(self._h, float(thresh_dB)), "lorahip_demod_set_threshold")
+        self._thresh = float(np.float32(thresh_dB))
 
     def setMTU(self, mtu):
         check(self._lib.lorahip_demod_set_mtu(self._h, int(mtu)), "lorahip_demod_set_mtu")
@@ -367,6 +369,32 @@ class LoRaDemod:
 
     def work_calls(self):
         return int(self._lib.lorahip_demod_work_calls(self._h))
+
+    def labels(self, channel):
+        """The stream labels the block posts at index 0 of its raw / dec / fft outputs, one per work() call ("" = none):
+        "SYNC", "P <fIndex>", "DC", "QC", "S<n> <fIndex>" (LoRaDemod.cpp:213,221-224,245,282,302-305,314-319), rebuilt from the
+        per-call trace (set_trace(True) before work())."""
+        out, nsym = [], 0
+        for r in self.trace(channel):
+            st = r["state_before"]
+            if st == 0:
+                if r["consumed"] == 2 * self.N:
+                    out.append("SYNC")
+                elif not (np.float32(r["snr"]) < np.float32(self._thresh)):
+                    out.append("P %.4f" % r["f_index"])
+                else:
+                    out.append("")
+            elif st == 1:
+                out.append("DC")
+            elif st == 2:
+                out.append("")
+            elif st == 3:
+                out.append("QC")
+                nsym = 0
+            else:
+                nsym += 1
+                out.append("S%d %.4f" % (nsym, r["f_index"]))
+        return out
 
     def trace(self, channel):
         n = self._lib.lorahip_demod_trace_len(self._h, int(channel))

@@ -67,6 +67,7 @@ def test_golden_stream_through_demod(gpu, golden, mode):
         d.work([g["iq_%d" % sf]])
         tr = d.trace(0)
         assert [t["consumed"] for t in tr] == g["consumed_%d" % sf].tolist()
+        assert d.labels(0) == g["labels_%d" % sf].tolist()          # the block's stream labels, rebuilt from the trace
         pk = d.packets()
         assert [p[1] for p in pk] == g["packet_calls_%d" % sf].tolist()
         assert np.array_equal(np.stack([p[2] for p in pk]), g["packets_%d" % sf])
