@@ -14,10 +14,11 @@ namespace lorahip {
  *   groups and the readers' ds_read_b64 groups each tile the LDS banks exactly once.
  **********************************************************************/
 template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_,
-          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false>
+          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false, bool X1_SWAP_ = false>
 struct FastCfg
 {
     static constexpr int PREFETCH = PREFETCH_;        // next window set's loads: 0 none (loaded at the top), 1 issued after the dechirp of this set, 2 at the top of this set
+    static constexpr bool X1_SWAP = X1_SWAP_;         // exchange 1 as a 4x4 transpose between the wave's 16-lane rows and registers (v_permlane16/32_swap), no LDS
     static constexpr bool NB_SELECT = NB_SELECT_;     // peak's neighbours by register select + lane shuffle instead of staging all bins in LDS
     static constexpr bool NT = NT_;                   // non-temporal hint on the IQ loads (read once, never reused)
     static constexpr bool CH_LDS = CH_LDS_;           // chirp table read from LDS per window (else loop-invariant registers)
@@ -196,6 +197,38 @@ struct FastCore
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int g = 0; g < NG1; g++) runPhase<LOG2N, B1, B2, false>(v1[g], (t + T * g) & (R - 1), sTw, nullptr);
+            if (C::X1_SWAP)
+            {
+                // T = 64, one group of 16 per lane: lane (klow = t & 15, row = t >> 4) holds positions klow + 16*e + 256*row and
+                // must end up with positions (t + 64*g) + 256*e2, i.e. vl[g][e2] at row r = v1[r + 4g] of row e2: for every g a
+                // 4x4 transpose between the row number and the low two bits of the register number -- two butterfly stages of
+                // row swaps (rows r <-> r^1, then r <-> r^2), one instruction per register pair and component.
+                static_assert(!C::X1_SWAP || (T == 64 && NG1 == 1 && G1 == 16 && GL == 4 && NGL == 4), "row-swap exchange: SF10 shape only");
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                {
+                    unsigned m[4][2];
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+                    {
+                        m[a][0] = __float_as_uint(v1[0][a + 4 * b].x);
+                        m[a][1] = __float_as_uint(v1[0][a + 4 * b].y);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+                    {
+                        v2u r;
+                        r = __builtin_amdgcn_permlane16_swap(m[0][c], m[1][c], false, false); m[0][c] = r.x; m[1][c] = r.y;
+                        r = __builtin_amdgcn_permlane16_swap(m[2][c], m[3][c], false, false); m[2][c] = r.x; m[3][c] = r.y;
+                        r = __builtin_amdgcn_permlane32_swap(m[0][c], m[2][c], false, false); m[0][c] = r.x; m[2][c] = r.y;
+                        r = __builtin_amdgcn_permlane32_swap(m[1][c], m[3][c], false, false); m[1][c] = r.x; m[3][c] = r.y;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; a++) vl[b][a] = MAKE2(__uint_as_float(m[a][0]), __uint_as_float(m[a][1]));
+                }
+            }
+            else
+            {
             // exchange 1: element (rl, rh, col) of this window at rh*X1 + col*R + rl
             v2f *X1w = X + wsub * (GL * C::X1);
 #pragma unroll
@@ -213,6 +246,7 @@ struct FastCore
             for (int g = 0; g < NGL; g++)
 #pragma unroll
                 for (int e = 0; e < GL; e++) vl[g][e] = X1w[e * C::X1 + (t + T * g)];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
