@@ -317,6 +317,7 @@ typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  false, false, 
 typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true, true> Cfg7l;   // neighbours by register select
 typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true> Cfg8l;
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true, true> Cfg9l;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true, false, true> Cfg9m;   // exchange 1 by DPP + row swaps
 typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true> Cfg10l;
 typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, false, true> Cfg10m;   // exchange 1 by row swaps
 typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true, true> Cfg10n;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
@@ -367,7 +368,7 @@ hipError_t launchFast(const int sf, const int variant, const DetectArgs &a, cons
         default: return launchCfg<Cfg7j>(a, ft, stream);      // measured best (profiles/r01/s8_variants.txt)
         }
     case 8: return variant == 6 ? launchCfg<Cfg8f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg8g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg8h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg8>(a, ft, stream) : variant == 11 ? launchCfg<Cfg8j>(a, ft, stream) : variant == 13 ? launchCfg<Cfg8l>(a, ft, stream) : variant == 9 ? launchCfg<Cfg8i>(a, ft, stream) : launchCfg<Cfg8j>(a, ft, stream);
-    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg9g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg9h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg9>(a, ft, stream) : variant == 11 ? launchCfg<Cfg9j>(a, ft, stream) : variant == 13 ? launchCfg<Cfg9l>(a, ft, stream) : variant == 9 ? launchCfg<Cfg9i>(a, ft, stream) : launchCfg<Cfg9j>(a, ft, stream);
+    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg9g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg9h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg9>(a, ft, stream) : variant == 13 ? launchCfg<Cfg9l>(a, ft, stream) : variant == 12 ? launchCfg<Cfg9m>(a, ft, stream) : variant == 9 ? launchCfg<Cfg9i>(a, ft, stream) : variant == 11 ? launchCfg<Cfg9j>(a, ft, stream) : launchCfg<Cfg9m>(a, ft, stream);
     case 10: return variant == 6 ? launchCfg<Cfg10f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg10g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg10h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg10>(a, ft, stream) : variant == 13 ? launchCfg<Cfg10l>(a, ft, stream) : variant == 12 ? launchCfg<Cfg10m>(a, ft, stream) : variant == 14 ? launchCfg<Cfg10n>(a, ft, stream) : variant == 9 ? launchCfg<Cfg10i>(a, ft, stream) : variant == 11 ? launchCfg<Cfg10j>(a, ft, stream) : launchCfg<Cfg10m>(a, ft, stream);
     default: return hipErrorInvalidValue;
     }

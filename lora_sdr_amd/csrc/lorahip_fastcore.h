@@ -203,7 +203,7 @@ struct FastCore
                 // must end up with positions (t + 64*g) + 256*e2, i.e. vl[g][e2] at row r = v1[r + 4g] of row e2: for every g a
                 // 4x4 transpose between the row number and the low two bits of the register number -- two butterfly stages of
                 // row swaps (rows r <-> r^1, then r <-> r^2), one instruction per register pair and component.
-                static_assert(!C::X1_SWAP || (T == 64 && NG1 == 1 && G1 == 16 && GL == 4 && NGL == 4), "row-swap exchange: SF10 shape only");
+                static_assert(!C::X1_SWAP || ((T == 64 || T == 32) && NG1 == 1 && G1 == 16 && GL == 4 && NGL == 4), "row-swap exchange: SF9 / SF10 shape only");
 #pragma unroll
                 for (int b = 0; b < 4; b++)
                 {
@@ -218,10 +218,28 @@ struct FastCore
                     for (int c = 0; c < 2; c++)
                     {
                         v2u r;
-                        r = __builtin_amdgcn_permlane16_swap(m[0][c], m[1][c], false, false); m[0][c] = r.x; m[1][c] = r.y;
-                        r = __builtin_amdgcn_permlane16_swap(m[2][c], m[3][c], false, false); m[2][c] = r.x; m[3][c] = r.y;
-                        r = __builtin_amdgcn_permlane32_swap(m[0][c], m[2][c], false, false); m[0][c] = r.x; m[2][c] = r.y;
-                        r = __builtin_amdgcn_permlane32_swap(m[1][c], m[3][c], false, false); m[1][c] = r.x; m[3][c] = r.y;
+                        if (T == 64)
+                        {
+                            // row number = lane bits (4,5)
+                            r = __builtin_amdgcn_permlane16_swap(m[0][c], m[1][c], false, false); m[0][c] = r.x; m[1][c] = r.y;
+                            r = __builtin_amdgcn_permlane16_swap(m[2][c], m[3][c], false, false); m[2][c] = r.x; m[3][c] = r.y;
+                            r = __builtin_amdgcn_permlane32_swap(m[0][c], m[2][c], false, false); m[0][c] = r.x; m[2][c] = r.y;
+                            r = __builtin_amdgcn_permlane32_swap(m[1][c], m[3][c], false, false); m[1][c] = r.x; m[3][c] = r.y;
+                        }
+                        else
+                        {
+                            // T = 32 (two windows per wave): row number = lane bits (3,4). Bit 3 lives inside a 16-lane row: DPP row_ror:8
+                            // brings lane l^8, the bank mask keeps the half that stays (two movs per register pair)
+#pragma unroll
+                            for (int p = 0; p < 4; p += 2)
+                            {
+                                const unsigned A = m[p][c], B = m[p + 1][c];
+                                m[p][c] = __builtin_amdgcn_update_dpp(A, B, 0x128, 0xf, 0xC, false);       // lanes 8..15 of a row take B[l^8]
+                                m[p + 1][c] = __builtin_amdgcn_update_dpp(B, A, 0x128, 0xf, 0x3, false);   // lanes 0..7 take A[l^8]
+                            }
+                            r = __builtin_amdgcn_permlane16_swap(m[0][c], m[2][c], false, false); m[0][c] = r.x; m[2][c] = r.y;
+                            r = __builtin_amdgcn_permlane16_swap(m[1][c], m[3][c], false, false); m[1][c] = r.x; m[3][c] = r.y;
+                        }
                     }
 #pragma unroll
                     for (int a = 0; a < 4; a++) vl[b][a] = MAKE2(__uint_as_float(m[a][0]), __uint_as_float(m[a][1]));
