@@ -78,6 +78,8 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 
     typename K::TwR twR;
     K::loadTwR(twR, reinterpret_cast<const v2f *>(ft.twStage), t);
+    typename K::TwM twM;
+    K::loadTwM(twM, reinterpret_cast<const v2f *>(ft.twStage), t);
 
     // chirp table values of this lane's sample positions. One table serves both selections:
     // _upChirpTable = conj(_downChirpTable) entry by entry (LoRaDemod.cpp:103-104)
@@ -203,7 +205,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         // ---- phases / exchanges; the next set's samples go in flight once phase 0's inputs are staged and land
         // while this set is transformed (past the end: re-read the last set, harmless and branch-free)
         v2f vl[NGL][GL];
-        K::fft(x, X, wsub, t, sTw, twR, vl, [&]() { if (C::PREFETCH == 1) issueLoads(set + waveCount < nSets ? set + waveCount : nSets - 1); });
+        K::fft(x, X, wsub, t, sTw, twR, vl, [&]() { if (C::PREFETCH == 1) issueLoads(set + waveCount < nSets ? set + waveCount : nSets - 1); }, &twM);
 
         // ---- scan (LoRaDetector.hpp:36-48); final bins into the (now free) exchange region for the neighbour fetch
         v2f *F = X + wsub * FS;
@@ -320,7 +322,11 @@ typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true, false, true> Cfg9m;   // exchange 1 by DPP + row swaps
 typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true> Cfg10l;
 typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, false, true> Cfg10m;   // exchange 1 by row swaps
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true, true> Cfg10n;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true, true> Cfg10n;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 0, true, false, true, true> Cfg10o;   // no prefetch, middle twiddles in registers
+typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  false, false, 1, true, false, true, true> Cfg10p;   // 2 waves/SIMD, everything in registers
+typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 0, true, false, true, true> Cfg9o;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  false, false, 1, true, false, true, true> Cfg9p;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
 
 bool fastAvailable(const int sf) { return sf >= 7 && sf <= 10; }
 
@@ -368,8 +374,8 @@ hipError_t launchFast(const int sf, const int variant, const DetectArgs &a, cons
         default: return launchCfg<Cfg7j>(a, ft, stream);      // measured best (profiles/r01/s8_variants.txt)
         }
     case 8: return variant == 6 ? launchCfg<Cfg8f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg8g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg8h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg8>(a, ft, stream) : variant == 11 ? launchCfg<Cfg8j>(a, ft, stream) : variant == 13 ? launchCfg<Cfg8l>(a, ft, stream) : variant == 9 ? launchCfg<Cfg8i>(a, ft, stream) : launchCfg<Cfg8j>(a, ft, stream);
-    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg9g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg9h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg9>(a, ft, stream) : variant == 13 ? launchCfg<Cfg9l>(a, ft, stream) : variant == 12 ? launchCfg<Cfg9m>(a, ft, stream) : variant == 9 ? launchCfg<Cfg9i>(a, ft, stream) : variant == 11 ? launchCfg<Cfg9j>(a, ft, stream) : launchCfg<Cfg9m>(a, ft, stream);
-    case 10: return variant == 6 ? launchCfg<Cfg10f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg10g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg10h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg10>(a, ft, stream) : variant == 13 ? launchCfg<Cfg10l>(a, ft, stream) : variant == 12 ? launchCfg<Cfg10m>(a, ft, stream) : variant == 14 ? launchCfg<Cfg10n>(a, ft, stream) : variant == 9 ? launchCfg<Cfg10i>(a, ft, stream) : variant == 11 ? launchCfg<Cfg10j>(a, ft, stream) : launchCfg<Cfg10m>(a, ft, stream);
+    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg9g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg9h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg9>(a, ft, stream) : variant == 13 ? launchCfg<Cfg9l>(a, ft, stream) : variant == 12 ? launchCfg<Cfg9m>(a, ft, stream) : variant == 15 ? launchCfg<Cfg9o>(a, ft, stream) : variant == 16 ? launchCfg<Cfg9p>(a, ft, stream) : variant == 9 ? launchCfg<Cfg9i>(a, ft, stream) : variant == 11 ? launchCfg<Cfg9j>(a, ft, stream) : launchCfg<Cfg9m>(a, ft, stream);
+    case 10: return variant == 6 ? launchCfg<Cfg10f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg10g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg10h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg10>(a, ft, stream) : variant == 13 ? launchCfg<Cfg10l>(a, ft, stream) : variant == 12 ? launchCfg<Cfg10m>(a, ft, stream) : variant == 15 ? launchCfg<Cfg10o>(a, ft, stream) : variant == 16 ? launchCfg<Cfg10p>(a, ft, stream) : variant == 14 ? launchCfg<Cfg10n>(a, ft, stream) : variant == 9 ? launchCfg<Cfg10i>(a, ft, stream) : variant == 11 ? launchCfg<Cfg10j>(a, ft, stream) : launchCfg<Cfg10m>(a, ft, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -14,10 +14,11 @@ namespace lorahip {
  *   groups and the readers' ds_read_b64 groups each tile the LDS banks exactly once.
  **********************************************************************/
 template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_,
-          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false, bool X1_SWAP_ = false>
+          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false, bool X1_SWAP_ = false, bool TW_MID_REG_ = false>
 struct FastCfg
 {
     static constexpr int PREFETCH = PREFETCH_;        // next window set's loads: 0 none (loaded at the top), 1 issued after the dechirp of this set, 2 at the top of this set
+    static constexpr bool TW_MID_REG = TW_MID_REG_;   // middle-phase twiddles (they depend on the lane only) in registers instead of LDS reads per window
     static constexpr bool X1_SWAP = X1_SWAP_;         // exchange 1 as a 4x4 transpose between the wave's 16-lane rows and registers (v_permlane16/32_swap), no LDS
     static constexpr bool NB_SELECT = NB_SELECT_;     // peak's neighbours by register select + lane shuffle instead of staging all bins in LDS
     static constexpr bool NT = NT_;                   // non-temporal hint on the IQ loads (read once, never reused)
@@ -66,6 +67,7 @@ struct FastCfg
     static constexpr int FS = N + 8;                            // final-bin rows of the wave's windows (8 pad: 16-lane write groups tile the banks)
     static constexpr int XW = (XE > WPW * FS ? XE : WPW * FS) + 2;   // v2f per wave; also holds WPW*N ints
     static constexpr int TWN = (TW_LDS + 1) & ~1;
+    static constexpr int MSLOTS = NPH_ == 3 ? lastPhaseSlots<LOG2N_, PB1_, PB2_>() : 1;   // register twiddles of the middle phase
 };
 
 
@@ -96,6 +98,30 @@ struct FastCore
                     twR[g][slot] = twStage[base];
                     twR[g][slot + 1] = twStage[base + (1 << b)];
                     twR[g][slot + 2] = twStage[base + (2 << b)];
+                    slot += 3;
+                }
+        }
+    }
+
+    typedef v2f TwM[(C::TW_MID_REG && NPH == 3) ? P / C::G1 : 1][(C::TW_MID_REG && NPH == 3) ? C::MSLOTS : 1];
+    //! register twiddles of the middle phase: klow = (t + T*g) mod R
+    static __device__ __forceinline__ void loadTwM(TwM &twM, const v2f *__restrict__ twStage, const int t)
+    {
+        if (!(C::TW_MID_REG && NPH == 3)) return;
+#pragma unroll
+        for (int g = 0; g < ((C::TW_MID_REG && NPH == 3) ? P / C::G1 : 0); g++)
+        {
+            const int klow = (t + T * g) & (R - 1);
+            int slot = 0;
+#pragma unroll
+            for (int b = B1; b < B2; b += 2)
+#pragma unroll
+                for (int kl = 0; kl < (1 << (b - B1)); kl++)
+                {
+                    const int base = twStageOffset(LOG2N, b) + klow + (kl << B1);
+                    twM[g][slot] = twStage[base];
+                    twM[g][slot + 1] = twStage[base + (1 << b)];
+                    twM[g][slot + 2] = twStage[base + (2 << b)];
                     slot += 3;
                 }
         }
@@ -139,7 +165,7 @@ struct FastCore
     //! region. `mid` is called once phase 0's inputs are staged (the batch kernel issues its prefetch there).
     template <class MID>
     static __device__ __forceinline__ void fft(const v2f (&x)[R][VEC], v2f *X, const int wsub, const int t,
-                                               const v2f *sTw, const TwR &twR, v2f (&vl)[NGL][GL], MID mid)
+                                               const v2f *sTw, const TwR &twR, v2f (&vl)[NGL][GL], MID mid, const TwM *twMp = nullptr)
     {
         // ---- phase 0: bits [0, B1) in registers, one group per u -----------------------------
         // register r holds sample index high part a = r; its work-array position low bits are rev(a)
@@ -196,7 +222,11 @@ struct FastCore
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int g = 0; g < NG1; g++) runPhase<LOG2N, B1, B2, false>(v1[g], (t + T * g) & (R - 1), sTw, nullptr);
+            for (int g = 0; g < NG1; g++)
+            {
+                if (C::TW_MID_REG) runPhase<LOG2N, B1, B2, true>(v1[g], 0, nullptr, (*twMp)[C::TW_MID_REG ? g : 0]);
+                else runPhase<LOG2N, B1, B2, false>(v1[g], (t + T * g) & (R - 1), sTw, nullptr);
+            }
             if (C::X1_SWAP)
             {
                 // T = 64, one group of 16 per lane: lane (klow = t & 15, row = t >> 4) holds positions klow + 16*e + 256*row and

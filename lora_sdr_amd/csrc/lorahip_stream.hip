@@ -43,6 +43,8 @@ demodStream(const StreamArgs s)
     for (int i = threadIdx.x; i < N; i += blockDim.x) sCh[i] = reinterpret_cast<const v2f *>(s.down)[i];
     typename K::TwR twR;
     K::loadTwR(twR, reinterpret_cast<const v2f *>(s.twStage), t);
+    typename K::TwM twM;
+    K::loadTwM(twM, reinterpret_cast<const v2f *>(s.twStage), t);
     __syncthreads();
 
     // ---- this lane group's channel and its state (replicated in the T lanes) ----------------------
@@ -91,7 +93,7 @@ demodStream(const StreamArgs s)
         __builtin_amdgcn_wave_barrier();
 
         v2f vl[NGL][GL];
-        K::fft(x, X, wsub, t, sTw, twR, vl, []() {});
+        K::fft(x, X, wsub, t, sTw, twR, vl, []() {}, &twM);
         v2f *F = X + wsub * FS;
         float bestV;
         int bestI;
