@@ -185,6 +185,10 @@ size_t lorahip_demod_num_packets(const lorahip_demod *d);
 /* packet i: channel, round index it was posted in, and length; symbols copied if out != NULL */
 int lorahip_demod_get_packet(const lorahip_demod *d, size_t i, int32_t *channel, int64_t *round,
                              size_t *len, int16_t *out, size_t cap);
+/* all queued packets at once, in posting order: per packet channel / round / length, and the symbols back to back */
+size_t lorahip_demod_num_packet_symbols(const lorahip_demod *d);
+int lorahip_demod_get_packets(const lorahip_demod *d, int32_t *channels, int64_t *rounds, int64_t *lens, size_t cap_packets,
+                              int16_t *syms, size_t cap_syms);
 void lorahip_demod_clear_packets(lorahip_demod *d);
 /* total work() calls made (sum over channels) since create/activate */
 int64_t lorahip_demod_work_calls(const lorahip_demod *d);

@@ -85,6 +85,8 @@ SIGNATURES = {
     "lorahip_demod_num_packets": (C.c_size_t, [C.c_void_p]),
     "lorahip_demod_get_packet": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]),
+    "lorahip_demod_num_packet_symbols": (C.c_size_t, [C.c_void_p]),
+    "lorahip_demod_get_packets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "lorahip_demod_clear_packets": (None, [C.c_void_p]),
     "lorahip_demod_work_calls": (C.c_int64, [C.c_void_p]),
     "lorahip_demod_set_trace": (C.c_int, [C.c_void_p, C.c_int]),

@@ -354,15 +354,14 @@ class LoRaDemod:
 
     def packets(self, clear=True):
         """[(channel, round, int16 symbols)] -- the Pothos::Packet payloads of output port 0"""
-        out = []
-        for i in range(self._lib.lorahip_demod_num_packets(self._h)):
-            ch, rd, ln = C.c_int32(), C.c_int64(), C.c_size_t()
-            check(self._lib.lorahip_demod_get_packet(self._h, i, C.byref(ch), C.byref(rd), C.byref(ln), None, 0),
-                  "lorahip_demod_get_packet")
-            syms = np.empty(ln.value, np.int16)
-            check(self._lib.lorahip_demod_get_packet(self._h, i, None, None, None, syms.ctypes.data, syms.size),
-                  "lorahip_demod_get_packet")
-            out.append((ch.value, rd.value, syms))
+        n = self._lib.lorahip_demod_num_packets(self._h)
+        ns = self._lib.lorahip_demod_num_packet_symbols(self._h)
+        ch, rd, ln = np.empty(n, np.int32), np.empty(n, np.int64), np.empty(n, np.int64)
+        syms = np.empty(ns, np.int16)
+        check(self._lib.lorahip_demod_get_packets(self._h, ch.ctypes.data, rd.ctypes.data, ln.ctypes.data, n, syms.ctypes.data, ns),
+              "lorahip_demod_get_packets")
+        ends = np.cumsum(ln)
+        out = [(int(ch[i]), int(rd[i]), syms[ends[i] - ln[i]:ends[i]].copy()) for i in range(n)]
         if clear:
             self._lib.lorahip_demod_clear_packets(self._h)
         return out

@@ -35,11 +35,13 @@ struct Channel
     std::vector<lorahip_work_result> trace;
 };
 
+//! one posted packet: its symbols are pktSyms[off, off+len) of the owning demod (flat storage: tens of thousands of
+//! packets per run must not cost an allocation each)
 struct Packet
 {
     int32_t channel;
     int64_t round;
-    std::vector<int16_t> syms;
+    size_t off, len;
 };
 
 } // namespace
@@ -55,6 +57,7 @@ struct lorahip_demod
     int64_t workCalls;
     std::vector<Channel> ch;
     std::vector<Packet> packets;
+    std::vector<int16_t> pktSyms;
     // per-round staging (host pinned + device), sized for B windows
     char *h, *d;
     size_t stageBytes;
@@ -265,7 +268,9 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
                     Packet p;
                     p.channel = int32_t(c);
                     p.round = rounds;
-                    p.syms.assign(k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
+                    p.off = dm->pktSyms.size();
+                    p.len = k.symCount;
+                    dm->pktSyms.insert(dm->pktSyms.end(), k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
                     dm->packets.push_back(p);
                     r.packet_len = int32_t(k.symCount);
                     k.finefreqError = 0;
@@ -383,12 +388,14 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
                 Packet pk;
                 pk.channel = int32_t(c);
                 pk.round = q.callIndex;
-                pk.syms.assign(k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
+                pk.off = dm->pktSyms.size();
+                pk.len = size_t(q.len);
+                dm->pktSyms.insert(dm->pktSyms.end(), k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
                 const size_t fresh = size_t(q.len) - k.symCount;
-                pk.syms.insert(pk.syms.end(), sy + p, sy + p + fresh);
+                dm->pktSyms.insert(dm->pktSyms.end(), sy + p, sy + p + fresh);
                 p += fresh;
                 k.symCount = 0;
-                dm->packets.push_back(std::move(pk));
+                dm->packets.push_back(pk);
             }
             // what is left belongs to a packet still being received
             const size_t left = size_t(hNSym[c]) - p;
@@ -558,16 +565,35 @@ int lorahip_demod_get_packet(const lorahip_demod *dm, const size_t i, int32_t *c
     const Packet &p = dm->packets[i];
     if (channel) *channel = p.channel;
     if (round) *round = p.round;
-    if (len) *len = p.syms.size();
+    if (len) *len = p.len;
     if (out)
     {
-        if (cap < p.syms.size()) return LORAHIP_E_INVALID;
-        std::memcpy(out, p.syms.data(), p.syms.size() * sizeof(int16_t));
+        if (cap < p.len) return LORAHIP_E_INVALID;
+        std::memcpy(out, dm->pktSyms.data() + p.off, p.len * sizeof(int16_t));
     }
     return LORAHIP_OK;
 }
 
-void lorahip_demod_clear_packets(lorahip_demod *dm) { if (dm) dm->packets.clear(); }
+size_t lorahip_demod_num_packet_symbols(const lorahip_demod *dm) { return dm ? dm->pktSyms.size() : 0; }
+
+int lorahip_demod_get_packets(const lorahip_demod *dm, int32_t *channels, int64_t *rounds, int64_t *lens, const size_t cap_packets,
+                              int16_t *syms, const size_t cap_syms)
+{
+    if (dm == nullptr || cap_packets < dm->packets.size() || cap_syms < dm->pktSyms.size()) return LORAHIP_E_INVALID;
+    size_t o = 0;
+    for (size_t i = 0; i < dm->packets.size(); i++)
+    {
+        const Packet &p = dm->packets[i];
+        if (channels) channels[i] = p.channel;
+        if (rounds) rounds[i] = p.round;
+        if (lens) lens[i] = int64_t(p.len);
+        if (syms) std::memcpy(syms + o, dm->pktSyms.data() + p.off, p.len * sizeof(int16_t));
+        o += p.len;
+    }
+    return LORAHIP_OK;
+}
+
+void lorahip_demod_clear_packets(lorahip_demod *dm) { if (dm) { dm->packets.clear(); dm->pktSyms.clear(); } }
 
 int64_t lorahip_demod_work_calls(const lorahip_demod *dm) { return dm ? dm->workCalls : 0; }
 

@@ -34,20 +34,25 @@ iq = iq.contiguous()
 torch.cuda.synchronize()
 print("SF%d: %d channels x %d samples (%.1f MB), %d frames of %d data symbols" % (sf, B, iq.shape[1], iq.numel() * 8 / 1e6, a.frames, a.nsyms))
 for mode in [int(m) for m in a.modes.split(",")]:
-    best = None
-    for rep in range(3):
-        d = L.LoRaDemod(sf, n_channels=B); d.set_mode(mode); d.setMTU(a.nsyms)
+    # one demodulator object, like a running block: the first work() also allocates its staging buffers (reported as
+    # "cold"), the following ones reuse them. Packets are verified on the first pass.
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(mode); d.setMTU(a.nsyms)
+    times = []
+    for rep in range(4):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         rounds = d.work(iq)
-        dt = time.perf_counter() - t0
-        calls = d.work_calls(); pk = d.packets()
-        if best is None or dt < best[0]: best = (dt, calls, len(pk), rounds, pk)
-        d.close()
-    dt, calls, npk, rounds, pk = best
+        times.append(time.perf_counter() - t0)
+        if rep == 0:
+            calls = d.work_calls(); pk = d.packets()
+        else:
+            d.packets()
+        d.activate()
+    dt = min(times[1:])
     ok = 0
     for ch, rd, s in pk[: 4 * V]:
-        f = sum(1 for c2, r2, _ in pk if c2 == ch and r2 < rd)
+        f = sum(1 for c2, r2, _ in pk[: 64 * V] if c2 == ch and r2 < rd)
         want = (data[ch % V, f].cpu().numpy() + 0) % N
         ok += int(len(s) == a.nsyms and np.array_equal((s.astype(np.int64) - want) % N, np.full(a.nsyms, (s[0] - want[0]) % N)))
-    print("  mode %d: %.1f ms, %d work() calls in %d rounds -> %.2f Msym/s; %d packets (expected %d), %d/%d checked packets carry the sent symbols (constant bin offset)"
-          % (mode, dt * 1e3, calls, rounds, calls / dt / 1e6, npk, B * a.frames, ok, min(len(pk), 4 * V)))
+    print("  mode %d: %.1f ms warm (%.1f ms cold), %d work() calls in %d rounds -> %.2f Msym/s; %d packets (expected %d), %d/%d checked packets carry the sent symbols (constant bin offset)"
+          % (mode, dt * 1e3, times[0] * 1e3, calls, rounds, calls / dt / 1e6, len(pk), B * a.frames, ok, min(len(pk), 4 * V)))
+    d.close()
