@@ -107,8 +107,16 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     }
     __syncthreads();
 
-    const unsigned waveId = blockIdx.x * WAVES + wave;
-    const unsigned waveCount = gridDim.x * WAVES;
+    // which window sets this wave walks: set = first, first + waveCount, ... < last
+    unsigned waveId = blockIdx.x * WAVES + wave, waveCount = gridDim.x * WAVES, setEnd = nSets;
+    if (C::XCD_CONTIG && gridDim.x >= 8 && (gridDim.x & 7) == 0)
+    {
+        // workgroups are dealt round-robin to the 8 XCDs: give each XCD one contiguous eighth of the batch
+        const unsigned xcd = blockIdx.x & 7, perXcd = (nSets + 7) / 8;
+        waveCount = (gridDim.x >> 3) * WAVES;
+        waveId = xcd * perXcd + (blockIdx.x >> 3) * WAVES + wave;
+        setEnd = (xcd + 1) * perXcd < nSets ? (xcd + 1) * perXcd : nSets;
+    }
     int pending = 0;                                       // tail records waiting in tr
 
     v2f xn[R][VEC];
@@ -118,10 +126,10 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         const unsigned wc_ = w_ < a.nWindows ? w_ : a.nWindows - 1;
         K::load(xn, gIq + (a.offsets ? a.offsets[wc_] : (long long)wc_ * a.stride), t);
     };
-    if (C::PREFETCH && waveId < nSets) issueLoads(waveId);
+    if (C::PREFETCH && waveId < setEnd) issueLoads(waveId);
     const v2f fconst0 = gFine[0];
 
-    for (unsigned set = waveId; set < nSets; set += waveCount)
+    for (unsigned set = waveId; set < setEnd; set += waveCount)
     {
         const unsigned w = set * WPW + wsub;
         const bool active = w < a.nWindows;
@@ -141,7 +149,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int u = 0; u < VEC; u++) x[r][u] = xn[r][u];
-        if (C::PREFETCH == 2) issueLoads(set + waveCount < nSets ? set + waveCount : nSets - 1);
+        if (C::PREFETCH == 2) issueLoads(set + waveCount < setEnd ? set + waveCount : nSets - 1);
 
         // ---- fine-tune index chain for windows whose index moves (LoRaDemod.cpp:160-162) -------------
         int *sIdx = reinterpret_cast<int *>(X) + wsub * N;   // aliases the exchange region (free until phase 0 ends)
@@ -205,7 +213,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         // ---- phases / exchanges; the next set's samples go in flight once phase 0's inputs are staged and land
         // while this set is transformed (past the end: re-read the last set, harmless and branch-free)
         v2f vl[NGL][GL];
-        K::fft(x, X, wsub, t, sTw, twR, vl, [&]() { if (C::PREFETCH == 1) issueLoads(set + waveCount < nSets ? set + waveCount : nSets - 1); }, &twM);
+        K::fft(x, X, wsub, t, sTw, twR, vl, [&]() { if (C::PREFETCH == 1) issueLoads(set + waveCount < setEnd ? set + waveCount : nSets - 1); }, &twM);
 
         // ---- scan (LoRaDetector.hpp:36-48); final bins into the (now free) exchange region for the neighbour fetch
         v2f *F = X + wsub * FS;
@@ -316,7 +324,8 @@ typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 
 typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true> Cfg8j;
 typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true> Cfg7j;
 typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  false, false, 1, true> Cfg7k;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true, true> Cfg7l;   // neighbours by register select
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true, true> Cfg7l;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true, false, false, false, true> Cfg7x;   // XCD-contiguous walk   // neighbours by register select
 typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true> Cfg8l;
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true, true> Cfg9l;
 typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true, false, true> Cfg9m;   // exchange 1 by DPP + row swaps
@@ -371,6 +380,7 @@ hipError_t launchFast(const int sf, const int variant, const DetectArgs &a, cons
         case 11: return launchCfg<Cfg7j>(a, ft, stream);
         case 12: return launchCfg<Cfg7k>(a, ft, stream);
         case 13: return launchCfg<Cfg7l>(a, ft, stream);
+        case 14: return launchCfg<Cfg7x>(a, ft, stream);
         default: return launchCfg<Cfg7j>(a, ft, stream);      // measured best (profiles/r01/s8_variants.txt)
         }
     case 8: return variant == 6 ? launchCfg<Cfg8f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg8g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg8h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg8>(a, ft, stream) : variant == 11 ? launchCfg<Cfg8j>(a, ft, stream) : variant == 13 ? launchCfg<Cfg8l>(a, ft, stream) : variant == 9 ? launchCfg<Cfg8i>(a, ft, stream) : launchCfg<Cfg8j>(a, ft, stream);

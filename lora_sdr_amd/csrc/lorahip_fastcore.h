@@ -14,10 +14,11 @@ namespace lorahip {
  *   groups and the readers' ds_read_b64 groups each tile the LDS banks exactly once.
  **********************************************************************/
 template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_,
-          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false, bool X1_SWAP_ = false, bool TW_MID_REG_ = false>
+          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false, bool X1_SWAP_ = false, bool TW_MID_REG_ = false, bool XCD_CONTIG_ = false>
 struct FastCfg
 {
     static constexpr int PREFETCH = PREFETCH_;        // next window set's loads: 0 none (loaded at the top), 1 issued after the dechirp of this set, 2 at the top of this set
+    static constexpr bool XCD_CONTIG = XCD_CONTIG_;   // workgroups of one XCD (blockIdx mod 8) walk one contiguous eighth of the batch (else: sets interleaved over all workgroups)
     static constexpr bool TW_MID_REG = TW_MID_REG_;   // middle-phase twiddles (they depend on the lane only) in registers instead of LDS reads per window
     static constexpr bool X1_SWAP = X1_SWAP_;         // exchange 1 as a 4x4 transpose between the wave's 16-lane rows and registers (v_permlane16/32_swap), no LDS
     static constexpr bool NB_SELECT = NB_SELECT_;     // peak's neighbours by register select + lane shuffle instead of staging all bins in LDS
