@@ -294,48 +294,33 @@ static hipError_t launchCfg(const DetectArgs &a, const FastTables &ft, hipStream
     return uni ? launchOne<C, false, true>(a, ft, stream) : launchOne<C, false, false>(a, ft, stream);
 }
 
-//              LOG2N T VEC NPH PB1 PB2 w/SIMD  X0: ROT PAD S  D   chLDS twLDS prefetch
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  false> Cfg7a;   // 8 lanes x 16 pts: [R2,4] X [4,4]
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  true>  Cfg7b;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  true,  true,  true>  Cfg7c;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  4,          1,  1,  0, 0,  true,  true,  false> Cfg7d;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  false, false, true>  Cfg7e;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  2>     Cfg7f;   // loads issued at the top of the set
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  false, 1>     Cfg7g;   // last-phase twiddles in registers
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  1, true> Cfg7h;  // non-temporal IQ loads
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  false, 1, true> Cfg7i;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg8;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1>     Cfg8g;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  1, true> Cfg8h;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1, true> Cfg8i;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  2>     Cfg8f;    // 16 lanes x 16 pts: [4,4] X [4,4]
-typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  true>  Cfg9;    // 32 lanes x 16 pts: [R2,4] X [4,4] X [4]
-typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  2>     Cfg9f;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  true>  Cfg10;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  2>     Cfg10f;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1>     Cfg10g;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  true,  1, true> Cfg10h;
-typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  false, 1>     Cfg9g;
-typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  true,  1, true> Cfg9h;
-typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  true,  false, 1, true> Cfg9i;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  true,  false, 1, true> Cfg10i;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true> Cfg10j;   // chirp values in registers too
-typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true> Cfg9j;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true> Cfg8j;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true> Cfg7j;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  false, false, 1, true> Cfg7k;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true, true> Cfg7l;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  false, true,  1, true, false, false, false, true> Cfg7x;   // XCD-contiguous walk   // neighbours by register select
-typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true> Cfg8l;
-typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true, true> Cfg9l;
-typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 1, true, false, true> Cfg9m;   // exchange 1 by DPP + row swaps
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true> Cfg10l;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, false, true> Cfg10m;   // exchange 1 by row swaps
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 1, true, true, true> Cfg10n;
-typedef FastCfg<10, 6, 1,  3,  4,  8,  3,          0,  1,  0, 0,  false, false, 0, true, false, true, true> Cfg10o;   // no prefetch, middle twiddles in registers
-typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  false, false, 1, true, false, true, true> Cfg10p;   // 2 waves/SIMD, everything in registers
-typedef FastCfg<9,  5, 2,  3,  3,  7,  3,          2,  1,  1, 8,  false, false, 0, true, false, true, true> Cfg9o;
-typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  false, false, 1, true, false, true, true> Cfg9p;   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
+/***********************************************************************
+ * configurations: the geometry of an SF is fixed (lanes per window, vector width, phases, the exchange-0 LDS layout found
+ * with tools/lds_conflicts.py); what varies between the selectable variants is a set of options.
+ **********************************************************************/
+template <int SF> struct Geo;
+//                                         LOG2T VEC NPH PB1 PB2   X0: ROT PAD S  D
+template <> struct Geo<7>  { enum { LOG2T = 3, VEC = 2, NPH = 2, PB1 = 3, PB2 = 7, ROT = 1, PAD = 1, S = 0, D = 0 }; };   //  8 lanes x 16 pts: [R2,4] X [4,4]
+template <> struct Geo<8>  { enum { LOG2T = 4, VEC = 1, NPH = 2, PB1 = 4, PB2 = 8, ROT = 0, PAD = 1, S = 0, D = 0 }; };   // 16 lanes x 16 pts: [4,4] X [4,4]
+template <> struct Geo<9>  { enum { LOG2T = 5, VEC = 2, NPH = 3, PB1 = 3, PB2 = 7, ROT = 2, PAD = 1, S = 1, D = 8 }; };   // 32 lanes x 16 pts: [R2,4] X [4,4] X [4]
+template <> struct Geo<10> { enum { LOG2T = 6, VEC = 1, NPH = 3, PB1 = 4, PB2 = 8, ROT = 0, PAD = 1, S = 0, D = 0 }; };   // 64 lanes x 16 pts: [4,4] X [4,4] X [4]
+
+enum : unsigned
+{
+    W2 = 1u << 0, W4 = 1u << 1,         // waves per SIMD the register budget is set for (default 3)
+    CH_REG = 1u << 2,                    // chirp values of the lane's sample positions in registers (default: LDS copy of the table)
+    TW_REG = 1u << 3,                    // last-phase twiddles in registers (default: LDS table)
+    PF_NONE = 1u << 4, PF_EARLY = 1u << 5,   // next set's loads: none / at the top of the set (default: after the dechirp)
+    NT = 1u << 6,                        // non-temporal IQ loads
+    NB_SEL = 1u << 7,                    // peak's neighbours by register select (default: bins staged in LDS)
+    X1_SWAP = 1u << 8,                   // exchange 1 by row swaps / DPP (SF9, SF10)
+    TWM_REG = 1u << 9,                   // middle-phase twiddles in registers
+    XCD = 1u << 10                       // XCD-contiguous walk over the batch
+};
+template <int SF, unsigned O>
+using Fast = FastCfg<SF, Geo<SF>::LOG2T, Geo<SF>::VEC, Geo<SF>::NPH, Geo<SF>::PB1, Geo<SF>::PB2, (O & W2) ? 2 : (O & W4) ? 4 : 3,
+                     Geo<SF>::ROT, Geo<SF>::PAD, Geo<SF>::S, Geo<SF>::D, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
+                     (O & NT) != 0, (O & NB_SEL) != 0, (O & X1_SWAP) != 0, (O & TWM_REG) != 0, (O & XCD) != 0>;
 
 bool fastAvailable(const int sf) { return sf >= 7 && sf <= 10; }
 
@@ -358,36 +343,49 @@ static bool layoutOk()
 
 bool fastLayoutsOk()
 {
-    return layoutOk<Cfg7a>() && layoutOk<Cfg7e>() && layoutOk<Cfg8>() && layoutOk<Cfg9>() && layoutOk<Cfg10>();
+    return layoutOk<Fast<7, 0>>() && layoutOk<Fast<8, 0>>() && layoutOk<Fast<9, 0>>() && layoutOk<Fast<10, 0>>();
 }
+
+/***********************************************************************
+ * selectable variants (lorahip_set_variant): 0 = the measured best per SF (profiles/r01/s8_variants.txt keeps every A/B
+ * pair); the numbers of the others are stable, tests/test_gpu_parity.py runs every one of them against the oracle.
+ **********************************************************************/
+typedef hipError_t (*FastLaunch)(const DetectArgs &, const FastTables &, hipStream_t);
+struct FastVariant { int sf, variant; FastLaunch launch; };
+#define V(SF, N, OPTS) { SF, N, &launchCfg<Fast<SF, (OPTS)>> }
+static const FastVariant kFastVariants[] = {
+    // SF7
+    V(7, 0, CH_REG | NT),                                  // default
+    V(7, 2, PF_NONE), V(7, 3, W2), V(7, 4, W4 | PF_NONE), V(7, 5, W2 | CH_REG | TW_REG), V(7, 6, PF_EARLY), V(7, 7, TW_REG),
+    V(7, 8, NT), V(7, 9, TW_REG | NT), V(7, 10, 0), V(7, 11, CH_REG | NT), V(7, 12, W2 | CH_REG | TW_REG | NT),
+    V(7, 13, CH_REG | NT | NB_SEL), V(7, 14, CH_REG | NT | XCD),
+    // SF8
+    V(8, 0, CH_REG | TW_REG | NT),                         // default
+    V(8, 6, PF_EARLY), V(8, 7, TW_REG), V(8, 8, NT), V(8, 9, TW_REG | NT), V(8, 10, 0), V(8, 11, CH_REG | TW_REG | NT),
+    V(8, 13, CH_REG | TW_REG | NT | NB_SEL),
+    // SF9
+    V(9, 0, CH_REG | TW_REG | NT | X1_SWAP),               // default
+    V(9, 6, PF_EARLY), V(9, 7, TW_REG), V(9, 8, NT), V(9, 9, TW_REG | NT), V(9, 10, 0), V(9, 11, CH_REG | TW_REG | NT),
+    V(9, 12, CH_REG | TW_REG | NT | X1_SWAP), V(9, 13, CH_REG | TW_REG | NT | NB_SEL), V(9, 15, CH_REG | TW_REG | NT | X1_SWAP | TWM_REG | PF_NONE),
+    V(9, 16, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG),
+    // SF10
+    V(10, 0, CH_REG | TW_REG | NT | X1_SWAP),              // default
+    V(10, 6, PF_EARLY), V(10, 7, TW_REG), V(10, 8, NT), V(10, 9, TW_REG | NT), V(10, 10, 0), V(10, 11, CH_REG | TW_REG | NT),
+    V(10, 12, CH_REG | TW_REG | NT | X1_SWAP), V(10, 13, CH_REG | TW_REG | NT | NB_SEL), V(10, 14, CH_REG | TW_REG | NT | NB_SEL | X1_SWAP),
+    V(10, 15, CH_REG | TW_REG | NT | X1_SWAP | TWM_REG | PF_NONE), V(10, 16, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG),
+};
+#undef V
 
 hipError_t launchFast(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
-    switch (sf)
+    const FastVariant *def = nullptr;
+    for (const FastVariant &v : kFastVariants)
     {
-    case 7:
-        switch (variant)
-        {
-        case 2: return launchCfg<Cfg7a>(a, ft, stream);
-        case 3: return launchCfg<Cfg7c>(a, ft, stream);
-        case 4: return launchCfg<Cfg7d>(a, ft, stream);
-        case 5: return launchCfg<Cfg7e>(a, ft, stream);
-        case 6: return launchCfg<Cfg7f>(a, ft, stream);
-        case 7: return launchCfg<Cfg7g>(a, ft, stream);
-        case 8: return launchCfg<Cfg7h>(a, ft, stream);
-        case 9: return launchCfg<Cfg7i>(a, ft, stream);
-        case 10: return launchCfg<Cfg7b>(a, ft, stream);
-        case 11: return launchCfg<Cfg7j>(a, ft, stream);
-        case 12: return launchCfg<Cfg7k>(a, ft, stream);
-        case 13: return launchCfg<Cfg7l>(a, ft, stream);
-        case 14: return launchCfg<Cfg7x>(a, ft, stream);
-        default: return launchCfg<Cfg7j>(a, ft, stream);      // measured best (profiles/r01/s8_variants.txt)
-        }
-    case 8: return variant == 6 ? launchCfg<Cfg8f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg8g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg8h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg8>(a, ft, stream) : variant == 11 ? launchCfg<Cfg8j>(a, ft, stream) : variant == 13 ? launchCfg<Cfg8l>(a, ft, stream) : variant == 9 ? launchCfg<Cfg8i>(a, ft, stream) : launchCfg<Cfg8j>(a, ft, stream);
-    case 9: return variant == 6 ? launchCfg<Cfg9f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg9g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg9h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg9>(a, ft, stream) : variant == 13 ? launchCfg<Cfg9l>(a, ft, stream) : variant == 12 ? launchCfg<Cfg9m>(a, ft, stream) : variant == 15 ? launchCfg<Cfg9o>(a, ft, stream) : variant == 16 ? launchCfg<Cfg9p>(a, ft, stream) : variant == 9 ? launchCfg<Cfg9i>(a, ft, stream) : variant == 11 ? launchCfg<Cfg9j>(a, ft, stream) : launchCfg<Cfg9m>(a, ft, stream);
-    case 10: return variant == 6 ? launchCfg<Cfg10f>(a, ft, stream) : variant == 7 ? launchCfg<Cfg10g>(a, ft, stream) : variant == 8 ? launchCfg<Cfg10h>(a, ft, stream) : variant == 10 ? launchCfg<Cfg10>(a, ft, stream) : variant == 13 ? launchCfg<Cfg10l>(a, ft, stream) : variant == 12 ? launchCfg<Cfg10m>(a, ft, stream) : variant == 15 ? launchCfg<Cfg10o>(a, ft, stream) : variant == 16 ? launchCfg<Cfg10p>(a, ft, stream) : variant == 14 ? launchCfg<Cfg10n>(a, ft, stream) : variant == 9 ? launchCfg<Cfg10i>(a, ft, stream) : variant == 11 ? launchCfg<Cfg10j>(a, ft, stream) : launchCfg<Cfg10m>(a, ft, stream);
-    default: return hipErrorInvalidValue;
+        if (v.sf != sf) continue;
+        if (v.variant == variant) return v.launch(a, ft, stream);
+        if (v.variant == 0) def = &v;
     }
+    return def ? def->launch(a, ft, stream) : hipErrorInvalidValue;     // unknown numbers run the default
 }
 
 } // namespace lorahip
