@@ -456,37 +456,36 @@ static hipError_t launchCfgWide(const DetectArgs &a, const FastTables &ft, hipSt
     return uni ? launchOneWide<C, false, true>(a, ft, stream) : launchOneWide<C, false, false>(a, ft, stream);
 }
 
-//              LOG2N VEC w/SIMD X0: ROT PAD S  D   chLDS twLDS
-// 128 lanes x 16 pts: [R2,4] X [4,4] X [4,4]
-typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  false, false> Cfg11a;
-typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false> Cfg11b;
-typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  true,  false> Cfg11c;
-typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  false, true>  Cfg11d;
-typedef WideCfg<11,  2,  2,         0,  1,  4, 1,  true,  true>  Cfg11e;
-typedef WideCfg<11,  2,  4,         0,  1,  4, 1,  false, false, false> Cfg11f;   // no register prefetch: 4 workgroups per CU
-typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, false> Cfg11g;
-typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, true, true> Cfg11h;   // non-temporal IQ loads
-typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, false, true> Cfg11i;
-typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, false, true, 1> Cfg11j;   // one window (2 wavefronts) per workgroup
-typedef WideCfg<11,  2,  3,         0,  1,  4, 1,  false, false, true, true, 1> Cfg11k;
-typedef WideCfg<11,  2,  3,         3,  1,  1, 4,  false, false, false, true, 1, true, 2, 8> Cfg11l;   // in-place middle phase
-typedef WideCfg<11,  2,  3,         3,  1,  1, 4,  false, false, false, true, 0, true, 2, 8> Cfg11m;
-// 256 lanes x 16 pts: [4,4] X [4,4] X [4,4]
-typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  false, false> Cfg12a;
-typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false> Cfg12b;
-typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  true,  false> Cfg12c;
-typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  false, true>  Cfg12d;
-typedef WideCfg<12,  1,  2,         0,  1,  0, 0,  true,  true>  Cfg12e;
-typedef WideCfg<12,  1,  4,         0,  1,  0, 0,  false, false, false> Cfg12f;
-typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, false> Cfg12g;
-typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, true, true> Cfg12h;
-typedef WideCfg<12,  1,  3,         0,  1,  0, 0,  false, false, false, true> Cfg12i;
-typedef WideCfg<12,  1,  3,         0,  1,  6, 16, false, false, false, true, 0, true, 7, 16> Cfg12l;   // in-place middle phase
-typedef WideCfg<12,  1,  3,         0,  1,  6, 16, false, false, true,  true, 0, true, 7, 16> Cfg12m;
+/***********************************************************************
+ * configurations: geometry per SF x layout (the plain padded exchange-0 layout, or the swizzled one the in-place middle
+ * phase needs -- both found with tools/lds_conflicts.py), plus an option mask.
+ **********************************************************************/
+template <int SF, bool INPLACE> struct WGeo;
+//                                                  VEC  X0: ROT PAD S  D   S2 D2
+template <> struct WGeo<11, false> { enum { VEC = 2, ROT = 0, PAD = 1, S = 4, D = 1,  S2 = 0, D2 = 0 }; };    // 128 lanes x 16 pts: [R2,4] X [4,4] X [4,4]
+template <> struct WGeo<11, true>  { enum { VEC = 2, ROT = 3, PAD = 1, S = 1, D = 4,  S2 = 2, D2 = 8 }; };
+template <> struct WGeo<12, false> { enum { VEC = 1, ROT = 0, PAD = 1, S = 0, D = 0,  S2 = 0, D2 = 0 }; };    // 256 lanes x 16 pts: [4,4] X [4,4] X [4,4]
+template <> struct WGeo<12, true>  { enum { VEC = 1, ROT = 0, PAD = 1, S = 6, D = 16, S2 = 7, D2 = 16 }; };
+
+enum : unsigned
+{
+    WW2 = 1u << 0, WW4 = 1u << 1,       // waves per SIMD the register budget is set for (default 3)
+    WCH_LDS = 1u << 2,                   // chirp values from an LDS copy of the table (default: registers)
+    WTW_LDS = 1u << 3,                   // last-phase twiddles from the LDS table (default: registers)
+    WPF_NONE = 1u << 4,                  // no register prefetch of the next window
+    WNT = 1u << 5,                       // non-temporal IQ loads
+    WONE = 1u << 6,                      // one window per workgroup (SF11: 128 threads)
+    WINPLACE = 1u << 7                   // in-place middle phase (3 barriers per window instead of 4)
+};
+template <int SF, unsigned O>
+using Wide = WideCfg<SF, WGeo<SF, (O & WINPLACE) != 0>::VEC, (O & WW2) ? 2 : (O & WW4) ? 4 : 3,
+                     WGeo<SF, (O & WINPLACE) != 0>::ROT, WGeo<SF, (O & WINPLACE) != 0>::PAD, WGeo<SF, (O & WINPLACE) != 0>::S,
+                     WGeo<SF, (O & WINPLACE) != 0>::D, (O & WCH_LDS) != 0, (O & WTW_LDS) != 0, !(O & WPF_NONE), (O & WNT) != 0,
+                     (O & WONE) ? 1 : 0, (O & WINPLACE) != 0, WGeo<SF, (O & WINPLACE) != 0>::S2, WGeo<SF, (O & WINPLACE) != 0>::D2>;
 
 // streaming demodulator configurations (demodStreamWide below): one channel per workgroup, in-place middle phase
-typedef WideCfg<11,  2,  2,         3,  1,  1, 4,  false, false, false, false, 1, true, 2, 8>  StreamWide11;
-typedef WideCfg<12,  1,  2,         0,  1,  6, 16, false, false, false, false, 0, true, 7, 16> StreamWide12;
+typedef Wide<11, WW2 | WPF_NONE | WONE | WINPLACE> StreamWide11;
+typedef Wide<12, WW2 | WPF_NONE | WINPLACE> StreamWide12;
 
 bool wideAvailable(const int sf) { return sf == 11 || sf == 12; }
 
@@ -505,58 +504,44 @@ static bool layoutOk()
     return true;
 }
 
+bool wideLayoutsOk();
+
+/***********************************************************************
+ * selectable variants (lorahip_set_variant): 0 = the measured best per SF (profiles/r01/s8_variants.txt)
+ **********************************************************************/
+typedef hipError_t (*WideLaunch)(const DetectArgs &, const FastTables &, hipStream_t);
+struct WideVariant { int sf, variant; WideLaunch launch; bool (*layoutOk)(); };
+#define V(SF, N, OPTS) { SF, N, &launchCfgWide<Wide<SF, (OPTS)>>, &layoutOk<Wide<SF, (OPTS)>> }
+static const WideVariant kWideVariants[] = {
+    // SF11
+    V(11, 0, WPF_NONE | WNT | WONE | WINPLACE),            // default
+    V(11, 2, WW2), V(11, 3, WW2 | WCH_LDS), V(11, 4, WW2 | WTW_LDS), V(11, 5, WW2 | WCH_LDS | WTW_LDS), V(11, 6, WW4 | WPF_NONE),
+    V(11, 7, WPF_NONE), V(11, 8, WNT), V(11, 9, WPF_NONE | WNT), V(11, 10, 0), V(11, 11, WPF_NONE | WNT | WONE), V(11, 12, WNT | WONE),
+    V(11, 13, WPF_NONE | WNT | WONE | WINPLACE), V(11, 14, WPF_NONE | WNT | WINPLACE),
+    // SF12
+    V(12, 0, WNT | WINPLACE),                              // default
+    V(12, 2, WW2), V(12, 3, WW2 | WCH_LDS), V(12, 4, WW2 | WTW_LDS), V(12, 5, WW2 | WCH_LDS | WTW_LDS), V(12, 6, WW4 | WPF_NONE),
+    V(12, 7, WPF_NONE), V(12, 8, WNT), V(12, 9, WPF_NONE | WNT), V(12, 10, 0), V(12, 13, WPF_NONE | WNT | WINPLACE), V(12, 14, WNT | WINPLACE),
+};
+#undef V
+
 bool wideLayoutsOk()
 {
-    return layoutOk<Cfg11a>() && layoutOk<Cfg11b>() && layoutOk<Cfg11c>() && layoutOk<Cfg11d>() && layoutOk<Cfg11e>() &&
-           layoutOk<Cfg11f>() && layoutOk<Cfg11g>() && layoutOk<Cfg11h>() && layoutOk<Cfg11i>() && layoutOk<Cfg11j>() &&
-           layoutOk<Cfg11k>() && layoutOk<Cfg11l>() && layoutOk<Cfg11m>() &&
-           layoutOk<Cfg12a>() && layoutOk<Cfg12b>() && layoutOk<Cfg12c>() && layoutOk<Cfg12d>() && layoutOk<Cfg12e>() &&
-           layoutOk<Cfg12f>() && layoutOk<Cfg12g>() && layoutOk<Cfg12h>() && layoutOk<Cfg12i>() && layoutOk<Cfg12l>() &&
-           layoutOk<Cfg12m>() && layoutOk<StreamWide11>() && layoutOk<StreamWide12>();
+    for (const WideVariant &v : kWideVariants) if (!v.layoutOk()) return false;
+    return layoutOk<StreamWide11>() && layoutOk<StreamWide12>();
 }
 
 hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
-    switch (sf)
+    const WideVariant *def = nullptr;
+    for (const WideVariant &v : kWideVariants)
     {
-    case 11:
-        switch (variant)
-        {
-        case 2: return launchCfgWide<Cfg11a>(a, ft, stream);
-        case 3: return launchCfgWide<Cfg11c>(a, ft, stream);
-        case 4: return launchCfgWide<Cfg11d>(a, ft, stream);
-        case 5: return launchCfgWide<Cfg11e>(a, ft, stream);
-        case 6: return launchCfgWide<Cfg11f>(a, ft, stream);
-        case 7: return launchCfgWide<Cfg11g>(a, ft, stream);
-        case 8: return launchCfgWide<Cfg11h>(a, ft, stream);
-        case 10: return launchCfgWide<Cfg11b>(a, ft, stream);
-        case 11: return launchCfgWide<Cfg11j>(a, ft, stream);
-        case 12: return launchCfgWide<Cfg11k>(a, ft, stream);
-        case 13: return launchCfgWide<Cfg11l>(a, ft, stream);
-        case 14: return launchCfgWide<Cfg11m>(a, ft, stream);
-        case 9: return launchCfgWide<Cfg11i>(a, ft, stream);
-        default: return launchCfgWide<Cfg11l>(a, ft, stream);   // measured best (profiles/r01/s8_variants.txt)
-        }
-    case 12:
-        switch (variant)
-        {
-        case 2: return launchCfgWide<Cfg12a>(a, ft, stream);
-        case 3: return launchCfgWide<Cfg12c>(a, ft, stream);
-        case 4: return launchCfgWide<Cfg12d>(a, ft, stream);
-        case 5: return launchCfgWide<Cfg12e>(a, ft, stream);
-        case 6: return launchCfgWide<Cfg12f>(a, ft, stream);
-        case 7: return launchCfgWide<Cfg12g>(a, ft, stream);
-        case 8: return launchCfgWide<Cfg12h>(a, ft, stream);
-        case 9: return launchCfgWide<Cfg12i>(a, ft, stream);
-        case 10: return launchCfgWide<Cfg12b>(a, ft, stream);
-        case 13: return launchCfgWide<Cfg12l>(a, ft, stream);
-        case 14: return launchCfgWide<Cfg12m>(a, ft, stream);
-        default: return launchCfgWide<Cfg12m>(a, ft, stream);   // measured best (profiles/r01/s8_variants.txt)
-        }
-    default: return hipErrorInvalidValue;
+        if (v.sf != sf) continue;
+        if (v.variant == variant) return v.launch(a, ft, stream);
+        if (v.variant == 0) def = &v;
     }
+    return def ? def->launch(a, ft, stream) : hipErrorInvalidValue;     // unknown numbers run the default
 }
-
 
 /***********************************************************************
  * Streaming demodulator for the long windows: a workgroup OWNS a channel (T = 128 / 256 lanes) and walks its stream
