@@ -348,7 +348,7 @@ bool fastLayoutsOk()
 
 /***********************************************************************
  * selectable variants (lorahip_set_variant): 0 = the measured best per SF (profiles/r01/s8_variants.txt keeps every A/B
- * pair); the numbers of the others are stable, tests/test_gpu_parity.py runs every one of them against the oracle.
+ * pair); the numbers of the others are stable, tests/test_gpu_parity.py runs every one of them against the CPU restatement of the reference.
  **********************************************************************/
 typedef hipError_t (*FastLaunch)(const DetectArgs &, const FastTables &, hipStream_t);
 struct FastVariant { int sf, variant; FastLaunch launch; };
