@@ -122,3 +122,10 @@ EOF2
     done
   done
 fi
+
+if [[ $what == *multi* ]]; then
+  # the N > 1 path of bench.py on the one GPU that is here: 2 ranks over gloo, both on device 0 (halved batch so both fit)
+  LORA_BENCH_BACKEND=gloo LORA_BENCH_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+      bench.py --gpus 2 --steps 100 --warmup 10 --channels 2048 > $O/multi2.json 2> $O/multi2.err
+  tail -c 1200 $O/multi2.json; tail -3 $O/multi2.err
+fi
