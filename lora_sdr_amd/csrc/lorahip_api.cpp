@@ -20,6 +20,19 @@ int hipFail(const hipError_t e, const char *what)
     return LORAHIP_E_HIP;
 }
 
+hipError_t ensureDynamicLds(const void *kernel, const size_t bytes, unsigned long long &doneMask)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&doneMask, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+    if (e != hipSuccess) return e;
+    __atomic_fetch_or(&doneMask, bit, __ATOMIC_RELEASE);
+    return hipSuccess;
+}
+
 static bool isGfx950(const int device)
 {
     hipDeviceProp_t prop;

@@ -268,13 +268,10 @@ static hipError_t launchOne(const DetectArgs &a, const FastTables &ft, hipStream
 {
     constexpr int WAVES = 4;
     const size_t smem = smemBytes<C>();
-    static bool attrSet = false;
-    if (!attrSet)
+    static unsigned long long attrDone = 0;
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(detectFast<C, DBG, UNI>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(detectFast<C, DBG, UNI>), smem, attrDone);
         if (e != hipSuccess) return e;
-        attrSet = true;
     }
     const unsigned nSets = (a.nWindows + C::WPW - 1) / C::WPW;
     // persistent: as many blocks as stay resident, never more than there are sets of work

@@ -129,6 +129,10 @@ hipError_t launchModFrames(float2 *iq, long long frameStride, const unsigned sho
 hipError_t launchAwgn(float2 *iq, size_t n, float sigma, unsigned long long seed, hipStream_t stream);
 hipError_t launchMembw(const float2 *iq, size_t nBytes, int pattern, int blocks, float *scratch, hipStream_t stream);
 
+//! hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes are per device, and one
+//! process may drive several contexts on several devices from several threads
+hipError_t ensureDynamicLds(const void *kernel, size_t bytes, unsigned long long &doneMask);
+
 void setLastError(const std::string &s);
 int hipFail(hipError_t e, const char *what);
 

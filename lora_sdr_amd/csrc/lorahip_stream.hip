@@ -155,13 +155,10 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
 {
     constexpr int WAVES = 4;
     const size_t smem = size_t(C::TWN + C::N) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2);
-    static bool attrSet = false;
-    if (!attrSet)
+    static unsigned long long attrDone = 0;
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(demodStream<C>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C>), smem, attrDone);
         if (e != hipSuccess) return e;
-        attrSet = true;
     }
     const unsigned perBlock = WAVES * C::WPW;
     const unsigned grid = (s.nChannels + perBlock - 1) / perBlock;

@@ -428,13 +428,10 @@ template <class C, bool DBG, bool UNI>
 static hipError_t launchOneWide(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
     const size_t smem = WideSmem<C>::bytes();
-    static bool attrSet = false;
-    if (!attrSet)
+    static unsigned long long attrDone = 0;
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(detectWide<C, DBG, UNI>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(detectWide<C, DBG, UNI>), smem, attrDone);
         if (e != hipSuccess) return e;
-        attrSet = true;
     }
     const unsigned nSets = (a.nWindows + C::WPB - 1) / C::WPB;
     // persistent: as many workgroups as stay resident, never more than there are sets of work
@@ -755,13 +752,10 @@ template <class C>
 static hipError_t launchStreamWideCfg(const StreamArgs &s, hipStream_t stream)
 {
     const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2);
-    static bool attrSet = false;
-    if (!attrSet)
+    static unsigned long long attrDone = 0;
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(demodStreamWide<C>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C>), smem, attrDone);
         if (e != hipSuccess) return e;
-        attrSet = true;
     }
     if (s.nChannels == 0) return hipSuccess;
     hipLaunchKernelGGL((demodStreamWide<C>), dim3(s.nChannels), dim3(C::T), smem, stream, s);
