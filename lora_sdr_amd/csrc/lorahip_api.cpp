@@ -175,6 +175,7 @@ int lorahip_set_stream(lorahip_ctx *ctx, void *hip_stream)
 int lorahip_synchronize(lorahip_ctx *ctx)
 {
     if (ctx == nullptr) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(ctx->device);
     LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
     return LORAHIP_OK;
 }
@@ -225,6 +226,7 @@ int lorahip_detect_batch(lorahip_ctx *ctx, const lorahip_batch *b)
 {
     const int rc = checkBatch(ctx, b);
     if (rc != LORAHIP_OK || b->n_windows == 0) return rc;
+    const DeviceGuard guard(ctx->device);
     DetectArgs a;
     fillArgs(ctx, b, a);
     FastTables ft;
@@ -239,7 +241,7 @@ int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b)
 {
     int rc = checkBatch(ctx, b);
     if (rc != LORAHIP_OK || b->n_windows == 0) return rc;
-    LORAHIP_TRY(hipSetDevice(ctx->device));
+    const DeviceGuard guard(ctx->device);
     const size_t N = ctx->N, W = b->n_windows;
     const size_t stride = b->window_stride ? b->window_stride : N;
     size_t iqLen = 0;
@@ -312,6 +314,7 @@ int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b)
 int lorahip_timer_start(lorahip_ctx *ctx)
 {
     if (ctx == nullptr) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(ctx->device);
     LORAHIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     return LORAHIP_OK;
 }
@@ -319,6 +322,7 @@ int lorahip_timer_start(lorahip_ctx *ctx)
 int lorahip_timer_stop(lorahip_ctx *ctx, float *elapsed_ms)
 {
     if (ctx == nullptr || elapsed_ms == nullptr) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(ctx->device);
     LORAHIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     LORAHIP_TRY(hipEventSynchronize(ctx->ev1));
     LORAHIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
@@ -328,6 +332,7 @@ int lorahip_timer_stop(lorahip_ctx *ctx, float *elapsed_ms)
 int lorahip_membw_probe(lorahip_ctx *ctx, const float *buf_dev, const size_t n_bytes, const int pattern, const int blocks_per_cu)
 {
     if (ctx == nullptr || buf_dev == nullptr || blocks_per_cu < 1) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(ctx->device);
     LORAHIP_TRY(launchMembw(reinterpret_cast<const float2 *>(buf_dev), n_bytes, pattern, ctx->cuCount * blocks_per_cu,
                             reinterpret_cast<float *>(ctx->dTwStage), ctx->stream));
     return LORAHIP_OK;
@@ -337,6 +342,7 @@ int lorahip_synth_symbols(lorahip_ctx *ctx, float *iq_dev, const uint16_t *sym_d
                           const float ampl, const float noise_sigma, const uint64_t seed)
 {
     if (ctx == nullptr || (n_windows && (!iq_dev || !sym_dev))) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(ctx->device);
     LORAHIP_TRY(launchSynth(ctx->sf, reinterpret_cast<float2 *>(iq_dev), sym_dev, n_windows, ampl, noise_sigma,
                             (unsigned long long)seed, ctx->stream));
     return LORAHIP_OK;
@@ -354,6 +360,7 @@ int lorahip_mod_frames(lorahip_ctx *ctx, float *iq_dev, const size_t frame_strid
 {
     if (ctx == nullptr || (n_frames && (!iq_dev || !syms_dev)) || nsyms == 0 || nsyms > 0x7fffffu || padding > 0x7fffffu) return LORAHIP_E_INVALID;
     if (n_frames > 0xffffffffu || frame_stride < lorahip_mod_frame_len(ctx->sf, nsyms, padding)) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(ctx->device);
     LORAHIP_TRY(launchModFrames(reinterpret_cast<float2 *>(iq_dev), (long long)frame_stride, syms_dev, n_frames, int(nsyms), int(sync), ampl,
                                 int(padding), ctx->sf, ctx->stream));
     return LORAHIP_OK;
@@ -362,6 +369,7 @@ int lorahip_mod_frames(lorahip_ctx *ctx, float *iq_dev, const size_t frame_strid
 int lorahip_add_awgn(lorahip_ctx *ctx, float *iq_dev, const size_t n_samples, const float sigma, const uint64_t seed)
 {
     if (ctx == nullptr || (n_samples && !iq_dev)) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(ctx->device);
     LORAHIP_TRY(launchAwgn(reinterpret_cast<float2 *>(iq_dev), n_samples, sigma, (unsigned long long)seed, ctx->stream));
     return LORAHIP_OK;
 }
@@ -375,6 +383,7 @@ int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, con
     if (!syms_dev || !nsyms_dev || !out_dev || !out_len_dev || !dropped_dev || n_packets > 0x7fffffffu) return LORAHIP_E_INVALID;
     if (cfg->sf < 1 || cfg->sf > 16 || cfg->ppm < 0 || cfg->ppm > cfg->sf || cfg->rdd < 0 || cfg->rdd > 4 || cfg->data_length < 0) return LORAHIP_E_INVALID;
     if (sym_stride == 0 || sym_stride > size_t(decodeMaxSymbols()) || (out_stride & 1) || out_stride < 2 * (sym_stride + 8)) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(ctx->device);
     DecodeArgs a;
     a.syms = syms_dev; a.nsyms = nsyms_dev; a.out = out_dev; a.outLen = out_len_dev; a.dropped = dropped_dev;
     a.nPackets = unsigned(n_packets); a.symStride = int(sym_stride); a.outStride = int(out_stride);

@@ -124,7 +124,7 @@ static int launchRound(lorahip_demod *dm, const float *iqDev, const size_t n)
 static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     const size_t N = dm->N, B = dm->B;
-    LORAHIP_TRY(hipSetDevice(dm->ctx->device));
+    const DeviceGuard guard(dm->ctx->device);
     const Round hr = carve(dm->h, B);
     std::vector<uint32_t> live, second;
     std::vector<lorahip_work_result> res(B);
@@ -299,7 +299,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     lorahip_ctx *ctx = dm->ctx;
     const size_t N = dm->N, B = dm->B;
-    LORAHIP_TRY(hipSetDevice(ctx->device));
+    const DeviceGuard guard(ctx->device);
     size_t maxLen = 0;
     for (size_t c = 0; c < B; c++) if (dm->ch[c].len - dm->ch[c].pos > maxLen) maxLen = dm->ch[c].len - dm->ch[c].pos;
     // work() calls per channel per launch: enough for a clean stream in one launch, bounded so that the
@@ -532,7 +532,7 @@ int lorahip_demod_run_device(lorahip_demod *dm, const float *iq_dev, const size_
 int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size_t *n_samples, int64_t *rounds)
 {
     if (dm == nullptr || streams == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
-    LORAHIP_TRY(hipSetDevice(dm->ctx->device));
+    const DeviceGuard guard(dm->ctx->device);
     size_t total = 0;
     for (size_t c = 0; c < dm->B; c++)
     {

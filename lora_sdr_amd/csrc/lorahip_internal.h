@@ -133,6 +133,21 @@ hipError_t launchMembw(const float2 *iq, size_t nBytes, int pattern, int blocks,
 //! process may drive several contexts on several devices from several threads
 hipError_t ensureDynamicLds(const void *kernel, size_t bytes, unsigned long long &doneMask);
 
+//! makes a context's device current for the duration of an entry point and restores the caller's afterwards (a process
+//! may hold contexts on several devices; torch keeps its own notion of the current device)
+struct DeviceGuard
+{
+    int prev;
+    bool switched;
+    explicit DeviceGuard(const int device) : prev(-1), switched(false)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 void setLastError(const std::string &s);
 int hipFail(hipError_t e, const char *what);
 
