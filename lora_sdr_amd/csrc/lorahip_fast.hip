@@ -355,11 +355,12 @@ static const FastVariant kFastVariants[] = {
     V(7, 0, CH_REG | NT),                                  // default
     V(7, 2, PF_NONE), V(7, 3, W2), V(7, 4, W4 | PF_NONE), V(7, 5, W2 | CH_REG | TW_REG), V(7, 6, PF_EARLY), V(7, 7, TW_REG),
     V(7, 8, NT), V(7, 9, TW_REG | NT), V(7, 10, 0), V(7, 11, CH_REG | NT), V(7, 12, W2 | CH_REG | TW_REG | NT),
-    V(7, 13, CH_REG | NT | NB_SEL), V(7, 14, CH_REG | NT | XCD),
+    V(7, 13, CH_REG | NT | NB_SEL), V(7, 14, CH_REG | NT | XCD), V(7, 15, CH_REG | TW_REG | NT | PF_NONE), V(7, 16, CH_REG | TW_REG | NT | PF_NONE | NB_SEL),
+    V(7, 17, W4 | CH_REG | NT | PF_NONE),
     // SF8
     V(8, 0, CH_REG | TW_REG | NT),                         // default
     V(8, 6, PF_EARLY), V(8, 7, TW_REG), V(8, 8, NT), V(8, 9, TW_REG | NT), V(8, 10, 0), V(8, 11, CH_REG | TW_REG | NT),
-    V(8, 13, CH_REG | TW_REG | NT | NB_SEL),
+    V(8, 13, CH_REG | TW_REG | NT | NB_SEL), V(8, 15, CH_REG | TW_REG | NT | PF_NONE), V(8, 17, W4 | CH_REG | NT | PF_NONE),
     // SF9
     V(9, 0, CH_REG | TW_REG | NT | X1_SWAP),               // default
     V(9, 6, PF_EARLY), V(9, 7, TW_REG), V(9, 8, NT), V(9, 9, TW_REG | NT), V(9, 10, 0), V(9, 11, CH_REG | TW_REG | NT),
