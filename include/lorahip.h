@@ -190,6 +190,9 @@ size_t lorahip_demod_num_packet_symbols(const lorahip_demod *d);
 int lorahip_demod_get_packets(const lorahip_demod *d, int32_t *channels, int64_t *rounds, int64_t *lens, size_t cap_packets,
                               int16_t *syms, size_t cap_syms);
 void lorahip_demod_clear_packets(lorahip_demod *d);
+/* samples of `channel`'s stream the last lorahip_demod_run[_device] consumed (the sum of its consume() calls, :320): a
+ * streaming caller presents the unconsumed remainder again in front of the next chunk, as the framework's port buffer does */
+int64_t lorahip_demod_consumed(const lorahip_demod *d, size_t channel);
 /* total work() calls made (sum over channels) since create/activate */
 int64_t lorahip_demod_work_calls(const lorahip_demod *d);
 /* optional trace of every work() call: enable before run, then read back */

@@ -88,6 +88,7 @@ SIGNATURES = {
     "lorahip_demod_num_packet_symbols": (C.c_size_t, [C.c_void_p]),
     "lorahip_demod_get_packets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "lorahip_demod_clear_packets": (None, [C.c_void_p]),
+    "lorahip_demod_consumed": (C.c_int64, [C.c_void_p, C.c_size_t]),
     "lorahip_demod_work_calls": (C.c_int64, [C.c_void_p]),
     "lorahip_demod_set_trace": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_trace_len": (C.c_size_t, [C.c_void_p, C.c_size_t]),

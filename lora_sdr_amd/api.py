@@ -366,6 +366,10 @@ class LoRaDemod:
             self._lib.lorahip_demod_clear_packets(self._h)
         return out
 
+    def consumed(self, channel):
+        """samples of the channel's stream consumed by the last work()"""
+        return int(self._lib.lorahip_demod_consumed(self._h, int(channel)))
+
     def work_calls(self):
         return int(self._lib.lorahip_demod_work_calls(self._h))
 

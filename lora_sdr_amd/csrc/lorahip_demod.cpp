@@ -12,6 +12,7 @@
 // _prevValue) start at zero here.
 #include "lorahip_internal.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -310,6 +311,8 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     const size_t capMem = (size_t(256) << 20) / (B * perCall);
     if (cap > capMem) cap = capMem;
     if (cap < 8) cap = 8;
+    // test hook: a small per-launch record capacity forces the resume path (several launches per run)
+    if (const char *e = std::getenv("LORAHIP_STREAM_CAP")) { const long v = std::atol(e); if (v >= 1) cap = size_t(v); }
     const size_t capPkt = cap / 4 + 2;               // a packet costs at least 5 calls (3 sync, quarter, 1 symbol)
 
     size_t cur = 0;
@@ -336,6 +339,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     const StreamPacket *hPkt = reinterpret_cast<StreamPacket *>(h + oPkt);
     const short *hSym = reinterpret_cast<short *>(h + oSym);
     const lorahip_work_result *hCalls = reinterpret_cast<lorahip_work_result *>(h + oCalls);
+    std::vector<size_t> carry(B, 0);
     for (size_t c = 0; c < B; c++)
     {
         Channel &k = dm->ch[c];
@@ -346,6 +350,9 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         st.fineTuneIndex = k.fineTuneIndex; st.finefreqError = k.finefreqError; st.symCount = int(k.symCount); st.callCount = 0;
         st.pos = (long long)k.pos;
         if (k.outSymbols.size() < k.symCount) k.outSymbols.resize(k.symCount, 0);
+        // symbols of a packet that is still being received when the run starts. _symCount itself is only reset at
+        // QUARTERCHIRP (:279), so outside DATASYMBOLS it still holds the length of the LAST packet: nothing is carried then
+        carry[c] = k.state == ST_DATASYMBOLS ? k.symCount : 0;
     }
     LORAHIP_TRY(hipMemcpyAsync(d, h, oN, hipMemcpyHostToDevice, ctx->stream));       // base, len, state
 
@@ -379,7 +386,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         for (size_t c = 0; c < B; c++)
         {
             Channel &k = dm->ch[c];
-            // symbols of this launch continue the packet the previous launches left open (k.outSymbols[0..k.symCount))
+            // symbols of this launch continue the packet the previous launches left open (k.outSymbols[0..carry[c]))
             const short *sy = hSym + c * cap;
             size_t p = 0;
             for (int j = 0; j < hNPkt[c]; j++)
@@ -390,20 +397,20 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
                 pk.round = q.callIndex;
                 pk.off = dm->pktSyms.size();
                 pk.len = size_t(q.len);
-                dm->pktSyms.insert(dm->pktSyms.end(), k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
-                const size_t fresh = size_t(q.len) - k.symCount;
+                dm->pktSyms.insert(dm->pktSyms.end(), k.outSymbols.begin(), k.outSymbols.begin() + long(carry[c]));
+                const size_t fresh = size_t(q.len) - carry[c];
                 dm->pktSyms.insert(dm->pktSyms.end(), sy + p, sy + p + fresh);
                 p += fresh;
-                k.symCount = 0;
+                carry[c] = 0;
                 dm->packets.push_back(pk);
             }
             // what is left belongs to a packet still being received
             const size_t left = size_t(hNSym[c]) - p;
             if (left)
             {
-                if (k.outSymbols.size() < k.symCount + left) k.outSymbols.resize(k.symCount + left, 0);
-                for (size_t i = 0; i < left; i++) k.outSymbols[k.symCount + i] = sy[p + i];
-                k.symCount += left;
+                if (k.outSymbols.size() < carry[c] + left) k.outSymbols.resize(carry[c] + left, 0);
+                for (size_t i = 0; i < left; i++) k.outSymbols[carry[c] + i] = sy[p + i];
+                carry[c] += left;
             }
             dm->workCalls += hN[c];
             if (dm->tracing) k.trace.insert(k.trace.end(), hCalls + c * cap, hCalls + c * cap + hN[c]);
@@ -596,6 +603,12 @@ int lorahip_demod_get_packets(const lorahip_demod *dm, int32_t *channels, int64_
 void lorahip_demod_clear_packets(lorahip_demod *dm) { if (dm) { dm->packets.clear(); dm->pktSyms.clear(); } }
 
 int64_t lorahip_demod_work_calls(const lorahip_demod *dm) { return dm ? dm->workCalls : 0; }
+
+int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
+{
+    if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
+    return int64_t(dm->ch[channel].pos);
+}
 
 int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)
 {

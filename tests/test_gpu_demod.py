@@ -252,3 +252,64 @@ def test_loopback_mod_noise_demod(gpu, sf, mode):
         assert np.array_equal(s, sent[ch, seen[ch]]), "channel %d frame %d" % (ch, seen[ch])
         seen[ch] += 1
     assert (seen == frames).all()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sf", [7, 9, 11])
+def test_chunked_streaming_equals_one_shot(gpu, oracle, sf, mode):
+    """a running receiver: the stream arrives in chunks of arbitrary size, the block keeps its state between work() calls
+    (fine-tune index, frequency error, symbols of a half-received packet) and the caller re-presents what was not
+    consumed -- the packets must be those of one work() over the whole stream, and of the oracle's block"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(100 + sf)
+    N = 1 << sf
+    B = 5
+    streams = [frames(oracle, rng, sf, 3, 9 + c, off=rng.uniform(-0.4, 0.4), noise=0.05, lead=int(rng.integers(0, N)))[0] for c in range(B)]
+    one = L.LoRaDemod(sf, n_channels=B); one.set_mode(mode); one.setMTU(9)
+    one.work(streams)
+    want = [[p[2] for p in one.packets(clear=False) if p[0] == c] for c in range(B)]
+    for c in range(B):
+        ref = oracle.demod_run(sf, streams[c], mtu=9)["packets"]
+        assert len(ref) == len(want[c]) and all(np.array_equal(a, b) for a, (_, b) in zip(want[c], ref))
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(mode); d.setMTU(9)
+    got = [[] for _ in range(B)]
+    fed = [0] * B                       # samples handed over so far
+    rest = [np.zeros(0, np.complex64) for _ in range(B)]
+    while any(fed[c] < len(streams[c]) or len(rest[c]) >= 2 * N for c in range(B)):
+        bufs = []
+        for c in range(B):
+            n = int(rng.integers(N // 3, 5 * N))
+            bufs.append(np.concatenate([rest[c], streams[c][fed[c]:fed[c] + n]]))
+            fed[c] = min(len(streams[c]), fed[c] + n)
+        d.work(bufs)
+        for ch, _, s in d.packets():
+            got[ch].append(s)
+        progressed = False
+        for c in range(B):
+            k = d.consumed(c)
+            progressed |= k > 0
+            rest[c] = bufs[c][k:]
+        if not progressed and all(fed[c] >= len(streams[c]) for c in range(B)):
+            break
+    for c in range(B):
+        assert len(got[c]) == len(want[c]), "channel %d: %d packets, expected %d" % (c, len(got[c]), len(want[c]))
+        assert all(np.array_equal(a, b) for a, b in zip(got[c], want[c]))
+
+
+@pytest.mark.parametrize("sf", [7, 10, 12])
+def test_stream_kernel_resumes_when_its_record_buffer_fills(gpu, oracle, sf, monkeypatch):
+    """the streaming launch stops a channel when its per-launch record buffer is full and is relaunched from the saved state:
+    with a capacity of 5 calls per launch every frame is cut many times, packets and traces must not change"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(7 * sf)
+    B = 6
+    streams = [frames(oracle, rng, sf, 2, 7 + c, off=rng.uniform(-0.4, 0.4), noise=0.03, lead=int(rng.integers(0, 100)))[0] for c in range(B)]
+    monkeypatch.setenv("LORAHIP_STREAM_CAP", "5")
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(7); d.set_trace(True)
+    d.work(streams)
+    pk = d.packets()
+    for c in range(B):
+        r = oracle.demod_run(sf, streams[c], mtu=7)
+        compare_channel(d.trace(c), r["calls"])
+        mine = [p[2] for p in pk if p[0] == c]
+        assert len(mine) == len(r["packets"]) and all(np.array_equal(a, b) for a, (_, b) in zip(mine, r["packets"]))
