@@ -111,3 +111,27 @@ def test_receive_chain_bytes_in_bytes_out(gpu, golden, sf, cr):
     out = dec.work([p[2] for p in pk])
     assert all(o is not None and np.array_equal(o, data) for o in out)
     assert dec.getDropped() == 0
+
+
+def test_longest_packets_and_limits(gpu, oracle):
+    """512 symbols per packet is what one launch accepts (twice the block's default MTU); every coding rate at that size
+    against the oracle, and the C ABI refuses a larger stride instead of truncating"""
+    import ctypes as C
+    import lora_sdr_amd as L
+    from lora_sdr_amd import _lib
+    rng = np.random.default_rng(3)
+    dec = L.LoRaDecoder()
+    for sf, cr in ((12, "4/4"), (10, "4/5"), (8, "4/6"), (7, "4/7"), (9, "4/8")):
+        dec.setSpreadFactor(sf); dec.setCodingRate(cr); dec.enableExplicit(False); dec.enableCrcc(False); dec.setDataLength(100)
+        pk = [rng.integers(0, 1 << sf, n).astype(np.uint16) for n in (512, 511, 509, 505, 8)]
+        for s, out in zip(pk, dec.work(pk)):
+            o, _ = oracle.decode(sf, s, cr=cr, explicit=False, crcc=False, data_length=100)
+            assert (o is None) == (out is None) and (o is None or np.array_equal(o, out))
+    lib = L.load()
+    cfg = _lib.DecoderCfg(C.sizeof(_lib.DecoderCfg), 10, 0, 4, 0, 1, 0, 1, 0, 8)
+    ctx = L.Context(7)
+    z = gpu.zeros(4096, dtype=gpu.int32, device="cuda")
+    p = C.c_void_p(z.data_ptr())
+    assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 513, p, 1, p, 2 * (513 + 8), p, p) == -1      # stride too long
+    assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 64, p, 1, p, 2 * 64, p, p) == -1               # output stride too short
+    assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 64, p, 0, p, 2 * 72, p, p) == 0                # empty batch

@@ -313,3 +313,29 @@ def test_stream_kernel_resumes_when_its_record_buffer_fills(gpu, oracle, sf, mon
         compare_channel(d.trace(c), r["calls"])
         mine = [p[2] for p in pk if p[0] == c]
         assert len(mine) == len(r["packets"]) and all(np.array_equal(a, b) for a, (_, b) in zip(mine, r["packets"]))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_sync_word_threshold_and_mtu_settings(gpu, oracle, mode):
+    """the block's three setters: a non-default sync word (and the wrong one: no lock), a threshold high enough that the
+    padding squelches the packet early, MTU 4 / 1 / 0 (a packet per symbol) -- every call and packet as the oracle's block"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(7)
+    sf, N = 8, 256
+    syms = rng.integers(0, N, 9).astype(np.uint16)
+    fr = oracle.mod_frame(sf, syms, sync=0x34, padding=4)
+    st = np.concatenate([fr, fr, np.zeros(2 * N, np.complex64)])
+    st += (0.01 * (rng.standard_normal(st.size) + 1j * rng.standard_normal(st.size))).astype(np.complex64)
+    cases = ((0x34, 64, 10.0), (0x34, 4, 10.0), (0x12, 64, 10.0), (0x34, 1, -30.0), (0x34, 0, -30.0), (0x34, 64, 60.0))
+    d = L.LoRaDemod(sf, n_channels=len(cases))       # one channel per setting would need one block each: run them one by one
+    d.close()
+    for sync, mtu, thresh in cases:
+        d = L.LoRaDemod(sf)
+        d.set_mode(mode); d.setSync(sync); d.setMTU(mtu); d.setThreshold(thresh); d.set_trace(True)
+        d.work([st])
+        r = oracle.demod_run(sf, st, sync=sync, mtu=mtu, thresh=thresh)
+        compare_channel(d.trace(0), r["calls"])
+        pk = d.packets()
+        assert [p[1] for p in pk] == [c for c, _ in r["packets"]], (sync, mtu, thresh)
+        assert all(np.array_equal(p[2], q) for p, (_, q) in zip(pk, r["packets"]))
+        d.close()
