@@ -53,7 +53,8 @@ extern "C" {
 /* chirp selection per window */
 #define LORAHIP_CHIRP_UP    0      /* _upChirpTable  = conj(entry)  LoRaDemod.cpp:103 (FRAMESYNC, DATASYMBOLS) */
 #define LORAHIP_CHIRP_DOWN  1      /* _downChirpTable = entry       LoRaDemod.cpp:104 (DOWNCHIRP0/1)           */
-#define LORAHIP_CHIRP_NONE  2      /* input is already dechirped: the LoRaDetector::feed seam                 */
+#define LORAHIP_CHIRP_NONE  2      /* input is already dechirped: the LoRaDetector::feed seam (no dechirp loop:
+                                      fine_idx0 / fine_err are ignored, fine_idx_out = fine_idx0)               */
 
 const char *lorahip_strerror(int code);
 const char *lorahip_last_error(void);       /* thread-local text of the last LORAHIP_E_HIP */

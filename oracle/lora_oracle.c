@@ -243,7 +243,8 @@ static void *batch_body(void *arg)
         const int sel = j->chirpSel ? j->chirpSel[w] : 0;
         const lo_cf32 *chirp = sel == 0 ? j->up : (sel == 1 ? j->down : NULL);
         const int idx0 = j->fineIdx0 ? j->fineIdx0[w] : 0;
-        const float e = j->fineErr ? j->fineErr[w] : 0.0f;
+        /* LORAHIP_CHIRP_NONE (the LoRaDetector::feed seam) has no dechirp loop at all: the index does not move */
+        const float e = (chirp && j->fineErr) ? j->fineErr[w] : 0.0f;
         const int idx1 = lo_dechirp((int)N, in, chirp, chirp ? j->fine : NULL, idx0, e, dec);
         if (j->fineIdxOut) j->fineIdxOut[w] = idx1;
         if (j->decOut) memcpy(j->decOut + w * N, dec, sizeof(lo_cf32) * N);

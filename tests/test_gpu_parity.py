@@ -301,3 +301,26 @@ def test_steady_state_kernels_all_variants(gpu, oracle, sf):
     o2 = oracle.detect_batch(sf, iq[:1500], chirp_sel=1, want_fft=True, nthreads=8)
     g2 = ctx.detect_batch(d[:1500], chirp_sel_all=L.CHIRP_DOWN, want_fft=True)
     check(o2, g2, where="steady-dbg sf%d" % sf)
+
+
+@pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
+def test_per_window_settings_at_scale(gpu, oracle, sf):
+    """per-window chirp selection, fine-tune start index and error on batches large enough that every persistent wave /
+    workgroup runs many window sets (the index chain's LDS scratch aliases the exchange region of the previous set)"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(300 + sf)
+    N = 1 << sf
+    M = 128 * N
+    W = {7: 60013, 8: 30011, 9: 12007, 10: 6007, 11: 3001, 12: 1801}[sf]
+    iq, _ = make_iq(rng, sf, W, snr_db=0.0 if sf >= 9 else 6.0)
+    sel = rng.integers(0, 3, W).astype(np.int32)
+    err = np.where(rng.random(W) < 0.5, 0.0, rng.uniform(-2.5, 2.5, W)).astype(np.float32)
+    err[rng.random(W) < 0.05] = np.float32(N / 8 + 0.3)                   # a few large ones: several wraps per window
+    idx0 = rng.integers(0, M, W).astype(np.int32)
+    ctx = L.Context(sf)
+    t = gpu.from_numpy
+    g = ctx.detect_batch(t(iq).cuda(), chirp_sel=t(sel).cuda(), fine_idx0=t(idx0).cuda(), fine_err=t(err).cuda(), want_fine_idx=True)
+    gpu.cuda.synchronize()
+    o = oracle.detect_batch(sf, iq, chirp_sel=sel, fine_idx0=idx0, fine_err=err, nthreads=8)
+    assert np.array_equal(to_np(g["fineIdxOut"]), o["fineIdxOut"]), "index recurrence end state"
+    check(o, g, fft=False, where="per-window at scale sf%d" % sf)
