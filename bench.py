@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--moving", action="store_true",
+                    help="diagnostic: per-window fine-tune error and start index (the DATASYMBOLS shape of a locked receiver: "
+                         "LoRaDemod.cpp:160-162 moves the index every sample) instead of the launch-uniform steady state")
     ap.add_argument("--alias-windows", action="store_true",
                     help="diagnostic: every window reads window 0 (no HBM traffic): the compute-only time of the kernel")
     ap.add_argument("--traffic", type=float, default=None,
@@ -143,8 +146,12 @@ def main():
     out = dict(sym=torch.empty(W, dtype=torch.int16, device=dev), power=torch.empty(W, dtype=torch.float32, device=dev),
                powerAvg=torch.empty(W, dtype=torch.float32, device=dev), fIndex=torch.empty(W, dtype=torch.float32, device=dev))
     offsets = torch.zeros(W, dtype=torch.int64, device=dev) if a.alias_windows else None
+    fine_err = fine_idx0 = None
+    if a.moving:
+        fine_err = (torch.rand(W, generator=g, device=dev) * 4.0 - 2.0).to(torch.float32)
+        fine_idx0 = torch.randint(0, 128 * N, (W,), generator=g, device=dev, dtype=torch.int32)
     batch = ctx.make_batch(iq, W, out["sym"], out["power"], out["powerAvg"], out["fIndex"], chirp_sel_all=L.CHIRP_UP,
-                           offsets=offsets)
+                           offsets=offsets, fine_err=fine_err, fine_idx0=fine_idx0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -205,7 +212,7 @@ def main():
                                    % (B, sf, N, S), "sf": sf, "channels_per_gpu": B, "symbols_per_channel": S,
                        "iq_bytes_per_step_per_gpu": W * N * 8, "noise_sigma": a.noise_sigma,
                        "parallelism": "channels sharded, %d rank(s), no data-path collective" % world,
-                       "kernel_variant": a.variant, "alias_windows": bool(a.alias_windows),
+                       "kernel_variant": a.variant, "alias_windows": bool(a.alias_windows), "moving_fine_index": bool(a.moving),
                        "ramp_seconds": a.ramp_seconds},
             "symbol_error_rate_vs_sent": ser, "bin_offset": bin_offset,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

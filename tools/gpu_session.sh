@@ -129,3 +129,17 @@ if [[ $what == *multi* ]]; then
       bench.py --gpus 2 --steps 100 --warmup 10 --channels 2048 > $O/multi2.json 2> $O/multi2.err
   tail -c 1200 $O/multi2.json; tail -3 $O/multi2.err
 fi
+
+if [[ $what == *moving* ]]; then
+  for sf in ${QSF:-7 10 12}; do
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline --moving > $O/mov_sf$sf.json 2> $O/mov_sf$sf.err
+    python - <<EOF2
+import json
+try:
+    d = json.loads(open("$O/mov_sf$sf.json").read().strip().splitlines()[-1])
+    print("SF$sf moving fine index:", round(d["value"], 1), "Msym/s, launch_us", round(d["roofline"]["launch_us"],1))
+except Exception as e:
+    print("SF$sf failed", e); print(open("$O/mov_sf$sf.err").read()[-600:])
+EOF2
+  done
+fi
