@@ -63,12 +63,62 @@ struct RedRec { float v; int i; double tot; };
 //! where fineChainGroup<64,16> (1024-sample chunks) leaves the index of sample n
 __device__ __forceinline__ int chainSlot(const int n) { return (n & ~1023) + (n & 15) * 64 + ((n >> 4) & 63); }
 
+/*! The fine-tune index recurrence of a window that spans WPWIN wavefronts (fineChainGroup's scheme with the hand-over
+ * between wavefronts through LDS): every lane walks its 16 consecutive samples from a guessed start, the ends are
+ * compared with the successors' starts, the guesses repaired by the prefix sum of the mismatches, until all agree.
+ * Called by every thread of the workgroup (workgroup barriers inside); t = lane inside the window, wwin = wavefront
+ * inside the window, sC = 12 ints of LDS scratch per window. Leaves the index of sample n at sIdx[chainSlot(n)] and
+ * returns the index after the N steps (to every thread of the window). */
+template <int T, int M>
+__device__ __forceinline__ int fineChainBlock(const int idx0, const float d, const int t, const int wwin, int *sIdx, int *sC)
+{
+    constexpr int WPWIN = T / 64;
+    const int lane = t & 63;
+    const int first = fineStep(idx0, d, M);
+    int c = first - idx0;
+    if (c > M / 2) c -= M;
+    else if (c < -M / 2) c += M;
+    int g = (idx0 + c * (16 * t)) & (M - 1);
+    int loc[16];
+    int e = 0;
+    for (int round = 0; round <= T; round++)
+    {
+        int idx = g;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { loc[i] = idx; idx = fineStep(idx, d, M); }
+        e = idx;
+        if (lane == 63) sC[wwin] = e;                       // hand-over to the next wavefront
+        __syncthreads();
+        const int up = __shfl_up(e, 1, 64);
+        const int prevE = lane > 0 ? up : (wwin == 0 ? idx0 : sC[wwin - 1]);
+        int delta = (prevE - g) & (M - 1);
+        if (!__syncthreads_or(delta != 0)) break;
+        // inclusive prefix sum of the mismatches over the window's lanes (mod M)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const int o = __shfl_up(delta, off, 64);
+            if (lane >= off) delta += o;
+        }
+        if (lane == 63) sC[4 + wwin] = delta;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WPWIN - 1; k++) if (k < wwin) delta += sC[4 + k];
+        g = (g + delta) & (M - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) sIdx[wwin * 1024 + i * 64 + lane] = loc[i];
+    if (t == T - 1) sC[8] = e;
+    __syncthreads();
+    return sC[8];
+}
+
 template <class C>
 struct WideSmem
 {
     static constexpr size_t bytes()
     {
-        return size_t(C::TWN + C::CH_ELEMS + C::WPB * C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + size_t(C::WPB) * 2 * sizeof(float2) + sizeof(TailRec);
+        return size_t(C::TWN + C::CH_ELEMS + C::WPB * C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + size_t(C::WPB) * 2 * sizeof(float2) + sizeof(TailRec) + size_t(C::WPB) * 12 * sizeof(int);
     }
 };
 
@@ -88,6 +138,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
     RedRec *sRed = reinterpret_cast<RedRec *>(sX + WPB * C::XW);         // [4]: one per wavefront
     v2f *sNb = reinterpret_cast<v2f *>(sRed + 4);                        // [WPB][2]: bins left/right of the peak
     TailRec &tr = *reinterpret_cast<TailRec *>(sNb + WPB * 2);
+    int *sChain = reinterpret_cast<int *>(&tr + 1) + (threadIdx.x >> LOG2T) * 12;    // fineChainBlock scratch of this window
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -228,15 +279,8 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
             anyMoving = __syncthreads_or(moving);
             if (anyMoving)
             {
-                // the window's first wavefront walks the chain, 1024 samples (64 lanes x 16) at a time
-                if (t < 64)
-                {
-                    int idx = idx0;
-                    for (int chunk = 0; chunk < N / 1024; chunk++)
-                        idx = fineChainGroup<64, 16, M>(idx, moving ? d : 0.0f, t, sIdx + chunk * 1024);
-                    if (moving && t == 0 && a.fineIdxOut && active) a.fineIdxOut[w] = idx;
-                }
-                __syncthreads();
+                const int idxEnd = fineChainBlock<T, M>(idx0, moving ? d : 0.0f, t, t >> 6, sIdx, sChain);
+                if (moving && t == 0 && a.fineIdxOut && active) a.fineIdxOut[w] = idxEnd;
             }
         }
         if (!moving && t == 0 && active && a.fineIdxOut) a.fineIdxOut[w] = idx0;
@@ -560,6 +604,7 @@ demodStreamWide(const StreamArgs s)
     v2f *X = sTw + C::TWN;                                               // [XW]
     RedRec *sRed = reinterpret_cast<RedRec *>(X + C::XW);                // [WPWIN]
     v2f *sNb = reinterpret_cast<v2f *>(sRed + 4);                        // [2]
+    int *sChain = reinterpret_cast<int *>(sNb + 2);                      // [12] fineChainBlock scratch
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -617,14 +662,7 @@ demodStreamWide(const StreamArgs s)
         idxEnd = idx0;
         if (moving)
         {
-            if (t < 64)
-            {
-                int idx = idx0;
-                for (int chunk = 0; chunk < N / 1024; chunk++) idx = fineChainGroup<64, 16, M>(idx, d, t, sIdx + chunk * 1024);
-                if (t == 0) sRed[0].i = idx;
-            }
-            __syncthreads();
-            idxEnd = sRed[0].i;
+            idxEnd = fineChainBlock<T, M>(idx0, d, t, t >> 6, sIdx, sChain);
         }
         const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
         const v2f fconst = gFine[idx0];
@@ -751,7 +789,7 @@ demodStreamWide(const StreamArgs s)
 template <class C>
 static hipError_t launchStreamWideCfg(const StreamArgs &s, hipStream_t stream)
 {
-    const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2);
+    const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2) + 12 * sizeof(int);
     static unsigned long long attrDone = 0;
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C>), smem, attrDone);
