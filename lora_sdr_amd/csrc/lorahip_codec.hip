@@ -18,118 +18,108 @@ namespace lorahip {
 
 namespace {
 
-__device__ __forceinline__ unsigned char headerChecksum(const unsigned char *h)          // LoRaCodes.hpp:131-156
+__device__ __forceinline__ int parityOf(const unsigned v) { return __popc(v) & 1; }
+
+//! header checksum (LoRaCodes.hpp:131-156): five parity bits over the 12 header bits w = h[0] | (h[1] & 0xf) << 8, as masks
+__device__ __forceinline__ unsigned char headerChecksum(const unsigned char *h)
 {
-    const int a0 = (h[0] >> 4) & 1, a1 = (h[0] >> 5) & 1, a2 = (h[0] >> 6) & 1, a3 = (h[0] >> 7) & 1;
-    const int b0 = (h[0] >> 0) & 1, b1 = (h[0] >> 1) & 1, b2 = (h[0] >> 2) & 1, b3 = (h[0] >> 3) & 1;
-    const int c0 = (h[1] >> 0) & 1, c1 = (h[1] >> 1) & 1, c2 = (h[1] >> 2) & 1, c3 = (h[1] >> 3) & 1;
-    int res = (a0 ^ a1 ^ a2 ^ a3) << 4;
-    res |= (a3 ^ b1 ^ b2 ^ b3 ^ c0) << 3;
-    res |= (a2 ^ b0 ^ b3 ^ c1 ^ c3) << 2;
-    res |= (a1 ^ b0 ^ b2 ^ c0 ^ c1 ^ c2) << 1;
-    res |= a0 ^ b1 ^ c0 ^ c1 ^ c2 ^ c3;
-    return (unsigned char)res;
+    const unsigned w = h[0] | ((unsigned)(h[1] & 0xf) << 8);
+    return (unsigned char)(parityOf(w & 0xF12) | (parityOf(w & 0x725) << 1) | (parityOf(w & 0xA49) << 2) | (parityOf(w & 0x18E) << 3) |
+                           (parityOf(w & 0x0F0) << 4));
 }
 
-__device__ __forceinline__ unsigned short crc16sx(unsigned short crc, const unsigned short poly)   // :158-168
+//! one byte position of the CCITT crc, MSB first (:158-168)
+__device__ __forceinline__ unsigned short crc16sx(unsigned short crc, const unsigned short poly)
 {
-    for (int i = 0; i < 8; i++)
-        crc = (crc & 0x8000) ? (unsigned short)((crc << 1) ^ poly) : (unsigned short)(crc << 1);
+    for (int bit = 0; bit < 8; bit++)
+    {
+        const bool top = (crc & 0x8000) != 0;
+        crc = (unsigned short)(crc << 1);
+        if (top) crc ^= poly;
+    }
     return crc;
 }
 
-__device__ __forceinline__ unsigned char xsum8(unsigned char t)                             // :170-175
+//! payload checksum of the sx1272 (:170-194): crc over the bytes, masked with two steps of an 8-bit LFSR (taps 0xB8)
+__device__ unsigned short dataChecksum(const unsigned char *data, const int length)
 {
-    t ^= t >> 4;
-    t ^= t >> 2;
-    t ^= t >> 1;
-    return t & 1;
-}
-
-__device__ unsigned short dataChecksum(const unsigned char *data, const int length)        // :181-194
-{
-    unsigned short res = 0, crc = 0;
+    unsigned short res = 0;
     unsigned char v = 0xff;
     for (int i = 0; i < length; i++)
     {
-        crc = crc16sx(res, 0x1021);
-        v = (unsigned char)(xsum8(v & 0xB8) | (v << 1));
+        const unsigned short crc = crc16sx(res, 0x1021);
+        v = (unsigned char)((v << 1) | parityOf(v & 0xB8));
         res = crc ^ data[i];
     }
     res ^= v;
-    v = (unsigned char)(xsum8(v & 0xB8) | (v << 1));
+    v = (unsigned char)((v << 1) | parityOf(v & 0xB8));
     res ^= (unsigned short)(v << 8);
     return res;
 }
 
-//! the whitening sequence from the two interleaved LFSRs (:255-268); bufferSize is a uint16_t parameter there
+//! one byte step of a whitening register: feedback byte b0^b2^b3^b4, shifted in at the top (:255-268)
+__device__ __forceinline__ unsigned long long lfsrAdvance(const unsigned long long r)
+{
+    const unsigned long long fb = (r ^ (r >> 16) ^ (r >> 24) ^ (r >> 32)) & 0xff;
+    return (r >> 8) | (fb << 56);
+}
+
+//! de-whitening with the two interleaved registers: codeword position p (counted from bitOfs) uses register p mod 2.
+//! bufferSize is a uint16_t parameter in the reference.
 __device__ void whiteningLfsr(unsigned char *buffer, const unsigned short bufferSize, const int bitOfs, const int RDD)
 {
-    const unsigned char m = (unsigned char)(0xff >> (4 - RDD));
-    unsigned long long r0 = (1 == RDD) ? 0x05121100F8ECFEEFull : 0x6572D100E85C2EFFull;
-    unsigned long long r1 = (1 == RDD) ? 0xF8ECFEEFEFEFEFEFull : 0xE85C2EFFFFFFFFFFull;
-    int i;
-    for (i = 0; i < bitOfs; i++)
+    unsigned long long even = (RDD == 1) ? 0x05121100F8ECFEEFull : 0x6572D100E85C2EFFull;   // single-parity mode has its own seeds
+    unsigned long long odd = (RDD == 1) ? 0xF8ECFEEFEFEFEFEFull : 0xE85C2EFFFFFFFFFFull;
+    const unsigned char keep = (unsigned char)(0xff >> (4 - RDD));
+    for (int p = 0; p < bitOfs; p++)
     {
-        unsigned long long &r = (i & 1) ? r1 : r0;
-        r = (r >> 8) | (((r >> 32) ^ (r >> 24) ^ (r >> 16) ^ r) << 56);
+        if (p & 1) odd = lfsrAdvance(odd);
+        else even = lfsrAdvance(even);
     }
-    for (int j = 0; j < bufferSize; j++, i++)
+    for (int j = 0; j < bufferSize; j++)
     {
-        unsigned long long &r = (i & 1) ? r1 : r0;
-        buffer[j] ^= (unsigned char)(r & m);
-        r = (r >> 8) | (((r >> 32) ^ (r >> 24) ^ (r >> 16) ^ r) << 56);
+        if ((bitOfs + j) & 1) { buffer[j] ^= (unsigned char)(odd & keep); odd = lfsrAdvance(odd); }
+        else { buffer[j] ^= (unsigned char)(even & keep); even = lfsrAdvance(even); }
     }
 }
 
-__device__ __forceinline__ unsigned char decodeHamming84(const unsigned char b, bool &error, bool &bad)   // :222-259
+// The sx Hamming codes (:222-259, :284-312) and parity checks (:318-323, :335-343) as syndrome masks: parity bit k covers
+// the codeword bits in COVERk; a syndrome naming a data bit flips it, one naming a parity bit is ignored, anything else is
+// uncorrectable (8,4 only). The flip tables are packed 4 bits per syndrome value (0xF = uncorrectable).
+#define LORAHIP_COVER0 0x17u
+#define LORAHIP_COVER1 0x2Eu
+#define LORAHIP_COVER2 0x4Bu
+#define LORAHIP_COVER3 0x8Du
+
+__device__ __forceinline__ unsigned char decodeHamming84(const unsigned char b, bool &error, bool &bad)
 {
-    const int b0 = (b >> 0) & 1, b1 = (b >> 1) & 1, b2 = (b >> 2) & 1, b3 = (b >> 3) & 1;
-    const int b4 = (b >> 4) & 1, b5 = (b >> 5) & 1, b6 = (b >> 6) & 1, b7 = (b >> 7) & 1;
-    const int parity = (b0 ^ b1 ^ b2 ^ b4) | ((b1 ^ b2 ^ b3 ^ b5) << 1) | ((b0 ^ b1 ^ b3 ^ b6) << 2) | ((b0 ^ b2 ^ b3 ^ b7) << 3);
-    if (parity != 0) error = true;
-    switch (parity)
-    {
-    case 0xD: return (b ^ 1) & 0xf;
-    case 0x7: return (b ^ 2) & 0xf;
-    case 0xB: return (b ^ 4) & 0xf;
-    case 0xE: return (b ^ 8) & 0xf;
-    case 0x0: case 0x1: case 0x2: case 0x4: case 0x8: return b & 0xf;
-    default: bad = true; return b & 0xf;
-    }
+    const unsigned syn = parityOf(b & LORAHIP_COVER0) | (parityOf(b & LORAHIP_COVER1) << 1) | (parityOf(b & LORAHIP_COVER2) << 2) |
+                         (parityOf(b & LORAHIP_COVER3) << 3);
+    // syndrome 0..15 -> data bit to flip: 0xD:1 0x7:2 0xB:4 0xE:8; 0,1,2,4,8 -> none; the rest uncorrectable
+    const unsigned long long fix = 0xF81F4FF02FF0F000ull;
+    const unsigned f = (unsigned)(fix >> (4 * syn)) & 0xf;
+    if (syn) error = true;
+    if (f == 0xf) { bad = true; return b & 0xf; }
+    return (b ^ f) & 0xf;
 }
 
-__device__ __forceinline__ unsigned char decodeHamming74(const unsigned char b, bool &error)               // :284-312
+__device__ __forceinline__ unsigned char decodeHamming74(const unsigned char b, bool &error)
 {
-    const int b0 = (b >> 0) & 1, b1 = (b >> 1) & 1, b2 = (b >> 2) & 1, b3 = (b >> 3) & 1;
-    const int b4 = (b >> 4) & 1, b5 = (b >> 5) & 1, b6 = (b >> 6) & 1;
-    const int parity = (b0 ^ b1 ^ b2 ^ b4) | ((b1 ^ b2 ^ b3 ^ b5) << 1) | ((b0 ^ b1 ^ b3 ^ b6) << 2);
-    if (parity != 0) error = true;
-    switch (parity)
-    {
-    case 0x5: return (b ^ 1) & 0xf;
-    case 0x7: return (b ^ 2) & 0xf;
-    case 0x3: return (b ^ 4) & 0xf;
-    case 0x6: return (b ^ 8) & 0xf;
-    default: return b & 0xf;
-    }
+    const unsigned syn = parityOf(b & LORAHIP_COVER0 & 0x7f) | (parityOf(b & LORAHIP_COVER1 & 0x7f) << 1) | (parityOf(b & LORAHIP_COVER2 & 0x7f) << 2);
+    const unsigned fix = 0x28104000u;                  // syndrome 0..7 -> flip: 5:1 7:2 3:4 6:8
+    if (syn) error = true;
+    return (b ^ ((fix >> (4 * syn)) & 0xf)) & 0xf;
 }
 
-__device__ __forceinline__ unsigned char checkParity54(const unsigned char b, bool &error)                 // :318-323
+__device__ __forceinline__ unsigned char checkParity54(const unsigned char b, bool &error)
 {
-    int x = b ^ (b >> 2);
-    x = x ^ (x >> 1) ^ (b >> 4);
-    if (x & 1) error = true;
+    if (parityOf(b & 0x1F)) error = true;              // one parity bit (b4) over the data bits
     return b & 0xf;
 }
 
-__device__ __forceinline__ unsigned char checkParity64(const unsigned char b, bool &error)                 // :335-343
+__device__ __forceinline__ unsigned char checkParity64(const unsigned char b, bool &error)
 {
-    int x = b ^ (b >> 1) ^ (b >> 2);
-    int y = x ^ b ^ (b >> 3);
-    x ^= b >> 4;
-    y ^= b >> 5;
-    if ((x | y) & 1) error = true;
+    if (parityOf(b & LORAHIP_COVER0) | parityOf(b & LORAHIP_COVER1)) error = true;   // the first two Hamming parity bits
     return b & 0xf;
 }
 

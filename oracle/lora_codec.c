@@ -18,139 +18,124 @@
 
 static unsigned round_up(unsigned num, unsigned factor) { return ((num + factor - 1) / factor) * factor; }  /* :111-114 */
 
-/* LoRaCodes.hpp:131-156 */
+static int parity_of(unsigned v) { return __builtin_parity(v); }
+
+/* Header checksum (LoRaCodes.hpp:131-156): five parity bits over the 12 header bits w = h[0] | (h[1] & 0xf) << 8.
+ * The reference spells each one out as a chain of xors of named bits; as masks over w, bit 4 down to bit 0: */
 static uint8_t header_checksum(const uint8_t *h)
 {
-    const int a0 = (h[0] >> 4) & 1, a1 = (h[0] >> 5) & 1, a2 = (h[0] >> 6) & 1, a3 = (h[0] >> 7) & 1;
-    const int b0 = (h[0] >> 0) & 1, b1 = (h[0] >> 1) & 1, b2 = (h[0] >> 2) & 1, b3 = (h[0] >> 3) & 1;
-    const int c0 = (h[1] >> 0) & 1, c1 = (h[1] >> 1) & 1, c2 = (h[1] >> 2) & 1, c3 = (h[1] >> 3) & 1;
-    uint8_t res;
-    res = (uint8_t)((a0 ^ a1 ^ a2 ^ a3) << 4);
-    res |= (a3 ^ b1 ^ b2 ^ b3 ^ c0) << 3;
-    res |= (a2 ^ b0 ^ b3 ^ c1 ^ c3) << 2;
-    res |= (a1 ^ b0 ^ b2 ^ c0 ^ c1 ^ c2) << 1;
-    res |= a0 ^ b1 ^ c0 ^ c1 ^ c2 ^ c3;
+    static const unsigned mask[5] = { 0xF12, 0x725, 0xA49, 0x18E, 0x0F0 };
+    const unsigned w = h[0] | ((unsigned)(h[1] & 0xf) << 8);
+    uint8_t res = 0;
+    for (int k = 0; k < 5; k++) res |= (uint8_t)(parity_of(w & mask[k]) << k);
     return res;
 }
 
-/* LoRaCodes.hpp:158-168 */
+/* CRC-CCITT step for one byte position, MSB first (LoRaCodes.hpp:158-168) */
 static uint16_t crc16sx(uint16_t crc, const uint16_t poly)
 {
-    for (int i = 0; i < 8; i++) {
-        if (crc & 0x8000) crc = (uint16_t)((crc << 1) ^ poly);
-        else crc = (uint16_t)(crc << 1);
+    for (int bit = 0; bit < 8; bit++) {
+        const int top = crc & 0x8000;
+        crc = (uint16_t)(crc << 1);
+        if (top) crc ^= poly;
     }
     return crc;
 }
 
-/* LoRaCodes.hpp:170-175 */
-static uint8_t xsum8(uint8_t t)
-{
-    t ^= t >> 4;
-    t ^= t >> 2;
-    t ^= t >> 1;
-    return t & 1;
-}
-
-/* LoRaCodes.hpp:181-194 */
+/* payload checksum of the sx1272 (LoRaCodes.hpp:170-194): CCITT crc over the bytes, the result masked with two steps
+ * of an 8-bit LFSR (taps 0xB8) that advances once per byte */
 static uint16_t sx1272_data_checksum(const uint8_t *data, int length)
 {
     uint16_t res = 0;
     uint8_t v = 0xff;
-    uint16_t crc = 0;
     for (int i = 0; i < length; i++) {
-        crc = crc16sx(res, 0x1021);
-        v = (uint8_t)(xsum8(v & 0xB8) | (v << 1));
+        const uint16_t crc = crc16sx(res, 0x1021);
+        v = (uint8_t)((v << 1) | parity_of(v & 0xB8));
         res = crc ^ data[i];
     }
     res ^= v;
-    v = (uint8_t)(xsum8(v & 0xB8) | (v << 1));
+    v = (uint8_t)((v << 1) | parity_of(v & 0xB8));
     res ^= (uint16_t)(v << 8);
     return res;
 }
 
-/* LoRaCodes.hpp:255-268: the interleaved LFSRs; bufferSize is a uint16_t parameter in the reference */
+/* De-whitening with the two interleaved 64-bit LFSRs (LoRaCodes.hpp:255-268): codeword position p (counted from
+ * bitOfs) takes the low bits of register p mod 2, which then advances by one byte: feedback byte = b0^b2^b3^b4 of the
+ * register (x^8 polynomial 0x1D on bytes), shifted in at the top. The length is a uint16_t in the reference. */
+static uint64_t lfsr_advance(const uint64_t r)
+{
+    const uint64_t fb = (r ^ (r >> 16) ^ (r >> 24) ^ (r >> 32)) & 0xff;
+    return (r >> 8) | (fb << 56);
+}
+
 static void whitening_lfsr(uint8_t *buffer, uint16_t bufferSize, const int bitOfs, const size_t RDD)
 {
-    static const uint64_t seed1[2] = { 0x6572D100E85C2EFFull, 0xE85C2EFFFFFFFFFFull };
-    static const uint64_t seed2[2] = { 0x05121100F8ECFEEFull, 0xF8ECFEEFEFEFEFEFull };
-    const uint8_t m = (uint8_t)(0xff >> (4 - RDD));
-    uint64_t r[2] = { (1 == RDD) ? seed2[0] : seed1[0], (1 == RDD) ? seed2[1] : seed1[1] };
-    int i, j;
-    for (i = 0; i < bitOfs; i++)
-        r[i & 1] = (r[i & 1] >> 8) | (((r[i & 1] >> 32) ^ (r[i & 1] >> 24) ^ (r[i & 1] >> 16) ^ r[i & 1]) << 56);
-    for (j = 0; j < bufferSize; j++, i++) {
-        buffer[j] ^= r[i & 1] & m;
-        r[i & 1] = (r[i & 1] >> 8) | (((r[i & 1] >> 32) ^ (r[i & 1] >> 24) ^ (r[i & 1] >> 16) ^ r[i & 1]) << 56);
+    uint64_t reg[2];
+    if (RDD == 1) { reg[0] = 0x05121100F8ECFEEFull; reg[1] = 0xF8ECFEEFEFEFEFEFull; }   /* single-parity mode has its own seeds */
+    else { reg[0] = 0x6572D100E85C2EFFull; reg[1] = 0xE85C2EFFFFFFFFFFull; }
+    const uint8_t keep = (uint8_t)(0xff >> (4 - RDD));                                    /* 4+RDD bits per codeword */
+    for (int p = 0; p < bitOfs; p++) reg[p & 1] = lfsr_advance(reg[p & 1]);
+    for (int j = 0; j < (int)bufferSize; j++) {
+        const int p = bitOfs + j;
+        buffer[j] ^= (uint8_t)(reg[p & 1] & keep);
+        reg[p & 1] = lfsr_advance(reg[p & 1]);
     }
 }
 
-/* LoRaCodes.hpp:222-259 */
+/* The sx Hamming codes (LoRaCodes.hpp:222-259, :284-312) and parity checks (:318-323, :335-343) as syndrome masks:
+ * parity bit k of a codeword covers the bits in cover[k]; a non-zero syndrome that names a data bit flips it, one
+ * that names a parity bit is ignored, anything else is uncorrectable (8,4 only). */
+static const unsigned cover[4] = { 0x17, 0x2E, 0x4B, 0x8D };   /* p0: b0 b1 b2 b4 | p1: b1 b2 b3 b5 | p2: b0 b1 b3 b6 | p3: b0 b2 b3 b7 */
+
 static unsigned char decode_hamming84(const unsigned char b, int *error, int *bad)
 {
-    const int b0 = (b >> 0) & 1, b1 = (b >> 1) & 1, b2 = (b >> 2) & 1, b3 = (b >> 3) & 1;
-    const int b4 = (b >> 4) & 1, b5 = (b >> 5) & 1, b6 = (b >> 6) & 1, b7 = (b >> 7) & 1;
-    const int p0 = b0 ^ b1 ^ b2 ^ b4, p1 = b1 ^ b2 ^ b3 ^ b5, p2 = b0 ^ b1 ^ b3 ^ b6, p3 = b0 ^ b2 ^ b3 ^ b7;
-    const int parity = (p0 << 0) | (p1 << 1) | (p2 << 2) | (p3 << 3);
-    if (parity != 0) *error = 1;
-    switch (parity & 0xf) {
-    case 0xD: return (b ^ 1) & 0xf;
-    case 0x7: return (b ^ 2) & 0xf;
-    case 0xB: return (b ^ 4) & 0xf;
-    case 0xE: return (b ^ 8) & 0xf;
-    case 0x0: case 0x1: case 0x2: case 0x4: case 0x8: return b & 0xf;
-    default: *bad = 1; return b & 0xf;
-    }
+    /* syndrome -> data bit to flip (0 = none), or 0xff = uncorrectable */
+    static const unsigned char fix[16] = { 0, 0, 0, 0xff, 0, 0xff, 0xff, 2, 0, 0xff, 0xff, 4, 0xff, 1, 8, 0xff };
+    unsigned syn = 0;
+    for (int k = 0; k < 4; k++) syn |= (unsigned)parity_of(b & cover[k]) << k;
+    if (syn) *error = 1;
+    if (fix[syn] == 0xff) { *bad = 1; return b & 0xf; }
+    return (b ^ fix[syn]) & 0xf;
 }
 
-/* LoRaCodes.hpp:284-312 */
 static unsigned char decode_hamming74(const unsigned char b, int *error)
 {
-    const int b0 = (b >> 0) & 1, b1 = (b >> 1) & 1, b2 = (b >> 2) & 1, b3 = (b >> 3) & 1;
-    const int b4 = (b >> 4) & 1, b5 = (b >> 5) & 1, b6 = (b >> 6) & 1;
-    const int p0 = b0 ^ b1 ^ b2 ^ b4, p1 = b1 ^ b2 ^ b3 ^ b5, p2 = b0 ^ b1 ^ b3 ^ b6;
-    const int parity = (p0 << 0) | (p1 << 1) | (p2 << 2);
-    if (parity != 0) *error = 1;
-    switch (parity) {
-    case 0x5: return (b ^ 1) & 0xf;
-    case 0x7: return (b ^ 2) & 0xf;
-    case 0x3: return (b ^ 4) & 0xf;
-    case 0x6: return (b ^ 8) & 0xf;
-    default: return b & 0xf;
-    }
+    static const unsigned char fix[8] = { 0, 0, 0, 4, 0, 1, 8, 2 };
+    unsigned syn = 0;
+    for (int k = 0; k < 3; k++) syn |= (unsigned)parity_of(b & cover[k] & 0x7f) << k;
+    if (syn) *error = 1;
+    return (b ^ fix[syn]) & 0xf;
 }
 
-/* LoRaCodes.hpp:318-323 */
+/* 5/4: one parity bit over the four data bits (b4) */
 static unsigned char check_parity54(const unsigned char b, int *error)
 {
-    int x = b ^ (b >> 2);
-    x = x ^ (x >> 1) ^ (b >> 4);
-    if (x & 1) *error = 1;
+    if (parity_of(b & 0x1F)) *error = 1;
     return b & 0xf;
 }
 
-/* LoRaCodes.hpp:335-343 */
+/* 6/4: the first two parity bits of the Hamming code (b4, b5) */
 static unsigned char check_parity64(const unsigned char b, int *error)
 {
-    int x = b ^ (b >> 1) ^ (b >> 2);
-    int y = x ^ b ^ (b >> 3);
-    x ^= b >> 4;
-    y ^= b >> 5;
-    if ((x | y) & 1) *error = 1;
+    if (parity_of(b & cover[0]) | parity_of(b & cover[1])) *error = 1;
     return b & 0xf;
 }
 
-/* LoRaCodes.hpp:366-381 */
+/* Diagonal de-interleaver (LoRaCodes.hpp:366-381): block x turns 4+RDD symbols of PPM bits into PPM codewords of
+ * 4+RDD bits; bit m of symbol k is bit k of codeword (m + k) mod PPM. */
 static void diagonal_deinterleave(const uint16_t *symbols, const size_t numSymbols, uint8_t *codewords, const size_t PPM, const size_t RDD)
 {
-    for (size_t x = 0; x < numSymbols / (4 + RDD); x++) {
-        const size_t cwOff = x * PPM, symOff = x * (4 + RDD);
-        for (size_t k = 0; k < 4 + RDD; k++)
+    const size_t width = 4 + RDD;
+    for (size_t blk = 0; blk < numSymbols / width; blk++) {
+        uint8_t *cw = codewords + blk * PPM;
+        for (size_t k = 0; k < width; k++) {
+            const unsigned sym = symbols[blk * width + k];
+            size_t dst = k % PPM;
             for (size_t m = 0; m < PPM; m++) {
-                const size_t i = (m + k) % PPM;
-                const int bit = (symbols[symOff + k] >> m) & 1;
-                codewords[cwOff + i] |= (uint8_t)(bit << k);
+                cw[dst] |= (uint8_t)(((sym >> m) & 1u) << k);
+                dst = dst + 1 == PPM ? 0 : dst + 1;
             }
+        }
     }
 }
 
