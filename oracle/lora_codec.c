@@ -139,6 +139,22 @@ static void diagonal_deinterleave(const uint16_t *symbols, const size_t numSymbo
     }
 }
 
+/* the primitives one by one, for exhaustive checks against the reference's (tests/test_oracle_vs_ref.py) */
+int lo_code_primitive(int which, int b)
+{
+    int error = 0, bad = 0, v = 0;
+    switch (which) {
+    case 0: v = decode_hamming84((unsigned char)b, &error, &bad); break;
+    case 1: v = decode_hamming74((unsigned char)b, &error); break;
+    case 2: v = check_parity54((unsigned char)b, &error); break;
+    case 3: v = check_parity64((unsigned char)b, &error); break;
+    case 4: { uint8_t h[3] = { (uint8_t)(b & 0xff), (uint8_t)((b >> 8) & 0xf), 0 }; return header_checksum(h); }
+    case 5: return (uint16_t)((uint16_t)b ^ ((uint16_t)b >> 1));
+    default: return -1;
+    }
+    return v | (error ? 0x100 : 0) | (bad ? 0x200 : 0);
+}
+
 /* LoRaDecoder.cpp:196-397. Returns the number of output elements written to `out` (bytes; uint16 symbols when
  * interleaving is off), or -1 when the block posts nothing; *dropped is set when it called drop(). */
 long lo_decode(const lo_decoder_cfg *c, const uint16_t *syms, size_t nsyms, void *out, int *dropped)

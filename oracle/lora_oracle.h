@@ -105,6 +105,7 @@ typedef struct lo_decoder_cfg {
     int hdr;            /* enableHdr */
     int data_length;    /* setDataLength */
 } lo_decoder_cfg;
+int lo_code_primitive(int which, int b);   /* 0 hamming84, 1 hamming74, 2 parity54, 3 parity64, 4 header checksum (12 bits), 5 gray */
 long lo_decode(const lo_decoder_cfg *c, const uint16_t *syms, size_t nsyms, void *out, int *dropped);
 
 #ifdef __cplusplus

@@ -384,6 +384,25 @@ extern "C" long loraref_encode(const size_t sf, const size_t ppm, const char *cr
     return n;
 }
 
+//! the code primitives themselves, for exhaustive checks (LoRaCodes.hpp is included by the codec blocks' TUs; here again)
+#include "LoRaCodes.hpp"
+extern "C" int loraref_code_primitive(const int which, const int b)
+{
+    bool error = false, bad = false;
+    int v = 0;
+    switch (which)
+    {
+    case 0: v = decodeHamming84sx((unsigned char)b, error, bad); break;
+    case 1: v = decodeHamming74sx((unsigned char)b, error); break;
+    case 2: v = checkParity54((unsigned char)b, error); break;
+    case 3: v = checkParity64((unsigned char)b, error); break;
+    case 4: { uint8_t h[3] = { uint8_t(b & 0xff), uint8_t((b >> 8) & 0xf), 0 }; return headerChecksum(h); }
+    case 5: return binaryToGray16((unsigned short)b);
+    default: return -1;
+    }
+    return v | (error ? 0x100 : 0) | (bad ? 0x200 : 0);
+}
+
 //! timing aid: the decoder block created once, `reps` messages decoded back to back; returns seconds
 extern "C" double loraref_decode_bench(const size_t sf, const size_t ppm, const char *cr, const int crcc, const int errorCheck,
                                        const uint16_t *syms, const size_t nsyms, const size_t reps)

@@ -151,3 +151,21 @@ def test_decoder_matches_verbatim_block(oracle, ref, sf):
     a, _ = oracle.decode(sf, syms, cr="4/6", interleaving=False)
     b, _ = ref.decode(sf, syms, cr="4/6", interleaving=False)
     assert _same(a, b)
+
+
+def test_code_primitives_exhaustive(oracle, ref):
+    """TestCodesSx.cpp checks the reference's code primitives for every 0/1/2-bit error pattern; here every input value of
+    every primitive the decoder uses, restatement (parity masks, syndrome tables) against LoRaCodes.hpp itself: result,
+    error flag and uncorrectable flag"""
+    ref.L.loraref_code_primitive.restype = int
+    oracle.L.lo_code_primitive.restype = int
+    for which, span in ((0, 256), (1, 128), (2, 32), (3, 64), (4, 4096), (5, 65536)):
+        a = [oracle.L.lo_code_primitive(which, b) for b in range(span)]
+        b_ = [ref.L.loraref_code_primitive(which, b) for b in range(span)]
+        assert a == b_, "primitive %d" % which
+    # and the property TestCodesSx.cpp pins: single-bit errors of an (8,4) codeword are corrected, flagged, not "bad"
+    for d in range(16):
+        cw = next(c for c in range(256) if (c & 0xf) == d and oracle.L.lo_code_primitive(0, c) == d)
+        for bit in range(8):
+            r = oracle.L.lo_code_primitive(0, cw ^ (1 << bit))
+            assert (r & 0xf) == d and (r & 0x100) and not (r & 0x200)
