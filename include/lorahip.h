@@ -248,6 +248,33 @@ int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, con
                            const int32_t *nsyms_dev, size_t n_packets, uint8_t *out_dev, size_t out_stride,
                            int32_t *out_len_dev, int32_t *dropped_dev);
 
+/* -------------------------------------------------------------------------------------
+ * Front-end channeliser (the step before the path: SURVEY.md section 8f #4). NOT a reference component: the
+ * reference's topologies put Pothos' /comms/rotate and a decimating FIR in front of every LoRaDemod block; this
+ * does that for K channels of one wideband stream at once and writes the [channel][time] layout
+ * lorahip_demod_run_device() reads. Definition (x[n] = the wideband stream since the last reset, x[n<0] = 0,
+ * w_k = lorahip_channelizer_phase_inc(freq[k]), D = decim, L = n_taps, h = taps):
+ *
+ *     n_m    = (m + 1) D - 1                                  (every D new samples make one output)
+ *     y_k[m] = sum_{j<L} h[j] x[n_m - j] exp(-2 pi i frac(w_k (n_m - j) / 2^64))
+ *
+ * i.e. mix channel k's centre frequency (freq[k] cycles per input sample) down to 0, low-pass with h, keep every
+ * D-th sample. Evaluated in fp32 (fused multiply-add) on taps pre-rotated in double; the phase is a 64-bit
+ * counter, so there is no drift and a stream cut into arbitrary chunks gives bit-identical outputs to one call.
+ * run(): consumes n_in samples, writes *n_out = lorahip_channelizer_out_count(c, n_in) samples per channel at
+ * out_dev + k*out_stride (complex64, out_stride in samples >= *n_out). decim*(256 + n_taps/decim) samples must
+ * fit the LDS (decim <= 64 for short filters).
+ * ------------------------------------------------------------------------------------- */
+typedef struct lorahip_channelizer lorahip_channelizer;
+uint64_t lorahip_channelizer_phase_inc(double freq);          /* floor(frac(freq) * 2^64) */
+int lorahip_channelizer_create(lorahip_channelizer **out, lorahip_ctx *ctx, size_t n_channels, const double *freq,
+                               size_t decim, const float *taps, size_t n_taps);
+void lorahip_channelizer_destroy(lorahip_channelizer *c);
+int lorahip_channelizer_reset(lorahip_channelizer *c);
+size_t lorahip_channelizer_out_count(const lorahip_channelizer *c, size_t n_in);
+int lorahip_channelizer_run(lorahip_channelizer *c, const float *wide_dev, size_t n_in, float *out_dev,
+                            size_t out_stride, size_t *n_out);
+
 /* Measurement aid: one read-only streaming pass over n_bytes of device memory (pattern 0: linear
  * 16 B per lane; 1: the access shape of the tuned SF7 kernel). Time it with lorahip_timer_*; the
  * result is the practical HBM ceiling the roofline fraction can be compared with. */

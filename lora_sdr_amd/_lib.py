@@ -78,6 +78,12 @@ SIGNATURES = {
     "lorahip_add_awgn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_uint64]),
     "lorahip_decode_packets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_void_p]),
+    "lorahip_channelizer_phase_inc": (C.c_uint64, [C.c_double]),
+    "lorahip_channelizer_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "lorahip_channelizer_destroy": (None, [C.c_void_p]),
+    "lorahip_channelizer_reset": (C.c_int, [C.c_void_p]),
+    "lorahip_channelizer_out_count": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "lorahip_channelizer_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lorahip_demod_activate": (C.c_int, [C.c_void_p]),
     "lorahip_demod_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),

@@ -255,6 +255,64 @@ class Context:
         return iq
 
 
+def design_lowpass(decim, n_taps, cutoff=None):
+    """Windowed-sinc (Blackman-Harris) low-pass prototype for the channeliser, unit DC gain; cutoff in cycles per input
+    sample (default 0.5/decim = half the channel rate)."""
+    fc = 0.5 / decim if cutoff is None else float(cutoff)
+    t = np.arange(n_taps) - 0.5 * (n_taps - 1)
+    a = 2.0 * np.pi * np.arange(n_taps) / max(n_taps - 1, 1)
+    win = 0.35875 - 0.48829 * np.cos(a) + 0.14128 * np.cos(2 * a) - 0.01168 * np.cos(3 * a)
+    h = 2.0 * fc * np.sinc(2.0 * fc * t) * (win if n_taps > 1 else 1.0)
+    return (h / h.sum()).astype(np.float32)
+
+
+class Channelizer:
+    """K channels out of one wideband complex64 stream: mix each centre frequency (cycles per input sample) to 0, low-pass,
+    keep every decim-th sample; output (K, n_out) in the layout LoRaDemod.work() takes. Stateful: consecutive run() calls
+    continue one stream (filter history and mixer phase carried), reset() starts a new one. See include/lorahip.h."""
+
+    def __init__(self, ctx, freqs, decim, taps):
+        self._lib = load()
+        self._ctx = ctx                                                  # borrowed: device and stream
+        self._h = C.c_void_p()
+        f = np.ascontiguousarray(freqs, np.float64).reshape(-1)
+        t = np.ascontiguousarray(taps, np.float32).reshape(-1)
+        check(self._lib.lorahip_channelizer_create(C.byref(self._h), ctx._h, f.size, f.ctypes.data, int(decim), t.ctypes.data, t.size),
+              "lorahip_channelizer_create")
+        self.n_channels, self.decim, self.n_taps = int(f.size), int(decim), int(t.size)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.lorahip_channelizer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        check(self._lib.lorahip_channelizer_reset(self._h), "lorahip_channelizer_reset")
+
+    def out_count(self, n_in):
+        return int(self._lib.lorahip_channelizer_out_count(self._h, int(n_in)))
+
+    def run(self, wide, out=None):
+        """wide: 1-D complex64 device tensor (the next samples of the stream); returns the (K, n_out) complex64 tensor"""
+        import torch
+        if wide.dim() != 1 or wide.dtype != torch.complex64:
+            raise ValueError("wide must be a 1-D complex64 device tensor")
+        wide = wide.contiguous()
+        n_out = self.out_count(wide.numel())
+        if out is None:
+            out = torch.empty((self.n_channels, n_out), dtype=torch.complex64, device=wide.device)
+        elif out.dim() != 2 or out.shape[0] != self.n_channels or out.shape[1] < n_out or out.dtype != torch.complex64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (K, >= n_out) complex64 tensor")
+        self._ctx.use_torch_stream()
+        got = C.c_size_t()
+        check(self._lib.lorahip_channelizer_run(self._h, C.c_void_p(wide.data_ptr()) if wide.numel() else None, wide.numel(),
+                                                C.c_void_p(out.data_ptr()) if out.numel() else None, int(out.shape[1]), C.byref(got)),
+              "lorahip_channelizer_run")
+        return out[:, :got.value]
+
+
 class LoRaDetector:
     """`LoRaDetector<float>` (LoRaDetector.hpp:8-72): feed N samples, detect() -> arg-max bin."""
 

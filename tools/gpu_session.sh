@@ -89,6 +89,32 @@ if [[ $what == *sq* ]]; then
   cat $O/pmc_summary_sq.txt
 fi
 
+if [[ $what == *chan* ]]; then
+  CH="${CHARGS:---channels 8 --decim 8 --taps 64}"
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/chan_prof -o chan --output-format csv -- \
+      python $R/tools/bench_chan.py $CH > $O/chan_prof.log 2>&1 )
+  grep "^K=" $O/chan_prof.log
+  find $O/chan_prof -name "*kernel_stats.csv" | head -1 | xargs head -6
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" \
+             "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
+             "GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $set -d $O/chan_SQ$i -o pmc --output-format csv -- \
+        python $R/tools/bench_chan.py $CH --reps 2 > $O/chan_SQ$i.log 2>&1 )
+  done
+  python - <<EOF2
+import csv, glob, collections
+tot = collections.defaultdict(float); n = collections.defaultdict(int)
+for f in glob.glob("$O/chan_SQ*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "channelize" in r.get("Kernel_Name", ""):
+            tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+for k in sorted(tot):
+    print("%-24s %16.0f per launch (%d launches)" % (k, tot[k] / n[k], n[k]))
+EOF2
+fi
+
 if [[ $what == *tailtest* ]]; then
   timeout 120 tools/tailtest.bin > $O/tailtest.log 2>&1; cat $O/tailtest.log
 fi
