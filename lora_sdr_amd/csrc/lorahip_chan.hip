@@ -57,7 +57,7 @@ struct ChanArgs
     long long outStride;
     long long mLo;                  // absolute index of the first output of this call
     long long nOut;
-    int K, L, D, QP;
+    int K, L, D, QP, nGroups;
 };
 
 //! sample n of the stream (absolute index): from this call's chunk, from the history kept from earlier calls, or 0
@@ -114,16 +114,21 @@ template <int RM>
 __device__ __forceinline__ void tapFma(v2f (&acc)[RM][CHAN_KG], const TapCoef &G, const typename TapRegs<RM>::X &X)
 {
     const v2f gk[CHAN_KG] = {G.c0, G.c1, G.c2, G.c3, G.c4, G.c5, G.c6, G.c7};
+    v2f x[RM];
+    if constexpr (RM == 2) { x[0] = (v2f){X[0], X[1]}; x[1] = (v2f){X[2], X[3]}; }
+    else x[0] = X;
+    // the two halves of a complex multiply-add use the same accumulator: all first halves, then all second halves, so
+    // that no packed FMA waits for the one issued just before it
 #pragma unroll
     for (int k = 0; k < CHAN_KG; k++)
-    {
-        if constexpr (RM == 2)
-        {
-            cmacS(acc[0][k], gk[k], (v2f){X[0], X[1]});
-            cmacS(acc[1][k], gk[k], (v2f){X[2], X[3]});
-        }
-        else cmacS(acc[0][k], gk[k], X);
-    }
+#pragma unroll
+        for (int r = 0; r < RM; r++)
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[r][k]) : "s"(gk[k]), "v"(x[r]));                  // (g.x*x.x, g.x*x.y)
+#pragma unroll
+    for (int k = 0; k < CHAN_KG; k++)
+#pragma unroll
+        for (int r = 0; r < RM; r++)
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc[r][k]) : "s"(gk[k]), "v"(x[r]));   // (-g.y*x.y, g.y*x.x)
 }
 
 //! e^{-2 pi i ph / 2^32}: nearest quarter turn taken out exactly, then the fp32 sine / cosine kernels on [-pi/4, pi/4]
@@ -141,6 +146,51 @@ __device__ __forceinline__ v2f mixerPhase(const unsigned ph)
     return (v2f){neg ? -c1 : c1, neg ? s1 : -s1};
 }
 
+//! the common tile: wholly inside this call's chunk. Uniform base + 32-bit byte offsets (no 64-bit vector arithmetic),
+//! 8 loads in flight per lane and round; the LDS slot walks by a constant with one conditional wrap
+__device__ __forceinline__ void tileStageInside(float2 *xs, const float2 *chunkAt, const int D, const int QP, const int TI, const int t)
+{
+    const char *__restrict__ bp = reinterpret_cast<const char *>(chunkAt);
+    const int dq = CHAN_THREADS / D, dp = CHAN_THREADS - dq * D;
+    const int step = dp * QP + dq, wrap = 1 - D * QP;           // next sample 256 on: phase + dp (mod D), slot + dq (+ 1 on wrap)
+    int q = t / D, p = t - q * D;
+    int idx = p * QP + q;
+    for (int tt = t; tt < TI; tt += 8 * CHAN_THREADS)
+    {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const float2 *>(bp + min(unsigned(tt + u * CHAN_THREADS), unsigned(TI - 1)) * 8u);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+        {
+            if (tt + u * CHAN_THREADS < TI) xs[idx] = v[u];
+            p += dp; idx += step;
+            if (p >= D) { p -= D; idx += wrap; }
+        }
+    }
+}
+//! any tile, fetch and store back to back: 8 loads in flight per lane and round
+__device__ __forceinline__ void tileStage(float2 *xs, const ChanArgs &a, const long long tileStart, const int D, const int QP, const int TI, const int t)
+{
+    const int dq = CHAN_THREADS / D, dp = CHAN_THREADS - dq * D;
+    for (int tt = t; tt < TI; tt += 8 * CHAN_THREADS)
+    {
+        float2 v[8];
+        int q = tt / D, p = tt - q * D;
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = tt + u * CHAN_THREADS < TI ? streamSample(a, tileStart + tt + u * CHAN_THREADS) : make_float2(0.0f, 0.0f);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+        {
+            if (tt + u * CHAN_THREADS < TI) xs[p * QP + q] = v[u];
+            p += dp; q += dq;
+            if (p >= D) { p -= D; q++; }
+        }
+    }
+}
+
+// One workgroup = one tile of 256*RM output times x one group of 8 channels; blockIdx.x = tile * nGroups + group: the groups
+// of a tile are neighbours in launch order and share the tile's input in L2.
 template <int RM>
 __global__ __launch_bounds__(CHAN_THREADS) void channelize(const ChanArgs a)
 {
@@ -148,45 +198,16 @@ __global__ __launch_bounds__(CHAN_THREADS) void channelize(const ChanArgs a)
     constexpr int TM = CHAN_THREADS * RM;
     const int t = threadIdx.x;
     const int D = a.D, L = a.L, QP = a.QP;
+    const int TI = (TM - 1) * D + L;
     // tiles sit on absolute multiples of TM, so an output's place in its tile -- and with it every rounding -- does not
     // depend on how the stream was cut into calls
-    const long long mTile = (a.mLo / TM + (long long)blockIdx.x) * TM;
+    const int group = int(blockIdx.x % unsigned(a.nGroups));
+    const long long mTile = (a.mLo / TM + (long long)(blockIdx.x / unsigned(a.nGroups))) * TM;
     const long long tileStart = (mTile + 1) * D - L;            // oldest sample of the tile's first output
-    const int TI = (TM - 1) * D + L;
-
-    // stage the input span, split by decimation phase; 8 loads in flight per lane. Common case first: the tile lies
-    // inside this call's chunk and D divides 256 (a lane keeps its phase, its LDS slot advances by 256/D per round)
     {
-        int q = t / D, p = t - q * D;
-        const int dq = CHAN_THREADS / D, dp = CHAN_THREADS - dq * D;
         const long long rel = tileStart - a.n0;
-        if (rel >= 0 && rel + TI <= a.nChunk && dp == 0)
-        {
-            const float2 *__restrict__ bp = a.chunk + rel;
-            int idx = p * QP + q;
-            for (int i0 = t; i0 < TI; i0 += 8 * CHAN_THREADS, idx += 8 * dq)
-            {
-                float2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) if (i0 + u * CHAN_THREADS < TI) v[u] = bp[i0 + u * CHAN_THREADS];
-#pragma unroll
-                for (int u = 0; u < 8; u++) if (i0 + u * CHAN_THREADS < TI) xs[idx + u * dq] = v[u];
-            }
-        }
-        else
-            for (int i0 = t; i0 < TI; i0 += 8 * CHAN_THREADS)
-            {
-                float2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = i0 + u * CHAN_THREADS < TI ? streamSample(a, tileStart + i0 + u * CHAN_THREADS) : make_float2(0.0f, 0.0f);
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                {
-                    if (i0 + u * CHAN_THREADS < TI) xs[p * QP + q] = v[u];
-                    p += dp; q += dq;
-                    if (p >= D) { p -= D; q++; }
-                }
-            }
+        if (rel >= 0 && rel + TI <= a.nChunk) tileStageInside(xs, a.chunk + rel, D, QP, TI, t);
+        else tileStage(xs, a, tileStart, D, QP, TI, t);
     }
     __syncthreads();
 
@@ -200,7 +221,7 @@ __global__ __launch_bounds__(CHAN_THREADS) void channelize(const ChanArgs a)
     // of tap j run, tap j+1's LDS read and scalar coefficient load are in flight. Both return through lgkmcnt and scalar
     // loads complete out of order, so the only safe wait is lgkmcnt(0) -- placed BEFORE the next issue, one whole FMA block
     // (16*RM v_pk_fma_f32) after the loads it waits for were issued.
-    const v2f *__restrict__ g = a.taps + (size_t)blockIdx.y * (L + 1) * CHAN_KG;
+    const v2f *__restrict__ g = a.taps + (size_t)group * (L + 1) * CHAN_KG;
     const unsigned lds0 = unsigned(uintptr_t(xs)) + unsigned(t) * 8u;       // low half of a flat LDS address = the LDS offset
     // Nothing but the loads, the wait and the FMAs is left in the loop: the LDS offset of every tap ((j mod D)*QP + j/D
     // samples) comes from a table, one tap ahead. Both tables carry a dummy entry past the end for the last prefetch.
@@ -216,10 +237,16 @@ __global__ __launch_bounds__(CHAN_THREADS) void channelize(const ChanArgs a)
         unsigned offB;
         g += 2 * CHAN_KG; op += 2;
         tapWait<RM>(gA, xA, offA);
+#ifdef LORAHIP_CHAN_EXP_NOLOAD
+        gB = gA; xB = xA; offB = offA;
+#else
         tapIssue<RM>(gB, xB, offB, g - CHAN_KG, op, lds0 + offA);
+#endif
         tapFma<RM>(acc, gA, xA);
         tapWait<RM>(gB, xB, offB);
+#ifndef LORAHIP_CHAN_EXP_NOLOAD
         tapIssue<RM>(gA, xA, offA, g, op + 1, lds0 + offB);
+#endif
         tapFma<RM>(acc, gB, xB);
     }
     tapWait<RM>(gA, xA, offA);                              // nothing may still be in flight when the registers are reused
@@ -228,25 +255,25 @@ __global__ __launch_bounds__(CHAN_THREADS) void channelize(const ChanArgs a)
     // samples): lane k of every wavefront evaluates the first factor for channel k -- one sine/cosine per lane instead of
     // eight --, the second comes from a per-channel table of 256 entries; 256 outputs on it is one more constant step.
     // Tiles sit on absolute output indices, so all of this is independent of how the stream was cut into calls.
-    const int chBase = blockIdx.y * CHAN_KG;
+    const int chBase = group * CHAN_KG;
     const v2f mine = mixerPhase(unsigned((a.w[chBase + (t & (CHAN_KG - 1))] * (unsigned long long)((mTile + 1) * D - 1)) >> 32));
     int mineRe = __float_as_int(mine.x), mineIm = __float_as_int(mine.y);
     asm volatile("" : "+v"(mineRe), "+v"(mineIm));             // two separate registers for the lane reads below
-    const long long mLoc = mTile - a.mLo + t;
+    const int mLoc = int(mTile - a.mLo) + t;                    // this call's output index (a call makes < 2^30 outputs)
 #pragma unroll
     for (int k = 0; k < CHAN_KG; k++)
     {
         const int ch = chBase + k;                              // w, step, laneRot are padded to whole groups
         const v2f base = {__int_as_float(__builtin_amdgcn_readlane(mineRe, k)), __int_as_float(__builtin_amdgcn_readlane(mineIm, k))};
         v2f rot = cmulF(a.laneRot[ch * CHAN_THREADS + t], base);
-        float2 *o = a.out + (size_t)ch * a.outStride + mLoc;
+        char *o = reinterpret_cast<char *>(a.out + (size_t)ch * a.outStride);       // uniform; + 32-bit byte offset per lane
 #pragma unroll
         for (int r = 0; r < RM; r++)
         {
             if (r) rot = cmulF(rot, a.step[ch]);                // the output 256 places on: phase advanced by w*256*D
             const v2f y = cmulF(acc[r][k], rot);
-            const long long ml = mLoc + r * CHAN_THREADS;
-            if (ch < a.K && ml >= 0 && ml < a.nOut) o[r * CHAN_THREADS] = make_float2(y.x, y.y);
+            const int ml = mLoc + r * CHAN_THREADS;
+            if (ch < a.K && ml >= 0 && ml < int(a.nOut)) *reinterpret_cast<float2 *>(o + unsigned(ml) * 8u) = make_float2(y.x, y.y);
         }
     }
 }
@@ -270,6 +297,7 @@ static int chanRun(lorahip_channelizer *c, const float2 *wide, const size_t nIn,
     if (nOutP) *nOutP = nOut;
     if (nIn == 0) return LORAHIP_OK;
     if (nOut && (out == nullptr || outStride < nOut)) return LORAHIP_E_INVALID;
+    if (nOut > (size_t(1) << 30)) { setLastError("channeliser: more than 2^30 outputs per channel in one call"); return LORAHIP_E_INVALID; }
     ChanArgs a;
     a.chunk = wide; a.nChunk = (long long)nIn;
     a.hist = c->dHist[c->cur]; a.histLen = c->HC;
@@ -281,11 +309,11 @@ static int chanRun(lorahip_channelizer *c, const float2 *wide, const size_t nIn,
     a.tapOff = c->dTapOff;
     a.out = out; a.outStride = (long long)outStride;
     a.mLo = (long long)mLo; a.nOut = (long long)nOut;
-    a.K = c->K; a.L = c->L; a.D = c->D; a.QP = c->QP;
+    a.K = c->K; a.L = c->L; a.D = c->D; a.QP = c->QP; a.nGroups = c->nGroups;
     if (nOut)
     {
         const int TM = CHAN_THREADS * c->RM;
-        const dim3 grid((unsigned)((mLo % TM + nOut + TM - 1) / TM), (unsigned)c->nGroups);
+        const dim3 grid((unsigned)(size_t(c->nGroups) * ((mLo % TM + nOut + TM - 1) / TM)));
         if (c->RM == 2)
         {
             LORAHIP_TRY(ensureDynamicLds(reinterpret_cast<const void *>(&channelize<2>), c->ldsBytes, gLdsMask[1]));

@@ -25,7 +25,12 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters)
                 if (MODE == 3) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc[i]) : "s"(gsi), "v"(x));
                 if (MODE == 4) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i].x) : "v"(gv.x), "v"(x.x));
                 if (MODE == 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[i]) : "s"(gsi), "v"(x));
+                if (MODE >= 6) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[i]) : "s"(gsi), "v"(x));
             }
+        // the channeliser's block boundary: a wait every 32 FMAs (MODE 6), plus ten s_nop (MODE 7), plus an LDS read (MODE 8)
+        if (MODE == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x));
+        if (MODE == 7) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0" : "+v"(x));
+        if (MODE == 8) { unsigned addr = threadIdx.x * 8; asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b64 %0, %1" : "+v"(x) : "v"(addr)); }
     }
     float s = 0;
     for (int i = 0; i < 16; i++) s += acc[i].x + acc[i].y;
@@ -33,7 +38,7 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters)
 }
 template <int MODE> void run(const char *name, float *out, float *in, int wavesPerSimd)
 {
-    const int iters = 20000, blocks = 256 * wavesPerSimd;       // 256 CUs x (4 waves per block = 1 per SIMD) x wavesPerSimd
+    const int iters = 400000, blocks = 256 * wavesPerSimd;       // 256 CUs x (4 waves per block = 1 per SIMD) x wavesPerSimd
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     k<MODE><<<blocks, 256>>>(out, in, 2000);
     hipDeviceSynchronize();
@@ -50,7 +55,7 @@ int main()
 {
     float *in, *out; hipMalloc(&in, 4096); hipMalloc(&out, 256 * 8 * 256 * 4);
     float h[64]; for (int i = 0; i < 64; i++) h[i] = 1.0f / (i + 3); hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
-    for (int w : {1, 2, 4})
+    for (int w : {4})
     {
         run<0>("v_pk_fma_f32 vgpr", out, in, w);
         run<1>("v_pk_fma_f32 sgpr src0", out, in, w);
@@ -58,6 +63,9 @@ int main()
         run<3>("v_pk_fma_f32 sgpr op_sel+neg", out, in, w);
         run<5>("v_pk_fma_f32 sgpr op_sel_hi:[0,1,1]", out, in, w);
         run<4>("v_fma_f32 vgpr", out, in, w);
+        run<6>("pk_fma sgpr + s_waitcnt per 64", out, in, w);
+        run<7>("pk_fma sgpr + s_waitcnt + 10 s_nop per 64", out, in, w);
+        run<8>("pk_fma sgpr + s_waitcnt + ds_read per 64", out, in, w);
     }
     return 0;
 }
