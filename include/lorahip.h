@@ -159,6 +159,9 @@ int lorahip_demod_activate(lorahip_demod *d);                            /* acti
  * 2 = from the host: one batch launch per lock-step round, the frame machine on the host between launches.
  * Both produce identical packets, traces and signals. */
 int lorahip_demod_set_mode(lorahip_demod *d, int mode);
+/* Launch on an existing hipStream_t from now on (same meaning as lorahip_set_stream): work queued on that stream before a
+ * run -- a channeliser, a modulator, a copy -- is ordered before the run's kernels. A run returns with the stream drained. */
+int lorahip_demod_set_stream(lorahip_demod *d, void *hip_stream);
 
 /* Per-channel outcome of one work() round (what the block would have done on its ports). */
 typedef struct lorahip_work_result {

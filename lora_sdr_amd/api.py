@@ -399,6 +399,10 @@ class LoRaDemod:
         if _is_torch(streams):
             if streams.dim() != 2 or streams.shape[0] != self.n_channels:
                 raise ValueError("expected a (n_channels, samples) tensor")
+            import torch
+            # run on torch's current stream: whatever produced `streams` there is ordered before the demodulator's kernels
+            check(self._lib.lorahip_demod_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(streams.device).cuda_stream)),
+                  "lorahip_demod_set_stream")
             check(self._lib.lorahip_demod_run_device(self._h, _dptr(streams), int(streams.shape[1]),
                                                      C.byref(rounds)), "lorahip_demod_run_device")
             return rounds.value

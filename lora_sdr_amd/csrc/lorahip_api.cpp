@@ -42,14 +42,19 @@ static bool isGfx950(const int device)
 
 static int growStage(lorahip_ctx *ctx, const size_t bytes)
 {
-    if (bytes <= ctx->dStageBytes) return LORAHIP_OK;
-    if (ctx->dStage) { (void)hipFree(ctx->dStage); ctx->dStage = nullptr; ctx->dStageBytes = 0; }
-    if (ctx->hStage) { (void)hipHostFree(ctx->hStage); ctx->hStage = nullptr; ctx->hStageBytes = 0; }
+    if (bytes <= ctx->dStageBytes && bytes <= ctx->hStageBytes) return LORAHIP_OK;
+    if (ctx->dStage) { (void)hipFree(ctx->dStage); ctx->dStage = nullptr; }
+    if (ctx->hStage) { (void)hipHostFree(ctx->hStage); ctx->hStage = nullptr; }
+    ctx->dStageBytes = ctx->hStageBytes = 0;                    // both or neither: a half-grown pair must not look usable
     const size_t cap = bytes + bytes / 4;
     LORAHIP_TRY(hipMalloc(&ctx->dStage, cap));
-    ctx->dStageBytes = cap;
-    LORAHIP_TRY(hipHostMalloc(&ctx->hStage, cap, hipHostMallocDefault));
-    ctx->hStageBytes = cap;
+    const hipError_t e = hipHostMalloc(&ctx->hStage, cap, hipHostMallocDefault);
+    if (e != hipSuccess)
+    {
+        (void)hipFree(ctx->dStage); ctx->dStage = nullptr; ctx->hStage = nullptr;
+        return hipFail(e, "hipHostMalloc(staging)");
+    }
+    ctx->dStageBytes = ctx->hStageBytes = cap;
     return LORAHIP_OK;
 }
 
@@ -102,7 +107,7 @@ int lorahip_create(lorahip_ctx **out, const int device, const int sf)
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); setLastError("no HIP device"); return LORAHIP_E_NODEVICE; }
     if (device < 0 || device >= n) return LORAHIP_E_NODEVICE;
     if (!isGfx950(device)) return LORAHIP_E_ARCH;
-    LORAHIP_TRY(hipSetDevice(device));
+    const DeviceGuard guard(device);                            // the caller's current device is restored on return
 
     lorahip_ctx *ctx = new (std::nothrow) lorahip_ctx();
     if (ctx == nullptr) return LORAHIP_E_NOMEM;
@@ -147,7 +152,7 @@ int lorahip_create(lorahip_ctx **out, const int device, const int sf)
 void lorahip_destroy(lorahip_ctx *ctx)
 {
     if (ctx == nullptr) return;
-    (void)hipSetDevice(ctx->device);
+    const DeviceGuard guard(ctx->device);
     if (ctx->ownStream) (void)hipStreamSynchronize(ctx->ownStream);
     if (ctx->dUp) (void)hipFree(ctx->dUp);
     if (ctx->dDown) (void)hipFree(ctx->dDown);
@@ -253,7 +258,12 @@ int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b)
             if (size_t(b->offsets[w]) + N > iqLen) iqLen = size_t(b->offsets[w]) + N;
         }
     }
-    else iqLen = (W - 1) * stride + N;
+    else
+    {
+        if (stride > (size_t(1) << 40) / W) return LORAHIP_E_INVALID;
+        iqLen = (W - 1) * stride + N;
+    }
+    if (iqLen > (size_t(1) << 40)) return LORAHIP_E_INVALID;     // 8 TiB of samples: a wrapped or garbage offset, not a batch
 
     // carve one staging block: inputs first, then outputs (256 B aligned pieces)
     struct Piece { size_t off, bytes; };

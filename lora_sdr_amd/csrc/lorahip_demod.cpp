@@ -515,6 +515,12 @@ int lorahip_demod_set_mode(lorahip_demod *dm, const int mode)
     return LORAHIP_OK;
 }
 
+int lorahip_demod_set_stream(lorahip_demod *dm, void *hip_stream)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    return lorahip_set_stream(dm->ctx, hip_stream);
+}
+
 int lorahip_demod_activate(lorahip_demod *dm)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;

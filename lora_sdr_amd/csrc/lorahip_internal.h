@@ -141,7 +141,8 @@ struct DeviceGuard
     bool switched;
     explicit DeviceGuard(const int device) : prev(-1), switched(false)
     {
-        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipSetDevice(device); }       // nothing to restore
+        else if (prev != device) switched = hipSetDevice(device) == hipSuccess;
     }
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard &) = delete;
