@@ -428,9 +428,35 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         k.pos = size_t(st.pos);
         if (st.callCount > rounds) rounds = st.callCount;
     }
-    // the host-driven path posts packets round by round, channels in order inside a round
-    std::stable_sort(dm->packets.begin() + long(firstNewPacket), dm->packets.end(),
-                     [](const Packet &x, const Packet &y) { return x.round != y.round ? x.round < y.round : x.channel < y.channel; });
+    // The host-driven path posts packets round by round, channels in order inside a round. The new packets were appended
+    // channel by channel with rounds ascending inside a channel: a stable counting sort by round restores that order in
+    // O(packets + rounds) instead of a comparison sort of tens of thousands of records (which cost more than the kernel).
+    // Several launches per run can interleave channels inside a round; that case is detected and falls back to the sort.
+    {
+        const size_t nNew = dm->packets.size() - firstNewPacket;
+        if (nNew > 1)
+        {
+            Packet *first = dm->packets.data() + firstNewPacket;
+            bool sorted = true, channelsAscendPerRound = true;
+            for (size_t i = 1; i < nNew && sorted; i++)
+                sorted = first[i - 1].round < first[i].round || (first[i - 1].round == first[i].round && first[i - 1].channel <= first[i].channel);
+            if (!sorted && rounds >= 0 && size_t(rounds) <= 4 * nNew + 1024)
+            {
+                std::vector<size_t> start(size_t(rounds) + 2, 0);
+                for (size_t i = 0; i < nNew; i++) start[size_t(first[i].round) + 1]++;
+                for (size_t r = 1; r < start.size(); r++) start[r] += start[r - 1];
+                std::vector<Packet> tmp(nNew);
+                for (size_t i = 0; i < nNew; i++) tmp[start[size_t(first[i].round)]++] = first[i];
+                for (size_t i = 1; i < nNew && channelsAscendPerRound; i++)
+                    channelsAscendPerRound = tmp[i - 1].round != tmp[i].round || tmp[i - 1].channel <= tmp[i].channel;
+                std::copy(tmp.begin(), tmp.end(), first);
+                sorted = channelsAscendPerRound;
+            }
+            if (!sorted)
+                std::stable_sort(first, first + nNew,
+                                 [](const Packet &x, const Packet &y) { return x.round != y.round ? x.round < y.round : x.channel < y.channel; });
+        }
+    }
     if (roundsOut) *roundsOut = rounds;
     return LORAHIP_OK;
 }
