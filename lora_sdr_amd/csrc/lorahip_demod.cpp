@@ -12,6 +12,8 @@
 // _prevValue) start at zero here.
 #include "lorahip_internal.h"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -66,6 +68,7 @@ struct lorahip_demod
     int mode;                        // 0 auto, 1 device streaming kernel, 2 host-driven rounds
     // streaming path: device + pinned-host mirrors, grown on demand
     char *sDev, *sHost; size_t sBytes;
+    char *dDense, *hDense; size_t denseBytes;   // the used part of the record arrays, packed for the copy back
 };
 
 namespace {
@@ -301,6 +304,12 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     lorahip_ctx *ctx = dm->ctx;
     const size_t N = dm->N, B = dm->B;
     const DeviceGuard guard(ctx->device);
+    // diagnostic: LORAHIP_DEMOD_TIMING=1 prints where a run's host wall clock goes
+    static const bool timing = std::getenv("LORAHIP_DEMOD_TIMING") != nullptr;
+    typedef std::chrono::steady_clock Clock;
+    const Clock::time_point t0 = Clock::now();
+    double tDev = 0, tAsm = 0;
+    size_t d2hBytes = 0;
     size_t maxLen = 0;
     for (size_t c = 0; c < B; c++) if (dm->ch[c].len - dm->ch[c].pos > maxLen) maxLen = dm->ch[c].len - dm->ch[c].pos;
     // work() calls per channel per launch: enough for a clean stream in one launch, bounded so that the
@@ -329,16 +338,13 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         if (dm->sHost) { (void)hipHostFree(dm->sHost); dm->sHost = nullptr; }
         dm->sBytes = 0;
         LORAHIP_TRY(hipMalloc((void **)&dm->sDev, cur));
-        LORAHIP_TRY(hipHostMalloc((void **)&dm->sHost, cur, hipHostMallocDefault));
+        LORAHIP_TRY(hipHostMalloc((void **)&dm->sHost, oPkt, hipHostMallocDefault));       // the host mirrors only the head: placement, state, counts
         dm->sBytes = cur;
     }
     char *h = dm->sHost, *d = dm->sDev;
     long long *hBase = reinterpret_cast<long long *>(h + oBase), *hLen = reinterpret_cast<long long *>(h + oLen);
     StreamState *hState = reinterpret_cast<StreamState *>(h + oState);
     const int *hN = reinterpret_cast<int *>(h + oN), *hNSym = reinterpret_cast<int *>(h + oNSym), *hNPkt = reinterpret_cast<int *>(h + oNPkt);
-    const StreamPacket *hPkt = reinterpret_cast<StreamPacket *>(h + oPkt);
-    const short *hSym = reinterpret_cast<short *>(h + oSym);
-    const lorahip_work_result *hCalls = reinterpret_cast<lorahip_work_result *>(h + oCalls);
     std::vector<size_t> carry(B, 0);
     for (size_t c = 0; c < B; c++)
     {
@@ -377,21 +383,60 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
 
     const size_t firstNewPacket = dm->packets.size();
+    const Clock::time_point t1 = Clock::now();
     while (true)
     {
+        const Clock::time_point ta = Clock::now();
         LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
-        LORAHIP_TRY(hipMemcpyAsync(h + oState, d + oState, cur - oState, hipMemcpyDeviceToHost, ctx->stream));
+        // results back in two steps: the per-channel state and counts first (small), then only as many columns of the
+        // [channel][capacity] record arrays as the fullest channel used -- the capacities are worst-case bounds, several
+        // times what a run fills
+        LORAHIP_TRY(hipMemcpyAsync(h + oState, d + oState, oPkt - oState, hipMemcpyDeviceToHost, ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+        size_t maxSym = 0, maxPkt = 0, maxCalls = 0;
+        for (size_t c = 0; c < B; c++)
+        {
+            if (size_t(hNSym[c]) > maxSym) maxSym = size_t(hNSym[c]);
+            if (size_t(hNPkt[c]) > maxPkt) maxPkt = size_t(hNPkt[c]);
+            if (size_t(hN[c]) > maxCalls) maxCalls = size_t(hN[c]);
+        }
+        const size_t nbPkt = align256(B * maxPkt * sizeof(StreamPacket)), nbSym = align256(B * maxSym * sizeof(short));
+        const size_t nbCalls = dm->tracing ? align256(B * maxCalls * sizeof(lorahip_work_result)) : 0;
+        const size_t nbDense = nbPkt + nbSym + nbCalls;
+        if (nbDense > dm->denseBytes)
+        {
+            if (dm->dDense) { (void)hipFree(dm->dDense); dm->dDense = nullptr; }
+            if (dm->hDense) { (void)hipHostFree(dm->hDense); dm->hDense = nullptr; }
+            dm->denseBytes = 0;
+            const size_t want = nbDense + nbDense / 4;
+            LORAHIP_TRY(hipMalloc((void **)&dm->dDense, want));
+            const hipError_t e = hipHostMalloc((void **)&dm->hDense, want, hipHostMallocDefault);
+            if (e != hipSuccess) { (void)hipFree(dm->dDense); dm->dDense = nullptr; dm->hDense = nullptr; return hipFail(e, "hipHostMalloc(dense records)"); }
+            dm->denseBytes = want;
+        }
+        LORAHIP_TRY(launchCompactRows(dm->dDense, d + oPkt, B, capPkt * sizeof(StreamPacket), maxPkt * sizeof(StreamPacket), ctx->stream));
+        LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt, d + oSym, B, cap * sizeof(short), maxSym * sizeof(short), ctx->stream));
+        if (dm->tracing)
+            LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt + nbSym, d + oCalls, B, cap * sizeof(lorahip_work_result),
+                                          maxCalls * sizeof(lorahip_work_result), ctx->stream));
+        if (nbDense) LORAHIP_TRY(hipMemcpyAsync(dm->hDense, dm->dDense, nbDense, hipMemcpyDeviceToHost, ctx->stream));
+        LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+        const StreamPacket *hPkt = reinterpret_cast<const StreamPacket *>(dm->hDense);
+        const short *hSym = reinterpret_cast<const short *>(dm->hDense + nbPkt);
+        const lorahip_work_result *hCalls = reinterpret_cast<const lorahip_work_result *>(dm->hDense + nbPkt + nbSym);
+        d2hBytes += (oPkt - oState) + B * (maxPkt * sizeof(StreamPacket) + maxSym * sizeof(short) + (dm->tracing ? maxCalls * sizeof(lorahip_work_result) : 0));
+        const Clock::time_point tb = Clock::now();
+        tDev += std::chrono::duration<double>(tb - ta).count();
         bool more = false;
         for (size_t c = 0; c < B; c++)
         {
             Channel &k = dm->ch[c];
             // symbols of this launch continue the packet the previous launches left open (k.outSymbols[0..carry[c]))
-            const short *sy = hSym + c * cap;
+            const short *sy = hSym + c * maxSym;
             size_t p = 0;
             for (int j = 0; j < hNPkt[c]; j++)
             {
-                const StreamPacket &q = hPkt[c * capPkt + size_t(j)];
+                const StreamPacket &q = hPkt[c * maxPkt + size_t(j)];
                 Packet pk;
                 pk.channel = int32_t(c);
                 pk.round = q.callIndex;
@@ -413,11 +458,13 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
                 carry[c] += left;
             }
             dm->workCalls += hN[c];
-            if (dm->tracing) k.trace.insert(k.trace.end(), hCalls + c * cap, hCalls + c * cap + hN[c]);
+            if (dm->tracing) k.trace.insert(k.trace.end(), hCalls + c * maxCalls, hCalls + c * maxCalls + hN[c]);
             if (size_t(hN[c]) == cap || size_t(hNPkt[c]) == capPkt) more = true;
         }
+        tAsm += std::chrono::duration<double>(Clock::now() - tb).count();
         if (!more) break;
     }
+    const Clock::time_point t2 = Clock::now();
     int64_t rounds = 0;
     for (size_t c = 0; c < B; c++)
     {
@@ -458,6 +505,10 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         }
     }
     if (roundsOut) *roundsOut = rounds;
+    if (timing)
+        std::fprintf(stderr, "lorahip demod run: setup+H2D %.3f ms, kernel+D2H(%.1f MB)+sync %.3f ms, packet assembly %.3f ms, state+order %.3f ms\n",
+                     std::chrono::duration<double>(t1 - t0).count() * 1e3, double(d2hBytes) / 1e6, tDev * 1e3, tAsm * 1e3,
+                     std::chrono::duration<double>(Clock::now() - t2).count() * 1e3);
     return LORAHIP_OK;
 }
 
@@ -479,7 +530,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     lorahip_demod *dm = new (std::nothrow) lorahip_demod();
     if (dm == nullptr) return LORAHIP_E_NOMEM;
     dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
-    dm->mode = 0; dm->sDev = nullptr; dm->sHost = nullptr; dm->sBytes = 0;
+    dm->mode = 0; dm->sDev = nullptr; dm->sHost = nullptr; dm->sBytes = 0; dm->dDense = nullptr; dm->hDense = nullptr; dm->denseBytes = 0;
     int rc = lorahip_create(&dm->ctx, device, sf);
     if (rc != LORAHIP_OK) { delete dm; return rc; }
     dm->N = size_t(1) << sf;
@@ -509,6 +560,8 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->dIq) (void)hipFree(dm->dIq);
     if (dm->sDev) (void)hipFree(dm->sDev);
     if (dm->sHost) (void)hipHostFree(dm->sHost);
+    if (dm->dDense) (void)hipFree(dm->dDense);
+    if (dm->hDense) (void)hipHostFree(dm->hDense);
     lorahip_destroy(dm->ctx);
     delete dm;
 }

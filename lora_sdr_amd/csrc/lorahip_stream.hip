@@ -173,6 +173,30 @@ typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  
 typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  true,  true,  0> Stream9;
 typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  true,  true,  0> Stream10;
 
+//! the used columns of a [rows][capacity] record array packed densely (2-byte units): what goes back to the host is what a
+//! run filled, not the worst-case capacity
+__global__ void compactRows(unsigned short *__restrict__ dst, const unsigned short *__restrict__ src, const size_t rows,
+                            const size_t srcPitch, const size_t width)
+{
+    const size_t total = rows * width;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const size_t r = i / width;
+        dst[i] = src[r * srcPitch + (i - r * width)];
+    }
+}
+
+hipError_t launchCompactRows(void *dst, const void *src, const size_t rows, const size_t srcPitchBytes, const size_t rowBytes, hipStream_t stream)
+{
+    if (rows == 0 || rowBytes == 0) return hipSuccess;
+    if ((srcPitchBytes | rowBytes) & 1) return hipErrorInvalidValue;
+    const size_t total = rows * (rowBytes / 2);
+    const unsigned grid = unsigned(total / 256 + 1 > 65536 ? 65536 : total / 256 + 1);
+    hipLaunchKernelGGL(compactRows, dim3(grid), dim3(256), 0, stream, static_cast<unsigned short *>(dst), static_cast<const unsigned short *>(src),
+                       rows, srcPitchBytes / 2, rowBytes / 2);
+    return hipGetLastError();
+}
+
 bool streamAvailable(const int sf) { return sf >= 7 && sf <= 12; }
 
 hipError_t launchStream(const int sf, const StreamArgs &s, hipStream_t stream)
