@@ -119,9 +119,52 @@ __device__ __forceinline__ void bfly4corev(v2f &f0, v2f &f1, v2f &f2, v2f &f3, c
     f1 = addRotv(s5, s4);
     f3 = subRotv(s5, s4);
 }
+// Issue order matters to the assembler, not to the arithmetic: the compiler cannot see inside an asm statement, assumes the
+// worst (a gfx940 dst_sel forwarding hazard) whenever one asm result is consumed by the very next instruction, and pads with
+// an s_nop -- which costs about two thirds of a packed operation (tools/pkfma_rate.hip). The helpers below therefore
+// interleave independent products so that no asm result is used by its immediate successor. Same operations, same bits.
+__device__ __forceinline__ v2f mulLoV(const v2f a, const v2f b)     // (a.x*b.x, a.y*b.x)
+{
+    v2f p;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));
+    return p;
+}
+__device__ __forceinline__ v2f mulHiV(const v2f a, const v2f b)     // (a.y*b.y, a.x*b.y)
+{
+    v2f q;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(q) : "v"(a), "v"(b));
+    return q;
+}
+__device__ __forceinline__ v2f subAddV(const v2f p, const v2f q)    // (p.x-q.x, p.y+q.y)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));
+    return r;
+}
 __device__ __forceinline__ void bfly4v(v2f &f0, v2f &f1, v2f &f2, v2f &f3, const v2f t1, const v2f t2, const v2f t3)
 {
-    bfly4corev(f0, f1, f2, f3, cmulv(f1, t1), cmulv(f2, t2), cmulv(f3, t3));
+    const v2f p1 = mulLoV(f1, t1), q1 = mulHiV(f1, t1), p2 = mulLoV(f2, t2), q2 = mulHiV(f2, t2), p3 = mulLoV(f3, t3), q3 = mulHiV(f3, t3);
+    const v2f s0 = subAddV(p1, q1), s1 = subAddV(p2, q2), s2 = subAddV(p3, q3);
+    bfly4corev(f0, f1, f2, f3, s0, s1, s2);
+}
+//! x[i] = (x[i] * c[i]) * f for CNT values, four at a time with the products interleaved (see above)
+template <int CNT>
+__device__ __forceinline__ void dechirpMany(v2f *x, const v2f *c, const v2f f)
+{
+    static_assert(CNT % 4 == 0, "four values per round");
+#pragma unroll
+    for (int i = 0; i < CNT; i += 4)
+    {
+        v2f p[4], q[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { p[j] = mulLoV(x[i + j], c[i + j]); q[j] = mulHiV(x[i + j], c[i + j]); }
+#pragma unroll
+        for (int j = 0; j < 4; j++) y[j] = subAddV(p[j], q[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { p[j] = mulLoV(y[j], f); q[j] = mulHiV(y[j], f); }
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[i + j] = subAddV(p[j], q[j]);
+    }
 }
 __device__ __forceinline__ void bfly4unitv(v2f &f0, v2f &f1, v2f &f2, v2f &f3) { bfly4corev(f0, f1, f2, f3, f1, f2, f3); }
 __device__ __forceinline__ void bfly2unitv(v2f &f0, v2f &f1)

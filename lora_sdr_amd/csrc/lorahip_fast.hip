@@ -179,10 +179,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             // launch-uniform table selection, constant fine-tune entry: the hot path
             if (a.chirpSelAll != LORAHIP_CHIRP_NONE)
             {
-#pragma unroll
-                for (int r = 0; r < R; r++)
-#pragma unroll
-                    for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulv(x[r][u], cw[r][u]), fconst);
+                dechirpMany<R * VEC>(&x[0][0], &cw[0][0], fconst);
             }
         }
         else

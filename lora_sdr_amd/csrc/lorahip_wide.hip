@@ -312,10 +312,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         {
             if (a.chirpSelAll != LORAHIP_CHIRP_NONE)
             {
-#pragma unroll
-                for (int r = 0; r < R; r++)
-#pragma unroll
-                    for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulv(x[r][u], cw[r][u]), fconst);
+                dechirpMany<R * VEC>(&x[0][0], &cw[0][0], fconst);
             }
         }
         else
