@@ -313,7 +313,9 @@ static int chanRun(lorahip_channelizer *c, const float2 *wide, const size_t nIn,
     if (nOut)
     {
         const int TM = CHAN_THREADS * c->RM;
-        const dim3 grid((unsigned)(size_t(c->nGroups) * ((mLo % TM + nOut + TM - 1) / TM)));
+        const size_t nBlocks = size_t(c->nGroups) * ((mLo % TM + nOut + TM - 1) / TM);
+        if (nBlocks > 0x7fffffffu) { setLastError("channeliser: channels x outputs of one call exceed the launch grid"); return LORAHIP_E_INVALID; }
+        const dim3 grid((unsigned)nBlocks);
         if (c->RM == 2)
         {
             LORAHIP_TRY(ensureDynamicLds(reinterpret_cast<const void *>(&channelize<2>), c->ldsBytes, gLdsMask[1]));

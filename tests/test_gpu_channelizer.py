@@ -17,7 +17,7 @@ def _stream(rng, n):
 TOL = 4e-6
 
 
-@pytest.mark.parametrize("K,D,L", [(8, 8, 64), (3, 5, 37), (19, 16, 128), (1, 1, 1), (2, 1, 9), (9, 64, 256), (5, 72, 300)])
+@pytest.mark.parametrize("K,D,L", [(8, 8, 64), (3, 5, 37), (19, 16, 128), (1, 1, 1), (2, 1, 9), (9, 64, 256), (5, 72, 300), (4, 10, 3)])
 def test_against_float64_definition(gpu, K, D, L):
     import torch
     import lora_sdr_amd as Lh
