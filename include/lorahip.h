@@ -193,6 +193,12 @@ int lorahip_demod_get_packet(const lorahip_demod *d, size_t i, int32_t *channel,
 size_t lorahip_demod_num_packet_symbols(const lorahip_demod *d);
 int lorahip_demod_get_packets(const lorahip_demod *d, int32_t *channels, int64_t *rounds, int64_t *lens, size_t cap_packets,
                               int16_t *syms, size_t cap_syms);
+/* The queued packets in the batched decoder's input layout, on the device (same order as lorahip_demod_get_packets): packet p's
+ * symbols at syms_dev + p*sym_stride (zero padded), its length in nsyms_dev[p] -- a packet longer than sym_stride keeps its true
+ * length there and lorahip_decode_packets() reports -2 for it --, its channel in channel_dev[p] (nullable). *n_packets = number of
+ * queued packets (also when cap_packets is too small: LORAHIP_E_INVALID then). Does not clear the queue. */
+int lorahip_demod_packets_to_device(lorahip_demod *d, uint16_t *syms_dev, size_t sym_stride, int32_t *nsyms_dev, int32_t *channel_dev,
+                                    size_t cap_packets, size_t *n_packets);
 void lorahip_demod_clear_packets(lorahip_demod *d);
 /* samples of `channel`'s stream the last lorahip_demod_run[_device] consumed (the sum of its consume() calls, :320): a
  * streaming caller presents the unconsumed remainder again in front of the next chunk, as the framework's port buffer does */
@@ -232,7 +238,7 @@ int lorahip_add_awgn(lorahip_ctx *ctx, float *iq_dev, size_t n_samples, float si
  *   packet p: nsyms_dev[p] symbols at syms_dev + p*sym_stride (sym_stride <= 512)
  *   out_len_dev[p]: number of output elements posted at out_dev + p*out_stride -- bytes, or uint16 symbols when
  *       interleaving is off --, -1 if the block posts nothing (fewer than 8 symbols, or dropped), -2 if the packet is
- *       longer than this build supports; dropped_dev[p] = 1 where the block calls drop() (the "dropped" signal).
+ *       longer than this build supports or than sym_stride; dropped_dev[p] = 1 where the block calls drop() (the "dropped" signal).
  *   out_stride: even, >= 2*(sym_stride + 8). ctx supplies the device and the stream only (any SF).
  * ------------------------------------------------------------------------------------- */
 typedef struct lorahip_decoder_cfg {

@@ -87,6 +87,7 @@ SIGNATURES = {
     "lorahip_demod_activate": (C.c_int, [C.c_void_p]),
     "lorahip_demod_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lorahip_demod_packets_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lorahip_demod_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "lorahip_demod_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "lorahip_demod_num_packets": (C.c_size_t, [C.c_void_p]),

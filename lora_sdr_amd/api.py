@@ -358,6 +358,7 @@ class LoRaDemod:
         check(self._lib.lorahip_demod_create(C.byref(self._h), int(device), int(sf), int(n_channels)),
               "lorahip_demod_create")
         self.sf, self.N, self.n_channels = int(sf), 1 << int(sf), int(n_channels)
+        self._device = int(device)
         self._thresh = -30.0                                            # LoRaDemod.cpp:72
 
     @staticmethod
@@ -427,6 +428,29 @@ class LoRaDemod:
         if clear:
             self._lib.lorahip_demod_clear_packets(self._h)
         return out
+
+    def packets_device(self, stride=None, clear=True):
+        """The queued packets as device tensors in the decoder's input layout -- (P, stride) int16 symbols (zero padded), (P,) int32
+        lengths, (P,) int32 channels -- ready for LoRaDecoder.decode_batch(); no per-packet Python work."""
+        import torch
+        n = int(self._lib.lorahip_demod_num_packets(self._h))
+        dev = torch.device("cuda", int(self._device))
+        if stride is None:
+            ln = np.empty(n, np.int64)
+            if n:
+                check(self._lib.lorahip_demod_get_packets(self._h, None, None, ln.ctypes.data, n, None, 1 << 62), "lorahip_demod_get_packets")
+            stride = max(8, int(ln.max()) if n else 8)
+        syms = torch.zeros((n, int(stride)), dtype=torch.int16, device=dev)
+        nsyms = torch.zeros(n, dtype=torch.int32, device=dev)
+        chan = torch.zeros(n, dtype=torch.int32, device=dev)
+        got = C.c_size_t()
+        if n:
+            torch.cuda.current_stream(dev).synchronize()            # the tensors above are zero-filled on torch's stream
+            check(self._lib.lorahip_demod_packets_to_device(self._h, C.c_void_p(syms.data_ptr()), int(stride), C.c_void_p(nsyms.data_ptr()),
+                                                            C.c_void_p(chan.data_ptr()), n, C.byref(got)), "lorahip_demod_packets_to_device")
+        if clear:
+            self._lib.lorahip_demod_clear_packets(self._h)
+        return syms, nsyms, chan
 
     def consumed(self, channel):
         """samples of the channel's stream consumed by the last work()"""

@@ -299,6 +299,21 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
  * Streaming path: the device walks every channel (lorahip_stream.hip); the host only drains the
  * per-call records, assembles the packets and keeps the Channel mirrors in step.
  **********************************************************************/
+//! device + pinned scratch pair for packed records (grown on demand, both or neither)
+static int growDense(lorahip_demod *dm, const size_t bytes)
+{
+    if (bytes <= dm->denseBytes) return LORAHIP_OK;
+    if (dm->dDense) { (void)hipFree(dm->dDense); dm->dDense = nullptr; }
+    if (dm->hDense) { (void)hipHostFree(dm->hDense); dm->hDense = nullptr; }
+    dm->denseBytes = 0;
+    const size_t want = bytes + bytes / 4;
+    LORAHIP_TRY(hipMalloc((void **)&dm->dDense, want));
+    const hipError_t e = hipHostMalloc((void **)&dm->hDense, want, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipFree(dm->dDense); dm->dDense = nullptr; dm->hDense = nullptr; return hipFail(e, "hipHostMalloc(dense records)"); }
+    dm->denseBytes = want;
+    return LORAHIP_OK;
+}
+
 static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     lorahip_ctx *ctx = dm->ctx;
@@ -403,17 +418,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         const size_t nbPkt = align256(B * maxPkt * sizeof(StreamPacket)), nbSym = align256(B * maxSym * sizeof(short));
         const size_t nbCalls = dm->tracing ? align256(B * maxCalls * sizeof(lorahip_work_result)) : 0;
         const size_t nbDense = nbPkt + nbSym + nbCalls;
-        if (nbDense > dm->denseBytes)
-        {
-            if (dm->dDense) { (void)hipFree(dm->dDense); dm->dDense = nullptr; }
-            if (dm->hDense) { (void)hipHostFree(dm->hDense); dm->hDense = nullptr; }
-            dm->denseBytes = 0;
-            const size_t want = nbDense + nbDense / 4;
-            LORAHIP_TRY(hipMalloc((void **)&dm->dDense, want));
-            const hipError_t e = hipHostMalloc((void **)&dm->hDense, want, hipHostMallocDefault);
-            if (e != hipSuccess) { (void)hipFree(dm->dDense); dm->dDense = nullptr; dm->hDense = nullptr; return hipFail(e, "hipHostMalloc(dense records)"); }
-            dm->denseBytes = want;
-        }
+        { const int grc = growDense(dm, nbDense); if (grc != LORAHIP_OK) return grc; }
         LORAHIP_TRY(launchCompactRows(dm->dDense, d + oPkt, B, capPkt * sizeof(StreamPacket), maxPkt * sizeof(StreamPacket), ctx->stream));
         LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt, d + oSym, B, cap * sizeof(short), maxSym * sizeof(short), ctx->stream));
         if (dm->tracing)
@@ -682,6 +687,35 @@ int lorahip_demod_get_packets(const lorahip_demod *dm, int32_t *channels, int64_
         if (syms) std::memcpy(syms + o, dm->pktSyms.data() + p.off, p.len * sizeof(int16_t));
         o += p.len;
     }
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const size_t sym_stride, int32_t *nsyms_dev, int32_t *channel_dev,
+                                    const size_t cap_packets, size_t *n_packets)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    const size_t P = dm->packets.size();
+    if (n_packets) *n_packets = P;
+    if (P == 0) return LORAHIP_OK;
+    if (syms_dev == nullptr || nsyms_dev == nullptr || sym_stride == 0 || cap_packets < P) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(dm->ctx->device);
+    const size_t nbSym = align256(P * sym_stride * sizeof(uint16_t)), nbInt = align256(P * sizeof(int32_t));
+    { const int grc = growDense(dm, nbSym + 2 * nbInt); if (grc != LORAHIP_OK) return grc; }
+    uint16_t *hs = reinterpret_cast<uint16_t *>(dm->hDense);
+    int32_t *hn = reinterpret_cast<int32_t *>(dm->hDense + nbSym), *hc = reinterpret_cast<int32_t *>(dm->hDense + nbSym + nbInt);
+    std::memset(hs, 0, P * sym_stride * sizeof(uint16_t));
+    for (size_t i = 0; i < P; i++)
+    {
+        const Packet &p = dm->packets[i];
+        std::memcpy(hs + i * sym_stride, dm->pktSyms.data() + p.off, (p.len < sym_stride ? p.len : sym_stride) * sizeof(uint16_t));
+        hn[i] = int32_t(p.len > 0x7fffffffu ? 0x7fffffff : p.len);     // the true length: a packet longer than the stride is flagged by the decoder
+        hc[i] = p.channel;
+    }
+    hipStream_t st = dm->ctx->stream;
+    LORAHIP_TRY(hipMemcpyAsync(syms_dev, hs, P * sym_stride * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    LORAHIP_TRY(hipMemcpyAsync(nsyms_dev, hn, P * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (channel_dev) LORAHIP_TRY(hipMemcpyAsync(channel_dev, hc, P * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    LORAHIP_TRY(hipStreamSynchronize(st));                              // the pinned scratch is reused by the next run
     return LORAHIP_OK;
 }
 

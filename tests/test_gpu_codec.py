@@ -111,6 +111,19 @@ def test_receive_chain_bytes_in_bytes_out(gpu, golden, sf, cr):
     out = dec.work([p[2] for p in pk])
     assert all(o is not None and np.array_equal(o, data) for o in out)
     assert dec.getDropped() == 0
+    # the same hand-off without per-packet host work: the queued packets in the decoder's layout on the device
+    d.activate(); d.work(iq)
+    ps, pn, pc = d.packets_device(clear=False)
+    assert ps.shape == (B, max(8, len(syms))) and sorted(pc.cpu().tolist()) == list(range(B))
+    host = d.packets()
+    assert all(np.array_equal(ps[i, :len(p[2])].cpu().numpy(), p[2]) and int(pn[i]) == len(p[2]) and int(pc[i]) == p[0] for i, p in enumerate(host))
+    o2, l2, dr2 = dec.decode_batch(ps, pn)
+    assert bool((l2 == len(data)).all()) and int(dr2.sum()) == 0
+    assert np.array_equal(o2[:, :len(data)].cpu().numpy(), np.tile(data.astype(np.uint8), (B, 1)))
+    # a row shorter than its packet is refused by the decoder, not read past
+    short = ps[:, :16].contiguous()
+    _, l3, _ = dec.decode_batch(short, pn)
+    assert bool((l3 == -2).all())
 
 
 def test_longest_packets_and_limits(gpu, oracle):
