@@ -283,6 +283,12 @@ int lorahip_channelizer_reset(lorahip_channelizer *c);
 size_t lorahip_channelizer_out_count(const lorahip_channelizer *c, size_t n_in);
 int lorahip_channelizer_run(lorahip_channelizer *c, const float *wide_dev, size_t n_in, float *out_dev,
                             size_t out_stride, size_t *n_out);
+/* A batch of independent captures in one launch (recordings, antennas): capture s is the n_in samples at wide_dev + s*capture_stride,
+ * processed like a fresh stream (from sample 0, zero history; bit-identical to reset() + run() on it); its channel k goes to
+ * out_dev + (s*n_channels + k)*out_stride, *n_out = n_in / decim samples each. The object's own stream state is not touched.
+ * n_captures <= 65535. */
+int lorahip_channelizer_run_captures(lorahip_channelizer *c, const float *wide_dev, size_t n_captures, size_t capture_stride,
+                                     size_t n_in, float *out_dev, size_t out_stride, size_t *n_out);
 
 /* Measurement aid: one read-only streaming pass over n_bytes of device memory (pattern 0: linear
  * 16 B per lane; 1: the access shape of the tuned SF7 kernel). Time it with lorahip_timer_*; the

@@ -84,6 +84,7 @@ SIGNATURES = {
     "lorahip_channelizer_reset": (C.c_int, [C.c_void_p]),
     "lorahip_channelizer_out_count": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "lorahip_channelizer_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "lorahip_channelizer_run_captures": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lorahip_demod_activate": (C.c_int, [C.c_void_p]),
     "lorahip_demod_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

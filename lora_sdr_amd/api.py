@@ -313,6 +313,24 @@ class Channelizer:
         return out[:, :got.value]
 
 
+    def run_captures(self, wide):
+        """wide: (S, n_in) complex64 device tensor of S independent captures -> (S, K, n_in // decim) tensor, one launch; every
+        capture is processed like a fresh stream, the object's own stream state is left alone"""
+        import torch
+        if wide.dim() != 2 or wide.dtype != torch.complex64:
+            raise ValueError("wide must be a (captures, samples) complex64 device tensor")
+        wide = wide.contiguous()
+        S, n_in = int(wide.shape[0]), int(wide.shape[1])
+        n_out = n_in // self.decim
+        out = torch.empty((S, self.n_channels, n_out), dtype=torch.complex64, device=wide.device)
+        self._ctx.use_torch_stream()
+        got = C.c_size_t()
+        check(self._lib.lorahip_channelizer_run_captures(self._h, C.c_void_p(wide.data_ptr()) if wide.numel() else None, S, n_in, n_in,
+                                                         C.c_void_p(out.data_ptr()) if out.numel() else None, n_out, C.byref(got)),
+              "lorahip_channelizer_run_captures")
+        return out
+
+
 class LoRaDetector:
     """`LoRaDetector<float>` (LoRaDetector.hpp:8-72): feed N samples, detect() -> arg-max bin."""
 

@@ -58,13 +58,14 @@ struct ChanArgs
     long long mLo;                  // absolute index of the first output of this call
     long long nOut;
     int K, L, D, QP, nGroups;
+    long long captureIn, captureOut;    // batch of independent captures (blockIdx.y): sample / output-row strides, 0 for a stream
 };
 
 //! sample n of the stream (absolute index): from this call's chunk, from the history kept from earlier calls, or 0
-__device__ __forceinline__ float2 streamSample(const ChanArgs &a, const long long n)
+__device__ __forceinline__ float2 streamSample(const ChanArgs &a, const float2 *chunk, const long long n)
 {
     const long long c = n - a.n0, h = c + a.histLen;
-    const float2 *src = c >= 0 ? a.chunk + c : a.hist + h;
+    const float2 *src = c >= 0 ? chunk + c : a.hist + h;
     const bool ok = c >= 0 ? c < a.nChunk : h >= 0;
     float2 v = make_float2(0.0f, 0.0f);
     if (ok) v = *src;
@@ -170,7 +171,7 @@ __device__ __forceinline__ void tileStageInside(float2 *xs, const float2 *chunkA
     }
 }
 //! any tile, fetch and store back to back: 8 loads in flight per lane and round
-__device__ __forceinline__ void tileStage(float2 *xs, const ChanArgs &a, const long long tileStart, const int D, const int QP, const int TI, const int t)
+__device__ __forceinline__ void tileStage(float2 *xs, const ChanArgs &a, const float2 *chunk, const long long tileStart, const int D, const int QP, const int TI, const int t)
 {
     const int dq = CHAN_THREADS / D, dp = CHAN_THREADS - dq * D;
     for (int tt = t; tt < TI; tt += 8 * CHAN_THREADS)
@@ -178,7 +179,7 @@ __device__ __forceinline__ void tileStage(float2 *xs, const ChanArgs &a, const l
         float2 v[8];
         int q = tt / D, p = tt - q * D;
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = tt + u * CHAN_THREADS < TI ? streamSample(a, tileStart + tt + u * CHAN_THREADS) : make_float2(0.0f, 0.0f);
+        for (int u = 0; u < 8; u++) v[u] = tt + u * CHAN_THREADS < TI ? streamSample(a, chunk, tileStart + tt + u * CHAN_THREADS) : make_float2(0.0f, 0.0f);
 #pragma unroll
         for (int u = 0; u < 8; u++)
         {
@@ -205,9 +206,10 @@ __global__ __launch_bounds__(CHAN_THREADS) void channelize(const ChanArgs a)
     const long long mTile = (a.mLo / TM + (long long)(blockIdx.x / unsigned(a.nGroups))) * TM;
     const long long tileStart = (mTile + 1) * D - L;            // oldest sample of the tile's first output
     {
+        const float2 *chunk = a.chunk + (size_t)blockIdx.y * a.captureIn;       // this capture's samples (blockIdx.y = 0 for a stream)
         const long long rel = tileStart - a.n0;
-        if (rel >= 0 && rel + TI <= a.nChunk) tileStageInside(xs, a.chunk + rel, D, QP, TI, t);
-        else tileStage(xs, a, tileStart, D, QP, TI, t);
+        if (rel >= 0 && rel + TI <= a.nChunk) tileStageInside(xs, chunk + rel, D, QP, TI, t);
+        else tileStage(xs, a, chunk, tileStart, D, QP, TI, t);
     }
     __syncthreads();
 
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(CHAN_THREADS) void channelize(const ChanArgs a)
         const int ch = chBase + k;                              // w, step, laneRot are padded to whole groups
         const v2f base = {__int_as_float(__builtin_amdgcn_readlane(mineRe, k)), __int_as_float(__builtin_amdgcn_readlane(mineIm, k))};
         v2f rot = cmulF(a.laneRot[ch * CHAN_THREADS + t], base);
-        char *o = reinterpret_cast<char *>(a.out + (size_t)ch * a.outStride);       // uniform; + 32-bit byte offset per lane
+        char *o = reinterpret_cast<char *>(a.out + (size_t)blockIdx.y * a.captureOut + (size_t)ch * a.outStride);     // uniform; + 32-bit byte offset per lane
 #pragma unroll
         for (int r = 0; r < RM; r++)
         {
@@ -282,17 +284,21 @@ __global__ __launch_bounds__(CHAN_THREADS) void channelize(const ChanArgs a)
 __global__ void chanHistory(const ChanArgs a, float2 *newHist)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.histLen) newHist[i] = streamSample(a, a.n0 + a.nChunk - a.histLen + i);
+    if (i < a.histLen) newHist[i] = streamSample(a, a.chunk, a.n0 + a.nChunk - a.histLen + i);
 }
 
 static unsigned long long gLdsMask[2] = {0, 0};
 
-static int chanRun(lorahip_channelizer *c, const float2 *wide, const size_t nIn, float2 *out, const size_t outStride, size_t *nOutP)
+//! captures == 0: the next nIn samples of THE stream (history and phase carried). captures > 0: that many independent captures of nIn
+//! samples each, every one from sample 0 with zero history; the stream state is not touched.
+static int chanRun(lorahip_channelizer *c, const float2 *wide, const size_t nIn, float2 *out, const size_t outStride, size_t *nOutP,
+                   const size_t captures = 0, const size_t captureStride = 0)
 {
     lorahip_ctx *ctx = c->ctx;
     const DeviceGuard guard(ctx->device);
     const unsigned long long D = (unsigned long long)c->D;
-    const unsigned long long mLo = c->n0 / D, mHi = (c->n0 + nIn) / D;
+    const unsigned long long n0 = captures ? 0 : c->n0;
+    const unsigned long long mLo = n0 / D, mHi = (n0 + nIn) / D;
     const size_t nOut = size_t(mHi - mLo);
     if (nOutP) *nOutP = nOut;
     if (nIn == 0) return LORAHIP_OK;
@@ -300,8 +306,9 @@ static int chanRun(lorahip_channelizer *c, const float2 *wide, const size_t nIn,
     if (nOut > (size_t(1) << 30)) { setLastError("channeliser: more than 2^30 outputs per channel in one call"); return LORAHIP_E_INVALID; }
     ChanArgs a;
     a.chunk = wide; a.nChunk = (long long)nIn;
-    a.hist = c->dHist[c->cur]; a.histLen = c->HC;
-    a.n0 = (long long)c->n0;
+    a.hist = c->dHist[c->cur]; a.histLen = captures ? 0 : c->HC;        // no history: samples before the capture read as 0
+    a.n0 = (long long)n0;
+    a.captureIn = (long long)captureStride; a.captureOut = (long long)(size_t(c->K) * outStride);
     a.taps = reinterpret_cast<const v2f *>(c->dTaps);
     a.w = c->dW;
     a.step = reinterpret_cast<const v2f *>(c->dRot);
@@ -315,7 +322,7 @@ static int chanRun(lorahip_channelizer *c, const float2 *wide, const size_t nIn,
         const int TM = CHAN_THREADS * c->RM;
         const size_t nBlocks = size_t(c->nGroups) * ((mLo % TM + nOut + TM - 1) / TM);
         if (nBlocks > 0x7fffffffu) { setLastError("channeliser: channels x outputs of one call exceed the launch grid"); return LORAHIP_E_INVALID; }
-        const dim3 grid((unsigned)nBlocks);
+        const dim3 grid((unsigned)nBlocks, (unsigned)(captures ? captures : 1));
         if (c->RM == 2)
         {
             LORAHIP_TRY(ensureDynamicLds(reinterpret_cast<const void *>(&channelize<2>), c->ldsBytes, gLdsMask[1]));
@@ -328,6 +335,7 @@ static int chanRun(lorahip_channelizer *c, const float2 *wide, const size_t nIn,
         }
         LORAHIP_TRY(hipGetLastError());
     }
+    if (captures) return LORAHIP_OK;
     hipLaunchKernelGGL(chanHistory, dim3((c->HC + 255) / 256), dim3(256), 0, ctx->stream, a, c->dHist[c->cur ^ 1]);
     LORAHIP_TRY(hipGetLastError());
     c->cur ^= 1;
@@ -459,6 +467,15 @@ int lorahip_channelizer_run(lorahip_channelizer *c, const float *wide_dev, const
 {
     if (c == nullptr || (n_in && wide_dev == nullptr)) return LORAHIP_E_INVALID;
     return chanRun(c, reinterpret_cast<const float2 *>(wide_dev), n_in, reinterpret_cast<float2 *>(out_dev), out_stride, n_out);
+}
+
+int lorahip_channelizer_run_captures(lorahip_channelizer *c, const float *wide_dev, const size_t n_captures, const size_t capture_stride,
+                                     const size_t n_in, float *out_dev, const size_t out_stride, size_t *n_out)
+{
+    if (c == nullptr || n_captures > 65535u || (n_captures && n_in && (wide_dev == nullptr || capture_stride < n_in))) return LORAHIP_E_INVALID;
+    if (n_out) *n_out = n_in / size_t(c->D);
+    if (n_captures == 0 || n_in == 0) return LORAHIP_OK;
+    return chanRun(c, reinterpret_cast<const float2 *>(wide_dev), n_in, reinterpret_cast<float2 *>(out_dev), out_stride, n_out, n_captures, capture_stride);
 }
 
 } // extern "C"

@@ -102,6 +102,30 @@ def test_chunked_stream_is_bit_identical(gpu):
     assert np.array_equal(glued.view(np.uint32), whole.view(np.uint32))
 
 
+def test_batch_of_captures_equals_fresh_streams(gpu):
+    import torch
+    import lora_sdr_amd as Lh
+    from oracle import channelizer as oc
+    rng = np.random.default_rng(9)
+    K, D, L, S, n = 10, 8, 64, 5, 7001
+    x = torch.from_numpy(np.stack([_stream(rng, n) for _ in range(S)])).cuda()
+    freqs = rng.uniform(-0.5, 0.5, K)
+    h = oc.design_lowpass(D, L)
+    with Lh.Context(7) as ctx:
+        ch = Lh.Channelizer(ctx, freqs, D, h)
+        ch.run(x[0, :1234])                                  # leave the stream in some state: run_captures must not care
+        batch = ch.run_captures(x).cpu().numpy()
+        assert ch.out_count(D) == (1234 + D) // D - 1234 // D  # ... nor change it
+        singles = []
+        for s_ in range(S):
+            ch.reset()
+            singles.append(ch.run(x[s_]).cpu().numpy())
+        ch.close()
+    assert batch.shape == (S, K, n // D)
+    for s_ in range(S):
+        assert np.array_equal(batch[s_].view(np.uint32), singles[s_].view(np.uint32))
+
+
 def test_argument_checks(gpu):
     import lora_sdr_amd as Lh
     h = np.ones(8, np.float32)
