@@ -115,6 +115,26 @@ def test_many_channels_lockstep(gpu, oracle, sf, mode):
     assert len(d.trace(7)) == 0
 
 
+def test_sf6_runs_on_host_rounds(gpu, oracle):
+    """SF6 has no streaming kernel: mode 0 (auto) falls back to host-driven rounds, mode 1 is refused -- and the rounds follow the oracle"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(66)
+    sf, N = 6, 64
+    streams = [frames(oracle, rng, sf, 2, 9 + c, off=rng.uniform(-0.4, 0.4), noise=0.02, lead=int(rng.integers(0, 2 * N)))[0] for c in range(5)]
+    d = L.LoRaDemod(sf, n_channels=5); d.setMTU(64); d.set_trace(True)
+    d.work(streams)
+    pk = d.packets()
+    for c in range(5):
+        r = oracle.demod_run(sf, streams[c], mtu=64)
+        compare_channel(d.trace(c), r["calls"])
+        mine = [p[2] for p in pk if p[0] == c]
+        assert len(mine) == len(r["packets"]) and all(np.array_equal(a, b) for a, (_, b) in zip(mine, r["packets"]))
+    d.set_mode(1)
+    with pytest.raises(L.LoraHipError):
+        d.work(streams)
+    d.close()
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_device_resident_streams(gpu, oracle, mode):
     """lorahip_demod_run_device: the streams are already one (B, samples) tensor in HBM"""
