@@ -21,7 +21,7 @@
  *   3. lorahip_demod_*   B channels of the `LoRaDemod` block (LoRaDemod.cpp:68-143 setters,
  *      :145-327 work()): same parameters (sf, sync, thresh, mtu), same 5-state frame
  *      machine, same int16 symbol packets; driven by a streaming kernel that walks every
- *      channel's stream on the device (SF7-10), or in lock-step from the host with one batch
+ *      channel's stream on the device (SF6-12), or in lock-step from the host with one batch
  *      launch per work() round (lorahip_demod_set_mode).
  *
  * Results: symbol indices and FFT bins are bit-identical to the reference CPU path

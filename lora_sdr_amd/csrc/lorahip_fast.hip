@@ -294,6 +294,7 @@ static hipError_t launchCfg(const DetectArgs &a, const FastTables &ft, hipStream
  **********************************************************************/
 template <int SF> struct Geo;
 //                                         LOG2T VEC NPH PB1 PB2   X0: ROT PAD S  D
+template <> struct Geo<6>  { enum { LOG2T = 2, VEC = 4, NPH = 2, PB1 = 2, PB2 = 6, ROT = 2, PAD = 1, S = 0, D = 0 }; };   //  4 lanes x 16 pts: [4] X [4,4]
 template <> struct Geo<7>  { enum { LOG2T = 3, VEC = 2, NPH = 2, PB1 = 3, PB2 = 7, ROT = 1, PAD = 1, S = 0, D = 0 }; };   //  8 lanes x 16 pts: [R2,4] X [4,4]
 template <> struct Geo<8>  { enum { LOG2T = 4, VEC = 1, NPH = 2, PB1 = 4, PB2 = 8, ROT = 0, PAD = 1, S = 0, D = 0 }; };   // 16 lanes x 16 pts: [4,4] X [4,4]
 template <> struct Geo<9>  { enum { LOG2T = 5, VEC = 2, NPH = 3, PB1 = 3, PB2 = 7, ROT = 2, PAD = 1, S = 1, D = 8 }; };   // 32 lanes x 16 pts: [R2,4] X [4,4] X [4]
@@ -316,7 +317,7 @@ using Fast = FastCfg<SF, Geo<SF>::LOG2T, Geo<SF>::VEC, Geo<SF>::NPH, Geo<SF>::PB
                      Geo<SF>::ROT, Geo<SF>::PAD, Geo<SF>::S, Geo<SF>::D, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
                      (O & NT) != 0, (O & NB_SEL) != 0, (O & X1_SWAP) != 0, (O & TWM_REG) != 0, (O & XCD) != 0>;
 
-bool fastAvailable(const int sf) { return sf >= 7 && sf <= 10; }
+bool fastAvailable(const int sf) { return sf >= 6 && sf <= 10; }
 
 //! host-side check of a configuration's exchange-0 layout: every (row, window, element) has its own word inside the
 //! wave's region
@@ -337,7 +338,7 @@ static bool layoutOk()
 
 bool fastLayoutsOk()
 {
-    return layoutOk<Fast<7, 0>>() && layoutOk<Fast<8, 0>>() && layoutOk<Fast<9, 0>>() && layoutOk<Fast<10, 0>>();
+    return layoutOk<Fast<6, 0>>() && layoutOk<Fast<7, 0>>() && layoutOk<Fast<8, 0>>() && layoutOk<Fast<9, 0>>() && layoutOk<Fast<10, 0>>();
 }
 
 /***********************************************************************
@@ -348,6 +349,9 @@ typedef hipError_t (*FastLaunch)(const DetectArgs &, const FastTables &, hipStre
 struct FastVariant { int sf, variant; FastLaunch launch; };
 #define V(SF, N, OPTS) { SF, N, &launchCfg<Fast<SF, (OPTS)>> }
 static const FastVariant kFastVariants[] = {
+    // SF6
+    V(6, 0, 0),                                            // default: 16 windows per wave keep the LDS copies of chirp / twiddles cheap
+    V(6, 7, TW_REG), V(6, 8, NT), V(6, 10, 0), V(6, 11, CH_REG | NT), V(6, 12, CH_REG | TW_REG | NT), V(6, 15, CH_REG | TW_REG | NT | PF_NONE),
     // SF7
     V(7, 0, CH_REG | NT),                                  // default
     V(7, 2, PF_NONE), V(7, 3, W2), V(7, 4, W4 | PF_NONE), V(7, 5, W2 | CH_REG | TW_REG), V(7, 6, PF_EARLY), V(7, 7, TW_REG),

@@ -135,11 +135,15 @@ struct FastCore
         for (int r = 0; r < R; r++)
         {
             const v2f *p = in_ + VEC * t + VEC * T * r;
-            if (VEC == 2)
+            if (VEC >= 2)
             {
-                const v4f q = C::NT ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)) : *reinterpret_cast<const v4f *>(p);
-                xn[r][0] = MAKE2(q.x, q.y);
-                xn[r][VEC - 1] = MAKE2(q.z, q.w);
+#pragma unroll
+                for (int h = 0; h < VEC / 2; h++)                  // 16 bytes = two samples per load instruction
+                {
+                    const v4f q = C::NT ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p) + h) : reinterpret_cast<const v4f *>(p)[h];
+                    xn[r][(2 * h) % VEC] = MAKE2(q.x, q.y);
+                    xn[r][(2 * h + 1) % VEC] = MAKE2(q.z, q.w);
+                }
             }
             else xn[r][0] = C::NT ? __builtin_nontemporal_load(p) : *p;
         }
@@ -152,11 +156,15 @@ struct FastCore
         for (int r = 0; r < R; r++)
         {
             const v2f *p = sCh + VEC * t + VEC * T * r;
-            if (VEC == 2)
+            if (VEC >= 2)
             {
-                const v4f q = *reinterpret_cast<const v4f *>(p);
-                cw[r][0] = MAKE2(q.x, q.y);
-                cw[r][VEC - 1] = MAKE2(q.z, q.w);
+#pragma unroll
+                for (int h = 0; h < VEC / 2; h++)
+                {
+                    const v4f q = reinterpret_cast<const v4f *>(p)[h];
+                    cw[r][(2 * h) % VEC] = MAKE2(q.x, q.y);
+                    cw[r][(2 * h + 1) % VEC] = MAKE2(q.z, q.w);
+                }
             }
             else cw[r][0] = *p;
         }

@@ -168,6 +168,7 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
 }
 
 //             LOG2N T VEC NPH PB1 PB2 w/SIMD  X0: ROT PAD S  D   chLDS twLDS prefetch
+typedef FastCfg<6,  2, 4,  2,  2,  6,  3,          2,  1,  0, 0,  true,  true,  0> Stream6;
 typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  0> Stream7;
 typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  0> Stream8;
 typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  true,  true,  0> Stream9;
@@ -197,12 +198,13 @@ hipError_t launchCompactRows(void *dst, const void *src, const size_t rows, cons
     return hipGetLastError();
 }
 
-bool streamAvailable(const int sf) { return sf >= 7 && sf <= 12; }
+bool streamAvailable(const int sf) { return sf >= 6 && sf <= 12; }
 
 hipError_t launchStream(const int sf, const StreamArgs &s, hipStream_t stream)
 {
     switch (sf)
     {
+    case 6: return launchStreamCfg<Stream6>(s, stream);
     case 7: return launchStreamCfg<Stream7>(s, stream);
     case 8: return launchStreamCfg<Stream8>(s, stream);
     case 9: return launchStreamCfg<Stream9>(s, stream);

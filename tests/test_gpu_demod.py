@@ -76,7 +76,7 @@ def test_golden_stream_through_demod(gpu, golden, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("sf", [6, 7, 8, 9, 10, 11, 12])
 def test_many_channels_lockstep(gpu, oracle, sf, mode):
     """channels with different lengths, frequency offsets, sync alignment and noise, one of them pure
     noise and one too short to work at all: every channel must follow its own oracle block"""
@@ -115,23 +115,21 @@ def test_many_channels_lockstep(gpu, oracle, sf, mode):
     assert len(d.trace(7)) == 0
 
 
-def test_sf6_runs_on_host_rounds(gpu, oracle):
-    """SF6 has no streaming kernel: mode 0 (auto) falls back to host-driven rounds, mode 1 is refused -- and the rounds follow the oracle"""
+@pytest.mark.parametrize("mode", [0] + MODES)
+def test_sf6_demodulator(gpu, oracle, mode):
+    """SF6 (64-point windows, 4 lanes each): the streaming kernel, host-driven rounds and the automatic choice all follow the oracle"""
     import lora_sdr_amd as L
     rng = np.random.default_rng(66)
     sf, N = 6, 64
-    streams = [frames(oracle, rng, sf, 2, 9 + c, off=rng.uniform(-0.4, 0.4), noise=0.02, lead=int(rng.integers(0, 2 * N)))[0] for c in range(5)]
-    d = L.LoRaDemod(sf, n_channels=5); d.setMTU(64); d.set_trace(True)
+    streams = [frames(oracle, rng, sf, 2, 9 + c, off=rng.uniform(-0.4, 0.4), noise=0.02, lead=int(rng.integers(0, 2 * N)))[0] for c in range(21)]
+    d = L.LoRaDemod(sf, n_channels=21); d.set_mode(mode); d.setMTU(64); d.set_trace(True)
     d.work(streams)
     pk = d.packets()
-    for c in range(5):
+    for c in range(21):
         r = oracle.demod_run(sf, streams[c], mtu=64)
         compare_channel(d.trace(c), r["calls"])
         mine = [p[2] for p in pk if p[0] == c]
         assert len(mine) == len(r["packets"]) and all(np.array_equal(a, b) for a, (_, b) in zip(mine, r["packets"]))
-    d.set_mode(1)
-    with pytest.raises(L.LoraHipError):
-        d.work(streams)
     d.close()
 
 
