@@ -324,3 +324,31 @@ def test_per_window_settings_at_scale(gpu, oracle, sf):
     o = oracle.detect_batch(sf, iq, chirp_sel=sel, fine_idx0=idx0, fine_err=err, nthreads=8)
     assert np.array_equal(to_np(g["fineIdxOut"]), o["fineIdxOut"]), "index recurrence end state"
     check(o, g, fft=False, where="per-window at scale sf%d" % sf)
+
+
+@pytest.mark.parametrize("sf", [7, 12])
+def test_batches_beyond_2_pow_31_samples(gpu, oracle, sf):
+    """one launch over 2.5 G samples (20 GB of IQ, what 288 GB of HBM invites): sample offsets no longer fit 32 bits. Every window
+    must still decode to the symbol that was synthesised into it, and the windows past the 2^31-sample line equal the CPU oracle."""
+    import lora_sdr_amd as L
+    torch = gpu
+    N = 1 << sf
+    W = (5 << 29) // N                                            # 2.5 * 2^30 samples
+    free, _ = torch.cuda.mem_get_info()
+    if free < 26 * (1 << 30):
+        pytest.skip("needs 26 GB of free HBM")
+    ctx = L.Context(sf)
+    g = torch.Generator(device="cuda"); g.manual_seed(31 + sf)
+    sym = torch.randint(0, N, (W,), generator=g, device="cuda", dtype=torch.int32).to(torch.int16)
+    iq = ctx.synth_symbols(sym, ampl=1.0, noise_sigma=0.3, seed=9)
+    r = ctx.detect_batch(iq)
+    torch.cuda.synchronize()
+    got = r["sym"].view(torch.int16).to(torch.int64) & 0xffff
+    assert bool((((got - (sym.to(torch.int64) & 0xffff)) % N) == 1).all())          # genChirp symbol s -> bin s+1
+    first = ((1 << 31) // N) - 8                                   # 16 windows straddling sample 2^31, and the last 16
+    for lo in (first, W - 16):
+        o = oracle.detect_batch(sf, iq[lo * N:(lo + 16) * N].cpu().numpy(), nthreads=4)
+        assert np.array_equal(o["sym"], r["sym"][lo:lo + 16].cpu().numpy().view(np.uint16))
+        assert np.abs(o["power"] - r["power"][lo:lo + 16].cpu().numpy()).max() <= TOL_DB
+    del iq, r
+    torch.cuda.empty_cache()
