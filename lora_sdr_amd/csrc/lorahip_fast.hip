@@ -323,6 +323,11 @@ template <unsigned O>
 using Fast9b = FastCfg<9, 4, 1, 2, 5, 9, (O & W2) ? 2 : (O & W4) ? 4 : 3, 0, 1, 0, 0, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
                        (O & NT) != 0, (O & NB_SEL) != 0, false, false, false>;
 
+// SF11 inside one wavefront: 64 lanes x 32 points, phases [R2,4,4] X [4] X [4,4], both exchanges wave-local (no workgroup barrier)
+template <unsigned O>
+using Fast11q = FastCfg<11, 6, 1, 3, 5, 7, (O & W2) ? 2 : (O & W4) ? 4 : 3, 0, 1, 0, 0, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
+                        (O & NT) != 0, (O & NB_SEL) != 0, false, (O & TWM_REG) != 0, false>;
+
 bool fastAvailable(const int sf) { return sf >= 6 && sf <= 10; }
 
 //! host-side check of a configuration's exchange-0 layout: every (row, window, element) has its own word inside the
@@ -344,7 +349,7 @@ static bool layoutOk()
 
 bool fastLayoutsOk()
 {
-    return layoutOk<Fast<6, 0>>() && layoutOk<Fast<7, 0>>() && layoutOk<Fast<8, 0>>() && layoutOk<Fast<9, 0>>() && layoutOk<Fast9b<0>>() && layoutOk<Fast<10, 0>>();
+    return layoutOk<Fast<6, 0>>() && layoutOk<Fast<7, 0>>() && layoutOk<Fast<8, 0>>() && layoutOk<Fast<9, 0>>() && layoutOk<Fast9b<0>>() && layoutOk<Fast11q<0>>() && layoutOk<Fast<10, 0>>();
 }
 
 /***********************************************************************
@@ -382,6 +387,10 @@ static const FastVariant kFastVariants[] = {
     V(9, 16, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG),
     { 9, 20, &launchCfg<Fast9b<W2 | CH_REG | TW_REG | NT>> }, { 9, 21, &launchCfg<Fast9b<W2 | NT>> }, { 9, 22, &launchCfg<Fast9b<W2 | TW_REG | NT>> },
     { 9, 23, &launchCfg<Fast9b<W2 | CH_REG | NT>> }, { 9, 24, &launchCfg<Fast9b<W2 | CH_REG | TW_REG | NT | PF_NONE>> },
+    // SF11 per wavefront (the default SF11 kernel is lorahip_wide.hip's)
+    { 11, 20, &launchCfg<Fast11q<W2 | NT | PF_NONE>> }, { 11, 21, &launchCfg<Fast11q<W2 | TW_REG | NT | PF_NONE>> },
+    { 11, 22, &launchCfg<Fast11q<W2 | CH_REG | TW_REG | NT | PF_NONE>> }, { 11, 23, &launchCfg<Fast11q<W2 | NT>> },
+    { 11, 24, &launchCfg<Fast11q<W2 | TW_REG | TWM_REG | NT | PF_NONE>> },
     // SF10
     V(10, 0, CH_REG | TW_REG | NT | X1_SWAP),              // default
     V(10, 6, PF_EARLY), V(10, 7, TW_REG), V(10, 8, NT), V(10, 9, TW_REG | NT), V(10, 10, 0), V(10, 11, CH_REG | TW_REG | NT),

@@ -182,6 +182,7 @@ static hipError_t launchGeneric(const DetectArgs &a, hipStream_t stream)
 hipError_t launchDetect(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
     if (variant != 1 && fastAvailable(sf)) return launchFast(sf, variant, a, ft, stream);
+    if (sf == 11 && variant >= 20 && variant <= 24) return launchFast(sf, variant, a, ft, stream);          // window-per-wavefront SF11 (variants 20+)
     if (variant != 1 && wideAvailable(sf)) return launchWide(sf, variant, a, ft, stream);
     switch (sf)
     {
