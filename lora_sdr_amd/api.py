@@ -441,8 +441,8 @@ class LoRaDemod:
         syms = np.empty(ns, np.int16)
         check(self._lib.lorahip_demod_get_packets(self._h, ch.ctypes.data, rd.ctypes.data, ln.ctypes.data, n, syms.ctypes.data, ns),
               "lorahip_demod_get_packets")
-        ends = np.cumsum(ln)
-        out = [(int(ch[i]), int(rd[i]), syms[ends[i] - ln[i]:ends[i]].copy()) for i in range(n)]
+        parts = np.split(syms, np.cumsum(ln)[:-1]) if n else []       # views into one array: no per-packet copy
+        out = list(zip(ch.tolist(), rd.tolist(), parts))
         if clear:
             self._lib.lorahip_demod_clear_packets(self._h)
         return out
