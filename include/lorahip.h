@@ -24,6 +24,10 @@
  *      channel's stream on the device (SF6-12), or in lock-step from the host with one batch
  *      launch per work() round (lorahip_demod_set_mode).
  *
+ * Around the path (each behind its own entry points further down): the batched modulator + AWGN channel
+ * (lorahip_mod_frames, lorahip_add_awgn), the batched decoder (lorahip_decode_packets) with the packet hand-off
+ * lorahip_demod_packets_to_device, and the front-end channeliser (lorahip_channelizer_*).
+ *
  * Results: symbol indices and FFT bins are bit-identical to the reference CPU path
  * compiled without FMA contraction (the kernels evaluate kissfft's radix-4/2 DIT graph
  * with kissfft's own float twiddles, op for op); power / powerAvg / fIndex agree to
