@@ -310,7 +310,8 @@ enum : unsigned
     NB_SEL = 1u << 7,                    // peak's neighbours by register select (default: bins staged in LDS)
     X1_SWAP = 1u << 8,                   // exchange 1 by row swaps / DPP (SF9, SF10)
     TWM_REG = 1u << 9,                   // middle-phase twiddles in registers
-    XCD = 1u << 10                       // XCD-contiguous walk over the batch
+    XCD = 1u << 10,                      // XCD-contiguous walk over the batch
+    W1 = 1u << 11                        // one wave per SIMD: the 512-register budget (what does not fit 256 lands in AGPRs, not scratch)
 };
 template <int SF, unsigned O>
 using Fast = FastCfg<SF, Geo<SF>::LOG2T, Geo<SF>::VEC, Geo<SF>::NPH, Geo<SF>::PB1, Geo<SF>::PB2, (O & W2) ? 2 : (O & W4) ? 4 : 3,
@@ -325,7 +326,7 @@ using Fast9b = FastCfg<9, 4, 1, 2, 5, 9, (O & W2) ? 2 : (O & W4) ? 4 : 3, 0, 1, 
 
 // SF11 inside one wavefront: 64 lanes x 32 points, phases [R2,4,4] X [4] X [4,4], both exchanges wave-local (no workgroup barrier)
 template <unsigned O>
-using Fast11q = FastCfg<11, 6, 1, 3, 5, 7, (O & W2) ? 2 : (O & W4) ? 4 : 3, 0, 1, 0, 0, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
+using Fast11q = FastCfg<11, 6, 1, 3, 5, 7, (O & W1) ? 1 : (O & W2) ? 2 : (O & W4) ? 4 : 3, 0, 1, 0, 0, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
                         (O & NT) != 0, (O & NB_SEL) != 0, false, (O & TWM_REG) != 0, false>;
 
 bool fastAvailable(const int sf) { return sf >= 6 && sf <= 10; }
