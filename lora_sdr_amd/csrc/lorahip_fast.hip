@@ -359,12 +359,15 @@ bool fastLayoutsOk()
  **********************************************************************/
 typedef hipError_t (*FastLaunch)(const DetectArgs &, const FastTables &, hipStream_t);
 
-//! SF9 default: the two-phase geometry for launch-uniform batches without debug ports, the three-phase one otherwise
+//! SF9 default: the two-phase geometry, with the option set that measured best for the shape of the call
 static hipError_t launchSf9Default(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
-    const bool uni = a.chirpSel == nullptr && a.fineErr == nullptr && !a.decOut && !a.fftOut;
-    return uni ? launchCfg<Fast9b<W2 | CH_REG | TW_REG | NT | PF_NONE>>(a, ft, stream) : launchCfg<Fast<9, CH_REG | TW_REG | NT | X1_SWAP>>(a, ft, stream);
+    if (a.decOut || a.fftOut) return launchCfg<Fast<9, CH_REG | TW_REG | NT | X1_SWAP>>(a, ft, stream);        // debug ports: three-phase kernel
+    const bool uni = a.chirpSel == nullptr && a.fineErr == nullptr;
+    // per-window settings need registers for the index chain: last-phase twiddles from the LDS table there (+4 % over the three-phase kernel)
+    return uni ? launchCfg<Fast9b<W2 | CH_REG | TW_REG | NT | PF_NONE>>(a, ft, stream) : launchCfg<Fast9b<W2 | CH_REG | NT>>(a, ft, stream);
 }
+
 struct FastVariant { int sf, variant; FastLaunch launch; };
 #define V(SF, N, OPTS) { SF, N, &launchCfg<Fast<SF, (OPTS)>> }
 static const FastVariant kFastVariants[] = {
