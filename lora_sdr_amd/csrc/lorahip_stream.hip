@@ -172,7 +172,7 @@ typedef FastCfg<6,  2, 4,  2,  2,  6,  3,          2,  1,  0, 0,  true,  true,  
 typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  0> Stream7;
 typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  0> Stream8;
 typedef FastCfg<9,  4, 1,  2,  5,  9,  2,          0,  1,  0, 0,  true,  true,  0> Stream9;    // 16 lanes x 32 points, two phases (+7 % over 32 x 16, three phases)
-typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  true,  true,  0> Stream10;
+typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  true,  true,  0, false, false, true> Stream10;   // exchange 1 as register row swaps
 
 //! the used columns of a [rows][capacity] record array packed densely (2-byte units): what goes back to the host is what a
 //! run filled, not the worst-case capacity
