@@ -1,24 +1,28 @@
 #!/usr/bin/env python
-"""Benchmark of the MI355X LoRa demod hot path: Msymbols/s demodulated (dechirp + FFT + argmax).
+"""Benchmark of the MI355X LoRa demod hot path: Msymbols/s demodulated (dechirp + FFT + argmax), per SF.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sf 7 --channels 4096 --symbols 256]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (one lorahip_detect_batch launch) over one batch of
-synthetic IQ already resident in HBM: `channels` channels x `symbols` symbol windows of 2^SF
-cf32 samples. Default workload = BASELINE.json configs[1]: 4096 channels SF7 (N=128 FFT),
-256 windows per channel = 1 GiB of IQ per step. With N > 1 every rank demodulates its own
-`channels` channels (independent units, no data-path collective): weak scaling; the value is
-the whole-job aggregate.
+A "step" is one pass of the hot path (one lorahip_detect_batch launch) over one batch of synthetic IQ already resident
+in HBM: `channels` channels x `symbols` symbol windows of 2^SF cf32 samples. The headline workload (value / config /
+roofline) is BASELINE.json configs[1]: 4096 channels SF7 (N=128 FFT) x 256 windows per channel = 1 GiB of IQ per step.
+With N > 1 every rank demodulates its own channels (independent units, no data-path collective): weak scaling; every
+value is the whole-job aggregate.
 
 Rank 0 prints ONE JSON line. Besides the contract fields it carries
-  roofline      HBM roofline of the detect kernel: algorithmic bytes/launch (8*2^SF+14 per
-                window) / average launch duration measured with HIP events
-                recorded on the launch stream inside the C ABI (lorahip_timer_start/stop)
-  cpu_baseline  the reference CPU path (oracle/_ref: the real LoRaDemod.cpp + kissfft, or the
-                oracle's C port where that is absent) timed on this box's host cores on a
-                bounded sample of the same IQ
+  roofline      HBM roofline of the detect kernel: algorithmic bytes/launch (8*2^SF+14 per window) /
+                average launch duration measured with HIP events on the launch stream inside the C ABI
+  cpu_baseline  the reference CPU path (oracle/_ref: the real LoRaDemod.cpp + kissfft compiled in place) timed on this
+                box's host cores on a bounded sample of the same IQ, at the three flag sets BASELINE.md names
+  per_sf        the metric is "per SF": the same measurement at SF7..12 (SF12 = BASELINE configs[2], 1024 channels), each
+                with its roofline fraction, a CPU baseline, and ALL windows of the batch compared with the CPU oracle
+  moving        the locked-receiver batch shape (every window its own fine-tune error and start index, LoRaDemod.cpp:160-162)
+  level3        whole LoRaDemod blocks (frame sync, frequency estimate, packets) through the streaming kernel, end to end
+  config5       BASELINE configs[4]: SF10, 8192 channels x 64 windows at -10 dB SNR, symbol error rate GPU and CPU
+  mixed         BASELINE configs[3]: 16384 channels, SF = 7 + c mod 6, byte-weighted shards, symbols gathered over RCCL
+Single-shape runs for profiling: --sf S [--moving] [--alias-windows] [--fine-gather]; --config mixed runs configs[3] alone.
 """
 import argparse
 import json
@@ -31,208 +35,560 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "Msymbols/sec demodulated (dechirp+FFT+argmax)"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ramp-seconds", type=float, default=0.3,
                     help="untimed launches before the warm-up steps until the GPU has left its idle clocks "
                          "(a cold MI355X needs ~40 ms of load to ramp: tools/ramp.py, profiles/r01/s4_clock_ramp.txt)")
-    ap.add_argument("--sf", type=int, default=7)
+    ap.add_argument("--sf", type=int, default=None, help="single-shape run at this SF (no sweep); default: SF7 headline + SF7..12 sweep")
     ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default: 1 GiB of IQ per step)")
     ap.add_argument("--symbols", type=int, default=None, help="symbol windows per channel per step")
     ap.add_argument("--noise-sigma", type=float, default=0.5, help="AWGN per I/Q component (signal amplitude 1)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--no-sweep", action="store_true", help="headline line only (no per_sf / moving / level3 / config5 / mixed)")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
+    ap.add_argument("--config", choices=["default", "mixed"], default="default",
+                    help="mixed: BASELINE configs[3] alone (16384 channels, SF = 7 + c mod 6, sharded over the ranks)")
     ap.add_argument("--moving", action="store_true",
-                    help="diagnostic: per-window fine-tune error and start index (the DATASYMBOLS shape of a locked receiver: "
-                         "LoRaDemod.cpp:160-162 moves the index every sample) instead of the launch-uniform steady state")
+                    help="single-shape diagnostic: per-window fine-tune error and start index (the DATASYMBOLS shape of a locked "
+                         "receiver) instead of the launch-uniform steady state")
     ap.add_argument("--alias-windows", action="store_true",
-                    help="diagnostic: every window reads window 0 (no HBM traffic): the compute-only time of the kernel")
+                    help="single-shape diagnostic: every window reads window 0 (no HBM traffic): the compute-only time")
+    ap.add_argument("--fine-gather", action="store_true",
+                    help="A/B: read the fine-tune table in HBM (round-1 path) instead of the split tables (lorahip_set_fine_gather)")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
 
 
-def default_geometry(sf):
-    # BASELINE.json configs: 4096 channels SF7, 1024 channels SF12; in between keep 1 GiB per step
-    channels = {7: 4096, 8: 4096, 9: 2048, 10: 2048, 11: 1024, 12: 1024}.get(sf, 4096)
-    symbols = (1 << 30) // (channels * (8 << sf))
-    return channels, max(symbols, 1)
+def r4(x):
+    """4 significant digits: keeps the one JSON line short"""
+    return float("%.4g" % x)
 
 
-def cpu_baseline(sf, iq_host, samples_per_stream, n_streams, seconds):
-    """Time the reference CPU path on a bounded sample of the same IQ. Returns the JSON object."""
+class Env:
+    """torch / distributed plumbing shared by the sections"""
+
+    def __init__(self, a):
+        import torch
+        self.torch = torch
+        self.a = a
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != a.gpus and self.world > 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, self.world))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        # test hooks (tools/gpu_r02.sh "multi"): several ranks on ONE GPU over gloo exercise the N > 1 code path where only a
+        # single device exists; a real multi-GPU run uses neither
+        self.backend = os.environ.get("LORA_BENCH_BACKEND", "nccl")
+        if os.environ.get("LORA_BENCH_ONE_DEVICE"):
+            local = 0
+        self.local = local
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        self.dist = None
+        self.rccl_ranks = None
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+            # prove the collective backend is up on device tensors before anything is timed
+            t = torch.ones(1, device=self.dev if self.backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+            self.rccl_ranks = int(t.item()) if self.backend == "nccl" else None
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, *vals):
+        if self.dist is None:
+            return vals
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return tuple(float(v) for v in t)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+class Shape:
+    """one batch of B channels x S windows at one SF, resident in HBM, with its outputs"""
+
+    def __init__(self, env, L, sf, B, S, noise_sigma, variant=0):
+        torch = env.torch
+        self.env, self.L, self.sf, self.N, self.B, self.S, self.W = env, L, sf, 1 << sf, B, S, B * S
+        self.ctx = L.Context(sf, device=env.local)
+        self.ctx.set_variant(variant)
+        self.ctx.use_torch_stream()
+        g = self.g = torch.Generator(device=env.dev)
+        g.manual_seed(0x10AA + env.rank + 977 * sf)
+        self.sym = torch.randint(0, self.N, (self.W,), generator=g, device=env.dev, dtype=torch.int32).to(torch.int16)
+        self.iq = self.ctx.synth_symbols(self.sym, ampl=1.0, noise_sigma=noise_sigma, seed=0x5EED0000 + env.rank + 131 * sf)
+        self.out = self.new_out()
+        self.fine_err = self.fine_idx0 = None
+
+    def new_out(self):
+        torch, W, dev = self.env.torch, self.W, self.env.dev
+        return dict(sym=torch.empty(W, dtype=torch.int16, device=dev), power=torch.empty(W, dtype=torch.float32, device=dev),
+                    powerAvg=torch.empty(W, dtype=torch.float32, device=dev), fIndex=torch.empty(W, dtype=torch.float32, device=dev))
+
+    def moving_inputs(self):
+        """per-window _finefreqError in [-2, 2) bins and a random start index: the DATASYMBOLS shape"""
+        torch = self.env.torch
+        if self.fine_err is None:
+            self.fine_err = (torch.rand(self.W, generator=self.g, device=self.env.dev) * 4.0 - 2.0).to(torch.float32)
+            self.fine_idx0 = torch.randint(0, 128 * self.N, (self.W,), generator=self.g, device=self.env.dev, dtype=torch.int32)
+        return self.fine_err, self.fine_idx0
+
+    def measure(self, steps, warmup, ramp_seconds, moving=False, alias=False):
+        """ramp, W warm-up launches, then exactly K timed launches between barriers; returns (elapsed_s, kernel_ms) = max over ranks"""
+        env, torch, ctx = self.env, self.env.torch, self.ctx
+        out = self.new_out() if moving else self.out
+        offsets = torch.zeros(self.W, dtype=torch.int64, device=env.dev) if alias else None
+        fe = fi = None
+        if moving:
+            fe, fi = self.moving_inputs()
+            self.out_moving = out
+        batch = ctx.make_batch(self.iq, self.W, out["sym"], out["power"], out["powerAvg"], out["fIndex"], chirp_sel_all=self.L.CHIRP_UP,
+                               offsets=offsets, fine_err=fe, fine_idx0=fi)
+        # clock ramp: the first ~40 ms of load after idle run at reduced clocks (profiles/r01/s4_clock_ramp.txt)
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < ramp_seconds:
+            for _ in range(10):
+                ctx.detect_batch_raw(batch)
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            ctx.detect_batch_raw(batch)
+        env.barrier()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(steps):
+            ctx.detect_batch_raw(batch)
+        kernel_ms = ctx.timer_stop()          # HIP events on the launch stream, around exactly the K launches
+        env.barrier()
+        elapsed = time.perf_counter() - t0
+        return env.max_over_ranks(elapsed, kernel_ms)
+
+    def ser_vs_sent(self, out=None):
+        """genChirp's phase ramp is one sample ahead of the demod's table: a window-aligned symbol s lands in
+        bin s+1; the frame sync of the real receiver removes that constant. Returns (symbol error rate, the constant)."""
+        torch = self.env.torch
+        got = (out or self.out)["sym"].to(torch.int32) & 0xffff
+        sent = self.sym.to(torch.int32) & 0xffff
+        diff = (got - sent) % self.N
+        off = int(torch.mode(diff).values)
+        return float((diff != off).float().mean()), off
+
+    def host_iq(self):
+        if not hasattr(self, "_host"):
+            self._host = self.iq.cpu().numpy()
+        return self._host
+
+    def oracle_check(self, threads, moving=False):
+        """ALL windows of the batch through the CPU oracle (oracle/lora_oracle.c, pinned to the reference): indices must be
+        identical; power / fIndex differences are reported"""
+        import numpy as np
+        from oracle.oracle import Oracle
+        out = self.out_moving if moving else self.out
+        kw = {}
+        if moving:
+            kw = dict(fine_err=self.fine_err.cpu().numpy(), fine_idx0=self.fine_idx0.cpu().numpy())
+        o = Oracle().detect_batch(self.sf, self.host_iq(), nthreads=threads, **kw)
+        gs = out["sym"].cpu().numpy().view(np.uint16)
+        fin = np.isfinite(o["power"])
+        return {"windows": int(self.W), "index_mismatches": int((o["sym"] != gs).sum()),
+                "max_power_diff_dB": r4(float(np.abs(out["power"].cpu().numpy() - o["power"])[fin].max())),
+                "max_fIndex_diff": r4(float(np.abs(out["fIndex"].cpu().numpy() - o["fIndex"]).max()))}
+
+    def close(self):
+        self.ctx.close()
+
+
+def host_cpu_info():
+    cores = os.cpu_count() or 1
+    info = {"host_threads": cores}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        info["cgroup_cpu_max"] = "unlimited" if q[0] == "max" else r4(float(q[0]) / float(q[1]))
+    except Exception:
+        pass
+    return info
+
+
+_best_threads = {}
+
+
+def cpu_baseline(sf, iq_host, samples_per_stream, n_streams, seconds, flags="-O2", probe=True):
+    """Time the reference CPU path (the verbatim LoRaDemod.cpp work() loop: dechirp + kissfft + detect + frame machine) on a
+    bounded sample of the same IQ. Returns the JSON object."""
     from oracle.oracle import Oracle, Ref
     cores = os.cpu_count() or 1
-    if Ref.available():
-        impl, kind, what = Ref(), "reference", "LoRaDemod.cpp+LoRaDetector.hpp+kissfft.hh compiled in place (g++ -O2, no FMA)"
+    if Ref.available(flags):
+        impl, kind = Ref(flags), "reference"
+    elif flags == "-O2":
+        impl, kind = Oracle(), "port"
     else:
-        impl, kind, what = Oracle(), "port", "oracle/lora_oracle.c restatement (gcc -O2, no FMA)"
-    # pick the thread count that is fastest on this box (SMT / allocator contention can make "all
-    # hardware threads" slower), with ~1 s probes, then run that for ~`seconds` of wall time
+        return None
+    cands = sorted({min(cores, n_streams), max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True)
+    if not probe and sf in _best_threads:
+        cands = [_best_threads[sf]]
+    elif not probe and _best_threads:
+        cands = [list(_best_threads.values())[0]]
     best = None
-    for threads in sorted({min(cores, n_streams), max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
+    for threads in cands:
+        # the thread count that is fastest on this box (SMT / cgroup quota can make "all hardware threads" slower): ~0.5 s probes
         threads = min(threads, n_streams)
         t0 = time.perf_counter()
         calls = impl.demod_bench(sf, iq_host, samples_per_stream, n_streams, threads, 1)
         dt = time.perf_counter() - t0
-        rep = max(1, int(1.0 / max(dt, 1e-4)))
-        t0 = time.perf_counter()
-        calls = impl.demod_bench(sf, iq_host, samples_per_stream, n_streams, threads, rep)
-        dt = time.perf_counter() - t0
+        if len(cands) > 1:
+            rep = max(1, int(0.5 / max(dt, 1e-4)))
+            t0 = time.perf_counter()
+            calls = impl.demod_bench(sf, iq_host, samples_per_stream, n_streams, threads, rep)
+            dt = (time.perf_counter() - t0) / rep
+            calls //= rep
         if best is None or calls / dt > best[0]:
-            best = (calls / dt, threads, dt / rep)
+            best = (calls / dt, threads, dt)
     threads = best[1]
+    _best_threads.setdefault(sf, threads)
     repeat = max(1, int(seconds / max(best[2], 1e-4)))
     t0 = time.perf_counter()
     calls = impl.demod_bench(sf, iq_host, samples_per_stream, n_streams, threads, repeat)
     dt = time.perf_counter() - t0
-    want = n_streams
-    return {"value": calls / dt / 1e6, "unit": "Msym/s", "cores": threads, "kind": kind,
-            "sample": "%d channels x %d samples of the same SF%d IQ, %d passes = %d work() calls (one dechirp+FFT+detect each) in %.1f s wall; %s"
-                      % (want, samples_per_stream, sf, repeat, calls, dt, what),
-            "host_cores_total": cores}
+    v = calls / dt / 1e6
+    return {"value": r4(v), "unit": "Msym/s", "cores": threads, "per_core": r4(v / threads), "kind": kind, "flags": "g++ %s, no FMA" % flags,
+            "sample": "%d ch x %d samples of the same SF%d IQ, %d work() calls in %.1f s" % (n_streams, samples_per_stream, sf, calls, dt)}
 
 
-def main():
-    a = parse()
-    import torch
-    import lora_sdr_amd as L
-    from lora_sdr_amd.shard import bytes_per_symbol
+def roofline_obj(sf, W, launch_s, traffic, L):
+    alg = W * L.bytes_per_symbol(sf)
+    ach = alg / launch_s / 1e9
+    return {"bound": "hbm", "achieved": r4(ach), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r4(ach / HBM_PEAK_GBS), "traffic": traffic,
+            "kernel": "lorahip detect (dechirp+FFT+detect fused)", "launch_us": r4(launch_s * 1e6), "algorithmic_bytes_per_launch": alg,
+            "bytes_per_symbol": L.bytes_per_symbol(sf)}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # test hooks (tools/gpu_session.sh "multi"): run several ranks on ONE GPU over gloo to exercise the N > 1 code path
-    # where only a single device exists; a real multi-GPU run uses neither
-    backend = os.environ.get("LORA_BENCH_BACKEND", "nccl")
-    if os.environ.get("LORA_BENCH_ONE_DEVICE"):
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+
+def traffic_for(sf, a):
+    """HBM bytes per launch measured in a separate rocprofv3 --pmc pass of this command (profiles/traffic.json, committed)"""
+    if a.traffic is not None:
+        return a.traffic
+    if a.channels is not None or a.symbols is not None:
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["per_sf"][str(sf)].get("total_bytes")
+    except Exception:
+        return None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def section_level3(env, L, sf):
+    """B channels of the LoRaDemod block over whole frames through the streaming kernel (tools/bench_demod.py's workload)"""
+    import numpy as np
+    from lora_sdr_amd import workloads as WL
+    torch = env.torch
+    B, frames, nsyms = WL.LEVEL3_CHANNELS[sf], 4, 48
+    ctx = L.Context(sf, device=env.local)
+    iq, data = WL.frame_streams(ctx, B, frames, nsyms, sigma=0.05)
+    d = L.LoRaDemod(sf, n_channels=B, device=env.local)
+    d.set_mode(1)
+    d.setMTU(nsyms)
+    best = None
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d.work(iq)
+        dt = time.perf_counter() - t0
+        if rep == 0:
+            calls = d.work_calls()
+            pk = d.packets()
         else:
-            dist.init_process_group(backend)
+            d.packets()
+            if best is None or dt < best[0]:
+                best = (dt, d.kernel_ms())
+        d.activate()
+    n_pk, ok = WL.check_frame_packets(pk, data, 1 << sf, nsyms)
+    res = {"sf": sf, "channels": B, "work_calls": int(calls), "Msym_s_e2e": r4(calls / best[0] / 1e6), "e2e_ms": r4(best[0] * 1e3),
+           "kernel_us": r4(best[1] * 1e3), "Msym_s_kernel": r4(calls / (best[1] / 1e3) / 1e6),
+           "frac_kernel": r4(calls * L.bytes_per_symbol(sf) / (best[1] / 1e3) / 1e9 / HBM_PEAK_GBS),
+           "packets": n_pk, "packets_expected": B * frames, "packets_ok": ok}
+    if env.rank == 0 and env.world == 1:
+        # the same streams through the CPU oracle's restated block (pinned to the verbatim LoRaDemod.cpp): identical packets
+        from oracle.oracle import Oracle
+        orc = Oracle()
+        by_ch = {}
+        for ch, _rd, s in pk:
+            by_ch.setdefault(ch, []).append(s)
+        bad = 0
+        chk = list(range(0, min(B, 8)))
+        for c in chk:
+            r = orc.demod_run(sf, iq[c].cpu().numpy(), mtu=nsyms, keep=False)
+            want = [p for _c, p in r["packets"]]
+            got = by_ch.get(c, [])
+            bad += int(len(want) != len(got) or any(not np.array_equal(x, y) for x, y in zip(want, got)))
+        res["oracle_channels_checked"] = len(chk)
+        res["oracle_channel_mismatches"] = bad
+    d.close()
+    ctx.close()
+    del iq
+    return res
 
-    sf = a.sf
-    N = 1 << sf
-    ch_def, sy_def = default_geometry(sf)
-    B = a.channels or ch_def
-    S = a.symbols or sy_def
-    W = B * S
 
-    ctx = L.Context(sf, device=local)
-    ctx.set_variant(a.variant)
-    ctx.use_torch_stream()
+def section_config5(env, L, a, threads):
+    """BASELINE configs[4]: SF10, 8192 channels x 64 windows, AWGN at -10 dB SNR per sample (signal power 1, noise variance 10)"""
+    import numpy as np
+    sh = Shape(env, L, 10, 8192, 64, noise_sigma=5.0 ** 0.5, variant=a.variant)
+    elapsed, kernel_ms = sh.measure(a.steps, a.warmup, 0.1)
+    ser, off = sh.ser_vs_sent()
+    res = {"sf": 10, "channels": 8192, "symbols": 64, "snr_dB": -10, "Msym_s": r4(sh.W * a.steps * env.world / elapsed / 1e6),
+           "frac": r4(sh.W * L.bytes_per_symbol(10) / (kernel_ms / 1e3 / a.steps) / 1e9 / HBM_PEAK_GBS), "ser_gpu": ser, "bin_offset": off}
+    if env.rank == 0 and env.world == 1:
+        from oracle.oracle import Oracle
+        o = Oracle().detect_batch(10, sh.host_iq(), nthreads=threads)
+        sent = sh.sym.cpu().numpy().view(np.uint16).astype(np.int64)
+        res["ser_cpu"] = float(((o["sym"].astype(np.int64) - sent) % 1024 != off).mean())
+        res["gpu_vs_cpu_index_mismatches"] = int((o["sym"] != sh.out["sym"].cpu().numpy().view(np.uint16)).sum())
+        res["windows_checked"] = int(sh.W)
+    sh.close()
+    return res
 
-    # synthetic input, generated in HBM: random symbols per (channel, window), continuous stream per channel
-    g = torch.Generator(device=dev)
-    g.manual_seed(0x10AA + rank)
-    sym = torch.randint(0, N, (W,), generator=g, device=dev, dtype=torch.int32).to(torch.int16)
-    iq = ctx.synth_symbols(sym, ampl=1.0, noise_sigma=a.noise_sigma, seed=0x5EED0000 + rank)
-    out = dict(sym=torch.empty(W, dtype=torch.int16, device=dev), power=torch.empty(W, dtype=torch.float32, device=dev),
-               powerAvg=torch.empty(W, dtype=torch.float32, device=dev), fIndex=torch.empty(W, dtype=torch.float32, device=dev))
-    offsets = torch.zeros(W, dtype=torch.int64, device=dev) if a.alias_windows else None
-    fine_err = fine_idx0 = None
-    if a.moving:
-        fine_err = (torch.rand(W, generator=g, device=dev) * 4.0 - 2.0).to(torch.float32)
-        fine_idx0 = torch.randint(0, 128 * N, (W,), generator=g, device=dev, dtype=torch.int32)
-    batch = ctx.make_batch(iq, W, out["sym"], out["power"], out["powerAvg"], out["fIndex"], chirp_sel_all=L.CHIRP_UP,
-                           offsets=offsets, fine_err=fine_err, fine_idx0=fine_idx0)
 
-    def barrier():
+def section_mixed(env, L, a, S=16, n_channels=16384):
+    """BASELINE configs[3]: 16384 channels, SF(c) = 7 + c mod 6, S symbols each; byte-weighted contiguous shards
+    (lora_sdr_amd/shard.py), one launch per SF bucket on its own HIP stream, symbols gathered to every rank at the end."""
+    import numpy as np
+    from lora_sdr_amd import workloads as WL
+    from lora_sdr_amd.shard import gather_symbols
+    torch = env.torch
+    sfs = WL.mixed_sf_channels(n_channels)
+    mine = L.shard_channels(sfs, env.world)[env.rank]
+    buckets, order, total_bytes = [], [], 0
+    for sf in range(7, 13):
+        N = 1 << sf
+        glob = np.nonzero(sfs == sf)[0]
+        g = torch.Generator(device=env.dev)
+        g.manual_seed(0xC0F3 + sf)                                   # the same "sent" symbols on every rank: the global truth
+        sent_all = torch.randint(0, N, (glob.size, S), generator=g, device=env.dev, dtype=torch.int32)
+        total_bytes += glob.size * S * L.bytes_per_symbol(sf)
+        ch = mine[sfs[mine] == sf]
+        if ch.size == 0:
+            continue
+        pos = torch.from_numpy(np.searchsorted(glob, ch)).to(env.dev)
+        sym = sent_all[pos].to(torch.int16).reshape(-1).contiguous()
+        gen = L.Context(sf, device=env.local)
+        gen.use_torch_stream()
+        iq = gen.synth_symbols(sym, ampl=1.0, noise_sigma=a.noise_sigma, seed=0x5EED1000 + sf)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        gen.close()
+        ctx = L.Context(sf, device=env.local)                        # launches on its private non-blocking stream: the buckets overlap
+        ctx.set_variant(a.variant)
+        W = int(ch.size) * S
+        out = dict(sym=torch.empty(W, dtype=torch.int16, device=env.dev), power=torch.empty(W, dtype=torch.float32, device=env.dev),
+                   powerAvg=torch.empty(W, dtype=torch.float32, device=env.dev), fIndex=torch.empty(W, dtype=torch.float32, device=env.dev))
+        b = ctx.make_batch(iq, W, out["sym"], out["power"], out["powerAvg"], out["fIndex"], chirp_sel_all=L.CHIRP_UP)
+        buckets.append((sf, ctx, b, iq, out, sym, ch))
+        order.append(ch)
+    torch.cuda.synchronize()
 
-    # clock ramp: the first ~40 ms of load after idle run at reduced clocks (profiles/r01/s4_clock_ramp.txt);
-    # keep launching (untimed) until that is over, then the W warm-up steps, then the timed K steps
+    def step():
+        for _sf, ctx, b, *_ in buckets:
+            ctx.detect_batch_raw(b)
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < a.ramp_seconds:
-        for _ in range(10):
-            ctx.detect_batch_raw(batch)
+    while time.perf_counter() - t_ramp < 0.2:
+        step()
         torch.cuda.synchronize()
     for _ in range(a.warmup):
-        ctx.detect_batch_raw(batch)
-    barrier()
+        step()
+    env.barrier()
     t0 = time.perf_counter()
-    ctx.timer_start()
     for _ in range(a.steps):
-        ctx.detect_batch_raw(batch)
-    kernel_ms = ctx.timer_stop()          # HIP events on the launch stream, around exactly the K launches
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+        step()
+    env.barrier()
+    (elapsed,) = env.max_over_ranks(time.perf_counter() - t0)
+    res = {"channels": n_channels, "symbols_per_channel": S, "sf_rule": "7 + c mod 6", "my_channels_rank0": int(mine.size),
+           "Msym_s": r4(n_channels * S * a.steps / elapsed / 1e6), "ms_per_step": r4(elapsed * 1e3 / a.steps),
+           "frac_byte_weighted": r4(total_bytes * a.steps / elapsed / 1e9 / (HBM_PEAK_GBS * env.world)),
+           "iq_bytes_per_step": int(sum(int((sfs == sf).sum()) * S * (8 << sf) for sf in range(7, 13)))}
+    # ---- end of run: the 2 B/symbol results to every rank (north_star: RCCL only as an embarrassingly parallel split) ----
+    local_sym = torch.cat([o["sym"].reshape(-1, S) for (_sf, _c, _b, _iq, o, _s, _ch) in buckets]) if buckets else torch.zeros((0, S), dtype=torch.int16, device=env.dev)
+    local_ch = np.concatenate(order) if order else np.zeros(0, np.int64)
+    dist, made = env.dist, False
+    try:
+        if dist is None:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=env.dev)
+            made = True
+        backend_cpu = env.dist is not None and env.backend != "nccl"
+        t0 = time.perf_counter()
+        full = gather_symbols(local_sym.cpu() if backend_cpu else local_sym, local_ch, n_channels)
+        torch.cuda.synchronize()
+        res["gather_ms"] = r4((time.perf_counter() - t0) * 1e3)
+        res["gather_backend"] = "gloo" if backend_cpu else "nccl (RCCL), %d rank(s)" % dist.get_world_size()
+        # check against the sent symbols (constant +1 bin of genChirp vs the demod table, SURVEY.md section 7h)
+        full = full.to(env.dev).to(torch.int32) & 0xffff
+        bad = 0
+        for sf in range(7, 13):
+            N = 1 << sf
+            glob = np.nonzero(sfs == sf)[0]
+            g = torch.Generator(device=env.dev)
+            g.manual_seed(0xC0F3 + sf)
+            sent_all = torch.randint(0, N, (glob.size, S), generator=g, device=env.dev, dtype=torch.int32)
+            got = full[torch.from_numpy(glob).to(env.dev)]
+            bad += int((((got - sent_all) % N) != 1).sum())
+        res["symbol_errors_vs_sent"] = bad
+        res["symbols_checked"] = n_channels * S
+    except Exception as e:                                           # pragma: no cover - environment dependent
+        res["gather_backend"] = "failed: %s" % str(e)[:80]
+    finally:
+        if made:
+            dist.destroy_process_group()
+    for _sf, ctx, *_ in buckets:
+        ctx.close()
+    return res
 
-    # correctness of what was timed: recovered symbols vs sent (+ a cross-check of a slice vs the CPU oracle below)
-    got = out["sym"].to(torch.int32) & 0xffff
-    sent = sym.to(torch.int32) & 0xffff
-    diff = (got - sent) % N
-    bin_offset = int(torch.mode(diff).values)
-    ser = float((diff != bin_offset).float().mean())
-    # genChirp's phase ramp is one sample ahead of the demod's table (SURVEY.md §7h): a window-aligned
-    # symbol s lands in bin s+1; the frame sync of the real receiver removes that constant
 
-    if rank == 0:
-        total_syms = W * a.steps * world
-        value = total_syms / elapsed / 1e6
+# ------------------------------------------------------------------------------------------------------------------
+def main():
+    a = parse()
+    env = Env(a)
+    import lora_sdr_amd as L
+    from lora_sdr_amd import workloads as WL
+    single = a.sf is not None or a.moving or a.alias_windows
+    sweep = not single and not a.no_sweep and a.config == "default"
+    rank0 = env.rank == 0
+    solo = rank0 and env.world == 1                     # CPU-side work (baseline, oracle) only here
+
+    if a.config == "mixed":
+        m = section_mixed(env, L, a)
+        if rank0:
+            line = {"metric": METRIC, "value": m["Msym_s"], "unit": "Msym/s", "n_gpus": env.world, "steps": a.steps, "warmup": a.warmup,
+                    "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                    "data": "synthetic", "config": {"workload": "BASELINE configs[3]: 16384 channels, SF = 7 + c mod 6, 16 symbols each, "
+                                                                "byte-weighted shards over %d rank(s)" % env.world},
+                    "roofline": {"bound": "hbm", "frac": m["frac_byte_weighted"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "achieved": r4(m["frac_byte_weighted"] * HBM_PEAK_GBS), "traffic": None}, "mixed": m, "rccl_ranks": env.rccl_ranks}
+            print(json.dumps(line), flush=True)
+        env.close()
+        return
+
+    sf0 = a.sf if a.sf is not None else 7
+    ch_def, sy_def = WL.default_geometry(sf0)
+    B, S = a.channels or ch_def, a.symbols or sy_def
+    sh = Shape(env, L, sf0, B, S, a.noise_sigma, a.variant)
+    if a.fine_gather:
+        sh.ctx.set_fine_gather(True)
+    elapsed, kernel_ms = sh.measure(a.steps, a.warmup, a.ramp_seconds, moving=a.moving, alias=a.alias_windows)
+    ser, off = sh.ser_vs_sent(sh.out_moving if a.moving else None) if not a.alias_windows else (None, None)
+    line = None
+    threads = min(os.cpu_count() or 1, 64)
+    if rank0:
         launch_s = kernel_ms / 1e3 / a.steps
-        traffic = a.traffic
-        if traffic is None and a.channels is None and a.symbols is None:
-            # measured in a separate rocprofv3 --pmc pass of this same command (tools/gpu_session.sh pmc), committed
-            try:
-                t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["per_sf"][str(sf)]
-                traffic = t.get("total_bytes")
-            except Exception:
-                traffic = None
-        alg_bytes = W * bytes_per_symbol(sf)
-        achieved = alg_bytes / launch_s / 1e9
         line = {
-            "metric": "Msymbols/sec demodulated (dechirp+FFT+argmax)", "value": value, "unit": "Msym/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3 / a.steps,
+            "metric": METRIC, "value": sh.W * a.steps * env.world / elapsed / 1e6, "unit": "Msym/s",
+            "n_gpus": env.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3 / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch %d channels SF=%d (N=%d FFT) x %d symbol windows per channel per step, per GPU"
-                                   % (B, sf, N, S), "sf": sf, "channels_per_gpu": B, "symbols_per_channel": S,
-                       "iq_bytes_per_step_per_gpu": W * N * 8, "noise_sigma": a.noise_sigma,
-                       "parallelism": "channels sharded, %d rank(s), no data-path collective" % world,
+            "config": {"workload": "batch %d channels SF=%d (N=%d FFT) x %d symbol windows per channel per step, per GPU" % (B, sf0, sh.N, S),
+                       "sf": sf0, "channels_per_gpu": B, "symbols_per_channel": S, "iq_bytes_per_step_per_gpu": sh.W * sh.N * 8,
+                       "noise_sigma": a.noise_sigma, "parallelism": "channels sharded, %d rank(s), no data-path collective" % env.world,
                        "kernel_variant": a.variant, "alias_windows": bool(a.alias_windows), "moving_fine_index": bool(a.moving),
-                       "ramp_seconds": a.ramp_seconds},
-            "symbol_error_rate_vs_sent": ser, "bin_offset": bin_offset,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "lorahip detect (dechirp+FFT+detect fused)", "launch_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_symbol": bytes_per_symbol(sf)},
+                       "fine_gather": bool(a.fine_gather), "ramp_seconds": a.ramp_seconds},
+            "symbol_error_rate_vs_sent": ser, "bin_offset": off,
+            "roofline": roofline_obj(sf0, sh.W, launch_s, None if (a.moving or a.alias_windows) else traffic_for(sf0, a), L),
         }
-        if world == 1 and not a.no_cpu_baseline:
-            n_streams = min(B, 512)
-            host = iq[:n_streams * S * N].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(sf, host, S * N, n_streams, a.cpu_seconds)
-            # the same slice through the oracle's batch checker: indices must agree exactly
-            from oracle.oracle import Oracle
-            k = min(W, 2048)
-            o = Oracle().detect_batch(sf, host[:k * N], nthreads=os.cpu_count() or 1)
-            line["oracle_index_mismatches_in_%d" % k] = int((o["sym"] != out["sym"][:k].cpu().numpy().view("uint16")).sum())
+        if env.rccl_ranks is not None:
+            line["rccl_ranks"] = env.rccl_ranks
+    if solo and not a.no_cpu_baseline:
+        n_streams = min(B, 512)
+        host = sh.host_iq()[:n_streams * S * sh.N]
+        cb = cpu_baseline(sf0, host, S * sh.N, n_streams, a.cpu_seconds)
+        threads = cb["cores"]
+        cb.update(host_cpu_info())
+        # BASELINE.md: the other two flag sets beside -O2 (same sources; result-identical for finite input)
+        cb["other_flags"] = [x for x in (cpu_baseline(sf0, host, S * sh.N, n_streams, 2.0, f, probe=False) for f in ("-O3 -fcx-limited-range", "-O3")) if x]
+        for x in cb["other_flags"]:
+            x.pop("sample", None); x.pop("kind", None); x.pop("unit", None)
+        line["cpu_baseline"] = cb
+    if solo and not a.alias_windows:
+        line["oracle"] = sh.oracle_check(threads, moving=a.moving)
+
+    if sweep:
+        per_sf, moving, level3 = [], [], []
+        for sf in range(7, 13):
+            if sf != sf0:
+                b2, s2 = WL.default_geometry(sf)
+                cur = Shape(env, L, sf, b2, s2, a.noise_sigma, a.variant)
+                e2, k2 = cur.measure(a.steps, a.warmup, a.ramp_seconds)
+            else:
+                cur, e2, k2 = sh, elapsed, kernel_ms
+            ser2, off2 = cur.ser_vs_sent()
+            ent = {"sf": sf, "channels": cur.B, "symbols": cur.S, "Msym_s": r4(cur.W * a.steps * env.world / e2 / 1e6),
+                   "launch_us": r4(k2 * 1e3 / a.steps), "frac": r4(cur.W * L.bytes_per_symbol(sf) / (k2 / 1e3 / a.steps) / 1e9 / HBM_PEAK_GBS),
+                   "traffic": traffic_for(sf, a), "ser_vs_sent": ser2}
+            # the locked-receiver shape on the same IQ
+            e3, k3 = cur.measure(a.steps, a.warmup, 0.1, moving=True)
+            mv = {"sf": sf, "Msym_s": r4(cur.W * a.steps * env.world / e3 / 1e6), "launch_us": r4(k3 * 1e3 / a.steps),
+                  "frac": r4(cur.W * L.bytes_per_symbol(sf) / (k3 / 1e3 / a.steps) / 1e9 / HBM_PEAK_GBS)}
+            if solo:
+                if sf != sf0:
+                    ent["oracle"] = cur.oracle_check(threads)
+                    if not a.no_cpu_baseline:
+                        n_streams = min(cur.B, 512)
+                        cbs = cpu_baseline(sf, cur.host_iq()[:n_streams * cur.S * cur.N], cur.S * cur.N, n_streams, 2.0, probe=False)
+                        ent["cpu_baseline"] = {"value": cbs["value"], "cores": cbs["cores"], "per_core": cbs["per_core"], "flags": "-O2"}
+                else:
+                    ent["oracle"] = line["oracle"]
+                    if "cpu_baseline" in line:
+                        ent["cpu_baseline"] = {k: line["cpu_baseline"][k] for k in ("value", "cores", "per_core")}
+                        ent["cpu_baseline"]["flags"] = "-O2"
+                mv["oracle"] = cur.oracle_check(threads, moving=True)
+            per_sf.append(ent)
+            moving.append(mv)
+            if cur is not sh:
+                cur.close()
+            del cur
+            env.torch.cuda.empty_cache()
+        sh.close()
+        del sh
+        env.torch.cuda.empty_cache()
+        if env.world == 1:
+            for sf in range(7, 13):
+                level3.append(section_level3(env, L, sf))
+                env.torch.cuda.empty_cache()
+        c5 = section_config5(env, L, a, threads) if env.world == 1 else None
+        env.torch.cuda.empty_cache()
+        mixed = section_mixed(env, L, a)
+        if rank0:
+            line["per_sf"], line["moving"] = per_sf, moving
+            if level3:
+                line["level3"] = level3
+            if c5:
+                line["config5"] = c5
+            line["mixed"] = mixed
+    if rank0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    env.close()
 
 
 if __name__ == "__main__":

@@ -62,7 +62,7 @@ extern "C" {
 
 const char *lorahip_strerror(int code);
 const char *lorahip_last_error(void);       /* thread-local text of the last LORAHIP_E_HIP */
-int lorahip_version(void);                  /* ABI version, currently 1 */
+int lorahip_version(void);                  /* ABI version, currently 2 (1 -> 2: lorahip_work_result grew, level-3 ports and labels) */
 int lorahip_device_count(void);             /* number of usable gfx950 devices, 0 if none */
 int lorahip_selfcheck(void);                /* host-only: the kernels' compile-time LDS layouts are consistent; no device needed */
 
@@ -94,6 +94,18 @@ int lorahip_synchronize(lorahip_ctx *ctx);
 /* Kernel variant: 0 = auto (fastest validated for this SF), 1 = generic LDS kernel.
  * All variants produce identical symbol indices and FFT bins. */
 int lorahip_set_variant(lorahip_ctx *ctx, int variant);
+
+/* How the kernels obtain _fineTuneTable[_fineTuneIndex] for windows whose index moves (LoRaDemod.cpp:159-162). Default (0): no
+ * table read at all -- the index sequence in closed form, the entry as the product of two small fp64 factor tables held in LDS,
+ * which the library has checked against all 128*N entries of the reference's table on this host (lorahip_fine_split_active() == 1;
+ * if that check ever failed the tables are not built and the kernels read the table). 1: always read the table in HBM and walk
+ * the index chain (the A/B switch; results are bit-identical either way). */
+int lorahip_set_fine_gather(lorahip_ctx *ctx, int enable);
+int lorahip_fine_split_active(const lorahip_ctx *ctx);
+/* host-only self tests of the above (no device needed): 1 if the split reproduces every entry of the fine-tune table of `sf`;
+ * the index sequence of one window as the kernels evaluate it (idx_out: N entries, *path = 1 closed form / 0 serial chain) */
+int lorahip_fine_split_selftest(int sf);
+int lorahip_fine_indices_host(int sf, int32_t idx0, float err, int32_t *idx_out, int32_t *idx_end, int32_t *path);
 
 /* One batch of independent windows. All pointers are DEVICE pointers for
  * lorahip_detect_batch and HOST pointers for lorahip_detect_batch_host.
@@ -166,6 +178,8 @@ int lorahip_demod_set_mode(lorahip_demod *d, int mode);
 /* Launch on an existing hipStream_t from now on (same meaning as lorahip_set_stream): work queued on that stream before a
  * run -- a channeliser, a modulator, a copy -- is ordered before the run's kernels. A run returns with the stream drained. */
 int lorahip_demod_set_stream(lorahip_demod *d, void *hip_stream);
+/* same switch as lorahip_set_fine_gather, for the demodulator's kernels */
+int lorahip_demod_set_fine_gather(lorahip_demod *d, int enable);
 
 /* Per-channel outcome of one work() round (what the block would have done on its ports). */
 typedef struct lorahip_work_result {
@@ -178,6 +192,11 @@ typedef struct lorahip_work_result {
     int32_t signals;        /* 1 at DOWNCHIRP1: error/power/snr emitted        :267-269 */
     int32_t sig_error;
     float sig_power, sig_snr;
+    /* the dechirp state of this call (LoRaDemod.cpp:157-166): what lorahip_demod_get_ports() replays the debug ports from */
+    int32_t fine_idx_before;   /* _fineTuneIndex when the call began                                          */
+    int32_t fine_idx_after;    /* ... after the N steps of window 0 (where the sync check's window 1 starts :191) */
+    float fine_err_before;     /* _finefreqError when the call began                                          */
+    int32_t reserved;
 } lorahip_work_result;
 
 /* Feed every channel's whole stream (host memory, cf32, n_samples[c] samples each) and run
@@ -209,6 +228,30 @@ void lorahip_demod_clear_packets(lorahip_demod *d);
 int64_t lorahip_demod_consumed(const lorahip_demod *d, size_t channel);
 /* total work() calls made (sum over channels) since create/activate */
 int64_t lorahip_demod_work_calls(const lorahip_demod *d);
+/* device time of the streaming kernel launches of the last lorahip_demod_run[_device] (HIP events on the launch stream; 0 in the
+ * host-driven mode): what the level-3 roofline line of bench.py is computed from */
+double lorahip_demod_kernel_ms(const lorahip_demod *d);
+/* Debug ports of the block, opt-in like the trace (they triple the HBM traffic): what LoRaDemod::work() writes to its "raw", "dec"
+ * and "fft" outputs (LoRaDemod.cpp:81-83,163-164,172,320-324), per channel, for the NEXT runs. Device buffers owned by the caller:
+ *   fft_dev  [n_channels][fft_cap_frames][N] cf32   one frame of N bins per work() call: window 0's FFT (:172, produce(N) :324)
+ *   dec_dev  [n_channels][dec_cap_samples]   cf32   `total` dechirped samples per call (:164, produce(total) :322): window 0's first
+ *                                                   min(total, N), and window 1 when the call consumed 2N (the sync check, :189-206)
+ *   raw_dev  [n_channels][raw_cap_samples]   cf32   the samples consumed (:163, :321)
+ * Any pointer may be NULL (that port stays off); p == NULL switches all off. Bins and samples are bit-identical to the reference's.
+ * What exceeds a capacity is dropped; lorahip_demod_port_counts() reports what the last run produced. Labels: see below. */
+typedef struct lorahip_demod_ports {
+    size_t struct_size;     /* = sizeof(lorahip_demod_ports) */
+    float *fft_dev; size_t fft_cap_frames;
+    float *dec_dev; size_t dec_cap_samples;
+    float *raw_dev; size_t raw_cap_samples;
+} lorahip_demod_ports;
+int lorahip_demod_set_ports(lorahip_demod *d, const lorahip_demod_ports *p);
+int lorahip_demod_port_counts(const lorahip_demod *d, size_t channel, size_t *fft_frames, size_t *dec_samples, size_t *raw_samples);
+/* The stream labels work() posts at index 0 of what each call produces on raw / dec / fft (LoRaDemod.cpp:314-319) -- "SYNC",
+ * "P <fIndex>", "DC", "QC", "S<n> <fIndex>", or none ("") -- for every call in `channel`'s trace (lorahip_demod_set_trace), as
+ * NUL-terminated strings back to back, formatted like the reference's (fixed, 4 decimals). Label k sits at element k*N of the fft
+ * port and at element sum(consumed[0..k)) of raw / dec. *n_calls = number of strings, *bytes = bytes needed; buf may be NULL. */
+int lorahip_demod_get_labels(const lorahip_demod *d, size_t channel, char *buf, size_t cap, size_t *n_calls, size_t *bytes);
 /* optional trace of every work() call: enable before run, then read back */
 int lorahip_demod_set_trace(lorahip_demod *d, int enable);
 size_t lorahip_demod_trace_len(const lorahip_demod *d, size_t channel);

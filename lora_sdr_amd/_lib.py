@@ -38,12 +38,19 @@ class DecoderCfg(C.Structure):
                                                                           "explicit_hdr", "hdr", "data_length")]
 
 
+class DemodPorts(C.Structure):
+    """struct lorahip_demod_ports"""
+    _fields_ = [("struct_size", C.c_size_t), ("fft_dev", C.c_void_p), ("fft_cap_frames", C.c_size_t), ("dec_dev", C.c_void_p),
+                ("dec_cap_samples", C.c_size_t), ("raw_dev", C.c_void_p), ("raw_cap_samples", C.c_size_t)]
+
+
 class WorkResult(C.Structure):
     """struct lorahip_work_result"""
     _fields_ = [("consumed", C.c_int64), ("state_before", C.c_int32), ("value", C.c_int32),
                 ("power", C.c_float), ("power_avg", C.c_float), ("snr", C.c_float), ("f_index", C.c_float),
                 ("worked", C.c_int32), ("packet_len", C.c_int32), ("signals", C.c_int32),
-                ("sig_error", C.c_int32), ("sig_power", C.c_float), ("sig_snr", C.c_float)]
+                ("sig_error", C.c_int32), ("sig_power", C.c_float), ("sig_snr", C.c_float),
+                ("fine_idx_before", C.c_int32), ("fine_idx_after", C.c_int32), ("fine_err_before", C.c_float), ("reserved", C.c_int32)]
 
 
 # every symbol include/lorahip.h declares: name -> (restype, argtypes)
@@ -60,6 +67,11 @@ SIGNATURES = {
     "lorahip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lorahip_synchronize": (C.c_int, [C.c_void_p]),
     "lorahip_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "lorahip_set_fine_gather": (C.c_int, [C.c_void_p, C.c_int]),
+    "lorahip_fine_split_active": (C.c_int, [C.c_void_p]),
+    "lorahip_fine_split_selftest": (C.c_int, [C.c_int]),
+    "lorahip_fine_indices_host": (C.c_int, [C.c_int, C.c_int32, C.c_float, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lorahip_demod_set_fine_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_detect_batch": (C.c_int, [C.c_void_p, C.POINTER(Batch)]),
     "lorahip_detect_batch_host": (C.c_int, [C.c_void_p, C.POINTER(Batch)]),
     "lorahip_timer_start": (C.c_int, [C.c_void_p]),
@@ -99,7 +111,11 @@ SIGNATURES = {
     "lorahip_demod_clear_packets": (None, [C.c_void_p]),
     "lorahip_demod_consumed": (C.c_int64, [C.c_void_p, C.c_size_t]),
     "lorahip_demod_work_calls": (C.c_int64, [C.c_void_p]),
+    "lorahip_demod_kernel_ms": (C.c_double, [C.c_void_p]),
     "lorahip_demod_set_trace": (C.c_int, [C.c_void_p, C.c_int]),
+    "lorahip_demod_set_ports": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lorahip_demod_port_counts": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lorahip_demod_get_labels": (C.c_int, [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lorahip_demod_trace_len": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "lorahip_demod_get_trace": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(WorkResult), C.c_size_t]),
     "lorahip_membw_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),

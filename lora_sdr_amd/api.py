@@ -89,6 +89,13 @@ class Context:
     def synchronize(self):
         check(self._lib.lorahip_synchronize(self._h), "lorahip_synchronize")
 
+    def set_fine_gather(self, on):
+        """A/B switch: read the fine-tune table in HBM instead of evaluating it from the split tables (include/lorahip.h)"""
+        check(self._lib.lorahip_set_fine_gather(self._h, int(bool(on))), "lorahip_set_fine_gather")
+
+    def fine_split_active(self):
+        return bool(self._lib.lorahip_fine_split_active(self._h))
+
     def timer_start(self):
         check(self._lib.lorahip_timer_start(self._h), "lorahip_timer_start")
 
@@ -476,6 +483,14 @@ class LoRaDemod:
 
     def work_calls(self):
         return int(self._lib.lorahip_demod_work_calls(self._h))
+
+    def kernel_ms(self):
+        """device time of the streaming kernel launches of the last work() (HIP events on the launch stream)"""
+        return float(self._lib.lorahip_demod_kernel_ms(self._h))
+
+    def set_fine_gather(self, on):
+        """A/B switch: read the fine-tune table in HBM instead of evaluating it from the split tables (include/lorahip.h)"""
+        check(self._lib.lorahip_demod_set_fine_gather(self._h, int(bool(on))), "lorahip_demod_set_fine_gather")
 
     def labels(self, channel):
         """The stream labels the block posts at index 0 of its raw / dec / fft outputs, one per work() call ("" = none):

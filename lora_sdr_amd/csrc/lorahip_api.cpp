@@ -80,7 +80,7 @@ const char *lorahip_strerror(const int code)
 
 const char *lorahip_last_error(void) { return g_lastError.c_str(); }
 
-int lorahip_version(void) { return 1; }
+int lorahip_version(void) { return 2; }
 
 int lorahip_selfcheck(void)
 {
@@ -136,6 +136,18 @@ int lorahip_create(lorahip_ctx **out, const int device, const int sf)
         LORAHIP_CK(hipMemcpy(ctx->dDown, t.down.data(), nb, hipMemcpyHostToDevice));
         LORAHIP_CK(hipMemcpy(ctx->dTw, t.twiddle.data(), nb, hipMemcpyHostToDevice));
         LORAHIP_CK(hipMemcpy(ctx->dFine, t.fine.data(), nb * LORAHIP_FINE_STEPS, hipMemcpyHostToDevice));
+        {
+            // fp64 factor tables that reproduce the fine-tune table without a gather (lorahip_fine.h); only when the host check of
+            // all 128*N entries passes -- otherwise the kernels keep reading the table itself
+            std::vector<double> fa, fb;
+            if (buildFineSplit(sf, t.fine, fa, fb))
+            {
+                LORAHIP_CK(hipMalloc((void **)&ctx->dFineA, fa.size() * sizeof(double)));
+                LORAHIP_CK(hipMalloc((void **)&ctx->dFineB, fb.size() * sizeof(double)));
+                LORAHIP_CK(hipMemcpy(ctx->dFineA, fa.data(), fa.size() * sizeof(double), hipMemcpyHostToDevice));
+                LORAHIP_CK(hipMemcpy(ctx->dFineB, fb.data(), fb.size() * sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
         const std::vector<cf32> st = buildStageTwiddles(sf, t.twiddle);
         LORAHIP_CK(hipMalloc((void **)&ctx->dTwStage, (st.size() + 1) * sizeof(cf32)));
         LORAHIP_CK(hipMemcpy(ctx->dTwStage, st.data(), st.size() * sizeof(cf32), hipMemcpyHostToDevice));
@@ -159,6 +171,8 @@ void lorahip_destroy(lorahip_ctx *ctx)
     if (ctx->dTw) (void)hipFree(ctx->dTw);
     if (ctx->dFine) (void)hipFree(ctx->dFine);
     if (ctx->dTwStage) (void)hipFree(ctx->dTwStage);
+    if (ctx->dFineA) (void)hipFree(ctx->dFineA);
+    if (ctx->dFineB) (void)hipFree(ctx->dFineB);
     if (ctx->dStage) (void)hipFree(ctx->dStage);
     if (ctx->hStage) (void)hipHostFree(ctx->hStage);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -192,6 +206,19 @@ int lorahip_set_variant(lorahip_ctx *ctx, const int variant)
     return LORAHIP_OK;
 }
 
+int lorahip_set_fine_gather(lorahip_ctx *ctx, const int enable)
+{
+    if (ctx == nullptr) return LORAHIP_E_INVALID;
+    ctx->fineGather = enable != 0;
+    return LORAHIP_OK;
+}
+
+int lorahip_fine_split_active(const lorahip_ctx *ctx)
+{
+    if (ctx == nullptr) return LORAHIP_E_INVALID;
+    return (ctx->dFineA != nullptr && ctx->dFineB != nullptr && !ctx->fineGather) ? 1 : 0;
+}
+
 static int checkBatch(const lorahip_ctx *ctx, const lorahip_batch *b)
 {
     if (ctx == nullptr || b == nullptr) return LORAHIP_E_INVALID;
@@ -223,6 +250,8 @@ static void fillArgs(const lorahip_ctx *ctx, const lorahip_batch *b, DetectArgs 
     a.down = ctx->dDown;
     a.fine = ctx->dFine;
     a.tw = ctx->dTw;
+    a.fineA = ctx->fineGather ? nullptr : ctx->dFineA;
+    a.fineB = ctx->fineGather ? nullptr : ctx->dFineB;
     a.nWindows = unsigned(b->n_windows);
     a.powerScale = ctx->powerScale;
 }
@@ -391,7 +420,15 @@ int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, con
     if (ctx == nullptr || cfg == nullptr || cfg->struct_size != sizeof(lorahip_decoder_cfg)) return LORAHIP_E_INVALID;
     if (n_packets == 0) return LORAHIP_OK;
     if (!syms_dev || !nsyms_dev || !out_dev || !out_len_dev || !dropped_dev || n_packets > 0x7fffffffu) return LORAHIP_E_INVALID;
-    if (cfg->sf < 1 || cfg->sf > 16 || cfg->ppm < 0 || cfg->ppm > cfg->sf || cfg->rdd < 0 || cfg->rdd > 4 || cfg->data_length < 0) return LORAHIP_E_INVALID;
+    if (cfg->sf < 1 || cfg->sf > LORAHIP_SF_MAX || cfg->ppm < 0 || cfg->ppm > cfg->sf || cfg->rdd < 0 || cfg->rdd > 4 || cfg->data_length < 0) return LORAHIP_E_INVALID;
+    // An explicit header occupies the first 5 codewords of the first (PPM-codeword) block: with fewer than 5 bits per symbol the
+    // reference whitens `PPM - 5` (an unsigned short: ~65535) codewords past its buffer (LoRaDecoder.cpp:235, undefined behaviour).
+    // There is nothing to be identical to; refuse the configuration instead of corrupting device memory.
+    if (cfg->explicit_hdr && cfg->interleaving && (cfg->ppm ? cfg->ppm : cfg->sf) < 5)
+    {
+        setLastError("explicit header needs a symbol size (PPM) of at least 5 bits");
+        return LORAHIP_E_INVALID;
+    }
     if (sym_stride == 0 || sym_stride > size_t(decodeMaxSymbols()) || (out_stride & 1) || out_stride < 2 * (sym_stride + 8)) return LORAHIP_E_INVALID;
     const DeviceGuard guard(ctx->device);
     DecodeArgs a;

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64) decodePackets(const DecodeArgs a)
         if (PPM > sf || nsyms < LORAHIP_N_HDR_SYMBOLS) break;                                // :202 (throws), :208
         const int numSymbols = ((nsyms + (4 + a.rdd) - 1) / (4 + a.rdd)) * (4 + a.rdd);      // :210
         const int numCodewords = (numSymbols / (4 + a.rdd)) * PPM;                           // :211
-        if (numSymbols > LORAHIP_DEC_MAX_SYMBOLS || nsyms > a.symStride) { outLen = -2; break; }   // larger than this build / this row supports
+        if (numSymbols > LORAHIP_DEC_MAX_SYMBOLS || nsyms > a.symStride || numCodewords + 4 > LORAHIP_DEC_MAX_CODEWORDS) { outLen = -2; break; }   // larger than this build / this row supports
         int rdd = a.rdd;                                                                     // :215
         for (int i = 0; i < numSymbols; i++)                                                 // :218-222
         {

@@ -36,6 +36,8 @@ struct Channel
     std::vector<int16_t> outSymbols;
     size_t base, len, pos;  // stream placement in the device buffer, read position
     std::vector<lorahip_work_result> trace;
+    size_t traceStart;      // first trace entry of the last run
+    size_t portFft, portDec, portRaw;   // frames / samples the last run produced on the debug ports
 };
 
 //! one posted packet: its symbols are pktSyms[off, off+len) of the owning demod (flat storage: tens of thousands of
@@ -69,6 +71,11 @@ struct lorahip_demod
     // streaming path: device + pinned-host mirrors, grown on demand
     char *sDev, *sHost; size_t sBytes;
     char *dDense, *hDense; size_t denseBytes;   // the used part of the record arrays, packed for the copy back
+    hipEvent_t evK0, evK1;           // around the streaming kernel launches of a run (lorahip_demod_kernel_ms)
+    double kernelMs;
+    lorahip_demod_ports ports;       // level-3 debug ports (all pointers null: off)
+    bool portsOn, userTracing;
+    char *dPort; size_t dPortBytes;  // scratch of the port replay: window descriptors, replayed fft / dec windows
 };
 
 namespace {
@@ -164,7 +171,9 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
             r.value = hr.sym[i];
             r.power = hr.power[i]; r.power_avg = hr.pavg[i]; r.f_index = hr.fidx[i];
             r.snr = r.power - r.power_avg;                                      // :173
+            r.fine_idx_before = k.fineTuneIndex; r.fine_err_before = k.finefreqError;
             k.fineTuneIndex = hr.idxOut[i];
+            r.fine_idx_after = k.fineTuneIndex;
             if (k.state == ST_FRAMESYNC)
             {
                 const bool squelched = r.snr < dm->thresh;                      // :174
@@ -389,6 +398,8 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.symOut = reinterpret_cast<short *>(d + oSym);
     a.calls = dm->tracing ? reinterpret_cast<lorahip_work_result *>(d + oCalls) : nullptr;
     a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
+    a.fineA = ctx->fineGather ? nullptr : ctx->dFineA;
+    a.fineB = ctx->fineGather ? nullptr : ctx->dFineB;
     a.nChannels = unsigned(B);
     a.cap = int(cap);
     a.capPkt = int(capPkt);
@@ -399,15 +410,20 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 
     const size_t firstNewPacket = dm->packets.size();
     const Clock::time_point t1 = Clock::now();
+    dm->kernelMs = 0.0;
+    if (dm->evK0 == nullptr) { LORAHIP_TRY(hipEventCreate(&dm->evK0)); LORAHIP_TRY(hipEventCreate(&dm->evK1)); }
     while (true)
     {
         const Clock::time_point ta = Clock::now();
+        LORAHIP_TRY(hipEventRecord(dm->evK0, ctx->stream));
         LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
+        LORAHIP_TRY(hipEventRecord(dm->evK1, ctx->stream));
         // results back in two steps: the per-channel state and counts first (small), then only as many columns of the
         // [channel][capacity] record arrays as the fullest channel used -- the capacities are worst-case bounds, several
         // times what a run fills
         LORAHIP_TRY(hipMemcpyAsync(h + oState, d + oState, oPkt - oState, hipMemcpyDeviceToHost, ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+        { float ms = 0.0f; if (hipEventElapsedTime(&ms, dm->evK0, dm->evK1) == hipSuccess) dm->kernelMs += ms; }
         size_t maxSym = 0, maxPkt = 0, maxCalls = 0;
         for (size_t c = 0; c < B; c++)
         {
@@ -517,11 +533,145 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     return LORAHIP_OK;
 }
 
+/***********************************************************************
+ * Level-3 debug ports: the block's "raw" / "dec" / "fft" outputs (LoRaDemod.cpp:81-83). The run records, per work() call, the
+ * dechirp state it started from (lorahip_work_result.fine_*); the ports are then REPLAYED from that trace with the batch
+ * kernels -- the same arithmetic on the same inputs, hence the same bits -- and scattered into the caller's per-channel
+ * port streams. Off unless asked for: they triple the HBM traffic.
+ **********************************************************************/
+static int growPort(lorahip_demod *dm, const size_t bytes)
+{
+    if (bytes <= dm->dPortBytes) return LORAHIP_OK;
+    if (dm->dPort) { (void)hipFree(dm->dPort); dm->dPort = nullptr; dm->dPortBytes = 0; }
+    LORAHIP_TRY(hipMalloc((void **)&dm->dPort, bytes));
+    dm->dPortBytes = bytes;
+    return LORAHIP_OK;
+}
+
+static int fillPorts(lorahip_demod *dm, const float *iqDev)
+{
+    lorahip_ctx *ctx = dm->ctx;
+    const size_t N = dm->N, B = dm->B;
+    const lorahip_demod_ports &P = dm->ports;
+    const DeviceGuard guard(ctx->device);
+    struct Seg { long long src, dst; int len; };
+    std::vector<int64_t> wOff; std::vector<int32_t> wSel, wIdx; std::vector<float> wErr;
+    std::vector<Seg> segFft, segDec, segRaw;                      // src of fft/dec segments: window number * N (chunk-relative later)
+    for (size_t c = 0; c < B; c++)
+    {
+        Channel &k = dm->ch[c];
+        size_t decPos = 0, frame = 0;
+        for (size_t i = k.traceStart; i < k.trace.size(); i++, frame++)
+        {
+            const lorahip_work_result &r = k.trace[i];
+            const bool down = r.state_before == ST_DOWNCHIRP0 || r.state_before == ST_DOWNCHIRP1;   // _chirpTable == _downChirpTable
+            const size_t w = wOff.size();
+            wOff.push_back(int64_t(k.base + decPos));             // the run starts at the head of the channel's stream: pos == produced
+            wSel.push_back(down ? LORAHIP_CHIRP_DOWN : LORAHIP_CHIRP_UP);
+            wIdx.push_back(r.fine_idx_before);
+            wErr.push_back(r.fine_err_before);
+            const size_t total = size_t(r.consumed);
+            if (P.fft_dev && frame < P.fft_cap_frames) segFft.push_back({ (long long)(w * N), (long long)((c * P.fft_cap_frames + frame) * N), int(N) });
+            if (P.dec_dev)
+            {
+                const size_t n0 = total < N ? total : N;
+                if (decPos < P.dec_cap_samples)
+                    segDec.push_back({ (long long)(w * N), (long long)(c * P.dec_cap_samples + decPos), int(decPos + n0 <= P.dec_cap_samples ? n0 : P.dec_cap_samples - decPos) });
+            }
+            if (total == 2 * N && r.state_before == ST_FRAMESYNC)
+            {
+                // the sync check dechirped window 1 too (:189-206): it starts from the committed index and is part of what `dec` produces
+                const size_t w1 = wOff.size();
+                wOff.push_back(int64_t(k.base + decPos + N));
+                wSel.push_back(LORAHIP_CHIRP_UP);
+                wIdx.push_back(r.fine_idx_after);
+                wErr.push_back(r.fine_err_before);
+                if (P.dec_dev && decPos + N < P.dec_cap_samples)
+                    segDec.push_back({ (long long)(w1 * N), (long long)(c * P.dec_cap_samples + decPos + N),
+                                       int(decPos + 2 * N <= P.dec_cap_samples ? N : P.dec_cap_samples - decPos - N) });
+            }
+            decPos += total;
+        }
+        k.portFft = frame; k.portDec = decPos; k.portRaw = decPos;
+        if (P.raw_dev && decPos) segRaw.push_back({ (long long)k.base, (long long)(c * P.raw_cap_samples), int(decPos <= P.raw_cap_samples ? decPos : P.raw_cap_samples) });
+    }
+    hipStream_t st = ctx->stream;
+    auto scatter = [&](float *dst, const float *src, const std::vector<Seg> &segs, const size_t first, const size_t last, const long long srcBias, char *scratch) -> int
+    {
+        // segments [first, last) of `segs`, their src offsets rebased by srcBias
+        const size_t n = last - first;
+        if (n == 0) return LORAHIP_OK;
+        std::vector<long long> so(n), dof(n); std::vector<int> ln(n);
+        for (size_t i = 0; i < n; i++) { so[i] = segs[first + i].src - srcBias; dof[i] = segs[first + i].dst; ln[i] = segs[first + i].len; }
+        long long *dSo = reinterpret_cast<long long *>(scratch), *dDo = dSo + n;
+        int *dLn = reinterpret_cast<int *>(dDo + n);
+        LORAHIP_TRY(hipMemcpyAsync(dSo, so.data(), n * sizeof(long long), hipMemcpyHostToDevice, st));
+        LORAHIP_TRY(hipMemcpyAsync(dDo, dof.data(), n * sizeof(long long), hipMemcpyHostToDevice, st));
+        LORAHIP_TRY(hipMemcpyAsync(dLn, ln.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+        LORAHIP_TRY(launchCopySegments(reinterpret_cast<float2 *>(dst), reinterpret_cast<const float2 *>(src), dSo, dDo, dLn, n, st));
+        LORAHIP_TRY(hipStreamSynchronize(st));                  // the host vectors die with this scope
+        return LORAHIP_OK;
+    };
+    const size_t W = wOff.size();
+    // replay in chunks: at most ~256 MiB of replayed windows per port at a time
+    size_t chunk = (size_t(256) << 20) / (N * sizeof(cf32));
+    if (chunk < 64) chunk = 64;
+    if (chunk > W) chunk = W;
+    const size_t descBytes = align256(chunk * 2 * (2 * sizeof(long long) + sizeof(int)) + segRaw.size() * (2 * sizeof(long long) + sizeof(int)) + 64);
+    const size_t winBytes = align256(chunk * N * sizeof(cf32));
+    const size_t inBytes = align256(chunk * sizeof(int64_t)) + 3 * align256(chunk * sizeof(int32_t));
+    const size_t outBytes = align256(chunk * sizeof(uint16_t)) + 3 * align256(chunk * sizeof(float));
+    { const int rc = growPort(dm, descBytes + 2 * winBytes + inBytes + outBytes); if (rc != LORAHIP_OK) return rc; }
+    char *cur = dm->dPort;
+    char *dDesc = cur; cur += descBytes;
+    float *tFft = reinterpret_cast<float *>(cur); cur += winBytes;
+    float *tDec = reinterpret_cast<float *>(cur); cur += winBytes;
+    int64_t *dOff = reinterpret_cast<int64_t *>(cur); cur += align256(chunk * sizeof(int64_t));
+    int32_t *dSel = reinterpret_cast<int32_t *>(cur); cur += align256(chunk * sizeof(int32_t));
+    int32_t *dIdx = reinterpret_cast<int32_t *>(cur); cur += align256(chunk * sizeof(int32_t));
+    float *dErr = reinterpret_cast<float *>(cur); cur += align256(chunk * sizeof(int32_t));
+    uint16_t *dSym = reinterpret_cast<uint16_t *>(cur); cur += align256(chunk * sizeof(uint16_t));
+    float *dPow = reinterpret_cast<float *>(cur); cur += align256(chunk * sizeof(float));
+    float *dAvg = reinterpret_cast<float *>(cur); cur += align256(chunk * sizeof(float));
+    float *dFi = reinterpret_cast<float *>(cur);
+    if (P.raw_dev) { const int rc = scatter(P.raw_dev, iqDev, segRaw, 0, segRaw.size(), 0, dDesc); if (rc != LORAHIP_OK) return rc; }
+    size_t fi = 0, di = 0;
+    for (size_t w0 = 0; w0 < W && (P.fft_dev || P.dec_dev); w0 += chunk)
+    {
+        const size_t n = W - w0 < chunk ? W - w0 : chunk;
+        LORAHIP_TRY(hipMemcpyAsync(dOff, wOff.data() + w0, n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        LORAHIP_TRY(hipMemcpyAsync(dSel, wSel.data() + w0, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        LORAHIP_TRY(hipMemcpyAsync(dIdx, wIdx.data() + w0, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        LORAHIP_TRY(hipMemcpyAsync(dErr, wErr.data() + w0, n * sizeof(float), hipMemcpyHostToDevice, st));
+        lorahip_batch b;
+        std::memset(&b, 0, sizeof(b));
+        b.struct_size = sizeof(b);
+        b.iq = iqDev; b.n_windows = n; b.offsets = dOff; b.chirp_sel = dSel; b.fine_idx0 = dIdx; b.fine_err = dErr;
+        b.sym = dSym; b.power = dPow; b.power_avg = dAvg; b.f_index = dFi;
+        b.fft_out = P.fft_dev ? tFft : nullptr;
+        b.dec_out = P.dec_dev ? tDec : nullptr;
+        const int rc = lorahip_detect_batch(ctx, &b);
+        if (rc != LORAHIP_OK) return rc;
+        const long long lo = (long long)(w0 * N), hi = (long long)((w0 + n) * N);
+        size_t f1 = fi; while (f1 < segFft.size() && segFft[f1].src < hi) f1++;
+        size_t d1 = di; while (d1 < segDec.size() && segDec[d1].src < hi) d1++;
+        int rc2 = scatter(P.fft_dev, tFft, segFft, fi, f1, lo, dDesc);
+        if (rc2 == LORAHIP_OK) rc2 = scatter(P.dec_dev, tDec, segDec, di, d1, lo, dDesc);
+        if (rc2 != LORAHIP_OK) return rc2;
+        fi = f1; di = d1;
+    }
+    return LORAHIP_OK;
+}
+
 static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(dm->ctx->sf));
     if (stream && !streamAvailable(dm->ctx->sf)) { setLastError("no streaming kernel for this SF"); return LORAHIP_E_INVALID; }
-    return stream ? runStream(dm, iqDev, roundsOut) : runRounds(dm, iqDev, roundsOut);
+    for (auto &k : dm->ch) { k.traceStart = k.trace.size(); k.portFft = k.portDec = k.portRaw = 0; }
+    dm->tracing = dm->userTracing || dm->portsOn;               // the port replay reads the per-call trace
+    const int rc = stream ? runStream(dm, iqDev, roundsOut) : runRounds(dm, iqDev, roundsOut);
+    if (rc != LORAHIP_OK || !dm->portsOn) return rc;
+    return fillPorts(dm, iqDev);
 }
 
 } // namespace
@@ -535,6 +685,8 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     lorahip_demod *dm = new (std::nothrow) lorahip_demod();
     if (dm == nullptr) return LORAHIP_E_NOMEM;
     dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
+    dm->evK0 = nullptr; dm->evK1 = nullptr; dm->kernelMs = 0.0;
+    std::memset(&dm->ports, 0, sizeof(dm->ports)); dm->portsOn = false; dm->userTracing = false; dm->dPort = nullptr; dm->dPortBytes = 0;
     dm->mode = 0; dm->sDev = nullptr; dm->sHost = nullptr; dm->sBytes = 0; dm->dDense = nullptr; dm->hDense = nullptr; dm->denseBytes = 0;
     int rc = lorahip_create(&dm->ctx, device, sf);
     if (rc != LORAHIP_OK) { delete dm; return rc; }
@@ -545,8 +697,13 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->workCalls = 0;
     dm->ch.resize(n_channels);
     dm->stageBytes = carve(nullptr, n_channels).total;
-    if (hipMalloc((void **)&dm->d, dm->stageBytes) != hipSuccess ||
-        hipHostMalloc((void **)&dm->h, dm->stageBytes, hipHostMallocDefault) != hipSuccess)
+    bool staged;
+    {
+        const DeviceGuard guard(device);                    // lorahip_create() restored the caller's device: allocate on OURS
+        staged = hipMalloc((void **)&dm->d, dm->stageBytes) == hipSuccess &&
+                 hipHostMalloc((void **)&dm->h, dm->stageBytes, hipHostMallocDefault) == hipSuccess;
+    }
+    if (!staged)
     {
         lorahip_demod_destroy(dm);
         return LORAHIP_E_NOMEM;
@@ -559,7 +716,8 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
 void lorahip_demod_destroy(lorahip_demod *dm)
 {
     if (dm == nullptr) return;
-    if (dm->ctx) (void)hipSetDevice(dm->ctx->device);
+    {
+    const DeviceGuard guard(dm->ctx ? dm->ctx->device : 0);   // the caller's current device is restored on return
     if (dm->d) (void)hipFree(dm->d);
     if (dm->h) (void)hipHostFree(dm->h);
     if (dm->dIq) (void)hipFree(dm->dIq);
@@ -567,6 +725,10 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->sHost) (void)hipHostFree(dm->sHost);
     if (dm->dDense) (void)hipFree(dm->dDense);
     if (dm->hDense) (void)hipHostFree(dm->hDense);
+    if (dm->dPort) (void)hipFree(dm->dPort);
+    if (dm->evK0) (void)hipEventDestroy(dm->evK0);
+    if (dm->evK1) (void)hipEventDestroy(dm->evK1);
+    }
     lorahip_destroy(dm->ctx);
     delete dm;
 }
@@ -603,6 +765,12 @@ int lorahip_demod_set_stream(lorahip_demod *dm, void *hip_stream)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
     return lorahip_set_stream(dm->ctx, hip_stream);
+}
+
+int lorahip_demod_set_fine_gather(lorahip_demod *dm, const int enable)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    return lorahip_set_fine_gather(dm->ctx, enable);
 }
 
 int lorahip_demod_activate(lorahip_demod *dm)
@@ -723,6 +891,8 @@ void lorahip_demod_clear_packets(lorahip_demod *dm) { if (dm) { dm->packets.clea
 
 int64_t lorahip_demod_work_calls(const lorahip_demod *dm) { return dm ? dm->workCalls : 0; }
 
+double lorahip_demod_kernel_ms(const lorahip_demod *dm) { return dm ? dm->kernelMs : 0.0; }
+
 int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
 {
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
@@ -732,8 +902,9 @@ int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
 int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
-    dm->tracing = enable != 0;
-    if (!dm->tracing) for (auto &k : dm->ch) k.trace.clear();
+    dm->userTracing = enable != 0;
+    dm->tracing = dm->userTracing || dm->portsOn;
+    if (!dm->userTracing) for (auto &k : dm->ch) { k.trace.clear(); k.traceStart = 0; }
     return LORAHIP_OK;
 }
 
@@ -741,6 +912,75 @@ size_t lorahip_demod_trace_len(const lorahip_demod *dm, const size_t channel)
 {
     if (dm == nullptr || channel >= dm->B) return 0;
     return dm->ch[channel].trace.size();
+}
+
+int lorahip_demod_set_ports(lorahip_demod *dm, const lorahip_demod_ports *p)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (p == nullptr) { std::memset(&dm->ports, 0, sizeof(dm->ports)); dm->portsOn = false; }
+    else
+    {
+        if (p->struct_size != sizeof(lorahip_demod_ports)) return LORAHIP_E_INVALID;
+        if ((p->fft_dev && !p->fft_cap_frames) || (p->dec_dev && !p->dec_cap_samples) || (p->raw_dev && !p->raw_cap_samples)) return LORAHIP_E_INVALID;
+        dm->ports = *p;
+        dm->portsOn = p->fft_dev || p->dec_dev || p->raw_dev;
+    }
+    dm->tracing = dm->userTracing || dm->portsOn;
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_port_counts(const lorahip_demod *dm, const size_t channel, size_t *fft_frames, size_t *dec_samples, size_t *raw_samples)
+{
+    if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
+    const Channel &k = dm->ch[channel];
+    if (fft_frames) *fft_frames = k.portFft;
+    if (dec_samples) *dec_samples = k.portDec;
+    if (raw_samples) *raw_samples = k.portRaw;
+    return LORAHIP_OK;
+}
+
+//! the label LoRaDemod::work() posts for one call (LoRaDemod.cpp:213,220-224,232,245,258,282,302-305): "" = none
+static std::string labelOf(const lorahip_work_result &r, const size_t N, const float thresh, size_t &symCount)
+{
+    char buf[64];
+    buf[0] = 0;
+    switch (r.state_before)
+    {
+    case ST_FRAMESYNC:
+        if (size_t(r.consumed) == 2 * N) return "SYNC";                                           // :213
+        if (!(r.snr < thresh)) { std::snprintf(buf, sizeof(buf), "P %.4f", double(r.f_index)); return buf; }   // :220-224 (fixed, precision 4)
+        return "";                                                                                // :232
+    case ST_DOWNCHIRP0: return "DC";                                                              // :245
+    case ST_DOWNCHIRP1: return "";                                                                // :258
+    case ST_QUARTERCHIRP: symCount = 0; return "QC";                                              // :281-282
+    default:
+        symCount++;                                                                               // :290
+        std::snprintf(buf, sizeof(buf), "S%zu %.4f", symCount, double(r.f_index));                // :302-305
+        return buf;
+    }
+}
+
+int lorahip_demod_get_labels(const lorahip_demod *dm, const size_t channel, char *buf, const size_t cap, size_t *n_calls, size_t *bytes)
+{
+    if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
+    const auto &t = dm->ch[channel].trace;
+    // _symCount is only reset at QUARTERCHIRP (:279); a trace that starts inside a packet continues the count the channel held then
+    size_t symCount = 0;
+    if (!t.empty() && t.front().state_before == ST_DATASYMBOLS)
+    {
+        size_t inTrace = 0;
+        for (const auto &r : t) { if (r.state_before != ST_DATASYMBOLS) break; inTrace++; if (r.packet_len) { symCount = size_t(r.packet_len) - inTrace; break; } }
+    }
+    size_t used = 0;
+    for (const auto &r : t)
+    {
+        const std::string s = labelOf(r, dm->N, dm->thresh, symCount);
+        if (buf && used + s.size() + 1 <= cap) std::memcpy(buf + used, s.c_str(), s.size() + 1);
+        used += s.size() + 1;
+    }
+    if (n_calls) *n_calls = t.size();
+    if (bytes) *bytes = used;
+    return (buf == nullptr || used <= cap) ? LORAHIP_OK : LORAHIP_E_INVALID;
 }
 
 int lorahip_demod_get_trace(const lorahip_demod *dm, const size_t channel, lorahip_work_result *out, const size_t cap)

@@ -60,6 +60,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     v2f *sCh = sTw + C::TWN;                                                          // [CH_ELEMS]
     v2f *sX = sCh + C::CH_ELEMS;                                                      // [WAVES][XW]
     TailRec *sTail = reinterpret_cast<TailRec *>(sX + WAVES * XW);                       // [WAVES]
+    double2 *sFine = reinterpret_cast<double2 *>(sTail + WAVES);                         // split fine-tune tables (non-UNI kernels)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR
@@ -80,6 +81,9 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     K::loadTwR(twR, reinterpret_cast<const v2f *>(ft.twStage), t);
     typename K::TwM twM;
     K::loadTwM(twM, reinterpret_cast<const v2f *>(ft.twStage), t);
+    FineLds fl;
+    fl.A = nullptr; fl.B = nullptr;
+    if (!UNI) fl = fineLoadLds<C::LOG2N>(sFine, a.fineA, a.fineB, threadIdx.x, blockDim.x);
 
     // chirp table values of this lane's sample positions. One table serves both selections:
     // _upChirpTable = conj(_downChirpTable) entry by entry (LoRaDemod.cpp:103-104)
@@ -151,14 +155,28 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             for (int u = 0; u < VEC; u++) x[r][u] = xn[r][u];
         if (C::PREFETCH == 2) issueLoads(set + waveCount < setEnd ? set + waveCount : nSets - 1);
 
-        // ---- fine-tune index chain for windows whose index moves (LoRaDemod.cpp:160-162) -------------
+        // ---- fine-tune indices of this lane's samples for windows whose index moves (LoRaDemod.cpp:160-162): closed form
+        // (lorahip_fine.h); a wave that holds a window where the form does not apply walks the exact chain instead
         int *sIdx = reinterpret_cast<int *>(X) + wsub * N;   // aliases the exchange region (free until phase 0 ends)
-        if (!UNI && anyMoving)
+        unsigned yv[R][VEC];
+        if constexpr (!UNI) if (anyMoving)
         {
-            const int idxEnd = K::fineChain(idx0, moving ? d : 0.0f, t, sIdx);
+            const FinePlan pl = finePlan(moving ? d : 0.0f, K::M);
+            const unsigned ymax = fineLaneIndices<C::LOG2N, VEC, T, R>(idx0, pl, t, yv);
+            int idxEnd = fineEndIndex(idx0, pl, C::LOG2N, C::LOG2N + 7);
+            if (__any(!pl.regular || ymax == (unsigned)K::M))
+            {
+                idxEnd = K::fineChain(idx0, moving ? d : 0.0f, t, sIdx);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int u = 0; u < VEC; u++) yv[r][u] = (unsigned)sIdx[K::idxSlot(VEC * t + u + VEC * T * r)];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             if (moving && t == 0 && a.fineIdxOut && active) a.fineIdxOut[w] = idxEnd;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
         if (!moving && t == 0 && active && a.fineIdxOut) a.fineIdxOut[w] = idx0;
 
@@ -192,7 +210,11 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
                 {
                     const v2f c = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
                     v2f f = fconst;
-                    if (anyMoving && moving) f = gFine[sIdx[K::idxSlot(VEC * t + u + VEC * T * r)]];
+                    if (anyMoving)
+                    {
+                        const unsigned yi = yv[r][u];     // = idx0 in the windows that do not move
+                        f = fl.A ? fineEval<fineSplitLog2H(C::LOG2N)>(yi, fl) : gFine[yi];
+                    }
                     const v2f y = cmulv(cmulv(x[r][u], c), f);
                     x[r][u] = dechirp ? y : x[r][u];
                 }
@@ -254,17 +276,18 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
  * launch
  **********************************************************************/
 template <class C>
-static size_t smemBytes()
+static size_t smemBytes(const bool withFine)
 {
     constexpr int WAVES = 4;
-    return size_t(C::TWN + C::CH_ELEMS) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2) + size_t(WAVES) * sizeof(TailRec);
+    return size_t(C::TWN + C::CH_ELEMS) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2) + size_t(WAVES) * sizeof(TailRec) +
+           (withFine ? FineDims<C::LOG2N>::BYTES : 0);
 }
 
 template <class C, bool DBG, bool UNI>
 static hipError_t launchOne(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
     constexpr int WAVES = 4;
-    const size_t smem = smemBytes<C>();
+    const size_t smem = smemBytes<C>(!UNI);
     static unsigned long long attrDone = 0;
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(detectFast<C, DBG, UNI>), smem, attrDone);

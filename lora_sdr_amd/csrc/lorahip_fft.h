@@ -2,6 +2,7 @@
 // lorahip_wide.hip: a window across the wavefronts of a workgroup). Numerics contract: lorahip_device.h.
 #pragma once
 #include "lorahip_device.h"
+#include "lorahip_fine.h"
 
 namespace lorahip {
 
@@ -188,6 +189,65 @@ __device__ __forceinline__ int fineChainGroup(const int idx0, const float d, con
 }
 
 #define MAKE2(X, Y) (v2f{(X), (Y)})
+
+/***********************************************************************
+ * The fine-tune multiplier without the table gather (lorahip_fine.h): split tables in LDS, closed-form indices.
+ **********************************************************************/
+struct FineLds { const double2 *A, *B; };              // LDS copies of the split tables; A == nullptr: gather from the table in HBM
+
+//! entries of the two split tables for N = 2^LOG2N
+template <int LOG2N> struct FineDims
+{
+    static constexpr int LOG2M = LOG2N + 7, LH = fineSplitLog2H(LOG2N);
+    static constexpr int NA = 1 << (LOG2M - LH), NB = 1 << LH;
+    static constexpr size_t BYTES = size_t(NA + NB) * sizeof(double2);
+};
+
+//! workgroup copy of the split tables into LDS (call before a __syncthreads())
+template <int LOG2N>
+__device__ __forceinline__ FineLds fineLoadLds(double2 *dst, const double2 *gA, const double2 *gB, const int tid, const int nThreads)
+{
+    typedef FineDims<LOG2N> D;
+    FineLds f;
+    f.A = nullptr; f.B = nullptr;
+    if (gA == nullptr) return f;
+    for (int i = tid; i < D::NA; i += nThreads) dst[i] = gA[i];
+    for (int i = tid; i < D::NB; i += nThreads) dst[D::NA + i] = gB[i];
+    f.A = dst; f.B = dst + D::NA;
+    return f;
+}
+
+//! _fineTuneTable[y] from the split tables: one fp64 complex product, rounded to float (checked entry by entry on the host)
+template <int LH>
+__device__ __forceinline__ v2f fineEval(const unsigned y, const FineLds &s)
+{
+    const double2 a = s.A[y >> LH], b = s.B[y & ((1u << LH) - 1u)];
+    const double re = __builtin_fma(a.x, b.x, -(a.y * b.y));
+    const double im = __builtin_fma(a.x, b.y, a.y * b.x);
+    return v2f{(float)re, (float)im};
+}
+
+//! closed-form fine-tune indices of a lane's own samples n = VEC*t + u + VEC*T*r (lorahip_fine.h); returns the largest one
+template <int LOG2N, int VEC, int T, int R>
+__device__ __forceinline__ unsigned fineLaneIndices(const int idx0, const FinePlan &p, const int t, unsigned (&y)[R][VEC])
+{
+    constexpr int LOG2M = LOG2N + 7;
+    const unsigned Q = fineReduce(unsigned(VEC * T) * p.q, p, LOG2M);          // VEC*T*q < N*(M+1) < 2^32
+    unsigned ymax = 0;
+#pragma unroll
+    for (int u = 0; u < VEC; u++)
+    {
+        unsigned v = fineReduce(unsigned(idx0) + __umul24(unsigned(VEC * t + u), p.q), p, LOG2M);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+        {
+            y[r][u] = v;
+            ymax = v > ymax ? v : ymax;
+            v = fineAdvance(v, Q, p);
+        }
+    }
+    return ymax;
+}
 
 struct TailRec { unsigned w[64]; int idx[64]; float val[64]; double tot[64]; v2f l[64]; v2f r[64]; };
 

@@ -32,9 +32,10 @@ template <int N>
 __device__ __forceinline__ void frameStep(StreamState &st, const StreamArgs &s, StreamOut &o, const bool writer,
                                           const int value, const float power, const float powerAvg, const float snr,
                                           const float fIndex, const bool squelched, const bool syncd, const bool match0,
-                                          const bool match1)
+                                          const bool match1, const int fineIdxBefore, const float fineErrBefore)
 {
     const int stateBefore = st.state;
+    const int fineIdxAfter = st.fineTuneIndex;      // the caller has committed window 0's steps (:160-162)
     int total = 0, packetLen = 0, signals = 0, sigError = 0;
     switch (st.state)
     {
@@ -97,6 +98,7 @@ __device__ __forceinline__ void frameStep(StreamState &st, const StreamArgs &s, 
         r.sig_error = sigError;
         r.sig_power = signals ? power : 0.0f;
         r.sig_snr = signals ? snr : 0.0f;
+        r.fine_idx_before = fineIdxBefore; r.fine_idx_after = fineIdxAfter; r.fine_err_before = fineErrBefore; r.reserved = 0;
         o.out[o.calls] = r;
     }
     o.calls++;

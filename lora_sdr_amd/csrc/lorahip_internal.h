@@ -18,6 +18,9 @@ struct HostTables
     std::vector<cf32> up, down, fine, twiddle;
 };
 void buildHostTables(int sf, HostTables &t, bool wantFine);
+//! the fp64 factor tables of lorahip_fine.h (interleaved re, im) for the given fine-tune table; false (and empty tables) unless
+//! EVERY entry of `fine` is reproduced bit for bit by the device's evaluation order (mul, fma, convert)
+bool buildFineSplit(int sf, const std::vector<cf32> &fine, std::vector<double> &A, std::vector<double> &B);
 
 //! kernel argument block (device pointers), one launch = nWindows independent windows
 struct DetectArgs
@@ -40,6 +43,8 @@ struct DetectArgs
     const float2 *down;
     const float2 *fine;
     const float2 *tw;
+    const double2 *fineA;       // split of the fine-tune table (lorahip_fine.h), fp64; nullptr: gather from `fine`
+    const double2 *fineB;
     unsigned nWindows;
     float powerScale;           // float(20*log10(double(N)))  LoRaDetector.hpp:18
 };
@@ -87,6 +92,7 @@ struct StreamArgs
     int *nPkt;                  // [nChannels]
     int capPkt;
     const float2 *down, *fine, *twStage;
+    const double2 *fineA, *fineB;   // split of the fine-tune table (lorahip_fine.h); nullptr: gather from `fine`
     unsigned nChannels;
     int cap;
     float powerScale;
@@ -122,6 +128,8 @@ bool streamAvailable(int sf);
 hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchStreamWide(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchCompactRows(void *dst, const void *src, size_t rows, size_t srcPitchBytes, size_t rowBytes, hipStream_t stream);
+hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *srcOff, const long long *dstOff, const int *len, size_t nSeg,
+                              hipStream_t stream);
 hipError_t launchSynth(int sf, float2 *iq, const unsigned short *sym, size_t nWindows,
                        float ampl, float sigma, unsigned long long seed, hipStream_t stream);
 
@@ -166,6 +174,8 @@ struct lorahip_ctx
     hipStream_t ownStream;
     hipStream_t stream;
     float2 *dUp, *dDown, *dFine, *dTw, *dTwStage;
+    double2 *dFineA, *dFineB;   // nullptr when the split did not verify on this host (kernels gather then)
+    int fineGather;             // A/B switch (lorahip_set_fine_gather): read the fine-tune table itself even though the split verified
     int cuCount;
     hipEvent_t ev0, ev1;
     float powerScale;

@@ -31,6 +31,7 @@ demodStream(const StreamArgs s)
     v2f *sTw = reinterpret_cast<v2f *>(smemRaw);          // [TWN]
     v2f *sCh = sTw + C::TWN;                                // [N] down-chirp table (the up-chirp is its conjugate)
     v2f *sX = sCh + N;                                      // [WAVES][XW]
+    double2 *sFine = reinterpret_cast<double2 *>(sX + WAVES * XW);   // split fine-tune tables (lorahip_fine.h)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -45,6 +46,7 @@ demodStream(const StreamArgs s)
     K::loadTwR(twR, reinterpret_cast<const v2f *>(s.twStage), t);
     typename K::TwM twM;
     K::loadTwM(twM, reinterpret_cast<const v2f *>(s.twStage), t);
+    const FineLds fl = fineLoadLds<C::LOG2N>(sFine, s.fineA, s.fineB, threadIdx.x, blockDim.x);
     __syncthreads();
 
     // ---- this lane group's channel and its state (replicated in the T lanes) ----------------------
@@ -68,12 +70,27 @@ demodStream(const StreamArgs s)
         int *sIdx = reinterpret_cast<int *>(X) + wsub * N;
         idxEnd = idx0;
         const bool anyMoving = __any(moving);
+        unsigned yv[R][VEC];
         if (anyMoving)
         {
-            const int e = K::fineChain(idx0, moving ? d : 0.0f, t, sIdx);
+            // closed-form indices of this lane's samples (lorahip_fine.h); a wave that holds a channel where the form does not
+            // apply walks the exact chain instead
+            const FinePlan pl = finePlan(moving ? d : 0.0f, K::M);
+            const unsigned ymax = fineLaneIndices<C::LOG2N, VEC, T, R>(idx0, pl, t, yv);
+            int e = fineEndIndex(idx0, pl, C::LOG2N, C::LOG2N + 7);
+            if (__any(!pl.regular || ymax == (unsigned)K::M))
+            {
+                e = K::fineChain(idx0, moving ? d : 0.0f, t, sIdx);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int u = 0; u < VEC; u++) yv[r][u] = (unsigned)sIdx[K::idxSlot(VEC * t + u + VEC * T * r)];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             if (moving) idxEnd = e;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
         v2f cw[R][VEC];
         K::chirpFromLds(cw, sCh, t);
@@ -86,7 +103,7 @@ demodStream(const StreamArgs s)
             {
                 const v2f cv = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
                 v2f f = fconst;
-                if (anyMoving && moving) f = gFine[sIdx[K::idxSlot(VEC * t + u + VEC * T * r)]];
+                if (anyMoving) f = fl.A ? fineEval<fineSplitLog2H(C::LOG2N)>(yv[r][u], fl) : gFine[yv[r][u]];     // = the entry at idx0 where nothing moves
                 x[r][u] = cmulv(cmulv(x[r][u], cv), f);
             }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -115,6 +132,8 @@ demodStream(const StreamArgs s)
         // ---- window 0 (:157-172) ----
         int value, idxEnd;
         float power, powerAvg, fIndex;
+        const int fineIdxBefore = st.fineTuneIndex;
+        const float fineErrBefore = st.finefreqError;
         detect(live, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd);
         const float snr = power - powerAvg;                                             // :173
         const bool squelched = snr < s.thresh;                                          // :174
@@ -139,7 +158,7 @@ demodStream(const StreamArgs s)
         }
 
         // ---- the frame machine (:176-312) ----
-        if (live) frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1);
+        if (live) frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
     }
     if (mine && t == 0)
     {
@@ -154,7 +173,7 @@ template <class C>
 static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
 {
     constexpr int WAVES = 4;
-    const size_t smem = size_t(C::TWN + C::N) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2);
+    const size_t smem = size_t(C::TWN + C::N) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2) + FineDims<C::LOG2N>::BYTES;
     static unsigned long long attrDone = 0;
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C>), smem, attrDone);
@@ -195,6 +214,29 @@ hipError_t launchCompactRows(void *dst, const void *src, const size_t rows, cons
     const unsigned grid = unsigned(total / 256 + 1 > 65536 ? 65536 : total / 256 + 1);
     hipLaunchKernelGGL(compactRows, dim3(grid), dim3(256), 0, stream, static_cast<unsigned short *>(dst), static_cast<const unsigned short *>(src),
                        rows, srcPitchBytes / 2, rowBytes / 2);
+    return hipGetLastError();
+}
+
+//! nSeg independent copies of cf32 runs: segment i moves len[i] elements from src + srcOff[i] to dst + dstOff[i] (the level-3
+//! debug ports: replayed windows -> the per-channel port streams)
+__global__ void copySegments(float2 *__restrict__ dst, const float2 *__restrict__ src, const long long *__restrict__ srcOff,
+                             const long long *__restrict__ dstOff, const int *__restrict__ len, const unsigned nSeg)
+{
+    for (unsigned i = blockIdx.x; i < nSeg; i += gridDim.x)
+    {
+        const float2 *s = src + srcOff[i];
+        float2 *d = dst + dstOff[i];
+        const int n = len[i];
+        for (int j = threadIdx.x; j < n; j += blockDim.x) d[j] = s[j];
+    }
+}
+
+hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *srcOff, const long long *dstOff, const int *len, const size_t nSeg,
+                              hipStream_t stream)
+{
+    if (nSeg == 0) return hipSuccess;
+    const unsigned grid = unsigned(nSeg > 65535 ? 65535 : nSeg);
+    hipLaunchKernelGGL(copySegments, dim3(grid), dim3(256), 0, stream, dst, src, srcOff, dstOff, len, unsigned(nSeg));
     return hipGetLastError();
 }
 

@@ -116,10 +116,12 @@ __device__ __forceinline__ int fineChainBlock(const int idx0, const float d, con
 template <class C>
 struct WideSmem
 {
-    static constexpr size_t bytes()
+    //! everything but the split fine-tune tables (16-byte multiple: the tables follow)
+    static constexpr size_t base()
     {
-        return size_t(C::TWN + C::CH_ELEMS + C::WPB * C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + size_t(C::WPB) * 2 * sizeof(float2) + sizeof(TailRec) + size_t(C::WPB) * 12 * sizeof(int);
+        return (size_t(C::TWN + C::CH_ELEMS + C::WPB * C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + size_t(C::WPB) * 2 * sizeof(float2) + sizeof(TailRec) + size_t(C::WPB) * 12 * sizeof(int) + 15) & ~size_t(15);
     }
+    static constexpr size_t bytes(const bool withFine) { return base() + (withFine ? FineDims<C::LOG2N>::BYTES : 0); }
 };
 
 template <class C, bool DBG, bool UNI>
@@ -139,6 +141,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
     v2f *sNb = reinterpret_cast<v2f *>(sRed + 4);                        // [WPB][2]: bins left/right of the peak
     TailRec &tr = *reinterpret_cast<TailRec *>(sNb + WPB * 2);
     int *sChain = reinterpret_cast<int *>(&tr + 1) + (threadIdx.x >> LOG2T) * 12;    // fineChainBlock scratch of this window
+    double2 *sFine = reinterpret_cast<double2 *>(smemRaw + WideSmem<C>::base());     // split fine-tune tables (non-UNI kernels)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -173,6 +176,10 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
                 slot += 3;
             }
     }
+
+    FineLds fl;
+    fl.A = nullptr; fl.B = nullptr;
+    if (!UNI) fl = fineLoadLds<LOG2N>(sFine, a.fineA, a.fineB, tid, C::BLOCK);
 
     // chirp table values of this lane's sample positions: _upChirpTable = conj(_downChirpTable) (LoRaDemod.cpp:103-104)
     const bool perWindowSel = !UNI && a.chirpSel != nullptr;
@@ -271,15 +278,28 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
 #pragma unroll
             for (int u = 0; u < VEC; u++) x[r][u] = xn[r][u];
 
-        // ---- fine-tune index chain for windows whose index moves (LoRaDemod.cpp:160-162) ------
+        // ---- fine-tune indices of this lane's samples for windows whose index moves (LoRaDemod.cpp:160-162): closed form
+        // (lorahip_fine.h); a workgroup that holds a window where the form does not apply walks the exact chain instead
         int *sIdx = reinterpret_cast<int *>(X);             // aliases the exchange region (free until phase 0 ends)
-        bool anyMoving = false;
-        if (!UNI)
+        bool anyMoving = false, usedChain = false;
+        unsigned yv[R][VEC];
+        if constexpr (!UNI)
         {
             anyMoving = __syncthreads_or(moving);
             if (anyMoving)
             {
-                const int idxEnd = fineChainBlock<T, M>(idx0, moving ? d : 0.0f, t, t >> 6, sIdx, sChain);
+                const FinePlan pl = finePlan(moving ? d : 0.0f, M);
+                const unsigned ymax = fineLaneIndices<LOG2N, VEC, T, R>(idx0, pl, t, yv);
+                int idxEnd = fineEndIndex(idx0, pl, LOG2N, LOG2N + 7);
+                usedChain = __syncthreads_or(!pl.regular || ymax == (unsigned)M);
+                if (usedChain)
+                {
+                    idxEnd = fineChainBlock<T, M>(idx0, moving ? d : 0.0f, t, t >> 6, sIdx, sChain);
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+#pragma unroll
+                        for (int u = 0; u < VEC; u++) yv[r][u] = (unsigned)sIdx[chainSlot(VEC * t + u + VEC * T * r)];
+                }
                 if (moving && t == 0 && a.fineIdxOut && active) a.fineIdxOut[w] = idxEnd;
             }
         }
@@ -325,11 +345,15 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
                 {
                     const v2f c = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
                     v2f f = fconst;
-                    if (anyMoving && moving) f = gFine[sIdx[chainSlot(VEC * t + u + VEC * T * r)]];
+                    if (anyMoving)
+                    {
+                        const unsigned yi = yv[r][u];     // = idx0 in the windows that do not move
+                        f = fl.A ? fineEval<fineSplitLog2H(LOG2N)>(yi, fl) : gFine[yi];
+                    }
                     const v2f y = cmulv(cmulv(x[r][u], c), f);
                     x[r][u] = dechirp ? y : x[r][u];
                 }
-            if (anyMoving) __syncthreads();               // sIdx is about to be overwritten by exchange 0
+            if (usedChain) __syncthreads();               // sIdx is about to be overwritten by exchange 0
         }
         if (DBG && a.decOut && active)
         {
@@ -468,7 +492,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
 template <class C, bool DBG, bool UNI>
 static hipError_t launchOneWide(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
-    const size_t smem = WideSmem<C>::bytes();
+    const size_t smem = WideSmem<C>::bytes(!UNI);
     static unsigned long long attrDone = 0;
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(detectWide<C, DBG, UNI>), smem, attrDone);
@@ -602,6 +626,7 @@ demodStreamWide(const StreamArgs s)
     RedRec *sRed = reinterpret_cast<RedRec *>(X + C::XW);                // [WPWIN]
     v2f *sNb = reinterpret_cast<v2f *>(sRed + 4);                        // [2]
     int *sChain = reinterpret_cast<int *>(sNb + 2);                      // [12] fineChainBlock scratch
+    double2 *sFine = reinterpret_cast<double2 *>(sChain + 12);           // split fine-tune tables (lorahip_fine.h)
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -628,6 +653,7 @@ demodStreamWide(const StreamArgs s)
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int u = 0; u < VEC; u++) ch[r][u] = reinterpret_cast<const v2f *>(s.down)[VEC * t + u + VEC * T * r];
+    const FineLds fl = fineLoadLds<LOG2N>(sFine, s.fineA, s.fineB, t, T);
     __syncthreads();
 
     const unsigned c = blockIdx.x;                         // one channel per workgroup
@@ -654,12 +680,26 @@ demodStreamWide(const StreamArgs s)
             else x[r][0] = *p;
         }
         const float d = err * (float)LORAHIP_FINE_STEPS;
-        const bool moving = d != 0.0f;
+        const bool moving = d != 0.0f;                       // workgroup-uniform
         int *sIdx = reinterpret_cast<int *>(X);
         idxEnd = idx0;
+        unsigned yv[R][VEC];
+        bool usedChain = false;
         if (moving)
         {
-            idxEnd = fineChainBlock<T, M>(idx0, d, t, t >> 6, sIdx, sChain);
+            // closed-form indices of this lane's samples (lorahip_fine.h); the exact chain where the form does not apply
+            const FinePlan pl = finePlan(d, M);
+            const unsigned ymax = fineLaneIndices<LOG2N, VEC, T, R>(idx0, pl, t, yv);
+            idxEnd = fineEndIndex(idx0, pl, LOG2N, LOG2N + 7);
+            usedChain = !pl.regular || __syncthreads_or(ymax == (unsigned)M);
+            if (usedChain)
+            {
+                idxEnd = fineChainBlock<T, M>(idx0, d, t, t >> 6, sIdx, sChain);
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int u = 0; u < VEC; u++) yv[r][u] = (unsigned)sIdx[chainSlot(VEC * t + u + VEC * T * r)];
+            }
         }
         const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
         const v2f fconst = gFine[idx0];
@@ -670,10 +710,10 @@ demodStreamWide(const StreamArgs s)
             {
                 const v2f cv = MAKE2(ch[r][u].x, sgn * ch[r][u].y);
                 v2f f = fconst;
-                if (moving) f = gFine[sIdx[chainSlot(VEC * t + u + VEC * T * r)]];
+                if (moving) f = fl.A ? fineEval<fineSplitLog2H(LOG2N)>(yv[r][u], fl) : gFine[yv[r][u]];
                 x[r][u] = cmulv(cmulv(x[r][u], cv), f);
             }
-        if (moving) __syncthreads();                       // sIdx is about to be overwritten by exchange 0
+        if (usedChain) __syncthreads();                    // sIdx is about to be overwritten by exchange 0
 
         // phase 0 -> exchange 0
         v2f v0[VEC][R];
@@ -757,6 +797,8 @@ demodStreamWide(const StreamArgs s)
     {
         int value, idxEnd;
         float power, powerAvg, fIndex;
+        const int fineIdxBefore = st.fineTuneIndex;
+        const float fineErrBefore = st.finefreqError;
         detect(base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd);
         const float snr = power - powerAvg;                                             // :173
         const bool squelched = snr < s.thresh;                                          // :174
@@ -771,7 +813,7 @@ demodStreamWide(const StreamArgs s)
             detect(base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, power, powerAvg, fIndex, idxEnd1);
             match1 = (value1 + 4) / 8 == (s.sync & 0xf);                               // :205; snr is not recomputed
         }
-        frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1);
+        frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
     }
     if (t == 0)
     {
@@ -786,7 +828,7 @@ demodStreamWide(const StreamArgs s)
 template <class C>
 static hipError_t launchStreamWideCfg(const StreamArgs &s, hipStream_t stream)
 {
-    const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2) + 12 * sizeof(int);
+    const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2) + 12 * sizeof(int) + FineDims<C::LOG2N>::BYTES;
     static unsigned long long attrDone = 0;
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C>), smem, attrDone);

@@ -16,6 +16,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liblora_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libloraref.so")
+# timing-only builds of the same reference sources at the other flag sets BASELINE.md asks for (oracle/Makefile)
+REF_VARIANTS = {"-O2": REF_SO, "-O3 -fcx-limited-range": os.path.join(HERE, "_ref", "libloraref_O3cx.so"),
+                "-O3": os.path.join(HERE, "_ref", "libloraref_O3.so")}
 
 _f32p = C.POINTER(C.c_float)
 _i16p = C.POINTER(C.c_int16)
@@ -244,11 +247,11 @@ class Ref:
     """The real reference code (LoRaDetector.hpp, kissfft.hh, ChirpGenerator.hpp, LoRaDemod.cpp, LoRaMod.cpp)."""
 
     @staticmethod
-    def available():
-        return os.path.exists(REF_SO)
+    def available(flags="-O2"):
+        return os.path.exists(REF_VARIANTS[flags])
 
-    def __init__(self):
-        L = self.L = C.CDLL(REF_SO)
+    def __init__(self, flags="-O2"):
+        L = self.L = C.CDLL(REF_VARIANTS[flags])
         L.loraref_detector_new.restype = C.c_void_p
         L.loraref_detector_new.argtypes = [C.c_size_t]
         L.loraref_detector_free.argtypes = [C.c_void_p]

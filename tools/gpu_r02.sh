@@ -1,0 +1,50 @@
+#!/bin/bash
+# Round-2 GPU sessions (one gpurun call each):  gpurun --timeout N -- 'bash tools/gpu_r02.sh <section> [...]'
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+what="${*:-tests}"
+export TMPDIR=/tmp
+TAG=${TAG:-x}
+
+SETS=( "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum"
+       "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum"
+       "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU"
+       "TA_FLAT_READ_WAVEFRONTS_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+       "SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES SQ_WAVES" )
+
+pmc_run() {   # pmc_run <outprefix> <cmd...>: one rocprofv3 pass per counter set
+  local pre=$1; shift
+  local i=0
+  for set in "${SETS[@]}"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $set -d $O/${pre}_set$i -o pmc --output-format csv -- "$@" > $O/${pre}_set$i.log 2>&1 )
+  done
+}
+
+if [[ $what == *tests* ]]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> $O/pytest_gpu.log
+  tail -5 $O/pytest_gpu.log
+fi
+
+if [[ $what == *l2* ]]; then
+  # L1/L2/SQ counters of the locked-receiver batch shape (bench.py --moving) and of the streaming demodulator
+  for sf in ${L2SF:-7 10 12}; do
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline --moving > $O/${TAG}_moving_sf$sf.json 2> $O/${TAG}_moving_sf$sf.err
+    pmc_run ${TAG}_l2_mov_sf$sf python $R/bench.py --sf $sf --moving --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline
+    python tools/pmc_kernels.py "$O/${TAG}_l2_mov_sf${sf}_set*" detect "bench.py --sf $sf --moving" | tee $O/${TAG}_l2_mov_sf$sf.txt
+    case $sf in 7) CH=16384;; 8|9) CH=8192;; 10) CH=4096;; *) CH=1024;; esac
+    timeout 200 python tools/bench_demod.py --sf $sf --channels $CH --modes 1 > $O/${TAG}_level3_sf$sf.txt 2>&1
+    pmc_run ${TAG}_l2_str_sf$sf python $R/tools/bench_demod.py --sf $sf --channels $CH --modes 1
+    python tools/pmc_kernels.py "$O/${TAG}_l2_str_sf${sf}_set*" demodStream "tools/bench_demod.py --sf $sf --channels $CH (streaming kernel)" | tee $O/${TAG}_l2_str_sf$sf.txt
+    tail -2 $O/${TAG}_level3_sf$sf.txt
+  done
+fi
+
+if [[ $what == *bench* ]]; then
+  timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+  echo "bench exit $?"; tail -c 3000 $O/${TAG}_bench.json; tail -5 $O/${TAG}_bench.err
+fi
