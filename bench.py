@@ -383,18 +383,13 @@ def section_mixed(env, L, a, S=16, n_channels=16384):
     sfs = WL.mixed_sf_channels(n_channels)
     mine = L.shard_channels(sfs, env.world)[env.rank]
     buckets, order, total_bytes = [], [], 0
+    sent_all = WL.mixed_sent(sfs, S, env.dev)                        # the same "sent" symbols on every rank: the global truth
     for sf in range(7, 13):
-        N = 1 << sf
-        glob = np.nonzero(sfs == sf)[0]
-        g = torch.Generator(device=env.dev)
-        g.manual_seed(0xC0F3 + sf)                                   # the same "sent" symbols on every rank: the global truth
-        sent_all = torch.randint(0, N, (glob.size, S), generator=g, device=env.dev, dtype=torch.int32)
-        total_bytes += glob.size * S * L.bytes_per_symbol(sf)
+        total_bytes += int((sfs == sf).sum()) * S * L.bytes_per_symbol(sf)
         ch = mine[sfs[mine] == sf]
         if ch.size == 0:
             continue
-        pos = torch.from_numpy(np.searchsorted(glob, ch)).to(env.dev)
-        sym = sent_all[pos].to(torch.int16).reshape(-1).contiguous()
+        sym = sent_all[torch.from_numpy(ch).to(env.dev)].to(torch.int16).reshape(-1).contiguous()
         gen = L.Context(sf, device=env.local)
         gen.use_torch_stream()
         iq = gen.synth_symbols(sym, ampl=1.0, noise_sigma=a.noise_sigma, seed=0x5EED1000 + sf)
@@ -447,16 +442,7 @@ def section_mixed(env, L, a, S=16, n_channels=16384):
         res["gather_ms"] = r4((time.perf_counter() - t0) * 1e3)
         res["gather_backend"] = "gloo" if backend_cpu else "nccl (RCCL), %d rank(s)" % dist.get_world_size()
         # check against the sent symbols (constant +1 bin of genChirp vs the demod table)
-        full = full.to(env.dev).to(torch.int32) & 0xffff
-        bad = 0
-        for sf in range(7, 13):
-            N = 1 << sf
-            glob = np.nonzero(sfs == sf)[0]
-            g = torch.Generator(device=env.dev)
-            g.manual_seed(0xC0F3 + sf)
-            sent_all = torch.randint(0, N, (glob.size, S), generator=g, device=env.dev, dtype=torch.int32)
-            got = full[torch.from_numpy(glob).to(env.dev)]
-            bad += int((((got - sent_all) % N) != 1).sum())
+        bad = WL.mixed_errors(full.to(env.dev), sfs, S)
         res["symbol_errors_vs_sent"] = bad
         res["symbols_checked"] = n_channels * S
     except Exception as e:                                           # pragma: no cover - environment dependent

@@ -37,7 +37,9 @@ public:
     //! feed simply sets an input sample                                   LoRaDetector.hpp:23
     void feed(const size_t i, const std::complex<Type> &samp)
     {
-        (void)lorahip_detector_feed(_det, i, samp.real(), samp.imag());
+        // i >= N is undefined behaviour in the reference (a write past _fftInput); here it is an error the caller hears about
+        if (lorahip_detector_feed(_det, i, samp.real(), samp.imag()) != LORAHIP_OK)
+            throw std::out_of_range("LoRaDetectorHip::feed: sample index outside the window");
     }
 
     //! calculates argmax(abs(fft(input)))                                 LoRaDetector.hpp:29

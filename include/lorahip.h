@@ -89,6 +89,7 @@ int lorahip_sf(const lorahip_ctx *ctx);
 /* Launch on an existing hipStream_t (e.g. torch's current stream) from now on. NULL is HIP's
  * null stream. Until this is called the context uses a private non-blocking stream. */
 int lorahip_set_stream(lorahip_ctx *ctx, void *hip_stream);
+int lorahip_reset_stream(lorahip_ctx *ctx);          /* back to the private stream */
 int lorahip_synchronize(lorahip_ctx *ctx);
 
 /* Kernel variant: 0 = auto (fastest validated for this SF), 1 = generic LDS kernel.
@@ -136,9 +137,11 @@ typedef struct lorahip_batch {
 } lorahip_batch;
 
 int lorahip_detect_batch(lorahip_ctx *ctx, const lorahip_batch *b);       /* async, device ptrs */
-int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b);  /* sync, host ptrs;
-                                   iq must hold max(offset)+N samples: pass iq_len via window_stride
-                                   semantics or offsets; see lorahip_api.cpp */
+/* The same with HOST pointers, synchronous: inputs are staged to the device, the call returns with the outputs filled.
+ * `iq` must hold every sample a window reads, i.e. at least
+ *     offsets ? max_w(offsets[w]) + N  :  (n_windows - 1) * (window_stride ? window_stride : N) + N
+ * samples (that many are copied); offsets must be >= 0, fine_idx0 in [0, 128*N): LORAHIP_E_INVALID otherwise. */
+int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b);
 
 /* Time the last `n` launches made through this context between two internal HIP events
  * recorded on the launch stream (bench.py uses this for the roofline line). */
@@ -178,6 +181,7 @@ int lorahip_demod_set_mode(lorahip_demod *d, int mode);
 /* Launch on an existing hipStream_t from now on (same meaning as lorahip_set_stream): work queued on that stream before a
  * run -- a channeliser, a modulator, a copy -- is ordered before the run's kernels. A run returns with the stream drained. */
 int lorahip_demod_set_stream(lorahip_demod *d, void *hip_stream);
+int lorahip_demod_reset_stream(lorahip_demod *d);    /* back to the private stream */
 /* same switch as lorahip_set_fine_gather, for the demodulator's kernels */
 int lorahip_demod_set_fine_gather(lorahip_demod *d, int enable);
 
@@ -244,6 +248,9 @@ typedef struct lorahip_demod_ports {
     float *fft_dev; size_t fft_cap_frames;
     float *dec_dev; size_t dec_cap_samples;
     float *raw_dev; size_t raw_cap_samples;
+    int32_t host_buffers;   /* 1: the three pointers are HOST buffers (a framework's port buffers): the library keeps device
+                               buffers of the same shape and copies what a run produced into them before the run returns */
+    int32_t reserved;
 } lorahip_demod_ports;
 int lorahip_demod_set_ports(lorahip_demod *d, const lorahip_demod_ports *p);
 int lorahip_demod_port_counts(const lorahip_demod *d, size_t channel, size_t *fft_frames, size_t *dec_samples, size_t *raw_samples);

@@ -41,7 +41,8 @@ class DecoderCfg(C.Structure):
 class DemodPorts(C.Structure):
     """struct lorahip_demod_ports"""
     _fields_ = [("struct_size", C.c_size_t), ("fft_dev", C.c_void_p), ("fft_cap_frames", C.c_size_t), ("dec_dev", C.c_void_p),
-                ("dec_cap_samples", C.c_size_t), ("raw_dev", C.c_void_p), ("raw_cap_samples", C.c_size_t)]
+                ("dec_cap_samples", C.c_size_t), ("raw_dev", C.c_void_p), ("raw_cap_samples", C.c_size_t),
+                ("host_buffers", C.c_int32), ("reserved", C.c_int32)]
 
 
 class WorkResult(C.Structure):
@@ -66,6 +67,8 @@ SIGNATURES = {
     "lorahip_sf": (C.c_int, [C.c_void_p]),
     "lorahip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lorahip_synchronize": (C.c_int, [C.c_void_p]),
+    "lorahip_reset_stream": (C.c_int, [C.c_void_p]),
+    "lorahip_demod_reset_stream": (C.c_int, [C.c_void_p]),
     "lorahip_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_set_fine_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_fine_split_active": (C.c_int, [C.c_void_p]),

@@ -247,6 +247,8 @@ class Context:
         F, S = int(syms.shape[0]), int(syms.shape[1])
         flen = self.mod_frame_len(S, padding)
         stride = int(frame_stride or flen)
+        if stride < flen:
+            raise ValueError("frame_stride %d is shorter than the frame (%d samples)" % (stride, flen))
         row = lead + stride + tail
         iq = torch.zeros((F, row), dtype=torch.complex64, device=syms.device)
         self.use_torch_stream()
@@ -384,7 +386,7 @@ class LoRaDemod:
               "lorahip_demod_create")
         self.sf, self.N, self.n_channels = int(sf), 1 << int(sf), int(n_channels)
         self._device = int(device)
-        self._thresh = -30.0                                            # LoRaDemod.cpp:72
+        self._port_bufs = dict(fft=None, dec=None, raw=None)
 
     @staticmethod
     def make(sf):
@@ -402,7 +404,6 @@ class LoRaDemod:
 
     def setThreshold(self, thresh_dB):
         check(self._lib.lorahip_demod_set_threshold(self._h, float(thresh_dB)), "lorahip_demod_set_threshold")
-        self._thresh = float(np.float32(thresh_dB))
 
     def setMTU(self, mtu):
         check(self._lib.lorahip_demod_set_mtu(self._h, int(mtu)), "lorahip_demod_set_mtu")
@@ -429,8 +430,12 @@ class LoRaDemod:
             # run on torch's current stream: whatever produced `streams` there is ordered before the demodulator's kernels
             check(self._lib.lorahip_demod_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(streams.device).cuda_stream)),
                   "lorahip_demod_set_stream")
-            check(self._lib.lorahip_demod_run_device(self._h, _dptr(streams), int(streams.shape[1]),
-                                                     C.byref(rounds)), "lorahip_demod_run_device")
+            try:
+                check(self._lib.lorahip_demod_run_device(self._h, _dptr(streams), int(streams.shape[1]),
+                                                         C.byref(rounds)), "lorahip_demod_run_device")
+            finally:
+                # torch may destroy that stream later: later calls (numpy work(), packets_device()) use the private one again
+                self._lib.lorahip_demod_reset_stream(self._h)
             return rounds.value
         if len(streams) != self.n_channels:
             raise ValueError("expected %d streams" % self.n_channels)
@@ -493,30 +498,49 @@ class LoRaDemod:
         check(self._lib.lorahip_demod_set_fine_gather(self._h, int(bool(on))), "lorahip_demod_set_fine_gather")
 
     def labels(self, channel):
-        """The stream labels the block posts at index 0 of its raw / dec / fft outputs, one per work() call ("" = none):
-        "SYNC", "P <fIndex>", "DC", "QC", "S<n> <fIndex>" (LoRaDemod.cpp:213,221-224,245,282,302-305,314-319), rebuilt from the
-        per-call trace (set_trace(True) before work())."""
-        out, nsym = [], 0
-        for r in self.trace(channel):
-            st = r["state_before"]
-            if st == 0:
-                if r["consumed"] == 2 * self.N:
-                    out.append("SYNC")
-                elif not (np.float32(r["snr"]) < np.float32(self._thresh)):
-                    out.append("P %.4f" % r["f_index"])
-                else:
-                    out.append("")
-            elif st == 1:
-                out.append("DC")
-            elif st == 2:
-                out.append("")
-            elif st == 3:
-                out.append("QC")
-                nsym = 0
-            else:
-                nsym += 1
-                out.append("S%d %.4f" % (nsym, r["f_index"]))
-        return out
+        """The stream labels the block posts at index 0 of what each work() call produces on raw / dec / fft, one per call
+        ("" = none): "SYNC", "P <fIndex>", "DC", "QC", "S<n> <fIndex>" (LoRaDemod.cpp:213,221-224,245,282,302-305,314-319),
+        formatted by the library from the per-call trace (set_trace(True) before work())."""
+        n, nb = C.c_size_t(), C.c_size_t()
+        check(self._lib.lorahip_demod_get_labels(self._h, int(channel), None, 0, C.byref(n), C.byref(nb)), "lorahip_demod_get_labels")
+        buf = C.create_string_buffer(max(nb.value, 1))
+        check(self._lib.lorahip_demod_get_labels(self._h, int(channel), buf, nb.value, C.byref(n), C.byref(nb)), "lorahip_demod_get_labels")
+        out = buf.raw[:nb.value].split(b"\0")[:n.value]
+        return [x.decode() for x in out]
+
+    def set_ports(self, fft_frames=0, dec_samples=0, raw_samples=0):
+        """Attach the block's debug ports for the next work() calls (LoRaDemod.cpp:81-83): per channel, `fft_frames` frames of N
+        FFT bins (one per work() call), `dec_samples` dechirped samples, `raw_samples` consumed samples; 0 = that port off,
+        all 0 = ports off. The buffers are device tensors owned by this object; read them with ports(channel)."""
+        import torch
+        dev = torch.device("cuda", int(self._device))
+        B = self.n_channels
+        self._port_bufs = dict(
+            fft=torch.zeros((B, int(fft_frames), self.N), dtype=torch.complex64, device=dev) if fft_frames else None,
+            dec=torch.zeros((B, int(dec_samples)), dtype=torch.complex64, device=dev) if dec_samples else None,
+            raw=torch.zeros((B, int(raw_samples)), dtype=torch.complex64, device=dev) if raw_samples else None)
+        torch.cuda.synchronize(dev)
+        if not (fft_frames or dec_samples or raw_samples):
+            check(self._lib.lorahip_demod_set_ports(self._h, None), "lorahip_demod_set_ports")
+            return
+        p = _lib.DemodPorts()
+        p.struct_size = C.sizeof(_lib.DemodPorts)
+        b = self._port_bufs
+        p.fft_dev, p.fft_cap_frames = (b["fft"].data_ptr() if fft_frames else None), int(fft_frames)
+        p.dec_dev, p.dec_cap_samples = (b["dec"].data_ptr() if dec_samples else None), int(dec_samples)
+        p.raw_dev, p.raw_cap_samples = (b["raw"].data_ptr() if raw_samples else None), int(raw_samples)
+        check(self._lib.lorahip_demod_set_ports(self._h, C.byref(p)), "lorahip_demod_set_ports")
+
+    def ports(self, channel):
+        """what the last work() produced on the debug ports of `channel`: dict of device tensors fft (frames, N), dec (samples,),
+        raw (samples,) -- cut to what was produced (or to the capacity given to set_ports)"""
+        nf, nd, nr = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        check(self._lib.lorahip_demod_port_counts(self._h, int(channel), C.byref(nf), C.byref(nd), C.byref(nr)), "lorahip_demod_port_counts")
+        b = self._port_bufs
+        return dict(fft=None if b["fft"] is None else b["fft"][channel, :min(nf.value, b["fft"].shape[1])],
+                    dec=None if b["dec"] is None else b["dec"][channel, :min(nd.value, b["dec"].shape[1])],
+                    raw=None if b["raw"] is None else b["raw"][channel, :min(nr.value, b["raw"].shape[1])],
+                    produced=dict(fft=nf.value, dec=nd.value, raw=nr.value))
 
     def trace(self, channel):
         n = self._lib.lorahip_demod_trace_len(self._h, int(channel))

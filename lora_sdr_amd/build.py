@@ -53,5 +53,7 @@ def build_lib(force=False, verbose=False, extra=()):
 
 
 if __name__ == "__main__":
-    build_lib(force="--force" in sys.argv, verbose=True)
+    # --all-variants: also compile the round-1 A/B kernel variants (profiling only; the shipped library carries the default,
+    # the generic kernel and one alternative per SF)
+    build_lib(force="--force" in sys.argv, verbose=True, extra=("-DLORAHIP_ALL_VARIANTS",) if "--all-variants" in sys.argv else ())
     print(LIB)

@@ -191,6 +191,13 @@ int lorahip_set_stream(lorahip_ctx *ctx, void *hip_stream)
     return LORAHIP_OK;
 }
 
+int lorahip_reset_stream(lorahip_ctx *ctx)
+{
+    if (ctx == nullptr) return LORAHIP_E_INVALID;
+    ctx->stream = ctx->ownStream;
+    return LORAHIP_OK;
+}
+
 int lorahip_synchronize(lorahip_ctx *ctx)
 {
     if (ctx == nullptr) return LORAHIP_E_INVALID;
@@ -278,6 +285,9 @@ int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b)
     const DeviceGuard guard(ctx->device);
     const size_t N = ctx->N, W = b->n_windows;
     const size_t stride = b->window_stride ? b->window_stride : N;
+    if (b->fine_idx0)                                            // host pointers: the index must lie inside the 128*N-entry table
+        for (size_t w = 0; w < W; w++)
+            if (b->fine_idx0[w] < 0 || size_t(b->fine_idx0[w]) >= N * LORAHIP_FINE_STEPS) return LORAHIP_E_INVALID;
     size_t iqLen = 0;
     if (b->offsets)
     {

@@ -37,6 +37,7 @@ struct Channel
     size_t base, len, pos;  // stream placement in the device buffer, read position
     std::vector<lorahip_work_result> trace;
     size_t traceStart;      // first trace entry of the last run
+    size_t traceSymCount0;  // _symCount when the trace began (labels "S<n>" continue a packet that was open then)
     size_t portFft, portDec, portRaw;   // frames / samples the last run produced on the debug ports
 };
 
@@ -73,7 +74,9 @@ struct lorahip_demod
     char *dDense, *hDense; size_t denseBytes;   // the used part of the record arrays, packed for the copy back
     hipEvent_t evK0, evK1;           // around the streaming kernel launches of a run (lorahip_demod_kernel_ms)
     double kernelMs;
-    lorahip_demod_ports ports;       // level-3 debug ports (all pointers null: off)
+    lorahip_demod_ports ports;       // level-3 debug ports (all pointers null: off); DEVICE pointers (the library's own when the caller's are host buffers)
+    lorahip_demod_ports hostPorts;   // the caller's host buffers (host_buffers == 1)
+    float *ownFft, *ownDec, *ownRaw; // device mirrors owned by the library for host_buffers
     bool portsOn, userTracing;
     char *dPort; size_t dPortBytes;  // scratch of the port replay: window descriptors, replayed fft / dec windows
 };
@@ -635,6 +638,27 @@ static int fillPorts(lorahip_demod *dm, const float *iqDev)
     float *dAvg = reinterpret_cast<float *>(cur); cur += align256(chunk * sizeof(float));
     float *dFi = reinterpret_cast<float *>(cur);
     if (P.raw_dev) { const int rc = scatter(P.raw_dev, iqDev, segRaw, 0, segRaw.size(), 0, dDesc); if (rc != LORAHIP_OK) return rc; }
+    struct HostCopy
+    {
+        static int run(lorahip_demod *dm, hipStream_t st)
+        {
+            // host port buffers: what each channel produced, out of the library's device mirrors
+            const lorahip_demod_ports &H = dm->hostPorts, &D = dm->ports;
+            const size_t N = dm->N;
+            for (size_t c = 0; c < dm->B; c++)
+            {
+                const Channel &k = dm->ch[c];
+                const size_t nf = k.portFft < D.fft_cap_frames ? k.portFft : D.fft_cap_frames;
+                const size_t nd = k.portDec < D.dec_cap_samples ? k.portDec : D.dec_cap_samples;
+                const size_t nr = k.portRaw < D.raw_cap_samples ? k.portRaw : D.raw_cap_samples;
+                if (H.fft_dev && nf) LORAHIP_TRY(hipMemcpyAsync(H.fft_dev + 2 * c * D.fft_cap_frames * N, D.fft_dev + 2 * c * D.fft_cap_frames * N, nf * N * sizeof(cf32), hipMemcpyDeviceToHost, st));
+                if (H.dec_dev && nd) LORAHIP_TRY(hipMemcpyAsync(H.dec_dev + 2 * c * D.dec_cap_samples, D.dec_dev + 2 * c * D.dec_cap_samples, nd * sizeof(cf32), hipMemcpyDeviceToHost, st));
+                if (H.raw_dev && nr) LORAHIP_TRY(hipMemcpyAsync(H.raw_dev + 2 * c * D.raw_cap_samples, D.raw_dev + 2 * c * D.raw_cap_samples, nr * sizeof(cf32), hipMemcpyDeviceToHost, st));
+            }
+            LORAHIP_TRY(hipStreamSynchronize(st));
+            return LORAHIP_OK;
+        }
+    };
     size_t fi = 0, di = 0;
     for (size_t w0 = 0; w0 < W && (P.fft_dev || P.dec_dev); w0 += chunk)
     {
@@ -660,6 +684,7 @@ static int fillPorts(lorahip_demod *dm, const float *iqDev)
         if (rc2 != LORAHIP_OK) return rc2;
         fi = f1; di = d1;
     }
+    if (dm->hostPorts.host_buffers) return HostCopy::run(dm, st);
     return LORAHIP_OK;
 }
 
@@ -687,6 +712,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
     dm->evK0 = nullptr; dm->evK1 = nullptr; dm->kernelMs = 0.0;
     std::memset(&dm->ports, 0, sizeof(dm->ports)); dm->portsOn = false; dm->userTracing = false; dm->dPort = nullptr; dm->dPortBytes = 0;
+    std::memset(&dm->hostPorts, 0, sizeof(dm->hostPorts)); dm->ownFft = dm->ownDec = dm->ownRaw = nullptr;
     dm->mode = 0; dm->sDev = nullptr; dm->sHost = nullptr; dm->sBytes = 0; dm->dDense = nullptr; dm->hDense = nullptr; dm->denseBytes = 0;
     int rc = lorahip_create(&dm->ctx, device, sf);
     if (rc != LORAHIP_OK) { delete dm; return rc; }
@@ -696,6 +722,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->tracing = false;
     dm->workCalls = 0;
     dm->ch.resize(n_channels);
+    for (auto &k : dm->ch) { k.traceStart = 0; k.traceSymCount0 = 0; k.portFft = k.portDec = k.portRaw = 0; }
     dm->stageBytes = carve(nullptr, n_channels).total;
     bool staged;
     {
@@ -726,6 +753,9 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->dDense) (void)hipFree(dm->dDense);
     if (dm->hDense) (void)hipHostFree(dm->hDense);
     if (dm->dPort) (void)hipFree(dm->dPort);
+    if (dm->ownFft) (void)hipFree(dm->ownFft);
+    if (dm->ownDec) (void)hipFree(dm->ownDec);
+    if (dm->ownRaw) (void)hipFree(dm->ownRaw);
     if (dm->evK0) (void)hipEventDestroy(dm->evK0);
     if (dm->evK1) (void)hipEventDestroy(dm->evK1);
     }
@@ -765,6 +795,12 @@ int lorahip_demod_set_stream(lorahip_demod *dm, void *hip_stream)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
     return lorahip_set_stream(dm->ctx, hip_stream);
+}
+
+int lorahip_demod_reset_stream(lorahip_demod *dm)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    return lorahip_reset_stream(dm->ctx);
 }
 
 int lorahip_demod_set_fine_gather(lorahip_demod *dm, const int enable)
@@ -902,9 +938,11 @@ int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
 int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    const bool was = dm->tracing;
     dm->userTracing = enable != 0;
     dm->tracing = dm->userTracing || dm->portsOn;
-    if (!dm->userTracing) for (auto &k : dm->ch) { k.trace.clear(); k.traceStart = 0; }
+    if (!dm->userTracing) for (auto &k : dm->ch) { k.trace.clear(); k.traceStart = 0; k.traceSymCount0 = k.symCount; }
+    else if (!was) for (auto &k : dm->ch) k.traceSymCount0 = k.symCount;
     return LORAHIP_OK;
 }
 
@@ -917,14 +955,30 @@ size_t lorahip_demod_trace_len(const lorahip_demod *dm, const size_t channel)
 int lorahip_demod_set_ports(lorahip_demod *dm, const lorahip_demod_ports *p)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
-    if (p == nullptr) { std::memset(&dm->ports, 0, sizeof(dm->ports)); dm->portsOn = false; }
-    else
+    const DeviceGuard guard(dm->ctx->device);
+    if (dm->ownFft) { (void)hipFree(dm->ownFft); dm->ownFft = nullptr; }
+    if (dm->ownDec) { (void)hipFree(dm->ownDec); dm->ownDec = nullptr; }
+    if (dm->ownRaw) { (void)hipFree(dm->ownRaw); dm->ownRaw = nullptr; }
+    std::memset(&dm->ports, 0, sizeof(dm->ports));
+    std::memset(&dm->hostPorts, 0, sizeof(dm->hostPorts));
+    dm->portsOn = false;
+    if (p != nullptr)
     {
         if (p->struct_size != sizeof(lorahip_demod_ports)) return LORAHIP_E_INVALID;
         if ((p->fft_dev && !p->fft_cap_frames) || (p->dec_dev && !p->dec_cap_samples) || (p->raw_dev && !p->raw_cap_samples)) return LORAHIP_E_INVALID;
         dm->ports = *p;
-        dm->portsOn = p->fft_dev || p->dec_dev || p->raw_dev;
+        if (p->host_buffers)
+        {
+            dm->hostPorts = *p;
+            dm->ports.host_buffers = 0;
+            dm->ports.fft_dev = dm->ports.dec_dev = dm->ports.raw_dev = nullptr;
+            if (p->fft_dev) { LORAHIP_TRY(hipMalloc((void **)&dm->ownFft, dm->B * p->fft_cap_frames * dm->N * sizeof(cf32))); dm->ports.fft_dev = dm->ownFft; }
+            if (p->dec_dev) { LORAHIP_TRY(hipMalloc((void **)&dm->ownDec, dm->B * p->dec_cap_samples * sizeof(cf32))); dm->ports.dec_dev = dm->ownDec; }
+            if (p->raw_dev) { LORAHIP_TRY(hipMalloc((void **)&dm->ownRaw, dm->B * p->raw_cap_samples * sizeof(cf32))); dm->ports.raw_dev = dm->ownRaw; }
+        }
+        dm->portsOn = dm->ports.fft_dev || dm->ports.dec_dev || dm->ports.raw_dev;
     }
+    if (dm->portsOn && !dm->tracing) for (auto &k : dm->ch) k.traceSymCount0 = k.symCount;
     dm->tracing = dm->userTracing || dm->portsOn;
     return LORAHIP_OK;
 }
@@ -964,13 +1018,8 @@ int lorahip_demod_get_labels(const lorahip_demod *dm, const size_t channel, char
 {
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
     const auto &t = dm->ch[channel].trace;
-    // _symCount is only reset at QUARTERCHIRP (:279); a trace that starts inside a packet continues the count the channel held then
-    size_t symCount = 0;
-    if (!t.empty() && t.front().state_before == ST_DATASYMBOLS)
-    {
-        size_t inTrace = 0;
-        for (const auto &r : t) { if (r.state_before != ST_DATASYMBOLS) break; inTrace++; if (r.packet_len) { symCount = size_t(r.packet_len) - inTrace; break; } }
-    }
+    // _symCount is only reset at QUARTERCHIRP (:279): a trace that starts inside a packet continues the count the channel held then
+    size_t symCount = dm->ch[channel].traceSymCount0;
     size_t used = 0;
     for (const auto &r : t)
     {

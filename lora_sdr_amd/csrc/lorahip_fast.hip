@@ -373,7 +373,11 @@ static bool layoutOk()
 
 bool fastLayoutsOk()
 {
-    return layoutOk<Fast<6, 0>>() && layoutOk<Fast<7, 0>>() && layoutOk<Fast<8, 0>>() && layoutOk<Fast<9, 0>>() && layoutOk<Fast9b<0>>() && layoutOk<Fast11q<0>>() && layoutOk<Fast<10, 0>>();
+    bool ok = layoutOk<Fast<6, 0>>() && layoutOk<Fast<7, 0>>() && layoutOk<Fast<8, 0>>() && layoutOk<Fast<9, 0>>() && layoutOk<Fast9b<0>>() && layoutOk<Fast<10, 0>>();
+#ifdef LORAHIP_ALL_VARIANTS
+    ok = ok && layoutOk<Fast11q<0>>();
+#endif
+    return ok;
 }
 
 /***********************************************************************
@@ -393,23 +397,30 @@ static hipError_t launchSf9Default(const DetectArgs &a, const FastTables &ft, hi
 
 struct FastVariant { int sf, variant; FastLaunch launch; };
 #define V(SF, N, OPTS) { SF, N, &launchCfg<Fast<SF, (OPTS)>> }
+// What ships: per SF the default (0) and ONE alternative -- variant 10, every table (chirp, twiddles) read from LDS, the option
+// set the streaming demodulator's kernels run with -- beside the generic kernel (1, lorahip_kernels.hip). The losers of the
+// round-1 tuning (profiles/r01/s8_variants.txt keeps every A/B pair) are compiled only with -DLORAHIP_ALL_VARIANTS
+// (python -m lora_sdr_amd.build --all-variants), under their old numbers.
 static const FastVariant kFastVariants[] = {
-    // SF6
     V(6, 0, 0),                                            // default: 16 windows per wave keep the LDS copies of chirp / twiddles cheap
-    V(6, 7, TW_REG), V(6, 8, NT), V(6, 10, 0), V(6, 11, CH_REG | NT), V(6, 12, CH_REG | TW_REG | NT), V(6, 15, CH_REG | TW_REG | NT | PF_NONE),
-    // SF7
+    V(6, 10, CH_REG | NT),
     V(7, 0, CH_REG | NT),                                  // default
+    V(7, 10, 0),
+    V(8, 0, CH_REG | TW_REG | NT),                         // default
+    V(8, 10, 0),
+    { 9, 0, &launchSf9Default },                           // default: geometry chosen per call, see launchSf9Default
+    V(9, 10, 0),
+    V(10, 0, CH_REG | TW_REG | NT | X1_SWAP),              // default
+    V(10, 10, 0),
+#ifdef LORAHIP_ALL_VARIANTS
+    V(6, 7, TW_REG), V(6, 8, NT), V(6, 11, CH_REG | NT), V(6, 12, CH_REG | TW_REG | NT), V(6, 15, CH_REG | TW_REG | NT | PF_NONE),
     V(7, 2, PF_NONE), V(7, 3, W2), V(7, 4, W4 | PF_NONE), V(7, 5, W2 | CH_REG | TW_REG), V(7, 6, PF_EARLY), V(7, 7, TW_REG),
-    V(7, 8, NT), V(7, 9, TW_REG | NT), V(7, 10, 0), V(7, 11, CH_REG | NT), V(7, 12, W2 | CH_REG | TW_REG | NT),
+    V(7, 8, NT), V(7, 9, TW_REG | NT), V(7, 11, CH_REG | NT), V(7, 12, W2 | CH_REG | TW_REG | NT),
     V(7, 13, CH_REG | NT | NB_SEL), V(7, 14, CH_REG | NT | XCD), V(7, 15, CH_REG | TW_REG | NT | PF_NONE), V(7, 16, CH_REG | TW_REG | NT | PF_NONE | NB_SEL),
     V(7, 17, W4 | CH_REG | NT | PF_NONE),
-    // SF8
-    V(8, 0, CH_REG | TW_REG | NT),                         // default
-    V(8, 6, PF_EARLY), V(8, 7, TW_REG), V(8, 8, NT), V(8, 9, TW_REG | NT), V(8, 10, 0), V(8, 11, CH_REG | TW_REG | NT),
+    V(8, 6, PF_EARLY), V(8, 7, TW_REG), V(8, 8, NT), V(8, 9, TW_REG | NT), V(8, 11, CH_REG | TW_REG | NT),
     V(8, 13, CH_REG | TW_REG | NT | NB_SEL), V(8, 15, CH_REG | TW_REG | NT | PF_NONE), V(8, 17, W4 | CH_REG | NT | PF_NONE),
-    // SF9
-    { 9, 0, &launchSf9Default },                           // default: geometry chosen per call, see launchSf9Default
-    V(9, 6, PF_EARLY), V(9, 7, TW_REG), V(9, 8, NT), V(9, 9, TW_REG | NT), V(9, 10, 0), V(9, 11, CH_REG | TW_REG | NT),
+    V(9, 6, PF_EARLY), V(9, 7, TW_REG), V(9, 8, NT), V(9, 9, TW_REG | NT), V(9, 11, CH_REG | TW_REG | NT),
     V(9, 12, CH_REG | TW_REG | NT | X1_SWAP), V(9, 13, CH_REG | TW_REG | NT | NB_SEL), V(9, 15, CH_REG | TW_REG | NT | X1_SWAP | TWM_REG | PF_NONE),
     V(9, 16, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG),
     { 9, 20, &launchCfg<Fast9b<W2 | CH_REG | TW_REG | NT>> }, { 9, 21, &launchCfg<Fast9b<W2 | NT>> }, { 9, 22, &launchCfg<Fast9b<W2 | TW_REG | NT>> },
@@ -418,11 +429,10 @@ static const FastVariant kFastVariants[] = {
     { 11, 20, &launchCfg<Fast11q<W2 | NT | PF_NONE>> }, { 11, 21, &launchCfg<Fast11q<W2 | TW_REG | NT | PF_NONE>> },
     { 11, 22, &launchCfg<Fast11q<W2 | CH_REG | TW_REG | NT | PF_NONE>> }, { 11, 23, &launchCfg<Fast11q<W2 | NT>> },
     { 11, 24, &launchCfg<Fast11q<W2 | TW_REG | TWM_REG | NT | PF_NONE>> },
-    // SF10
-    V(10, 0, CH_REG | TW_REG | NT | X1_SWAP),              // default
-    V(10, 6, PF_EARLY), V(10, 7, TW_REG), V(10, 8, NT), V(10, 9, TW_REG | NT), V(10, 10, 0), V(10, 11, CH_REG | TW_REG | NT),
+    V(10, 6, PF_EARLY), V(10, 7, TW_REG), V(10, 8, NT), V(10, 9, TW_REG | NT), V(10, 11, CH_REG | TW_REG | NT),
     V(10, 12, CH_REG | TW_REG | NT | X1_SWAP), V(10, 13, CH_REG | TW_REG | NT | NB_SEL), V(10, 14, CH_REG | TW_REG | NT | NB_SEL | X1_SWAP),
     V(10, 15, CH_REG | TW_REG | NT | X1_SWAP | TWM_REG | PF_NONE), V(10, 16, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG),
+#endif
 };
 #undef V
 

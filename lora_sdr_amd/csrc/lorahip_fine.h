@@ -23,7 +23,7 @@
 //     (only when frac(d) is within M 2^-25 of an integer from the wrong side: `regular` below), (b) for d > 0 the
 //     sequence lands on y = ceil(d) - 1, where the reference yields 0 instead of wrapping (closed form: the value M).
 //     Such windows take the exact index chain (fineChainGroup / fineChainBlock); the two paths are tested against each
-//     other and against the serial recurrence of the CPU oracle (tests/test_cabi.py, tests/test_gpu_parity.py).
+//     other and against the serial recurrence itself (tests/test_fine_index.py on the host, tests/test_gpu_parity.py on the device).
 #pragma once
 #include "lorahip_internal.h"
 

@@ -92,7 +92,7 @@ extern "C" int lorahip_fine_split_selftest(const int sf)
 
 // Host evaluation of the fine-tune index sequence of one window the way the tuned kernels do it (lorahip_fine.h): closed form
 // where it is valid (*path = 1), else the serial recurrence (*path = 0). idx_out: N entries (index used for sample n), *idx_end:
-// the index after the window. Test hook: compared with the reference recurrence for adversarial steps (tests/test_cabi.py).
+// the index after the window. Test hook: compared with the reference recurrence for adversarial steps (tests/test_fine_index.py).
 extern "C" int lorahip_fine_indices_host(const int sf, const int32_t idx0, const float err, int32_t *idx_out, int32_t *idx_end, int32_t *path)
 {
     using namespace lorahip;

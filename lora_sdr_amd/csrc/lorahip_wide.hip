@@ -574,16 +574,20 @@ bool wideLayoutsOk();
 typedef hipError_t (*WideLaunch)(const DetectArgs &, const FastTables &, hipStream_t);
 struct WideVariant { int sf, variant; WideLaunch launch; bool (*layoutOk)(); };
 #define V(SF, N, OPTS) { SF, N, &launchCfgWide<Wide<SF, (OPTS)>>, &layoutOk<Wide<SF, (OPTS)>> }
+// ships: the default (0) and one alternative per SF (10: the plain exchange-0 layout, four barriers per window, register
+// prefetch); the rest of the round-1 A/B set only with -DLORAHIP_ALL_VARIANTS (profiles/r01/s8_variants.txt)
 static const WideVariant kWideVariants[] = {
-    // SF11
     V(11, 0, WPF_NONE | WNT | WONE | WINPLACE),            // default
-    V(11, 2, WW2), V(11, 3, WW2 | WCH_LDS), V(11, 4, WW2 | WTW_LDS), V(11, 5, WW2 | WCH_LDS | WTW_LDS), V(11, 6, WW4 | WPF_NONE),
-    V(11, 7, WPF_NONE), V(11, 8, WNT), V(11, 9, WPF_NONE | WNT), V(11, 10, 0), V(11, 11, WPF_NONE | WNT | WONE), V(11, 12, WNT | WONE),
-    V(11, 13, WPF_NONE | WNT | WONE | WINPLACE), V(11, 14, WPF_NONE | WNT | WINPLACE),
-    // SF12
+    V(11, 10, 0),
     V(12, 0, WNT | WINPLACE),                              // default
+    V(12, 10, 0),
+#ifdef LORAHIP_ALL_VARIANTS
+    V(11, 2, WW2), V(11, 3, WW2 | WCH_LDS), V(11, 4, WW2 | WTW_LDS), V(11, 5, WW2 | WCH_LDS | WTW_LDS), V(11, 6, WW4 | WPF_NONE),
+    V(11, 7, WPF_NONE), V(11, 8, WNT), V(11, 9, WPF_NONE | WNT), V(11, 11, WPF_NONE | WNT | WONE), V(11, 12, WNT | WONE),
+    V(11, 13, WPF_NONE | WNT | WONE | WINPLACE), V(11, 14, WPF_NONE | WNT | WINPLACE),
     V(12, 2, WW2), V(12, 3, WW2 | WCH_LDS), V(12, 4, WW2 | WTW_LDS), V(12, 5, WW2 | WCH_LDS | WTW_LDS), V(12, 6, WW4 | WPF_NONE),
-    V(12, 7, WPF_NONE), V(12, 8, WNT), V(12, 9, WPF_NONE | WNT), V(12, 10, 0), V(12, 13, WPF_NONE | WNT | WINPLACE), V(12, 14, WNT | WINPLACE),
+    V(12, 7, WPF_NONE), V(12, 8, WNT), V(12, 9, WPF_NONE | WNT), V(12, 13, WPF_NONE | WNT | WINPLACE), V(12, 14, WNT | WINPLACE),
+#endif
 };
 #undef V
 

@@ -73,3 +73,27 @@ def check_frame_packets(packets, data, N, nsyms, limit=None):
 def mixed_sf_channels(n_channels=16384):
     """BASELINE.json configs[3]: SF(c) = 7 + (c mod 6)"""
     return 7 + (np.arange(n_channels) % 6)
+
+
+def mixed_sent(sfs, S, device="cpu"):
+    """the symbols "sent" on every channel of the mixed-SF workload: (n_channels, S) int32, symbol (c, k) < 2^SF(c). A counter
+    hash in plain integer tensor arithmetic, so every rank -- and the CPU-side structure test -- derives the same truth."""
+    import torch
+    n = len(sfs)
+    idx = torch.arange(n * S, dtype=torch.int64, device=device).reshape(n, S)
+    h = (idx * 2654435761 + 0x9E3779B9) & 0xFFFFFFFF
+    h = (h ^ (h >> 15)) * 2246822519 & 0xFFFFFFFF
+    h = h ^ (h >> 13)
+    mask = torch.as_tensor((1 << np.asarray(sfs, np.int64)) - 1, dtype=torch.int64, device=device).reshape(n, 1)
+    return (h & mask).to(torch.int32)
+
+
+def mixed_errors(full, sfs, S, bin_offset=1):
+    """gathered (n_channels, S) symbols against mixed_sent(): demodulating a window-aligned genChirp symbol s yields bin
+    s + 1. Returns the number of symbols that differ."""
+    import torch
+    dev = full.device
+    sent = mixed_sent(sfs, S, dev)
+    n = torch.as_tensor(1 << np.asarray(sfs, np.int64), dtype=torch.int64, device=dev).reshape(-1, 1)
+    got = full.to(torch.int64) & 0xffff
+    return int((((got - sent.to(torch.int64)) % n) != bin_offset).sum())

@@ -1,0 +1,182 @@
+// TEST INFRASTRUCTURE ONLY (oracle/) -- never linked or called by the product path.
+//
+// extern "C" driver of the multi-channel Pothos block lora_sdr_amd/pothos/LoRaDemodBatch.cpp, compiled against the recording
+// fake of oracle/stub/Pothos and linked with liblorahip.so into oracle/_ref/libloradrop.so. The same .so carries
+// oracle/ref_driver.cpp around the reference's OWN LoRaDemod.cpp with the two-line patch of INTEGRATION.md section 1 applied
+// (LoRaDetector<float> -> LoRaDetectorHip<float>; the patched copy is a build product under oracle/_ref/, never committed),
+// so the `loraref_demod_*` entry points of this library run the verbatim block on the HIP detector.
+// tests/test_gpu_dropin.py compares both with the recorded behaviour of the unpatched reference.
+#include <Pothos/Framework.hpp>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+typedef std::complex<float> cf32;
+
+namespace {
+
+struct ChanLog
+{
+    std::vector<cf32> raw, dec, fft;
+    std::vector<std::pair<size_t, std::string>> rawLabels, decLabels, fftLabels;    // absolute element index, id
+    std::vector<std::vector<int16_t>> packets;
+    size_t consumed;
+};
+
+struct BatchHandle
+{
+    Pothos::Block *block;
+    size_t N, B, maxWindows;
+    std::vector<std::vector<cf32>> rawBuf, decBuf, fftBuf;      // the framework's port buffers
+    std::vector<ChanLog> log;
+    int64_t works;
+};
+
+} // namespace
+
+extern "C" {
+
+void *loradrop_batch_new(const size_t sf, const size_t channels, const size_t maxWindows)
+{
+    auto it = Pothos::BlockRegistry::table2().find("/lora/lora_demod_batch");
+    if (it == Pothos::BlockRegistry::table2().end()) return nullptr;
+    auto h = new BatchHandle();
+    try { h->block = it->second(sf, channels); }
+    catch (const std::exception &) { delete h; return nullptr; }
+    h->N = size_t(1) << sf; h->B = channels; h->maxWindows = maxWindows; h->works = 0;
+    h->block->calls.at("setMaxWindows")(double(maxWindows));
+    h->rawBuf.resize(channels); h->decBuf.resize(channels); h->fftBuf.resize(channels); h->log.resize(channels);
+    for (size_t c = 0; c < channels; c++)
+    {
+        const std::string s = std::to_string(c);
+        // buffers of the size the block's buffer-manager hook asks for, like the framework would allocate them
+        const size_t nbRaw = h->block->getOutputBufferManager("raw" + s, "")->args.bufferSize;
+        const size_t nbFft = h->block->getOutputBufferManager("fft" + s, "")->args.bufferSize;
+        h->rawBuf[c].resize(nbRaw / sizeof(cf32)); h->decBuf[c].resize(nbRaw / sizeof(cf32)); h->fftBuf[c].resize(nbFft / sizeof(cf32));
+        h->block->output("raw" + s)->_buff = Pothos::BufferChunk::view(h->rawBuf[c].data(), nbRaw);
+        h->block->output("dec" + s)->_buff = Pothos::BufferChunk::view(h->decBuf[c].data(), nbRaw);
+        h->block->output("fft" + s)->_buff = Pothos::BufferChunk::view(h->fftBuf[c].data(), nbFft);
+        h->log[c].consumed = 0;
+    }
+    h->block->activate();
+    return h;
+}
+
+void loradrop_batch_free(void *p)
+{
+    auto h = reinterpret_cast<BatchHandle *>(p);
+    delete h->block;
+    delete h;
+}
+
+int loradrop_batch_set(void *p, const char *name, const double v)
+{
+    auto h = reinterpret_cast<BatchHandle *>(p);
+    auto it = h->block->calls.find(name);
+    if (it == h->block->calls.end()) return -1;
+    it->second(v);
+    return 0;
+}
+
+//! every channel's whole stream (iq: [channels][samplesPerChannel] cf32): call work() the way a scheduler would -- each input
+//! presents what the block has not consumed yet -- until no channel has 2N samples left. Returns the number of work() calls.
+int64_t loradrop_batch_run(void *p, const float *iq, const size_t samplesPerChannel)
+{
+    auto h = reinterpret_cast<BatchHandle *>(p);
+    const size_t N = h->N, B = h->B;
+    std::vector<size_t> pos(B, 0);
+    while (true)
+    {
+        bool any = false;
+        for (size_t c = 0; c < B; c++)
+        {
+            auto in = h->block->input(int(c));
+            in->_elems = samplesPerChannel - pos[c];
+            in->_buff = Pothos::BufferChunk::view(const_cast<float *>(iq) + 2 * (c * samplesPerChannel + pos[c]), in->_elems * sizeof(cf32));
+            in->consumed = 0;
+            any = any || in->_elems >= 2 * N;
+            const std::string s = std::to_string(c);
+            for (const char *port : { "raw", "dec", "fft" }) { auto o = h->block->output(port + s); o->produced = 0; o->labels.clear(); }
+        }
+        if (!any) break;
+        h->block->work();
+        h->works++;
+        size_t progressed = 0;
+        for (size_t c = 0; c < B; c++)
+        {
+            const std::string s = std::to_string(c);
+            ChanLog &L = h->log[c];
+            auto raw = h->block->output("raw" + s), dec = h->block->output("dec" + s), fft = h->block->output("fft" + s), out = h->block->output(int(c));
+            for (const auto &l : raw->labels) L.rawLabels.emplace_back(L.raw.size() + l.index, l.id);
+            for (const auto &l : dec->labels) L.decLabels.emplace_back(L.dec.size() + l.index, l.id);
+            for (const auto &l : fft->labels) L.fftLabels.emplace_back(L.fft.size() + l.index, l.id);
+            L.raw.insert(L.raw.end(), h->rawBuf[c].begin(), h->rawBuf[c].begin() + long(raw->produced));
+            L.dec.insert(L.dec.end(), h->decBuf[c].begin(), h->decBuf[c].begin() + long(dec->produced));
+            L.fft.insert(L.fft.end(), h->fftBuf[c].begin(), h->fftBuf[c].begin() + long(fft->produced));
+            for (const auto &bytes : out->messages)
+            {
+                std::vector<int16_t> syms(bytes.size() / sizeof(int16_t));
+                if (!syms.empty()) std::memcpy(syms.data(), bytes.data(), syms.size() * sizeof(int16_t));
+                L.packets.push_back(syms);
+            }
+            out->messages.clear();
+            const size_t used = h->block->input(int(c))->consumed;
+            pos[c] += used; L.consumed += used; progressed += used;
+        }
+        if (progressed == 0) break;     // cannot happen; guards the loop
+    }
+    return h->works;
+}
+
+size_t loradrop_batch_count(void *p, const size_t c, const char *what)
+{
+    const ChanLog &L = reinterpret_cast<BatchHandle *>(p)->log.at(c);
+    const std::string w(what);
+    if (w == "raw") return L.raw.size();
+    if (w == "dec") return L.dec.size();
+    if (w == "fft") return L.fft.size();
+    if (w == "rawLabels") return L.rawLabels.size();
+    if (w == "decLabels") return L.decLabels.size();
+    if (w == "fftLabels") return L.fftLabels.size();
+    if (w == "packets") return L.packets.size();
+    if (w == "consumed") return L.consumed;
+    return 0;
+}
+
+void loradrop_batch_get_stream(void *p, const size_t c, const char *what, float *out)
+{
+    const ChanLog &L = reinterpret_cast<BatchHandle *>(p)->log.at(c);
+    const std::string w(what);
+    const std::vector<cf32> &v = w == "raw" ? L.raw : (w == "dec" ? L.dec : L.fft);
+    if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(cf32));
+}
+
+//! label i of a port: its absolute element index is returned, its id copied into buf
+size_t loradrop_batch_get_label(void *p, const size_t c, const char *what, const size_t i, char *buf, const size_t cap)
+{
+    const ChanLog &L = reinterpret_cast<BatchHandle *>(p)->log.at(c);
+    const std::string w(what);
+    const auto &v = w == "raw" ? L.rawLabels : (w == "dec" ? L.decLabels : L.fftLabels);
+    const auto &l = v.at(i);
+    if (cap) { std::strncpy(buf, l.second.c_str(), cap - 1); buf[cap - 1] = 0; }
+    return l.first;
+}
+
+size_t loradrop_batch_packet_len(void *p, const size_t c, const size_t i) { return reinterpret_cast<BatchHandle *>(p)->log.at(c).packets.at(i).size(); }
+void loradrop_batch_get_packet(void *p, const size_t c, const size_t i, int16_t *out)
+{
+    const auto &s = reinterpret_cast<BatchHandle *>(p)->log.at(c).packets.at(i);
+    if (!s.empty()) std::memcpy(out, s.data(), s.size() * sizeof(int16_t));
+}
+
+size_t loradrop_batch_num_signals(void *p) { return reinterpret_cast<BatchHandle *>(p)->block->signals.size(); }
+double loradrop_batch_get_signal(void *p, const size_t i, char *buf, const size_t cap)
+{
+    const auto &r = reinterpret_cast<BatchHandle *>(p)->block->signals.at(i);
+    if (cap) { std::strncpy(buf, r.name.c_str(), cap - 1); buf[cap - 1] = 0; }
+    return r.value;
+}
+
+} // extern "C"

@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liblora_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libloraref.so")
 # timing-only builds of the same reference sources at the other flag sets BASELINE.md asks for (oracle/Makefile)
-REF_VARIANTS = {"-O2": REF_SO, "-O3 -fcx-limited-range": os.path.join(HERE, "_ref", "libloraref_O3cx.so"),
+DROPIN_SO = os.path.join(HERE, "_ref", "libloradrop.so")    # the drop-in, compiled (oracle/Makefile): reference block + HIP detector, batch block
+REF_VARIANTS = {"dropin": DROPIN_SO, "-O2": REF_SO, "-O3 -fcx-limited-range": os.path.join(HERE, "_ref", "libloraref_O3cx.so"),
                 "-O3": os.path.join(HERE, "_ref", "libloraref_O3.so")}
 
 _f32p = C.POINTER(C.c_float)
@@ -395,3 +396,79 @@ class Ref:
     def demod_bench(self, sf, iq, samples_per_stream, n_streams, nthreads, repeat=1):
         iq = _cf(iq)
         return int(self.L.loraref_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads, repeat))
+
+
+class DropInBatch:
+    """lora_sdr_amd/pothos/LoRaDemodBatch.cpp (the multi-channel Pothos block of INTEGRATION.md section 2) compiled against the fake
+    Pothos and linked with liblorahip.so: oracle/_ref/libloradrop.so, driven by oracle/dropin_driver.cpp."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(DROPIN_SO)
+
+    def __init__(self, sf, channels, max_windows=64):
+        L = self.L = C.CDLL(DROPIN_SO)
+        L.loradrop_batch_new.restype = C.c_void_p
+        L.loradrop_batch_new.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t]
+        L.loradrop_batch_free.argtypes = [C.c_void_p]
+        L.loradrop_batch_set.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.loradrop_batch_run.restype = C.c_int64
+        L.loradrop_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.loradrop_batch_count.restype = C.c_size_t
+        L.loradrop_batch_count.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p]
+        L.loradrop_batch_get_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_void_p]
+        L.loradrop_batch_get_label.restype = C.c_size_t
+        L.loradrop_batch_get_label.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.loradrop_batch_packet_len.restype = C.c_size_t
+        L.loradrop_batch_packet_len.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        L.loradrop_batch_get_packet.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, _i16p]
+        L.loradrop_batch_num_signals.restype = C.c_size_t
+        L.loradrop_batch_num_signals.argtypes = [C.c_void_p]
+        L.loradrop_batch_get_signal.restype = C.c_double
+        L.loradrop_batch_get_signal.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        self.sf, self.B = sf, channels
+        self.h = L.loradrop_batch_new(sf, channels, max_windows)
+        if not self.h:
+            raise RuntimeError("LoRaDemodBatch could not be created (no gfx950 device, or the block is not registered)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.loradrop_batch_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set(self, name, v):
+        assert self.L.loradrop_batch_set(self.h, name.encode(), float(v)) == 0, name
+
+    def run(self, iq):
+        """iq: (channels, samples) complex64 -> per-channel dicts: consumed, raw / dec / fft streams, labels per port as
+        [(element index, id)], packets; plus the block's signal log [(name, value)]"""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        assert iq.shape[0] == self.B
+        works = self.L.loradrop_batch_run(self.h, iq.ctypes.data, iq.shape[1])
+        buf = C.create_string_buffer(64)
+        out = []
+        for c in range(self.B):
+            d = {"consumed": self.L.loradrop_batch_count(self.h, c, b"consumed")}
+            for port in ("raw", "dec", "fft"):
+                a = np.empty(self.L.loradrop_batch_count(self.h, c, port.encode()), np.complex64)
+                self.L.loradrop_batch_get_stream(self.h, c, port.encode(), a.ctypes.data)
+                d[port] = a
+                labs = []
+                for i in range(self.L.loradrop_batch_count(self.h, c, (port + "Labels").encode())):
+                    idx = self.L.loradrop_batch_get_label(self.h, c, port.encode(), i, buf, 64)
+                    labs.append((idx, buf.value.decode()))
+                d[port + "_labels"] = labs
+            pk = []
+            for i in range(self.L.loradrop_batch_count(self.h, c, b"packets")):
+                p = np.zeros(self.L.loradrop_batch_packet_len(self.h, c, i), np.int16)
+                self.L.loradrop_batch_get_packet(self.h, c, i, _ptr(p, _i16p))
+                pk.append(p)
+            d["packets"] = pk
+            out.append(d)
+        sig = []
+        for i in range(self.L.loradrop_batch_num_signals(self.h)):
+            v = self.L.loradrop_batch_get_signal(self.h, i, buf, 64)
+            sig.append((buf.value.decode(), v))
+        return out, sig, works

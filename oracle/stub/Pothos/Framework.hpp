@@ -241,6 +241,14 @@ public:
         return t;
     }
     BlockRegistry(const std::string &path, FactoryVoid f) { tableVoid()[path] = f; }
+    //! two size_t parameters (a multi-channel block: sf, channels)
+    typedef Block *(*FactorySizeT2)(const size_t, const size_t);
+    static std::map<std::string, FactorySizeT2> &table2(void)
+    {
+        static std::map<std::string, FactorySizeT2> t;
+        return t;
+    }
+    BlockRegistry(const std::string &path, FactorySizeT2 f) { table2()[path] = f; }
 };
 
 } // namespace Pothos

@@ -32,12 +32,13 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     # struct lorahip_batch: 16 pointer-sized fields incl. one int32 padded to 8
     assert C.sizeof(_lib.Batch) == 16 * 8
-    assert C.sizeof(_lib.WorkResult) == 56
+    assert C.sizeof(_lib.WorkResult) == 72
+    assert C.sizeof(_lib.DemodPorts) == 8 * 8
 
 
 def test_version_and_errors():
     lib = L.load()
-    assert lib.lorahip_version() == 1
+    assert lib.lorahip_version() == 2
     assert lib.lorahip_selfcheck() == 0, lib.lorahip_last_error()     # every kernel's LDS exchange layout is injective
     assert lib.lorahip_strerror(0) == b"ok"
     assert lib.lorahip_strerror(-5) == b"device is not gfx950"
@@ -81,6 +82,14 @@ def test_product_never_touches_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU", ""), "%s mentions oracle" % f
                 assert "/root/reference" not in src
+
+
+@pytest.mark.gpu
+def test_cpp_detector_shim_detects_on_the_gpu(tmp_path):
+    """the success branch of the test below, in the -m gpu set: the C++ shim class finds the DC tone in bin 0"""
+    import torch
+    assert torch.cuda.is_available()
+    test_cpp_detector_shim_compiles_links_and_fails_loudly(tmp_path)
 
 
 def test_cpp_detector_shim_compiles_links_and_fails_loudly(tmp_path):

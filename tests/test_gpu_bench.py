@@ -1,0 +1,41 @@
+"""GPU: bench.py's contract line and its BASELINE configs[3] mode, at toy sizes (the driver runs the real thing)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*args):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_mixed_sf_config_one_rank_over_rccl(gpu):
+    """BASELINE configs[3] on one GPU: 16384 channels bucketed by SF, one launch per bucket on its own stream, symbols
+    gathered through torch.distributed's nccl backend (= RCCL) and checked against the sent ones"""
+    d = run_bench("--config", "mixed", "--steps", "3", "--warmup", "1")
+    m = d["mixed"]
+    assert m["channels"] == 16384 and m["symbols_checked"] == 16384 * 16
+    assert m["symbol_errors_vs_sent"] == 0
+    assert "nccl" in m["gather_backend"]
+    assert 0 < m["frac_byte_weighted"] < 1 and d["value"] == m["Msym_s"]
+
+
+def test_single_shape_line_keeps_the_contract(gpu):
+    d = run_bench("--sf", "8", "--channels", "256", "--symbols", "16", "--steps", "3", "--warmup", "1", "--ramp-seconds", "0", "--cpu-seconds", "0.3")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "oracle"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["symbol_error_rate_vs_sent"] == 0.0
+    assert d["oracle"]["windows"] == 256 * 16 and d["oracle"]["index_mismatches"] == 0
+    assert d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] in ("reference", "port")
+    m = run_bench("--sf", "8", "--channels", "256", "--symbols", "16", "--steps", "3", "--warmup", "1", "--ramp-seconds", "0", "--no-cpu-baseline", "--moving")
+    assert m["oracle"]["index_mismatches"] == 0 and m["config"]["moving_fine_index"] is True

@@ -4,6 +4,8 @@ and the committed golden stream -- and the BASELINE.json configs that are parity
 import numpy as np
 import pytest
 
+from conftest import same_values
+
 pytestmark = pytest.mark.gpu
 
 TOL_DB = 2e-5
@@ -357,3 +359,57 @@ def test_sync_word_threshold_and_mtu_settings(gpu, oracle, mode):
         assert [p[1] for p in pk] == [c for c, _ in r["packets"]], (sync, mtu, thresh)
         assert all(np.array_equal(p[2], q) for p, (_, q) in zip(pk, r["packets"]))
         d.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sf", [7, 9, 11])
+def test_level3_debug_ports_and_labels(gpu, oracle, golden, sf, mode):
+    """the block's raw / dec / fft outputs and stream labels at level 3 of the C ABI (lorahip_demod_set_ports,
+    lorahip_demod_get_labels; LoRaDemod.cpp:81-83,163-164,172,314-324): bit-identical to the restated block, which is pinned to the
+    verbatim LoRaDemod.cpp; for SF7 / SF9 also against the checksums recorded from the verbatim block"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(100 + sf)
+    N = 1 << sf
+    if sf in (7, 9):
+        g = golden("demod_stream.npz")
+        st0, mtu = g["iq_%d" % sf], int(g["mtu_%d" % sf])
+    else:
+        st0, _ = frames(oracle, rng, sf, 1, 6, off=0.3)
+        mtu = 6
+    st1, _ = frames(oracle, rng, sf, 2, mtu, off=-0.4, lead=N // 3)
+    n = max(st0.size, st1.size)
+    streams = np.zeros((2, n), np.complex64)
+    streams[0, :st0.size] = st0
+    streams[1, :st1.size] = st1
+    d = L.LoRaDemod(sf, n_channels=2)
+    d.set_mode(mode)
+    d.setMTU(mtu)
+    d.set_trace(True)
+    cap_frames = n // (N // 4) + 8
+    d.set_ports(fft_frames=cap_frames, dec_samples=n, raw_samples=n)
+    d.work(gpu.from_numpy(streams).to("cuda:0"))
+    for c in range(2):
+        r = oracle.demod_run(sf, streams[c], mtu=mtu)
+        consumed = np.array([k["consumed"] for k in r["calls"]])
+        p = d.ports(c)
+        assert p["produced"] == dict(fft=len(consumed), dec=int(consumed.sum()), raw=int(consumed.sum()))
+        assert same_values(p["raw"].cpu().numpy(), streams[c][:int(consumed.sum())])
+        assert same_values(p["fft"].cpu().numpy(), np.stack(r["fft"]))
+        want_dec = np.concatenate([r["dec"][k][:int(consumed[k])] for k in range(len(consumed))])
+        assert same_values(p["dec"].cpu().numpy(), want_dec)
+        assert d.labels(c) == [k["label"] for k in r["calls"]]
+        if c == 0 and sf in (7, 9):
+            fft = p["fft"].cpu().numpy()
+            assert np.array_equal(np.abs(fft).argmax(axis=1), g["fft_peak_%d" % sf])
+            assert same_values(fft.sum(axis=1), g["fft_sum_%d" % sf])
+            starts = np.concatenate([[0], np.cumsum(consumed)[:-1]])
+            dec = p["dec"].cpu().numpy()
+            for j, k in enumerate([0, 5, 12, 20]):
+                m = min(N, int(consumed[k]))
+                assert same_values(dec[starts[k]:starts[k] + m], g["dec_first_%d" % sf][j][:m])
+    # ports off again: nothing is produced, the run is the plain one
+    d.set_ports()
+    d.activate()
+    d.work(gpu.from_numpy(streams).to("cuda:0"))
+    assert d.ports(0)["produced"] == dict(fft=0, dec=0, raw=0)
+    d.close()

@@ -1,0 +1,121 @@
+"""The drop-in, compiled and run: oracle/_ref/libloradrop.so holds
+
+  (a) the reference's own LoRaDemod.cpp with the two-line patch of INTEGRATION.md section 1 (LoRaDetector<float> ->
+      LoRaDetectorHip<float>), built against the fake Pothos of oracle/stub and linked with liblorahip.so;
+  (b) lora_sdr_amd/pothos/LoRaDemodBatch.cpp, the multi-channel Pothos block on level 3 of the C ABI.
+
+Both are compared with the UNPATCHED reference block (oracle/_ref/libloraref.so: verbatim LoRaDemod.cpp on the reference's own
+LoRaDetector / kissfft) on the same streams: consumption, labels, packets, signals, the fft / dec / raw ports. The libraries
+are built by oracle/Makefile where /root/reference exists and travel to the GPU box as binaries."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import same_values
+
+TOL_DB = 2e-5
+
+
+def _need(path):
+    if not os.path.exists(path):
+        pytest.skip("%s not built (needs /root/reference at build time)" % os.path.basename(path))
+
+
+def test_dropin_library_loads_and_fails_loudly_without_a_gpu():
+    """CPU: the drop-in library resolves against liblorahip.so; without a gfx950 device the batch block's constructor throws
+    (no silent CPU path) and the patched reference block cannot be made either"""
+    import torch
+    from oracle.oracle import DROPIN_SO, DropInBatch
+    _need(DROPIN_SO)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError):
+        DropInBatch(7, 2)
+
+
+def streams_for(golden, oracle, sf, rng):
+    """three channels of equal length: the golden stream, the same delayed, and a fresh two-frame stream with an offset"""
+    g = golden("demod_stream.npz")
+    base = g["iq_%d" % sf]
+    N = 1 << sf
+    mtu = int(g["mtu_%d" % sf])
+    st2 = np.concatenate([np.zeros(37, np.complex64), base])
+    syms = [rng.integers(0, N, mtu).astype(np.uint16) for _ in range(2)]
+    parts = [np.zeros(N // 2 + 11, np.complex64)]
+    for s in syms:
+        parts.append(oracle.mod_frame(sf, s, padding=3))
+    st3 = np.concatenate(parts)
+    st3 = (st3 * np.exp(2j * np.pi * 0.37 / N * np.arange(st3.size))).astype(np.complex64)
+    st3 += (0.03 * (rng.standard_normal(st3.size) + 1j * rng.standard_normal(st3.size))).astype(np.complex64)
+    n = max(base.size, st2.size, st3.size) + N
+    out = np.zeros((3, n), np.complex64)
+    for i, s in enumerate((base, st2, st3)):
+        out[i, :s.size] = s
+    return out, mtu
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sf", [7, 9])
+def test_patched_reference_block_on_the_hip_detector(gpu, golden, sf):
+    """(a): /root/reference/LoRaDemod.cpp itself, its detector swapped for LoRaDetectorHip, against the unpatched block"""
+    from oracle.oracle import Ref, REF_VARIANTS
+    _need(REF_VARIANTS["dropin"])
+    _need(REF_VARIANTS["-O2"])
+    g = golden("demod_stream.npz")
+    iq, mtu = g["iq_%d" % sf], int(g["mtu_%d" % sf])
+    want = Ref("-O2").demod_run(sf, iq, mtu=mtu)
+    got = Ref("dropin").demod_run(sf, iq, mtu=mtu)
+    assert got["consumed"].tolist() == want["consumed"].tolist() == g["consumed_%d" % sf].tolist()
+    assert got["labels"] == want["labels"]
+    assert same_values(got["fft"], want["fft"])                 # the fft port: every bin of every call, bit for bit
+    assert same_values(got["dec"], want["dec"])                 # the dec port is the block's own arithmetic either way
+    assert [c for c, _ in got["packets"]] == [c for c, _ in want["packets"]]
+    assert all(np.array_equal(a, b) for (_, a), (_, b) in zip(got["packets"], want["packets"]))
+    assert [n for n, _ in got["signals"]] == [n for n, _ in want["signals"]]
+    assert np.allclose([v for _, v in got["signals"]], [v for _, v in want["signals"]], rtol=0, atol=TOL_DB)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sf", [7, 9])
+def test_batch_block_posts_what_the_reference_block_posts(gpu, golden, oracle, sf):
+    """(b): LoRaDemodBatch with three channels against three runs of the unpatched reference block"""
+    from oracle.oracle import Ref, REF_VARIANTS, DropInBatch
+    _need(REF_VARIANTS["dropin"])
+    _need(REF_VARIANTS["-O2"])
+    rng = np.random.default_rng(sf)
+    iq, mtu = streams_for(golden, oracle, sf, rng)
+    N = 1 << sf
+    blk = DropInBatch(sf, 3, max_windows=16)                    # small buffers: several work() calls of the block per stream
+    blk.set("setMTU", mtu)
+    chans, signals, works = blk.run(iq)
+    assert works > 1
+    ref = Ref("-O2")
+    sig_by_channel = {}
+    cur = None
+    for name, v in signals:
+        if name == "channel":
+            cur = int(v)
+        else:
+            sig_by_channel.setdefault(cur, []).append((name, v))
+    for c in range(3):
+        want = ref.demod_run(sf, iq[c], mtu=mtu)
+        got = chans[c]
+        consumed = want["consumed"]
+        assert got["consumed"] == int(consumed.sum())
+        starts = np.concatenate([[0], np.cumsum(consumed)[:-1]])
+        # raw = the samples consumed; dec = `total` dechirped samples per call; fft = N bins per call
+        assert same_values(got["raw"], iq[c][:int(consumed.sum())])
+        want_dec = np.concatenate([want["dec"][k, :int(consumed[k])] for k in range(len(consumed))])
+        assert same_values(got["dec"], want_dec)
+        assert same_values(got["fft"], want["fft"].reshape(-1))
+        lab = [(int(starts[k]), l) for k, l in enumerate(want["labels"]) if l]
+        assert got["raw_labels"] == lab and got["dec_labels"] == lab
+        assert got["fft_labels"] == [(k * N, l) for k, l in enumerate(want["labels"]) if l]
+        assert len(got["packets"]) == len(want["packets"]) >= 2
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got["packets"], want["packets"]))
+        ws = want["signals"]
+        gs = sig_by_channel.get(c, [])
+        assert [n for n, _ in gs] == [n for n, _ in ws]
+        assert np.allclose([v for _, v in gs], [v for _, v in ws], rtol=0, atol=TOL_DB)
+    blk.close()

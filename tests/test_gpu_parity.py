@@ -270,9 +270,9 @@ def test_golden_detector_kat(gpu, golden, sf):
     assert np.abs(to_np(r["fIndex"]) - ref_f).max() <= TOL_FIDX
 
 
-# every selectable kernel variant per SF (lorahip_kernels.hip / lorahip_fast.hip / lorahip_wide.hip); 1 = generic
-VARIANTS = {6: [0, 1, 7, 8, 10, 11, 12, 15], 7: list(range(18)), 8: [0, 1, 6, 7, 8, 9, 10, 11, 13, 15, 17], 9: [0, 1, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 20, 21, 22, 23, 24], 10: [0, 1, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16],
-            11: list(range(15)) + [20, 21, 22, 23, 24], 12: list(range(11)) + [13, 14]}
+# the kernel variants the library ships (lorahip_set_variant): 0 = tuned default, 1 = generic kernel, 10 = the one alternative per
+# SF; the round-1 A/B zoo is compiled only with -DLORAHIP_ALL_VARIANTS (profiles/r01/s8_variants.txt is its record)
+VARIANTS = {sf: [0, 1, 10] for sf in range(6, 13)}
 
 
 @pytest.mark.parametrize("sf", range(6, 13))

@@ -74,3 +74,52 @@ def test_gather_over_gloo_world2():
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res)
     assert all(r[2] == 37.0 for r in res)
+
+
+def _mixed_worker(rank, world, port, q):
+    """BASELINE configs[3] end to end minus the GPU: the shard plan, the per-bucket result layout, the gather and the check that
+    bench.py --config mixed performs, with the demodulator replaced by its defining property (symbol s -> bin s + 1)"""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from lora_sdr_amd import workloads as WL
+    from lora_sdr_amd.shard import gather_symbols, shard_channels
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_ch, S = 16384, 16
+    sfs = WL.mixed_sf_channels(n_ch)
+    mine = shard_channels(sfs, world)[rank]
+    sent = WL.mixed_sent(sfs, S)
+    parts, order = [], []
+    for sf in range(7, 13):                                    # one "launch" per SF bucket, like the bench
+        ch = mine[sfs[mine] == sf]
+        if ch.size == 0:
+            continue
+        got = (sent[torch.from_numpy(ch)] + 1) % (1 << sf)
+        parts.append(got.to(torch.int16))
+        order.append(ch)
+    full = gather_symbols(torch.cat(parts), np.concatenate(order), n_ch)
+    bad = WL.mixed_errors(full, sfs, S)
+    # and a corrupted result must be caught
+    full2 = full.clone()
+    full2[5, 3] ^= 1
+    q.put((rank, bad, WL.mixed_errors(full2, sfs, S), int(mine.size)))
+    dist.destroy_process_group()
+
+
+def test_mixed_sf_config_structure_over_gloo_world2():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0, "gloo worker failed"
+    res = sorted(q.get(timeout=10) for _ in procs)
+    assert [r[1] for r in res] == [0, 0] and [r[2] for r in res] == [1, 1]
+    assert sum(r[3] for r in res) == 16384

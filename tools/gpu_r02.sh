@@ -44,6 +44,53 @@ if [[ $what == *l2* ]]; then
   done
 fi
 
+PMCA="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"
+PMCB="SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES"
+pmc1() {   # pmc1 <outprefix> <counters> <cmd...>: ONE rocprofv3 pass
+  local pre=$1 set=$2; shift 2
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $set -d $O/${pre} -o pmc --output-format csv -- "$@" > $O/${pre}.log 2>&1 )
+}
+line() {   # line <json file> <label>
+  python - "$1" "$2" <<'EOP'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-34s %8.1f Msym/s  frac %.3f  launch %.1f us  ser %s" % (sys.argv[2], d["value"], d["roofline"]["frac"], d["roofline"]["launch_us"], d.get("symbol_error_rate_vs_sent")))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e); print(open(sys.argv[1].replace(".json", ".err")).read()[-600:])
+EOP
+}
+
+if [[ $what == *after* ]]; then
+  # the locked-receiver shape with the split tables (default) and with the round-1 table gather (A/B), then the L1/L2 counters
+  for sf in ${L2SF:-7 10 12}; do
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline --moving > $O/${TAG}_moving_sf$sf.json 2> $O/${TAG}_moving_sf$sf.err
+    line $O/${TAG}_moving_sf$sf.json "SF$sf moving, split tables"
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline --moving --fine-gather > $O/${TAG}_moving_gather_sf$sf.json 2> $O/${TAG}_moving_gather_sf$sf.err
+    line $O/${TAG}_moving_gather_sf$sf.json "SF$sf moving, table gather"
+  done
+  for sf in ${PMCSF:-7 10}; do
+    pmc1 ${TAG}_l2_mov_sf${sf}_setA "$PMCA" python $R/bench.py --sf $sf --moving --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline
+    python tools/pmc_kernels.py "$O/${TAG}_l2_mov_sf${sf}_set*" detect "bench.py --sf $sf --moving" | tee $O/${TAG}_l2_mov_sf$sf.txt
+    case $sf in 7) CH=16384;; 8|9) CH=8192;; 10) CH=4096;; *) CH=1024;; esac
+    timeout 200 python tools/bench_demod.py --sf $sf --channels $CH --modes 1 > $O/${TAG}_level3_sf$sf.txt 2>&1
+    tail -1 $O/${TAG}_level3_sf$sf.txt
+    pmc1 ${TAG}_l2_str_sf${sf}_setA "$PMCA" python $R/tools/bench_demod.py --sf $sf --channels $CH --modes 1
+    python tools/pmc_kernels.py "$O/${TAG}_l2_str_sf${sf}_set*" demodStream "tools/bench_demod.py --sf $sf --channels $CH (streaming kernel)" | tee $O/${TAG}_l2_str_sf$sf.txt
+  done
+  pmc1 ${TAG}_l2_mov_sf7_setB "$PMCB" python $R/bench.py --sf 7 --moving --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline
+  python tools/pmc_kernels.py "$O/${TAG}_l2_mov_sf7_set*" detect "bench.py --sf 7 --moving" | tee $O/${TAG}_l2_mov_sf7.txt
+fi
+
+if [[ $what == *movvar* ]]; then
+  # A/B of option sets on the locked-receiver shape (needs a library built with --all-variants)
+  for spec in ${MOVVARS:-7:0 7:3 7:5 7:10 10:0 10:16 10:10 12:0 12:2 12:10}; do
+    sf=${spec%%:*}; v=${spec##*:}
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline --moving --variant $v > $O/${TAG}_movvar_sf${sf}_v$v.json 2> $O/${TAG}_movvar_sf${sf}_v$v.err
+    line $O/${TAG}_movvar_sf${sf}_v$v.json "SF$sf moving variant $v"
+  done
+fi
+
 if [[ $what == *bench* ]]; then
   timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
   echo "bench exit $?"; tail -c 3000 $O/${TAG}_bench.json; tail -5 $O/${TAG}_bench.err
