@@ -68,6 +68,20 @@ def parse():
     return ap.parse_args()
 
 
+def emit(env, line):
+    """Rank 0 prints THE line -- after the process group is gone and every C-level stdout buffer is flushed (RCCL prints a version
+    banner through C stdio, which would otherwise land after the line when the process exits)"""
+    import ctypes
+    env.close()
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if line is not None:
+        print(json.dumps(line, separators=(",", ":")), flush=True)
+
+
 def r4(x):
     """4 significant digits: keeps the one JSON line short"""
     return float("%.4g" % x)
@@ -214,8 +228,8 @@ class Shape:
         gs = out["sym"].cpu().numpy().view(np.uint16)
         fin = np.isfinite(o["power"])
         return {"windows": int(self.W), "index_mismatches": int((o["sym"] != gs).sum()),
-                "max_power_diff_dB": r4(float(np.abs(out["power"].cpu().numpy() - o["power"])[fin].max())),
-                "max_fIndex_diff": r4(float(np.abs(out["fIndex"].cpu().numpy() - o["fIndex"]).max()))}
+                "max_dB": r4(float(np.abs(out["power"].cpu().numpy() - o["power"])[fin].max())),
+                "max_fIndex": r4(float(np.abs(out["fIndex"].cpu().numpy() - o["fIndex"]).max()))}
 
     def close(self):
         self.ctx.close()
@@ -373,7 +387,7 @@ def section_config5(env, L, a, threads):
     return res
 
 
-def section_mixed(env, L, a, S=16, n_channels=16384):
+def section_mixed(env, L, a, S=16, n_channels=16384, rccl_single=False):
     """BASELINE configs[3]: 16384 channels, SF(c) = 7 + c mod 6, S symbols each; byte-weighted contiguous shards
     (lora_sdr_amd/shard.py), one launch per SF bucket on its own HIP stream, symbols gathered to every rank at the end."""
     import numpy as np
@@ -429,6 +443,15 @@ def section_mixed(env, L, a, S=16, n_channels=16384):
     local_ch = np.concatenate(order) if order else np.zeros(0, np.int64)
     dist, made = env.dist, False
     try:
+        if dist is None and not rccl_single:
+            # one rank, no collective to run: the local result is the global one (bench.py --config mixed sets up a 1-rank
+            # RCCL group instead, so that the gather itself is exercised on a single GPU: tests/test_gpu_bench.py)
+            full = torch.zeros((n_channels, S), dtype=torch.int16, device=env.dev)
+            full[torch.from_numpy(local_ch).to(env.dev)] = local_sym
+            res["gather_backend"] = "none (1 rank)"
+            res["symbol_errors_vs_sent"] = WL.mixed_errors(full, sfs, S)
+            res["symbols_checked"] = n_channels * S
+            raise StopIteration
         if dist is None:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -445,6 +468,8 @@ def section_mixed(env, L, a, S=16, n_channels=16384):
         bad = WL.mixed_errors(full.to(env.dev), sfs, S)
         res["symbol_errors_vs_sent"] = bad
         res["symbols_checked"] = n_channels * S
+    except StopIteration:
+        pass
     except Exception as e:                                           # pragma: no cover - environment dependent
         res["gather_backend"] = "failed: %s" % str(e)[:80]
     finally:
@@ -467,7 +492,7 @@ def main():
     solo = rank0 and env.world == 1                     # CPU-side work (baseline, oracle) only here
 
     if a.config == "mixed":
-        m = section_mixed(env, L, a)
+        m = section_mixed(env, L, a, rccl_single=True)
         if rank0:
             line = {"metric": METRIC, "value": m["Msym_s"], "unit": "Msym/s", "n_gpus": env.world, "steps": a.steps, "warmup": a.warmup,
                     "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -475,8 +500,7 @@ def main():
                                                                 "byte-weighted shards over %d rank(s)" % env.world},
                     "roofline": {"bound": "hbm", "frac": m["frac_byte_weighted"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "achieved": r4(m["frac_byte_weighted"] * HBM_PEAK_GBS), "traffic": None}, "mixed": m, "rccl_ranks": env.rccl_ranks}
-            print(json.dumps(line), flush=True)
-        env.close()
+        emit(env, line if rank0 else None)
         return
 
     sf0 = a.sf if a.sf is not None else 7
@@ -572,9 +596,7 @@ def main():
             if c5:
                 line["config5"] = c5
             line["mixed"] = mixed
-    if rank0:
-        print(json.dumps(line), flush=True)
-    env.close()
+    emit(env, line if rank0 else None)
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 // LoRaDetector shim (include/lorahip.h). Host-side only; kernels are in lorahip_kernels.hip.
 #include "lorahip_internal.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>

@@ -309,6 +309,30 @@ __device__ __forceinline__ void tailValues(const float powerScale, const float m
     if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
 }
 
+//! The same values for a caller whose lanes hold the window's results REPLICATED (the streaming kernels: every lane of a
+//! channel's group runs the frame machine): even and odd lanes each evaluate one of the two logarithms and one of the two
+//! hypotenuses -- the same routines on the same operands, hence the same bits -- and swap with their neighbour (DPP quad_perm
+//! [1,0,3,2]), instead of every lane evaluating all four.
+template <class CPX>
+__device__ __forceinline__ void tailValuesPaired(const float powerScale, const float maxValue, const double total,
+                                                 const CPX leftBin, const CPX rightBin, const int lane,
+                                                 float &power, float &powerAvg, float &fIndex)
+{
+    const bool odd = lane & 1;
+    const float noise = sqrtf((float)(total - (double)maxValue));
+    const float fundamental = sqrtf(maxValue);
+    const float lgMine = (float)log10d((double)(odd ? noise : fundamental));
+    const float hyMine = (float)hypotd(odd ? rightBin.x : leftBin.x, odd ? rightBin.y : leftBin.y);
+    const float lgOther = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(lgMine), 0xB1, 0xf, 0xf, false));
+    const float hyOther = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(hyMine), 0xB1, 0xf, 0xf, false));
+    powerAvg = 20 * (odd ? lgMine : lgOther) - powerScale;
+    power = 20 * (odd ? lgOther : lgMine) - powerScale;
+    const float left = odd ? hyOther : hyMine, right = odd ? hyMine : hyOther;
+    const double demon = (2.0 * (double)fundamental) - (double)right - (double)left;
+    fIndex = 0.0f;
+    if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
+}
+
 template <class CPX>
 __device__ __forceinline__ void detectTail(const DetectArgs &a, const unsigned w, const int maxIndex,
                                            const float maxValue, const double total,

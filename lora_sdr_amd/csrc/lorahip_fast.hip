@@ -203,21 +203,24 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         else
         {
             const float sgn = (perWindowSel && sel == LORAHIP_CHIRP_UP) ? -1.0f : 1.0f;
+            const v2f *cwf = &cw[0][0];
+            const auto chirpOf = [&](const int i) { return MAKE2(cwf[i].x, sgn * cwf[i].y); };
+            if (anyMoving)
+            {
+                // yv = idx0 in the windows that do not move
+                dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, dechirp);
+            }
+            else
+            {
 #pragma unroll
-            for (int r = 0; r < R; r++)
+                for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int u = 0; u < VEC; u++)
-                {
-                    const v2f c = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
-                    v2f f = fconst;
-                    if (anyMoving)
+                    for (int u = 0; u < VEC; u++)
                     {
-                        const unsigned yi = yv[r][u];     // = idx0 in the windows that do not move
-                        f = fl.A ? fineEval<fineSplitLog2H(C::LOG2N)>(yi, fl) : gFine[yi];
+                        const v2f y = cmulv(cmulv(x[r][u], chirpOf(r * VEC + u)), fconst);
+                        x[r][u] = dechirp ? y : x[r][u];
                     }
-                    const v2f y = cmulv(cmulv(x[r][u], c), f);
-                    x[r][u] = dechirp ? y : x[r][u];
-                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -386,13 +389,19 @@ bool fastLayoutsOk()
  **********************************************************************/
 typedef hipError_t (*FastLaunch)(const DetectArgs &, const FastTables &, hipStream_t);
 
-//! SF9 default: the two-phase geometry, with the option set that measured best for the shape of the call
-static hipError_t launchSf9Default(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
+/***********************************************************************
+ * defaults: the option set depends on the SHAPE of the call. Launch-uniform batches (one chirp selection, no moving fine-tune
+ * index: the steady state bench.py times) run the kernels tuned in round 1. Batches with per-window settings carry the
+ * closed-form index arithmetic and the fp64 table product per sample (lorahip_fine.h): at three waves per SIMD (168 registers)
+ * those kernels spill from SF8 up, so they get their own option sets (profiles/r02/s3_explore_moving_variants.txt:
+ * SF9 0.20 -> 0.36 of the HBM roofline, SF10 0.20 -> 0.34).
+ **********************************************************************/
+template <class UNI_CFG, class MOVING_CFG, class DBG_CFG>
+static hipError_t launchByShape(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
-    if (a.decOut || a.fftOut) return launchCfg<Fast<9, CH_REG | TW_REG | NT | X1_SWAP>>(a, ft, stream);        // debug ports: three-phase kernel
+    if (a.decOut || a.fftOut) return launchOne<DBG_CFG, true, false>(a, ft, stream);
     const bool uni = a.chirpSel == nullptr && a.fineErr == nullptr;
-    // per-window settings need registers for the index chain: last-phase twiddles from the LDS table there (+4 % over the three-phase kernel)
-    return uni ? launchCfg<Fast9b<W2 | CH_REG | TW_REG | NT | PF_NONE>>(a, ft, stream) : launchCfg<Fast9b<W2 | CH_REG | NT>>(a, ft, stream);
+    return uni ? launchOne<UNI_CFG, false, true>(a, ft, stream) : launchOne<MOVING_CFG, false, false>(a, ft, stream);
 }
 
 struct FastVariant { int sf, variant; FastLaunch launch; };
@@ -404,13 +413,17 @@ struct FastVariant { int sf, variant; FastLaunch launch; };
 static const FastVariant kFastVariants[] = {
     V(6, 0, 0),                                            // default: 16 windows per wave keep the LDS copies of chirp / twiddles cheap
     V(6, 10, CH_REG | NT),
-    V(7, 0, CH_REG | NT),                                  // default
+    V(7, 0, CH_REG | NT),                                  // default (every shape)
     V(7, 10, 0),
-    V(8, 0, CH_REG | TW_REG | NT),                         // default
+    // default SF8: uniform batches with the tables in registers, per-window settings with the tables in LDS
+    { 8, 0, &launchByShape<Fast<8, CH_REG | TW_REG | NT>, Fast<8, 0>, Fast<8, CH_REG | TW_REG | NT>> },
     V(8, 10, 0),
-    { 9, 0, &launchSf9Default },                           // default: geometry chosen per call, see launchSf9Default
+    // default SF9: uniform batches on the two-phase geometry (16 lanes x 32 points), per-window settings and the debug ports on the
+    // three-phase one (32 lanes x 16 points) at two waves per SIMD
+    { 9, 0, &launchByShape<Fast9b<W2 | CH_REG | TW_REG | NT | PF_NONE>, Fast<9, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>, Fast<9, CH_REG | TW_REG | NT | X1_SWAP>> },
     V(9, 10, 0),
-    V(10, 0, CH_REG | TW_REG | NT | X1_SWAP),              // default
+    // default SF10: per-window settings at two waves per SIMD with the middle-phase twiddles in registers too
+    { 10, 0, &launchByShape<Fast<10, CH_REG | TW_REG | NT | X1_SWAP>, Fast<10, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>, Fast<10, CH_REG | TW_REG | NT | X1_SWAP>> },
     V(10, 10, 0),
 #ifdef LORAHIP_ALL_VARIANTS
     V(6, 7, TW_REG), V(6, 8, NT), V(6, 11, CH_REG | NT), V(6, 12, CH_REG | TW_REG | NT), V(6, 15, CH_REG | TW_REG | NT | PF_NONE),
@@ -432,6 +445,9 @@ static const FastVariant kFastVariants[] = {
     V(10, 6, PF_EARLY), V(10, 7, TW_REG), V(10, 8, NT), V(10, 9, TW_REG | NT), V(10, 11, CH_REG | TW_REG | NT),
     V(10, 12, CH_REG | TW_REG | NT | X1_SWAP), V(10, 13, CH_REG | TW_REG | NT | NB_SEL), V(10, 14, CH_REG | TW_REG | NT | NB_SEL | X1_SWAP),
     V(10, 15, CH_REG | TW_REG | NT | X1_SWAP | TWM_REG | PF_NONE), V(10, 16, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG),
+    // round 2: the defaults at the 256-register budget of two waves per SIMD (the per-window-settings kernels spill at three)
+    V(7, 30, W2 | CH_REG | NT), V(8, 30, W2 | CH_REG | TW_REG | NT), V(9, 30, W2 | CH_REG | TW_REG | NT | X1_SWAP), V(9, 31, CH_REG | TW_REG | NT | X1_SWAP),
+    V(10, 30, W2 | CH_REG | TW_REG | NT | X1_SWAP), V(10, 31, W2 | CH_REG | TW_REG | NT | X1_SWAP | PF_NONE), V(8, 31, W2 | CH_REG | TW_REG | NT | PF_NONE),
 #endif
 };
 #undef V

@@ -227,6 +227,47 @@ __device__ __forceinline__ v2f fineEval(const unsigned y, const FineLds &s)
     return v2f{(float)re, (float)im};
 }
 
+//! x[i] = (x[i] * chirp(i)) * _fineTuneTable[y[i]] for CNT samples (LoRaDemod.cpp:159), four at a time: the eight LDS reads of
+//! a group (or its four table reads, where the split tables are not in use) are issued back to back, then the four fp64
+//! products and the two complex multiplies per sample -- straight-line code, so the reads of one group overlap the arithmetic
+//! of the previous one and at most four table entries are live. `chirp(i)` yields the chirp-table entry of sample i with the
+//! window's conjugation applied; lanes with keep == false leave x untouched (windows fed already dechirped).
+template <int LH, int CNT, class CHIRP>
+__device__ __forceinline__ void dechirpFine(v2f *x, CHIRP chirp, const unsigned *y, const FineLds &s, const v2f *__restrict__ gFine, const bool keep)
+{
+    static_assert(CNT % 4 == 0, "four values per round");
+    const bool split = s.A != nullptr;                          // uniform over the launch
+#pragma unroll
+    for (int i = 0; i < CNT; i += 4)
+    {
+        v2f f[4];
+        if (split)
+        {
+            double2 a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { a[j] = s.A[y[i + j] >> LH]; b[j] = s.B[y[i + j] & ((1u << LH) - 1u)]; }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const double re = __builtin_fma(a[j].x, b[j].x, -(a[j].y * b[j].y));
+                const double im = __builtin_fma(a[j].x, b[j].y, a[j].y * b[j].x);
+                f[j] = v2f{(float)re, (float)im};
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int j = 0; j < 4; j++) f[j] = gFine[y[i + j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const v2f v = cmulv(cmulv(x[i + j], chirp(i + j)), f[j]);
+            x[i + j] = keep ? v : x[i + j];
+        }
+    }
+}
+
 //! closed-form fine-tune indices of a lane's own samples n = VEC*t + u + VEC*T*r (lorahip_fine.h); returns the largest one
 template <int LOG2N, int VEC, int T, int R>
 __device__ __forceinline__ unsigned fineLaneIndices(const int idx0, const FinePlan &p, const int t, unsigned (&y)[R][VEC])

@@ -13,6 +13,7 @@
 // lorahip_demod.cpp's host path, which tests pin against the verbatim LoRaDemod.cpp.
 #include "lorahip_fastcore.h"
 #include "lorahip_framemachine.h"
+#include <cstdlib>
 
 namespace lorahip {
 
@@ -95,17 +96,18 @@ demodStream(const StreamArgs s)
         v2f cw[R][VEC];
         K::chirpFromLds(cw, sCh, t);
         const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
-        const v2f fconst = gFine[idx0];
+        const v2f *cwf = &cw[0][0];
+        const auto chirpOf = [&](const int i) { return MAKE2(cwf[i].x, sgn * cwf[i].y); };
+        // yv = idx0 in the channels where nothing moves
+        if (anyMoving) dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, true);
+        else
+        {
+            const v2f fconst = gFine[idx0];
 #pragma unroll
-        for (int r = 0; r < R; r++)
+            for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int u = 0; u < VEC; u++)
-            {
-                const v2f cv = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
-                v2f f = fconst;
-                if (anyMoving) f = fl.A ? fineEval<fineSplitLog2H(C::LOG2N)>(yv[r][u], fl) : gFine[yv[r][u]];     // = the entry at idx0 where nothing moves
-                x[r][u] = cmulv(cmulv(x[r][u], cv), f);
-            }
+                for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulv(x[r][u], chirpOf(r * VEC + u)), fconst);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -120,7 +122,7 @@ demodStream(const StreamArgs s)
         K::neighbours(vl, F, bestI, lane, t, l, r);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tailValues(s.powerScale, bestV, tot, l, r, power, powerAvg, fIndex);
+        tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
         value = bestI;
     };
 
@@ -134,7 +136,8 @@ demodStream(const StreamArgs s)
         float power, powerAvg, fIndex;
         const int fineIdxBefore = st.fineTuneIndex;
         const float fineErrBefore = st.finefreqError;
-        detect(live, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd);
+        const long long here = base + st.pos;
+        detect(live, here, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd);
         const float snr = power - powerAvg;                                             // :173
         const bool squelched = snr < s.thresh;                                          // :174
         if (live) st.fineTuneIndex = idxEnd;                                            // the loop commits the member (:160-162)
@@ -149,7 +152,7 @@ demodStream(const StreamArgs s)
             int value1, idxEnd1;
             float p1, pa1, fi1;
             // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
-            detect(need1, base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, p1, pa1, fi1, idxEnd1);
+            detect(need1, here + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, p1, pa1, fi1, idxEnd1);
             if (need1)
             {
                 match1 = (value1 + 4) / 8 == (s.sync & 0xf);                           // :205
@@ -187,10 +190,11 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
 }
 
 //             LOG2N T VEC NPH PB1 PB2 w/SIMD  X0: ROT PAD S  D   chLDS twLDS prefetch
-typedef FastCfg<6,  2, 4,  2,  2,  6,  3,          2,  1,  0, 0,  true,  true,  0> Stream6;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  3,          1,  1,  0, 0,  true,  true,  0> Stream7;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  3,          0,  1,  0, 0,  true,  true,  0> Stream8;
-typedef FastCfg<9,  4, 1,  2,  5,  9,  2,          0,  1,  0, 0,  true,  true,  0> Stream9;    // 16 lanes x 32 points, two phases (+7 % over 32 x 16, three phases)
+typedef FastCfg<6,  2, 4,  2,  2,  6,  2,          2,  1,  0, 0,  true,  true,  0> Stream6;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  true,  true,  0> Stream7;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  2,          0,  1,  0, 0,  true,  true,  0> Stream8;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  true,  true,  0, false, false, true> Stream9;    // 32 lanes x 16 points, three phases, exchange 1 as row swaps:
+                                                                                                                 // with the per-sample fine-tune arithmetic the 32-point geometry spills (0.20 -> 0.26 of the roofline)
 typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  true,  true,  0, false, false, true> Stream10;   // exchange 1 as register row swaps
 
 //! the used columns of a [rows][capacity] record array packed densely (2-byte units): what goes back to the host is what a

@@ -338,21 +338,24 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         else
         {
             const float sgn = (perWindowSel && sel == LORAHIP_CHIRP_UP) ? -1.0f : 1.0f;
+            const v2f *cwf = &cw[0][0];
+            const auto chirpOf = [&](const int i) { return MAKE2(cwf[i].x, sgn * cwf[i].y); };
+            if (anyMoving)
+            {
+                // yv = idx0 in the windows that do not move
+                dechirpFine<fineSplitLog2H(LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, dechirp);
+            }
+            else
+            {
 #pragma unroll
-            for (int r = 0; r < R; r++)
+                for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int u = 0; u < VEC; u++)
-                {
-                    const v2f c = MAKE2(cw[r][u].x, sgn * cw[r][u].y);
-                    v2f f = fconst;
-                    if (anyMoving)
+                    for (int u = 0; u < VEC; u++)
                     {
-                        const unsigned yi = yv[r][u];     // = idx0 in the windows that do not move
-                        f = fl.A ? fineEval<fineSplitLog2H(LOG2N)>(yi, fl) : gFine[yi];
+                        const v2f y = cmulv(cmulv(x[r][u], chirpOf(r * VEC + u)), fconst);
+                        x[r][u] = dechirp ? y : x[r][u];
                     }
-                    const v2f y = cmulv(cmulv(x[r][u], c), f);
-                    x[r][u] = dechirp ? y : x[r][u];
-                }
+            }
             if (usedChain) __syncthreads();               // sIdx is about to be overwritten by exchange 0
         }
         if (DBG && a.decOut && active)
@@ -576,10 +579,23 @@ struct WideVariant { int sf, variant; WideLaunch launch; bool (*layoutOk)(); };
 #define V(SF, N, OPTS) { SF, N, &launchCfgWide<Wide<SF, (OPTS)>>, &layoutOk<Wide<SF, (OPTS)>> }
 // ships: the default (0) and one alternative per SF (10: the plain exchange-0 layout, four barriers per window, register
 // prefetch); the rest of the round-1 A/B set only with -DLORAHIP_ALL_VARIANTS (profiles/r01/s8_variants.txt)
+//! defaults by call shape, like lorahip_fast.hip's: per-window settings (moving fine-tune index) at two waves per SIMD
+template <class UNI_CFG, class MOVING_CFG>
+static hipError_t launchWideByShape(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
+{
+    if (a.decOut || a.fftOut) return launchOneWide<UNI_CFG, true, false>(a, ft, stream);
+    const bool uni = a.chirpSel == nullptr && a.fineErr == nullptr;
+    return uni ? launchOneWide<UNI_CFG, false, true>(a, ft, stream) : launchOneWide<MOVING_CFG, false, false>(a, ft, stream);
+}
+static bool defaultLayoutsOk()
+{
+    return layoutOk<Wide<11, WPF_NONE | WNT | WONE | WINPLACE>>() && layoutOk<Wide<11, WW2 | WNT | WONE | WINPLACE>>() &&
+           layoutOk<Wide<12, WNT | WINPLACE>>() && layoutOk<Wide<12, WW2 | WNT | WINPLACE>>();
+}
 static const WideVariant kWideVariants[] = {
-    V(11, 0, WPF_NONE | WNT | WONE | WINPLACE),            // default
+    { 11, 0, &launchWideByShape<Wide<11, WPF_NONE | WNT | WONE | WINPLACE>, Wide<11, WW2 | WNT | WONE | WINPLACE>>, &defaultLayoutsOk },   // default
     V(11, 10, 0),
-    V(12, 0, WNT | WINPLACE),                              // default
+    { 12, 0, &launchWideByShape<Wide<12, WNT | WINPLACE>, Wide<12, WW2 | WNT | WINPLACE>>, &defaultLayoutsOk },                            // default
     V(12, 10, 0),
 #ifdef LORAHIP_ALL_VARIANTS
     V(11, 2, WW2), V(11, 3, WW2 | WCH_LDS), V(11, 4, WW2 | WTW_LDS), V(11, 5, WW2 | WCH_LDS | WTW_LDS), V(11, 6, WW4 | WPF_NONE),
@@ -587,6 +603,9 @@ static const WideVariant kWideVariants[] = {
     V(11, 13, WPF_NONE | WNT | WONE | WINPLACE), V(11, 14, WPF_NONE | WNT | WINPLACE),
     V(12, 2, WW2), V(12, 3, WW2 | WCH_LDS), V(12, 4, WW2 | WTW_LDS), V(12, 5, WW2 | WCH_LDS | WTW_LDS), V(12, 6, WW4 | WPF_NONE),
     V(12, 7, WPF_NONE), V(12, 8, WNT), V(12, 9, WPF_NONE | WNT), V(12, 13, WPF_NONE | WNT | WINPLACE), V(12, 14, WNT | WINPLACE),
+    // round 2: the defaults at the 256-register budget of two waves per SIMD
+    V(11, 30, WW2 | WPF_NONE | WNT | WONE | WINPLACE), V(11, 31, WW2 | WNT | WINPLACE), V(11, 29, WW2 | WNT | WONE | WINPLACE),
+    V(12, 30, WW2 | WNT | WINPLACE), V(12, 31, WW2 | WPF_NONE | WNT | WINPLACE),
 #endif
 };
 #undef V
@@ -706,17 +725,17 @@ demodStreamWide(const StreamArgs s)
             }
         }
         const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
-        const v2f fconst = gFine[idx0];
+        const v2f *chf = &ch[0][0];
+        const auto chirpOf = [&](const int i) { return MAKE2(chf[i].x, sgn * chf[i].y); };
+        if (moving) dechirpFine<fineSplitLog2H(LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, true);
+        else
+        {
+            const v2f fconst = gFine[idx0];
 #pragma unroll
-        for (int r = 0; r < R; r++)
+            for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int u = 0; u < VEC; u++)
-            {
-                const v2f cv = MAKE2(ch[r][u].x, sgn * ch[r][u].y);
-                v2f f = fconst;
-                if (moving) f = fl.A ? fineEval<fineSplitLog2H(LOG2N)>(yv[r][u], fl) : gFine[yv[r][u]];
-                x[r][u] = cmulv(cmulv(x[r][u], cv), f);
-            }
+                for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulv(x[r][u], chirpOf(r * VEC + u)), fconst);
+        }
         if (usedChain) __syncthreads();                    // sIdx is about to be overwritten by exchange 0
 
         // phase 0 -> exchange 0
@@ -793,7 +812,7 @@ demodStreamWide(const StreamArgs s)
             }
         }
         __syncthreads();                                                                      // B5
-        tailValues(s.powerScale, bestV, tot, sNb[0], sNb[1], power, powerAvg, fIndex);
+        tailValuesPaired(s.powerScale, bestV, tot, sNb[0], sNb[1], lane, power, powerAvg, fIndex);
         value = bestI;
     };
 

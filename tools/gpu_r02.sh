@@ -91,6 +91,13 @@ if [[ $what == *movvar* ]]; then
   done
 fi
 
+if [[ $what == *explore* ]]; then
+  timeout 600 python tools/explore_r02.py moving > $O/${TAG}_explore_moving.txt 2>&1; cat $O/${TAG}_explore_moving.txt | grep -v amdgpu.ids
+  for alt in ${STREAM_ALTS:-0}; do
+    LORAHIP_STREAM_ALT=$alt timeout 300 python tools/explore_r02.py stream > $O/${TAG}_explore_stream_alt$alt.txt 2>&1; grep "^SF" $O/${TAG}_explore_stream_alt$alt.txt
+  done
+fi
+
 if [[ $what == *bench* ]]; then
   timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
   echo "bench exit $?"; tail -c 3000 $O/${TAG}_bench.json; tail -5 $O/${TAG}_bench.err
