@@ -331,21 +331,27 @@ def section_level3(env, L, sf):
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        d.work(iq)
-        dt = time.perf_counter() - t0
+        d.work(iq)                                  # the streaming kernel + per-channel state back: packets stay on the device
+        t1 = time.perf_counter()
+        ps, pn, pc = d.packets_device(clear=False)  # ... packed there into the batched decoder's input layout
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        pk_host = d.packets()                       # ... or drained to the host queue (what a host consumer pays)
+        t3 = time.perf_counter()
         if rep == 0:
             calls = d.work_calls()
-            pk = d.packets()
-        else:
-            d.packets()
-            if best is None or dt < best[0]:
-                best = (dt, d.kernel_ms())
+            pk = pk_host
+            n_dev = int(ps.shape[0])
+        elif best is None or (t2 - t0) < best[0]:
+            best = (t2 - t0, d.kernel_ms(), (t1 - t0) + (t3 - t2))
         d.activate()
     n_pk, ok = WL.check_frame_packets(pk, data, 1 << sf, nsyms)
+    # e2e = host wall clock from IQ in HBM to packets in the decoder's layout in HBM; e2e_host = the same to packets in host memory
     res = {"sf": sf, "channels": B, "work_calls": int(calls), "Msym_s_e2e": r4(calls / best[0] / 1e6), "e2e_ms": r4(best[0] * 1e3),
+           "frac_e2e": r4(calls * L.bytes_per_symbol(sf) / best[0] / 1e9 / HBM_PEAK_GBS), "e2e_host_ms": r4(best[2] * 1e3),
            "kernel_us": r4(best[1] * 1e3), "Msym_s_kernel": r4(calls / (best[1] / 1e3) / 1e6),
            "frac_kernel": r4(calls * L.bytes_per_symbol(sf) / (best[1] / 1e3) / 1e9 / HBM_PEAK_GBS),
-           "packets": n_pk, "packets_expected": B * frames, "packets_ok": ok}
+           "packets": n_pk, "packets_device": n_dev, "packets_expected": B * frames, "packets_ok": ok}
     if env.rank == 0 and env.world == 1:
         # the same streams through the CPU oracle's restated block (pinned to the verbatim LoRaDemod.cpp): identical packets
         from oracle.oracle import Oracle

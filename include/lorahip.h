@@ -220,7 +220,9 @@ int lorahip_demod_get_packet(const lorahip_demod *d, size_t i, int32_t *channel,
 size_t lorahip_demod_num_packet_symbols(const lorahip_demod *d);
 int lorahip_demod_get_packets(const lorahip_demod *d, int32_t *channels, int64_t *rounds, int64_t *lens, size_t cap_packets,
                               int16_t *syms, size_t cap_syms);
-/* The queued packets in the batched decoder's input layout, on the device (same order as lorahip_demod_get_packets): packet p's
+/* The queued packets in the batched decoder's input layout, on the device. Straight after a run of the streaming mode -- nothing
+ * read back to the host yet, no packet begun in an earlier run -- the rows are packed on the device from the kernel's records
+ * (no host round trip; rows ordered by channel, then time); otherwise from the host queue in lorahip_demod_get_packets' order: packet p's
  * symbols at syms_dev + p*sym_stride (zero padded), its length in nsyms_dev[p] -- a packet longer than sym_stride keeps its true
  * length there and lorahip_decode_packets() reports -2 for it --, its channel in channel_dev[p] (nullable). *n_packets = number of
  * queued packets (also when cap_packets is too small: LORAHIP_E_INVALID then). Does not clear the queue. */

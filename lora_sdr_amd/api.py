@@ -387,6 +387,7 @@ class LoRaDemod:
         self.sf, self.N, self.n_channels = int(sf), 1 << int(sf), int(n_channels)
         self._device = int(device)
         self._port_bufs = dict(fft=None, dec=None, raw=None)
+        self._mtu = 256                                                 # LoRaDemod.cpp:73
 
     @staticmethod
     def make(sf):
@@ -407,6 +408,7 @@ class LoRaDemod:
 
     def setMTU(self, mtu):
         check(self._lib.lorahip_demod_set_mtu(self._h, int(mtu)), "lorahip_demod_set_mtu")
+        self._mtu = int(mtu)
 
     def activate(self):
         check(self._lib.lorahip_demod_activate(self._h), "lorahip_demod_activate")
@@ -461,15 +463,14 @@ class LoRaDemod:
 
     def packets_device(self, stride=None, clear=True):
         """The queued packets as device tensors in the decoder's input layout -- (P, stride) int16 symbols (zero padded), (P,) int32
-        lengths, (P,) int32 channels -- ready for LoRaDecoder.decode_batch(); no per-packet Python work."""
+        lengths, (P,) int32 channels -- ready for LoRaDecoder.decode_batch(); no per-packet Python work. Straight after a
+        work() of the streaming mode the packets never visit the host (rows ordered by channel, then time); otherwise the
+        rows follow packets()'s order. stride defaults to the MTU."""
         import torch
         n = int(self._lib.lorahip_demod_num_packets(self._h))
         dev = torch.device("cuda", int(self._device))
         if stride is None:
-            ln = np.empty(n, np.int64)
-            if n:
-                check(self._lib.lorahip_demod_get_packets(self._h, None, None, ln.ctypes.data, n, None, 1 << 62), "lorahip_demod_get_packets")
-            stride = max(8, int(ln.max()) if n else 8)
+            stride = max(8, min(self._mtu, 512))                # no packet is longer than the MTU (LoRaDemod.cpp:291)
         syms = torch.zeros((n, int(stride)), dtype=torch.int16, device=dev)
         nsyms = torch.zeros(n, dtype=torch.int32, device=dev)
         chan = torch.zeros(n, dtype=torch.int32, device=dev)

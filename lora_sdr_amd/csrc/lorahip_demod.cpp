@@ -79,6 +79,8 @@ struct lorahip_demod
     float *ownFft, *ownDec, *ownRaw; // device mirrors owned by the library for host_buffers
     bool portsOn, userTracing;
     char *dPort; size_t dPortBytes;  // scratch of the port replay: window descriptors, replayed fft / dec windows
+    void *pending;                   // PendingLaunch (records of the last streaming launch still on the device)
+    std::vector<size_t> carry;       // per channel: symbols of a packet begun before the launch being drained
 };
 
 namespace {
@@ -326,17 +328,168 @@ static int growDense(lorahip_demod *dm, const size_t bytes)
     return LORAHIP_OK;
 }
 
+//! where the pieces of one streaming launch live inside dm->sDev (device) / dm->sHost (host mirror of the head)
+struct StreamLayout
+{
+    size_t B, cap, capPkt;
+    bool tracing;
+    size_t oBase, oLen, oState, oN, oNSym, oNPkt, oPkt, oSym, oCalls, total;
+    void make(const size_t B_, const size_t cap_, const size_t capPkt_, const bool tracing_)
+    {
+        B = B_; cap = cap_; capPkt = capPkt_; tracing = tracing_;
+        size_t cur = 0;
+        auto carve = [&cur](const size_t bytes) { const size_t o = cur; cur += align256(bytes); return o; };
+        oBase = carve(B * sizeof(long long)); oLen = carve(B * sizeof(long long));
+        oState = carve(B * sizeof(StreamState));
+        oN = carve(B * sizeof(int)); oNSym = carve(B * sizeof(int)); oNPkt = carve(B * sizeof(int));
+        oPkt = carve(B * capPkt * sizeof(StreamPacket));
+        oSym = carve(B * cap * sizeof(short));
+        oCalls = carve(tracing ? B * cap * sizeof(lorahip_work_result) : 0);
+        total = cur;
+    }
+};
+
+//! The records of the LAST streaming launch of a run stay on the device until somebody needs them on the host: a receive chain
+//! that hands the packets to the batched decoder (lorahip_demod_packets_to_device) never does, and then nothing but the
+//! per-channel state and counts (52 B per channel) crosses PCIe per run.
+struct PendingLaunch
+{
+    bool valid;
+    StreamLayout lay;
+    size_t firstNewPacket;          // index in dm->packets of the first packet of the run this launch belongs to
+    int64_t rounds;
+    size_t packets, packetSyms;     // what draining will append
+    bool anyCarryIn, anyOpen;       // a channel entered the launch inside a packet / leaves it inside one
+    double drainMs;                 // LORAHIP_DEMOD_TIMING
+};
+
+static PendingLaunch &pendingOf(lorahip_demod *dm) { return *static_cast<PendingLaunch *>(dm->pending); }
+static std::vector<size_t> &carryOf(lorahip_demod *dm) { return dm->carry; }
+
+//! packets of one run in the order the host-driven path posts them: round by round, channels ascending inside a round
+static void orderNewPackets(lorahip_demod *dm, const size_t firstNewPacket, const int64_t rounds)
+{
+    // The new packets were appended channel by channel with rounds ascending inside a channel: a stable counting sort by round
+    // restores the order in O(packets + rounds) instead of a comparison sort of tens of thousands of records (which cost more
+    // than the kernel). Several launches per run can interleave channels inside a round; that case is detected and sorted.
+    const size_t nNew = dm->packets.size() - firstNewPacket;
+    if (nNew <= 1) return;
+    Packet *first = dm->packets.data() + firstNewPacket;
+    bool sorted = true, channelsAscendPerRound = true;
+    for (size_t i = 1; i < nNew && sorted; i++)
+        sorted = first[i - 1].round < first[i].round || (first[i - 1].round == first[i].round && first[i - 1].channel <= first[i].channel);
+    if (!sorted && rounds >= 0 && size_t(rounds) <= 4 * nNew + 1024)
+    {
+        std::vector<size_t> start(size_t(rounds) + 2, 0);
+        for (size_t i = 0; i < nNew; i++) start[size_t(first[i].round) + 1]++;
+        for (size_t r = 1; r < start.size(); r++) start[r] += start[r - 1];
+        std::vector<Packet> tmp(nNew);
+        for (size_t i = 0; i < nNew; i++) tmp[start[size_t(first[i].round)]++] = first[i];
+        for (size_t i = 1; i < nNew && channelsAscendPerRound; i++)
+            channelsAscendPerRound = tmp[i - 1].round != tmp[i].round || tmp[i - 1].channel <= tmp[i].channel;
+        std::copy(tmp.begin(), tmp.end(), first);
+        sorted = channelsAscendPerRound;
+    }
+    if (!sorted)
+        std::stable_sort(first, first + nNew,
+                         [](const Packet &x, const Packet &y) { return x.round != y.round ? x.round < y.round : x.channel < y.channel; });
+}
+
+//! records of one launch (still in dm->sDev; the counts in dm->sHost) -> the host queue, the per-channel traces and open packets
+static int drainLaunch(lorahip_demod *dm, const StreamLayout &L)
+{
+    lorahip_ctx *ctx = dm->ctx;
+    const size_t B = L.B;
+    char *h = dm->sHost, *d = dm->sDev;
+    const int *hN = reinterpret_cast<int *>(h + L.oN), *hNSym = reinterpret_cast<int *>(h + L.oNSym), *hNPkt = reinterpret_cast<int *>(h + L.oNPkt);
+    std::vector<size_t> &carry = carryOf(dm);
+    // only as many columns of the [channel][capacity] record arrays as the fullest channel used cross PCIe: the capacities are
+    // worst-case bounds, several times what a run fills
+    size_t maxSym = 0, maxPkt = 0, maxCalls = 0;
+    for (size_t c = 0; c < B; c++)
+    {
+        if (size_t(hNSym[c]) > maxSym) maxSym = size_t(hNSym[c]);
+        if (size_t(hNPkt[c]) > maxPkt) maxPkt = size_t(hNPkt[c]);
+        if (size_t(hN[c]) > maxCalls) maxCalls = size_t(hN[c]);
+    }
+    const size_t nbPkt = align256(B * maxPkt * sizeof(StreamPacket)), nbSym = align256(B * maxSym * sizeof(short));
+    const size_t nbCalls = L.tracing ? align256(B * maxCalls * sizeof(lorahip_work_result)) : 0;
+    const size_t nbDense = nbPkt + nbSym + nbCalls;
+    { const int grc = growDense(dm, nbDense); if (grc != LORAHIP_OK) return grc; }
+    LORAHIP_TRY(launchCompactRows(dm->dDense, d + L.oPkt, B, L.capPkt * sizeof(StreamPacket), maxPkt * sizeof(StreamPacket), ctx->stream));
+    LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt, d + L.oSym, B, L.cap * sizeof(short), maxSym * sizeof(short), ctx->stream));
+    if (L.tracing)
+        LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt + nbSym, d + L.oCalls, B, L.cap * sizeof(lorahip_work_result),
+                                      maxCalls * sizeof(lorahip_work_result), ctx->stream));
+    if (nbDense) LORAHIP_TRY(hipMemcpyAsync(dm->hDense, dm->dDense, nbDense, hipMemcpyDeviceToHost, ctx->stream));
+    LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+    const StreamPacket *hPkt = reinterpret_cast<const StreamPacket *>(dm->hDense);
+    const short *hSym = reinterpret_cast<const short *>(dm->hDense + nbPkt);
+    const lorahip_work_result *hCalls = reinterpret_cast<const lorahip_work_result *>(dm->hDense + nbPkt + nbSym);
+    for (size_t c = 0; c < B; c++)
+    {
+        Channel &k = dm->ch[c];
+        // symbols of this launch continue the packet the previous launches left open (k.outSymbols[0..carry[c]))
+        const short *sy = hSym + c * maxSym;
+        size_t p = 0;
+        for (int j = 0; j < hNPkt[c]; j++)
+        {
+            const StreamPacket &q = hPkt[c * maxPkt + size_t(j)];
+            Packet pk;
+            pk.channel = int32_t(c);
+            pk.round = q.callIndex;
+            pk.off = dm->pktSyms.size();
+            pk.len = size_t(q.len);
+            dm->pktSyms.insert(dm->pktSyms.end(), k.outSymbols.begin(), k.outSymbols.begin() + long(carry[c]));
+            const size_t fresh = size_t(q.len) - carry[c];
+            dm->pktSyms.insert(dm->pktSyms.end(), sy + p, sy + p + fresh);
+            p += fresh;
+            carry[c] = 0;
+            dm->packets.push_back(pk);
+        }
+        // what is left belongs to a packet still being received
+        const size_t left = size_t(hNSym[c]) - p;
+        if (left)
+        {
+            if (k.outSymbols.size() < carry[c] + left) k.outSymbols.resize(carry[c] + left, 0);
+            for (size_t i = 0; i < left; i++) k.outSymbols[carry[c] + i] = sy[p + i];
+            carry[c] += left;
+        }
+        if (L.tracing) k.trace.insert(k.trace.end(), hCalls + c * maxCalls, hCalls + c * maxCalls + hN[c]);
+    }
+    return LORAHIP_OK;
+}
+
+//! bring a pending launch's records to the host (any accessor of the queue / traces does this first)
+static int drainPending(lorahip_demod *dm)
+{
+    PendingLaunch &P = pendingOf(dm);
+    if (!P.valid) return LORAHIP_OK;
+    const DeviceGuard guard(dm->ctx->device);
+    typedef std::chrono::steady_clock Clock;
+    const Clock::time_point t0 = Clock::now();
+    P.valid = false;
+    const int rc = drainLaunch(dm, P.lay);
+    if (rc != LORAHIP_OK) return rc;
+    orderNewPackets(dm, P.firstNewPacket, P.rounds);
+    P.drainMs = std::chrono::duration<double>(Clock::now() - t0).count() * 1e3;
+    static const bool timing = std::getenv("LORAHIP_DEMOD_TIMING") != nullptr;
+    if (timing) std::fprintf(stderr, "lorahip demod: records of the last launch drained to the host in %.3f ms\n", P.drainMs);
+    return LORAHIP_OK;
+}
+
 static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     lorahip_ctx *ctx = dm->ctx;
     const size_t N = dm->N, B = dm->B;
     const DeviceGuard guard(ctx->device);
+    // the previous run's records live in the buffers this run is about to reuse
+    { const int rc = drainPending(dm); if (rc != LORAHIP_OK) return rc; }
     // diagnostic: LORAHIP_DEMOD_TIMING=1 prints where a run's host wall clock goes
     static const bool timing = std::getenv("LORAHIP_DEMOD_TIMING") != nullptr;
     typedef std::chrono::steady_clock Clock;
     const Clock::time_point t0 = Clock::now();
     double tDev = 0, tAsm = 0;
-    size_t d2hBytes = 0;
     size_t maxLen = 0;
     for (size_t c = 0; c < B; c++) if (dm->ch[c].len - dm->ch[c].pos > maxLen) maxLen = dm->ch[c].len - dm->ch[c].pos;
     // work() calls per channel per launch: enough for a clean stream in one launch, bounded so that the
@@ -351,28 +504,24 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     if (const char *e = std::getenv("LORAHIP_STREAM_CAP")) { const long v = std::atol(e); if (v >= 1) cap = size_t(v); }
     const size_t capPkt = cap / 4 + 2;               // a packet costs at least 5 calls (3 sync, quarter, 1 symbol)
 
-    size_t cur = 0;
-    auto carveS = [&cur](const size_t bytes) { const size_t o = cur; cur += align256(bytes); return o; };
-    const size_t oBase = carveS(B * sizeof(long long)), oLen = carveS(B * sizeof(long long));
-    const size_t oState = carveS(B * sizeof(StreamState));
-    const size_t oN = carveS(B * sizeof(int)), oNSym = carveS(B * sizeof(int)), oNPkt = carveS(B * sizeof(int));
-    const size_t oPkt = carveS(B * capPkt * sizeof(StreamPacket));
-    const size_t oSym = carveS(B * cap * sizeof(short));
-    const size_t oCalls = carveS(dm->tracing ? B * cap * sizeof(lorahip_work_result) : 0);
-    if (cur > dm->sBytes)
+    StreamLayout L;
+    L.make(B, cap, capPkt, dm->tracing);
+    if (L.total > dm->sBytes)
     {
         if (dm->sDev) { (void)hipFree(dm->sDev); dm->sDev = nullptr; }
         if (dm->sHost) { (void)hipHostFree(dm->sHost); dm->sHost = nullptr; }
         dm->sBytes = 0;
-        LORAHIP_TRY(hipMalloc((void **)&dm->sDev, cur));
-        LORAHIP_TRY(hipHostMalloc((void **)&dm->sHost, oPkt, hipHostMallocDefault));       // the host mirrors only the head: placement, state, counts
-        dm->sBytes = cur;
+        LORAHIP_TRY(hipMalloc((void **)&dm->sDev, L.total));
+        LORAHIP_TRY(hipHostMalloc((void **)&dm->sHost, L.oPkt, hipHostMallocDefault));       // the host mirrors only the head: placement, state, counts
+        dm->sBytes = L.total;
     }
     char *h = dm->sHost, *d = dm->sDev;
-    long long *hBase = reinterpret_cast<long long *>(h + oBase), *hLen = reinterpret_cast<long long *>(h + oLen);
-    StreamState *hState = reinterpret_cast<StreamState *>(h + oState);
-    const int *hN = reinterpret_cast<int *>(h + oN), *hNSym = reinterpret_cast<int *>(h + oNSym), *hNPkt = reinterpret_cast<int *>(h + oNPkt);
-    std::vector<size_t> carry(B, 0);
+    long long *hBase = reinterpret_cast<long long *>(h + L.oBase), *hLen = reinterpret_cast<long long *>(h + L.oLen);
+    StreamState *hState = reinterpret_cast<StreamState *>(h + L.oState);
+    const int *hN = reinterpret_cast<int *>(h + L.oN), *hNSym = reinterpret_cast<int *>(h + L.oNSym), *hNPkt = reinterpret_cast<int *>(h + L.oNPkt);
+    std::vector<size_t> &carry = carryOf(dm);
+    carry.assign(B, 0);
+    bool anyCarryIn = false;
     for (size_t c = 0; c < B; c++)
     {
         Channel &k = dm->ch[c];
@@ -386,20 +535,21 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         // symbols of a packet that is still being received when the run starts. _symCount itself is only reset at
         // QUARTERCHIRP (:279), so outside DATASYMBOLS it still holds the length of the LAST packet: nothing is carried then
         carry[c] = k.state == ST_DATASYMBOLS ? k.symCount : 0;
+        anyCarryIn = anyCarryIn || carry[c] != 0;
     }
-    LORAHIP_TRY(hipMemcpyAsync(d, h, oN, hipMemcpyHostToDevice, ctx->stream));       // base, len, state
+    LORAHIP_TRY(hipMemcpyAsync(d, h, L.oN, hipMemcpyHostToDevice, ctx->stream));       // base, len, state
 
     StreamArgs a;
     a.iq = reinterpret_cast<const float2 *>(iqDev);
-    a.base = reinterpret_cast<const long long *>(d + oBase);
-    a.len = reinterpret_cast<const long long *>(d + oLen);
-    a.state = reinterpret_cast<StreamState *>(d + oState);
-    a.nCalls = reinterpret_cast<int *>(d + oN);
-    a.nSym = reinterpret_cast<int *>(d + oNSym);
-    a.nPkt = reinterpret_cast<int *>(d + oNPkt);
-    a.pktOut = reinterpret_cast<StreamPacket *>(d + oPkt);
-    a.symOut = reinterpret_cast<short *>(d + oSym);
-    a.calls = dm->tracing ? reinterpret_cast<lorahip_work_result *>(d + oCalls) : nullptr;
+    a.base = reinterpret_cast<const long long *>(d + L.oBase);
+    a.len = reinterpret_cast<const long long *>(d + L.oLen);
+    a.state = reinterpret_cast<StreamState *>(d + L.oState);
+    a.nCalls = reinterpret_cast<int *>(d + L.oN);
+    a.nSym = reinterpret_cast<int *>(d + L.oNSym);
+    a.nPkt = reinterpret_cast<int *>(d + L.oNPkt);
+    a.pktOut = reinterpret_cast<StreamPacket *>(d + L.oPkt);
+    a.symOut = reinterpret_cast<short *>(d + L.oSym);
+    a.calls = dm->tracing ? reinterpret_cast<lorahip_work_result *>(d + L.oCalls) : nullptr;
     a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
     a.fineA = ctx->fineGather ? nullptr : ctx->dFineA;
     a.fineB = ctx->fineGather ? nullptr : ctx->dFineB;
@@ -415,81 +565,46 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     const Clock::time_point t1 = Clock::now();
     dm->kernelMs = 0.0;
     if (dm->evK0 == nullptr) { LORAHIP_TRY(hipEventCreate(&dm->evK0)); LORAHIP_TRY(hipEventCreate(&dm->evK1)); }
+    bool lastPending = false;
+    size_t pendPackets = 0, pendNSym = 0;
     while (true)
     {
         const Clock::time_point ta = Clock::now();
         LORAHIP_TRY(hipEventRecord(dm->evK0, ctx->stream));
         LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
         LORAHIP_TRY(hipEventRecord(dm->evK1, ctx->stream));
-        // results back in two steps: the per-channel state and counts first (small), then only as many columns of the
-        // [channel][capacity] record arrays as the fullest channel used -- the capacities are worst-case bounds, several
-        // times what a run fills
-        LORAHIP_TRY(hipMemcpyAsync(h + oState, d + oState, oPkt - oState, hipMemcpyDeviceToHost, ctx->stream));
+        // the per-channel state and counts come back after every launch (52 B per channel); the record arrays only when needed
+        LORAHIP_TRY(hipMemcpyAsync(h + L.oState, d + L.oState, L.oPkt - L.oState, hipMemcpyDeviceToHost, ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
         { float ms = 0.0f; if (hipEventElapsedTime(&ms, dm->evK0, dm->evK1) == hipSuccess) dm->kernelMs += ms; }
-        size_t maxSym = 0, maxPkt = 0, maxCalls = 0;
-        for (size_t c = 0; c < B; c++)
-        {
-            if (size_t(hNSym[c]) > maxSym) maxSym = size_t(hNSym[c]);
-            if (size_t(hNPkt[c]) > maxPkt) maxPkt = size_t(hNPkt[c]);
-            if (size_t(hN[c]) > maxCalls) maxCalls = size_t(hN[c]);
-        }
-        const size_t nbPkt = align256(B * maxPkt * sizeof(StreamPacket)), nbSym = align256(B * maxSym * sizeof(short));
-        const size_t nbCalls = dm->tracing ? align256(B * maxCalls * sizeof(lorahip_work_result)) : 0;
-        const size_t nbDense = nbPkt + nbSym + nbCalls;
-        { const int grc = growDense(dm, nbDense); if (grc != LORAHIP_OK) return grc; }
-        LORAHIP_TRY(launchCompactRows(dm->dDense, d + oPkt, B, capPkt * sizeof(StreamPacket), maxPkt * sizeof(StreamPacket), ctx->stream));
-        LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt, d + oSym, B, cap * sizeof(short), maxSym * sizeof(short), ctx->stream));
-        if (dm->tracing)
-            LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt + nbSym, d + oCalls, B, cap * sizeof(lorahip_work_result),
-                                          maxCalls * sizeof(lorahip_work_result), ctx->stream));
-        if (nbDense) LORAHIP_TRY(hipMemcpyAsync(dm->hDense, dm->dDense, nbDense, hipMemcpyDeviceToHost, ctx->stream));
-        LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
-        const StreamPacket *hPkt = reinterpret_cast<const StreamPacket *>(dm->hDense);
-        const short *hSym = reinterpret_cast<const short *>(dm->hDense + nbPkt);
-        const lorahip_work_result *hCalls = reinterpret_cast<const lorahip_work_result *>(dm->hDense + nbPkt + nbSym);
-        d2hBytes += (oPkt - oState) + B * (maxPkt * sizeof(StreamPacket) + maxSym * sizeof(short) + (dm->tracing ? maxCalls * sizeof(lorahip_work_result) : 0));
         const Clock::time_point tb = Clock::now();
         tDev += std::chrono::duration<double>(tb - ta).count();
         bool more = false;
+        pendPackets = pendNSym = 0;
         for (size_t c = 0; c < B; c++)
         {
-            Channel &k = dm->ch[c];
-            // symbols of this launch continue the packet the previous launches left open (k.outSymbols[0..carry[c]))
-            const short *sy = hSym + c * maxSym;
-            size_t p = 0;
-            for (int j = 0; j < hNPkt[c]; j++)
-            {
-                const StreamPacket &q = hPkt[c * maxPkt + size_t(j)];
-                Packet pk;
-                pk.channel = int32_t(c);
-                pk.round = q.callIndex;
-                pk.off = dm->pktSyms.size();
-                pk.len = size_t(q.len);
-                dm->pktSyms.insert(dm->pktSyms.end(), k.outSymbols.begin(), k.outSymbols.begin() + long(carry[c]));
-                const size_t fresh = size_t(q.len) - carry[c];
-                dm->pktSyms.insert(dm->pktSyms.end(), sy + p, sy + p + fresh);
-                p += fresh;
-                carry[c] = 0;
-                dm->packets.push_back(pk);
-            }
-            // what is left belongs to a packet still being received
-            const size_t left = size_t(hNSym[c]) - p;
-            if (left)
-            {
-                if (k.outSymbols.size() < carry[c] + left) k.outSymbols.resize(carry[c] + left, 0);
-                for (size_t i = 0; i < left; i++) k.outSymbols[carry[c] + i] = sy[p + i];
-                carry[c] += left;
-            }
             dm->workCalls += hN[c];
-            if (dm->tracing) k.trace.insert(k.trace.end(), hCalls + c * maxCalls, hCalls + c * maxCalls + hN[c]);
+            pendPackets += size_t(hNPkt[c]);
+            pendNSym += size_t(hNSym[c]);
             if (size_t(hN[c]) == cap || size_t(hNPkt[c]) == capPkt) more = true;
         }
-        tAsm += std::chrono::duration<double>(Clock::now() - tb).count();
+        // a launch that must be resumed hands its records over now (the next one reuses the buffers); so does a traced run (its
+        // callers read the trace next). Otherwise the records wait on the device.
+        if (more || dm->tracing)
+        {
+            const int rc = drainLaunch(dm, L);
+            if (rc != LORAHIP_OK) return rc;
+            tAsm += std::chrono::duration<double>(Clock::now() - tb).count();
+            anyCarryIn = false;
+            for (size_t c = 0; c < B; c++) anyCarryIn = anyCarryIn || carry[c] != 0;
+        }
+        else lastPending = true;
         if (!more) break;
     }
     const Clock::time_point t2 = Clock::now();
     int64_t rounds = 0;
+    bool anyOpen = false;
+    size_t openSyms = 0, carriedIn = 0;
     for (size_t c = 0; c < B; c++)
     {
         Channel &k = dm->ch[c];
@@ -498,40 +613,27 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         k.fineTuneIndex = st.fineTuneIndex; k.finefreqError = st.finefreqError; k.symCount = size_t(st.symCount);
         k.pos = size_t(st.pos);
         if (st.callCount > rounds) rounds = st.callCount;
+        if (st.state == ST_DATASYMBOLS) { anyOpen = true; openSyms += size_t(st.symCount); }
+        carriedIn += carry[c];
     }
-    // The host-driven path posts packets round by round, channels in order inside a round. The new packets were appended
-    // channel by channel with rounds ascending inside a channel: a stable counting sort by round restores that order in
-    // O(packets + rounds) instead of a comparison sort of tens of thousands of records (which cost more than the kernel).
-    // Several launches per run can interleave channels inside a round; that case is detected and falls back to the sort.
+    PendingLaunch &P = pendingOf(dm);
+    if (lastPending)
     {
-        const size_t nNew = dm->packets.size() - firstNewPacket;
-        if (nNew > 1)
-        {
-            Packet *first = dm->packets.data() + firstNewPacket;
-            bool sorted = true, channelsAscendPerRound = true;
-            for (size_t i = 1; i < nNew && sorted; i++)
-                sorted = first[i - 1].round < first[i].round || (first[i - 1].round == first[i].round && first[i - 1].channel <= first[i].channel);
-            if (!sorted && rounds >= 0 && size_t(rounds) <= 4 * nNew + 1024)
-            {
-                std::vector<size_t> start(size_t(rounds) + 2, 0);
-                for (size_t i = 0; i < nNew; i++) start[size_t(first[i].round) + 1]++;
-                for (size_t r = 1; r < start.size(); r++) start[r] += start[r - 1];
-                std::vector<Packet> tmp(nNew);
-                for (size_t i = 0; i < nNew; i++) tmp[start[size_t(first[i].round)]++] = first[i];
-                for (size_t i = 1; i < nNew && channelsAscendPerRound; i++)
-                    channelsAscendPerRound = tmp[i - 1].round != tmp[i].round || tmp[i - 1].channel <= tmp[i].channel;
-                std::copy(tmp.begin(), tmp.end(), first);
-                sorted = channelsAscendPerRound;
-            }
-            if (!sorted)
-                std::stable_sort(first, first + nNew,
-                                 [](const Packet &x, const Packet &y) { return x.round != y.round ? x.round < y.round : x.channel < y.channel; });
-        }
+        P.valid = true;
+        P.lay = L;
+        P.firstNewPacket = firstNewPacket;
+        P.rounds = rounds;
+        P.packets = pendPackets;
+        P.packetSyms = carriedIn + pendNSym - openSyms;     // symbols of the packets completed by this launch
+        P.anyCarryIn = anyCarryIn;
+        P.anyOpen = anyOpen;
+        P.drainMs = 0.0;
     }
+    else orderNewPackets(dm, firstNewPacket, rounds);
     if (roundsOut) *roundsOut = rounds;
     if (timing)
-        std::fprintf(stderr, "lorahip demod run: setup+H2D %.3f ms, kernel+D2H(%.1f MB)+sync %.3f ms, packet assembly %.3f ms, state+order %.3f ms\n",
-                     std::chrono::duration<double>(t1 - t0).count() * 1e3, double(d2hBytes) / 1e6, tDev * 1e3, tAsm * 1e3,
+        std::fprintf(stderr, "lorahip demod run: setup+H2D %.3f ms, kernel+state D2H+sync %.3f ms, record drain %.3f ms%s, state mirrors %.3f ms\n",
+                     std::chrono::duration<double>(t1 - t0).count() * 1e3, tDev * 1e3, tAsm * 1e3, lastPending ? " (last launch left on the device)" : "",
                      std::chrono::duration<double>(Clock::now() - t2).count() * 1e3);
     return LORAHIP_OK;
 }
@@ -692,6 +794,7 @@ static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(dm->ctx->sf));
     if (stream && !streamAvailable(dm->ctx->sf)) { setLastError("no streaming kernel for this SF"); return LORAHIP_E_INVALID; }
+    { const int rc = drainPending(dm); if (rc != LORAHIP_OK) return rc; }       // the previous run's records, if still on the device
     for (auto &k : dm->ch) { k.traceStart = k.trace.size(); k.portFft = k.portDec = k.portRaw = 0; }
     dm->tracing = dm->userTracing || dm->portsOn;               // the port replay reads the per-call trace
     const int rc = stream ? runStream(dm, iqDev, roundsOut) : runRounds(dm, iqDev, roundsOut);
@@ -711,6 +814,9 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     if (dm == nullptr) return LORAHIP_E_NOMEM;
     dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
     dm->evK0 = nullptr; dm->evK1 = nullptr; dm->kernelMs = 0.0;
+    dm->pending = new (std::nothrow) PendingLaunch();
+    if (dm->pending == nullptr) { delete dm; return LORAHIP_E_NOMEM; }
+    pendingOf(dm).valid = false;
     std::memset(&dm->ports, 0, sizeof(dm->ports)); dm->portsOn = false; dm->userTracing = false; dm->dPort = nullptr; dm->dPortBytes = 0;
     std::memset(&dm->hostPorts, 0, sizeof(dm->hostPorts)); dm->ownFft = dm->ownDec = dm->ownRaw = nullptr;
     dm->mode = 0; dm->sDev = nullptr; dm->sHost = nullptr; dm->sBytes = 0; dm->dDense = nullptr; dm->hDense = nullptr; dm->denseBytes = 0;
@@ -760,6 +866,7 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->evK1) (void)hipEventDestroy(dm->evK1);
     }
     lorahip_destroy(dm->ctx);
+    delete static_cast<PendingLaunch *>(dm->pending);
     delete dm;
 }
 
@@ -857,11 +964,25 @@ int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size
     return runAny(dm, dm->dIq, rounds);
 }
 
-size_t lorahip_demod_num_packets(const lorahip_demod *dm) { return dm ? dm->packets.size() : 0; }
+//! accessors of the host queue first bring over what the last streaming launch left on the device
+static lorahip_demod *drained(const lorahip_demod *dm)
+{
+    lorahip_demod *m = const_cast<lorahip_demod *>(dm);
+    if (m) (void)drainPending(m);
+    return m;
+}
+
+size_t lorahip_demod_num_packets(const lorahip_demod *dm)
+{
+    if (dm == nullptr) return 0;
+    const PendingLaunch &P = pendingOf(const_cast<lorahip_demod *>(dm));
+    return dm->packets.size() + (P.valid ? P.packets : 0);      // known from the per-channel counts: no drain needed
+}
 
 int lorahip_demod_get_packet(const lorahip_demod *dm, const size_t i, int32_t *channel, int64_t *round,
                              size_t *len, int16_t *out, const size_t cap)
 {
+    drained(dm);
     if (dm == nullptr || i >= dm->packets.size()) return LORAHIP_E_INVALID;
     const Packet &p = dm->packets[i];
     if (channel) *channel = p.channel;
@@ -875,11 +996,17 @@ int lorahip_demod_get_packet(const lorahip_demod *dm, const size_t i, int32_t *c
     return LORAHIP_OK;
 }
 
-size_t lorahip_demod_num_packet_symbols(const lorahip_demod *dm) { return dm ? dm->pktSyms.size() : 0; }
+size_t lorahip_demod_num_packet_symbols(const lorahip_demod *dm)
+{
+    if (dm == nullptr) return 0;
+    const PendingLaunch &P = pendingOf(const_cast<lorahip_demod *>(dm));
+    return dm->pktSyms.size() + (P.valid ? P.packetSyms : 0);
+}
 
 int lorahip_demod_get_packets(const lorahip_demod *dm, int32_t *channels, int64_t *rounds, int64_t *lens, const size_t cap_packets,
                               int16_t *syms, const size_t cap_syms)
 {
+    drained(dm);
     if (dm == nullptr || cap_packets < dm->packets.size() || cap_syms < dm->pktSyms.size()) return LORAHIP_E_INVALID;
     size_t o = 0;
     for (size_t i = 0; i < dm->packets.size(); i++)
@@ -898,6 +1025,36 @@ int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const
                                     const size_t cap_packets, size_t *n_packets)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    {
+        // The records of the last streaming launch are still on the device and nothing else is queued: pack them there
+        // (rows: channels ascending, time ascending inside a channel). A channel that entered the launch inside a packet
+        // needs symbols held on the host: those runs take the queue path below.
+        PendingLaunch &Q = pendingOf(dm);
+        if (Q.valid && dm->packets.empty() && !Q.anyCarryIn)
+        {
+            const size_t n = Q.packets;
+            if (n_packets) *n_packets = n;
+            if (n == 0) return LORAHIP_OK;
+            if (syms_dev == nullptr || nsyms_dev == nullptr || sym_stride == 0 || sym_stride > 0x7fffffffu || cap_packets < n) return LORAHIP_E_INVALID;
+            const DeviceGuard guard(dm->ctx->device);
+            const StreamLayout &L = Q.lay;
+            const int *hNPkt = reinterpret_cast<const int *>(dm->sHost + L.oNPkt);
+            const size_t nbRow = align256(L.B * sizeof(int));
+            { const int grc = growDense(dm, nbRow + n * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
+            int *hRow = reinterpret_cast<int *>(dm->hDense);
+            int acc = 0;
+            for (size_t c = 0; c < L.B; c++) { hRow[c] = acc; acc += hNPkt[c]; }
+            hipStream_t st = dm->ctx->stream;
+            LORAHIP_TRY(hipMemcpyAsync(dm->dDense, hRow, L.B * sizeof(int), hipMemcpyHostToDevice, st));
+            LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(dm->sDev + L.oPkt), reinterpret_cast<const int *>(dm->sDev + L.oNPkt),
+                                          reinterpret_cast<const short *>(dm->sDev + L.oSym), reinterpret_cast<const int *>(dm->dDense), L.B, int(L.cap),
+                                          int(L.capPkt), n, reinterpret_cast<long long *>(dm->dDense + nbRow), syms_dev, int(sym_stride), nsyms_dev,
+                                          channel_dev, st));
+            LORAHIP_TRY(hipStreamSynchronize(st));                          // the pinned scratch is reused by the next call
+            return LORAHIP_OK;
+        }
+    }
+    { const int rc = drainPending(dm); if (rc != LORAHIP_OK) return rc; }
     const size_t P = dm->packets.size();
     if (n_packets) *n_packets = P;
     if (P == 0) return LORAHIP_OK;
@@ -923,7 +1080,20 @@ int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const
     return LORAHIP_OK;
 }
 
-void lorahip_demod_clear_packets(lorahip_demod *dm) { if (dm) { dm->packets.clear(); dm->pktSyms.clear(); } }
+void lorahip_demod_clear_packets(lorahip_demod *dm)
+{
+    if (dm == nullptr) return;
+    PendingLaunch &P = pendingOf(dm);
+    if (P.valid)
+    {
+        // records still on the device: they can simply be dropped unless a channel is inside a packet -- the symbols it has
+        // received so far open the first packet of the next run
+        if (P.anyOpen) (void)drainPending(dm);
+        else P.valid = false;
+    }
+    dm->packets.clear();
+    dm->pktSyms.clear();
+}
 
 int64_t lorahip_demod_work_calls(const lorahip_demod *dm) { return dm ? dm->workCalls : 0; }
 
@@ -948,6 +1118,7 @@ int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)
 
 size_t lorahip_demod_trace_len(const lorahip_demod *dm, const size_t channel)
 {
+    drained(dm);
     if (dm == nullptr || channel >= dm->B) return 0;
     return dm->ch[channel].trace.size();
 }
@@ -1016,6 +1187,7 @@ static std::string labelOf(const lorahip_work_result &r, const size_t N, const f
 
 int lorahip_demod_get_labels(const lorahip_demod *dm, const size_t channel, char *buf, const size_t cap, size_t *n_calls, size_t *bytes)
 {
+    drained(dm);
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
     const auto &t = dm->ch[channel].trace;
     // _symCount is only reset at QUARTERCHIRP (:279): a trace that starts inside a packet continues the count the channel held then
@@ -1034,6 +1206,7 @@ int lorahip_demod_get_labels(const lorahip_demod *dm, const size_t channel, char
 
 int lorahip_demod_get_trace(const lorahip_demod *dm, const size_t channel, lorahip_work_result *out, const size_t cap)
 {
+    drained(dm);
     if (dm == nullptr || channel >= dm->B || out == nullptr) return LORAHIP_E_INVALID;
     const auto &t = dm->ch[channel].trace;
     if (cap < t.size()) return LORAHIP_E_INVALID;

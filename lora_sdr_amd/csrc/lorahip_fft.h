@@ -287,6 +287,17 @@ __device__ __forceinline__ unsigned fineLaneIndices(const int idx0, const FinePl
             v = fineAdvance(v, Q, p);
         }
     }
+    if (__any(p.sat))
+    {
+        // windows whose index walks down by one per sample and stays at 0 (lorahip_fine.h): the modular form is right until it
+        // wraps, i.e. for the samples n <= idx0
+#pragma unroll
+        for (int u = 0; u < VEC; u++)
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (p.sat && VEC * t + u + VEC * T * r > idx0) y[r][u] = 0;
+        if (p.sat) ymax = 0;                                                    // never the value M
+    }
     return ymax;
 }
 

@@ -21,7 +21,9 @@
 //     what the modulus M + 1 does. Hence y_n = (idx0 + n q) mod M' in closed form for a lane's own samples. The form
 //     fails in two situations, both detected per window: (a) float rounding of (float)y - d reaches the next integer
 //     (only when frac(d) is within M 2^-25 of an integer from the wrong side: `regular` below), (b) for d > 0 the
-//     sequence lands on y = ceil(d) - 1, where the reference yields 0 instead of wrapping (closed form: the value M).
+//     sequence lands on y = ceil(d) - 1, where the reference yields 0 instead of wrapping (closed form: the value M). For
+//     0 < d < 1 that landing is the rule, not the exception -- the index walks down to 0 and stays there -- and has its own
+//     closed form, y_n = max(idx0 - n, 0) (`sat`).
 //     Such windows take the exact index chain (fineChainGroup / fineChainBlock); the two paths are tested against each
 //     other and against the serial recurrence itself (tests/test_fine_index.py on the host, tests/test_gpu_parity.py on the device).
 #pragma once
@@ -37,13 +39,14 @@ struct FinePlan
     unsigned q;         // per-sample increment of the closed form
     unsigned mod;       // M or M + 1
     int regular;        // closed form valid for every start index (unless the sequence reaches the value M)
+    int sat;            // 0 < d < 1: the index walks down by one per sample and STAYS at 0 ((float)0 - d truncates to 0): y_n = max(idx0 - n, 0)
 };
 
 //! classify one window's step d = _finefreqError * _fineSteps; M = 128 N = 2^m, m <= 19
 __host__ __device__ inline FinePlan finePlan(const float d, const int M)
 {
     FinePlan p;
-    p.q = 0; p.mod = unsigned(M); p.regular = 1;
+    p.q = 0; p.mod = unsigned(M); p.regular = 1; p.sat = 0;
     if (d == 0.0f) return p;
     const float a = d < 0.0f ? -d : d;
     if (!(a < float(M / 2))) { p.regular = 0; return p; }            // huge or NaN: the serial chain decides
@@ -57,6 +60,7 @@ __host__ __device__ inline FinePlan finePlan(const float d, const int M)
             p.mod = unsigned(M) + 1u;
             p.q = unsigned(M) - unsigned(af);                        // M' - ceil(d)
             p.regular = fr > float(M) * 0x1p-25f;                    // (float)y - d never rounds up to the next integer
+            p.sat = p.regular && af == 0.0f;                         // ceil(d) = 1: the modular form reaches the value M where the reference sticks at 0
         }
     }
     else
@@ -88,6 +92,7 @@ __host__ __device__ inline unsigned fineAdvance(const unsigned y, const unsigned
 //! the index after the window's N steps; *hitEnd unused by callers that scan the samples themselves
 __host__ __device__ inline int fineEndIndex(const int idx0, const FinePlan &p, const int log2N, const int log2M)
 {
+    if (p.sat) return idx0 > (1 << log2N) ? idx0 - (1 << log2N) : 0;
     const unsigned y = fineReduce(unsigned(idx0) + (p.q << log2N), p, log2M);      // N q < 2^31
     return y == (1u << log2M) ? 0 : int(y);                                         // landing on M at the very end: the reference holds 0
 }

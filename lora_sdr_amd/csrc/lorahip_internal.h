@@ -128,6 +128,8 @@ bool streamAvailable(int sf);
 hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchStreamWide(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchCompactRows(void *dst, const void *src, size_t rows, size_t srcPitchBytes, size_t rowBytes, hipStream_t stream);
+hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, const int *rowStart, size_t nChannels, int cap, int capPkt,
+                             size_t nPackets, long long *srcOff, unsigned short *symsOut, int stride, int *nsymsOut, int *channelOut, hipStream_t stream);
 hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *srcOff, const long long *dstOff, const int *len, size_t nSeg,
                               hipStream_t stream);
 hipError_t launchSynth(int sf, float2 *iq, const unsigned short *sym, size_t nWindows,

@@ -244,6 +244,49 @@ hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *s
     return hipGetLastError();
 }
 
+/***********************************************************************
+ * Packets of a streaming launch straight into the batched decoder's input layout, device to device (no host round trip):
+ * channel c posted nPkt[c] packets, packet j = the next pktOut[c][j].len entries of the channel's symbol stream symOut[c][..];
+ * its row in the output is rowStart[c] + j (rowStart = exclusive scan of nPkt: channels ascending, time ascending inside one).
+ **********************************************************************/
+__global__ void packDescribe(const StreamPacket *__restrict__ pktOut, const int *__restrict__ nPkt, const int *__restrict__ rowStart,
+                             const unsigned nChannels, const int cap, const int capPkt, long long *__restrict__ srcOff,
+                             int *__restrict__ nsyms, int *__restrict__ channel)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nChannels) return;
+    long long off = (long long)c * cap;
+    const int row0 = rowStart[c];
+    for (int j = 0; j < nPkt[c]; j++)
+    {
+        const int len = pktOut[(size_t)c * capPkt + j].len;
+        srcOff[row0 + j] = off;
+        nsyms[row0 + j] = len;
+        if (channel) channel[row0 + j] = (int)c;
+        off += len;
+    }
+}
+
+__global__ void packCopy(const short *__restrict__ symOut, const long long *__restrict__ srcOff, const int *__restrict__ nsyms,
+                         unsigned short *__restrict__ dst, const int stride)
+{
+    const size_t p = blockIdx.x;
+    const int len = nsyms[p] < stride ? nsyms[p] : stride;
+    const short *src = symOut + srcOff[p];
+    for (int i = threadIdx.x; i < stride; i += blockDim.x) dst[p * stride + i] = i < len ? (unsigned short)src[i] : (unsigned short)0;
+}
+
+hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, const int *rowStart, const size_t nChannels,
+                             const int cap, const int capPkt, const size_t nPackets, long long *srcOff, unsigned short *symsOut, const int stride,
+                             int *nsymsOut, int *channelOut, hipStream_t stream)
+{
+    if (nPackets == 0) return hipSuccess;
+    hipLaunchKernelGGL(packDescribe, dim3(unsigned((nChannels + 255) / 256)), dim3(256), 0, stream, pktOut, nPkt, rowStart, unsigned(nChannels), cap, capPkt,
+                       srcOff, nsymsOut, channelOut);
+    hipLaunchKernelGGL(packCopy, dim3(unsigned(nPackets)), dim3(64), 0, stream, symOut, srcOff, nsymsOut, symsOut, stride);
+    return hipGetLastError();
+}
+
 bool streamAvailable(const int sf) { return sf >= 6 && sf <= 12; }
 
 hipError_t launchStream(const int sf, const StreamArgs &s, hipStream_t stream)

@@ -109,8 +109,9 @@ extern "C" int lorahip_fine_indices_host(const int sf, const int32_t idx0, const
         {
             const unsigned direct = fineReduce(unsigned(idx0) + unsigned(n) * p.q, p, log2M);
             if (direct != y) return LORAHIP_E_INVALID;                 // the two closed-form routes must agree
-            if (y == unsigned(M)) { ok = false; break; }
-            idx_out[n] = int32_t(y);
+            const unsigned use = (p.sat && n > idx0) ? 0u : y;         // fineLaneIndices' fix-up of the saturating case
+            if (!p.sat && y == unsigned(M)) { ok = false; break; }
+            idx_out[n] = int32_t(use);
             y = fineAdvance(y, p.q, p);
         }
         if (ok && idx_end) *idx_end = fineEndIndex(idx0, p, sf, log2M);

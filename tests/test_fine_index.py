@@ -53,6 +53,7 @@ def adversarial_errs(sf, rng):
                 e.append(sgn * (k + eps) / 128.0)
     e += list(rng.uniform(-2, 2, 60)) + list(rng.uniform(-40, 40, 30)) + list(rng.uniform(-0.01, 0.01, 20))
     e += [M / 256.0 / 128.0 * 0.999, -M / 256.0 / 128.0 * 1.001, float(M), 1e-9, -1e-9]
+    e += [0.3 / 128, 0.9 / 128, 0.02 / 128, 0.51 / 128]                     # 0 < d < 1: the index walks down to 0 and stays there
     return [np.float32(x) for x in e]
 
 
@@ -68,7 +69,7 @@ def test_closed_form_indices_equal_the_recurrence(sf):
         errs = errs[::3]
     for err in errs:
         d = float(np.float32(err) * np.float32(128))
-        starts = [0, 1, M - 1, M // 2, int(rng.integers(0, M)), int(rng.integers(0, M))]
+        starts = [0, 1, M - 1, M // 2, int(rng.integers(0, M)), int(rng.integers(0, M)), N // 3, N - 1, N, N + 1]
         c = int(np.ceil(abs(d)))
         # starts that reach the special value ceil(d)-1 (the reference yields 0 there instead of wrapping)
         if 0 < c < M:

@@ -413,3 +413,63 @@ def test_level3_debug_ports_and_labels(gpu, oracle, golden, sf, mode):
     d.work(gpu.from_numpy(streams).to("cuda:0"))
     assert d.ports(0)["produced"] == dict(fft=0, dec=0, raw=0)
     d.close()
+
+
+@pytest.mark.parametrize("sf", [7, 10, 12])
+def test_packets_packed_on_the_device_equal_the_host_queue(gpu, oracle, sf):
+    """lorahip_demod_packets_to_device straight after a streaming run packs the decoder's input rows from the kernel's records on
+    the device (no host round trip); the same packets must come out of the host queue. Then streams cut in the middle of a
+    packet: the run that ends inside a packet keeps its symbols, the next one completes it (host-queue path)."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(500 + sf)
+    N = 1 << sf
+    B = 9
+    mtu = 11
+    sts, want = [], []
+    for c in range(B):
+        st, syms = frames(oracle, rng, sf, 1 + c % 3, mtu, off=0.2 * (c % 4), lead=N // 2 + 3 * c)
+        sts.append(st)
+    n = max(s.size for s in sts) + 2 * N
+    streams = np.zeros((B, n), np.complex64)
+    for c, s in enumerate(sts):
+        streams[c, :s.size] = s
+        want.append([p for _k, p in oracle.demod_run(sf, streams[c], mtu=mtu, keep=False)["packets"]])
+    dev = gpu.from_numpy(streams).to("cuda:0")
+    d = L.LoRaDemod(sf, n_channels=B)
+    d.set_mode(1)
+    d.setMTU(mtu)
+    d.work(dev)
+    ps, pn, pc = d.packets_device(clear=False)                   # device path: rows by channel, then time
+    ps, pn, pc = ps.cpu().numpy(), pn.cpu().numpy(), pc.cpu().numpy()
+    assert ps.shape == (sum(len(w) for w in want), mtu)
+    assert pc.tolist() == [c for c in range(B) for _ in want[c]]
+    row = 0
+    for c in range(B):
+        for p in want[c]:
+            assert pn[row] == len(p) and np.array_equal(ps[row, :len(p)], p) and not ps[row, len(p):].any()
+            row += 1
+    host = d.packets(clear=False)                                # the host queue holds the same packets (round-major order)
+    assert sorted((c, tuple(s.tolist())) for c, _r, s in host) == sorted((int(pc[i]), tuple(ps[i, :pn[i]].tolist())) for i in range(len(pn)))
+    ps2, pn2, pc2 = d.packets_device()                           # now from the host queue: its order
+    assert [int(x) for x in pc2.cpu()] == [c for c, _r, _s in host]
+    assert all(np.array_equal(ps2[i, :len(s)].cpu().numpy(), s) for i, (_c, _r, s) in enumerate(host))
+    # ---- cut every stream inside its last packet: run 1 ends with open packets, run 2 completes them ----
+    d.activate()
+    cut = n - 2 * N - (3 * N + N // 2) - 4 * N                    # before the end of the last frame's data symbols
+    d.work(dev[:, :cut].contiguous())
+    first = d.packets()                                           # drains (channels are inside a packet)
+    used = [d.consumed(c) for c in range(B)]
+    rest = max(n - u for u in used)
+    tail = np.zeros((B, rest), np.complex64)
+    for c in range(B):
+        tail[c, :n - used[c]] = streams[c, used[c]:]
+    d.work(gpu.from_numpy(tail).to("cuda:0"))
+    ps3, pn3, pc3 = d.packets_device(clear=False)                 # a packet begun in run 1: host-queue path
+    second = d.packets()
+    got = {c: [] for c in range(B)}
+    for c, _r, s in first + second:
+        got[c].append(s)
+    for c in range(B):
+        assert len(got[c]) == len(want[c]) and all(np.array_equal(a, b) for a, b in zip(got[c], want[c])), c
+    assert [int(x) for x in pc3.cpu()] == [c for c, _r, _s in second]
+    d.close()

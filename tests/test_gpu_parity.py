@@ -173,6 +173,44 @@ def test_fine_tune_recurrence(gpu, oracle, sf):
     check(o, g, dec=True, where="fine sf%d" % sf)
 
 
+@pytest.mark.parametrize("sf", range(6, 13))
+def test_fine_index_closed_form_special_cases(gpu, oracle, sf):
+    """The tuned kernels evaluate the index recurrence in closed form and the table entry from the split tables
+    (lorahip_fine.h). The cases where the form is not the plain modular one, in whole batches so that every wave / workgroup
+    meets them: the index walking down to 0 and sticking there (0 < d < 1), landing on ceil(d) - 1 (the reference yields 0
+    there), steps a hair above an integer (float rounding reaches the next integer: serial chain), integer steps, both
+    signs -- with the split tables and with the table gather; all against the oracle's serial recurrence."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(700 + sf)
+    N = 1 << sf
+    M = 128 * N
+    cases = []
+    for d in (0.3, 0.9, 0.02):                                          # sticks at 0 inside the window, before it, never
+        cases += [(d, N // 3), (d, 0), (d, 5 * N)]
+    for d in (38.4, 2.5, 129.7):                                        # lands on ceil(d) - 1 after a few steps
+        c = int(np.ceil(d))
+        cases += [(d, c - 1 + 5 * c), (d, c - 1), (d, (c - 1 + (N // 2) * c) % M)]
+    for d in (38 + 2.0 ** -9, 7 + 2.0 ** -12, -(5 + 1 - 2.0 ** -10)):   # float rounding reaches the next integer in the high binades
+        cases += [(d, M - 3), (d, M // 2 + 1), (d, 17)]
+    for d in (3.0, -3.0, 128.0, -0.4, -77.7):
+        cases += [(d, 1), (d, M - 2)]
+    reps = {6: 600, 7: 600, 8: 300, 9: 150, 10: 80, 11: 40, 12: 24}[sf]
+    E = np.tile(np.array([d / 128.0 for d, _ in cases], np.float32), reps)
+    I = np.tile(np.array([i for _, i in cases], np.int32), reps)
+    W = E.size
+    iq, _ = make_iq(rng, sf, W, snr_db=8.0)
+    o = oracle.detect_batch(sf, iq, fine_idx0=I, fine_err=E, nthreads=8)
+    ctx = L.Context(sf)
+    t = gpu.from_numpy
+    for gather in (False, True):
+        ctx.set_fine_gather(gather)
+        assert ctx.fine_split_active() == (not gather)
+        g = ctx.detect_batch(t(iq).cuda(), fine_idx0=t(I).cuda(), fine_err=t(E).cuda(), want_fine_idx=True)
+        gpu.cuda.synchronize()
+        assert np.array_equal(to_np(g["fineIdxOut"]), o["fineIdxOut"]), "index recurrence end state (gather=%s)" % gather
+        check(o, g, fft=False, where="fine special cases sf%d gather=%s" % (sf, gather))
+
+
 def test_offsets_stride_and_overlap(gpu, oracle):
     """windows at arbitrary sample offsets (the sync machine consumes N-value, N/4+err, 2N ...)"""
     import lora_sdr_amd as L
