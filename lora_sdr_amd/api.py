@@ -447,19 +447,24 @@ class LoRaDemod:
         check(self._lib.lorahip_demod_run(self._h, ptrs, lens, C.byref(rounds)), "lorahip_demod_run")
         return rounds.value
 
-    def packets(self, clear=True):
-        """[(channel, round, int16 symbols)] -- the Pothos::Packet payloads of output port 0"""
+    def packets_arrays(self, clear=True):
+        """The queued packets as four flat arrays -- channel (int32), round (int64), length (int64), and all symbols back to
+        back (int16) -- in posting order: what lorahip_demod_get_packets delivers, without per-packet Python objects"""
         n = self._lib.lorahip_demod_num_packets(self._h)
         ns = self._lib.lorahip_demod_num_packet_symbols(self._h)
         ch, rd, ln = np.empty(n, np.int32), np.empty(n, np.int64), np.empty(n, np.int64)
         syms = np.empty(ns, np.int16)
         check(self._lib.lorahip_demod_get_packets(self._h, ch.ctypes.data, rd.ctypes.data, ln.ctypes.data, n, syms.ctypes.data, ns),
               "lorahip_demod_get_packets")
-        parts = np.split(syms, np.cumsum(ln)[:-1]) if n else []       # views into one array: no per-packet copy
-        out = list(zip(ch.tolist(), rd.tolist(), parts))
         if clear:
             self._lib.lorahip_demod_clear_packets(self._h)
-        return out
+        return ch, rd, ln, syms
+
+    def packets(self, clear=True):
+        """[(channel, round, int16 symbols)] -- the Pothos::Packet payloads of output port 0"""
+        ch, rd, ln, syms = self.packets_arrays(clear)
+        parts = np.split(syms, np.cumsum(ln)[:-1]) if ch.size else []       # views into one array: no per-packet copy
+        return list(zip(ch.tolist(), rd.tolist(), parts))
 
     def packets_device(self, stride=None, clear=True):
         """The queued packets as device tensors in the decoder's input layout -- (P, stride) int16 symbols (zero padded), (P,) int32
@@ -471,12 +476,12 @@ class LoRaDemod:
         dev = torch.device("cuda", int(self._device))
         if stride is None:
             stride = max(8, min(self._mtu, 512))                # no packet is longer than the MTU (LoRaDemod.cpp:291)
-        syms = torch.zeros((n, int(stride)), dtype=torch.int16, device=dev)
-        nsyms = torch.zeros(n, dtype=torch.int32, device=dev)
-        chan = torch.zeros(n, dtype=torch.int32, device=dev)
+        syms = torch.empty((n, int(stride)), dtype=torch.int16, device=dev)      # every element is written (rows are zero padded)
+        nsyms = torch.empty(n, dtype=torch.int32, device=dev)
+        chan = torch.empty(n, dtype=torch.int32, device=dev)
         got = C.c_size_t()
         if n:
-            torch.cuda.current_stream(dev).synchronize()            # the tensors above are zero-filled on torch's stream
+            torch.cuda.current_stream(dev).synchronize()            # the blocks may have pending work of their previous owner
             check(self._lib.lorahip_demod_packets_to_device(self._h, C.c_void_p(syms.data_ptr()), int(stride), C.c_void_p(nsyms.data_ptr()),
                                                             C.c_void_p(chan.data_ptr()), n, C.byref(got)), "lorahip_demod_packets_to_device")
         if clear:

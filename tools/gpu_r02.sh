@@ -98,6 +98,33 @@ if [[ $what == *explore* ]]; then
   done
 fi
 
+if [[ $what == *final* ]]; then
+  # the evidence profiles/r02 keeps: rocprofv3 kernel stats + the average of the timed steps for the three shapes bench.py reports
+  # (steady state, locked receiver, streaming demodulator), HBM traffic counters for roofline.traffic
+  for sf in ${FSF:-7 8 9 10 11 12}; do
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_sf$sf -o sf$sf --output-format csv -- \
+        python $R/bench.py --sf $sf --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_prof_sf$sf.log 2>&1 )
+    python tools/trace_tail.py $O/${TAG}_prof_sf$sf 200 | tee $O/${TAG}_sf${sf}_timed_steps.txt
+    find $O/${TAG}_prof_sf$sf -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} $O/${TAG}_sf${sf}_kernel_stats.csv
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_mov_sf$sf -o sf$sf --output-format csv -- \
+        python $R/bench.py --sf $sf --moving --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_prof_mov_sf$sf.log 2>&1 )
+    python tools/trace_tail.py $O/${TAG}_prof_mov_sf$sf 200 | tee $O/${TAG}_moving_sf${sf}_timed_steps.txt
+    case $sf in 7) CH=16384;; 8|9) CH=8192;; 10) CH=4096;; 11) CH=2048;; *) CH=1024;; esac
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_str_sf$sf -o sf$sf --output-format csv -- \
+        python $R/tools/bench_demod.py --sf $sf --channels $CH --modes 1 > $O/${TAG}_level3_sf$sf.txt 2>&1 )
+    find $O/${TAG}_prof_str_sf$sf -name '*kernel_stats.csv' | head -1 | xargs -r head -4 | cut -c1-200 | tee $O/${TAG}_level3_sf${sf}_kernel_stats.txt
+    tail -1 $O/${TAG}_level3_sf$sf.txt
+  done
+  for sf in ${FSF:-7 8 9 10 11 12}; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && timeout 300 rocprofv3 --pmc $c -d $O/pmc_${c}_sf$sf -o pmc --output-format csv -- \
+          python $R/bench.py --sf $sf --steps 5 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $O/pmc_${c}_sf$sf.log 2>&1 )
+    done
+  done
+  python tools/pmc_summary.py $O > $O/${TAG}_pmc_summary.txt 2>&1
+  tail -25 $O/${TAG}_pmc_summary.txt
+fi
+
 if [[ $what == *bench* ]]; then
   timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
   echo "bench exit $?"; tail -c 3000 $O/${TAG}_bench.json; tail -5 $O/${TAG}_bench.err
