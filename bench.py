@@ -549,6 +549,20 @@ def main():
         line["cpu_baseline"] = cb
     if solo and not a.alias_windows:
         line["oracle"] = sh.oracle_check(threads, moving=a.moving)
+    if solo and not single:
+        # the same path fed from HOST buffers (lorahip_detect_batch_host: stage, H2D, launch, results D2H): the PCIe-inclusive
+        # rate of SURVEY.md section 8d -- reported beside `value`, never as it
+        import numpy as np
+        k = min(sh.W, 65536)
+        part = sh.host_iq()[:k * sh.N]
+        sh.ctx.detect_batch(part)                                   # staging buffers allocated
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            r = sh.ctx.detect_batch(part)
+        dt = (time.perf_counter() - t0) / reps
+        ok = bool(np.array_equal(r["sym"], sh.out["sym"][:k].cpu().numpy().view(np.uint16)))
+        line["pcie_inclusive"] = {"Msym_s": r4(k / dt / 1e6), "GB_s": r4(k * sh.N * 8 / dt / 1e9), "windows": k, "same_symbols": ok}
 
     if sweep:
         per_sf, moving, level3 = [], [], []

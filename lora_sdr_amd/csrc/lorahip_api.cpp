@@ -447,7 +447,7 @@ int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, con
     a.nPackets = unsigned(n_packets); a.symStride = int(sym_stride); a.outStride = int(out_stride);
     a.sf = cfg->sf; a.ppm = cfg->ppm; a.rdd = cfg->rdd; a.crcc = cfg->crcc; a.interleaving = cfg->interleaving;
     a.errorCheck = cfg->error_check; a.explicitHdr = cfg->explicit_hdr; a.hdr = cfg->hdr; a.dataLength = cfg->data_length;
-    LORAHIP_TRY(launchDecode(a, ctx->stream));
+    LORAHIP_TRY(launchDecode(a, ctx->variant, ctx->stream));
     return LORAHIP_OK;
 }
 

@@ -1,11 +1,20 @@
-// Batched LoRaDecoder: symbol packets -> bytes, one lane per packet.
+// Batched LoRaDecoder: symbol packets -> bytes.
 //
 // What the LoRaDecoder block does for one message (LoRaDecoder.cpp:196-397 on LoRaCodes.hpp): Gray-code the demodulated
 // symbols with rounding to the symbol size, de-interleave diagonally into codewords (the first block always 4/8), strip the
 // whitening with the two interleaved LFSRs, Hamming / parity decode, parse and check the explicit header, check the
-// payload CRC. Integer and bit work on a few hundred bytes per packet: the parallel axis is the packet (the demodulator
-// hands over thousands per launch), each lane walks its packet exactly in the reference's order. The working arrays
-// (symbols, codewords, bytes) live in per-lane scratch.
+// payload CRC. Integer and bit work on a few hundred bytes per packet.
+//
+// decodeGroup (the default): a GROUP of G = 8 / 16 / 32 / 64 lanes of a wavefront owns a packet (G by the row length of the
+// launch), the packet's symbols, codewords and nibbles live in the group's slice of LDS, and every stage is data-parallel over
+// the lanes of the group: a lane Gray-codes its symbols, builds its codewords bit by bit from the (at most eight) symbols of
+// their interleaver block, whitens them from a precomputed table of the two LFSR sequences (they do not depend on the packet),
+// decodes its nibbles, assembles its bytes; the CRC is a sum over the lanes of byte * x^(8 k) mod P (a 256-entry table), folded
+// with lane shuffles. No per-lane arrays, no scratch. The order of the reference's decisions (what is decoded before which
+// check, which coding rate applies where) is kept exactly; only the loops became lanes.
+//
+// decodePackets (context variant 1): one lane walks one packet statement by statement in the reference's order, working arrays
+// in per-lane scratch -- the round-1 kernel, kept as the A/B checker.
 #include "lorahip_internal.h"
 
 namespace lorahip {
@@ -297,11 +306,302 @@ __global__ void __launch_bounds__(64) decodePackets(const DecodeArgs a)
     a.dropped[p] = dropped;
 }
 
-hipError_t launchDecode(const DecodeArgs &a, hipStream_t stream)
+
+/***********************************************************************
+ * group-per-packet decoder
+ **********************************************************************/
+namespace {
+
+#define LORAHIP_WHITEN_LEN 800                 // positions per register: (1564 codewords + 5) / 2 rounded up
+
+//! the byte sequences of the two whitening registers for both seed sets, and the CRC helper tables -- none depends on the packet
+struct CodecTables
+{
+    unsigned char white[2][2][LORAHIP_WHITEN_LEN];     // [single-parity seeds][odd register][step]: low byte before the step (:255-268)
+    unsigned short xpow[LORAHIP_WHITEN_LEN];            // x^(8 k) mod (x^16 + x^12 + x^5 + 1): one byte position of crc16sx, k times
+    unsigned char lfsr8[LORAHIP_WHITEN_LEN + 2];        // the 8-bit register of dataChecksum after k steps from 0xff (:170-194)
+};
+
+constexpr unsigned long long lfsrAdvanceC(const unsigned long long r)
+{
+    return (r >> 8) | ((((r ^ (r >> 16) ^ (r >> 24) ^ (r >> 32)) & 0xff)) << 56);
+}
+constexpr int parityC(unsigned v) { int p = 0; while (v) { p ^= 1; v &= v - 1; } return p; }
+
+constexpr CodecTables makeCodecTables()
+{
+    CodecTables t = {};
+    const unsigned long long seeds[2][2] = { { 0x6572D100E85C2EFFull, 0xE85C2EFFFFFFFFFFull }, { 0x05121100F8ECFEEFull, 0xF8ECFEEFEFEFEFEFull } };
+    for (int c = 0; c < 2; c++)
+        for (int o = 0; o < 2; o++)
+        {
+            unsigned long long r = seeds[c][o];
+            for (int n = 0; n < LORAHIP_WHITEN_LEN; n++) { t.white[c][o][n] = (unsigned char)(r & 0xff); r = lfsrAdvanceC(r); }
+        }
+    unsigned v = 1;                                      // x^0
+    for (int k = 0; k < LORAHIP_WHITEN_LEN; k++)
+    {
+        t.xpow[k] = (unsigned short)v;
+        for (int b = 0; b < 8; b++) v = ((v << 1) ^ ((v & 0x8000) ? 0x1021 : 0)) & 0xffff;
+    }
+    unsigned char l = 0xff;
+    for (int k = 0; k < LORAHIP_WHITEN_LEN + 2; k++) { t.lfsr8[k] = l; l = (unsigned char)((l << 1) | parityC(l & 0xB8)); }
+    return t;
+}
+
+__device__ const CodecTables kCodec = makeCodecTables();
+
+//! a * x^(8k) mod P for a byte a: the contribution of data byte a to the crc after k further byte steps
+__device__ __forceinline__ unsigned crcShift(const unsigned a, const unsigned xk)
+{
+    unsigned acc = 0, t = xk;
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+    {
+        acc ^= ((a >> b) & 1) ? t : 0u;
+        t = ((t << 1) ^ ((t & 0x8000) ? 0x1021u : 0u)) & 0xffffu;
+    }
+    return acc;
+}
+
+template <int G> __device__ __forceinline__ unsigned groupXor(unsigned v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v ^= __shfl_xor(v, o, G);
+    return v;
+}
+template <int G> __device__ __forceinline__ bool groupAny(const bool p)
+{
+    unsigned v = p ? 1u : 0u;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v |= __shfl_xor(v, o, G);
+    return v != 0;
+}
+
+} // namespace
+
+template <int G>
+__global__ void __launch_bounds__(256) decodeGroup(const DecodeArgs a, const int symCap)
+{
+    // per packet: symCap Gray-coded symbols (u16), then the codewords (u8), then the nibbles (u8), 16-byte aligned slices
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemDec[];
+    constexpr int PER_BLOCK = 256 / G;
+    const int cwCap = (symCap / 4) * 12 + 16;
+    const int slice = ((symCap * 2 + 2 * cwCap + 15) & ~15);
+    const int g = threadIdx.x / G, t = threadIdx.x % G;
+    unsigned short *sSym = reinterpret_cast<unsigned short *>(smemDec + (size_t)g * slice);
+    unsigned char *sCw = smemDec + (size_t)g * slice + symCap * 2;
+    unsigned char *sNib = sCw + cwCap;
+    const unsigned p = blockIdx.x * PER_BLOCK + g;
+    const bool have = p < a.nPackets;
+    const unsigned pc = have ? p : 0;
+    const int nsyms = have ? a.nsyms[pc] : 0;
+    const unsigned short *in = a.syms + (size_t)pc * a.symStride;
+    unsigned char *out = a.out + (size_t)pc * a.outStride;
+    int outLen = -1, dropped = 0;
+
+    const int sf = a.sf;
+    const int PPM = a.ppm == 0 ? sf : a.ppm;                                                 // LoRaDecoder.cpp:201
+    const int bs = 4 + a.rdd;                                                                // symbols per interleaver block
+    const int numSymbols = ((nsyms + bs - 1) / bs) * bs;                                     // :210
+    const int numCodewords = (numSymbols / bs) * PPM;                                        // :211
+    // group-uniform early outs (:202 throws, :208 too short; larger than this launch's rows / this build supports)
+    bool go = have && !(PPM > sf || nsyms < LORAHIP_N_HDR_SYMBOLS);
+    if (go && (numSymbols > symCap || nsyms > a.symStride || numCodewords + 4 > cwCap)) { outLen = -2; go = false; }
+
+    // ---- Gray code with rounding to the symbol size (:218-222) --------------------------------------------------------
+    if (go)
+        for (int i = t; i < numSymbols; i += G)
+        {
+            unsigned short sym = i < nsyms ? in[i] : 0;
+            sym = (unsigned short)(sym + (1 << (sf - PPM)) / 2);
+            sym = (unsigned short)(sym >> (sf - PPM));
+            sym = (unsigned short)(sym ^ (sym >> 1));
+            sSym[i] = sym;
+            if (!a.interleaving) reinterpret_cast<unsigned short *>(out)[i] = sym;          // :264-270
+        }
+    if (go && !a.interleaving) { outLen = numSymbols; go = false; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __syncthreads();
+
+    // ---- diagonal de-interleave (:366-381) + de-whitening (:225-255), one codeword per lane and round ------------------
+    // the first block is always 4/8 over 8 symbols unless the whole packet is (then every block is)
+    const bool hdrBlock = a.rdd != LORAHIP_HDR_RDD;
+    if (go)
+        for (int c = t; c < numCodewords + 4; c += G)
+        {
+            unsigned cw = 0;
+            if (c < numCodewords)
+            {
+                int x, i, symOff, R;
+                if (hdrBlock && c < PPM) { x = 0; i = c; symOff = 0; R = LORAHIP_HDR_RDD; }
+                else if (hdrBlock) { x = (c - PPM) / PPM; i = (c - PPM) - x * PPM; symOff = LORAHIP_N_HDR_SYMBOLS + x * bs; R = a.rdd; }
+                else { x = c / PPM; i = c - x * PPM; symOff = x * bs; R = a.rdd; }
+                // with a header block the payload's symbols may end inside a block of `bs`: the reference de-interleaves
+                // (numSymbols - 8) / bs whole blocks and leaves the rest of the codewords zero
+                const bool whole = !hdrBlock || c < PPM || (symOff + (4 + R) <= numSymbols);
+                if (whole)
+                    for (int k = 0; k < 4 + R; k++)
+                    {
+                        int m = i - (k % PPM);
+                        if (m < 0) m += PPM;
+                        cw |= ((sSym[symOff + k] >> m) & 1u) << k;
+                    }
+                // position in the whitening sequence: codeword index, minus the five header codewords that are not whitened
+                // (with a header block and nothing but it -- exactly 8 symbols -- the reference skips the payload's whitening call)
+                const int pos = a.explicitHdr ? c - LORAHIP_N_HDR_CODEWORDS : c;
+                if (pos >= 0 && !(hdrBlock && c >= PPM && numSymbols <= LORAHIP_N_HDR_SYMBOLS))
+                {
+                    const int Rw = (hdrBlock && c < PPM) ? LORAHIP_HDR_RDD : a.rdd;
+                    const unsigned keep = 0xffu >> (4 - Rw);
+                    cw ^= kCodec.white[Rw == 1 ? 1 : 0][pos & 1][pos >> 1] & keep;
+                }
+            }
+            sCw[c] = (unsigned char)cw;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __syncthreads();
+
+    // ---- header (:283-311), evaluated by every lane of the group alike -------------------------------------------------
+    bool error = false, bad = false;
+    const int nbytes = (numCodewords + 1) / 2;
+    long long packetLength = 0, dataLength = 0;
+    bool checkCrc = a.crcc != 0;
+    int rdd = a.rdd;
+    unsigned char h0 = 0, h1 = 0, h2 = 0;
+    if (go)
+    {
+        if (a.explicitHdr)
+        {
+            h0 = (unsigned char)((decodeHamming84(sCw[1], error, bad) & 0xf) | (decodeHamming84(sCw[0], error, bad) << 4));   // length
+            h1 = decodeHamming84(sCw[2], error, bad) & 0xf;                                      // coding rate and crc enable
+            h2 = (unsigned char)((decodeHamming84(sCw[4], error, bad) & 0xf) | (decodeHamming84(sCw[3], error, bad) << 4));   // checksum
+            const unsigned char hb[2] = { h0, h1 };
+            h2 ^= headerChecksum(hb);
+            if (error && a.errorCheck) { dropped = 1; go = false; }
+            if (go)
+            {
+                if (0 == (h1 & 1)) checkCrc = false;
+                rdd = (h1 >> 1) & 0x7;
+                if (rdd > 4) { dropped = 1; go = false; }
+                packetLength = h0;
+                dataLength = packetLength + ((h1 & 1) ? 5 : 3);
+            }
+        }
+        else
+        {
+            packetLength = a.dataLength;
+            dataLength = a.crcc ? packetLength + 2 : packetLength;
+        }
+        if (go && dataLength > nbytes) { dropped = 1; go = false; }                          // :313
+    }
+
+    // ---- nibbles (:315-361): codeword c -> nibble c (+1 after an explicit header); the first block is 4/8, the rest at the
+    // coding rate the HEADER names; decoded are the first block, the nibble that completes its last byte, and what
+    // dataLength bytes need -- errors anywhere else do not count, exactly as in the reference's loops
+    const int c0 = a.explicitHdr ? LORAHIP_N_HDR_CODEWORDS : 0, shift = a.explicitHdr ? 1 : 0;
+    if (go)
+    {
+        long long cEnd = 2 * dataLength - shift;                                             // first codeword NOT needed by the bytes
+        const int fill = PPM + (((PPM + shift) & 1) ? 1 : 0);                               // first block + the odd nibble
+        if (cEnd < fill) cEnd = fill;
+        if (a.explicitHdr) { sNib[0] = h0 & 0xf; sNib[1] = h0 >> 4; sNib[2] = h1 & 0xf; sNib[3] = 0; sNib[4] = h2 & 0xf; sNib[5] = h2 >> 4; }
+        for (int c = c0 + t; c < cEnd; c += G)
+        {
+            const unsigned char cw = sCw[c];
+            const unsigned char nib = c < PPM ? decodeHamming84(cw, error, bad) : decodeNibble(cw, rdd, error, bad);
+            sNib[c + shift] = nib & 0xf;
+        }
+        // the bytes beyond the decoded nibbles are zero in the reference's buffer
+        for (long long v = cEnd + shift + t; v < 2 * (dataLength + 1); v += G) sNib[v] = 0;
+    }
+    error = groupAny<G>(error);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __syncthreads();
+    if (go && error && a.errorCheck) { dropped = 1; go = false; }                            // :342, :363
+
+    // ---- checksum (:367-388): crc = sum over the bytes of byte * x^(8 (len-1-i)), then the two LFSR masks ---------------
+    int dOfs = 0;
+    if (go && (a.explicitHdr ? (h1 & 1) != 0 : checkCrc))
+    {
+        const int base = a.explicitHdr ? 3 : 0;
+        const int len = a.explicitHdr ? (int)packetLength : a.dataLength;
+        unsigned acc = 0;
+        for (int i = t; i < len; i += G)
+        {
+            const unsigned byte = sNib[2 * (base + i)] | (sNib[2 * (base + i) + 1] << 4);
+            // res_{i+1} = S(res_i) ^ d_i: byte i is shifted by the len-1-i byte steps that follow it
+            acc ^= crcShift(byte, kCodec.xpow[len - 1 - i]);
+        }
+        unsigned crc = groupXor<G>(acc);
+        crc ^= kCodec.lfsr8[len];                                                            // res ^= v after len steps
+        crc ^= (unsigned)kCodec.lfsr8[len + 1] << 8;                                         // ... and one step later, high byte
+        crc &= 0xffff;
+        const unsigned packetCrc = (sNib[2 * (base + len)] | (sNib[2 * (base + len) + 1] << 4)) |
+                                   ((sNib[2 * (base + len) + 2] | (sNib[2 * (base + len) + 3] << 4)) << 8);
+        if (a.explicitHdr)
+        {
+            if (crc != packetCrc && checkCrc) { dropped = 1; go = false; }
+        }
+        else if (crc != packetCrc) { dropped = 1; go = false; }
+        if (go && t == 0)
+        {
+            // bytes[len] ^= crc, bytes[len + 1] ^= crc >> 8 (:377-378, :386-387)
+            const unsigned lo = (sNib[2 * (base + len)] | (sNib[2 * (base + len) + 1] << 4)) ^ (crc & 0xff);
+            const unsigned hi = (sNib[2 * (base + len) + 2] | (sNib[2 * (base + len) + 3] << 4)) ^ (crc >> 8);
+            sNib[2 * (base + len)] = lo & 0xf; sNib[2 * (base + len) + 1] = (lo >> 4) & 0xf;
+            sNib[2 * (base + len) + 2] = hi & 0xf; sNib[2 * (base + len) + 3] = (hi >> 4) & 0xf;
+        }
+    }
+    if (go && a.explicitHdr && !a.hdr) { dOfs = 3; dataLength -= 5; }                        // :379
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __syncthreads();
+    // `dataLength -= 5` on a size_t wraps for a header without the crc flag that announces fewer than 2 bytes; the
+    // reference then fails to allocate its output and posts nothing
+    if (go && dataLength >= 0)
+    {
+        for (long long i = t; i < dataLength; i += G) out[i] = (unsigned char)(sNib[2 * (dOfs + i)] | (sNib[2 * (dOfs + i) + 1] << 4));   // :391-395
+        outLen = (int)dataLength;
+    }
+    if (have && t == 0)
+    {
+        a.outLen[p] = outLen;
+        a.dropped[p] = dropped;
+    }
+}
+
+template <int G>
+static hipError_t launchDecodeGroup(const DecodeArgs &a, hipStream_t stream)
+{
+    // rows of the launch bound the packet length: size the LDS slices for them
+    const int bsMin = 4;
+    const int symCap = ((a.symStride + 7 + bsMin) & ~3) + 8;
+    const int cwCap = (symCap / 4) * 12 + 16;
+    const size_t slice = size_t((symCap * 2 + 2 * cwCap + 15) & ~15);
+    const size_t smem = slice * (256 / G);
+    static unsigned long long attrDone = 0;
+    {
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(decodeGroup<G>), 160 * 1024, attrDone);
+        if (e != hipSuccess) return e;
+    }
+    const unsigned perBlock = 256 / G;
+    hipLaunchKernelGGL((decodeGroup<G>), dim3((a.nPackets + perBlock - 1) / perBlock), dim3(256), smem, stream, a, symCap);
+    return hipGetLastError();
+}
+
+hipError_t launchDecode(const DecodeArgs &a, const int variant, hipStream_t stream)
 {
     if (a.nPackets == 0) return hipSuccess;
-    hipLaunchKernelGGL(decodePackets, dim3((a.nPackets + 63) / 64), dim3(64), 0, stream, a);
-    return hipGetLastError();
+    if (variant == 1)
+    {
+        hipLaunchKernelGGL(decodePackets, dim3((a.nPackets + 63) / 64), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
+    // lanes per packet by the row length: a packet of n symbols has about n * PPM / (4 + rdd) codewords
+    if (a.symStride <= 24) return launchDecodeGroup<8>(a, stream);
+    if (a.symStride <= 64) return launchDecodeGroup<16>(a, stream);
+    if (a.symStride <= 160) return launchDecodeGroup<32>(a, stream);
+    return launchDecodeGroup<64>(a, stream);
 }
 
 int decodeMaxSymbols() { return LORAHIP_DEC_MAX_SYMBOLS - 8; }

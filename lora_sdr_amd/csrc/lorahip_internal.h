@@ -113,7 +113,7 @@ struct DecodeArgs
     int symStride, outStride;
     int sf, ppm, rdd, crcc, interleaving, errorCheck, explicitHdr, hdr, dataLength;
 };
-hipError_t launchDecode(const DecodeArgs &a, hipStream_t stream);
+hipError_t launchDecode(const DecodeArgs &a, int variant, hipStream_t stream);   // variant 1: the lane-per-packet checker
 int decodeMaxSymbols();
 
 //! launchers (lorahip_kernels.hip / lorahip_fast.hip)

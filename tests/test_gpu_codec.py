@@ -14,14 +14,18 @@ def configure(dec, sf, ppm, rdd, crcc, inter, ec, explicit, hdr, dlen):
     dec.enableInterleaving(inter); dec.enableErrorCheck(ec); dec.enableExplicit(explicit); dec.enableHdr(hdr); dec.setDataLength(dlen)
 
 
-def test_golden_codec_kat(gpu, golden):
-    """every recorded case, grouped by decoder configuration so that each launch carries a batch of packets"""
+@pytest.mark.parametrize("variant", [0, 1])
+def test_golden_codec_kat(gpu, golden, variant):
+    """every recorded case, grouped by decoder configuration so that each launch carries a batch of packets.
+    variant 0: a group of lanes per packet, every stage data-parallel, working set in LDS (the default);
+    variant 1: one lane walks one packet in the reference's statement order (the round-1 kernel, kept as the checker)"""
     import lora_sdr_amd as L
     g = golden("codec_kat.npz")
     groups = {}
     for i in range(int(g["count"])):
         groups.setdefault(tuple(int(v) for v in g["cfg_%d" % i]), []).append(i)
     dec = L.LoRaDecoder()
+    dec._ctx.set_variant(variant)
     checked = 0
     for cfg, idx in groups.items():
         configure(dec, *cfg)
@@ -148,3 +152,31 @@ def test_longest_packets_and_limits(gpu, oracle):
     assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 513, p, 1, p, 2 * (513 + 8), p, p) == -1      # stride too long
     assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 64, p, 1, p, 2 * 64, p, p) == -1               # output stride too short
     assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 64, p, 0, p, 2 * 72, p, p) == 0                # empty batch
+
+
+def test_decoder_edge_shapes_both_kernels_vs_oracle(gpu, oracle):
+    """packet lengths around the interleaver block sizes (exactly the 8 header symbols, one symbol more, a partial last block),
+    every coding rate, small symbol sizes, implicit / explicit header, crc on / off, rows of every lane-group size (8 / 16 / 32 /
+    64 lanes per packet): the group kernel, the lane-per-packet checker and the CPU oracle must agree on every output"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(11)
+    dec = L.LoRaDecoder()
+    total = 0
+    for variant in (0, 1):
+        dec._ctx.set_variant(variant)
+        rng = np.random.default_rng(11)
+        for sf, ppm in ((7, 0), (7, 5), (9, 6), (12, 0), (10, 8)):
+            for rdd in range(5):
+                for explicit in (True, False):
+                    for crcc in (False, True):
+                        configure(dec, sf, ppm, rdd, int(crcc), 1, 0, int(explicit), 0, 6)
+                        for lens in ((8, 9, 11, 12, 15, 16, 17), (23, 24, 40, 41), (100, 129, 160), (161, 300, 512)):
+                            pk = [rng.integers(0, 1 << sf, n).astype(np.uint16) for n in lens]
+                            res = dec.work(pk)
+                            for s_, out in zip(pk, res):
+                                o, _ = oracle.decode(sf, s_, ppm=ppm, cr=RDD_TO_CR[rdd], crcc=crcc, explicit=explicit, data_length=6)
+                                assert (o is None) == (out is None), (variant, sf, ppm, rdd, explicit, crcc, len(s_))
+                                if o is not None:
+                                    assert np.array_equal(o, out), (variant, sf, ppm, rdd, explicit, crcc, len(s_))
+                                total += 1
+    assert total == 2 * 5 * 5 * 2 * 2 * 17
