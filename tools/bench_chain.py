@@ -58,6 +58,6 @@ for rep in range(3):
     want = torch.from_numpy(data.astype(np.uint8)).cuda()
     ok = int(((out_len == len(data)) & (out[:, :len(data)] == want[None, :]).all(dim=1)).sum()) if out.shape[0] else 0
     tot = t_chan + t_dem + t_get + t_dec
-    print("  run %d: modulate %.1f ms, awgn %.1f ms | channelise %.1f ms, demodulate %.1f ms, packets to the decoder's layout %.1f ms, decode %.1f ms"
-          " -> %d/%d payloads correct; receive side %.1f ms = %.2f M frames/s, %.1f Msym/s, %.1f MB/s of payload"
-          % (rep, t_mod, t_awgn, t_chan, t_dem, t_get, t_dec, ok, B, tot, B / tot / 1e3, B * len(syms) / tot / 1e3, B * len(data) / tot / 1e3))
+    print("  run %d: modulate %.2f ms, awgn %.2f ms | channelise %.2f ms, demodulate %.3f ms, packets to the decoder's layout %.3f ms, decode %.3f ms"
+          " -> %d/%d payloads correct; receive side %.3f ms = %.2f M frames/s, %.1f Msym/s, %.1f MB/s of payload"
+          % (rep, t_mod, t_awgn, t_chan, t_dem, t_get, t_dec, ok, B, tot, B / tot / 1e3, B * len(syms) / tot / 1e3, B * len(data) / tot / 1e3), flush=True)
