@@ -163,6 +163,12 @@ int lorahip_detector_detect(lorahip_detector *det, size_t *index, float *power, 
 
 /* -------------------------------------------------------------------------------------
  * Level 3: B channels of the LoRaDemod block (declared here, see lorahip_demod.cpp).
+ *
+ * What "identical to the reference block" means here: symbol values and FFT bins are bit-exact by construction; power, powerAvg and
+ * fIndex equal the CPU build's to float rounding (<= 2e-5 dB / 2e-6 bins: the logarithms and the fp64 sum are evaluated in a
+ * different order), and the frame machine consumes them (`snr < thresh`, `_finefreqError += fIndex`, LoRaDemod.cpp:173-174,219).
+ * A value within that rounding of a decision boundary could therefore take the other branch than the CPU build; every trace the
+ * tests compare is identical, but at this level the guarantee is empirical.
  * ------------------------------------------------------------------------------------- */
 typedef struct lorahip_demod lorahip_demod;
 

@@ -21,6 +21,8 @@ int hipFail(const hipError_t e, const char *what)
     return LORAHIP_E_HIP;
 }
 
+// The attribute is set ONCE per (kernel, device). Kernels whose LDS size depends on the object (the channeliser's tile, the
+// decoder's rows) pass the device maximum, 160 KiB, so that a later, larger instance is covered too.
 hipError_t ensureDynamicLds(const void *kernel, const size_t bytes, unsigned long long &doneMask)
 {
     int dev = 0;

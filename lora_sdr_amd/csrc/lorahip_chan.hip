@@ -325,12 +325,12 @@ static int chanRun(lorahip_channelizer *c, const float2 *wide, const size_t nIn,
         const dim3 grid((unsigned)nBlocks, (unsigned)(captures ? captures : 1));
         if (c->RM == 2)
         {
-            LORAHIP_TRY(ensureDynamicLds(reinterpret_cast<const void *>(&channelize<2>), c->ldsBytes, gLdsMask[1]));
+            LORAHIP_TRY(ensureDynamicLds(reinterpret_cast<const void *>(&channelize<2>), 160 * 1024, gLdsMask[1]));
             hipLaunchKernelGGL(channelize<2>, grid, dim3(CHAN_THREADS), c->ldsBytes, ctx->stream, a);
         }
         else
         {
-            LORAHIP_TRY(ensureDynamicLds(reinterpret_cast<const void *>(&channelize<1>), c->ldsBytes, gLdsMask[0]));
+            LORAHIP_TRY(ensureDynamicLds(reinterpret_cast<const void *>(&channelize<1>), 160 * 1024, gLdsMask[0]));
             hipLaunchKernelGGL(channelize<1>, grid, dim3(CHAN_THREADS), c->ldsBytes, ctx->stream, a);
         }
         LORAHIP_TRY(hipGetLastError());
