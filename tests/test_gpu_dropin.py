@@ -119,3 +119,20 @@ def test_batch_block_posts_what_the_reference_block_posts(gpu, golden, oracle, s
         assert [n for n, _ in gs] == [n for n, _ in ws]
         assert np.allclose([v for _, v in gs], [v for _, v in ws], rtol=0, atol=TOL_DB)
     blk.close()
+
+
+@pytest.mark.gpu
+def test_oracle_equals_the_reference_on_this_box(gpu, oracle, ref):
+    """The GPU parity tests compare the HIP path with the plain-C restatement (oracle/lora_oracle.c); this closes the chain ON THE
+    GPU BOX: the restatement against the reference compiled in place (oracle/_ref/libloraref.so travels as a binary) -- detector
+    outputs and FFT bins for every SF, whole demodulator runs, the decoder -- by running tests/test_oracle_vs_ref.py's checks in
+    the -m gpu set."""
+    import test_oracle_vs_ref as T
+    for sf in range(6, 13):
+        T.test_detect_bit_exact(oracle, ref, sf)
+    T.test_detector_sweep_n1024(oracle, ref)
+    for sf, off in ((7, 0.3), (8, -0.4), (10, 0.25)):
+        T.test_demod_block_identical(oracle, ref, sf, off)
+    T.test_demod_sync_word_and_squelch(oracle, ref)
+    for sf in (7, 10, 12):
+        T.test_decoder_matches_verbatim_block(oracle, ref, sf)
