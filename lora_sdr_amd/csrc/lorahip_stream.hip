@@ -189,13 +189,14 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
     return hipGetLastError();
 }
 
+// chirp table from LDS (both selections share it), last-phase twiddles in registers (+3-10 % over the LDS table, session 10)
 //             LOG2N T VEC NPH PB1 PB2 w/SIMD  X0: ROT PAD S  D   chLDS twLDS prefetch
-typedef FastCfg<6,  2, 4,  2,  2,  6,  2,          2,  1,  0, 0,  true,  true,  0> Stream6;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  true,  true,  0> Stream7;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  2,          0,  1,  0, 0,  true,  true,  0> Stream8;
-typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  true,  true,  0, false, false, true> Stream9;    // 32 lanes x 16 points, three phases, exchange 1 as row swaps:
+typedef FastCfg<6,  2, 4,  2,  2,  6,  2,          2,  1,  0, 0,  true,  false,  0> Stream6;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  true,  false,  0> Stream7;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  2,          0,  1,  0, 0,  true,  false,  0> Stream8;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  true,  false,  0, false, false, true> Stream9;    // 32 lanes x 16 points, three phases, exchange 1 as row swaps:
                                                                                                                  // with the per-sample fine-tune arithmetic the 32-point geometry spills (0.20 -> 0.26 of the roofline)
-typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  true,  true,  0, false, false, true> Stream10;   // exchange 1 as register row swaps
+typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  true,  false,  0, false, false, true> Stream10;   // exchange 1 as register row swaps
 
 //! the used columns of a [rows][capacity] record array packed densely (2-byte units): what goes back to the host is what a
 //! run filled, not the worst-case capacity
