@@ -352,7 +352,7 @@ def section_level3(env, L, sf):
            "frac_e2e": r4(calls * L.bytes_per_symbol(sf) / best[0] / 1e9 / HBM_PEAK_GBS), "e2e_host_ms": r4(best[2] * 1e3),
            "kernel_us": r4(best[1] * 1e3), "Msym_s_kernel": r4(calls / (best[1] / 1e3) / 1e6),
            "frac_kernel": r4(calls * L.bytes_per_symbol(sf) / (best[1] / 1e3) / 1e9 / HBM_PEAK_GBS),
-           "packets": n_pk, "packets_device": n_dev, "packets_expected": B * frames, "packets_ok": ok}
+           "packets": n_pk, "packets_device": n_dev, "packets_expected": B * frames, "packets_ok": ok, "staggered_starts": True}
     if env.rank == 0 and env.world == 1:
         # the same streams through the CPU oracle's restated block (pinned to the verbatim LoRaDemod.cpp): identical packets
         from oracle.oracle import Oracle

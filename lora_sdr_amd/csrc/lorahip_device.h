@@ -333,6 +333,21 @@ __device__ __forceinline__ void tailValuesPaired(const float powerScale, const f
     if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
 }
 
+/*! The squelch decision alone (LoRaDemod.cpp:173-174: `snr = power - powerAvg; squelched = snr < thresh`) without the tail: in
+ * DATASYMBOLS nothing else of detect()'s float outputs is consumed (:286-306; fIndex only feeds the label), so the streaming
+ * kernels skip the two logarithms, the two hypotenuses and the neighbour fetch there. snr is estimated as
+ * 10 log10(maxValue / float(total - maxValue)) with the hardware log2 (error < 1e-4 dB against the exact float chain, whose own
+ * roundings are ~3e-5 dB); `sure` is false within 0.01 dB of the threshold or for degenerate windows (zero peak, zero or
+ * negative noise) -- the caller then evaluates the exact chain, so the decision is always the exact one. */
+__device__ __forceinline__ bool squelchQuick(const float maxValue, const double total, const float thresh, bool &sure)
+{
+    const float noise2 = (float)(total - (double)maxValue);
+    const float snrApprox = 3.01029995664f * (__builtin_amdgcn_logf(maxValue) - __builtin_amdgcn_logf(noise2));   // 10 log10 = 3.0103 log2
+    sure = maxValue > 0.0f && noise2 > 0.0f && __builtin_fabsf(snrApprox - thresh) > 0.01f && snrApprox == snrApprox &&
+           __builtin_fabsf(snrApprox) < 1e30f;
+    return snrApprox < thresh;
+}
+
 template <class CPX>
 __device__ __forceinline__ void detectTail(const DetectArgs &a, const unsigned w, const int maxIndex,
                                            const float maxValue, const double total,

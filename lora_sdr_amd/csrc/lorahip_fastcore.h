@@ -318,10 +318,11 @@ struct FastCore
     //! LoRaDetector.hpp:36-48 over the window's bins: writes them to F (the window's row of the now free exchange
     //! region, for the neighbour fetch) and to fftOut (optional debug port), and leaves the window's arg-max,
     //! its |X|^2 and the fp64 total in every lane of the window.
+    template <bool STORE_F = true>
     static __device__ __forceinline__ void scan(const v2f (&vl)[NGL][GL], v2f *F, v2f *fftOut, const int t,
                                                 float &bestV, int &bestI, double &tot)
     {
-        if (!C::NB_SELECT)
+        if (!C::NB_SELECT && STORE_F)
         {
 #pragma unroll
             for (int e = 0; e < GL; e++)
@@ -352,11 +353,12 @@ struct FastCore
     }
 
     //! bins k-1 and k+1 of the window's peak k (LoRaDetector.hpp:56-57), valid in every lane of the window
+    template <bool FROM_REGS = C::NB_SELECT>
     static __device__ __forceinline__ void neighbours(const v2f (&vl)[NGL][GL], const v2f *F, const int bestI, const int lane, const int t,
                                                       v2f &leftBin, v2f &rightBin)
     {
         const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
-        if (C::NB_SELECT)
+        if (FROM_REGS)
         {
             const int cil = bl & ((1 << BL) - 1), cir = br & ((1 << BL) - 1);
             const bool ownL = (cil & (T - 1)) == t;

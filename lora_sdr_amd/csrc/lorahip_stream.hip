@@ -61,8 +61,11 @@ demodStream(const StreamArgs s)
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
     // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
-    auto detect = [&](const bool on, const long long off, const bool downTable, const int idx0, const float err,
-                      int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd)
+    // `full` (wave-uniform) = the float outputs are wanted. In DATASYMBOLS only the squelch decision is (LoRaDemod.cpp:286-306):
+    // a wave whose channels are all there -- and no trace is kept -- skips the staging of the bins for the neighbour fetch and
+    // the tail, and decides the squelch from a quick estimate (squelchQuick), falling back to the exact chain near the threshold.
+    auto detect = [&](const bool on, const bool full, const long long off, const bool downTable, const int idx0, const float err,
+                      int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
         K::load(x, gIq + (on ? off : 0), t);
@@ -117,12 +120,30 @@ demodStream(const StreamArgs s)
         float bestV;
         int bestI;
         double tot;
-        K::scan(vl, F, nullptr, t, bestV, bestI, tot);
         v2f l, r;
-        K::neighbours(vl, F, bestI, lane, t, l, r);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
+        value = 0;
+        if (full)
+        {
+            K::scan(vl, F, nullptr, t, bestV, bestI, tot);
+            K::neighbours(vl, F, bestI, lane, t, l, r);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
+            squelched = (power - powerAvg) < s.thresh;                                   // :173-174
+        }
+        else
+        {
+            K::template scan<false>(vl, F, nullptr, t, bestV, bestI, tot);
+            bool sure;
+            squelched = squelchQuick(bestV, tot, s.thresh, sure);
+            power = powerAvg = fIndex = 0.0f;                                           // not consumed in DATASYMBOLS
+            if (__any(on && !sure))
+            {
+                K::template neighbours<true>(vl, F, bestI, lane, t, l, r);
+                tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
+                squelched = (power - powerAvg) < s.thresh;
+            }
+        }
         value = bestI;
     };
 
@@ -137,9 +158,10 @@ demodStream(const StreamArgs s)
         const int fineIdxBefore = st.fineTuneIndex;
         const float fineErrBefore = st.finefreqError;
         const long long here = base + st.pos;
-        detect(live, here, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd);
-        const float snr = power - powerAvg;                                             // :173
-        const bool squelched = snr < s.thresh;                                          // :174
+        const bool full = s.calls != nullptr || __any(live && st.state != ST_DATASYMBOLS);
+        bool squelched;
+        detect(live, full, here, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
+        const float snr = power - powerAvg;                                             // :173 (squelched = snr < thresh, :174, comes from detect)
         if (live) st.fineTuneIndex = idxEnd;                                            // the loop commits the member (:160-162)
 
         // ---- FRAMESYNC: second window when sync'd and the first sync word matches (:183-206) ----
@@ -152,7 +174,8 @@ demodStream(const StreamArgs s)
             int value1, idxEnd1;
             float p1, pa1, fi1;
             // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
-            detect(need1, here + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, p1, pa1, fi1, idxEnd1);
+            bool sq1;
+            detect(need1, true, here + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, p1, pa1, fi1, idxEnd1, sq1);
             if (need1)
             {
                 match1 = (value1 + 4) / 8 == (s.sync & 0xf);                           // :205

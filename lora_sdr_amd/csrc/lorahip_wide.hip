@@ -686,8 +686,11 @@ demodStreamWide(const StreamArgs s)
     o.init(s, c);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect; every argument is workgroup-uniform
-    auto detect = [&](const long long off, const bool downTable, const int idx0, const float err,
-                      int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd)
+    // `full` (workgroup-uniform) = the float outputs are wanted; in DATASYMBOLS without a trace only the squelch decision is
+    // (LoRaDemod.cpp:286-306): then the neighbour fetch, its barrier and the tail are skipped and the decision comes from a quick
+    // estimate (squelchQuick), with the exact chain as the fallback near the threshold
+    auto detect = [&](const bool full, const long long off, const bool downTable, const int idx0, const float err,
+                      int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
 #pragma unroll
@@ -800,8 +803,18 @@ demodStreamWide(const StreamArgs s)
                 tot += rk.tot;
             }
         }
-        // neighbours of the peak (LoRaDetector.hpp:56-57)
+        value = bestI;
+        bool needTail = full;
+        if (!full)
         {
+            bool sure;                                          // bestV, tot are identical in every thread: so is `sure`
+            squelched = squelchQuick(bestV, tot, s.thresh, sure);
+            power = powerAvg = fIndex = 0.0f;                   // not consumed in DATASYMBOLS
+            needTail = !sure;
+        }
+        if (needTail)
+        {
+            // neighbours of the peak (LoRaDetector.hpp:56-57)
             const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
             const bool ownL = (bl & (T - 1)) == t, ownR = (br & (T - 1)) == t;
             if (__any(ownL | ownR))
@@ -810,10 +823,10 @@ demodStreamWide(const StreamArgs s)
                 if (ownL) sNb[0] = mine;
                 if (ownR) sNb[1] = mine;
             }
+            __syncthreads();                                                                  // B5
+            tailValuesPaired(s.powerScale, bestV, tot, sNb[0], sNb[1], lane, power, powerAvg, fIndex);
+            squelched = (power - powerAvg) < s.thresh;                                       // :173-174
         }
-        __syncthreads();                                                                      // B5
-        tailValuesPaired(s.powerScale, bestV, tot, sNb[0], sNb[1], lane, power, powerAvg, fIndex);
-        value = bestI;
     };
 
     while ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt)                  // LoRaDemod.cpp:148
@@ -822,9 +835,10 @@ demodStreamWide(const StreamArgs s)
         float power, powerAvg, fIndex;
         const int fineIdxBefore = st.fineTuneIndex;
         const float fineErrBefore = st.finefreqError;
-        detect(base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd);
-        const float snr = power - powerAvg;                                             // :173
-        const bool squelched = snr < s.thresh;                                          // :174
+        bool squelched;
+        detect(s.calls != nullptr || st.state != ST_DATASYMBOLS, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power,
+               powerAvg, fIndex, idxEnd, squelched);
+        const float snr = power - powerAvg;                                             // :173 (squelched = snr < thresh, :174, comes from detect)
         st.fineTuneIndex = idxEnd;                                                      // :160-162
         const bool syncd = !squelched && (st.prevValue + 4) / 8 == 0;                  // :183
         const bool match0 = (value + 4) / 8 == (s.sync >> 4);                          // :184
@@ -833,7 +847,8 @@ demodStreamWide(const StreamArgs s)
         {
             int value1, idxEnd1;
             // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
-            detect(base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, power, powerAvg, fIndex, idxEnd1);
+            bool sq1;
+            detect(true, base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, power, powerAvg, fIndex, idxEnd1, sq1);
             match1 = (value1 + 4) / 8 == (s.sync & 0xf);                               // :205; snr is not recomputed
         }
         frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);

@@ -18,11 +18,13 @@ def default_geometry(sf):
 LEVEL3_CHANNELS = {6: 16384, 7: 16384, 8: 8192, 9: 8192, 10: 4096, 11: 2048, 12: 1024}
 
 
-def frame_streams(ctx, n_channels, n_frames=4, nsyms=48, sigma=0.05, sync=0x12, seed=1, distinct=64):
+def frame_streams(ctx, n_channels, n_frames=4, nsyms=48, sigma=0.05, sync=0x12, seed=1, distinct=64, stagger=True):
     """(n_channels, samples) complex64 device tensor: every channel carries n_frames LoRa frames (10 up-chirps, the two
     sync-word chirps, 2 1/4 down-chirps, nsyms data symbols; LoRaMod.cpp:135-229) separated by silence, plus AWGN.
-    `distinct` different payload sets are tiled over the channels. Returns (iq, data) with data[(c % distinct), frame, :]
-    the sent symbols."""
+    `distinct` different payload sets are tiled over the channels; with `stagger` the channels start at 16 different times
+    spread over half a frame, so that the channels sharing a wavefront are NOT in the same receiver state at the same time
+    (synchronised channels would flatter the streaming kernels, which take shortcuts when a whole wave is in DATASYMBOLS).
+    Returns (iq, data) with data[(c % distinct), frame, :] the sent symbols."""
     import torch
     sf, N = ctx.sf, ctx.N
     dev = torch.device("cuda", ctx.device)
@@ -43,7 +45,19 @@ def frame_streams(ctx, n_channels, n_frames=4, nsyms=48, sigma=0.05, sync=0x12, 
                   torch.zeros((V, 3 * N), dtype=torch.complex64, device=dev)]
     base = torch.cat(parts, dim=1)
     del parts, up
-    iq = base.repeat((n_channels + V - 1) // V, 1)[:n_channels].contiguous()
+    if stagger:
+        L0 = base.shape[1]
+        groups = 16
+        step = (per_frame * N // 2) // groups                       # leads 0 .. half a frame
+        iq = torch.zeros((n_channels, L0 + groups * step), dtype=torch.complex64, device=dev)
+        rows = torch.arange(n_channels, device=dev)
+        for gi in range(groups):
+            sel = rows[(rows * 7 + rows // 8) % groups == gi]       # neighbouring channels (one wave holds 1-16 of them) get different leads
+            if sel.numel():
+                lead = gi * step + 3 * gi
+                iq[sel, lead:lead + L0] = base[sel % V]
+    else:
+        iq = base.repeat((n_channels + V - 1) // V, 1)[:n_channels].contiguous()
     del base
     if sigma:
         ctx.add_awgn(iq, sigma, seed=seed)

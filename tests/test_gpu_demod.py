@@ -473,3 +473,46 @@ def test_packets_packed_on_the_device_equal_the_host_queue(gpu, oracle, sf):
         assert len(got[c]) == len(want[c]) and all(np.array_equal(a, b) for a, b in zip(got[c], want[c])), c
     assert [int(x) for x in pc3.cpu()] == [c for c, _r, _s in second]
     d.close()
+
+
+@pytest.mark.parametrize("sf", [7, 9, 10, 11, 12])
+def test_squelch_decisions_without_trace_at_the_threshold(gpu, oracle, sf):
+    """Without a trace the streaming kernels skip detect()'s float outputs in DATASYMBOLS and take the squelch decision
+    (LoRaDemod.cpp:173-174) from a quick estimate, falling back to the exact chain within 0.01 dB of the threshold. Thresholds
+    placed EXACTLY on snr values the reference computes for data symbols (and a hair beside them) must give the reference's
+    packets: lengths are decided by which symbol is squelched first."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(900 + sf)
+    N = 1 << sf
+    st, _ = frames(oracle, rng, sf, 3, 14, off=0.15, noise=0.4)
+    r0 = oracle.demod_run(sf, st, mtu=64, thresh=-30.0, keep=False)
+    snrs = sorted(c["snr"] for c in r0["calls"] if c["state"] == 4 and np.isfinite(c["snr"]))
+    picks = [snrs[len(snrs) // 4], snrs[len(snrs) // 2], snrs[(3 * len(snrs)) // 4]]
+    threshs = []
+    for v in picks:
+        v = np.float32(v)
+        threshs += [float(v), float(np.nextafter(v, np.float32(np.inf))), float(np.nextafter(v, np.float32(-np.inf))), float(v) + 0.004, float(v) - 0.004]
+    threshs += [-30.0, 3.0, 40.0]
+    dev = gpu.from_numpy(np.tile(st, (3, 1))).to("cuda:0")
+    d = L.LoRaDemod(sf, n_channels=3)
+    d.set_mode(1)
+    d.setMTU(64)
+    lens = set()
+    for th in threshs:
+        want = [p for _k, p in oracle.demod_run(sf, st, mtu=64, thresh=th, keep=False)["packets"]]
+        d.setThreshold(th)
+        d.activate()
+        d.work(dev)                                              # no trace: the quick path
+        got = {c: [] for c in range(3)}
+        for c, _r, s in d.packets():
+            got[c].append(s)
+        for c in range(3):
+            assert len(got[c]) == len(want) and all(np.array_equal(a, b) for a, b in zip(got[c], want)), (sf, th, c)
+        lens.add(tuple(len(p) for p in want))
+        # restore the state the next run starts from like the oracle's fresh block: a squelched window resets the tracking
+        d.close()
+        d = L.LoRaDemod(sf, n_channels=3)
+        d.set_mode(1)
+        d.setMTU(64)
+    assert len(lens) >= 3                                        # the thresholds really moved the packet boundaries
+    d.close()
