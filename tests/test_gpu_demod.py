@@ -516,3 +516,24 @@ def test_squelch_decisions_without_trace_at_the_threshold(gpu, oracle, sf):
         d.setMTU(64)
     assert len(lens) >= 3                                        # the thresholds really moved the packet boundaries
     d.close()
+
+
+def test_demod_on_a_second_device_while_the_first_is_current(gpu, oracle):
+    """a demodulator created for device 1 while device 0 is current (its staging buffers must live on ITS device; create / destroy
+    must leave the caller's current device alone); host-driven rounds and the streaming kernel -- needs two GPUs"""
+    import lora_sdr_amd as L
+    if gpu.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    rng = np.random.default_rng(4)
+    st, syms = frames(oracle, rng, 7, 1, 12)
+    gpu.cuda.set_device(0)
+    for mode in MODES:
+        d = L.LoRaDemod(7, n_channels=1, device=1)
+        assert gpu.cuda.current_device() == 0
+        d.set_mode(mode)
+        d.setMTU(12)
+        d.work([st])
+        pk = d.packets()
+        assert len(pk) == 1 and np.array_equal(pk[0][2], syms[0].astype(np.int16))
+        d.close()
+        assert gpu.cuda.current_device() == 0
