@@ -180,3 +180,20 @@ def test_decoder_edge_shapes_both_kernels_vs_oracle(gpu, oracle):
                                     assert np.array_equal(o, out), (variant, sf, ppm, rdd, explicit, crcc, len(s_))
                                 total += 1
     assert total == 2 * 5 * 5 * 2 * 2 * 17
+
+
+def test_decoder_refuses_configurations_the_reference_cannot_decode(gpu):
+    """an explicit header needs at least 5 bits per symbol (the reference whitens `PPM - 5` codewords as an unsigned short, i.e.
+    ~65535, past its buffer: LoRaDecoder.cpp:235); spreading factors beyond 12 do not exist on this path. The library refuses
+    both instead of corrupting device memory."""
+    import lora_sdr_amd as L
+    dec = L.LoRaDecoder()
+    pk = [np.arange(16, dtype=np.uint16)]
+    dec.setSpreadFactor(7); dec.setSymbolSize(4); dec.enableExplicit(True)
+    with pytest.raises(L.LoraHipError):
+        dec.work(pk)
+    dec.enableExplicit(False)
+    assert len(dec.work(pk)) == 1                                  # implicit header: fine
+    dec.setSymbolSize(0); dec.setSpreadFactor(13)
+    with pytest.raises(L.LoraHipError):
+        dec.work(pk)

@@ -390,3 +390,19 @@ def test_batches_beyond_2_pow_31_samples(gpu, oracle, sf):
         assert np.abs(o["power"] - r["power"][lo:lo + 16].cpu().numpy()).max() <= TOL_DB
     del iq, r
     torch.cuda.empty_cache()
+
+
+def test_argument_validation_at_the_boundary(gpu):
+    """host-pointer batches with a fine-tune index outside the 128*N-entry table are refused (the reference would read past its
+    table); the Python mirror refuses a frame stride shorter than the frame"""
+    import lora_sdr_amd as L
+    ctx = L.Context(7)
+    iq = np.zeros(4 * 128, np.complex64)
+    for bad in (-1, 128 * 128):
+        with pytest.raises(L.LoraHipError):
+            ctx.detect_batch(iq, fine_idx0=np.array([0, bad, 0, 0], np.int32), fine_err=np.zeros(4, np.float32))
+    ok = ctx.detect_batch(iq, fine_idx0=np.array([0, 128 * 128 - 1, 5, 0], np.int32), fine_err=np.full(4, 0.3, np.float32))
+    assert ok["sym"].shape == (4,)
+    syms = gpu.zeros((2, 5), dtype=gpu.int16, device="cuda")
+    with pytest.raises(ValueError):
+        ctx.mod_frames(syms, frame_stride=ctx.mod_frame_len(5) - 1)
