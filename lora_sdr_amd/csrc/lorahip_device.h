@@ -235,6 +235,35 @@ __device__ __forceinline__ unsigned groupReduceU(unsigned v)
 #undef LORAHIP_RED_STEP
     return v;
 }
+//! sum of a double over the aligned group of T lanes, result in every lane -- the same pairing tree (strides 1, 2, 4, ...) on all
+//! lanes, and every step adds the two partners' partial sums, which is commutative: all lanes end with the same bits. DPP row
+//! permutations / permlane swaps of the two halves, no LDS crossbar (the `__shfl_xor` of a double is two ds_bpermute per step).
+template <int T>
+__device__ __forceinline__ double groupSumF64(double v)
+{
+#define LORAHIP_SUM_DPP(CTRL) { const unsigned lo_ = __builtin_amdgcn_mov_dpp((unsigned)__double2loint(v), CTRL, 0xf, 0xf, false), \
+                                               hi_ = __builtin_amdgcn_mov_dpp((unsigned)__double2hiint(v), CTRL, 0xf, 0xf, false); \
+                                v += __hiloint2double((int)hi_, (int)lo_); }
+    if (T >= 2) LORAHIP_SUM_DPP(0xB1)       // quad_perm [1,0,3,2]
+    if (T >= 4) LORAHIP_SUM_DPP(0x4E)       // quad_perm [2,3,0,1]
+    if (T >= 8) LORAHIP_SUM_DPP(0x141)      // row_half_mirror: the other quad of the 8 holds one value in all its lanes
+    if (T >= 16) LORAHIP_SUM_DPP(0x140)     // row_mirror
+#undef LORAHIP_SUM_DPP
+    if (T >= 32)
+    {
+        const v2u l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+        const v2u h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+        v = __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+    }
+    if (T >= 64)
+    {
+        const v2u l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+        const v2u h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+        v = __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+    }
+    return v;
+}
+
 template <int T>
 __device__ __forceinline__ void groupArgmax(float &bestV, int &bestI)
 {

@@ -346,10 +346,9 @@ struct FastCore
         bestI = (t + T * (bestJ & (NGL - 1))) + ((bestJ / NGL) << BL);
         if (!(bestV > 0.0f)) bestI = 0;
         groupArgmax<T>(bestV, bestI);
-#pragma unroll
-        for (int off = T / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-        // every lane of the window now holds the window's (bestV, bestI); the xor tree adds the same
-        // fp64 partials in the same pairing on all lanes, so tot is identical on all of them too
+        tot = groupSumF64<T>(tot);
+        // every lane of the window now holds the window's (bestV, bestI); the tree adds the same fp64 partials in the
+        // same pairing on all lanes, so tot is identical on all of them too
     }
 
     //! bins k-1 and k+1 of the window's peak k (LoRaDetector.hpp:56-57), valid in every lane of the window

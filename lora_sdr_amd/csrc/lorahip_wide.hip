@@ -446,8 +446,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         int bestI = t + (bestE << LOG2T);
         if (!(bestV > 0.0f)) bestI = 0;
         groupArgmax<64>(bestV, bestI);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+        tot = groupSumF64<64>(tot);
         if (lane == 0) { sRed[wave].v = bestV; sRed[wave].i = bestI; sRed[wave].tot = tot; }
         __syncthreads();                                                                      // B4
         // every lane combines the window's wavefronts in the same order: identical results on all of them
@@ -788,8 +787,7 @@ demodStreamWide(const StreamArgs s)
         int bestI = t + (bestE << LOG2T);
         if (!(bestV > 0.0f)) bestI = 0;
         groupArgmax<64>(bestV, bestI);
-#pragma unroll
-        for (int off2 = 32; off2 > 0; off2 >>= 1) tot += __shfl_xor(tot, off2, 64);
+        tot = groupSumF64<64>(tot);
         if (lane == 0) { sRed[wave].v = bestV; sRed[wave].i = bestI; sRed[wave].tot = tot; }
         __syncthreads();                                                                      // B4
         {
