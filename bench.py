@@ -403,32 +403,32 @@ def section_mixed(env, L, a, S=16, n_channels=16384, rccl_single=False):
     torch = env.torch
     sfs = WL.mixed_sf_channels(n_channels)
     mine = L.shard_channels(sfs, env.world)[env.rank]
-    buckets, order, total_bytes = [], [], 0
+    total_bytes = sum(int((sfs == sf).sum()) * S * L.bytes_per_symbol(sf) for sf in range(7, 13))
     sent_all = WL.mixed_sent(sfs, S, env.dev)                        # the same "sent" symbols on every rank: the global truth
-    for sf in range(7, 13):
-        total_bytes += int((sfs == sf).sum()) * S * L.bytes_per_symbol(sf)
-        ch = mine[sfs[mine] == sf]
-        if ch.size == 0:
-            continue
-        sym = sent_all[torch.from_numpy(ch).to(env.dev)].to(torch.int16).reshape(-1).contiguous()
+    # this rank's channels behind the C-level scheduler (lorahip_mixed_*): buckets by SF, a stream per bucket, event join
+    mixed = L.MixedDetector(sfs[mine], device=env.local)
+    mixed.set_variant(a.variant)
+    parts, offsets, at = [], np.zeros(mine.size, np.int64), 0
+    for sf, first_row, n_ch in mixed.buckets:
+        local = np.nonzero(sfs[mine] == sf)[0]                       # ascending: the order of the bucket's rows
+        sym = sent_all[torch.from_numpy(mine[local]).to(env.dev)].to(torch.int16).reshape(-1).contiguous()
         gen = L.Context(sf, device=env.local)
         gen.use_torch_stream()
-        iq = gen.synth_symbols(sym, ampl=1.0, noise_sigma=a.noise_sigma, seed=0x5EED1000 + sf)
+        parts.append(gen.synth_symbols(sym, ampl=1.0, noise_sigma=a.noise_sigma, seed=0x5EED1000 + sf).reshape(-1))
         torch.cuda.synchronize()
         gen.close()
-        ctx = L.Context(sf, device=env.local)                        # launches on its private non-blocking stream: the buckets overlap
-        ctx.set_variant(a.variant)
-        W = int(ch.size) * S
-        out = dict(sym=torch.empty(W, dtype=torch.int16, device=env.dev), power=torch.empty(W, dtype=torch.float32, device=env.dev),
-                   powerAvg=torch.empty(W, dtype=torch.float32, device=env.dev), fIndex=torch.empty(W, dtype=torch.float32, device=env.dev))
-        b = ctx.make_batch(iq, W, out["sym"], out["power"], out["powerAvg"], out["fIndex"], chirp_sel_all=L.CHIRP_UP)
-        buckets.append((sf, ctx, b, iq, out, sym, ch))
-        order.append(ch)
+        offsets[local] = at + np.arange(n_ch, dtype=np.int64) * (S << sf)
+        at += n_ch * (S << sf)
+    iq = torch.cat(parts) if parts else torch.zeros(2, dtype=torch.float32, device=env.dev)
+    del parts
+    mixed.plan(offsets, S)
+    out = mixed.new_outputs()
+    local_ch = np.empty(mine.size, np.int64)
+    local_ch[mixed.rows] = mine                                      # row -> global channel
     torch.cuda.synchronize()
 
     def step():
-        for _sf, ctx, b, *_ in buckets:
-            ctx.detect_batch_raw(b)
+        mixed.detect(iq, out, sync=False)
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.2:
         step()
@@ -446,8 +446,8 @@ def section_mixed(env, L, a, S=16, n_channels=16384, rccl_single=False):
            "frac_byte_weighted": r4(total_bytes * a.steps / elapsed / 1e9 / (HBM_PEAK_GBS * env.world)),
            "iq_bytes_per_step": int(sum(int((sfs == sf).sum()) * S * (8 << sf) for sf in range(7, 13)))}
     # ---- end of run: the 2 B/symbol results to every rank (north_star: RCCL only as an embarrassingly parallel split) ----
-    local_sym = torch.cat([o["sym"].reshape(-1, S) for (_sf, _c, _b, _iq, o, _s, _ch) in buckets]) if buckets else torch.zeros((0, S), dtype=torch.int16, device=env.dev)
-    local_ch = np.concatenate(order) if order else np.zeros(0, np.int64)
+    mixed.synchronize()
+    local_sym = out["sym"]
     dist, made = env.dist, False
     try:
         if dist is None and not rccl_single:
@@ -482,8 +482,8 @@ def section_mixed(env, L, a, S=16, n_channels=16384, rccl_single=False):
     finally:
         if made:
             dist.destroy_process_group()
-    for _sf, ctx, *_ in buckets:
-        ctx.close()
+    res["scheduler"] = "lorahip_mixed_* (C ABI): %d SF buckets, one stream each" % len(mixed.buckets)
+    mixed.close()
     return res
 
 

@@ -143,6 +143,30 @@ int lorahip_detect_batch(lorahip_ctx *ctx, const lorahip_batch *b);       /* asy
  * samples (that many are copied); offsets must be >= 0, fine_idx0 in [0, 128*N): LORAHIP_E_INVALID otherwise. */
 int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b);
 
+/* -------------------------------------------------------------------------------------
+ * Mixed spreading factors in one call (BASELINE configs[3]: 16384 channels, SF = 7 + c mod 6). The reference runs one
+ * LoRaDemod block per channel, each with its own SF (LoRaDemod.cpp:119); a launch here is uniform in N, so the scheduler buckets
+ * the channels by SF, gives every bucket a level-2 context with its own HIP stream, issues the buckets' launches back to back
+ * (they overlap on the device) and joins them on events. Results are bucket-major: the channels of the lowest SF first, each
+ * bucket in ascending channel order; lorahip_mixed_rows() gives the row of every channel in the [rows][windows_per_channel]
+ * arrays.
+ *   create : SF of every channel (6..12)
+ *   plan   : channel c's windows_per_channel back-to-back windows start at sample channel_offset[c] of the IQ buffer
+ *   detect : asynchronous, device pointers, arrays of rows * windows_per_channel entries; the steady-state (up-chirp) shape
+ *   synchronize : returns when every bucket's launch of the last detect has finished
+ * ------------------------------------------------------------------------------------- */
+typedef struct lorahip_mixed lorahip_mixed;
+int lorahip_mixed_create(lorahip_mixed **m, int device, const int32_t *channel_sf, size_t n_channels);
+void lorahip_mixed_destroy(lorahip_mixed *m);
+size_t lorahip_mixed_num_buckets(const lorahip_mixed *m);
+int lorahip_mixed_bucket(const lorahip_mixed *m, size_t i, int32_t *sf, size_t *first_row, size_t *n_channels);
+/* bucket i's level-2 context, borrowed (owned by the scheduler): for lorahip_set_variant / timers / lorahip_timer_* on it */
+lorahip_ctx *lorahip_mixed_context(const lorahip_mixed *m, size_t i);
+int lorahip_mixed_rows(const lorahip_mixed *m, int64_t *row_of_channel);
+int lorahip_mixed_plan(lorahip_mixed *m, const int64_t *channel_offset, size_t windows_per_channel);
+int lorahip_mixed_detect(lorahip_mixed *m, const float *iq_dev, uint16_t *sym_dev, float *power_dev, float *power_avg_dev, float *f_index_dev);
+int lorahip_mixed_synchronize(lorahip_mixed *m);
+
 /* Time the last `n` launches made through this context between two internal HIP events
  * recorded on the launch stream (bench.py uses this for the roofline line). */
 int lorahip_timer_start(lorahip_ctx *ctx);

@@ -77,6 +77,15 @@ SIGNATURES = {
     "lorahip_demod_set_fine_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_detect_batch": (C.c_int, [C.c_void_p, C.POINTER(Batch)]),
     "lorahip_detect_batch_host": (C.c_int, [C.c_void_p, C.POINTER(Batch)]),
+    "lorahip_mixed_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]),
+    "lorahip_mixed_destroy": (None, [C.c_void_p]),
+    "lorahip_mixed_num_buckets": (C.c_size_t, [C.c_void_p]),
+    "lorahip_mixed_bucket": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lorahip_mixed_context": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "lorahip_mixed_rows": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lorahip_mixed_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lorahip_mixed_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lorahip_mixed_synchronize": (C.c_int, [C.c_void_p]),
     "lorahip_timer_start": (C.c_int, [C.c_void_p]),
     "lorahip_timer_stop": (C.c_int, [C.c_void_p, _f32p]),
     "lorahip_detector_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_size_t]),

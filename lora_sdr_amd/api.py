@@ -264,6 +264,64 @@ class Context:
         return iq
 
 
+class MixedDetector:
+    """Channels of different spreading factors demodulated in one call (lorahip_mixed_*: buckets by SF, one stream per bucket,
+    concurrent launches, event join -- all below Python). channel_sf: SF of every channel; plan(offsets, S): channel c's S
+    back-to-back windows start at sample offsets[c] of the IQ buffer. detect(iq) -> dict of (rows, S) device tensors in
+    bucket-major order; rows[c] is channel c's row."""
+
+    def __init__(self, channel_sf, device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        sf = np.ascontiguousarray(channel_sf, np.int32).reshape(-1)
+        check(self._lib.lorahip_mixed_create(C.byref(self._h), int(device), sf.ctypes.data, sf.size), "lorahip_mixed_create")
+        self.n_channels, self.device, self.S = int(sf.size), int(device), 0
+        self.rows = np.empty(sf.size, np.int64)
+        check(self._lib.lorahip_mixed_rows(self._h, self.rows.ctypes.data), "lorahip_mixed_rows")
+        self.buckets = []
+        for i in range(self._lib.lorahip_mixed_num_buckets(self._h)):
+            s_, r_, n_ = C.c_int32(), C.c_size_t(), C.c_size_t()
+            check(self._lib.lorahip_mixed_bucket(self._h, i, C.byref(s_), C.byref(r_), C.byref(n_)), "lorahip_mixed_bucket")
+            self.buckets.append((s_.value, r_.value, n_.value))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.lorahip_mixed_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_variant(self, variant):
+        for i in range(len(self.buckets)):
+            check(self._lib.lorahip_set_variant(C.c_void_p(self._lib.lorahip_mixed_context(self._h, i)), int(variant)), "lorahip_set_variant")
+
+    def plan(self, channel_offset, windows_per_channel):
+        off = np.ascontiguousarray(channel_offset, np.int64).reshape(-1)
+        if off.size != self.n_channels:
+            raise ValueError("one offset per channel")
+        check(self._lib.lorahip_mixed_plan(self._h, off.ctypes.data, int(windows_per_channel)), "lorahip_mixed_plan")
+        self.S = int(windows_per_channel)
+
+    def new_outputs(self):
+        import torch
+        dev = torch.device("cuda", self.device)
+        shape = (self.n_channels, self.S)
+        return dict(sym=torch.empty(shape, dtype=torch.int16, device=dev), power=torch.empty(shape, dtype=torch.float32, device=dev),
+                    powerAvg=torch.empty(shape, dtype=torch.float32, device=dev), fIndex=torch.empty(shape, dtype=torch.float32, device=dev))
+
+    def detect(self, iq, out=None, sync=True):
+        """asynchronous unless sync: the buckets run on their own streams; the caller's stream must have finished producing iq"""
+        out = out or self.new_outputs()
+        check(self._lib.lorahip_mixed_detect(self._h, _dptr(iq), _dptr(out["sym"]), _dptr(out["power"]), _dptr(out["powerAvg"]), _dptr(out["fIndex"])),
+              "lorahip_mixed_detect")
+        if sync:
+            self.synchronize()
+        return out
+
+    def synchronize(self):
+        check(self._lib.lorahip_mixed_synchronize(self._h), "lorahip_mixed_synchronize")
+
+
 def design_lowpass(decim, n_taps, cutoff=None):
     """Windowed-sinc (Blackman-Harris) low-pass prototype for the channeliser, unit DC gain; cutoff in cycles per input
     sample (default 0.5/decim = half the channel rate)."""
