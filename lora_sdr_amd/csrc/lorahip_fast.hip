@@ -82,7 +82,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     typename K::TwM twM;
     K::loadTwM(twM, reinterpret_cast<const v2f *>(ft.twStage), t);
     FineLds fl;
-    fl.A = nullptr; fl.B = nullptr;
+    fl.A = nullptr; fl.B = nullptr; fl.split = false;
     if (!UNI) fl = fineLoadLds<C::LOG2N>(sFine, a.fineA, a.fineB, threadIdx.x, blockDim.x);
 
     // chirp table values of this lane's sample positions. One table serves both selections:
@@ -204,7 +204,8 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         {
             const float sgn = (perWindowSel && sel == LORAHIP_CHIRP_UP) ? -1.0f : 1.0f;
             const v2f *cwf = &cw[0][0];
-            const auto chirpOf = [&](const int i) { return MAKE2(cwf[i].x, sgn * cwf[i].y); };
+            const v2f sgn2 = MAKE2(1.0f, sgn);                       // one packed multiply: (re, +-im), both exact
+            const auto chirpOf = [&](const int i) { return cwf[i] * sgn2; };
             if (anyMoving)
             {
                 // yv = idx0 in the windows that do not move

@@ -193,7 +193,8 @@ __device__ __forceinline__ int fineChainGroup(const int idx0, const float d, con
 /***********************************************************************
  * The fine-tune multiplier without the table gather (lorahip_fine.h): split tables in LDS, closed-form indices.
  **********************************************************************/
-struct FineLds { const double2 *A, *B; };              // LDS copies of the split tables; A == nullptr: gather from the table in HBM
+//! LDS copies of the split tables (addresses fixed at compile time); split == false: gather from the table in HBM instead
+struct FineLds { const double2 *A, *B; bool split; };
 
 //! entries of the two split tables for N = 2^LOG2N
 template <int LOG2N> struct FineDims
@@ -209,11 +210,10 @@ __device__ __forceinline__ FineLds fineLoadLds(double2 *dst, const double2 *gA, 
 {
     typedef FineDims<LOG2N> D;
     FineLds f;
-    f.A = nullptr; f.B = nullptr;
-    if (gA == nullptr) return f;
+    f.A = dst; f.B = dst + D::NA; f.split = gA != nullptr;
+    if (!f.split) return f;
     for (int i = tid; i < D::NA; i += nThreads) dst[i] = gA[i];
     for (int i = tid; i < D::NB; i += nThreads) dst[D::NA + i] = gB[i];
-    f.A = dst; f.B = dst + D::NA;
     return f;
 }
 
@@ -232,38 +232,97 @@ __device__ __forceinline__ v2f fineEval(const unsigned y, const FineLds &s)
 //! products and the two complex multiplies per sample -- straight-line code, so the reads of one group overlap the arithmetic
 //! of the previous one and at most four table entries are live. `chirp(i)` yields the chirp-table entry of sample i with the
 //! window's conjugation applied; lanes with keep == false leave x untouched (windows fed already dechirped).
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+//! LDS byte address of a pointer into shared memory
+__device__ __forceinline__ unsigned ldsByteAddress(const void *p)
+{
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+//! (i << 4) + base in one instruction (the compiler's own form of a 16-byte table index costs three)
+__device__ __forceinline__ unsigned entryAddress16(const unsigned i, const unsigned base)
+{
+    unsigned r;
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(r) : "v"(i), "s"(base));
+    return r;
+}
+
+//! the two split-table reads of one sample, issued without a wait (the caller waits with finePairWait)
+template <int LH>
+__device__ __forceinline__ void fineIssue(d2v &a, d2v &b, const unsigned y, const unsigned baseA, const unsigned baseB)
+{
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a) : "v"(entryAddress16(y >> LH, baseA)));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(b) : "v"(entryAddress16(y & ((1u << LH) - 1u), baseB)));
+}
+
+//! wait until at most LATER of this wave's LDS reads are outstanding: LDS returns in order, so the four values named here (a
+//! pair's) have arrived; naming them makes every use wait for this instruction
+template <int LATER>
+__device__ __forceinline__ void finePairWait(d2v &a0, d2v &b0, d2v &a1, d2v &b1)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1) : "n"(LATER));
+}
+
+template <bool SELECT, class CHIRP>
+__device__ __forceinline__ void fineApply(v2f &x, CHIRP chirp, const int i, const d2v a, const d2v b, const bool keep)
+{
+    const double re = __builtin_fma(a.x, b.x, -(a.y * b.y));
+    const double im = __builtin_fma(a.x, b.y, a.y * b.x);
+    const v2f v = cmulv(cmulv(x, chirp(i)), v2f{(float)re, (float)im});
+    x = (!SELECT || keep) ? v : x;
+}
+
+//! the split-table path of dechirpFine as a software pipeline over pairs of samples: the four LDS reads of the next pair are in
+//! flight while this pair's two fp64 products and four complex multiplies issue. The reads and the waits are written out
+//! (inline asm) because the compiler otherwise sinks every read to its use and waits for it at once.
+template <int LH, int CNT, bool SELECT, class CHIRP>
+__device__ __forceinline__ void dechirpFineSplit(v2f *x, CHIRP chirp, const unsigned *y, const FineLds &s, const bool keep)
+{
+    const unsigned baseA = __builtin_amdgcn_readfirstlane(ldsByteAddress(s.A)), baseB = __builtin_amdgcn_readfirstlane(ldsByteAddress(s.B));
+    d2v a[2][2], b[2][2];
+    fineIssue<LH>(a[0][0], b[0][0], y[0], baseA, baseB);
+    fineIssue<LH>(a[0][1], b[0][1], y[1], baseA, baseB);
+#pragma unroll
+    for (int i = 0; i < CNT; i += 2)
+    {
+        const int cur = (i >> 1) & 1;
+        if (i + 2 < CNT)
+        {
+            fineIssue<LH>(a[cur ^ 1][0], b[cur ^ 1][0], y[i + 2], baseA, baseB);
+            fineIssue<LH>(a[cur ^ 1][1], b[cur ^ 1][1], y[i + 3], baseA, baseB);
+            finePairWait<4>(a[cur][0], b[cur][0], a[cur][1], b[cur][1]);
+        }
+        else finePairWait<0>(a[cur][0], b[cur][0], a[cur][1], b[cur][1]);
+        fineApply<SELECT>(x[i], chirp, i, a[cur][0], b[cur][0], keep);
+        fineApply<SELECT>(x[i + 1], chirp, i + 1, a[cur][1], b[cur][1], keep);
+    }
+}
+
 template <int LH, int CNT, class CHIRP>
 __device__ __forceinline__ void dechirpFine(v2f *x, CHIRP chirp, const unsigned *y, const FineLds &s, const v2f *__restrict__ gFine, const bool keep)
 {
     static_assert(CNT % 4 == 0, "four values per round");
-    const bool split = s.A != nullptr;                          // uniform over the launch
-#pragma unroll
-    for (int i = 0; i < CNT; i += 4)
+    if (s.split)                                                // uniform over the launch
     {
-        v2f f[4];
-        if (split)
-        {
-            double2 a[4], b[4];
+        // no window of this wave fed already dechirped (the rule): no per-sample select
+        if (__all(keep)) dechirpFineSplit<LH, CNT, false>(x, chirp, y, s, keep);
+        else dechirpFineSplit<LH, CNT, true>(x, chirp, y, s, keep);
+    }
+    else
+    {
 #pragma unroll
-            for (int j = 0; j < 4; j++) { a[j] = s.A[y[i + j] >> LH]; b[j] = s.B[y[i + j] & ((1u << LH) - 1u)]; }
+        for (int i = 0; i < CNT; i += 4)
+        {
+            v2f f[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) f[j] = gFine[y[i + j]];
 #pragma unroll
             for (int j = 0; j < 4; j++)
             {
-                const double re = __builtin_fma(a[j].x, b[j].x, -(a[j].y * b[j].y));
-                const double im = __builtin_fma(a[j].x, b[j].y, a[j].y * b[j].x);
-                f[j] = v2f{(float)re, (float)im};
+                const v2f v = cmulv(cmulv(x[i + j], chirp(i + j)), f[j]);
+                x[i + j] = keep ? v : x[i + j];
             }
-        }
-        else
-        {
-#pragma unroll
-            for (int j = 0; j < 4; j++) f[j] = gFine[y[i + j]];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-        {
-            const v2f v = cmulv(cmulv(x[i + j], chirp(i + j)), f[j]);
-            x[i + j] = keep ? v : x[i + j];
         }
     }
 }

@@ -100,7 +100,8 @@ demodStream(const StreamArgs s)
         K::chirpFromLds(cw, sCh, t);
         const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
         const v2f *cwf = &cw[0][0];
-        const auto chirpOf = [&](const int i) { return MAKE2(cwf[i].x, sgn * cwf[i].y); };
+        const v2f sgn2 = MAKE2(1.0f, sgn);                       // one packed multiply: (re, +-im), both exact
+            const auto chirpOf = [&](const int i) { return cwf[i] * sgn2; };
         // yv = idx0 in the channels where nothing moves
         if (anyMoving) dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, true);
         else

@@ -178,7 +178,7 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
     }
 
     FineLds fl;
-    fl.A = nullptr; fl.B = nullptr;
+    fl.A = nullptr; fl.B = nullptr; fl.split = false;
     if (!UNI) fl = fineLoadLds<LOG2N>(sFine, a.fineA, a.fineB, tid, C::BLOCK);
 
     // chirp table values of this lane's sample positions: _upChirpTable = conj(_downChirpTable) (LoRaDemod.cpp:103-104)
@@ -339,7 +339,8 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         {
             const float sgn = (perWindowSel && sel == LORAHIP_CHIRP_UP) ? -1.0f : 1.0f;
             const v2f *cwf = &cw[0][0];
-            const auto chirpOf = [&](const int i) { return MAKE2(cwf[i].x, sgn * cwf[i].y); };
+            const v2f sgn2 = MAKE2(1.0f, sgn);                       // one packed multiply: (re, +-im), both exact
+            const auto chirpOf = [&](const int i) { return cwf[i] * sgn2; };
             if (anyMoving)
             {
                 // yv = idx0 in the windows that do not move
@@ -728,7 +729,8 @@ demodStreamWide(const StreamArgs s)
         }
         const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
         const v2f *chf = &ch[0][0];
-        const auto chirpOf = [&](const int i) { return MAKE2(chf[i].x, sgn * chf[i].y); };
+        const v2f sgn2 = MAKE2(1.0f, sgn);                       // one packed multiply: (re, +-im), both exact
+            const auto chirpOf = [&](const int i) { return chf[i] * sgn2; };
         if (moving) dechirpFine<fineSplitLog2H(LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, true);
         else
         {
