@@ -362,6 +362,22 @@ __device__ __forceinline__ void tailValuesPaired(const float powerScale, const f
     if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
 }
 
+//! fIndex alone, for the same replicated lanes: the fIndex operations of tailValuesPaired (hence its bits) without the two
+//! logarithms -- what FRAMESYNC consumes of an unsquelched window when no trace is kept (LoRaDemod.cpp:217-221)
+template <class CPX>
+__device__ __forceinline__ float fIndexPaired(const float maxValue, const CPX leftBin, const CPX rightBin, const int lane)
+{
+    const bool odd = lane & 1;
+    const float fundamental = sqrtf(maxValue);
+    const float hyMine = (float)hypotd(odd ? rightBin.x : leftBin.x, odd ? rightBin.y : leftBin.y);
+    const float hyOther = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(hyMine), 0xB1, 0xf, 0xf, false));
+    const float left = odd ? hyOther : hyMine, right = odd ? hyMine : hyOther;
+    const double demon = (2.0 * (double)fundamental) - (double)right - (double)left;
+    float fIndex = 0.0f;
+    if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
+    return fIndex;
+}
+
 /*! The squelch decision alone (LoRaDemod.cpp:173-174: `snr = power - powerAvg; squelched = snr < thresh`) without the tail: in
  * DATASYMBOLS nothing else of detect()'s float outputs is consumed (:286-306; fIndex only feeds the label), so the streaming
  * kernels skip the two logarithms, the two hypotenuses and the neighbour fetch there. snr is estimated as

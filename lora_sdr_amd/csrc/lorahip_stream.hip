@@ -61,10 +61,14 @@ demodStream(const StreamArgs s)
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
     // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
-    // `full` (wave-uniform) = the float outputs are wanted. In DATASYMBOLS only the squelch decision is (LoRaDemod.cpp:286-306):
-    // a wave whose channels are all there -- and no trace is kept -- skips the staging of the bins for the neighbour fetch and
-    // the tail, and decides the squelch from a quick estimate (squelchQuick), falling back to the exact chain near the threshold.
-    auto detect = [&](const bool on, const bool full, const long long off, const bool downTable, const int idx0, const float err,
+    // What of detect()'s float outputs a work() call consumes depends on the state (LoRaDemod.cpp:176-312): DATASYMBOLS the squelch
+    // decision alone; FRAMESYNC the squelch decision and, for an unsquelched window, fIndex; the down-chirp and quarter-chirp
+    // states only the peak's index. power / powerAvg / snr themselves only reach the labels and signals, i.e. the per-call trace.
+    // So unless a trace is kept (`all`), the squelch comes from a quick estimate with the exact chain as the fallback near the
+    // threshold (squelchQuick), the two logarithms are never evaluated otherwise, and the neighbours + fIndex only for lanes
+    // with wantFi whose window is not squelched. wantSq / wantFi are per lane group; the branches are wave-uniform.
+    const bool all = s.calls != nullptr;
+    auto detect = [&](const bool on, const bool wantSq, const bool wantFi, const long long off, const bool downTable, const int idx0, const float err,
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
@@ -123,7 +127,8 @@ demodStream(const StreamArgs s)
         double tot;
         v2f l, r;
         value = 0;
-        if (full)
+        const bool staged = all || __any(on && wantFi);                               // bins to LDS for the neighbour fetch
+        if (all)
         {
             K::scan(vl, F, nullptr, t, bestV, bestI, tot);
             K::neighbours(vl, F, bestI, lane, t, l, r);
@@ -134,15 +139,29 @@ demodStream(const StreamArgs s)
         }
         else
         {
-            K::template scan<false>(vl, F, nullptr, t, bestV, bestI, tot);
+            if (staged) K::scan(vl, F, nullptr, t, bestV, bestI, tot);
+            else K::template scan<false>(vl, F, nullptr, t, bestV, bestI, tot);
             bool sure;
             squelched = squelchQuick(bestV, tot, s.thresh, sure);
-            power = powerAvg = fIndex = 0.0f;                                           // not consumed in DATASYMBOLS
-            if (__any(on && !sure))
+            power = powerAvg = fIndex = 0.0f;                                           // not consumed without a trace
+            const bool exact = on && wantSq && !sure;
+            const bool fi = on && wantFi && (!sure || !squelched);
+            if (__any(exact || fi))
             {
-                K::template neighbours<true>(vl, F, bestI, lane, t, l, r);
-                tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
-                squelched = (power - powerAvg) < s.thresh;
+                if (staged) K::neighbours(vl, F, bestI, lane, t, l, r);
+                else K::template neighbours<true>(vl, F, bestI, lane, t, l, r);
+                if (staged)
+                {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (__any(exact))
+                {
+                    tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
+                    squelched = (power - powerAvg) < s.thresh;                           // the quick decision where it was sure, by construction
+                    power = powerAvg = 0.0f;
+                }
+                else fIndex = fIndexPaired(bestV, l, r, lane);
             }
         }
         value = bestI;
@@ -159,9 +178,8 @@ demodStream(const StreamArgs s)
         const int fineIdxBefore = st.fineTuneIndex;
         const float fineErrBefore = st.finefreqError;
         const long long here = base + st.pos;
-        const bool full = s.calls != nullptr || __any(live && st.state != ST_DATASYMBOLS);
         bool squelched;
-        detect(live, full, here, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
+        detect(live, st.state == ST_FRAMESYNC || st.state == ST_DATASYMBOLS, st.state == ST_FRAMESYNC, here, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
         const float snr = power - powerAvg;                                             // :173 (squelched = snr < thresh, :174, comes from detect)
         if (live) st.fineTuneIndex = idxEnd;                                            // the loop commits the member (:160-162)
 
@@ -176,7 +194,7 @@ demodStream(const StreamArgs s)
             float p1, pa1, fi1;
             // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
             bool sq1;
-            detect(need1, true, here + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, p1, pa1, fi1, idxEnd1, sq1);
+            detect(need1, true, true, here + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, p1, pa1, fi1, idxEnd1, sq1);
             if (need1)
             {
                 match1 = (value1 + 4) / 8 == (s.sync & 0xf);                           // :205

@@ -686,10 +686,12 @@ demodStreamWide(const StreamArgs s)
     o.init(s, c);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect; every argument is workgroup-uniform
-    // `full` (workgroup-uniform) = the float outputs are wanted; in DATASYMBOLS without a trace only the squelch decision is
-    // (LoRaDemod.cpp:286-306): then the neighbour fetch, its barrier and the tail are skipped and the decision comes from a quick
-    // estimate (squelchQuick), with the exact chain as the fallback near the threshold
-    auto detect = [&](const bool full, const long long off, const bool downTable, const int idx0, const float err,
+    // What a work() call consumes of the float outputs depends on its state (see demodStream, lorahip_stream.hip): without a
+    // trace the squelch decision comes from a quick estimate (squelchQuick) with the exact chain as the fallback near the
+    // threshold, fIndex is evaluated only for an unsquelched FRAMESYNC window, and the neighbour fetch with its barrier is skipped
+    // whenever neither is needed
+    const bool all = s.calls != nullptr;
+    auto detect = [&](const bool wantSq, const bool wantFi, const long long off, const bool downTable, const int idx0, const float err,
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
@@ -804,15 +806,17 @@ demodStreamWide(const StreamArgs s)
             }
         }
         value = bestI;
-        bool needTail = full;
-        if (!full)
+        // workgroup-uniform from here on: bestV, tot (hence the quick estimate and `sure`) are identical in every thread
+        bool needLogs = all, needFi = all;
+        if (!all)
         {
-            bool sure;                                          // bestV, tot are identical in every thread: so is `sure`
+            bool sure;
             squelched = squelchQuick(bestV, tot, s.thresh, sure);
-            power = powerAvg = fIndex = 0.0f;                   // not consumed in DATASYMBOLS
-            needTail = !sure;
+            power = powerAvg = fIndex = 0.0f;                   // not consumed without a trace
+            needLogs = wantSq && !sure;
+            needFi = wantFi && (!sure || !squelched);
         }
-        if (needTail)
+        if (needLogs || needFi)
         {
             // neighbours of the peak (LoRaDetector.hpp:56-57)
             const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
@@ -824,8 +828,13 @@ demodStreamWide(const StreamArgs s)
                 if (ownR) sNb[1] = mine;
             }
             __syncthreads();                                                                  // B5
-            tailValuesPaired(s.powerScale, bestV, tot, sNb[0], sNb[1], lane, power, powerAvg, fIndex);
-            squelched = (power - powerAvg) < s.thresh;                                       // :173-174
+            if (needLogs)
+            {
+                tailValuesPaired(s.powerScale, bestV, tot, sNb[0], sNb[1], lane, power, powerAvg, fIndex);
+                squelched = (power - powerAvg) < s.thresh;                                   // :173-174
+                if (!all) power = powerAvg = 0.0f;
+            }
+            else fIndex = fIndexPaired(bestV, sNb[0], sNb[1], lane);
         }
     };
 
@@ -836,7 +845,7 @@ demodStreamWide(const StreamArgs s)
         const int fineIdxBefore = st.fineTuneIndex;
         const float fineErrBefore = st.finefreqError;
         bool squelched;
-        detect(s.calls != nullptr || st.state != ST_DATASYMBOLS, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power,
+        detect(st.state == ST_FRAMESYNC || st.state == ST_DATASYMBOLS, st.state == ST_FRAMESYNC, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power,
                powerAvg, fIndex, idxEnd, squelched);
         const float snr = power - powerAvg;                                             // :173 (squelched = snr < thresh, :174, comes from detect)
         st.fineTuneIndex = idxEnd;                                                      // :160-162
@@ -848,7 +857,7 @@ demodStreamWide(const StreamArgs s)
             int value1, idxEnd1;
             // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
             bool sq1;
-            detect(true, base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, power, powerAvg, fIndex, idxEnd1, sq1);
+            detect(true, true, base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, power, powerAvg, fIndex, idxEnd1, sq1);
             match1 = (value1 + 4) / 8 == (s.sync & 0xf);                               // :205; snr is not recomputed
         }
         frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);

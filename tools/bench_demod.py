@@ -11,6 +11,7 @@ ap.add_argument("--sf", type=int, default=7); ap.add_argument("--channels", type
 ap.add_argument("--frames", type=int, default=4); ap.add_argument("--nsyms", type=int, default=48)
 ap.add_argument("--sigma", type=float, default=0.05); ap.add_argument("--modes", default="1,2")
 ap.add_argument("--fine-gather", action="store_true", help="A/B: read the fine-tune table in HBM (round-1 path)")
+ap.add_argument("--reps", type=int, default=4, help="work() passes over the same streams (the first one is the cold one)")
 a = ap.parse_args()
 sf, N, B = a.sf, 1 << a.sf, a.channels
 ctx = L.Context(sf)
@@ -23,7 +24,7 @@ for mode in [int(m) for m in a.modes.split(",")]:
     if a.fine_gather:
         d.set_fine_gather(True)
     times, kms = [], []
-    for rep in range(4):
+    for rep in range(max(2, a.reps)):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         rounds = d.work(iq)
         times.append(time.perf_counter() - t0); kms.append(d.kernel_ms())
