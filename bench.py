@@ -327,25 +327,41 @@ def section_level3(env, L, sf):
     d = L.LoRaDemod(sf, n_channels=B, device=env.local)
     d.set_mode(1)
     d.setMTU(nsyms)
-    best = None
-    for rep in range(3):
+    # pass 0: what the demodulator delivers (checked below); also allocates its staging buffers
+    d.work(iq)
+    ps, pn, pc = d.packets_device(clear=False)
+    calls = d.work_calls()
+    ch_, rd_, ln_, sy_ = d.packets_arrays()
+    pk = list(zip(ch_.tolist(), rd_.tolist(), np.split(sy_, np.cumsum(ln_)[:-1]) if ch_.size else []))
+    n_dev = int(ps.shape[0])
+
+    def one_pass(to_host=False):
+        d.clear_packets()
+        d.activate()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         d.work(iq)                                  # the streaming kernel + per-channel state back: packets stay on the device
         t1 = time.perf_counter()
-        ps, pn, pc = d.packets_device(clear=False)  # ... packed there into the batched decoder's input layout
+        d.packets_device(clear=False)               # ... packed there into the batched decoder's input layout
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        arr = d.packets_arrays()                    # ... or drained to the host queue (what a host consumer pays)
-        t3 = time.perf_counter()
-        if rep == 0:
-            calls = d.work_calls()
-            ch_, rd_, ln_, sy_ = arr
-            pk = list(zip(ch_.tolist(), rd_.tolist(), np.split(sy_, np.cumsum(ln_)[:-1]) if ch_.size else []))
-            n_dev = int(ps.shape[0])
-        elif best is None or (t2 - t0) < best[0]:
-            best = (t2 - t0, d.kernel_ms(), (t1 - t0) + (t3 - t2))
-        d.activate()
+        t3 = t2
+        if to_host:
+            d.packets_arrays()                      # ... or drained to the host queue (what a host consumer pays)
+            t3 = time.perf_counter()
+        return t2 - t0, d.kernel_ms(), (t1 - t0) + (t3 - t2)
+    # a receiver runs continuously: like the batch sections, time it with the device at its loaded clocks (a cold MI355X takes
+    # ~40 ms of work to leave its idle clocks) -- passes back to back, no host drain in between
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.25:
+        one_pass()
+    best = None
+    for _ in range(5):
+        r_ = one_pass()
+        if best is None or r_[0] < best[0]:
+            best = r_
+    best = (best[0], best[1], one_pass(to_host=True)[2])
+    d.activate()
     n_pk, ok = WL.check_frame_packets(pk, data, 1 << sf, nsyms)
     # e2e = host wall clock from IQ in HBM to packets in the decoder's layout in HBM; e2e_host = the same to packets in host memory
     res = {"sf": sf, "channels": B, "work_calls": int(calls), "Msym_s_e2e": r4(calls / best[0] / 1e6), "e2e_ms": r4(best[0] * 1e3),

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblorahip.so")
+# LORAHIP_LIB: another build of the same library (A/B measurements of kernel changes inside one GPU session, tools/gpu_ab.sh)
+LIB_PATH = os.environ.get("LORAHIP_LIB") or os.path.join(HERE, "liblorahip.so")
 
 OK = 0
 SF_MIN, SF_MAX = 6, 12

@@ -518,6 +518,10 @@ class LoRaDemod:
             self._lib.lorahip_demod_clear_packets(self._h)
         return ch, rd, ln, syms
 
+    def clear_packets(self):
+        """drop the queued packets (what packets*(clear=True) do after reading them)"""
+        self._lib.lorahip_demod_clear_packets(self._h)
+
     def packets(self, clear=True):
         """[(channel, round, int16 symbols)] -- the Pothos::Packet payloads of output port 0"""
         ch, rd, ln, syms = self.packets_arrays(clear)

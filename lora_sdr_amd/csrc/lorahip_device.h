@@ -362,6 +362,44 @@ __device__ __forceinline__ void tailValuesPaired(const float powerScale, const f
     if (demon != 0.0) fIndex = (float)(0.5 * (double)(right - left) / demon);
 }
 
+/*! LoRaDetector.hpp:36-48 over one lane's CNT bins, bin(j) in ascending bin order: as CH independent chains over consecutive
+ * quarters. Each chain is the reference's own scan (`if (mag2 > maxValue)` from 0: a NaN is never taken, the first maximum wins);
+ * the chains are merged in order with the same strict comparison -- the same winner, with a dependency depth of CNT/CH + 2
+ * instead of CNT -- and the fp64 total is the sum of the chains' partial sums (like the cross-lane trees, a different association
+ * of the same addends, each of them exact). Returns the winner's j. */
+template <int CNT, int CHAINS, class BIN>
+__device__ __forceinline__ int laneScan(BIN bin, float &bestV, double &tot)
+{
+    constexpr int CH = CNT >= 2 * CHAINS ? CHAINS : 1, PER = CNT / CH;
+    float cv[CH];
+    int cj[CH];
+    double ct[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) { cv[c] = 0.0f; cj[c] = 0; ct[c] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+        {
+            const int j = c * PER + k;
+            const auto b = bin(j);
+            const float mag2 = b.x * b.x + b.y * b.y;
+            ct[c] += (double)mag2;
+            if (mag2 > cv[c]) { cv[c] = mag2; cj[c] = j; }
+        }
+#pragma unroll
+    for (int w = 1; w < CH; w <<= 1)
+#pragma unroll
+        for (int c = 0; c + w < CH; c += 2 * w)
+        {
+            if (cv[c + w] > cv[c]) { cv[c] = cv[c + w]; cj[c] = cj[c + w]; }
+            ct[c] += ct[c + w];
+        }
+    bestV = cv[0];
+    tot = ct[0];
+    return cj[0];
+}
+
 //! fIndex alone, for the same replicated lanes: the fIndex operations of tailValuesPaired (hence its bits) without the two
 //! logarithms -- what FRAMESYNC consumes of an unsquelched window when no trace is kept (LoRaDemod.cpp:217-221)
 template <class CPX>

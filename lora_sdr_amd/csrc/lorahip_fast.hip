@@ -243,7 +243,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         float bestV;
         int bestI;
         double tot;
-        K::scan(vl, F, (DBG && a.fftOut && active) ? gFft + (size_t)w * N : nullptr, t, bestV, bestI, tot);
+        K::template scan<true, UNI ? 4 : 1>(vl, F, (DBG && a.fftOut && active) ? gFft + (size_t)w * N : nullptr, t, bestV, bestI, tot);
 
         // ---- defer the log/sqrt tail: one record per window, flushed 64 at a time ---------------
         v2f leftBin, rightBin;

@@ -318,7 +318,7 @@ struct FastCore
     //! LoRaDetector.hpp:36-48 over the window's bins: writes them to F (the window's row of the now free exchange
     //! region, for the neighbour fetch) and to fftOut (optional debug port), and leaves the window's arg-max,
     //! its |X|^2 and the fp64 total in every lane of the window.
-    template <bool STORE_F = true>
+    template <bool STORE_F = true, int CHAINS = 1>
     static __device__ __forceinline__ void scan(const v2f (&vl)[NGL][GL], v2f *F, v2f *fftOut, const int t,
                                                 float &bestV, int &bestI, double &tot)
     {
@@ -329,20 +329,15 @@ struct FastCore
 #pragma unroll
                 for (int g = 0; g < NGL; g++) F[(t + T * g) + (e << BL)] = vl[g][e];
         }
-        bestV = 0.0f;
-        int bestJ = 0;                                     // element number e*NGL + g of the lane's best bin
-        tot = 0.0;
+        if (fftOut)
+        {
 #pragma unroll
-        for (int e = 0; e < GL; e++)
+            for (int e = 0; e < GL; e++)
 #pragma unroll
-            for (int g = 0; g < NGL; g++)
-            {
-                const v2f bin = vl[g][e];
-                if (fftOut) fftOut[(t + T * g) + (e << BL)] = bin;
-                const float mag2 = bin.x * bin.x + bin.y * bin.y;
-                tot += (double)mag2;
-                if (mag2 > bestV) { bestV = mag2; bestJ = e * NGL + g; }
-            }
+                for (int g = 0; g < NGL; g++) fftOut[(t + T * g) + (e << BL)] = vl[g][e];
+        }
+        // element j = e*NGL + g of the lane is bin (t + T g) + (e << BL): ascending in j
+        const int bestJ = laneScan<GL * NGL, CHAINS>([&](const int j) { return vl[j % NGL][j / NGL]; }, bestV, tot);
         bestI = (t + T * (bestJ & (NGL - 1))) + ((bestJ / NGL) << BL);
         if (!(bestV > 0.0f)) bestI = 0;
         groupArgmax<T>(bestV, bestI);

@@ -333,19 +333,24 @@ __device__ __forceinline__ unsigned fineLaneIndices(const int idx0, const FinePl
 {
     constexpr int LOG2M = LOG2N + 7;
     const unsigned Q = fineReduce(unsigned(VEC * T) * p.q, p, LOG2M);          // VEC*T*q < N*(M+1) < 2^32
+    // y[r] = y[0] + r Q (mod M'): by doubling (Q, 2Q, 4Q, ...) instead of one long chain -- log2(R) dependent steps, not R
     unsigned ymax = 0;
 #pragma unroll
-    for (int u = 0; u < VEC; u++)
-    {
-        unsigned v = fineReduce(unsigned(idx0) + __umul24(unsigned(VEC * t + u), p.q), p, LOG2M);
+    for (int u = 0; u < VEC; u++) y[0][u] = fineReduce(unsigned(idx0) + __umul24(unsigned(VEC * t + u), p.q), p, LOG2M);
+    unsigned Qw = Q;
 #pragma unroll
-        for (int r = 0; r < R; r++)
-        {
-            y[r][u] = v;
-            ymax = v > ymax ? v : ymax;
-            v = fineAdvance(v, Q, p);
-        }
+    for (int w = 1; w < R; w <<= 1)
+    {
+#pragma unroll
+        for (int r = 0; r < w && r + w < R; r++)
+#pragma unroll
+            for (int u = 0; u < VEC; u++) y[r + w][u] = fineAdvance(y[r][u], Qw, p);
+        Qw = fineAdvance(Qw, Qw, p);
     }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int u = 0; u < VEC; u++) ymax = y[r][u] > ymax ? y[r][u] : ymax;
     if (__any(p.sat))
     {
         // windows whose index walks down by one per sample and stays at 0 (lorahip_fine.h): the modular form is right until it

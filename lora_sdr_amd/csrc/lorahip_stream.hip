@@ -68,10 +68,19 @@ demodStream(const StreamArgs s)
     // threshold (squelchQuick), the two logarithms are never evaluated otherwise, and the neighbours + fIndex only for lanes
     // with wantFi whose window is not squelched. wantSq / wantFi are per lane group; the branches are wave-uniform.
     const bool all = s.calls != nullptr;
+#ifdef LORAHIP_STREAM_TIMING
+    unsigned long long tsec[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#define TMARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsec[i] += now_ - tlast; tlast = now_; } while (0)
+#define TMARK_NOWAIT(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsec[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define TMARK(i)
+#define TMARK_NOWAIT(i)
+#endif
     auto detect = [&](const bool on, const bool wantSq, const bool wantFi, const long long off, const bool downTable, const int idx0, const float err,
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
+        TMARK(5);
         K::load(x, gIq + (on ? off : 0), t);
         const float d = err * (float)LORAHIP_FINE_STEPS;
         const bool moving = on && d != 0.0f;
@@ -100,6 +109,8 @@ demodStream(const StreamArgs s)
             }
             if (moving) idxEnd = e;
         }
+        TMARK_NOWAIT(0);
+        TMARK(1);
         v2f cw[R][VEC];
         K::chirpFromLds(cw, sCh, t);
         const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
@@ -119,8 +130,10 @@ demodStream(const StreamArgs s)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
+        TMARK(2);
         v2f vl[NGL][GL];
         K::fft(x, X, wsub, t, sTw, twR, vl, []() {}, &twM);
+        TMARK(3);
         v2f *F = X + wsub * FS;
         float bestV;
         int bestI;
@@ -165,8 +178,12 @@ demodStream(const StreamArgs s)
             }
         }
         value = bestI;
+        TMARK(4);
     };
 
+#ifdef LORAHIP_STREAM_TIMING
+    tlast = __builtin_amdgcn_s_memtime();
+#endif
     while (true)
     {
         const bool live = mine && (len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt;   // LoRaDemod.cpp:148
@@ -205,6 +222,11 @@ demodStream(const StreamArgs s)
         // ---- the frame machine (:176-312) ----
         if (live) frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
     }
+#ifdef LORAHIP_STREAM_TIMING
+    if (blockIdx.x == 7 && threadIdx.x == 0)
+        printf("stream timing (s_memtime ticks): index math %llu, load wait %llu, chirp+dechirp %llu, fft %llu, scan+tail %llu, frame machine+loop %llu; calls %d\n",
+               tsec[0], tsec[1], tsec[2], tsec[3], tsec[4], tsec[5], o.calls);
+#endif
     if (mine && t == 0)
     {
         s.state[c] = st;

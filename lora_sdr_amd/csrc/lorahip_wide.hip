@@ -17,6 +17,9 @@
 #include "lorahip_fft.h"
 #include "lorahip_framemachine.h"
 
+#ifndef SCAN_CHAINS_WIDE
+#define SCAN_CHAINS_WIDE 1
+#endif
 namespace lorahip {
 
 template <int LOG2N_, int VEC_, int MINW_, int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, bool PREFETCH_ = true, bool NT_ = false, int WPB_ = 0,
@@ -432,18 +435,14 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         else runPhase<LOG2N, B2, LOG2N, true>(vl, 0, nullptr, twR);
 
         // ---- scan (LoRaDetector.hpp:36-48): bin = t + T*e, ascending in e ----------------------
-        float bestV = 0.0f;
-        int bestE = 0;
-        double tot = 0.0;
-#pragma unroll
-        for (int e = 0; e < 16; e++)
+        if (DBG && a.fftOut && active)
         {
-            const v2f bin = vl[e];
-            if (DBG && a.fftOut && active) gFft[(size_t)w * N + t + (e << LOG2T)] = bin;
-            const float mag2 = bin.x * bin.x + bin.y * bin.y;
-            tot += (double)mag2;
-            if (mag2 > bestV) { bestV = mag2; bestE = e; }
+#pragma unroll
+            for (int e = 0; e < 16; e++) gFft[(size_t)w * N + t + (e << LOG2T)] = vl[e];
         }
+        float bestV;
+        double tot;
+        const int bestE = laneScan<16, SCAN_CHAINS_WIDE>([&](const int e) { return vl[e]; }, bestV, tot);
         int bestI = t + (bestE << LOG2T);
         if (!(bestV > 0.0f)) bestI = 0;
         groupArgmax<64>(bestV, bestI);
@@ -777,17 +776,9 @@ demodStreamWide(const StreamArgs s)
         runPhase<LOG2N, B2, LOG2N, true>(vl, 0, nullptr, twR);
 
         // scan (LoRaDetector.hpp:36-48)
-        float bestV = 0.0f;
-        int bestE = 0;
-        double tot = 0.0;
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-        {
-            const v2f bin = vl[e];
-            const float mag2 = bin.x * bin.x + bin.y * bin.y;
-            tot += (double)mag2;
-            if (mag2 > bestV) { bestV = mag2; bestE = e; }
-        }
+        float bestV;
+        double tot;
+        const int bestE = laneScan<16, SCAN_CHAINS_WIDE>([&](const int e) { return vl[e]; }, bestV, tot);
         int bestI = t + (bestE << LOG2T);
         if (!(bestV > 0.0f)) bestI = 0;
         groupArgmax<64>(bestV, bestI);

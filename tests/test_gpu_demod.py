@@ -477,10 +477,11 @@ def test_packets_packed_on_the_device_equal_the_host_queue(gpu, oracle, sf):
 
 @pytest.mark.parametrize("sf", [7, 9, 10, 11, 12])
 def test_squelch_decisions_without_trace_at_the_threshold(gpu, oracle, sf):
-    """Without a trace the streaming kernels skip detect()'s float outputs in DATASYMBOLS and take the squelch decision
-    (LoRaDemod.cpp:173-174) from a quick estimate, falling back to the exact chain within 0.01 dB of the threshold. Thresholds
-    placed EXACTLY on snr values the reference computes for data symbols (and a hair beside them) must give the reference's
-    packets: lengths are decided by which symbol is squelched first."""
+    """Without a trace the streaming kernels take the squelch decision (LoRaDemod.cpp:173-174) of DATASYMBOLS and FRAMESYNC
+    windows from a quick estimate, falling back to the exact chain within 0.01 dB of the threshold, and evaluate fIndex only for
+    unsquelched FRAMESYNC windows. Thresholds placed EXACTLY on snr values the reference computes for data symbols and for
+    windows of the sync search (and a hair beside them) must give the reference's packets: which symbol is squelched first
+    decides a packet's length, which preamble window is squelched decides whether (and where) the frame is found at all."""
     import lora_sdr_amd as L
     rng = np.random.default_rng(900 + sf)
     N = 1 << sf
@@ -488,6 +489,9 @@ def test_squelch_decisions_without_trace_at_the_threshold(gpu, oracle, sf):
     r0 = oracle.demod_run(sf, st, mtu=64, thresh=-30.0, keep=False)
     snrs = sorted(c["snr"] for c in r0["calls"] if c["state"] == 4 and np.isfinite(c["snr"]))
     picks = [snrs[len(snrs) // 4], snrs[len(snrs) // 2], snrs[(3 * len(snrs)) // 4]]
+    snrs0 = sorted(c["snr"] for c in r0["calls"] if c["state"] == 0 and np.isfinite(c["snr"]) and c["snr"] > -20.0)
+    assert len(snrs0) >= 4
+    picks += [snrs0[len(snrs0) // 3], snrs0[(2 * len(snrs0)) // 3], snrs0[-1]]
     threshs = []
     for v in picks:
         v = np.float32(v)

@@ -11,6 +11,7 @@ ap.add_argument("--sf", type=int, default=7); ap.add_argument("--channels", type
 ap.add_argument("--frames", type=int, default=4); ap.add_argument("--nsyms", type=int, default=48)
 ap.add_argument("--sigma", type=float, default=0.05); ap.add_argument("--modes", default="1,2")
 ap.add_argument("--fine-gather", action="store_true", help="A/B: read the fine-tune table in HBM (round-1 path)")
+ap.add_argument("--ramp-seconds", type=float, default=0.25, help="work() passes back to back before the timed ones (device at its loaded clocks)")
 ap.add_argument("--reps", type=int, default=4, help="work() passes over the same streams (the first one is the cold one)")
 a = ap.parse_args()
 sf, N, B = a.sf, 1 << a.sf, a.channels
@@ -24,18 +25,21 @@ for mode in [int(m) for m in a.modes.split(",")]:
     if a.fine_gather:
         d.set_fine_gather(True)
     times, kms = [], []
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    d.work(iq); cold = time.perf_counter() - t0                             # pass 0: checked below; allocates the staging buffers
+    calls = d.work_calls(); pk = d.packets(); d.activate()
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < a.ramp_seconds:
+        d.work(iq); d.clear_packets(); d.activate()
     for rep in range(max(2, a.reps)):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         rounds = d.work(iq)
         times.append(time.perf_counter() - t0); kms.append(d.kernel_ms())
-        if rep == 0:
-            calls = d.work_calls(); pk = d.packets()
-        else:
-            d.packets()
+        d.clear_packets()
         d.activate()
-    dt = min(times[1:])
+    dt = min(times)
     n, ok = WL.check_frame_packets(pk, data, N, a.nsyms)
-    print("  mode %d%s: %.1f ms warm (%.1f ms cold), kernel %.3f ms, %d work() calls in %d rounds -> %.2f Msym/s end to end, %.2f Msym/s kernel; %d packets (expected %d), %d/%d carry the sent symbols (constant bin offset)"
-          % (mode, " (table gather)" if a.fine_gather else "", dt * 1e3, times[0] * 1e3, min(kms[1:]), calls, rounds, calls / dt / 1e6,
-             calls / (min(kms[1:]) / 1e3) / 1e6 if min(kms[1:]) > 0 else float("nan"), len(pk), B * a.frames, ok, n))
+    print("  mode %d%s: %.2f ms warm (%.1f ms cold), kernel %.3f ms, %d work() calls in %d rounds -> %.2f Msym/s end to end, %.2f Msym/s kernel; %d packets (expected %d), %d/%d carry the sent symbols (constant bin offset)"
+          % (mode, " (table gather)" if a.fine_gather else "", dt * 1e3, cold * 1e3, min(kms), calls, rounds, calls / dt / 1e6,
+             calls / (min(kms) / 1e3) / 1e6 if min(kms) > 0 else float("nan"), len(pk), B * a.frames, ok, n))
     d.close()

@@ -19,3 +19,16 @@ for sf in ${L3SFS:-7 10 12}; do
   timeout 200 python tools/bench_demod.py --sf $sf --channels $CH --modes 1 > $O/${TAG}_level3_sf$sf.txt 2>&1
   tail -1 $O/${TAG}_level3_sf$sf.txt
 done
+if [[ -n "${STEADY:-}" ]]; then
+  for sf in $STEADY; do
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline > $O/${TAG}_steady_sf$sf.json 2> $O/${TAG}_steady_sf$sf.err
+    python - $O/${TAG}_steady_sf$sf.json $sf <<'EOP'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("SF%s steady %8.1f Msym/s frac %.3f launch %.1f us" % (sys.argv[2], d["value"], d["roofline"]["frac"], d["roofline"]["launch_us"]))
+except Exception as e:
+    print("SF", sys.argv[2], "FAILED", e)
+EOP
+  done
+fi
