@@ -66,7 +66,9 @@ demodStream(const StreamArgs s)
     // states only the peak's index. power / powerAvg / snr themselves only reach the labels and signals, i.e. the per-call trace.
     // So unless a trace is kept (`all`), the squelch comes from a quick estimate with the exact chain as the fallback near the
     // threshold (squelchQuick), the two logarithms are never evaluated otherwise, and the neighbours + fIndex only for lanes
-    // with wantFi whose window is not squelched. wantSq / wantFi are per lane group; the branches are wave-uniform.
+    // with wantFi = 1 whose window is not squelched -- or in any case for wantFi = 2: the second window of a FRAMESYNC call, whose
+    // fIndex the reference consumes without looking at that window's own snr (:203, :217-221). wantSq / wantFi are per lane group;
+    // the branches are wave-uniform.
     const bool all = s.calls != nullptr;
 #ifdef LORAHIP_STREAM_TIMING
     unsigned long long tsec[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -76,7 +78,7 @@ demodStream(const StreamArgs s)
 #define TMARK(i)
 #define TMARK_NOWAIT(i)
 #endif
-    auto detect = [&](const bool on, const bool wantSq, const bool wantFi, const long long off, const bool downTable, const int idx0, const float err,
+    auto detect = [&](const bool on, const bool wantSq, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
@@ -140,7 +142,7 @@ demodStream(const StreamArgs s)
         double tot;
         v2f l, r;
         value = 0;
-        const bool staged = all || __any(on && wantFi);                               // bins to LDS for the neighbour fetch
+        const bool staged = all || __any(on && wantFi != 0);                               // bins to LDS for the neighbour fetch
         if (all)
         {
             K::scan(vl, F, nullptr, t, bestV, bestI, tot);
@@ -158,7 +160,7 @@ demodStream(const StreamArgs s)
             squelched = squelchQuick(bestV, tot, s.thresh, sure);
             power = powerAvg = fIndex = 0.0f;                                           // not consumed without a trace
             const bool exact = on && wantSq && !sure;
-            const bool fi = on && wantFi && (!sure || !squelched);
+            const bool fi = on && (wantFi == 2 || (wantFi == 1 && (!sure || !squelched)));
             if (__any(exact || fi))
             {
                 if (staged) K::neighbours(vl, F, bestI, lane, t, l, r);
@@ -184,43 +186,53 @@ demodStream(const StreamArgs s)
 #ifdef LORAHIP_STREAM_TIMING
     tlast = __builtin_amdgcn_s_memtime();
 #endif
+    // A FRAMESYNC call that is sync'd and matches the first sync word looks at a SECOND window (LoRaDemod.cpp:183-206). The wave's
+    // channels run in lock step, so a second detect() inside the pass would be paid by all of them; instead the call is split over
+    // two passes of the loop: the first evaluates window 0 and parks (`pend`), the second evaluates window 1 in that channel's
+    // slot of the next pass -- while the other channels do their next calls -- and completes the frame machine step. Nothing is
+    // written and nothing is consumed in between, and the limits checked for the first pass cover the whole call.
+    bool pend = false;
+    int value0 = 0, fineIdxBefore0 = 0;
+    float snr0 = 0.0f, fineErrBefore0 = 0.0f;
     while (true)
     {
-        const bool live = mine && (len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt;   // LoRaDemod.cpp:148
+        const bool live = mine && (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt));   // LoRaDemod.cpp:148
         if (!__any(live)) break;
 
-        // ---- window 0 (:157-172) ----
+        // ---- this pass's window: window 0 of a call (:157-172), or window 1 of a parked one (:189-206) ----
+        const bool second = pend;
         int value, idxEnd;
         float power, powerAvg, fIndex;
-        const int fineIdxBefore = st.fineTuneIndex;
-        const float fineErrBefore = st.finefreqError;
-        const long long here = base + st.pos;
+        const int fineIdxBefore = second ? fineIdxBefore0 : st.fineTuneIndex;
+        const float fineErrBefore = second ? fineErrBefore0 : st.finefreqError;
+        const long long here = base + st.pos + (second ? N : 0);
+        const bool fs = st.state == ST_FRAMESYNC;
         bool squelched;
-        detect(live, st.state == ST_FRAMESYNC || st.state == ST_DATASYMBOLS, st.state == ST_FRAMESYNC, here, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
-        const float snr = power - powerAvg;                                             // :173 (squelched = snr < thresh, :174, comes from detect)
-        if (live) st.fineTuneIndex = idxEnd;                                            // the loop commits the member (:160-162)
+        detect(live, !second && (fs || st.state == ST_DATASYMBOLS), second ? 2 : (fs ? 1 : 0), here, st.downTable != 0, st.fineTuneIndex,
+               st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
+        float snr = power - powerAvg;                                                   // :173 (squelched = snr < thresh, :174, comes from detect)
+        // window 0: the loop commits the member (:160-162); window 1: `int ft = _fineTuneIndex` (:191) starts from the committed
+        // index and is not committed itself
+        if (live && !second) st.fineTuneIndex = idxEnd;
 
-        // ---- FRAMESYNC: second window when sync'd and the first sync word matches (:183-206) ----
-        const bool syncd = !squelched && (st.prevValue + 4) / 8 == 0;                  // :183
-        const bool match0 = (value + 4) / 8 == (s.sync >> 4);                          // :184
-        const bool need1 = live && st.state == ST_FRAMESYNC && syncd && match0;
-        bool match1 = false;
-        if (__any(need1))
+        bool syncd = !squelched && (st.prevValue + 4) / 8 == 0;                        // :183
+        bool match0 = (value + 4) / 8 == (s.sync >> 4);                                // :184
+        bool match1 = false, step = live;
+        if (second)
         {
-            int value1, idxEnd1;
-            float p1, pa1, fi1;
-            // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
-            bool sq1;
-            detect(need1, true, true, here + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, p1, pa1, fi1, idxEnd1, sq1);
-            if (need1)
-            {
-                match1 = (value1 + 4) / 8 == (s.sync & 0xf);                           // :205
-                power = p1; powerAvg = pa1; fIndex = fi1;                               // detect() overwrites the locals (:203); snr is not recomputed
-            }
+            match1 = (value + 4) / 8 == (s.sync & 0xf);                                // :205
+            // detect() overwrote power / powerAvg / fIndex (:203); value, snr and what follows from them are window 0's
+            value = value0; snr = snr0; squelched = false; syncd = true; match0 = true;
+            pend = false;
+        }
+        else if (live && fs && syncd && match0)
+        {
+            pend = true; step = false;
+            value0 = value; snr0 = snr; fineIdxBefore0 = fineIdxBefore; fineErrBefore0 = fineErrBefore;
         }
 
         // ---- the frame machine (:176-312) ----
-        if (live) frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
+        if (step) frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
     }
 #ifdef LORAHIP_STREAM_TIMING
     if (blockIdx.x == 7 && threadIdx.x == 0)

@@ -690,7 +690,7 @@ demodStreamWide(const StreamArgs s)
     // threshold, fIndex is evaluated only for an unsquelched FRAMESYNC window, and the neighbour fetch with its barrier is skipped
     // whenever neither is needed
     const bool all = s.calls != nullptr;
-    auto detect = [&](const bool wantSq, const bool wantFi, const long long off, const bool downTable, const int idx0, const float err,
+    auto detect = [&](const bool wantSq, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
@@ -805,7 +805,7 @@ demodStreamWide(const StreamArgs s)
             squelched = squelchQuick(bestV, tot, s.thresh, sure);
             power = powerAvg = fIndex = 0.0f;                   // not consumed without a trace
             needLogs = wantSq && !sure;
-            needFi = wantFi && (!sure || !squelched);
+            needFi = wantFi == 2 || (wantFi == 1 && (!sure || !squelched));   // 2: the second window of a FRAMESYNC call (:203, :217-221)
         }
         if (needLogs || needFi)
         {
@@ -836,7 +836,7 @@ demodStreamWide(const StreamArgs s)
         const int fineIdxBefore = st.fineTuneIndex;
         const float fineErrBefore = st.finefreqError;
         bool squelched;
-        detect(st.state == ST_FRAMESYNC || st.state == ST_DATASYMBOLS, st.state == ST_FRAMESYNC, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power,
+        detect(st.state == ST_FRAMESYNC || st.state == ST_DATASYMBOLS, st.state == ST_FRAMESYNC ? 1 : 0, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power,
                powerAvg, fIndex, idxEnd, squelched);
         const float snr = power - powerAvg;                                             // :173 (squelched = snr < thresh, :174, comes from detect)
         st.fineTuneIndex = idxEnd;                                                      // :160-162
@@ -848,7 +848,7 @@ demodStreamWide(const StreamArgs s)
             int value1, idxEnd1;
             // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
             bool sq1;
-            detect(true, true, base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, power, powerAvg, fIndex, idxEnd1, sq1);
+            detect(false, 2, base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, power, powerAvg, fIndex, idxEnd1, sq1);
             match1 = (value1 + 4) / 8 == (s.sync & 0xf);                               // :205; snr is not recomputed
         }
         frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);

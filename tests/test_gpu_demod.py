@@ -541,3 +541,65 @@ def test_demod_on_a_second_device_while_the_first_is_current(gpu, oracle):
         assert len(pk) == 1 and np.array_equal(pk[0][2], syms[0].astype(np.int16))
         d.close()
         assert gpu.cuda.current_device() == 0
+
+
+@pytest.mark.parametrize("sf", [7, 9, 11])
+def test_untraced_prefix_leaves_the_state_a_traced_run_has(gpu, oracle, sf):
+    """Without a trace the streaming kernels evaluate only what the frame machine consumes (a quick squelch estimate, fIndex only
+    where FRAMESYNC adds it to _finefreqError). Whatever they skip must not leak into the state: a stream is run (a) traced from
+    the start and (b) untraced up to a cut, traced from there -- for cuts all along the stream -- and (b)'s traced calls must be
+    the tail of (a)'s, including the fine-tune index and error each call starts from. The streams hold the case the shortcut must
+    not get wrong: a FRAMESYNC call whose first sync word matches and whose SECOND window is squelched noise -- the reference adds
+    that window's fIndex without looking at its snr (LoRaDemod.cpp:203, :217-221); the threshold is set so that noise IS squelched."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(4242 + sf)
+    N = 1 << sf
+    B = 4
+    streams = []
+    for c in range(B):
+        full = oracle.mod_frame(sf, rng.integers(0, N, 6).astype(np.uint16), sync=0x12, padding=0)
+        cut_at = (10 + 1) * N + int(rng.integers(-N // 8, N // 8))               # preamble + the first sync chirp, then noise instead of the second
+        good = oracle.mod_frame(sf, rng.integers(0, N, 6).astype(np.uint16), sync=0x12, padding=2)
+        st = np.concatenate([np.zeros(int(rng.integers(5, N)), np.complex64), full[:cut_at], np.zeros(N + N // 3, np.complex64), good,
+                             np.zeros(3 * N, np.complex64)])
+        st = (st * np.exp(2j * np.pi * rng.uniform(-0.3, 0.3) / N * np.arange(st.size))).astype(np.complex64)
+        st += (0.05 * (rng.standard_normal(st.size) + 1j * rng.standard_normal(st.size))).astype(np.complex64)
+        streams.append(st)
+    thresh = -6.0                                                                  # noise windows sit near -14 dB, chirps far above
+    ref, has_case = [], []
+    a = L.LoRaDemod(sf, n_channels=B); a.set_mode(1); a.setMTU(6); a.setThreshold(thresh); a.set_trace(True)
+    a.work(streams)
+    for c in range(B):
+        tr = a.trace(c)
+        want = oracle.demod_run(sf, streams[c], mtu=6, thresh=thresh)["calls"]
+        compare_channel(tr, want)
+        ref.append(tr)
+        # the case is really in the stream: a FRAMESYNC call that is sync'd (the call before it peaked at bin 0, unsquelched), matches
+        # the first sync word (0x12: (value + 4) / 8 == 1) and still consumes N - value -- its second window did not match
+        has_case.append(any(x["state"] == 0 and (x["value"] + 4) // 8 == 0 and y["state"] == 0 and y["snr"] >= thresh and (y["value"] + 4) // 8 == 1
+                            and y["consumed"] == N - y["value"] for x, y in zip(want, want[1:])))
+    a.close()
+    assert sum(has_case) >= 2                                                      # (where the cut came late the second sync word still matched)
+    total = min(len(s) for s in streams)
+    for cut in range(2 * N, total - 2 * N, (3 * N) // 2 + 7):
+        d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(6); d.setThreshold(thresh)
+        d.work([s[:cut] for s in streams])                                         # untraced: the shortcuts
+        used = [d.consumed(c) for c in range(B)]
+        n_before = []
+        for c in range(B):
+            pos, k = 0, 0
+            while k < len(ref[c]) and pos < used[c]:
+                pos += ref[c][k]["consumed"]; k += 1
+            assert pos == used[c], "channel %d: the untraced run stopped inside a reference call" % c
+            n_before.append(k)
+        d.clear_packets()
+        d.set_trace(True)
+        d.work([s[u:] for s, u in zip(streams, used)])                             # traced from where it stopped
+        for c in range(B):
+            got, want = d.trace(c), ref[c][n_before[c]:]
+            assert len(got) == len(want), (cut, c)
+            for g, w in zip(got, want):
+                for k in ("consumed", "state_before", "value", "fine_idx_before", "fine_idx_after", "packet_len"):
+                    assert g[k] == w[k], (cut, c, k)
+                assert np.float32(g["fine_err_before"]).tobytes() == np.float32(w["fine_err_before"]).tobytes(), (cut, c)
+        d.close()
