@@ -15,6 +15,12 @@
 #include "lorahip_framemachine.h"
 #include <cstdlib>
 
+#ifndef STREAM_STAGE_BINS
+#define STREAM_STAGE_BINS 1
+#endif
+#ifndef STREAM_SCAN_CHAINS
+#define STREAM_SCAN_CHAINS 1
+#endif
 namespace lorahip {
 
 template <class C>
@@ -142,10 +148,10 @@ demodStream(const StreamArgs s)
         double tot;
         v2f l, r;
         value = 0;
-        const bool staged = all || __any(on && wantFi != 0);                               // bins to LDS for the neighbour fetch
+        const bool staged = all || (STREAM_STAGE_BINS && __any(on && wantFi != 0));       // bins to LDS for the neighbour fetch (else: register select)
         if (all)
         {
-            K::scan(vl, F, nullptr, t, bestV, bestI, tot);
+            K::template scan<true, STREAM_SCAN_CHAINS>(vl, F, nullptr, t, bestV, bestI, tot);
             K::neighbours(vl, F, bestI, lane, t, l, r);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -154,8 +160,8 @@ demodStream(const StreamArgs s)
         }
         else
         {
-            if (staged) K::scan(vl, F, nullptr, t, bestV, bestI, tot);
-            else K::template scan<false>(vl, F, nullptr, t, bestV, bestI, tot);
+            if (staged) K::template scan<true, STREAM_SCAN_CHAINS>(vl, F, nullptr, t, bestV, bestI, tot);
+            else K::template scan<false, STREAM_SCAN_CHAINS>(vl, F, nullptr, t, bestV, bestI, tot);
             bool sure;
             squelched = squelchQuick(bestV, tot, s.thresh, sure);
             power = powerAvg = fIndex = 0.0f;                                           // not consumed without a trace
