@@ -167,6 +167,12 @@ int lorahip_mixed_plan(lorahip_mixed *m, const int64_t *channel_offset, size_t w
 int lorahip_mixed_detect(lorahip_mixed *m, const float *iq_dev, uint16_t *sym_dev, float *power_dev, float *power_avg_dev, float *f_index_dev);
 int lorahip_mixed_synchronize(lorahip_mixed *m);
 
+/* Pinned host memory for the host-pointer entry points (lorahip_detect_batch_host, lorahip_demod_run, the detector shim): buffers
+ * obtained here -- or any hipHostMalloc'ed / hipHostRegister'ed memory -- are read by the DMA engine directly; ordinary memory is
+ * gathered through the library's double-buffered pinned staging first (several threads, LORAHIP_UPLOAD_THREADS). NULL on failure. */
+void *lorahip_host_alloc(size_t bytes);
+void lorahip_host_free(void *p);
+
 /* Time the last `n` launches made through this context between two internal HIP events
  * recorded on the launch stream (bench.py uses this for the roofline line). */
 int lorahip_timer_start(lorahip_ctx *ctx);

@@ -87,6 +87,8 @@ SIGNATURES = {
     "lorahip_mixed_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "lorahip_mixed_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lorahip_mixed_synchronize": (C.c_int, [C.c_void_p]),
+    "lorahip_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "lorahip_host_free": (None, [C.c_void_p]),
     "lorahip_timer_start": (C.c_int, [C.c_void_p]),
     "lorahip_timer_stop": (C.c_int, [C.c_void_p, _f32p]),
     "lorahip_detector_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_size_t]),

@@ -264,6 +264,20 @@ class Context:
         return iq
 
 
+def pinned_empty(shape, dtype=np.complex64):
+    """numpy array in pinned host memory (lorahip_host_alloc): the host-pointer entry points -- Context.detect_batch_host,
+    LoRaDemod.work on host streams -- hand such buffers to the DMA engine directly instead of staging them first"""
+    import weakref
+    lib = load()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = lib.lorahip_host_alloc(max(n, 1))
+    if not ptr:
+        raise MemoryError("lorahip_host_alloc(%d)" % n)
+    buf = (C.c_char * max(n, 1)).from_address(ptr)
+    weakref.finalize(buf, lib.lorahip_host_free, C.c_void_p(ptr))
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class MixedDetector:
     """Channels of different spreading factors demodulated in one call (lorahip_mixed_*: buckets by SF, one stream per bucket,
     concurrent launches, event join -- all below Python). channel_sf: SF of every channel; plan(offsets, S): channel c's S

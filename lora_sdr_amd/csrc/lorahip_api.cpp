@@ -43,21 +43,22 @@ static bool isGfx950(const int device)
     return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
 }
 
-static int growStage(lorahip_ctx *ctx, const size_t bytes)
+//! device and pinned-host staging of the host-pointer entry point (the IQ itself goes through gatherUpload: device side only)
+static int growStage(lorahip_ctx *ctx, const size_t devBytes, const size_t hostBytes)
 {
-    if (bytes <= ctx->dStageBytes && bytes <= ctx->hStageBytes) return LORAHIP_OK;
+    if (devBytes <= ctx->dStageBytes && hostBytes <= ctx->hStageBytes) return LORAHIP_OK;
     if (ctx->dStage) { (void)hipFree(ctx->dStage); ctx->dStage = nullptr; }
     if (ctx->hStage) { (void)hipHostFree(ctx->hStage); ctx->hStage = nullptr; }
     ctx->dStageBytes = ctx->hStageBytes = 0;                    // both or neither: a half-grown pair must not look usable
-    const size_t cap = bytes + bytes / 4;
-    LORAHIP_TRY(hipMalloc(&ctx->dStage, cap));
-    const hipError_t e = hipHostMalloc(&ctx->hStage, cap, hipHostMallocDefault);
+    const size_t dCap = devBytes + devBytes / 4, hCap = hostBytes + hostBytes / 4 + 256;
+    LORAHIP_TRY(hipMalloc(&ctx->dStage, dCap));
+    const hipError_t e = hipHostMalloc(&ctx->hStage, hCap, hipHostMallocDefault);
     if (e != hipSuccess)
     {
         (void)hipFree(ctx->dStage); ctx->dStage = nullptr; ctx->hStage = nullptr;
         return hipFail(e, "hipHostMalloc(staging)");
     }
-    ctx->dStageBytes = ctx->hStageBytes = cap;
+    ctx->dStageBytes = dCap; ctx->hStageBytes = hCap;
     return LORAHIP_OK;
 }
 
@@ -178,6 +179,7 @@ void lorahip_destroy(lorahip_ctx *ctx)
     if (ctx->dFineB) (void)hipFree(ctx->dFineB);
     if (ctx->dStage) (void)hipFree(ctx->dStage);
     if (ctx->hStage) (void)hipHostFree(ctx->hStage);
+    destroyUploader(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -324,16 +326,24 @@ int lorahip_detect_batch_host(lorahip_ctx *ctx, const lorahip_batch *b)
     const Piece pIdxOut = carve(b->fine_idx_out ? W * sizeof(int32_t) : 0);
     const Piece pFft = carve(b->fft_out ? W * N * sizeof(cf32) : 0);
     const Piece pDec = carve(b->dec_out ? W * N * sizeof(cf32) : 0);
-    rc = growStage(ctx, cur);
+    // the device holds every piece; the pinned host mirror everything but the IQ, which is first in the layout (its offset there
+    // is 0) and travels through the double-buffered upload instead
+    const size_t hShift = pOff.off;
+    rc = growStage(ctx, cur, cur - hShift);
     if (rc != LORAHIP_OK) return rc;
 
-    char *h = static_cast<char *>(ctx->hStage), *d = static_cast<char *>(ctx->dStage);
-    std::memcpy(h + pIq.off, b->iq, pIq.bytes);
+    char *d = static_cast<char *>(ctx->dStage), *h = static_cast<char *>(ctx->hStage) - hShift;   // h + off is valid for off >= hShift
+    {
+        const void *src[1] = { b->iq };
+        const size_t len[1] = { pIq.bytes };
+        rc = gatherUpload(ctx, d + pIq.off, src, len, 1);
+        if (rc != LORAHIP_OK) return rc;
+    }
     if (b->offsets) std::memcpy(h + pOff.off, b->offsets, pOff.bytes);
     if (b->chirp_sel) std::memcpy(h + pSel.off, b->chirp_sel, pSel.bytes);
     if (b->fine_idx0) std::memcpy(h + pIdx.off, b->fine_idx0, pIdx.bytes);
     if (b->fine_err) std::memcpy(h + pErr.off, b->fine_err, pErr.bytes);
-    LORAHIP_TRY(hipMemcpyAsync(d, h, inBytes, hipMemcpyHostToDevice, ctx->stream));
+    if (inBytes > hShift) LORAHIP_TRY(hipMemcpyAsync(d + hShift, h + hShift, inBytes - hShift, hipMemcpyHostToDevice, ctx->stream));
 
     lorahip_batch db = *b;
     db.iq = reinterpret_cast<const float *>(d + pIq.off);

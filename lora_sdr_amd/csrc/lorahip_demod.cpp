@@ -956,10 +956,14 @@ int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size
         LORAHIP_TRY(hipMalloc((void **)&dm->dIq, (total ? total : 1) * sizeof(cf32)));
         dm->dIqSamples = total;
     }
-    for (size_t c = 0; c < dm->B; c++)
-        if (n_samples[c])
-            LORAHIP_TRY(hipMemcpyAsync(dm->dIq + 2 * dm->ch[c].base, streams[c], n_samples[c] * sizeof(cf32),
-                                       hipMemcpyHostToDevice, dm->ctx->stream));
+    {
+        // the channels' buffers gathered into one device array back to back (base = running total): pinned double-buffered upload
+        std::vector<const void *> src(dm->B);
+        std::vector<size_t> len(dm->B);
+        for (size_t c = 0; c < dm->B; c++) { src[c] = streams[c]; len[c] = n_samples[c] * sizeof(cf32); }
+        const int rc = gatherUpload(dm->ctx, dm->dIq, src.data(), len.data(), dm->B);
+        if (rc != LORAHIP_OK) return rc;
+    }
     LORAHIP_TRY(hipStreamSynchronize(dm->ctx->stream));
     return runAny(dm, dm->dIq, rounds);
 }

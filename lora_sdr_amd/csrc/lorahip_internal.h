@@ -167,6 +167,11 @@ int hipFail(hipError_t e, const char *what);
 
 } // namespace lorahip
 
+namespace lorahip {
+//! two pinned staging buffers of the host -> device gather (lorahip_upload.cpp)
+struct Uploader { void *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; };
+}
+
 struct lorahip_ctx
 {
     int device;
@@ -184,4 +189,12 @@ struct lorahip_ctx
     // staging for the host-pointer entry point (grown on demand)
     void *dStage; size_t dStageBytes;
     void *hStage; size_t hStageBytes;
+    lorahip::Uploader up;
 };
+
+namespace lorahip {
+//! n host pieces -> device memory back to back from dDst, asynchronous on ctx->stream (pinned pieces by DMA straight away, the
+//! others through the context's double-buffered pinned staging); the caller synchronises the stream
+int gatherUpload(lorahip_ctx *ctx, void *dDst, const void *const *src, const size_t *bytes, size_t n);
+void destroyUploader(lorahip_ctx *ctx);
+}

@@ -1,0 +1,143 @@
+// Host buffers -> HBM for the host-pointer entry points ("pinned-host double-buffered H2D"). The
+// reference's blocks hand over ordinary host memory (Pothos buffers, LoRaDemod.cpp:151-154); a plain hipMemcpy from pageable memory
+// stages it through the runtime's own bounce buffer, serially. Here: pieces scattered on the host are gathered into device memory
+// back to back through two pinned staging buffers -- several threads copy into one while the DMA engine drains the other -- and
+// pieces that already live in pinned memory (lorahip_host_alloc, or anything hipHostMalloc'ed / hipHostRegister'ed) skip the
+// staging copy and go straight to the DMA engine.
+#include "lorahip_internal.h"
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace lorahip {
+
+static const size_t kStageBytes = size_t(32) << 20;      // per staging buffer
+static const size_t kDirectMin = size_t(256) << 10;       // a pinned piece this large is not worth packing with its neighbours
+
+static int uploadThreads()
+{
+    static const int n = []() {
+        if (const char *e = std::getenv("LORAHIP_UPLOAD_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) return v; }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return hw >= 16 ? 6 : (hw >= 4 ? 3 : 1);
+    }();
+    return n;
+}
+
+static bool isPinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // ordinary memory: not an error
+    return at.type == hipMemoryTypeHost;
+}
+
+struct Seg { char *dst; const char *src; size_t bytes; };
+
+//! the segments of one staging fill, copied by the calling thread and up to T-1 helpers
+static void copySegments(const std::vector<Seg> &segs, const size_t total)
+{
+    const int T = total >= (size_t(4) << 20) ? uploadThreads() : 1;
+    if (T <= 1) { for (const Seg &s : segs) std::memcpy(s.dst, s.src, s.bytes); return; }
+    const size_t share = (total + T - 1) / T;
+    auto work = [&segs, share](const int k)
+    {
+        // thread k copies bytes [k*share, (k+1)*share) of the concatenation of the segments
+        size_t lo = size_t(k) * share, hi = lo + share, at = 0;
+        for (const Seg &s : segs)
+        {
+            const size_t a = at > lo ? at : lo, b = (at + s.bytes) < hi ? (at + s.bytes) : hi;
+            if (a < b) std::memcpy(s.dst + (a - at), s.src + (a - at), b - a);
+            at += s.bytes;
+            if (at >= hi) break;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < T; k++) pool.emplace_back(work, k);
+    work(0);
+    for (auto &t : pool) t.join();
+}
+
+int gatherUpload(lorahip_ctx *ctx, void *dDstV, const void *const *src, const size_t *bytes, const size_t n)
+{
+    char *dDst = static_cast<char *>(dDstV);
+    Uploader &u = ctx->up;
+    if (u.buf[0] == nullptr)
+    {
+        for (int k = 0; k < 2; k++)
+        {
+            const hipError_t e = hipHostMalloc(&u.buf[k], kStageBytes, hipHostMallocDefault);
+            if (e != hipSuccess) { u.buf[k] = nullptr; return hipFail(e, "hipHostMalloc(upload staging)"); }
+            LORAHIP_TRY(hipEventCreateWithFlags(&u.ev[k], hipEventDisableTiming));
+            u.busy[k] = false;
+        }
+    }
+    size_t done = 0;                                     // bytes of the destination already handed to the DMA engine
+    int k = 0;
+    std::vector<Seg> segs;
+    size_t fill = 0;
+    auto flush = [&]() -> int
+    {
+        if (fill == 0) return LORAHIP_OK;
+        copySegments(segs, fill);
+        LORAHIP_TRY(hipMemcpyAsync(dDst + done, u.buf[k], fill, hipMemcpyHostToDevice, ctx->stream));
+        LORAHIP_TRY(hipEventRecord(u.ev[k], ctx->stream));
+        u.busy[k] = true;
+        done += fill; fill = 0; segs.clear();
+        k ^= 1;
+        if (u.busy[k]) { LORAHIP_TRY(hipEventSynchronize(u.ev[k])); u.busy[k] = false; }     // the other buffer's DMA of two fills ago
+        return LORAHIP_OK;
+    };
+    if (u.busy[k]) { LORAHIP_TRY(hipEventSynchronize(u.ev[k])); u.busy[k] = false; }
+    for (size_t i = 0; i < n; i++)
+    {
+        const char *p = static_cast<const char *>(src[i]);
+        size_t left = bytes[i];
+        if (left == 0) continue;
+        if (left >= kDirectMin && isPinned(p))
+        {
+            const int rc = flush();
+            if (rc != LORAHIP_OK) return rc;
+            LORAHIP_TRY(hipMemcpyAsync(dDst + done, p, left, hipMemcpyHostToDevice, ctx->stream));
+            done += left;
+            continue;
+        }
+        while (left)
+        {
+            const size_t take = left < kStageBytes - fill ? left : kStageBytes - fill;
+            segs.push_back(Seg{static_cast<char *>(u.buf[k]) + fill, p, take});
+            fill += take; p += take; left -= take;
+            if (fill == kStageBytes) { const int rc = flush(); if (rc != LORAHIP_OK) return rc; }
+        }
+    }
+    return flush();
+}
+
+void destroyUploader(lorahip_ctx *ctx)
+{
+    for (int k = 0; k < 2; k++)
+    {
+        if (ctx->up.buf[k]) (void)hipHostFree(ctx->up.buf[k]);
+        if (ctx->up.ev[k]) (void)hipEventDestroy(ctx->up.ev[k]);
+        ctx->up.buf[k] = nullptr; ctx->up.ev[k] = nullptr;
+    }
+}
+
+} // namespace lorahip
+
+using namespace lorahip;
+
+extern "C" {
+
+void *lorahip_host_alloc(const size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void lorahip_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+} // extern "C"
