@@ -361,6 +361,18 @@ def section_level3(env, L, sf):
         if best is None or r_[0] < best[0]:
             best = r_
     best = (best[0], best[1], one_pass(to_host=True)[2])
+    # the same streams handed over as ordinary HOST buffers, one per channel (what a Pothos port gives the block): gathered through
+    # the pinned double-buffered upload, then the streaming kernel -- PCIe-bound, reported beside the device-resident figures
+    host = iq.cpu().numpy()
+    rows = [host[c] for c in range(B)]
+    d.clear_packets(); d.activate()
+    d.work(rows)                                    # the device-side IQ array of the host path is allocated here
+    d.clear_packets(); d.activate()
+    t0 = time.perf_counter()
+    d.work(rows)
+    from_host = time.perf_counter() - t0
+    del host, rows
+    d.clear_packets()
     d.activate()
     n_pk, ok = WL.check_frame_packets(pk, data, 1 << sf, nsyms)
     # e2e = host wall clock from IQ in HBM to packets in the decoder's layout in HBM; e2e_host = the same to packets in host memory
@@ -368,7 +380,8 @@ def section_level3(env, L, sf):
            "frac_e2e": r4(calls * L.bytes_per_symbol(sf) / best[0] / 1e9 / HBM_PEAK_GBS), "e2e_host_ms": r4(best[2] * 1e3),
            "kernel_us": r4(best[1] * 1e3), "Msym_s_kernel": r4(calls / (best[1] / 1e3) / 1e6),
            "frac_kernel": r4(calls * L.bytes_per_symbol(sf) / (best[1] / 1e3) / 1e9 / HBM_PEAK_GBS),
-           "packets": n_pk, "packets_device": n_dev, "packets_expected": B * frames, "packets_ok": ok, "staggered_starts": True}
+           "packets": n_pk, "packets_device": n_dev, "packets_expected": B * frames, "packets_ok": ok, "staggered_starts": True,
+           "from_host_ms": r4(from_host * 1e3), "from_host_GB_s": r4(iq.numel() * 8 / from_host / 1e9), "from_host_Msym_s": r4(calls / from_host / 1e6)}
     if env.rank == 0 and env.world == 1:
         # the same streams through the CPU oracle's restated block (pinned to the verbatim LoRaDemod.cpp): identical packets
         from oracle.oracle import Oracle
