@@ -12,7 +12,7 @@
 namespace lorahip {
 
 static const size_t kStageBytes = size_t(32) << 20;      // per staging buffer
-static const size_t kDirectMin = size_t(256) << 10;       // a pinned piece this large is not worth packing with its neighbours
+static const size_t kDirectMin = size_t(1) << 20;         // only pieces this large are asked whether they are pinned (a query per piece costs microseconds); smaller ones are packed
 
 static int uploadThreads()
 {

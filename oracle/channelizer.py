@@ -4,7 +4,9 @@ PARITY UNPINNED: the reference has no channeliser ("not
 its example topologies put Pothos' /comms/rotate and a decimating FIR in front of each LoRaDemod, and PothosComms is not part
 of /root/reference), so there are no golden vectors to pin this file against. It DEFINES what the kernel must compute, in
 float64, and the GPU tests hold the fp32 kernel to it within a stated tolerance; the chunk-invariance and end-to-end
-(channeliser -> demodulator recovers the sent symbols) properties do not depend on this file.
+(channeliser -> demodulator recovers the sent symbols) properties do not depend on this file. What CAN be pinned is pinned:
+tests/test_channelizer_vs_scipy.py holds this file to an independent implementation of the same textbook operations
+(translate, scipy.signal.lfilter, decimate) and its filter design to scipy.signal.firwin with the same window.
 
     n_m    = (m + 1) D - 1
     y_k[m] = sum_{j<L} h[j] x[n_m - j] exp(-2 pi i frac(w_k (n_m - j) / 2^64)),   x[n<0] = 0,  w_k = floor(frac(f_k) 2^64)
