@@ -131,7 +131,7 @@ extern "C" {
 void *lorahip_host_alloc(const size_t bytes)
 {
     void *p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 
