@@ -15,5 +15,6 @@ tail -3 gpurun_out/pytest_gpu.log > profiles/r02/${NEW}_pytest_gpu_tail.txt
 if [ -n "$OLD" ] && [ "$OLD" != "$NEW" ]; then
   git rm -q -f --ignore-unmatch profiles/r02/${OLD}_sf*_timed_steps.txt profiles/r02/${OLD}_moving_sf*_timed_steps.txt profiles/r02/${OLD}_sf*_kernel_stats.csv \
       profiles/r02/${OLD}_level3_sf*.txt profiles/r02/${OLD}_pmc_fetch_write_summary.txt profiles/r02/${OLD}_bench_default.json profiles/r02/${OLD}_pytest_gpu_tail.txt
-  sed -i "s/${OLD}_/${NEW}_/g" profiles/r02/README.md DESIGN.md README.md
+  # only references into profiles/r02 move on (r01 has files with the same session prefixes)
+  sed -i -E "s#(profiles/r01/)${OLD}_#\\1@@KEEP@@_#g; s/${OLD}_/${NEW}_/g; s#@@KEEP@@_#${OLD}_#g" profiles/r02/README.md DESIGN.md README.md
 fi
