@@ -61,6 +61,7 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     v2f *sX = sCh + C::CH_ELEMS;                                                      // [WAVES][XW]
     TailRec *sTail = reinterpret_cast<TailRec *>(sX + WAVES * XW);                       // [WAVES]
     double2 *sFine = reinterpret_cast<double2 *>(sTail + WAVES);                         // split fine-tune tables (non-UNI kernels)
+    static_assert(((size_t(C::TWN + C::CH_ELEMS + WAVES * XW) * sizeof(v2f) + WAVES * sizeof(TailRec)) & 15) == 0, "the split tables are read with ds_read_b128");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR

@@ -39,6 +39,7 @@ demodStream(const StreamArgs s)
     v2f *sCh = sTw + C::TWN;                                // [N] down-chirp table (the up-chirp is its conjugate)
     v2f *sX = sCh + N;                                      // [WAVES][XW]
     double2 *sFine = reinterpret_cast<double2 *>(sX + WAVES * XW);   // split fine-tune tables (lorahip_fine.h)
+    static_assert(((size_t(C::TWN + N + WAVES * XW) * sizeof(v2f)) & 15) == 0, "the split tables are read with ds_read_b128");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -649,6 +649,7 @@ demodStreamWide(const StreamArgs s)
     v2f *sNb = reinterpret_cast<v2f *>(sRed + 4);                        // [2]
     int *sChain = reinterpret_cast<int *>(sNb + 2);                      // [12] fineChainBlock scratch
     double2 *sFine = reinterpret_cast<double2 *>(sChain + 12);           // split fine-tune tables (lorahip_fine.h)
+    static_assert(((size_t(C::TWN + C::XW) * sizeof(v2f) + 4 * sizeof(RedRec) + 2 * sizeof(v2f) + 12 * sizeof(int)) & 15) == 0, "the split tables are read with ds_read_b128");
 
     const int t = threadIdx.x;
     const int lane = t & 63;
