@@ -417,8 +417,9 @@ static const FastVariant kFastVariants[] = {
     V(6, 10, CH_REG | NT),
     V(7, 0, CH_REG | NT),                                  // default (every shape)
     V(7, 10, 0),
-    // default SF8: uniform batches with the tables in registers, per-window settings with the tables in LDS
-    { 8, 0, &launchByShape<Fast<8, CH_REG | TW_REG | NT>, Fast<8, 0>, Fast<8, CH_REG | TW_REG | NT>> },
+    // default SF8: uniform batches with the tables in registers at three waves per SIMD, per-window settings with them at two (no
+    // prefetch: the third wave's latency hiding is worth less than the spills it costs -- session 30)
+    { 8, 0, &launchByShape<Fast<8, CH_REG | TW_REG | NT>, Fast<8, W2 | CH_REG | TW_REG | NT | PF_NONE>, Fast<8, CH_REG | TW_REG | NT>> },
     V(8, 10, 0),
     // default SF9: uniform batches on the two-phase geometry (16 lanes x 32 points), per-window settings and the debug ports on the
     // three-phase one (32 lanes x 16 points) at two waves per SIMD

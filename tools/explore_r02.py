@@ -43,7 +43,7 @@ def moving(sf, variant, steps=60):
 
 if what == "moving":
     # the shipped library knows 0 (default), 1 (generic) and 10; a --all-variants build also the round-1/2 A/B numbers
-    full = {7: [0, 30, 10], 8: [0, 30, 31, 10], 9: [0, 30, 31, 12, 16, 10, 20, 23], 10: [0, 30, 31, 16, 10], 11: [0, 30, 31, 29, 10], 12: [0, 30, 31, 2, 10]}
+    full = {7: [0, 30, 13, 10], 8: [0, 30, 31, 11, 13, 10], 9: [0, 30, 31, 12, 13, 16, 10], 10: [0, 30, 31, 12, 13, 14, 16, 10], 11: [0, 10], 12: [0, 10]}
     plan = full if os.environ.get("EXPLORE_ALL") else {sf: [0, 10] for sf in range(6, 13)}
     for sf, vs in plan.items():
         for v in vs:
