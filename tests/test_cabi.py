@@ -71,6 +71,10 @@ def test_no_gpu_fails_loudly():
         L.LoRaDetector(1024)
     with pytest.raises(L.LoraHipError):
         L.LoRaDemod(10)
+    with pytest.raises(L.LoraHipError):
+        L.MixedDetector([7, 8, 12])
+    with pytest.raises(MemoryError):                  # pinned memory comes from the HIP runtime: none without a device
+        L.pinned_empty((16,), np.complex64)
 
 
 def test_product_never_touches_oracle():
