@@ -363,15 +363,14 @@ def section_level3(env, L, sf):
     best = (best[0], best[1], one_pass(to_host=True)[2])
     # the same streams handed over as ordinary HOST buffers, one per channel (what a Pothos port gives the block): gathered through
     # the pinned double-buffered upload, then the streaming kernel -- PCIe-bound, reported beside the device-resident figures
-    host = iq.cpu().numpy()
-    rows = [host[c] for c in range(B)]
+    host = iq.cpu().numpy()                         # (B, samples): one buffer per channel for the C ABI (lorahip_demod_run)
     d.clear_packets(); d.activate()
-    d.work(rows)                                    # the device-side IQ array of the host path is allocated here
+    d.work(host)                                    # the device-side IQ array of the host path is allocated here
     d.clear_packets(); d.activate()
     t0 = time.perf_counter()
-    d.work(rows)
+    d.work(host)
     from_host = time.perf_counter() - t0
-    del host, rows
+    del host
     d.clear_packets()
     d.activate()
     n_pk, ok = WL.check_frame_packets(pk, data, 1 << sf, nsyms)

@@ -494,8 +494,8 @@ class LoRaDemod:
 
     def work(self, streams):
         """Feed one complete input stream per channel and run work() until < 2N samples remain
-        everywhere. streams: list of complex64 numpy arrays, or ONE torch complex64 device tensor
-        of shape (n_channels, samples). Returns the number of lock-step rounds."""
+        everywhere. streams: list of complex64 numpy arrays (one per channel, any lengths), ONE numpy array of shape
+        (n_channels, samples) in host memory, or ONE torch complex64 device tensor of that shape. Returns the number of lock-step rounds."""
         rounds = C.c_int64()
         if _is_torch(streams):
             if streams.dim() != 2 or streams.shape[0] != self.n_channels:
@@ -510,6 +510,16 @@ class LoRaDemod:
             finally:
                 # torch may destroy that stream later: later calls (numpy work(), packets_device()) use the private one again
                 self._lib.lorahip_demod_reset_stream(self._h)
+            return rounds.value
+        if isinstance(streams, np.ndarray) and streams.ndim == 2:
+            # one (n_channels, samples) host array: the per-channel pointers without a Python loop
+            if streams.shape[0] != self.n_channels:
+                raise ValueError("expected a (n_channels, samples) array")
+            a = np.ascontiguousarray(streams, np.complex64)
+            ptrs = (np.uint64(a.ctypes.data) + np.arange(self.n_channels, dtype=np.uint64) * np.uint64(a.strides[0]))
+            lens = np.full(self.n_channels, a.shape[1], dtype=np.uint64)
+            check(self._lib.lorahip_demod_run(self._h, ptrs.ctypes.data_as(C.POINTER(C.c_void_p)), lens.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                              C.byref(rounds)), "lorahip_demod_run")
             return rounds.value
         if len(streams) != self.n_channels:
             raise ValueError("expected %d streams" % self.n_channels)

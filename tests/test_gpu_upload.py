@@ -59,6 +59,29 @@ def test_demod_streams_from_host_memory_of_both_kinds(gpu, oracle):
     d.close()
 
 
+def test_demod_takes_one_2d_host_array(gpu, oracle):
+    """(n_channels, samples) in host memory: per-channel pointers computed without a Python loop -- same packets as the list form"""
+    import lora_sdr_amd as L
+    from test_gpu_demod import frames
+    rng = np.random.default_rng(5)
+    sf, B = 7, 33
+    rows = [frames(oracle, rng, sf, 2, 5, off=rng.uniform(-0.3, 0.3), noise=0.05, lead=100 + c)[0] for c in range(B)]
+    n = min(r.size for r in rows)
+    arr = np.stack([r[:n] for r in rows])
+    a = L.LoRaDemod(sf, n_channels=B); a.set_mode(1); a.setMTU(5)
+    a.work([arr[c] for c in range(B)])
+    want = a.packets()
+    b = L.LoRaDemod(sf, n_channels=B); b.set_mode(1); b.setMTU(5)
+    b.work(arr)
+    got = b.packets()
+    assert len(got) == len(want) > 0
+    for (c0, r0, s0), (c1, r1, s1) in zip(want, got):
+        assert c0 == c1 and r0 == r1 and np.array_equal(s0, s1)
+    with pytest.raises(ValueError):
+        b.work(arr[:-1])
+    a.close(); b.close()
+
+
 def test_pinned_allocation_round_trip():
     import lora_sdr_amd as L
     a = L.pinned_empty((3, 5), np.float32)
