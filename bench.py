@@ -316,7 +316,80 @@ def traffic_for(sf, a):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def section_level3(env, L, sf):
+def level3_parity(L, sf, iq, host, nsyms, gpu_packets, data, gpu_not_ok, threads):
+    """EVERY channel of the level-3 workload through the CPU reference block (oracle/_ref: the verbatim LoRaDemod.cpp, one fresh
+    block per channel; the pinned restatement where _ref did not travel) on the same IQ: packets compared symbol for symbol, then --
+    from one extra, untimed, traced pass of the streaming kernel -- every work() call's consumption and label kind
+    (LoRaDemod.cpp:213-232,245,282,302-320), i.e. the frame machine's path call by call. Also answers why packets_ok < packets:
+    the reference's own packets are held to the same "carries the sent symbols" test."""
+    import numpy as np
+    from lora_sdr_amd import workloads as WL
+    from oracle.oracle import Oracle, Ref
+    impl, kind = (Ref(), "reference") if Ref.available() else (Oracle(), "port")
+    B, N = host.shape[0], 1 << sf
+    t0 = time.perf_counter()
+    r = impl.demod_run_many(sf, host, mtu=nsyms, nthreads=threads, calls=True)
+    cpu_s = time.perf_counter() - t0
+    ch, _rd, ln, sy = gpu_packets
+    # the device's packets per channel in time order, laid out like the reference's arrays
+    order = np.argsort(ch, kind="stable")
+    start = np.concatenate([[0], np.cumsum(ln)])[:-1]
+    n_gpu = np.bincount(ch, minlength=B).astype(np.int32)
+    first = np.concatenate([[0], np.cumsum(n_gpu)])[:-1]
+    g_syms = np.zeros_like(r["pkt_syms"])
+    g_lens = np.zeros_like(r["pkt_lens"])
+    overflow = 0
+    fill = np.zeros(B, np.int64)
+    for k, p in enumerate(order.tolist()):
+        c = int(ch[p]); j = k - int(first[c]); n = int(ln[p])
+        if j >= g_lens.shape[1] or fill[c] + n > g_syms.shape[1]:
+            overflow += 1
+            continue
+        g_lens[c, j] = n
+        g_syms[c, fill[c]:fill[c] + n] = sy[start[p]:start[p] + n]
+        fill[c] += n
+    bad_ch = (n_gpu != r["n_packets"]) | (g_lens != r["pkt_lens"]).any(axis=1) | (g_syms != r["pkt_syms"]).any(axis=1)
+    # the reference's packets under the test packets_ok applies to the device's
+    ref_pk = []
+    for c in range(B):
+        at = 0
+        for j in range(int(r["n_packets"][c])):
+            n = int(r["pkt_lens"][c, j])
+            ref_pk.append((c, 0, r["pkt_syms"][c, at:at + n]))
+            at += n
+    n_ref, ok_ref = WL.check_frame_packets(ref_pk, data, N, nsyms)
+    out = {"oracle_kind": kind, "oracle_channels_checked": int(B), "oracle_channel_mismatches": int(bad_ch.sum()) + overflow,
+           "oracle_packets": int(n_ref), "packets_not_ok": int(gpu_not_ok), "packets_not_ok_in_reference_too": int(n_ref - ok_ref),
+           "oracle_cpu_s": r4(cpu_s)}
+    # one traced pass: per call consumed + label kind
+    dt = L.LoRaDemod(sf, n_channels=B, device=iq.device.index or 0)
+    dt.set_mode(1)
+    dt.setMTU(nsyms)
+    dt.set_trace(True)
+    dt.work(iq)
+    thresh = np.float32(-30.0)                                          # LoRaDemod.cpp:72 (default, as in the timed passes)
+    call_bad = calls_cmp = ch_bad = 0
+    for c in range(B):
+        t = dt.trace_array(c)
+        n = int(r["n_calls"][c])
+        st, co = t["state_before"], t["consumed"]
+        cls = np.where(st == 0, np.where(co == 2 * N, 1, np.where(~(t["snr"] < thresh), 2, 0)),
+                       np.where(st == 1, 3, np.where(st == 2, 0, np.where(st == 3, 4, 5)))).astype(np.uint8)
+        if t.size != n:
+            ch_bad += 1
+            call_bad += abs(int(t.size) - n)
+            continue
+        d_ = int(((co != r["consumed"][c, :n]) | (cls != r["cls"][c, :n])).sum())
+        call_bad += d_
+        ch_bad += int(d_ != 0)
+        calls_cmp += n
+    out.update({"trace_calls_compared": int(calls_cmp), "trace_call_mismatches": int(call_bad), "trace_channel_mismatches": int(ch_bad),
+                "trace_near_squelch": dt.near_threshold()[0], "trace_near_step": dt.near_threshold()[1]})
+    dt.close()
+    return out
+
+
+def section_level3(env, L, sf, threads=32):
     """B channels of the LoRaDemod block over whole frames through the streaming kernel (tools/bench_demod.py's workload)"""
     import numpy as np
     from lora_sdr_amd import workloads as WL
@@ -329,6 +402,7 @@ def section_level3(env, L, sf):
     d.setMTU(nsyms)
     # pass 0: what the demodulator delivers (checked below); also allocates its staging buffers
     d.work(iq)
+    near = d.near_threshold()
     ps, pn, pc = d.packets_device(clear=False)
     calls = d.work_calls()
     ch_, rd_, ln_, sy_ = d.packets_arrays()
@@ -370,7 +444,6 @@ def section_level3(env, L, sf):
     t0 = time.perf_counter()
     d.work(host)
     from_host = time.perf_counter() - t0
-    del host
     d.clear_packets()
     d.activate()
     n_pk, ok = WL.check_frame_packets(pk, data, 1 << sf, nsyms)
@@ -381,22 +454,10 @@ def section_level3(env, L, sf):
            "frac_kernel": r4(calls * L.bytes_per_symbol(sf) / (best[1] / 1e3) / 1e9 / HBM_PEAK_GBS),
            "packets": n_pk, "packets_device": n_dev, "packets_expected": B * frames, "packets_ok": ok, "staggered_starts": True,
            "from_host_ms": r4(from_host * 1e3), "from_host_GB_s": r4(iq.numel() * 8 / from_host / 1e9), "from_host_Msym_s": r4(calls / from_host / 1e6)}
+    res["near_squelch"], res["near_step"] = near                       # decisions within float rounding of their boundary (pass 0)
     if env.rank == 0 and env.world == 1:
-        # the same streams through the CPU oracle's restated block (pinned to the verbatim LoRaDemod.cpp): identical packets
-        from oracle.oracle import Oracle
-        orc = Oracle()
-        by_ch = {}
-        for ch, _rd, s in pk:
-            by_ch.setdefault(ch, []).append(s)
-        bad = 0
-        chk = list(range(0, min(B, 8)))
-        for c in chk:
-            r = orc.demod_run(sf, iq[c].cpu().numpy(), mtu=nsyms, keep=False)
-            want = [p for _c, p in r["packets"]]
-            got = by_ch.get(c, [])
-            bad += int(len(want) != len(got) or any(not np.array_equal(x, y) for x, y in zip(want, got)))
-        res["oracle_channels_checked"] = len(chk)
-        res["oracle_channel_mismatches"] = bad
+        res.update(level3_parity(L, sf, iq, host, nsyms, (ch_, rd_, ln_, sy_), data, n_pk - ok, threads))
+    del host
     d.close()
     ctx.close()
     del iq
@@ -640,7 +701,7 @@ def main():
         env.torch.cuda.empty_cache()
         if env.world == 1:
             for sf in range(7, 13):
-                level3.append(section_level3(env, L, sf))
+                level3.append(section_level3(env, L, sf, threads))
                 env.torch.cuda.empty_cache()
         c5 = section_config5(env, L, a, threads) if env.world == 1 else None
         env.torch.cuda.empty_cache()

@@ -273,6 +273,17 @@ int64_t lorahip_demod_work_calls(const lorahip_demod *d);
 /* device time of the streaming kernel launches of the last lorahip_demod_run[_device] (HIP events on the launch stream; 0 in the
  * host-driven mode): what the level-3 roofline line of bench.py is computed from */
 double lorahip_demod_kernel_ms(const lorahip_demod *d);
+/* The runtime signal for the caveat at the top of this section: how many decisions since the last activate() sat so close to their
+ * boundary that the last-place differences between this library's power / powerAvg / fIndex and a CPU build's could have flipped
+ * them. Counted, never altered.
+ *   near_squelch : work() calls in FRAMESYNC / DATASYMBOLS (the states that consume `snr < thresh`, LoRaDemod.cpp:174,217,291)
+ *                  with |snr - thresh| <= 4e-5 dB
+ *   near_step    : windows dechirped with a moving fine-tune index whose step _finefreqError * 128 (LoRaDemod.cpp:160) lies
+ *                  within 6e-5 of an integer, i.e. where a last-place difference in the fIndex values accumulated in
+ *                  _finefreqError (:219) would move the reference's int <- float truncation
+ * Both 0 means: every branch taken has a margin far above float rounding, so the identity with the CPU block holds by margin for
+ * that run, not only by observation. Either pointer may be NULL. */
+int lorahip_demod_near_threshold(const lorahip_demod *d, int64_t *near_squelch, int64_t *near_step);
 /* Debug ports of the block, opt-in like the trace (they triple the HBM traffic): what LoRaDemod::work() writes to its "raw", "dec"
  * and "fft" outputs (LoRaDemod.cpp:81-83,163-164,172,320-324), per channel, for the NEXT runs. Device buffers owned by the caller:
  *   fft_dev  [n_channels][fft_cap_frames][N] cf32   one frame of N bins per work() call: window 0's FFT (:172, produce(N) :324)

@@ -16,6 +16,14 @@ from . import _lib
 from ._lib import Batch, DecoderCfg, WorkResult, check, load, CHIRP_UP, CHIRP_DOWN, CHIRP_NONE  # noqa: F401
 
 
+# lorahip_work_result as a numpy record (include/lorahip.h)
+WORK_RESULT_DTYPE = np.dtype([("consumed", np.int64), ("state_before", np.int32), ("value", np.int32), ("power", np.float32),
+                              ("power_avg", np.float32), ("snr", np.float32), ("f_index", np.float32), ("worked", np.int32),
+                              ("packet_len", np.int32), ("signals", np.int32), ("sig_error", np.int32), ("sig_power", np.float32),
+                              ("sig_snr", np.float32), ("fine_idx_before", np.int32), ("fine_idx_after", np.int32),
+                              ("fine_err_before", np.float32), ("reserved", np.int32)])
+
+
 def host_tables(sf, fine=True):
     """(up, down, fine, twiddle) exactly as the reference builds them -- pure host code."""
     lib = load()
@@ -585,6 +593,13 @@ class LoRaDemod:
         """device time of the streaming kernel launches of the last work() (HIP events on the launch stream)"""
         return float(self._lib.lorahip_demod_kernel_ms(self._h))
 
+    def near_threshold(self):
+        """(near_squelch, near_step): decisions since activate() that sat within float rounding of their boundary -- |snr - thresh|
+        <= 4e-5 dB where the squelch is consumed, fine-tune steps within 6e-5 of an integer (include/lorahip.h). Counted, not changed."""
+        a, b = C.c_int64(), C.c_int64()
+        check(self._lib.lorahip_demod_near_threshold(self._h, C.byref(a), C.byref(b)), "lorahip_demod_near_threshold")
+        return a.value, b.value
+
     def set_fine_gather(self, on):
         """A/B switch: read the fine-tune table in HBM instead of evaluating it from the split tables (include/lorahip.h)"""
         check(self._lib.lorahip_demod_set_fine_gather(self._h, int(bool(on))), "lorahip_demod_set_fine_gather")
@@ -633,6 +648,14 @@ class LoRaDemod:
                     dec=None if b["dec"] is None else b["dec"][channel, :min(nd.value, b["dec"].shape[1])],
                     raw=None if b["raw"] is None else b["raw"][channel, :min(nr.value, b["raw"].shape[1])],
                     produced=dict(fft=nf.value, dec=nd.value, raw=nr.value))
+
+    def trace_array(self, channel):
+        """the per-call trace of `channel` as one numpy structured array (fields of lorahip_work_result): no per-call Python objects"""
+        n = self._lib.lorahip_demod_trace_len(self._h, int(channel))
+        arr = np.zeros(n, dtype=WORK_RESULT_DTYPE)
+        if n:
+            check(self._lib.lorahip_demod_get_trace(self._h, int(channel), C.cast(arr.ctypes.data, C.POINTER(WorkResult)), n), "lorahip_demod_get_trace")
+        return arr
 
     def trace(self, channel):
         n = self._lib.lorahip_demod_trace_len(self._h, int(channel))

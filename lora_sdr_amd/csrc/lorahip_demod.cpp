@@ -79,6 +79,7 @@ struct lorahip_demod
     float *ownFft, *ownDec, *ownRaw; // device mirrors owned by the library for host_buffers
     bool portsOn, userTracing;
     char *dPort; size_t dPortBytes;  // scratch of the port replay: window descriptors, replayed fft / dec windows
+    int64_t nNearSquelch, nNearStep; // decisions float rounding could flip, since activate() (lorahip_demod_near_threshold)
     void *pending;                   // PendingLaunch (records of the last streaming launch still on the device)
     std::vector<size_t> carry;       // per channel: symbols of a packet begun before the launch being drained
 };
@@ -177,6 +178,8 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
             r.power = hr.power[i]; r.power_avg = hr.pavg[i]; r.f_index = hr.fidx[i];
             r.snr = r.power - r.power_avg;                                      // :173
             r.fine_idx_before = k.fineTuneIndex; r.fine_err_before = k.finefreqError;
+            if ((k.state == ST_FRAMESYNC || k.state == ST_DATASYMBOLS) && nearSquelch(r.snr, dm->thresh)) dm->nNearSquelch++;
+            if (nearStep(k.finefreqError * float(LORAHIP_FINE_STEPS))) dm->nNearStep++;
             k.fineTuneIndex = hr.idxOut[i];
             r.fine_idx_after = k.fineTuneIndex;
             if (k.state == ST_FRAMESYNC)
@@ -197,6 +200,7 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
                 hr.sel[i] = k.downTable ? LORAHIP_CHIRP_DOWN : LORAHIP_CHIRP_UP;
                 hr.idx0[i] = k.fineTuneIndex;                                    // int ft = _fineTuneIndex  :191
                 hr.err[i] = k.finefreqError;
+                if (nearStep(k.finefreqError * float(LORAHIP_FINE_STEPS))) dm->nNearStep++;
             }
             rc = launchRound(dm, iqDev, second.size());
             if (rc != LORAHIP_OK) return rc;
@@ -333,7 +337,7 @@ struct StreamLayout
 {
     size_t B, cap, capPkt;
     bool tracing;
-    size_t oBase, oLen, oState, oN, oNSym, oNPkt, oPkt, oSym, oCalls, total;
+    size_t oBase, oLen, oState, oN, oNSym, oNPkt, oNear, oPkt, oSym, oCalls, total;
     void make(const size_t B_, const size_t cap_, const size_t capPkt_, const bool tracing_)
     {
         B = B_; cap = cap_; capPkt = capPkt_; tracing = tracing_;
@@ -342,6 +346,7 @@ struct StreamLayout
         oBase = carve(B * sizeof(long long)); oLen = carve(B * sizeof(long long));
         oState = carve(B * sizeof(StreamState));
         oN = carve(B * sizeof(int)); oNSym = carve(B * sizeof(int)); oNPkt = carve(B * sizeof(int));
+        oNear = carve(2 * sizeof(unsigned));
         oPkt = carve(B * capPkt * sizeof(StreamPacket));
         oSym = carve(B * cap * sizeof(short));
         oCalls = carve(tracing ? B * cap * sizeof(lorahip_work_result) : 0);
@@ -560,6 +565,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.thresh = dm->thresh;
     a.sync = dm->sync;
     a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
+    a.near = reinterpret_cast<unsigned *>(d + L.oNear);
 
     const size_t firstNewPacket = dm->packets.size();
     const Clock::time_point t1 = Clock::now();
@@ -570,6 +576,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     while (true)
     {
         const Clock::time_point ta = Clock::now();
+        LORAHIP_TRY(hipMemsetAsync(d + L.oNear, 0, 2 * sizeof(unsigned), ctx->stream));
         LORAHIP_TRY(hipEventRecord(dm->evK0, ctx->stream));
         LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
         LORAHIP_TRY(hipEventRecord(dm->evK1, ctx->stream));
@@ -581,6 +588,8 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         tDev += std::chrono::duration<double>(tb - ta).count();
         bool more = false;
         pendPackets = pendNSym = 0;
+        dm->nNearSquelch += reinterpret_cast<const unsigned *>(h + L.oNear)[0];
+        dm->nNearStep += reinterpret_cast<const unsigned *>(h + L.oNear)[1];
         for (size_t c = 0; c < B; c++)
         {
             dm->workCalls += hN[c];
@@ -827,6 +836,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->sync = 0x12; dm->thresh = -30.0f; dm->mtu = 256;        // LoRaDemod.cpp:71-73
     dm->tracing = false;
     dm->workCalls = 0;
+    dm->nNearSquelch = dm->nNearStep = 0;
     dm->ch.resize(n_channels);
     for (auto &k : dm->ch) { k.traceStart = 0; k.traceSymCount0 = 0; k.portFft = k.portDec = k.portRaw = 0; }
     dm->stageBytes = carve(nullptr, n_channels).total;
@@ -922,6 +932,7 @@ int lorahip_demod_activate(lorahip_demod *dm)
     // activate() resets only _state and _chirpTable (:139-143); everything else keeps the
     // constructor / zero state, or whatever the previous activation left
     for (auto &k : dm->ch) { k.state = ST_FRAMESYNC; k.downTable = false; }
+    dm->nNearSquelch = dm->nNearStep = 0;
     return LORAHIP_OK;
 }
 
@@ -1102,6 +1113,14 @@ void lorahip_demod_clear_packets(lorahip_demod *dm)
 int64_t lorahip_demod_work_calls(const lorahip_demod *dm) { return dm ? dm->workCalls : 0; }
 
 double lorahip_demod_kernel_ms(const lorahip_demod *dm) { return dm ? dm->kernelMs : 0.0; }
+
+int lorahip_demod_near_threshold(const lorahip_demod *dm, int64_t *near_squelch, int64_t *near_step)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (near_squelch) *near_squelch = dm->nNearSquelch;
+    if (near_step) *near_step = dm->nNearStep;
+    return LORAHIP_OK;
+}
 
 int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
 {

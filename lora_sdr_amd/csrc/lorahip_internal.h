@@ -73,6 +73,31 @@ struct StreamState
     long long pos;          // samples consumed so far
 };
 
+/* Decisions that the last-ulp differences between this library's power / powerAvg / fIndex and the CPU build's could flip
+ * (include/lorahip.h, lorahip_demod_near_threshold). They are COUNTED, never changed:
+ *   squelch: `snr < thresh` (LoRaDemod.cpp:174) consumed by FRAMESYNC / DATASYMBOLS with |snr - thresh| <= 4e-5 dB (twice the
+ *            tolerance the tests hold power and powerAvg to);
+ *   step:    a window dechirped with a moving index whose step d = _finefreqError * 128 (:160) lies within 6e-5 of an integer,
+ *            where ceil(d) / floor(d) -- the closed form's increment, i.e. where the reference's truncation falls -- would change
+ *            if the fIndex values accumulated in _finefreqError (:219) differed in their last place (1 ulp of 0.5 bins * 128
+ *            steps * up to 16 accumulations). */
+#define LORAHIP_NEAR_SNR_DB 4e-5f
+#define LORAHIP_NEAR_STEP 6e-5f
+__host__ __device__ inline bool nearSquelch(const float snr, const float thresh)
+{
+    const float m = snr - thresh;
+    return (m < 0.0f ? -m : m) <= LORAHIP_NEAR_SNR_DB;
+}
+__host__ __device__ inline bool nearStep(const float d)
+{
+    if (d == 0.0f || !(d == d)) return false;
+    const float a = d < 0.0f ? -d : d;
+    if (a >= 8388608.0f) return true;                      // every float this large is an integer
+    const float r = float(int(a + 0.5f));
+    const float m = a - r;
+    return (m < 0.0f ? -m : m) <= LORAHIP_NEAR_STEP;
+}
+
 //! one posted packet: the call (round) it was posted in and its length; its symbols are the next `len` entries
 //! of the channel's symbol stream (after what earlier launches carried over)
 struct StreamPacket { int callIndex; int len; };
@@ -99,6 +124,7 @@ struct StreamArgs
     float thresh;
     int sync;
     unsigned mtu;
+    unsigned *near;             // [2] decisions float rounding could flip (lorahip_demod_near_threshold): squelch margins, fine-tune steps
 };
 
 //! argument block of the batched decoder (lorahip_codec.hip); device pointers

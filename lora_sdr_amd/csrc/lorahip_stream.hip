@@ -117,6 +117,7 @@ demodStream(const StreamArgs s)
                 __builtin_amdgcn_wave_barrier();
             }
             if (moving) idxEnd = e;
+            if (moving && t == 0 && nearStep(d)) atomicAdd(s.near + 1, 1u);          // counted, not changed (lorahip_internal.h)
         }
         TMARK_NOWAIT(0);
         TMARK(1);
@@ -158,6 +159,7 @@ demodStream(const StreamArgs s)
             __builtin_amdgcn_wave_barrier();
             tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
             squelched = (power - powerAvg) < s.thresh;                                   // :173-174
+            if (on && wantSq && t == 0 && nearSquelch(power - powerAvg, s.thresh)) atomicAdd(s.near, 1u);
         }
         else
         {
@@ -181,6 +183,7 @@ demodStream(const StreamArgs s)
                 {
                     tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
                     squelched = (power - powerAvg) < s.thresh;                           // the quick decision where it was sure, by construction
+                    if (exact && t == 0 && nearSquelch(power - powerAvg, s.thresh)) atomicAdd(s.near, 1u);
                     power = powerAvg = 0.0f;
                 }
                 else fIndex = fIndexPaired(bestV, l, r, lane);

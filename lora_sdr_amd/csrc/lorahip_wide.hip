@@ -720,6 +720,7 @@ demodStreamWide(const StreamArgs s)
             const unsigned ymax = fineLaneIndices<LOG2N, VEC, T, R>(idx0, pl, t, yv);
             idxEnd = fineEndIndex(idx0, pl, LOG2N, LOG2N + 7);
             usedChain = !pl.regular || __syncthreads_or(ymax == (unsigned)M);
+            if (t == 0 && nearStep(d)) atomicAdd(s.near + 1, 1u);                    // counted, not changed (lorahip_internal.h)
             if (usedChain)
             {
                 idxEnd = fineChainBlock<T, M>(idx0, d, t, t >> 6, sIdx, sChain);
@@ -824,6 +825,7 @@ demodStreamWide(const StreamArgs s)
             {
                 tailValuesPaired(s.powerScale, bestV, tot, sNb[0], sNb[1], lane, power, powerAvg, fIndex);
                 squelched = (power - powerAvg) < s.thresh;                                   // :173-174
+                if (wantSq && t == 0 && nearSquelch(power - powerAvg, s.thresh)) atomicAdd(s.near, 1u);
                 if (!all) power = powerAvg = 0.0f;
             }
             else fIndex = fIndexPaired(bestV, sNb[0], sNb[1], lane);

@@ -536,3 +536,93 @@ int64_t lo_demod_bench(int sf, const lo_cf32 *iq, size_t samplesPerStream, int n
     free(jobs); free(th);
     return total;
 }
+
+/***********************************************************************
+ * Parity aid at scale (the restatement's twin of oracle/ref_driver.cpp::loraref_demod_run_many, same argument meaning): nStreams
+ * independent streams, every one from the zero start state, over nthreads. callClass: 0 no label, 1 "SYNC", 2 "P ..", 3 "DC",
+ * 4 "QC", 5 "S<n> .." (LoRaDemod.cpp:213,220-224,245,282,302-305).
+ **********************************************************************/
+typedef struct {
+    int sf; const lo_cf32 *iq; size_t sps; int lo, hi;
+    int sync; double thresh; size_t mtu;
+    int32_t *nCalls, *nPackets; int16_t *pktSyms; size_t symCap; int32_t *pktLens, *pktCall; size_t pktCap;
+    int32_t *callConsumed; uint8_t *callClass; size_t callCap;
+    int bad;
+} many_job;
+
+static void *many_body(void *arg)
+{
+    many_job *j = (many_job *)arg;
+    lo_demod *d = lo_demod_new(j->sf);
+    lo_demod_set_sync(d, (unsigned char)j->sync);
+    lo_demod_set_threshold(d, j->thresh);
+    lo_demod_set_mtu(d, j->mtu);
+    int16_t *pkt = (int16_t *)calloc(j->mtu ? j->mtu : 1, sizeof(int16_t));
+    for (int s = j->lo; s < j->hi; s++) {
+        lo_demod_activate(d);
+        d->prevValue = 0; d->freqError = 0; d->fineTuneIndex = 0; d->finefreqError = 0; d->symCount = 0;
+        const lo_cf32 *in = j->iq + (size_t)s * j->sps;
+        size_t pos = 0, at = 0, np = 0, calls = 0;
+        int ok = 1;
+        lo_work_result r;
+        while (lo_demod_work(d, in + pos, j->sps - pos, &r, NULL, NULL, pkt)) {
+            if (j->callConsumed || j->callClass) {
+                if (calls >= j->callCap) ok = 0;
+                else {
+                    if (j->callConsumed) j->callConsumed[(size_t)s * j->callCap + calls] = (int32_t)r.consumed;
+                    if (j->callClass) {
+                        uint8_t c = 0;
+                        if (r.label[0] == 'S' && r.label[1] == 'Y') c = 1;
+                        else if (r.label[0] == 'P') c = 2;
+                        else if (r.label[0] == 'D') c = 3;
+                        else if (r.label[0] == 'Q') c = 4;
+                        else if (r.label[0] == 'S') c = 5;
+                        j->callClass[(size_t)s * j->callCap + calls] = c;
+                    }
+                }
+            }
+            if (r.packetPosted) {
+                if (np >= j->pktCap || at + (size_t)r.packetLen > j->symCap) ok = 0;
+                else {
+                    memcpy(j->pktSyms + (size_t)s * j->symCap + at, pkt, (size_t)r.packetLen * sizeof(int16_t));
+                    j->pktLens[(size_t)s * j->pktCap + np] = r.packetLen;
+                    if (j->pktCall) j->pktCall[(size_t)s * j->pktCap + np] = (int32_t)calls;
+                    at += (size_t)r.packetLen;
+                }
+                np++;
+            }
+            calls++;
+            pos += (size_t)r.consumed;
+            if (!r.consumed) break;
+        }
+        j->nCalls[s] = (int32_t)calls;
+        j->nPackets[s] = ok ? (int32_t)np : -1;
+        if (!ok) j->bad = 1;
+    }
+    free(pkt);
+    lo_demod_free(d);
+    return NULL;
+}
+
+int64_t lo_demod_run_many(int sf, const lo_cf32 *iq, size_t samplesPerStream, int nStreams, int nthreads,
+                          int sync, double thresh, size_t mtu,
+                          int32_t *nCalls, int32_t *nPackets, int16_t *pktSyms, size_t symCap,
+                          int32_t *pktLens, int32_t *pktCall, size_t pktCap,
+                          int32_t *callConsumed, uint8_t *callClass, size_t callCap)
+{
+    const int T = nthreads > 1 ? nthreads : 1;
+    many_job *jobs = (many_job *)calloc((size_t)T, sizeof(many_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
+    for (int t = 0; t < T; t++) {
+        many_job j = { sf, iq, samplesPerStream, nStreams * t / T, nStreams * (t + 1) / T, sync, thresh, mtu,
+                       nCalls, nPackets, pktSyms, symCap, pktLens, pktCall, pktCap, callConsumed, callClass, callCap, 0 };
+        jobs[t] = j;
+        if (T == 1) many_body(&jobs[t]); else pthread_create(&th[t], NULL, many_body, &jobs[t]);
+    }
+    int64_t total = 0;
+    int bad = 0;
+    for (int t = 0; t < T; t++) { if (T > 1) pthread_join(th[t], NULL); bad |= jobs[t].bad; }
+    for (int s = 0; s < nStreams; s++) total += nCalls[s];
+    free(jobs); free(th);
+    return bad ? -1 : total;
+}

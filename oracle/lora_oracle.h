@@ -91,6 +91,14 @@ int lo_demod_work(lo_demod *d, const lo_cf32 *in, size_t avail, lo_work_result *
  * every stream is processed `repeat` times (fresh block each time); returns the total number
  * of work() calls (= windows dechirped+FFT'd+scanned). */
 int64_t lo_demod_bench(int sf, const lo_cf32 *iq, size_t samplesPerStream, int nStreams, int nthreads, int repeat);
+/* Parity aid at scale: nStreams independent streams from the zero start state; per stream its call count, its packets (lengths,
+ * posting call, symbols back to back) and optionally per call what it consumed and the kind of label it posted (0 none, 1 SYNC,
+ * 2 P, 3 DC, 4 QC, 5 S<n>). Returns the total number of calls, -1 if a capacity was too small (that stream's nPackets = -1). */
+int64_t lo_demod_run_many(int sf, const lo_cf32 *iq, size_t samplesPerStream, int nStreams, int nthreads,
+                          int sync, double thresh, size_t mtu,
+                          int32_t *nCalls, int32_t *nPackets, int16_t *pktSyms, size_t symCap,
+                          int32_t *pktLens, int32_t *pktCall, size_t pktCap,
+                          int32_t *callConsumed, uint8_t *callClass, size_t callCap);
 
 
 /* ---- receive-side codec (oracle/lora_codec.c): the LoRaDecoder block, LoRaDecoder.cpp:196-397 ---- */

@@ -236,6 +236,43 @@ class Oracle:
         iq = _cf(iq)
         return int(self.L.lo_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads, repeat))
 
+    def demod_run_many(self, sf, iq, sync=0x12, thresh=-30.0, mtu=256, nthreads=1, calls=False):
+        """the restated block over every row of a (streams, samples) array: see run_many()"""
+        return run_many(self.L.lo_demod_run_many, sf, iq, sync, thresh, mtu, nthreads, calls)
+
+
+def run_many(fn, sf, iq, sync, thresh, mtu, nthreads, calls):
+    """lo_demod_run_many / loraref_demod_run_many over a (streams, samples) complex64 array, every stream from the zero start
+    state -> dict: n_calls (S,), n_packets (S,), pkt_lens (S, pktCap), pkt_call (S, pktCap), pkt_syms (S, symCap) with a stream's
+    packets back to back, and with calls=True consumed (S, callCap) int32 and cls (S, callCap) uint8 per work() call (0 no label,
+    1 SYNC, 2 P, 3 DC, 4 QC, 5 S<n>)."""
+    iq = _cf(iq)
+    assert iq.ndim == 2
+    S, n = iq.shape
+    N = 1 << sf
+    # an unsquelched FRAMESYNC call consumes N - value (LoRaDemod.cpp:219), N/2 on average over noise: 4 calls per N samples is ample
+    # (the C side reports an overflow instead of truncating)
+    call_cap = 4 * (n // N) + 64 if calls else 1
+    sym_cap = n // N + 8
+    pkt_cap = n // (5 * N // 4) + 8
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_size_t if fn.__name__.startswith("loraref") else C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                   C.c_double, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                   C.c_void_p, C.c_void_p, C.c_size_t]
+    n_calls = np.zeros(S, np.int32)
+    n_packets = np.zeros(S, np.int32)
+    pkt_syms = np.zeros((S, sym_cap), np.int16)
+    pkt_lens = np.zeros((S, pkt_cap), np.int32)
+    pkt_call = np.zeros((S, pkt_cap), np.int32)
+    consumed = np.zeros((S, call_cap), np.int32) if calls else None
+    cls = np.zeros((S, call_cap), np.uint8) if calls else None
+    total = fn(sf, iq.ctypes.data, n, S, int(nthreads), int(sync), float(thresh), int(mtu), n_calls.ctypes.data, n_packets.ctypes.data,
+               pkt_syms.ctypes.data, sym_cap, pkt_lens.ctypes.data, pkt_call.ctypes.data, pkt_cap,
+               consumed.ctypes.data if calls else None, cls.ctypes.data if calls else None, call_cap)
+    assert total >= 0, "run_many: a per-stream capacity was too small"
+    return dict(total_calls=int(total), n_calls=n_calls, n_packets=n_packets, pkt_lens=pkt_lens, pkt_call=pkt_call, pkt_syms=pkt_syms,
+                consumed=consumed, cls=cls)
+
 
 CR_TO_RDD = {"4/4": 0, "4/5": 1, "4/6": 2, "4/7": 3, "4/8": 4}
 
@@ -396,6 +433,10 @@ class Ref:
     def demod_bench(self, sf, iq, samples_per_stream, n_streams, nthreads, repeat=1):
         iq = _cf(iq)
         return int(self.L.loraref_demod_bench(sf, iq.ctypes.data, samples_per_stream, n_streams, nthreads, repeat))
+
+    def demod_run_many(self, sf, iq, sync=0x12, thresh=-30.0, mtu=256, nthreads=1, calls=False):
+        """the verbatim LoRaDemod.cpp, one fresh block per row of a (streams, samples) array: see run_many()"""
+        return run_many(self.L.loraref_demod_run_many, sf, iq, sync, thresh, mtu, nthreads, calls)
 
 
 class DropInBatch:

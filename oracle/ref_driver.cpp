@@ -50,7 +50,8 @@ struct DemodHandle
     std::vector<std::vector<int16_t>> packets;
     std::vector<int64_t> packetCall;    // call index that posted each packet
     std::vector<Pothos::SignalRecord> signals;
-    bool keepBuffers;
+    int keepBuffers;                    // 0: count only, 1: consumed + labels + fft/dec snapshots per call, 2: consumed + labels only
+    int64_t callsMade;                  // work() calls since the handle was created
 };
 
 } // namespace
@@ -114,7 +115,8 @@ void *loraref_demod_new(const size_t sf, const int keepBuffers)
     auto h = new DemodHandle();
     h->block = it->second(sf);
     h->N = size_t(1) << sf;
-    h->keepBuffers = keepBuffers != 0;
+    h->keepBuffers = keepBuffers;
+    h->callsMade = 0;
     //the buffer-manager hooks set the reserves (LoRaDemod.cpp:330-358)
     h->block->getInputBufferManager("0", "");
     h->block->getOutputBufferManager("raw", "");
@@ -164,10 +166,14 @@ int64_t loraref_demod_run(void *p, const float *iq, const size_t nSamples)
         const size_t nMsgs = out0->messages.size();
         h->block->work();
         calls++;
+        h->callsMade++;
         if (h->keepBuffers)
         {
             h->consumed.push_back(int64_t(in->consumed));
             h->labels.push_back(raw->labels.size() > nLabels ? raw->labels.back().id : std::string());
+        }
+        if (h->keepBuffers == 1)
+        {
             auto f = reinterpret_cast<const float *>(h->fft.data());
             h->fftLog.insert(h->fftLog.end(), f, f + 2 * h->N);
             auto d = reinterpret_cast<const float *>(h->dec.data());
@@ -179,7 +185,7 @@ int64_t loraref_demod_run(void *p, const float *iq, const size_t nSamples)
             std::vector<int16_t> syms(bytes.size() / sizeof(int16_t));
             if (!syms.empty()) std::memcpy(syms.data(), bytes.data(), syms.size() * sizeof(int16_t));
             h->packets.push_back(syms);
-            h->packetCall.push_back(int64_t(h->consumed.size()) - 1);
+            h->packetCall.push_back(h->callsMade - 1);
         }
         if (!h->keepBuffers) { out0->messages.clear(); raw->labels.clear(); dec->labels.clear(); fft->labels.clear(); }
         pos += in->consumed;
@@ -261,6 +267,75 @@ int64_t loraref_demod_bench(const size_t sf, const float *iq, const size_t sampl
     for (auto &th : pool) th.join();
     int64_t total = 0;
     for (auto c : calls) total += c;
+    return total;
+}
+
+/*! Parity aid at scale: nStreams independent streams, each through a FRESH block (the zero start state the HIP path defines),
+ * split over nthreads. Per stream s: nCalls[s] work() calls, nPackets[s] packets whose lengths go to pktLens[s*pktCap + j], the
+ * posting call to pktCall[s*pktCap + j] (nullable) and whose symbols go back to back to pktSyms[s*symCap + ...]; optionally, per
+ * call, what it consumed (callConsumed[s*callCap + k]) and the kind of label it posted (callClass: 0 none, 1 "SYNC", 2 "P ..",
+ * 3 "DC", 4 "QC", 5 "S<n> .."; LoRaDemod.cpp:213,220-224,245,282,302-305). Returns the total number of calls, or -1 if a
+ * capacity was too small for some stream (that stream's nPackets is set to -1). */
+int64_t loraref_demod_run_many(const size_t sf, const float *iq, const size_t samplesPerStream, const int nStreams, const int nthreads,
+                               const int sync, const double thresh, const size_t mtu,
+                               int32_t *nCalls, int32_t *nPackets, int16_t *pktSyms, const size_t symCap,
+                               int32_t *pktLens, int32_t *pktCall, const size_t pktCap,
+                               int32_t *callConsumed, uint8_t *callClass, const size_t callCap)
+{
+    std::vector<int> bad(size_t(nthreads > 1 ? nthreads : 1), 0);
+    auto body = [&](const int tix, const int lo, const int hi)
+    {
+        for (int s = lo; s < hi; s++)
+        {
+            void *h = loraref_demod_new(sf, callConsumed || callClass ? 2 : 0);
+            auto dh = reinterpret_cast<DemodHandle *>(h);
+            dh->block->calls["setSync"](double(sync));
+            dh->block->calls["setThreshold"](thresh);
+            dh->block->calls["setMTU"](double(mtu));
+            const int64_t calls = loraref_demod_run(h, iq + 2 * size_t(s) * samplesPerStream, samplesPerStream);
+            nCalls[s] = int32_t(calls);
+            bool ok = dh->packets.size() <= pktCap;
+            size_t at = 0;
+            for (size_t j = 0; ok && j < dh->packets.size(); j++)
+            {
+                const auto &p = dh->packets[j];
+                if (at + p.size() > symCap) { ok = false; break; }
+                if (!p.empty()) std::memcpy(pktSyms + size_t(s) * symCap + at, p.data(), p.size() * sizeof(int16_t));
+                at += p.size();
+                pktLens[size_t(s) * pktCap + j] = int32_t(p.size());
+                if (pktCall) pktCall[size_t(s) * pktCap + j] = int32_t(dh->packetCall[j]);
+            }
+            if (callConsumed || callClass)
+            {
+                if (dh->consumed.size() > callCap) ok = false;
+                for (size_t k = 0; ok && k < dh->consumed.size(); k++)
+                {
+                    if (callConsumed) callConsumed[size_t(s) * callCap + k] = int32_t(dh->consumed[k]);
+                    if (callClass)
+                    {
+                        const std::string &id = dh->labels[k];
+                        uint8_t c = 0;
+                        if (id == "SYNC") c = 1;
+                        else if (id.size() && id[0] == 'P') c = 2;
+                        else if (id == "DC") c = 3;
+                        else if (id == "QC") c = 4;
+                        else if (id.size() && id[0] == 'S') c = 5;
+                        callClass[size_t(s) * callCap + k] = c;
+                    }
+                }
+            }
+            nPackets[s] = ok ? int32_t(dh->packets.size()) : -1;
+            if (!ok) bad[size_t(tix)] = 1;
+            loraref_demod_free(h);
+        }
+    };
+    const int T = nthreads > 1 ? nthreads : 1;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; t++) pool.emplace_back(body, t, nStreams * t / T, nStreams * (t + 1) / T);
+    for (auto &th : pool) th.join();
+    int64_t total = 0;
+    for (int s = 0; s < nStreams; s++) total += nCalls[s];
+    for (int b : bad) if (b) return -1;
     return total;
 }
 

@@ -197,3 +197,49 @@ def test_decoder_refuses_configurations_the_reference_cannot_decode(gpu):
     dec.setSymbolSize(0); dec.setSpreadFactor(13)
     with pytest.raises(L.LoraHipError):
         dec.work(pk)
+
+
+def loopback_case(torch, ref, cr, sigma, seed, sf=10, n_packets=5, padding=512, mtu=512):
+    """TestLoopback.cpp:66-133 with the path's blocks on the device: feeder -> encoder (verbatim LoRaEncoder.cpp through oracle/_ref:
+    not on the path) -> lorahip_mod_frames -> + lorahip_add_awgn -> streaming demodulator -> lorahip_decode_packets, and the
+    reference's own demodulator + decoder (verbatim LoRaDemod.cpp / LoRaDecoder.cpp) on the SAME noisy samples.
+    Returns (sent, hip_packets, ref_packets, hip_bytes, ref_bytes)."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(seed)
+    N = 1 << sf
+    sent = [rng.integers(0, 256, int(rng.integers(8, 129))).astype(np.uint8) for _ in range(n_packets)]   # testPlan :103-111
+    ctx = L.Context(sf)
+    frames = []
+    for data in sent:
+        syms = ref.encode(sf, data, cr=cr)                               # encoder defaults: explicit header, crc, whitening
+        tx = torch.from_numpy(syms.astype(np.int16).reshape(1, -1)).cuda()
+        frames.append(ctx.mod_frames(tx, ampl=1.0, padding=padding).reshape(-1))   # mod.setAmplitude(1.0), setPadding(512) :96,100
+    iq = torch.cat(frames + [torch.zeros(2 * N, dtype=torch.complex64, device="cuda")]).reshape(1, -1).contiguous()
+    ctx.add_awgn(iq, sigma=sigma, seed=seed)                             # noise.setAmplitude(4.0), "NORMAL" :97-99
+    d = L.LoRaDemod(sf, n_channels=1)
+    d.setMTU(mtu)                                                        # demod.setMTU(512) :101
+    d.work(iq)
+    hip_pk = [p[2] for p in d.packets()]
+    dec = L.LoRaDecoder()
+    dec.setSpreadFactor(sf); dec.setCodingRate(cr)                       # :93-95; everything else at the block's defaults
+    hip_bytes = [o for o in dec.work(hip_pk) if o is not None]
+    host = iq.cpu().numpy().reshape(-1)
+    ref_pk = [p for _c, p in ref.demod_run(sf, host, mtu=mtu)["packets"]]
+    ref_bytes = [o for o in (ref.decode(sf, p.astype(np.uint16), cr=cr)[0] for p in ref_pk) if o is not None]
+    d.close(); ctx.close()
+    return sent, hip_pk, ref_pk, hip_bytes, ref_bytes
+
+
+# /comms/noise_source is not in the reference tree (PothosComms) and its scaling is unpinned (SURVEY.md section 8c). Two readings of
+# "amplitude 4.0, NORMAL" are run: 4.0 as the standard deviation of each of I and Q (complex noise power 32: -15 dB SNR), and 4.0
+# as the RMS of the complex sample (sigma = 4/sqrt(2) per component: -12 dB SNR).
+@pytest.mark.parametrize("sigma", [4.0, 4.0 / 2 ** 0.5], ids=["sigma4_per_component", "rms4_complex"])
+@pytest.mark.parametrize("cr", ["4/7", "4/8"])
+def test_loopback_at_the_reference_parameters(gpu, ref, cr, sigma):
+    """the reference's integration test (TestLoopback.cpp:66-133: SF10, CR 4/7 and 4/8, unit signal, noise amplitude 4.0, padding
+    512, MTU 512, 5 packets of 8..128 random bytes) through the HIP chain: the symbol packets and the decoded bytes equal what the
+    verbatim LoRaDemod.cpp + LoRaDecoder.cpp deliver on the same noisy samples, and equal the bytes that were sent (verifyTestPlan)"""
+    sent, hip_pk, ref_pk, hip_bytes, ref_bytes = loopback_case(gpu, ref, cr, sigma, seed=20 + int(cr[-1]))
+    assert len(hip_pk) == len(ref_pk) and all(np.array_equal(a, b) for a, b in zip(hip_pk, ref_pk))
+    assert len(hip_bytes) == len(ref_bytes) and all(np.array_equal(a, b) for a, b in zip(hip_bytes, ref_bytes))
+    assert len(hip_bytes) == len(sent) and all(np.array_equal(a, b) for a, b in zip(hip_bytes, sent))

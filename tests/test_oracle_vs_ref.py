@@ -169,3 +169,57 @@ def test_code_primitives_exhaustive(oracle, ref):
         for bit in range(8):
             r = oracle.L.lo_code_primitive(0, cw ^ (1 << bit))
             assert (r & 0xf) == d and (r & 0x100) and not (r & 0x200)
+
+
+@pytest.mark.parametrize("sf", [7, 9])
+def test_many_streams_runner_identical(oracle, ref, sf):
+    """the all-channels runner bench.py's level-3 section uses (oracle.demod_run_many / ref.demod_run_many): every stream from
+    the zero start state, packets, per-call consumption and label kinds equal to the one-stream entry points and equal between the
+    restatement and the verbatim LoRaDemod.cpp"""
+    rng = np.random.default_rng(3 + sf)
+    N, S = 1 << sf, 10
+    streams = []
+    for _ in range(S):
+        f = oracle.mod_frame(sf, rng.integers(0, N, 20).astype(np.uint16), padding=3)
+        streams.append(np.concatenate([np.zeros(int(rng.integers(0, 2 * N)), np.complex64), f, np.zeros(3 * N, np.complex64), f]))
+    iq = np.zeros((S, max(len(x) for x in streams) + N), np.complex64)
+    for c, x in enumerate(streams):
+        iq[c, :len(x)] = x
+    iq += (0.1 * (rng.standard_normal(iq.shape) + 1j * rng.standard_normal(iq.shape))).astype(np.complex64)
+    a = oracle.demod_run_many(sf, iq, mtu=20, nthreads=3, calls=True)
+    b = ref.demod_run_many(sf, iq, mtu=20, nthreads=2, calls=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert (a["n_packets"] == 2).all()
+    kinds = {"": 0, "SYNC": 1, "P": 2, "D": 3, "Q": 4, "S": 5}
+    for c in range(S):
+        one = ref.demod_run(sf, iq[c], mtu=20)
+        n = int(b["n_calls"][c])
+        assert n == len(one["consumed"]) and np.array_equal(b["consumed"][c, :n], one["consumed"])
+        want = [kinds["SYNC" if lab == "SYNC" else lab[:1]] for lab in one["labels"]]
+        assert b["cls"][c, :n].tolist() == want
+        at = 0
+        for j, (call, p) in enumerate(one["packets"]):
+            assert b["pkt_lens"][c, j] == len(p) and b["pkt_call"][c, j] == call
+            assert np.array_equal(b["pkt_syms"][c, at:at + len(p)], p)
+            at += len(p)
+
+
+@pytest.mark.parametrize("cr,sigma", [("4/7", 4.0), ("4/8", 4.0 / 2 ** 0.5)])
+def test_loopback_kat_on_the_cpu(oracle, ref, cr, sigma):
+    """TestLoopback.cpp:66-133 at its own parameters (SF10, unit signal, noise amplitude 4.0 -- both readings of the unpinned
+    /comms/noise_source scale --, padding 512, MTU 512, 5 packets of 8..128 random bytes) through the verbatim blocks (encoder, mod,
+    demod, decoder) and through the restated demodulator + decoder on the same samples: same packets, same bytes, the bytes sent.
+    The GPU twin is tests/test_gpu_codec.py::test_loopback_at_the_reference_parameters."""
+    sf, N = 10, 1024
+    rng = np.random.default_rng(7)
+    sent = [rng.integers(0, 256, int(rng.integers(8, 129))).astype(np.uint8) for _ in range(5)]
+    frames = [ref.mod_frame(sf, ref.encode(sf, d, cr=cr), ampl=1.0, padding=512) for d in sent]
+    iq = np.concatenate(frames + [np.zeros(2 * N, np.complex64)])
+    iq = (iq + sigma * (rng.standard_normal(iq.size) + 1j * rng.standard_normal(iq.size))).astype(np.complex64)
+    rp = [p for _c, p in ref.demod_run(sf, iq, mtu=512)["packets"]]
+    op = [p for _c, p in oracle.demod_run(sf, iq, mtu=512, keep=False)["packets"]]
+    assert len(rp) == len(op) == 5 and all(np.array_equal(a, b) for a, b in zip(rp, op))
+    rb = [ref.decode(sf, p.astype(np.uint16), cr=cr)[0] for p in rp]
+    ob = [oracle.decode(sf, p.astype(np.uint16), cr=cr)[0] for p in op]
+    assert all(np.array_equal(a, b) and np.array_equal(a, s) for a, b, s in zip(rb, ob, sent))
