@@ -97,8 +97,8 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != a.gpus and self.world > 1:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, self.world))
+        if self.world != a.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: the line would not describe the run" % (a.gpus, self.world))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
         # test hooks (tools/gpu_r02.sh "multi"): several ranks on ONE GPU over gloo exercise the N > 1 code path where only a
@@ -577,8 +577,26 @@ def section_mixed(env, L, a, S=16, n_channels=16384, rccl_single=False):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def respawn_under_torchrun(a):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run would silently measure ONE rank: start the N ranks ourselves
+    (one process per GPU over RCCL, the launch line of the module docstring) -- or fail, never report n_gpus: 1 for a --gpus N run"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: re-launching as %s\n" % (a.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(a)                       # does not return
     env = Env(a)
     import lora_sdr_amd as L
     from lora_sdr_amd import workloads as WL
@@ -659,6 +677,28 @@ def main():
         line["pcie_inclusive"] = dict(host_rate(part), windows=k, buffers="ordinary host memory (gathered through pinned double-buffered staging)",
                                       pinned=host_rate(pin))
         del pin
+        # drop-in form (a) of INTEGRATION.md section 1: the reference's own LoRaDemod.cpp with its detector swapped for the level-1 shim
+        # (one window per detect(): a launch and a PCIe round trip each), against the unpatched block, one host thread each, on the
+        # same samples -- the honest figure for "change two lines and nothing else"
+        try:
+            from oracle.oracle import Ref
+            if Ref.available("dropin") and Ref.available("-O2"):
+                sps, ns = 512 * sh.N, 2
+                sample = sh.host_iq()[:sps * ns]
+                res = {}
+                for name, flags in (("shim", "dropin"), ("cpu", "-O2")):
+                    impl = Ref(flags)
+                    impl.demod_bench(sf0, sample[:8 * sh.N], 8 * sh.N, 1, 1, 1)          # contexts, tables, first launch
+                    t0 = time.perf_counter()
+                    calls = impl.demod_bench(sf0, sample, sps, ns, 1, 1)
+                    res[name] = (calls, time.perf_counter() - t0)
+                line["pcie_inclusive"]["level1_shim"] = {
+                    "what": "verbatim LoRaDemod.cpp + LoRaDetectorHip (one launch + PCIe round trip per detect()), 1 host thread",
+                    "work_calls": int(res["shim"][0]), "us_per_detect": r4(res["shim"][1] / max(res["shim"][0], 1) * 1e6),
+                    "Msym_s": r4(res["shim"][0] / res["shim"][1] / 1e6),
+                    "cpu_reference_1_thread_Msym_s": r4(res["cpu"][0] / res["cpu"][1] / 1e6)}
+        except Exception as e:                                       # pragma: no cover - the drop-in library may not have travelled
+            line["pcie_inclusive"]["level1_shim"] = {"error": str(e)[:120]}
 
     if sweep:
         per_sf, moving, level3 = [], [], []

@@ -167,6 +167,30 @@ int lorahip_mixed_plan(lorahip_mixed *m, const int64_t *channel_offset, size_t w
 int lorahip_mixed_detect(lorahip_mixed *m, const float *iq_dev, uint16_t *sym_dev, float *power_dev, float *power_avg_dev, float *f_index_dev);
 int lorahip_mixed_synchronize(lorahip_mixed *m);
 
+/* Several devices in one process ("one process, 8 devices, one host thread + stream per device"; the reference
+ * runs one LoRaDemod block per channel, LoRaDemod.cpp:119-122, and nothing in it binds those channels to one GPU). Channels are
+ * independent units, so there is no data-path collective: lorahip_mixed_create_multi splits the channels over devices[0..n_devices)
+ * with lorahip_shard_plan, gives every device its own scheduler (above) and its own host thread that issues that device's launches.
+ *   lorahip_shard_plan : host-only. SF buckets from the largest windows down, each cut into n_shards contiguous ranges; the
+ *                        count % n_shards left-over channels of a bucket go to the shards holding the fewest bytes so far (weight
+ *                        8*2^SF + 14 per window, lowest shard first among equals). The same rule as lora_sdr_amd/shard.py, which the
+ *                        one-process-per-GPU form of the split (bench.py under torch.distributed) uses.
+ *   create_multi       : devices may repeat (two shards on one GPU are two independent schedulers).
+ *   plan               : as above, with channel_offset[c] relative to the IQ buffer of channel c's OWN device.
+ *   rows               : channel c's row in the result arrays of its own device; lorahip_mixed_shard_of gives that device's index.
+ *   detect_multi       : arrays of n_devices device pointers (entry s lives on devices[s]; entries of shards without channels are
+ *                        ignored). Returns when every device's launches are issued; lorahip_mixed_synchronize joins all devices.
+ *   lorahip_mixed_shard: shard s's single-device scheduler, borrowed (buckets, contexts, timers); NULL for a shard without channels.
+ * On an object made by lorahip_mixed_create these report one shard; lorahip_mixed_detect refuses a multi-device object. */
+int lorahip_shard_plan(const int32_t *channel_sf, size_t n_channels, size_t n_shards, int32_t *shard_of_channel);
+int lorahip_mixed_create_multi(lorahip_mixed **m, const int *devices, size_t n_devices, const int32_t *channel_sf, size_t n_channels);
+size_t lorahip_mixed_num_devices(const lorahip_mixed *m);
+int lorahip_mixed_device(const lorahip_mixed *m, size_t shard, int32_t *device, size_t *n_channels);
+lorahip_mixed *lorahip_mixed_shard(const lorahip_mixed *m, size_t shard);
+int lorahip_mixed_shard_of(const lorahip_mixed *m, int32_t *shard_of_channel);
+int lorahip_mixed_detect_multi(lorahip_mixed *m, const float *const *iq_dev, uint16_t *const *sym_dev, float *const *power_dev,
+                               float *const *power_avg_dev, float *const *f_index_dev);
+
 /* Pinned host memory for the host-pointer entry points (lorahip_detect_batch_host, lorahip_demod_run, the detector shim): buffers
  * obtained here -- or any hipHostMalloc'ed / hipHostRegister'ed memory -- are read by the DMA engine directly; ordinary memory is
  * gathered through the library's double-buffered pinned staging first (several threads, LORAHIP_UPLOAD_THREADS). NULL on failure. */
@@ -291,7 +315,11 @@ int lorahip_demod_near_threshold(const lorahip_demod *d, int64_t *near_squelch, 
  *                                                   min(total, N), and window 1 when the call consumed 2N (the sync check, :189-206)
  *   raw_dev  [n_channels][raw_cap_samples]   cf32   the samples consumed (:163, :321)
  * Any pointer may be NULL (that port stays off); p == NULL switches all off. Bins and samples are bit-identical to the reference's.
- * What exceeds a capacity is dropped; lorahip_demod_port_counts() reports what the last run produced. Labels: see below. */
+ * What exceeds a capacity is dropped; lorahip_demod_port_counts() reports what the last run produced. Labels: see below.
+ * The ports are replayed from the per-call trace, so a run with ports on keeps one internally even when lorahip_demod_set_trace was
+ * never enabled: that trace lives for the run only (it is not visible through lorahip_demod_get_trace / _trace_len / _get_labels
+ * and does not accumulate), and like any traced run it drains the records to the host, i.e. the device-resident packet hand-off
+ * of lorahip_demod_packets_to_device takes its host-queue path. */
 typedef struct lorahip_demod_ports {
     size_t struct_size;     /* = sizeof(lorahip_demod_ports) */
     float *fft_dev; size_t fft_cap_frames;

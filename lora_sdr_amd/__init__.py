@@ -6,8 +6,8 @@ interface. There is no CPU implementation here: without the shared library (or w
 gfx950 device) the calls raise.
 """
 from ._lib import LoraHipError, load, LIB_PATH, CHIRP_UP, CHIRP_DOWN, CHIRP_NONE, SF_MIN, SF_MAX, FINE_STEPS  # noqa: F401
-from .api import Context, LoRaDetector, LoRaDemod, LoRaDecoder, Channelizer, MixedDetector, pinned_empty, design_lowpass, host_tables, device_count  # noqa: F401
+from .api import Context, LoRaDetector, LoRaDemod, LoRaDecoder, Channelizer, MixedDetector, MixedDetectorMulti, shard_plan, pinned_empty, design_lowpass, host_tables, device_count  # noqa: F401
 from .shard import shard_channels, bytes_per_symbol  # noqa: F401
 
-__all__ = ["Context", "LoRaDetector", "LoRaDemod", "LoRaDecoder", "Channelizer", "MixedDetector", "pinned_empty", "design_lowpass", "host_tables", "device_count", "LoraHipError", "load",
+__all__ = ["Context", "LoRaDetector", "LoRaDemod", "LoRaDecoder", "Channelizer", "MixedDetector", "MixedDetectorMulti", "shard_plan", "pinned_empty", "design_lowpass", "host_tables", "device_count", "LoraHipError", "load",
            "shard_channels", "bytes_per_symbol", "CHIRP_UP", "CHIRP_DOWN", "CHIRP_NONE"]

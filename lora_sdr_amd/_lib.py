@@ -87,6 +87,13 @@ SIGNATURES = {
     "lorahip_mixed_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "lorahip_mixed_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lorahip_mixed_synchronize": (C.c_int, [C.c_void_p]),
+    "lorahip_shard_plan": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "lorahip_mixed_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "lorahip_mixed_num_devices": (C.c_size_t, [C.c_void_p]),
+    "lorahip_mixed_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
+    "lorahip_mixed_shard": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "lorahip_mixed_shard_of": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lorahip_mixed_detect_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lorahip_host_alloc": (C.c_void_p, [C.c_size_t]),
     "lorahip_host_free": (None, [C.c_void_p]),
     "lorahip_timer_start": (C.c_int, [C.c_void_p]),

@@ -333,7 +333,11 @@ class MixedDetector:
 
     def detect(self, iq, out=None, sync=True):
         """asynchronous unless sync: the buckets run on their own streams; the caller's stream must have finished producing iq"""
+        import torch
         out = out or self.new_outputs()
+        # the buckets launch on private non-blocking streams: whatever torch's current stream still has queued -- the producer of
+        # `iq`, the previous owner of the recycled output blocks -- must be finished first (as LoRaDemod.packets_device does)
+        torch.cuda.current_stream(self.device).synchronize()
         check(self._lib.lorahip_mixed_detect(self._h, _dptr(iq), _dptr(out["sym"]), _dptr(out["power"]), _dptr(out["powerAvg"]), _dptr(out["fIndex"])),
               "lorahip_mixed_detect")
         if sync:
@@ -342,6 +346,80 @@ class MixedDetector:
 
     def synchronize(self):
         check(self._lib.lorahip_mixed_synchronize(self._h), "lorahip_mixed_synchronize")
+
+
+def shard_plan(channel_sf, n_shards):
+    """lorahip_shard_plan (host-only): the shard of every channel under the library's byte-weighted rule -- the C twin of
+    lora_sdr_amd.shard.shard_channels, used by lorahip_mixed_create_multi"""
+    lib = load()
+    sf = np.ascontiguousarray(channel_sf, np.int32).reshape(-1)
+    out = np.zeros(sf.size, np.int32)
+    check(lib.lorahip_shard_plan(sf.ctypes.data if sf.size else None, sf.size, int(n_shards), out.ctypes.data if sf.size else None), "lorahip_shard_plan")
+    return out
+
+
+class MixedDetectorMulti:
+    """lorahip_mixed_create_multi: mixed-SF channels over several devices of ONE process (one scheduler, host thread and set of
+    streams per device, no data-path collective). devices: list of device indices (may repeat). shard_of[c] = index into devices of
+    channel c, rows[c] = its row in that device's result arrays, channels_of(s) = shard s's channels in row order per bucket."""
+
+    def __init__(self, channel_sf, devices):
+        self._lib = load()
+        self._h = C.c_void_p()
+        sf = np.ascontiguousarray(channel_sf, np.int32).reshape(-1)
+        dv = np.ascontiguousarray(devices, np.int32).reshape(-1)
+        check(self._lib.lorahip_mixed_create_multi(C.byref(self._h), dv.ctypes.data, dv.size, sf.ctypes.data, sf.size), "lorahip_mixed_create_multi")
+        self.n_channels, self.devices, self.S = int(sf.size), [int(d) for d in dv], 0
+        self.shard_of = np.empty(sf.size, np.int32)
+        check(self._lib.lorahip_mixed_shard_of(self._h, self.shard_of.ctypes.data), "lorahip_mixed_shard_of")
+        self.rows = np.empty(sf.size, np.int64)
+        check(self._lib.lorahip_mixed_rows(self._h, self.rows.ctypes.data), "lorahip_mixed_rows")
+        self.counts = []
+        for s in range(len(self.devices)):
+            d_, n_ = C.c_int32(), C.c_size_t()
+            check(self._lib.lorahip_mixed_device(self._h, s, C.byref(d_), C.byref(n_)), "lorahip_mixed_device")
+            self.counts.append(int(n_.value))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.lorahip_mixed_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def plan(self, channel_offset, windows_per_channel):
+        """channel_offset[c]: first sample of channel c inside the IQ buffer of ITS device"""
+        off = np.ascontiguousarray(channel_offset, np.int64).reshape(-1)
+        if off.size != self.n_channels:
+            raise ValueError("one offset per channel")
+        check(self._lib.lorahip_mixed_plan(self._h, off.ctypes.data, int(windows_per_channel)), "lorahip_mixed_plan")
+        self.S = int(windows_per_channel)
+
+    def new_outputs(self):
+        import torch
+        outs = []
+        for s, dev_i in enumerate(self.devices):
+            dev = torch.device("cuda", dev_i)
+            shape = (self.counts[s], self.S)
+            outs.append(dict(sym=torch.empty(shape, dtype=torch.int16, device=dev), power=torch.empty(shape, dtype=torch.float32, device=dev),
+                             powerAvg=torch.empty(shape, dtype=torch.float32, device=dev), fIndex=torch.empty(shape, dtype=torch.float32, device=dev)))
+        return outs
+
+    def detect(self, iqs, outs=None, sync=True):
+        """iqs: one device tensor per shard (None where a shard has no channel); returns the per-shard output dicts"""
+        import torch
+        outs = outs or self.new_outputs()
+        for dev_i in set(self.devices):
+            torch.cuda.synchronize(dev_i)                           # inputs and recycled output blocks are ready (the shards run on private streams)
+        n = len(self.devices)
+
+        def arr(ts):
+            return (C.c_void_p * n)(*[(t.data_ptr() if t is not None and t.numel() else None) for t in ts])
+        check(self._lib.lorahip_mixed_detect_multi(self._h, arr(iqs), arr([o["sym"] for o in outs]), arr([o["power"] for o in outs]),
+                                                   arr([o["powerAvg"] for o in outs]), arr([o["fIndex"] for o in outs])), "lorahip_mixed_detect_multi")
+        if sync:
+            check(self._lib.lorahip_mixed_synchronize(self._h), "lorahip_mixed_synchronize")
+        return outs
 
 
 def design_lowpass(decim, n_taps, cutoff=None):

@@ -25,30 +25,81 @@ def _mtime(path):
     return os.path.getmtime(path) if os.path.exists(path) else 0.0
 
 
+def source_digest():
+    """sha256 over every source and header the library is built from (what a build log entry is stamped with)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def build_lib(force=False, verbose=False, extra=()):
     """Compile every HIP/C++ source (one object per translation unit, in parallel) and link
-    lora_sdr_amd/liblorahip.so; returns its path. Only stale objects are rebuilt."""
+    lora_sdr_amd/liblorahip.so; returns its path. Only stale objects are rebuilt unless force (or LORAHIP_FORCE_REBUILD=1 in the
+    environment): then every object is removed first and all translation units are compiled from clean. What was done is printed
+    and appended to lora_sdr_amd/build/build_log.jsonl (mode, translation units compiled, seconds, source digest)."""
+    import json
+    import time
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    force = bool(force) or os.environ.get("LORAHIP_FORCE_REBUILD", "") not in ("", "0")
     os.makedirs(OBJDIR, exist_ok=True)
-    hdr_t = max([_mtime(os.path.join(CSRC, h)) for h in HEADERS] + [_mtime(os.path.abspath(__file__))])
-    jobs, objs = [], []
+    t_start = time.time()
+    if force:
+        for f in os.listdir(OBJDIR):
+            if f.endswith(".o") or f.endswith(".stamp"):
+                os.remove(os.path.join(OBJDIR, f))
+        if os.path.exists(LIB):
+            os.remove(LIB)
+    # an object is current when its stamp holds the digest of its source, every header and the flags: by CONTENT, not by
+    # modification time (a checkout or a copy to another box may reorder mtimes)
+    import hashlib
+    hh = hashlib.sha256()
+    for name in sorted(HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            hh.update(name.encode() + b"\0" + f.read())
+    hh.update(" ".join(FLAGS + list(extra)).encode())
+    jobs, objs, stamps = [], [], {}
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        if force or extra or _mtime(obj) < max(_mtime(src), hdr_t):
+        h1 = hh.copy()
+        with open(src, "rb") as f:
+            h1.update(f.read())
+        want = h1.hexdigest()
+        have = open(obj + ".stamp").read().strip() if os.path.exists(obj + ".stamp") and os.path.exists(obj) else ""
+        if force or have != want:
             cmd = [hipcc] + FLAGS + list(extra) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
+            if os.path.exists(obj + ".stamp"):
+                os.remove(obj + ".stamp")
+            stamps[obj] = want
             jobs.append((s, subprocess.Popen(cmd)))
     failed = [s for s, p in jobs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for " + ", ".join(failed))
+    for obj, want in stamps.items():
+        with open(obj + ".stamp", "w") as f:
+            f.write(want + "\n")
+    linked = False
     if jobs or _mtime(LIB) < max(_mtime(o) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        linked = True
+    rec = {"mode": "clean" if force else "incremental", "compiled": [s for s, _ in jobs], "of": len(SOURCES), "linked": linked,
+           "seconds": round(time.time() - t_start, 1), "sources_sha16": source_digest(), "flags": FLAGS + list(extra), "time": int(t_start)}
+    print("lorahip build: %s, %d of %d translation units compiled%s in %.1f s (sources %s)"
+          % (rec["mode"], len(jobs), len(SOURCES), ", linked" if linked else ", library up to date", rec["seconds"], rec["sources_sha16"]), flush=True)
+    try:
+        with open(os.path.join(OBJDIR, "build_log.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
     return LIB
 
 

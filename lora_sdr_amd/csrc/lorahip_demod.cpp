@@ -473,9 +473,12 @@ static int drainPending(lorahip_demod *dm)
     const DeviceGuard guard(dm->ctx->device);
     typedef std::chrono::steady_clock Clock;
     const Clock::time_point t0 = Clock::now();
-    P.valid = false;
+    // the records stay pending until they HAVE been drained: after a failed drain (HIP error, no memory for the staging) the
+    // packet counts reported so far remain true and a later accessor retries. drainLaunch appends to the queue only after its
+    // last fallible step (the copy back), so a retry cannot duplicate packets.
     const int rc = drainLaunch(dm, P.lay);
     if (rc != LORAHIP_OK) return rc;
+    P.valid = false;
     orderNewPackets(dm, P.firstNewPacket, P.rounds);
     P.drainMs = std::chrono::duration<double>(Clock::now() - t0).count() * 1e3;
     static const bool timing = std::getenv("LORAHIP_DEMOD_TIMING") != nullptr;
@@ -804,11 +807,16 @@ static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(dm->ctx->sf));
     if (stream && !streamAvailable(dm->ctx->sf)) { setLastError("no streaming kernel for this SF"); return LORAHIP_E_INVALID; }
     { const int rc = drainPending(dm); if (rc != LORAHIP_OK) return rc; }       // the previous run's records, if still on the device
+    // the port replay reads the per-call trace; a trace the caller did not ask for lives for this run only (it must neither grow
+    // without bound in a long-running receiver nor show up in lorahip_demod_get_trace / _trace_len / _get_labels)
+    const bool internalTrace = dm->portsOn && !dm->userTracing;
+    if (internalTrace) for (auto &k : dm->ch) { k.trace.clear(); k.traceSymCount0 = k.symCount; }
     for (auto &k : dm->ch) { k.traceStart = k.trace.size(); k.portFft = k.portDec = k.portRaw = 0; }
-    dm->tracing = dm->userTracing || dm->portsOn;               // the port replay reads the per-call trace
-    const int rc = stream ? runStream(dm, iqDev, roundsOut) : runRounds(dm, iqDev, roundsOut);
-    if (rc != LORAHIP_OK || !dm->portsOn) return rc;
-    return fillPorts(dm, iqDev);
+    dm->tracing = dm->userTracing || dm->portsOn;
+    int rc = stream ? runStream(dm, iqDev, roundsOut) : runRounds(dm, iqDev, roundsOut);
+    if (rc == LORAHIP_OK && dm->portsOn) rc = fillPorts(dm, iqDev);
+    if (internalTrace) for (auto &k : dm->ch) { std::vector<lorahip_work_result>().swap(k.trace); k.traceStart = 0; }
+    return rc;
 }
 
 } // namespace
@@ -979,12 +987,12 @@ int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size
     return runAny(dm, dm->dIq, rounds);
 }
 
-//! accessors of the host queue first bring over what the last streaming launch left on the device
-static lorahip_demod *drained(const lorahip_demod *dm)
+//! accessors of the host queue first bring over what the last streaming launch left on the device; a failure there is the
+//! accessor's failure (the records stay pending, see drainPending)
+static int drained(const lorahip_demod *dm)
 {
     lorahip_demod *m = const_cast<lorahip_demod *>(dm);
-    if (m) (void)drainPending(m);
-    return m;
+    return m ? drainPending(m) : LORAHIP_E_INVALID;
 }
 
 size_t lorahip_demod_num_packets(const lorahip_demod *dm)
@@ -997,7 +1005,7 @@ size_t lorahip_demod_num_packets(const lorahip_demod *dm)
 int lorahip_demod_get_packet(const lorahip_demod *dm, const size_t i, int32_t *channel, int64_t *round,
                              size_t *len, int16_t *out, const size_t cap)
 {
-    drained(dm);
+    { const int rc = drained(dm); if (rc != LORAHIP_OK) return rc; }
     if (dm == nullptr || i >= dm->packets.size()) return LORAHIP_E_INVALID;
     const Packet &p = dm->packets[i];
     if (channel) *channel = p.channel;
@@ -1021,7 +1029,7 @@ size_t lorahip_demod_num_packet_symbols(const lorahip_demod *dm)
 int lorahip_demod_get_packets(const lorahip_demod *dm, int32_t *channels, int64_t *rounds, int64_t *lens, const size_t cap_packets,
                               int16_t *syms, const size_t cap_syms)
 {
-    drained(dm);
+    { const int rc = drained(dm); if (rc != LORAHIP_OK) return rc; }
     if (dm == nullptr || cap_packets < dm->packets.size() || cap_syms < dm->pktSyms.size()) return LORAHIP_E_INVALID;
     size_t o = 0;
     for (size_t i = 0; i < dm->packets.size(); i++)
@@ -1141,7 +1149,7 @@ int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)
 
 size_t lorahip_demod_trace_len(const lorahip_demod *dm, const size_t channel)
 {
-    drained(dm);
+    if (drained(dm) != LORAHIP_OK) return 0;                    // lorahip_last_error() says why
     if (dm == nullptr || channel >= dm->B) return 0;
     return dm->ch[channel].trace.size();
 }
@@ -1210,7 +1218,7 @@ static std::string labelOf(const lorahip_work_result &r, const size_t N, const f
 
 int lorahip_demod_get_labels(const lorahip_demod *dm, const size_t channel, char *buf, const size_t cap, size_t *n_calls, size_t *bytes)
 {
-    drained(dm);
+    { const int rc = drained(dm); if (rc != LORAHIP_OK) return rc; }
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
     const auto &t = dm->ch[channel].trace;
     // _symCount is only reset at QUARTERCHIRP (:279): a trace that starts inside a packet continues the count the channel held then
@@ -1229,7 +1237,7 @@ int lorahip_demod_get_labels(const lorahip_demod *dm, const size_t channel, char
 
 int lorahip_demod_get_trace(const lorahip_demod *dm, const size_t channel, lorahip_work_result *out, const size_t cap)
 {
-    drained(dm);
+    { const int rc = drained(dm); if (rc != LORAHIP_OK) return rc; }
     if (dm == nullptr || channel >= dm->B || out == nullptr) return LORAHIP_E_INVALID;
     const auto &t = dm->ch[channel].trace;
     if (cap < t.size()) return LORAHIP_E_INVALID;

@@ -195,7 +195,7 @@ int hipFail(hipError_t e, const char *what);
 
 namespace lorahip {
 //! two pinned staging buffers of the host -> device gather (lorahip_upload.cpp)
-struct Uploader { void *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; };
+struct Uploader { void *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; bool ready = false; };
 }
 
 struct lorahip_ctx

@@ -51,9 +51,17 @@ static void copySegments(const std::vector<Seg> &segs, const size_t total)
             if (at >= hi) break;
         }
     };
+    // no exception may cross the C ABI: a helper thread that cannot be started (std::system_error) has its share copied here
     std::vector<std::thread> pool;
-    for (int k = 1; k < T; k++) pool.emplace_back(work, k);
+    int started = 1;
+    try
+    {
+        pool.reserve(size_t(T - 1));
+        for (; started < T; started++) pool.emplace_back(work, started);
+    }
+    catch (...) {}
     work(0);
+    for (int k = started; k < T; k++) work(k);
     for (auto &t : pool) t.join();
 }
 
@@ -61,15 +69,24 @@ int gatherUpload(lorahip_ctx *ctx, void *dDstV, const void *const *src, const si
 {
     char *dDst = static_cast<char *>(dDstV);
     Uploader &u = ctx->up;
-    if (u.buf[0] == nullptr)
+    if (!u.ready)
     {
+        // both buffers and both events, or nothing: a transient failure (pinned memory exhausted) must leave the uploader in the
+        // state "not initialised", not half of it -- the next call tries again from scratch
+        destroyUploader(ctx);
         for (int k = 0; k < 2; k++)
         {
-            const hipError_t e = hipHostMalloc(&u.buf[k], kStageBytes, hipHostMallocDefault);
-            if (e != hipSuccess) { u.buf[k] = nullptr; return hipFail(e, "hipHostMalloc(upload staging)"); }
-            LORAHIP_TRY(hipEventCreateWithFlags(&u.ev[k], hipEventDisableTiming));
+            hipError_t e = hipHostMalloc(&u.buf[k], kStageBytes, hipHostMallocDefault);
+            if (e != hipSuccess) u.buf[k] = nullptr;
+            else e = hipEventCreateWithFlags(&u.ev[k], hipEventDisableTiming);
+            if (e != hipSuccess)
+            {
+                destroyUploader(ctx);
+                return hipFail(e, "upload staging (hipHostMalloc / hipEventCreate)");
+            }
             u.busy[k] = false;
         }
+        u.ready = true;
     }
     size_t done = 0;                                     // bytes of the destination already handed to the DMA engine
     int k = 0;
@@ -118,8 +135,9 @@ void destroyUploader(lorahip_ctx *ctx)
     {
         if (ctx->up.buf[k]) (void)hipHostFree(ctx->up.buf[k]);
         if (ctx->up.ev[k]) (void)hipEventDestroy(ctx->up.ev[k]);
-        ctx->up.buf[k] = nullptr; ctx->up.ev[k] = nullptr;
+        ctx->up.buf[k] = nullptr; ctx->up.ev[k] = nullptr; ctx->up.busy[k] = false;
     }
+    ctx->up.ready = false;
 }
 
 } // namespace lorahip

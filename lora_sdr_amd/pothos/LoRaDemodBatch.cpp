@@ -6,6 +6,9 @@
 // labels and debug ports per channel -- what changes is the shape: one block instance owns B inputs.
 //
 //   factory   /lora/lora_demod_batch(sf, channels)
+//   setDevices("0,1,2,3,4,5,6,7")  spread the B channels over several GPUs of the node: contiguous ranges
+//             from lorahip_shard_plan, one level-3 object per device, each run from its own host thread inside work(); the
+//             default is device 0 alone. Channels are independent: per-channel outputs do not depend on the split.
 //   inputs    0 .. B-1            complex float streams, reserve 2N each                       (LoRaDemod.cpp:79,90)
 //   outputs   "0" .. "B-1"        Pothos::Packet messages of int16 symbols                     (:80,295-298)
 //             "raw<c>" "dec<c>"   complex float streams, `total` elements per work() call      (:81-82,163-164,321-322)
@@ -20,6 +23,7 @@
 #include <complex>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "lorahip.h"
 
@@ -29,11 +33,11 @@ class LoRaDemodBatch : public Pothos::Block
 
 public:
     LoRaDemodBatch(const size_t sf, const size_t channels) :
-        N(size_t(1) << sf), B(channels), _d(nullptr), _maxWindows(64), _fftDropped(0)
+        N(size_t(1) << sf), B(channels), _sf(sf), _sync(0x12), _thresh(-30.0), _mtu(256), _maxWindows(64), _fftDropped(0)
     {
-        const int rc = lorahip_demod_create(&_d, 0, int(sf), channels);
-        if (rc != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch", std::string(lorahip_strerror(rc)) + " " + lorahip_last_error());
+        createShards(std::vector<int>(1, 0));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setSync));
+        this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setDevices));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setThreshold));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setMTU));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setMaxWindows));
@@ -53,17 +57,36 @@ public:
         sizeBuffers();
     }
 
-    ~LoRaDemodBatch(void) { lorahip_demod_destroy(_d); }
+    ~LoRaDemodBatch(void) { destroyShards(); }
 
     static Block *make(const size_t sf, const size_t channels) { return new LoRaDemodBatch(sf, channels); }
 
-    void setSync(const unsigned char sync) { lorahip_demod_set_sync(_d, sync); }
-    void setThreshold(const double thresh_dB) { lorahip_demod_set_threshold(_d, thresh_dB); }
-    void setMTU(const size_t mtu) { lorahip_demod_set_mtu(_d, mtu); }
+    void setSync(const unsigned char sync) { _sync = sync; for (auto &s : _shards) lorahip_demod_set_sync(s.d, sync); }
+    void setThreshold(const double thresh_dB) { _thresh = thresh_dB; for (auto &s : _shards) lorahip_demod_set_threshold(s.d, thresh_dB); }
+    void setMTU(const size_t mtu) { _mtu = mtu; for (auto &s : _shards) lorahip_demod_set_mtu(s.d, mtu); }
     void setMaxWindows(const size_t k) { _maxWindows = k ? k : 1; sizeBuffers(); }
     size_t fftFramesDropped(void) const { return _fftDropped; }
 
-    void activate(void) { lorahip_demod_activate(_d); }
+    //! comma-separated device indices, e.g. "0,1,2,3,4,5,6,7"; an index may repeat (two shards on one GPU)
+    void setDevices(const std::string &list)
+    {
+        std::vector<int> devs;
+        size_t at = 0;
+        while (at < list.size())
+        {
+            size_t end = list.find(',', at);
+            if (end == std::string::npos) end = list.size();
+            const std::string tok = list.substr(at, end - at);
+            if (tok.empty() || tok.find_first_not_of("0123456789 ") != std::string::npos) throw Pothos::InvalidArgumentException("LoRaDemodBatch::setDevices(" + list + ")", "not a list of device indices");
+            devs.push_back(std::atoi(tok.c_str()));
+            at = end + 1;
+        }
+        if (devs.empty()) throw Pothos::InvalidArgumentException("LoRaDemodBatch::setDevices()", "empty list");
+        createShards(devs);
+        sizeBuffers();
+    }
+
+    void activate(void) { for (auto &s : _shards) lorahip_demod_activate(s.d); }
 
     void work(void)
     {
@@ -80,14 +103,34 @@ public:
         }
         if (!any) return;
 
-        lorahip_demod_set_trace(_d, 1);
-        if (lorahip_demod_run(_d, streams.data(), avail.data(), nullptr) != LORAHIP_OK)
-            throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
+        // every device's channels in one launch on that device; several devices run side by side, each from its own host thread
+        std::vector<int> rcs(_shards.size(), LORAHIP_OK);
+        std::vector<std::string> errs(_shards.size());
+        auto runShard = [&](const size_t i)
+        {
+            Shard &s = _shards[i];
+            lorahip_demod_set_trace(s.d, 1);
+            rcs[i] = lorahip_demod_run(s.d, streams.data() + s.first, avail.data() + s.first, nullptr);
+            if (rcs[i] != LORAHIP_OK) errs[i] = lorahip_last_error();                    // the text is per thread
+        };
+        if (_shards.size() == 1) runShard(0);
+        else
+        {
+            std::vector<std::thread> pool;
+            for (size_t i = 0; i < _shards.size(); i++) pool.emplace_back(runShard, i);
+            for (auto &t : pool) t.join();
+        }
+        for (size_t i = 0; i < _shards.size(); i++)
+            if (rcs[i] != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch::work()", errs[i]);
 
         std::vector<lorahip_work_result> tr;
         std::vector<char> labels;
-        for (size_t c = 0; c < B; c++)
+        for (size_t cg = 0; cg < B; cg++)
         {
+            // channel cg of the block = channel c of the shard that owns it
+            const Shard &sh = _shards[_shardOf[cg]];
+            lorahip_demod *_d = sh.d;
+            const size_t c = cg - sh.first;
             const size_t nCalls = lorahip_demod_trace_len(_d, c);
             if (nCalls == 0) continue;
             tr.resize(nCalls);
@@ -101,10 +144,10 @@ public:
             lorahip_demod_port_counts(_d, c, &nf, &nd, &nr);
             const size_t frames = nf < _fftCap ? nf : _fftCap;
             _fftDropped += nf - frames;
-            auto raw = this->output("raw" + std::to_string(c)), dec = this->output("dec" + std::to_string(c)), fft = this->output("fft" + std::to_string(c));
-            std::memcpy(raw->buffer().template as<cf32 *>(), _raw.data() + c * capSamples, nr * sizeof(cf32));
-            std::memcpy(dec->buffer().template as<cf32 *>(), _dec.data() + c * capSamples, nd * sizeof(cf32));
-            std::memcpy(fft->buffer().template as<cf32 *>(), _fft.data() + c * _fftCap * N, frames * N * sizeof(cf32));
+            auto raw = this->output("raw" + std::to_string(cg)), dec = this->output("dec" + std::to_string(cg)), fft = this->output("fft" + std::to_string(cg));
+            std::memcpy(raw->buffer().template as<cf32 *>(), _raw.data() + cg * capSamples, nr * sizeof(cf32));
+            std::memcpy(dec->buffer().template as<cf32 *>(), _dec.data() + cg * capSamples, nd * sizeof(cf32));
+            std::memcpy(fft->buffer().template as<cf32 *>(), _fft.data() + cg * _fftCap * N, frames * N * sizeof(cf32));
 
             // labels at the first element each call produced (:314-319); signals (:267-269)
             size_t pos = 0;
@@ -121,33 +164,37 @@ public:
                 }
                 if (tr[k].signals)
                 {
-                    this->emitSignal("channel", int(c));
+                    this->emitSignal("channel", int(cg));
                     this->emitSignal("error", tr[k].sig_error);
                     this->emitSignal("power", tr[k].sig_power);
                     this->emitSignal("snr", tr[k].sig_snr);
                 }
                 pos += size_t(tr[k].consumed);
             }
-            this->input(int(c))->consume(size_t(lorahip_demod_consumed(_d, c)));        // the sum of consume(total), :320
+            this->input(int(cg))->consume(size_t(lorahip_demod_consumed(_d, c)));       // the sum of consume(total), :320
             raw->produce(nr);
             dec->produce(nd);
             fft->produce(frames * N);
         }
-        // packets, in the order the channels posted them (:295-298)
-        const size_t nPackets = lorahip_demod_num_packets(_d);
-        for (size_t i = 0; i < nPackets; i++)
+        // packets, in the order the channels posted them (:295-298); every channel has its own message port
+        for (const Shard &sh : _shards)
         {
-            int32_t ch = 0;
-            size_t len = 0;
-            lorahip_demod_get_packet(_d, i, &ch, nullptr, &len, nullptr, 0);
-            Pothos::Packet pkt;
-            pkt.payload = Pothos::BufferChunk(typeid(int16_t), len ? len : 1);
-            pkt.payload.length = len * sizeof(int16_t);
-            lorahip_demod_get_packet(_d, i, nullptr, nullptr, nullptr, pkt.payload.template as<int16_t *>(), len);
-            this->output(int(ch))->postMessage(pkt);
+            lorahip_demod *_d = sh.d;
+            const size_t nPackets = lorahip_demod_num_packets(_d);
+            for (size_t i = 0; i < nPackets; i++)
+            {
+                int32_t ch = 0;
+                size_t len = 0;
+                lorahip_demod_get_packet(_d, i, &ch, nullptr, &len, nullptr, 0);
+                Pothos::Packet pkt;
+                pkt.payload = Pothos::BufferChunk(typeid(int16_t), len ? len : 1);
+                pkt.payload.length = len * sizeof(int16_t);
+                lorahip_demod_get_packet(_d, i, nullptr, nullptr, nullptr, pkt.payload.template as<int16_t *>(), len);
+                this->output(int(sh.first + size_t(ch)))->postMessage(pkt);
+            }
+            lorahip_demod_clear_packets(_d);
+            lorahip_demod_set_trace(_d, 0);                                              // the next work() starts a fresh trace
         }
-        lorahip_demod_clear_packets(_d);
-        lorahip_demod_set_trace(_d, 0);                                                  // the next work() starts a fresh trace
     }
 
     //! output buffers large enough for what one work() produces (the reference does the same for its 2N / N, :330-358)
@@ -170,18 +217,53 @@ private:
         _raw.assign(B * capSamples, cf32());
         _dec.assign(B * capSamples, cf32());
         _fft.assign(B * _fftCap * N, cf32());
-        lorahip_demod_ports p;
-        std::memset(&p, 0, sizeof(p));
-        p.struct_size = sizeof(p);
-        p.fft_dev = reinterpret_cast<float *>(_fft.data()); p.fft_cap_frames = _fftCap;
-        p.dec_dev = reinterpret_cast<float *>(_dec.data()); p.dec_cap_samples = capSamples;
-        p.raw_dev = reinterpret_cast<float *>(_raw.data()); p.raw_cap_samples = capSamples;
-        p.host_buffers = 1;
-        if (lorahip_demod_set_ports(_d, &p) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch", lorahip_last_error());
+        for (const Shard &sh : _shards)
+        {
+            // a shard's channels are a contiguous range of the block's: its port buffers are that range of the staging arrays
+            lorahip_demod_ports p;
+            std::memset(&p, 0, sizeof(p));
+            p.struct_size = sizeof(p);
+            p.fft_dev = reinterpret_cast<float *>(_fft.data() + sh.first * _fftCap * N); p.fft_cap_frames = _fftCap;
+            p.dec_dev = reinterpret_cast<float *>(_dec.data() + sh.first * capSamples); p.dec_cap_samples = capSamples;
+            p.raw_dev = reinterpret_cast<float *>(_raw.data() + sh.first * capSamples); p.raw_cap_samples = capSamples;
+            p.host_buffers = 1;
+            if (lorahip_demod_set_ports(sh.d, &p) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch", lorahip_last_error());
+        }
     }
 
-    const size_t N, B;
-    lorahip_demod *_d;
+    struct Shard { lorahip_demod *d; size_t first, count; int device; };
+
+    void destroyShards(void)
+    {
+        for (auto &s : _shards) lorahip_demod_destroy(s.d);
+        _shards.clear();
+    }
+
+    //! B channels of one SF over the given devices: lorahip_shard_plan (equal weights: contiguous ranges, sizes differing by <= 1)
+    void createShards(const std::vector<int> &devices)
+    {
+        std::vector<int32_t> sfs(B, int32_t(_sf)), plan(B, 0);
+        if (lorahip_shard_plan(sfs.data(), B, devices.size(), plan.data()) != LORAHIP_OK) throw Pothos::InvalidArgumentException("LoRaDemodBatch::setDevices()", "bad device list");
+        destroyShards();
+        _shardOf.assign(B, 0);
+        for (size_t i = 0; i < devices.size(); i++)
+        {
+            size_t first = B, count = 0;
+            for (size_t c = 0; c < B; c++) if (size_t(plan[c]) == i) { if (first == B) first = c; count++; }
+            if (count == 0) continue;
+            Shard s; s.d = nullptr; s.first = first; s.count = count; s.device = devices[i];
+            const int rc = lorahip_demod_create(&s.d, devices[i], int(_sf), count);
+            if (rc != LORAHIP_OK) { destroyShards(); throw Pothos::Exception("LoRaDemodBatch", std::string(lorahip_strerror(rc)) + " " + lorahip_last_error()); }
+            lorahip_demod_set_sync(s.d, _sync); lorahip_demod_set_threshold(s.d, _thresh); lorahip_demod_set_mtu(s.d, _mtu);
+            for (size_t c = first; c < first + count; c++) _shardOf[c] = _shards.size();
+            _shards.push_back(s);
+        }
+    }
+
+    const size_t N, B, _sf;
+    unsigned char _sync; double _thresh; size_t _mtu;       // the setters' values, re-applied when the device list changes
+    std::vector<Shard> _shards;
+    std::vector<size_t> _shardOf;                           // per channel: index into _shards
     size_t _maxWindows, _fftCap, _fftDropped;
     std::vector<cf32> _raw, _dec, _fft;          // host staging of the three ports, [channel][capacity]
 };

@@ -80,6 +80,16 @@ int loradrop_batch_set(void *p, const char *name, const double v)
     return 0;
 }
 
+//! a registered call that takes a string (setDevices("0,1,..."))
+int loradrop_batch_set_string(void *p, const char *name, const char *v)
+{
+    auto h = reinterpret_cast<BatchHandle *>(p);
+    auto it = h->block->stringCalls.find(name);
+    if (it == h->block->stringCalls.end()) return -1;
+    try { it->second(v); } catch (const std::exception &) { return -2; }
+    return 0;
+}
+
 //! every channel's whole stream (iq: [channels][samplesPerChannel] cf32): call work() the way a scheduler would -- each input
 //! presents what the block has not consumed yet -- until no channel has 2N samples left. Returns the number of work() calls.
 int64_t loradrop_batch_run(void *p, const float *iq, const size_t samplesPerChannel)

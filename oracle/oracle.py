@@ -453,6 +453,7 @@ class DropInBatch:
         L.loradrop_batch_new.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t]
         L.loradrop_batch_free.argtypes = [C.c_void_p]
         L.loradrop_batch_set.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.loradrop_batch_set_string.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.loradrop_batch_run.restype = C.c_int64
         L.loradrop_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.loradrop_batch_count.restype = C.c_size_t
@@ -481,6 +482,10 @@ class DropInBatch:
 
     def set(self, name, v):
         assert self.L.loradrop_batch_set(self.h, name.encode(), float(v)) == 0, name
+
+    def set_string(self, name, v):
+        """a registered call with a string argument (setDevices); returns 0, -1 unknown call, -2 the block threw"""
+        return int(self.L.loradrop_batch_set_string(self.h, name.encode(), str(v).encode()))
 
     def run(self, iq):
         """iq: (channels, samples) complex64 -> per-channel dicts: consumed, raw / dec / fft streams, labels per port as

@@ -73,6 +73,8 @@ def test_no_gpu_fails_loudly():
         L.LoRaDemod(10)
     with pytest.raises(L.LoraHipError):
         L.MixedDetector([7, 8, 12])
+    with pytest.raises(L.LoraHipError):
+        L.MixedDetectorMulti([7, 8, 12], [0, 0])
     with pytest.raises(MemoryError):                  # pinned memory comes from the HIP runtime: none without a device
         L.pinned_empty((16,), np.complex64)
 
@@ -88,11 +90,34 @@ def test_product_never_touches_oracle():
                 assert "/root/reference" not in src
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_c_shard_plan_equals_shard_py(world):
+    """lorahip_shard_plan (what lorahip_mixed_create_multi splits the channels over the devices of one process with, SURVEY.md
+    section 8e) is the rule of lora_sdr_amd/shard.py (the one-process-per-GPU form): BASELINE configs[3], ragged buckets, one SF,
+    fewer channels than shards. Host-only: no GPU needed."""
+    from lora_sdr_amd.shard import shard_channels
+    rng = np.random.default_rng(world)
+    cases = [7 + np.arange(16384) % 6, np.array([12, 7, 7]), np.full(1000, 10), rng.integers(6, 13, 777), np.array([9]),
+             np.concatenate([np.full(5, 7), np.full(3, 12)])]
+    for sfs in cases:
+        plan = L.shard_plan(sfs, world)
+        parts = shard_channels(sfs, world)
+        want = np.empty(len(sfs), np.int32)
+        for r, p in enumerate(parts):
+            want[p] = r
+        assert np.array_equal(plan, want)
+    assert L.shard_plan([], world).size == 0
+    lib = L.load()
+    assert lib.lorahip_shard_plan(None, 0, 0, None) == -1                 # no shards
+    bad = np.array([7, 0], np.int32); out = np.zeros(2, np.int32)
+    assert lib.lorahip_shard_plan(bad.ctypes.data, 2, 2, out.ctypes.data) == -1
+    assert lib.lorahip_mixed_create_multi(None, None, 0, None, 0) == -1
+
+
 @pytest.mark.gpu
-def test_cpp_detector_shim_detects_on_the_gpu(tmp_path):
+def test_cpp_detector_shim_detects_on_the_gpu(gpu, tmp_path):
     """the success branch of the test below, in the -m gpu set: the C++ shim class finds the DC tone in bin 0"""
-    import torch
-    assert torch.cuda.is_available()
+    assert gpu.cuda.is_available()
     test_cpp_detector_shim_compiles_links_and_fails_loudly(tmp_path)
 
 

@@ -39,3 +39,23 @@ def test_single_shape_line_keeps_the_contract(gpu):
     assert d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] in ("reference", "port")
     m = run_bench("--sf", "8", "--channels", "256", "--symbols", "16", "--steps", "3", "--warmup", "1", "--ramp-seconds", "0", "--no-cpu-baseline", "--moving")
     assert m["oracle"]["index_mismatches"] == 0 and m["config"]["moving_fine_index"] is True
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks(gpu):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset re-launches itself under torch.distributed.run (it used to run one rank and
+    report n_gpus: 1). The box has one GPU: both ranks share it over gloo (the test hooks of tools/gpu_session.sh "multi")."""
+    env = dict(os.environ, LORA_BENCH_BACKEND="gloo", LORA_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sf", "7", "--channels", "256", "--symbols", "16", "--steps", "3",
+                        "--warmup", "1", "--ramp-seconds", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and "2 rank(s)" in d["config"]["parallelism"]
+    assert "re-launching" in r.stderr
+
+
+def test_gpus_n_that_contradicts_the_launcher_is_refused(gpu):
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sf", "7", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)

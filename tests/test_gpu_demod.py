@@ -415,6 +415,42 @@ def test_level3_debug_ports_and_labels(gpu, oracle, golden, sf, mode):
     d.close()
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_ports_without_a_trace_keep_no_trace(gpu, oracle, mode):
+    """debug ports on, tracing never asked for: the library needs a per-call trace internally for the port replay, but it lives for
+    one run only -- nothing accumulates over the runs of a long-lived receiver and nothing leaks into the trace / label accessors --
+    while the ports still carry the block's outputs"""
+    import lora_sdr_amd as L
+    sf, N, mtu = 8, 256, 7
+    rng = np.random.default_rng(88)
+    st, _ = frames(oracle, rng, sf, 2, mtu, off=0.3, lead=N // 3)
+    streams = st.reshape(1, -1)
+    d = L.LoRaDemod(sf, n_channels=1)
+    d.set_mode(mode)
+    d.setMTU(mtu)
+    d.set_ports(fft_frames=st.size // (N // 4) + 8, dec_samples=st.size, raw_samples=st.size)
+    r = oracle.demod_run(sf, st, mtu=mtu)
+    consumed = np.array([k["consumed"] for k in r["calls"]])
+    for _ in range(3):
+        d.activate()
+        d.work(gpu.from_numpy(streams).to("cuda:0"))
+        assert d.trace(0) == [] and d.labels(0) == []
+        p = d.ports(0)
+        assert p["produced"] == dict(fft=len(consumed), dec=int(consumed.sum()), raw=int(consumed.sum()))
+        assert same_values(p["fft"].cpu().numpy(), np.stack(r["fft"]))
+        assert len(d.packets()) == len(r["packets"])
+        # the zero start state for the next pass (activate() alone keeps the fine-tune members, like the reference)
+        d.close()
+        d = L.LoRaDemod(sf, n_channels=1)
+        d.set_mode(mode); d.setMTU(mtu)
+        d.set_ports(fft_frames=st.size // (N // 4) + 8, dec_samples=st.size, raw_samples=st.size)
+    # one object, several runs: still no trace
+    for _ in range(3):
+        d.work(gpu.from_numpy(streams).to("cuda:0"))
+        assert d.trace(0) == []
+    d.close()
+
+
 @pytest.mark.parametrize("sf", [7, 10, 12])
 def test_packets_packed_on_the_device_equal_the_host_queue(gpu, oracle, sf):
     """lorahip_demod_packets_to_device straight after a streaming run packs the decoder's input rows from the kernel's records on

@@ -34,12 +34,28 @@ def test_dropin_library_loads_and_fails_loudly_without_a_gpu():
         DropInBatch(7, 2)
 
 
+def base_stream(golden, oracle, sf):
+    """(stream, mtu): the golden demodulator stream where the fixture holds one (SF7, SF9); for the long windows (SF11, SF12: the
+    wide kernels, demodStreamWide) a two-frame stream with a fractional frequency offset and noise made here -- the comparison is
+    against the reference block run live on the same samples either way"""
+    if sf in (7, 9):
+        g = golden("demod_stream.npz")
+        return g["iq_%d" % sf], int(g["mtu_%d" % sf])
+    rng = np.random.default_rng(1000 + sf)
+    N, mtu = 1 << sf, 9
+    parts = [np.zeros(N // 3 + 5, np.complex64)]
+    for _ in range(2):
+        parts.append(oracle.mod_frame(sf, rng.integers(0, N, mtu).astype(np.uint16), padding=3))
+    x = np.concatenate(parts + [np.zeros(2 * N, np.complex64)])
+    x = (x * np.exp(2j * np.pi * (-0.29) / N * np.arange(x.size))).astype(np.complex64)
+    x += (0.05 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))).astype(np.complex64)
+    return x, mtu
+
+
 def streams_for(golden, oracle, sf, rng):
-    """three channels of equal length: the golden stream, the same delayed, and a fresh two-frame stream with an offset"""
-    g = golden("demod_stream.npz")
-    base = g["iq_%d" % sf]
+    """three channels of equal length: the base stream, the same delayed, and a fresh two-frame stream with an offset"""
+    base, mtu = base_stream(golden, oracle, sf)
     N = 1 << sf
-    mtu = int(g["mtu_%d" % sf])
     st2 = np.concatenate([np.zeros(37, np.complex64), base])
     syms = [rng.integers(0, N, mtu).astype(np.uint16) for _ in range(2)]
     parts = [np.zeros(N // 2 + 11, np.complex64)]
@@ -56,17 +72,19 @@ def streams_for(golden, oracle, sf, rng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sf", [7, 9])
-def test_patched_reference_block_on_the_hip_detector(gpu, golden, sf):
+@pytest.mark.parametrize("sf", [7, 9, 11, 12])
+def test_patched_reference_block_on_the_hip_detector(gpu, golden, oracle, sf):
     """(a): /root/reference/LoRaDemod.cpp itself, its detector swapped for LoRaDetectorHip, against the unpatched block"""
     from oracle.oracle import Ref, REF_VARIANTS
     _need(REF_VARIANTS["dropin"])
     _need(REF_VARIANTS["-O2"])
-    g = golden("demod_stream.npz")
-    iq, mtu = g["iq_%d" % sf], int(g["mtu_%d" % sf])
+    iq, mtu = base_stream(golden, oracle, sf)
     want = Ref("-O2").demod_run(sf, iq, mtu=mtu)
     got = Ref("dropin").demod_run(sf, iq, mtu=mtu)
-    assert got["consumed"].tolist() == want["consumed"].tolist() == g["consumed_%d" % sf].tolist()
+    assert got["consumed"].tolist() == want["consumed"].tolist()
+    if sf in (7, 9):
+        assert got["consumed"].tolist() == golden("demod_stream.npz")["consumed_%d" % sf].tolist()
+    assert len(want["packets"]) >= 2
     assert got["labels"] == want["labels"]
     assert same_values(got["fft"], want["fft"])                 # the fft port: every bin of every call, bit for bit
     assert same_values(got["dec"], want["dec"])                 # the dec port is the block's own arithmetic either way
@@ -77,9 +95,12 @@ def test_patched_reference_block_on_the_hip_detector(gpu, golden, sf):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sf", [7, 9])
-def test_batch_block_posts_what_the_reference_block_posts(gpu, golden, oracle, sf):
-    """(b): LoRaDemodBatch with three channels against three runs of the unpatched reference block"""
+@pytest.mark.parametrize("sf,devices", [(7, None), (9, None), (11, None), (12, None), (7, "0,0"), (11, "0, 0,0")])
+def test_batch_block_posts_what_the_reference_block_posts(gpu, golden, oracle, sf, devices):
+    """(b): LoRaDemodBatch with three channels against three runs of the unpatched reference block. SF11 / SF12 run the streaming
+    kernel of the long windows (demodStreamWide). With setDevices the block spreads its channels over several level-3 objects, one
+    per device and host thread -- here every "device" is device 0, the one GPU a test box has: what each
+    channel's ports carry must not depend on the split."""
     from oracle.oracle import Ref, REF_VARIANTS, DropInBatch
     _need(REF_VARIANTS["dropin"])
     _need(REF_VARIANTS["-O2"])
@@ -87,6 +108,9 @@ def test_batch_block_posts_what_the_reference_block_posts(gpu, golden, oracle, s
     iq, mtu = streams_for(golden, oracle, sf, rng)
     N = 1 << sf
     blk = DropInBatch(sf, 3, max_windows=16)                    # small buffers: several work() calls of the block per stream
+    if devices:
+        assert blk.set_string("setDevices", "0,x") == -2        # Pothos::InvalidArgumentException, like the sibling blocks' setters
+        assert blk.set_string("setDevices", devices) == 0
     blk.set("setMTU", mtu)
     chans, signals, works = blk.run(iq)
     assert works > 1

@@ -96,3 +96,47 @@ def test_mixed_scheduler_refuses_bad_input(gpu):
     with pytest.raises(L.LoraHipError):
         m.plan([0, -5], 4)
     m.close()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_multi_device_scheduler_equals_single_device(gpu, devices):
+    """lorahip_mixed_create_multi (one process, one host thread + streams per device) with every "device"
+    being device 0 -- the one GPU a test box has: the channels are split by lorahip_shard_plan, every shard gets its OWN IQ buffer
+    and result arrays (as separate devices would), the shards' launches are issued from their own host threads -- and every
+    channel's results equal the single-device scheduler's over the same windows, bit for bit"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(7 + len(devices))
+    sfs = (7 + np.arange(41) % 6).astype(np.int32)
+    S = 8
+    buf, offsets, iq_of = build(rng, sfs, S)
+    single = L.MixedDetector(sfs)
+    single.plan(offsets, S)
+    ref_out = {k: v.cpu().numpy() for k, v in single.detect(gpu.from_numpy(buf.view(np.float32)).cuda()).items()}
+    multi = L.MixedDetectorMulti(sfs, devices)
+    assert np.array_equal(multi.shard_of, L.shard_plan(sfs, len(devices))) and sum(multi.counts) == len(sfs)
+    # per shard: its own buffer holding only its channels, back to back
+    off = np.zeros(len(sfs), np.int64)
+    iqs = []
+    for s in range(len(devices)):
+        mine = np.nonzero(multi.shard_of == s)[0]
+        at, parts = 0, []
+        for c in mine:
+            off[c] = at
+            parts.append(iq_of[c].reshape(-1))
+            at += parts[-1].size
+        iqs.append(gpu.from_numpy(np.concatenate(parts).view(np.float32)).cuda() if parts else None)
+    multi.plan(off, S)
+    outs = multi.detect(iqs)
+    again = multi.detect(iqs)
+    for s in range(len(devices)):
+        assert all(gpu.equal(outs[s][k], again[s][k]) for k in ("sym", "power", "powerAvg", "fIndex"))
+    for c in range(len(sfs)):
+        s, r = int(multi.shard_of[c]), int(multi.rows[c])
+        for k in ("sym", "power", "powerAvg", "fIndex"):
+            assert np.array_equal(outs[s][k][r].cpu().numpy(), ref_out[k][int(single.rows[c])]), (c, k)
+    # the single-device entry point refuses a multi-device object instead of reading the wrong buffer
+    lib = L.load()
+    z = gpu.zeros(16, device="cuda")
+    assert lib.lorahip_mixed_detect(multi._h, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr()) == -1
+    assert lib.lorahip_mixed_num_devices(multi._h) == len(devices) and lib.lorahip_mixed_num_devices(single._h) == 1
+    multi.close(); single.close()

@@ -406,3 +406,35 @@ def test_argument_validation_at_the_boundary(gpu):
     syms = gpu.zeros((2, 5), dtype=gpu.int16, device="cuda")
     with pytest.raises(ValueError):
         ctx.mod_frames(syms, frame_stride=ctx.mod_frame_len(5) - 1)
+
+
+@pytest.mark.parametrize("sf", [7, 10, 12])
+def test_synth_symbols_is_genchirp(gpu, oracle, sf):
+    """lorahip_synth_symbols -- the generator of every benchmark's input -- against genChirp (ChirpGenerator.hpp:22-47: f from
+    -pi + f0, f += 2 pi / N BEFORE use, wrap at +pi, phaseAccum += f, polar(ampl, phaseAccum)), per window from phase 0:
+    (1) against the definition in exact arithmetic (float64 here): only the final rounding of cos / sin separates them;
+    (2) against the reference's own float recurrence (the pinned restatement oracle.genchirp): the recurrence accumulates float
+        rounding in f and phaseAccum (up to ~9e-6 N: measured 4.8e-4 / 8.8e-3 / 3.5e-2 at SF7 / 10 / 12), so the tolerance is
+        2e-5 N -- far below the 2 pi / N spacing of anything the demodulator resolves;
+    (3) both demodulate to the same bins."""
+    import lora_sdr_amd as L
+    torch = gpu
+    N = 1 << sf
+    rng = np.random.default_rng(sf)
+    sym = np.concatenate([rng.integers(0, N, 29), [0, 1, N - 1, N // 2]]).astype(np.uint16)
+    ampl = 0.75
+    ctx = L.Context(sf)
+    got = ctx.synth_symbols(torch.from_numpy(sym.view(np.int16)).cuda(), ampl=ampl).cpu().numpy().reshape(len(sym), N)
+    i = np.arange(N)
+    n1 = i + 1.0
+    for k, s in enumerate(sym.tolist()):
+        f = -np.pi + 2 * np.pi * s / N + n1 * (2 * np.pi / N)                  # f after its pre-increment, before the wrap
+        f = np.where(f > np.pi, f - 2 * np.pi, f)                               # :31 / :39
+        exact = ampl * np.exp(1j * np.cumsum(f))
+        assert np.abs(got[k] - exact).max() <= 1e-6 * N ** 0.5 + 2e-7, (s, np.abs(got[k] - exact).max())
+        ref, _ = oracle.genchirp(N, 1, N, np.float32(2 * np.pi * s / N), False, ampl, 0.0)
+        assert np.abs(got[k] - ref).max() <= 2e-5 * N, (s, np.abs(got[k] - ref).max())
+    refs = np.stack([oracle.genchirp(N, 1, N, np.float32(2 * np.pi * s / N), False, ampl, 0.0)[0] for s in sym.tolist()])
+    a, b = oracle.detect_batch(sf, got.reshape(-1)), oracle.detect_batch(sf, refs.reshape(-1))
+    assert np.array_equal(a["sym"], b["sym"]) and np.array_equal(a["sym"], (sym.astype(np.int64) + 1) % N)   # the +1 bin of SURVEY.md section 7h
+    ctx.close()

@@ -82,7 +82,7 @@ def test_demod_takes_one_2d_host_array(gpu, oracle):
     a.close(); b.close()
 
 
-def test_pinned_allocation_round_trip():
+def test_pinned_allocation_round_trip(gpu):
     import lora_sdr_amd as L
     a = L.pinned_empty((3, 5), np.float32)
     a[...] = np.arange(15, dtype=np.float32).reshape(3, 5)
