@@ -80,6 +80,14 @@ struct lorahip_demod
     bool portsOn, userTracing;
     char *dPort; size_t dPortBytes;  // scratch of the port replay: window descriptors, replayed fft / dec windows
     int64_t nNearSquelch, nNearStep; // decisions float rounding could flip, since activate() (lorahip_demod_near_threshold)
+    // Streaming mode keeps the per-channel frame-machine state ON THE DEVICE between runs (its pinned copy in sHost is what the host
+    // reads); the Channel mirrors above are brought up to date only when somebody needs them (host-driven rounds, ports, accessors)
+    bool devStateFresh;              // the device holds the current state: the next streaming run need not upload it
+    bool mirrorsStale;               // ch[].state .. ch[].pos lag behind the pinned copy of the device state
+    bool activatePending;            // activate() since the last run, not yet applied to the device state / the mirrors
+    bool uniform; size_t uniSpc;     // the streams of the current run are n_channels x uniSpc samples back to back (lorahip_demod_run_device)
+    bool geomApplied;                // ch[].base / len / pos hold the current run's placement
+    bool portCountsDirty;            // ch[].portFft / portDec / portRaw may be non-zero
     void *pending;                   // PendingLaunch (records of the last streaming launch still on the device)
     std::vector<size_t> carry;       // per channel: symbols of a packet begun before the launch being drained
 };
@@ -138,9 +146,22 @@ static int launchRound(lorahip_demod *dm, const float *iqDev, const size_t n)
     return LORAHIP_OK;
 }
 
+//! ch[].base / len / pos of a uniform run (filled only for the paths that read them: host-driven rounds, the port replay)
+static void applyGeometry(lorahip_demod *dm)
+{
+    if (dm->geomApplied) return;
+    for (size_t c = 0; c < dm->B; c++) { dm->ch[c].base = c * dm->uniSpc; dm->ch[c].len = dm->uniSpc; dm->ch[c].pos = 0; }
+    dm->geomApplied = true;
+}
+
+static void syncMirrors(lorahip_demod *dm);
+
 static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     const size_t N = dm->N, B = dm->B;
+    syncMirrors(dm);
+    applyGeometry(dm);
+    dm->devStateFresh = false;                                  // the mirrors are about to change: the device copy goes stale
     const DeviceGuard guard(dm->ctx->device);
     const Round hr = carve(dm->h, B);
     std::vector<uint32_t> live, second;
@@ -486,6 +507,38 @@ static int drainPending(lorahip_demod *dm)
     return LORAHIP_OK;
 }
 
+//! the head of the streaming buffers inside dm->sHost: offsets that depend on the channel count only (StreamLayout::make)
+static StreamState *hostStates(lorahip_demod *dm)
+{
+    StreamLayout L;
+    L.make(dm->B, 8, 4, false);
+    return reinterpret_cast<StreamState *>(dm->sHost + L.oState);
+}
+
+//! bring the Channel mirrors up to date with the device's state (its pinned copy): only the paths that read them pay for it
+static void syncMirrors(lorahip_demod *dm)
+{
+    if (dm->mirrorsStale && dm->sHost)
+    {
+        const StreamState *hs = hostStates(dm);
+        for (size_t c = 0; c < dm->B; c++)
+        {
+            Channel &k = dm->ch[c];
+            const StreamState &st = hs[c];
+            k.state = st.state; k.downTable = st.downTable != 0; k.prevValue = short(st.prevValue); k.freqError = st.freqError;
+            k.fineTuneIndex = st.fineTuneIndex; k.finefreqError = st.finefreqError; k.symCount = size_t(st.symCount);
+            k.pos = size_t(st.pos);
+        }
+    }
+    dm->mirrorsStale = false;
+    if (dm->activatePending)
+    {
+        for (auto &k : dm->ch) { k.state = ST_FRAMESYNC; k.downTable = false; }     // activate() (:139-143), deferred
+        dm->activatePending = false;
+        dm->devStateFresh = false;                      // the device copy does not have it: the next streaming run uploads
+    }
+}
+
 static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     lorahip_ctx *ctx = dm->ctx;
@@ -498,8 +551,8 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     typedef std::chrono::steady_clock Clock;
     const Clock::time_point t0 = Clock::now();
     double tDev = 0, tAsm = 0;
-    size_t maxLen = 0;
-    for (size_t c = 0; c < B; c++) if (dm->ch[c].len - dm->ch[c].pos > maxLen) maxLen = dm->ch[c].len - dm->ch[c].pos;
+    size_t maxLen = dm->uniform ? dm->uniSpc : 0;
+    if (!dm->uniform) for (size_t c = 0; c < B; c++) if (dm->ch[c].len - dm->ch[c].pos > maxLen) maxLen = dm->ch[c].len - dm->ch[c].pos;
     // work() calls per channel per launch: enough for a clean stream in one launch, bounded so that the
     // per-launch buffers stay moderate (the launch is resumable)
     const size_t perCall = sizeof(short) + (dm->tracing ? sizeof(lorahip_work_result) : 0) + sizeof(StreamPacket) / 4 + 1;
@@ -516,9 +569,11 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     L.make(B, cap, capPkt, dm->tracing);
     if (L.total > dm->sBytes)
     {
+        syncMirrors(dm);                             // the pinned copy of the state goes away with the buffers
         if (dm->sDev) { (void)hipFree(dm->sDev); dm->sDev = nullptr; }
         if (dm->sHost) { (void)hipHostFree(dm->sHost); dm->sHost = nullptr; }
         dm->sBytes = 0;
+        dm->devStateFresh = false;
         LORAHIP_TRY(hipMalloc((void **)&dm->sDev, L.total));
         LORAHIP_TRY(hipHostMalloc((void **)&dm->sHost, L.oPkt, hipHostMallocDefault));       // the host mirrors only the head: placement, state, counts
         dm->sBytes = L.total;
@@ -530,27 +585,53 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     std::vector<size_t> &carry = carryOf(dm);
     carry.assign(B, 0);
     bool anyCarryIn = false;
-    for (size_t c = 0; c < B; c++)
+    // A steady receiver -- run after run in this mode, device buffers, nothing touched in between -- uploads nothing: the state is
+    // where the last run left it on the device, the placement of uniform streams is computed by the kernel, every run starts at
+    // sample 0 of its buffer (flag `fresh`), and an activate() in between travels as a flag too.
+    const bool resident = dm->devStateFresh;
+    const bool activate = resident && dm->activatePending;
+    if (resident)
     {
-        Channel &k = dm->ch[c];
-        hBase[c] = (long long)k.base;
-        hLen[c] = (long long)k.len;
-        StreamState &st = hState[c];
-        st.state = k.state; st.downTable = k.downTable ? 1 : 0; st.prevValue = k.prevValue; st.freqError = k.freqError;
-        st.fineTuneIndex = k.fineTuneIndex; st.finefreqError = k.finefreqError; st.symCount = int(k.symCount); st.callCount = 0;
-        st.pos = (long long)k.pos;
-        if (k.outSymbols.size() < k.symCount) k.outSymbols.resize(k.symCount, 0);
-        // symbols of a packet that is still being received when the run starts. _symCount itself is only reset at
-        // QUARTERCHIRP (:279), so outside DATASYMBOLS it still holds the length of the LAST packet: nothing is carried then
-        carry[c] = k.state == ST_DATASYMBOLS ? k.symCount : 0;
-        anyCarryIn = anyCarryIn || carry[c] != 0;
+        // symbols of a packet that is still being received when the run starts (see below): from the pinned copy of the state
+        if (!activate)
+            for (size_t c = 0; c < B; c++)
+                if (hState[c].state == ST_DATASYMBOLS && hState[c].symCount) { carry[c] = size_t(hState[c].symCount); anyCarryIn = true; }
+        if (anyCarryIn)
+        {
+            // the open packet's symbols so far were kept in the mirrors' outSymbols by the drain of the run that received them
+            for (size_t c = 0; c < B; c++) if (carry[c] && dm->ch[c].outSymbols.size() < carry[c]) dm->ch[c].outSymbols.resize(carry[c], 0);
+        }
     }
-    LORAHIP_TRY(hipMemcpyAsync(d, h, L.oN, hipMemcpyHostToDevice, ctx->stream));       // base, len, state
+    else
+    {
+        syncMirrors(dm);
+        for (size_t c = 0; c < B; c++)
+        {
+            Channel &k = dm->ch[c];
+            StreamState &st = hState[c];
+            st.state = k.state; st.downTable = k.downTable ? 1 : 0; st.prevValue = k.prevValue; st.freqError = k.freqError;
+            st.fineTuneIndex = k.fineTuneIndex; st.finefreqError = k.finefreqError; st.symCount = int(k.symCount); st.callCount = 0;
+            st.pos = 0;
+            if (k.outSymbols.size() < k.symCount) k.outSymbols.resize(k.symCount, 0);
+            // symbols of a packet that is still being received when the run starts. _symCount itself is only reset at
+            // QUARTERCHIRP (:279), so outside DATASYMBOLS it still holds the length of the LAST packet: nothing is carried then
+            carry[c] = k.state == ST_DATASYMBOLS ? k.symCount : 0;
+            anyCarryIn = anyCarryIn || carry[c] != 0;
+        }
+        LORAHIP_TRY(hipMemcpyAsync(d + L.oState, h + L.oState, L.oN - L.oState, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (!dm->uniform)
+    {
+        for (size_t c = 0; c < B; c++) { hBase[c] = (long long)dm->ch[c].base; hLen[c] = (long long)dm->ch[c].len; }
+        LORAHIP_TRY(hipMemcpyAsync(d, h, L.oState, hipMemcpyHostToDevice, ctx->stream));       // base, len
+    }
 
     StreamArgs a;
     a.iq = reinterpret_cast<const float2 *>(iqDev);
     a.base = reinterpret_cast<const long long *>(d + L.oBase);
     a.len = reinterpret_cast<const long long *>(d + L.oLen);
+    a.uniformLen = dm->uniform ? (long long)dm->uniSpc : -1;
+    a.flags = 1 | (activate ? 2 : 0);                 // first launch of the run: every channel starts at sample 0, call 0
     a.state = reinterpret_cast<StreamState *>(d + L.oState);
     a.nCalls = reinterpret_cast<int *>(d + L.oN);
     a.nSym = reinterpret_cast<int *>(d + L.oNSym);
@@ -569,6 +650,9 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.sync = dm->sync;
     a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
     a.near = reinterpret_cast<unsigned *>(d + L.oNear);
+    if (activate) dm->activatePending = false;        // applied by the kernel when it loads the state
+    dm->devStateFresh = false;                        // until the run has completed
+    dm->mirrorsStale = true;
 
     const size_t firstNewPacket = dm->packets.size();
     const Clock::time_point t1 = Clock::now();
@@ -583,6 +667,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         LORAHIP_TRY(hipEventRecord(dm->evK0, ctx->stream));
         LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
         LORAHIP_TRY(hipEventRecord(dm->evK1, ctx->stream));
+        a.flags = 0;                                  // a resumed launch continues where the state says
         // the per-channel state and counts come back after every launch (52 B per channel); the record arrays only when needed
         LORAHIP_TRY(hipMemcpyAsync(h + L.oState, d + L.oState, L.oPkt - L.oState, hipMemcpyDeviceToHost, ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -593,13 +678,16 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         pendPackets = pendNSym = 0;
         dm->nNearSquelch += reinterpret_cast<const unsigned *>(h + L.oNear)[0];
         dm->nNearStep += reinterpret_cast<const unsigned *>(h + L.oNear)[1];
+        const int icap = int(cap), icapPkt = int(capPkt);
+        int64_t calls = 0;
         for (size_t c = 0; c < B; c++)
         {
-            dm->workCalls += hN[c];
+            calls += hN[c];
             pendPackets += size_t(hNPkt[c]);
             pendNSym += size_t(hNSym[c]);
-            if (size_t(hN[c]) == cap || size_t(hNPkt[c]) == capPkt) more = true;
+            more = more || hN[c] == icap || hNPkt[c] == icapPkt;
         }
+        dm->workCalls += calls;
         // a launch that must be resumed hands its records over now (the next one reuses the buffers); so does a traced run (its
         // callers read the trace next). Otherwise the records wait on the device.
         if (more || dm->tracing)
@@ -619,15 +707,12 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     size_t openSyms = 0, carriedIn = 0;
     for (size_t c = 0; c < B; c++)
     {
-        Channel &k = dm->ch[c];
         const StreamState &st = hState[c];
-        k.state = st.state; k.downTable = st.downTable != 0; k.prevValue = short(st.prevValue); k.freqError = st.freqError;
-        k.fineTuneIndex = st.fineTuneIndex; k.finefreqError = st.finefreqError; k.symCount = size_t(st.symCount);
-        k.pos = size_t(st.pos);
         if (st.callCount > rounds) rounds = st.callCount;
         if (st.state == ST_DATASYMBOLS) { anyOpen = true; openSyms += size_t(st.symCount); }
-        carriedIn += carry[c];
     }
+    if (anyCarryIn || lastPending) for (size_t c = 0; c < B; c++) carriedIn += carry[c];
+    dm->devStateFresh = true;                         // the device holds what the pinned copy says; the mirrors lag (mirrorsStale)
     PendingLaunch &P = pendingOf(dm);
     if (lastPending)
     {
@@ -644,9 +729,9 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     else orderNewPackets(dm, firstNewPacket, rounds);
     if (roundsOut) *roundsOut = rounds;
     if (timing)
-        std::fprintf(stderr, "lorahip demod run: setup+H2D %.3f ms, kernel+state D2H+sync %.3f ms, record drain %.3f ms%s, state mirrors %.3f ms\n",
-                     std::chrono::duration<double>(t1 - t0).count() * 1e3, tDev * 1e3, tAsm * 1e3, lastPending ? " (last launch left on the device)" : "",
-                     std::chrono::duration<double>(Clock::now() - t2).count() * 1e3);
+        std::fprintf(stderr, "lorahip demod run: setup+H2D %.3f ms%s, kernel+state D2H+sync %.3f ms, record drain %.3f ms%s, state scan %.3f ms\n",
+                     std::chrono::duration<double>(t1 - t0).count() * 1e3, resident ? " (state resident on the device)" : "", tDev * 1e3, tAsm * 1e3,
+                     lastPending ? " (last launch left on the device)" : "", std::chrono::duration<double>(Clock::now() - t2).count() * 1e3);
     return LORAHIP_OK;
 }
 
@@ -671,6 +756,7 @@ static int fillPorts(lorahip_demod *dm, const float *iqDev)
     const size_t N = dm->N, B = dm->B;
     const lorahip_demod_ports &P = dm->ports;
     const DeviceGuard guard(ctx->device);
+    applyGeometry(dm);                                          // the replay reads ch[].base
     struct Seg { long long src, dst; int len; };
     std::vector<int64_t> wOff; std::vector<int32_t> wSel, wIdx; std::vector<float> wErr;
     std::vector<Seg> segFft, segDec, segRaw;                      // src of fft/dec segments: window number * N (chunk-relative later)
@@ -810,9 +896,13 @@ static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     // the port replay reads the per-call trace; a trace the caller did not ask for lives for this run only (it must neither grow
     // without bound in a long-running receiver nor show up in lorahip_demod_get_trace / _trace_len / _get_labels)
     const bool internalTrace = dm->portsOn && !dm->userTracing;
-    if (internalTrace) for (auto &k : dm->ch) { k.trace.clear(); k.traceSymCount0 = k.symCount; }
-    for (auto &k : dm->ch) { k.traceStart = k.trace.size(); k.portFft = k.portDec = k.portRaw = 0; }
+    if (internalTrace) { syncMirrors(dm); for (auto &k : dm->ch) { k.trace.clear(); k.traceSymCount0 = k.symCount; } }
     dm->tracing = dm->userTracing || dm->portsOn;
+    if (dm->tracing || dm->portCountsDirty)
+    {
+        for (auto &k : dm->ch) { k.traceStart = k.trace.size(); k.portFft = k.portDec = k.portRaw = 0; }
+        dm->portCountsDirty = dm->portsOn;                       // a run without ports leaves them at zero: nothing to reset next time
+    }
     int rc = stream ? runStream(dm, iqDev, roundsOut) : runRounds(dm, iqDev, roundsOut);
     if (rc == LORAHIP_OK && dm->portsOn) rc = fillPorts(dm, iqDev);
     if (internalTrace) for (auto &k : dm->ch) { std::vector<lorahip_work_result>().swap(k.trace); k.traceStart = 0; }
@@ -845,6 +935,8 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->tracing = false;
     dm->workCalls = 0;
     dm->nNearSquelch = dm->nNearStep = 0;
+    dm->devStateFresh = false; dm->mirrorsStale = false; dm->activatePending = false;
+    dm->uniform = false; dm->uniSpc = 0; dm->geomApplied = true; dm->portCountsDirty = true;
     dm->ch.resize(n_channels);
     for (auto &k : dm->ch) { k.traceStart = 0; k.traceSymCount0 = 0; k.portFft = k.portDec = k.portRaw = 0; }
     dm->stageBytes = carve(nullptr, n_channels).total;
@@ -938,8 +1030,10 @@ int lorahip_demod_activate(lorahip_demod *dm)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
     // activate() resets only _state and _chirpTable (:139-143); everything else keeps the
-    // constructor / zero state, or whatever the previous activation left
-    for (auto &k : dm->ch) { k.state = ST_FRAMESYNC; k.downTable = false; }
+    // constructor / zero state, or whatever the previous activation left. While the state lives on the device (streaming mode)
+    // the reset travels with the next launch as a flag; the mirrors get it when they are next brought up to date.
+    if (dm->devStateFresh) dm->activatePending = true;
+    else { syncMirrors(dm); for (auto &k : dm->ch) { k.state = ST_FRAMESYNC; k.downTable = false; } }
     dm->nNearSquelch = dm->nNearStep = 0;
     return LORAHIP_OK;
 }
@@ -947,12 +1041,9 @@ int lorahip_demod_activate(lorahip_demod *dm)
 int lorahip_demod_run_device(lorahip_demod *dm, const float *iq_dev, const size_t samples_per_channel, int64_t *rounds)
 {
     if (dm == nullptr || iq_dev == nullptr) return LORAHIP_E_INVALID;
-    for (size_t c = 0; c < dm->B; c++)
-    {
-        dm->ch[c].base = c * samples_per_channel;
-        dm->ch[c].len = samples_per_channel;
-        dm->ch[c].pos = 0;
-    }
+    // n_channels streams of equal length back to back: the placement is two numbers, not 3 * n_channels (ch[].base / len / pos are
+    // filled only for the paths that read them, applyGeometry)
+    dm->uniform = true; dm->uniSpc = samples_per_channel; dm->geomApplied = false;
     return runAny(dm, iq_dev, rounds);
 }
 
@@ -961,6 +1052,7 @@ int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size
     if (dm == nullptr || streams == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
     const DeviceGuard guard(dm->ctx->device);
     size_t total = 0;
+    dm->uniform = false; dm->geomApplied = true;
     for (size_t c = 0; c < dm->B; c++)
     {
         if (n_samples[c] && streams[c] == nullptr) return LORAHIP_E_INVALID;
@@ -1133,6 +1225,7 @@ int lorahip_demod_near_threshold(const lorahip_demod *dm, int64_t *near_squelch,
 int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
 {
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
+    if (dm->mirrorsStale && dm->sHost) return int64_t(hostStates(const_cast<lorahip_demod *>(dm))[channel].pos);
     return int64_t(dm->ch[channel].pos);
 }
 
@@ -1140,6 +1233,7 @@ int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
     const bool was = dm->tracing;
+    syncMirrors(dm);                                            // traceSymCount0 is read from the mirrors
     dm->userTracing = enable != 0;
     dm->tracing = dm->userTracing || dm->portsOn;
     if (!dm->userTracing) for (auto &k : dm->ch) { k.trace.clear(); k.traceStart = 0; k.traceSymCount0 = k.symCount; }
@@ -1180,7 +1274,7 @@ int lorahip_demod_set_ports(lorahip_demod *dm, const lorahip_demod_ports *p)
         }
         dm->portsOn = dm->ports.fft_dev || dm->ports.dec_dev || dm->ports.raw_dev;
     }
-    if (dm->portsOn && !dm->tracing) for (auto &k : dm->ch) k.traceSymCount0 = k.symCount;
+    if (dm->portsOn && !dm->tracing) { syncMirrors(dm); for (auto &k : dm->ch) k.traceSymCount0 = k.symCount; }
     dm->tracing = dm->userTracing || dm->portsOn;
     return LORAHIP_OK;
 }

@@ -124,6 +124,8 @@ struct StreamArgs
     float thresh;
     int sync;
     unsigned mtu;
+    long long uniformLen;       // >= 0: channel c's stream is the uniformLen samples at c * uniformLen (base / len are not read)
+    int flags;                  // bit 0: first launch of a run -- every channel starts at sample 0, call 0; bit 1: activate() first
     unsigned *near;             // [2] decisions float rounding could flip (lorahip_demod_near_threshold): squelch margins, fine-tune steps
 };
 

@@ -62,7 +62,10 @@ demodStream(const StreamArgs s)
     const bool mine = c < s.nChannels;
     const unsigned cc = mine ? c : 0;
     StreamState st = s.state[cc];
-    const long long base = s.base[cc], len = mine ? s.len[cc] : 0;
+    if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
+    if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
+    const long long base = s.uniformLen >= 0 ? (long long)cc * s.uniformLen : s.base[cc];
+    const long long len = !mine ? 0 : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]);
     StreamOut o;
     o.init(s, cc);
 

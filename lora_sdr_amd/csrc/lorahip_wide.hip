@@ -681,7 +681,10 @@ demodStreamWide(const StreamArgs s)
 
     const unsigned c = blockIdx.x;                         // one channel per workgroup
     StreamState st = s.state[c];
-    const long long base = s.base[c], len = s.len[c];
+    if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
+    if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
+    const long long base = s.uniformLen >= 0 ? (long long)c * s.uniformLen : s.base[c];
+    const long long len = s.uniformLen >= 0 ? s.uniformLen : s.len[c];
     StreamOut o;
     o.init(s, c);
 
