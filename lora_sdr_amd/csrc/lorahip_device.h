@@ -264,6 +264,21 @@ __device__ __forceinline__ double groupSumF64(double v)
     return v;
 }
 
+//! sum of a float over the aligned group of T lanes, result in every lane (the same pairing tree as groupSumF64, half the moves)
+template <int T>
+__device__ __forceinline__ float groupSumF32(float v)
+{
+#define LORAHIP_SUM_DPP32(CTRL) v += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), CTRL, 0xf, 0xf, false));
+    if (T >= 2) LORAHIP_SUM_DPP32(0xB1)
+    if (T >= 4) LORAHIP_SUM_DPP32(0x4E)
+    if (T >= 8) LORAHIP_SUM_DPP32(0x141)
+    if (T >= 16) LORAHIP_SUM_DPP32(0x140)
+#undef LORAHIP_SUM_DPP32
+    if (T >= 32) { const v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r.x) + __uint_as_float(r.y); }
+    if (T >= 64) { const v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r.x) + __uint_as_float(r.y); }
+    return v;
+}
+
 template <int T>
 __device__ __forceinline__ void groupArgmax(float &bestV, int &bestI)
 {
@@ -400,6 +415,26 @@ __device__ __forceinline__ int laneScan(BIN bin, float &bestV, double &tot)
     return cj[0];
 }
 
+/*! laneScan with the total in fp32: the arg-max part is the reference's scan unchanged (same comparisons, same winner); the total is
+ * only good for the streaming kernels' QUICK squelch estimate (squelchQuickF below), never for a value that leaves the kernel. */
+template <int CNT, class BIN>
+__device__ __forceinline__ int laneScanQuick(BIN bin, float &bestV, float &totF)
+{
+    float cv = 0.0f, ct[2] = {0.0f, 0.0f};
+    int cj = 0;
+#pragma unroll
+    for (int j = 0; j < CNT; j++)
+    {
+        const auto b = bin(j);
+        const float mag2 = b.x * b.x + b.y * b.y;
+        ct[j & 1] += mag2;
+        if (mag2 > cv) { cv = mag2; cj = j; }
+    }
+    bestV = cv;
+    totF = ct[0] + ct[1];
+    return cj;
+}
+
 //! fIndex alone, for the same replicated lanes: the fIndex operations of tailValuesPaired (hence its bits) without the two
 //! logarithms -- what FRAMESYNC consumes of an unsquelched window when no trace is kept (LoRaDemod.cpp:217-221)
 template <class CPX>
@@ -428,6 +463,22 @@ __device__ __forceinline__ bool squelchQuick(const float maxValue, const double 
     const float snrApprox = 3.01029995664f * (__builtin_amdgcn_logf(maxValue) - __builtin_amdgcn_logf(noise2));   // 10 log10 = 3.0103 log2
     sure = maxValue > 0.0f && noise2 > 0.0f && __builtin_fabsf(snrApprox - thresh) > 0.01f && snrApprox == snrApprox &&
            __builtin_fabsf(snrApprox) < 1e30f;
+    return snrApprox < thresh;
+}
+
+/*! squelchQuick on a total that was accumulated in fp32 (laneScanQuick + groupSumF32: at most CNT + log2 T roundings, relative error
+ * below `relErr`). noise2 = total - maxValue cancels when the peak dominates, so its relative error is relErr * (1 + maxValue /
+ * noise2): the band around the threshold inside which the caller must evaluate the exact fp64 chain widens by exactly that (in dB:
+ * 4.343 * relative error, doubled for slack) -- the decision taken outside the band is the exact one for any threshold the block
+ * can be given. */
+__device__ __forceinline__ bool squelchQuickF(const float maxValue, const float totalF, const float thresh, const float relErr, bool &sure)
+{
+    const float noise2 = totalF - maxValue;
+    const float ratio = maxValue / noise2;
+    const float snrApprox = 3.01029995664f * (__builtin_amdgcn_logf(maxValue) - __builtin_amdgcn_logf(noise2));   // 10 log10 = 3.0103 log2
+    const float band = 0.01f + 8.7f * relErr * (1.0f + ratio);
+    sure = maxValue > 0.0f && noise2 > 0.0f && __builtin_fabsf(snrApprox - thresh) > band && snrApprox == snrApprox &&
+           __builtin_fabsf(snrApprox) < 1e30f && band == band && band < 1e30f;
     return snrApprox < thresh;
 }
 

@@ -207,10 +207,13 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
             const v2f *cwf = &cw[0][0];
             const v2f sgn2 = MAKE2(1.0f, sgn);                       // one packed multiply: (re, +-im), both exact
             const auto chirpOf = [&](const int i) { return cwf[i] * sgn2; };
+            const auto chirpRaw = [&](const int i) { return cwf[i]; };
             if (anyMoving)
             {
-                // yv = idx0 in the windows that do not move
-                dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, dechirp);
+                // yv = idx0 in the windows that do not move. A launch-uniform table selection is already in the values (s0 above):
+                // no per-sample sign multiply then
+                if (perWindowSel) dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, dechirp);
+                else dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC>(&x[0][0], chirpRaw, &yv[0][0], fl, gFine, dechirp);
             }
             else
             {

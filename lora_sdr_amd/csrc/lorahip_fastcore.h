@@ -346,6 +346,26 @@ struct FastCore
         // same pairing on all lanes, so tot is identical on all of them too
     }
 
+    //! scan() for a caller that only needs the window's arg-max and a QUICK total (fp32: the streaming kernels' squelch estimate,
+    //! squelchQuickF; anything that leaves the kernel comes from scan()). Same winner as scan(): the same strict comparisons.
+    static constexpr float QUICK_REL_ERR = float(GL * NGL + LOG2T + 2) * 0x1p-24f;
+    template <bool STORE_F>
+    static __device__ __forceinline__ void scanQuick(const v2f (&vl)[NGL][GL], v2f *F, const int t, float &bestV, int &bestI, float &totF)
+    {
+        if (!C::NB_SELECT && STORE_F)
+        {
+#pragma unroll
+            for (int e = 0; e < GL; e++)
+#pragma unroll
+                for (int g = 0; g < NGL; g++) F[(t + T * g) + (e << BL)] = vl[g][e];
+        }
+        const int bestJ = laneScanQuick<GL * NGL>([&](const int j) { return vl[j % NGL][j / NGL]; }, bestV, totF);
+        bestI = (t + T * (bestJ & (NGL - 1))) + ((bestJ / NGL) << BL);
+        if (!(bestV > 0.0f)) bestI = 0;
+        groupArgmax<T>(bestV, bestI);
+        totF = groupSumF32<T>(totF);
+    }
+
     //! bins k-1 and k+1 of the window's peak k (LoRaDetector.hpp:56-57), valid in every lane of the window
     template <bool FROM_REGS = C::NB_SELECT>
     static __device__ __forceinline__ void neighbours(const v2f (&vl)[NGL][GL], const v2f *F, const int bestI, const int lane, const int t,

@@ -264,19 +264,23 @@ __device__ __forceinline__ void finePairWait(d2v &a0, d2v &b0, d2v &a1, d2v &b1)
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1) : "n"(LATER));
 }
 
-template <bool SELECT, class CHIRP>
+//! CONJ: chirp(i) is the DOWN-chirp table's entry and the window wants the up-chirp table, its conjugate (LoRaDemod.cpp:103): the
+//! conjugation rides on the multiply's sign modifiers (cmulConjv: the same products, the same roundings) instead of costing a
+//! packed multiply by (1, -1) per sample
+template <bool SELECT, bool CONJ, class CHIRP>
 __device__ __forceinline__ void fineApply(v2f &x, CHIRP chirp, const int i, const d2v a, const d2v b, const bool keep)
 {
     const double re = __builtin_fma(a.x, b.x, -(a.y * b.y));
     const double im = __builtin_fma(a.x, b.y, a.y * b.x);
-    const v2f v = cmulv(cmulv(x, chirp(i)), v2f{(float)re, (float)im});
+    const v2f xc = CONJ ? cmulConjv(x, chirp(i)) : cmulv(x, chirp(i));
+    const v2f v = cmulv(xc, v2f{(float)re, (float)im});
     x = (!SELECT || keep) ? v : x;
 }
 
 //! the split-table path of dechirpFine as a software pipeline over pairs of samples: the four LDS reads of the next pair are in
 //! flight while this pair's two fp64 products and four complex multiplies issue. The reads and the waits are written out
 //! (inline asm) because the compiler otherwise sinks every read to its use and waits for it at once.
-template <int LH, int CNT, bool SELECT, class CHIRP>
+template <int LH, int CNT, bool SELECT, bool CONJ, class CHIRP>
 __device__ __forceinline__ void dechirpFineSplit(v2f *x, CHIRP chirp, const unsigned *y, const FineLds &s, const bool keep)
 {
     const unsigned baseA = __builtin_amdgcn_readfirstlane(ldsByteAddress(s.A)), baseB = __builtin_amdgcn_readfirstlane(ldsByteAddress(s.B));
@@ -294,20 +298,20 @@ __device__ __forceinline__ void dechirpFineSplit(v2f *x, CHIRP chirp, const unsi
             finePairWait<4>(a[cur][0], b[cur][0], a[cur][1], b[cur][1]);
         }
         else finePairWait<0>(a[cur][0], b[cur][0], a[cur][1], b[cur][1]);
-        fineApply<SELECT>(x[i], chirp, i, a[cur][0], b[cur][0], keep);
-        fineApply<SELECT>(x[i + 1], chirp, i + 1, a[cur][1], b[cur][1], keep);
+        fineApply<SELECT, CONJ>(x[i], chirp, i, a[cur][0], b[cur][0], keep);
+        fineApply<SELECT, CONJ>(x[i + 1], chirp, i + 1, a[cur][1], b[cur][1], keep);
     }
 }
 
-template <int LH, int CNT, class CHIRP>
+template <int LH, int CNT, bool CONJ = false, class CHIRP>
 __device__ __forceinline__ void dechirpFine(v2f *x, CHIRP chirp, const unsigned *y, const FineLds &s, const v2f *__restrict__ gFine, const bool keep)
 {
     static_assert(CNT % 4 == 0, "four values per round");
     if (s.split)                                                // uniform over the launch
     {
         // no window of this wave fed already dechirped (the rule): no per-sample select
-        if (__all(keep)) dechirpFineSplit<LH, CNT, false>(x, chirp, y, s, keep);
-        else dechirpFineSplit<LH, CNT, true>(x, chirp, y, s, keep);
+        if (__all(keep)) dechirpFineSplit<LH, CNT, false, CONJ>(x, chirp, y, s, keep);
+        else dechirpFineSplit<LH, CNT, true, CONJ>(x, chirp, y, s, keep);
     }
     else
     {
@@ -320,7 +324,8 @@ __device__ __forceinline__ void dechirpFine(v2f *x, CHIRP chirp, const unsigned 
 #pragma unroll
             for (int j = 0; j < 4; j++)
             {
-                const v2f v = cmulv(cmulv(x[i + j], chirp(i + j)), f[j]);
+                const v2f xc = CONJ ? cmulConjv(x[i + j], chirp(i + j)) : cmulv(x[i + j], chirp(i + j));
+                const v2f v = cmulv(xc, f[j]);
                 x[i + j] = keep ? v : x[i + j];
             }
         }

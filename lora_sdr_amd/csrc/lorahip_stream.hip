@@ -21,6 +21,9 @@
 #ifndef STREAM_SCAN_CHAINS
 #define STREAM_SCAN_CHAINS 1
 #endif
+#ifndef STREAM_WPS
+#define STREAM_WPS 2            // wavefronts per SIMD the register budget is set for (3 = 168 VGPRs: A/B builds, profiles/r03)
+#endif
 namespace lorahip {
 
 template <class C>
@@ -57,8 +60,15 @@ demodStream(const StreamArgs s)
     const FineLds fl = fineLoadLds<C::LOG2N>(sFine, s.fineA, s.fineB, threadIdx.x, blockDim.x);
     __syncthreads();
 
+    // With one channel per wavefront (T = 64: SF10) everything the frame machine touches is WAVE-UNIFORM; saying so (v_readfirstlane
+    // on what comes out of the vector unit) moves the machine -- state, 64-bit positions, record pointers, counters -- into scalar
+    // registers and onto the scalar unit. With several channels per wavefront the state is replicated in each channel's T lanes.
+    constexpr bool UNI = WPW == 1;
+    const auto uniI = [](const int v) { return UNI ? __builtin_amdgcn_readfirstlane(v) : v; };
+    const auto uniF = [](const float v) { return UNI ? __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))) : v; };
+
     // ---- this lane group's channel and its state (replicated in the T lanes) ----------------------
-    const unsigned c = (blockIdx.x * WAVES + wave) * WPW + wsub;
+    const unsigned c = UNI ? (unsigned)uniI(int((blockIdx.x * WAVES + wave) * WPW)) : (blockIdx.x * WAVES + wave) * WPW + wsub;
     const bool mine = c < s.nChannels;
     const unsigned cc = mine ? c : 0;
     StreamState st = s.state[cc];
@@ -129,16 +139,37 @@ demodStream(const StreamArgs s)
         const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
         const v2f *cwf = &cw[0][0];
         const v2f sgn2 = MAKE2(1.0f, sgn);                       // one packed multiply: (re, +-im), both exact
-            const auto chirpOf = [&](const int i) { return cwf[i] * sgn2; };
+        const auto chirpOf = [&](const int i) { return cwf[i] * sgn2; };
+        const auto chirpRaw = [&](const int i) { return cwf[i]; };
+        // When every channel of the wave uses the same table -- the up-chirp table in FRAMESYNC / DATASYMBOLS, i.e. nearly always --
+        // the conjugation rides on the multiply's sign modifiers (cmulConjv / the CONJ pipeline: the same products and roundings)
+        // instead of a packed multiply by (1, -1) per sample; a wave that mixes the two (a channel in its two down-chirp calls)
+        // takes the general form. Idle groups (`on` false) go with whatever the others use: their results are dropped.
+        const bool allUp = !__any(on && downTable), allDown = !__any(on && !downTable);
         // yv = idx0 in the channels where nothing moves
-        if (anyMoving) dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, true);
+        if (anyMoving)
+        {
+            if (allUp) dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC, true>(&x[0][0], chirpRaw, &yv[0][0], fl, gFine, true);
+            else if (allDown) dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC, false>(&x[0][0], chirpRaw, &yv[0][0], fl, gFine, true);
+            else dechirpFine<fineSplitLog2H(C::LOG2N), R * VEC, false>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, true);
+        }
         else
         {
             const v2f fconst = gFine[idx0];
+            if (allUp)
+            {
 #pragma unroll
-            for (int r = 0; r < R; r++)
+                for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulv(x[r][u], chirpOf(r * VEC + u)), fconst);
+                    for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulConjv(x[r][u], cwf[r * VEC + u]), fconst);
+            }
+            else
+            {
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulv(x[r][u], chirpOf(r * VEC + u)), fconst);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -166,10 +197,13 @@ demodStream(const StreamArgs s)
         }
         else
         {
-            if (staged) K::template scan<true, STREAM_SCAN_CHAINS>(vl, F, nullptr, t, bestV, bestI, tot);
-            else K::template scan<false, STREAM_SCAN_CHAINS>(vl, F, nullptr, t, bestV, bestI, tot);
+            // no fp64 total on this path: the squelch estimate takes an fp32 one (scanQuick / squelchQuickF, whose `sure` band
+            // accounts for it); the exact total is summed only where the exact chain is evaluated
+            float totF;
+            if (staged) K::template scanQuick<true>(vl, F, t, bestV, bestI, totF);
+            else K::template scanQuick<false>(vl, F, t, bestV, bestI, totF);
             bool sure;
-            squelched = squelchQuick(bestV, tot, s.thresh, sure);
+            squelched = squelchQuickF(bestV, totF, s.thresh, K::QUICK_REL_ERR, sure);
             power = powerAvg = fIndex = 0.0f;                                           // not consumed without a trace
             const bool exact = on && wantSq && !sure;
             const bool fi = on && (wantFi == 2 || (wantFi == 1 && (!sure || !squelched)));
@@ -184,6 +218,12 @@ demodStream(const StreamArgs s)
                 }
                 if (__any(exact))
                 {
+                    // LoRaDetector.hpp:36-48's double total, in scan()'s association (the bins are still in registers)
+                    {
+                        float bv_;
+                        (void)laneScan<GL * NGL, STREAM_SCAN_CHAINS>([&](const int j) { return vl[j % NGL][j / NGL]; }, bv_, tot);
+                        tot = groupSumF64<T>(tot);
+                    }
                     tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
                     squelched = (power - powerAvg) < s.thresh;                           // the quick decision where it was sure, by construction
                     if (exact && t == 0 && nearSquelch(power - powerAvg, s.thresh)) atomicAdd(s.near, 1u);
@@ -192,7 +232,10 @@ demodStream(const StreamArgs s)
                 else fIndex = fIndexPaired(bestV, l, r, lane);
             }
         }
-        value = bestI;
+        value = uniI(bestI);
+        squelched = uniI(squelched) != 0;
+        fIndex = uniF(fIndex); power = uniF(power); powerAvg = uniF(powerAvg);
+        idxEnd = uniI(idxEnd);
         TMARK(4);
     };
 
@@ -245,7 +288,11 @@ demodStream(const StreamArgs s)
         }
 
         // ---- the frame machine (:176-312) ----
-        if (step) frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
+        if (step)
+        {
+            frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
+            st.finefreqError = uniF(st.finefreqError);          // a float add runs on the vector unit: back to a scalar where uniform
+        }
     }
 #ifdef LORAHIP_STREAM_TIMING
     if (blockIdx.x == 7 && threadIdx.x == 0)
@@ -280,12 +327,12 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
 
 // chirp table from LDS (both selections share it), last-phase twiddles in registers (+3-10 % over the LDS table, session 10)
 //             LOG2N T VEC NPH PB1 PB2 w/SIMD  X0: ROT PAD S  D   chLDS twLDS prefetch
-typedef FastCfg<6,  2, 4,  2,  2,  6,  2,          2,  1,  0, 0,  true,  false,  0> Stream6;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  2,          1,  1,  0, 0,  true,  false,  0> Stream7;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  2,          0,  1,  0, 0,  true,  false,  0> Stream8;
-typedef FastCfg<9,  5, 2,  3,  3,  7,  2,          2,  1,  1, 8,  true,  false,  0, false, false, true> Stream9;    // 32 lanes x 16 points, three phases, exchange 1 as row swaps:
+typedef FastCfg<6,  2, 4,  2,  2,  6,  STREAM_WPS,          2,  1,  0, 0,  true,  false,  0> Stream6;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  STREAM_WPS,          1,  1,  0, 0,  true,  false,  0> Stream7;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  STREAM_WPS,          0,  1,  0, 0,  true,  false,  0> Stream8;
+typedef FastCfg<9,  5, 2,  3,  3,  7,  STREAM_WPS,          2,  1,  1, 8,  true,  false,  0, false, false, true> Stream9;    // 32 lanes x 16 points, three phases, exchange 1 as row swaps:
                                                                                                                  // with the per-sample fine-tune arithmetic the 32-point geometry spills (0.20 -> 0.26 of the roofline)
-typedef FastCfg<10, 6, 1,  3,  4,  8,  2,          0,  1,  0, 0,  true,  false,  0, false, false, true> Stream10;   // exchange 1 as register row swaps
+typedef FastCfg<10, 6, 1,  3,  4,  8,  STREAM_WPS,          0,  1,  0, 0,  true,  false,  0, false, false, true> Stream10;   // exchange 1 as register row swaps
 
 //! the used columns of a [rows][capacity] record array packed densely (2-byte units): what goes back to the host is what a
 //! run filled, not the worst-case capacity

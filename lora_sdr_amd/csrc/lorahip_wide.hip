@@ -346,8 +346,10 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
             const auto chirpOf = [&](const int i) { return cwf[i] * sgn2; };
             if (anyMoving)
             {
-                // yv = idx0 in the windows that do not move
-                dechirpFine<fineSplitLog2H(LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, dechirp);
+                // yv = idx0 in the windows that do not move; a launch-uniform selection is already in the values (s0): no sign multiply
+                const auto chirpRaw = [&](const int i) { return cwf[i]; };
+                if (perWindowSel) dechirpFine<fineSplitLog2H(LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, dechirp);
+                else dechirpFine<fineSplitLog2H(LOG2N), R * VEC>(&x[0][0], chirpRaw, &yv[0][0], fl, gFine, dechirp);
             }
             else
             {
@@ -679,7 +681,13 @@ demodStreamWide(const StreamArgs s)
     const FineLds fl = fineLoadLds<LOG2N>(sFine, s.fineA, s.fineB, t, T);
     __syncthreads();
 
-    const unsigned c = blockIdx.x;                         // one channel per workgroup
+    // One channel per workgroup: everything the frame machine touches is WORKGROUP-UNIFORM. Saying so (v_readfirstlane where a value
+    // comes out of the vector unit: the peak, the squelch decision, fIndex) lets the whole machine -- state, 64-bit positions, record
+    // pointers and counters, the fine-tune plan -- live in scalar registers and run on the scalar unit instead of being replicated
+    // in every lane's vector registers.
+    const auto uniI = [](const int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const auto uniF = [](const float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
+    const unsigned c = blockIdx.x;
     StreamState st = s.state[c];
     if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
     if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
@@ -698,10 +706,11 @@ demodStreamWide(const StreamArgs s)
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
+        const v2f *win = gIq + off;                          // scalar base, per-lane offsets
 #pragma unroll
         for (int r = 0; r < R; r++)
         {
-            const v2f *p = gIq + off + VEC * t + VEC * T * r;
+            const v2f *p = win + VEC * t + VEC * T * r;
             if (VEC == 2)
             {
                 const v4f q = *reinterpret_cast<const v4f *>(p);
@@ -719,32 +728,38 @@ demodStreamWide(const StreamArgs s)
         if (moving)
         {
             // closed-form indices of this lane's samples (lorahip_fine.h); the exact chain where the form does not apply
-            const FinePlan pl = finePlan(d, M);
+            FinePlan pl = finePlan(d, M);
+            pl.q = (unsigned)uniI((int)pl.q); pl.mod = (unsigned)uniI((int)pl.mod); pl.regular = uniI(pl.regular); pl.sat = uniI(pl.sat);
             const unsigned ymax = fineLaneIndices<LOG2N, VEC, T, R>(idx0, pl, t, yv);
-            idxEnd = fineEndIndex(idx0, pl, LOG2N, LOG2N + 7);
+            idxEnd = uniI(fineEndIndex(idx0, pl, LOG2N, LOG2N + 7));
             usedChain = !pl.regular || __syncthreads_or(ymax == (unsigned)M);
             if (t == 0 && nearStep(d)) atomicAdd(s.near + 1, 1u);                    // counted, not changed (lorahip_internal.h)
             if (usedChain)
             {
-                idxEnd = fineChainBlock<T, M>(idx0, d, t, t >> 6, sIdx, sChain);
+                idxEnd = uniI(fineChainBlock<T, M>(idx0, d, t, t >> 6, sIdx, sChain));
 #pragma unroll
                 for (int r = 0; r < R; r++)
 #pragma unroll
                     for (int u = 0; u < VEC; u++) yv[r][u] = (unsigned)sIdx[chainSlot(VEC * t + u + VEC * T * r)];
             }
         }
-        const float sgn = downTable ? 1.0f : -1.0f;        // _upChirpTable = conj(entry)  LoRaDemod.cpp:103
+        // _upChirpTable = conj(entry) (LoRaDemod.cpp:103): the table selection is workgroup-uniform here, so the conjugation rides on
+        // the multiply's sign modifiers (cmulConjv / the CONJ pipeline) instead of a packed multiply by (1, -1) per sample
         const v2f *chf = &ch[0][0];
-        const v2f sgn2 = MAKE2(1.0f, sgn);                       // one packed multiply: (re, +-im), both exact
-            const auto chirpOf = [&](const int i) { return chf[i] * sgn2; };
-        if (moving) dechirpFine<fineSplitLog2H(LOG2N), R * VEC>(&x[0][0], chirpOf, &yv[0][0], fl, gFine, true);
+        const auto chirpRaw = [&](const int i) { return chf[i]; };
+        if (moving)
+        {
+            if (downTable) dechirpFine<fineSplitLog2H(LOG2N), R * VEC, false>(&x[0][0], chirpRaw, &yv[0][0], fl, gFine, true);
+            else dechirpFine<fineSplitLog2H(LOG2N), R * VEC, true>(&x[0][0], chirpRaw, &yv[0][0], fl, gFine, true);
+        }
         else
         {
             const v2f fconst = gFine[idx0];
 #pragma unroll
             for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int u = 0; u < VEC; u++) x[r][u] = cmulv(cmulv(x[r][u], chirpOf(r * VEC + u)), fconst);
+                for (int u = 0; u < VEC; u++)
+                    x[r][u] = cmulv(downTable ? cmulv(x[r][u], chf[r * VEC + u]) : cmulConjv(x[r][u], chf[r * VEC + u]), fconst);
         }
         if (usedChain) __syncthreads();                    // sIdx is about to be overwritten by exchange 0
 
@@ -780,14 +795,25 @@ demodStreamWide(const StreamArgs s)
         for (int e = 0; e < 16; e++) vl[e] = X[C::x0off(rmid | rev4(e, HB)) + klow];
         runPhase<LOG2N, B2, LOG2N, true>(vl, 0, nullptr, twR);
 
-        // scan (LoRaDetector.hpp:36-48)
+        // scan (LoRaDetector.hpp:36-48). Without a trace the total only feeds the quick squelch estimate: fp32 then (laneScanQuick,
+        // squelchQuickF); the fp64 total is summed where the exact chain is evaluated (below)
         float bestV;
         double tot;
-        const int bestE = laneScan<16, SCAN_CHAINS_WIDE>([&](const int e) { return vl[e]; }, bestV, tot);
+        int bestE;
+        if (all)
+        {
+            bestE = laneScan<16, SCAN_CHAINS_WIDE>([&](const int e) { return vl[e]; }, bestV, tot);
+            tot = groupSumF64<64>(tot);
+        }
+        else
+        {
+            float totF;
+            bestE = laneScanQuick<16>([&](const int e) { return vl[e]; }, bestV, totF);
+            tot = (double)groupSumF32<64>(totF);
+        }
         int bestI = t + (bestE << LOG2T);
         if (!(bestV > 0.0f)) bestI = 0;
         groupArgmax<64>(bestV, bestI);
-        tot = groupSumF64<64>(tot);
         if (lane == 0) { sRed[wave].v = bestV; sRed[wave].i = bestI; sRed[wave].tot = tot; }
         __syncthreads();                                                                      // B4
         {
@@ -801,13 +827,18 @@ demodStreamWide(const StreamArgs s)
                 tot += rk.tot;
             }
         }
+        // workgroup-uniform from here on: every thread combined the same records in the same order
+        bestI = uniI(bestI);
+        bestV = uniF(bestV);
+        tot = __hiloint2double(uniI(__double2hiint(tot)), uniI(__double2loint(tot)));
         value = bestI;
-        // workgroup-uniform from here on: bestV, tot (hence the quick estimate and `sure`) are identical in every thread
         bool needLogs = all, needFi = all;
         if (!all)
         {
             bool sure;
-            squelched = squelchQuick(bestV, tot, s.thresh, sure);
+            squelched = squelchQuickF(bestV, (float)tot, s.thresh, float(16 + 6 + WPWIN + 2) * 0x1p-24f, sure);
+            squelched = uniI(squelched) != 0;
+            sure = uniI(sure) != 0;
             power = powerAvg = fIndex = 0.0f;                   // not consumed without a trace
             needLogs = wantSq && !sure;
             needFi = wantFi == 2 || (wantFi == 1 && (!sure || !squelched));   // 2: the second window of a FRAMESYNC call (:203, :217-221)
@@ -824,40 +855,74 @@ demodStreamWide(const StreamArgs s)
                 if (ownR) sNb[1] = mine;
             }
             __syncthreads();                                                                  // B5
+            if (needLogs && !all)
+            {
+                // the exact chain wants LoRaDetector.hpp:36-48's double total, in the traced path's association (bins still in registers)
+                float bv_;
+                double te;
+                (void)laneScan<16, SCAN_CHAINS_WIDE>([&](const int e) { return vl[e]; }, bv_, te);
+                te = groupSumF64<64>(te);
+                if (lane == 0) sRed[wave].tot = te;
+                __syncthreads();
+                tot = sRed[0].tot;
+#pragma unroll
+                for (int k = 1; k < WPWIN; k++) tot += sRed[k].tot;
+                tot = __hiloint2double(uniI(__double2hiint(tot)), uniI(__double2loint(tot)));
+            }
             if (needLogs)
             {
                 tailValuesPaired(s.powerScale, bestV, tot, sNb[0], sNb[1], lane, power, powerAvg, fIndex);
+                power = uniF(power); powerAvg = uniF(powerAvg); fIndex = uniF(fIndex);
                 squelched = (power - powerAvg) < s.thresh;                                   // :173-174
+                squelched = uniI(squelched) != 0;
                 if (wantSq && t == 0 && nearSquelch(power - powerAvg, s.thresh)) atomicAdd(s.near, 1u);
                 if (!all) power = powerAvg = 0.0f;
             }
-            else fIndex = fIndexPaired(bestV, sNb[0], sNb[1], lane);
+            else fIndex = uniF(fIndexPaired(bestV, sNb[0], sNb[1], lane));
         }
     };
 
-    while ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt)                  // LoRaDemod.cpp:148
+    // A FRAMESYNC call that is sync'd and matches the first sync word looks at a SECOND window (LoRaDemod.cpp:183-206): it is taken
+    // in the next pass of the loop (`pend`), so that the kernel holds ONE instance of the window code, not two -- nothing is written
+    // and nothing is consumed in between, and the limits checked for the first pass cover the whole call (same scheme as demodStream).
+    bool pend = false;
+    int value0 = 0, fineIdxBefore0 = 0;
+    float snr0 = 0.0f, fineErrBefore0 = 0.0f;
+    while (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt))          // LoRaDemod.cpp:148
     {
+        const bool second = pend;
         int value, idxEnd;
         float power, powerAvg, fIndex;
-        const int fineIdxBefore = st.fineTuneIndex;
-        const float fineErrBefore = st.finefreqError;
+        const int fineIdxBefore = second ? fineIdxBefore0 : st.fineTuneIndex;
+        const float fineErrBefore = second ? fineErrBefore0 : st.finefreqError;
+        const bool fs = st.state == ST_FRAMESYNC;
         bool squelched;
-        detect(st.state == ST_FRAMESYNC || st.state == ST_DATASYMBOLS, st.state == ST_FRAMESYNC ? 1 : 0, base + st.pos, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value, power,
-               powerAvg, fIndex, idxEnd, squelched);
-        const float snr = power - powerAvg;                                             // :173 (squelched = snr < thresh, :174, comes from detect)
-        st.fineTuneIndex = idxEnd;                                                      // :160-162
-        const bool syncd = !squelched && (st.prevValue + 4) / 8 == 0;                  // :183
-        const bool match0 = (value + 4) / 8 == (s.sync >> 4);                          // :184
-        bool match1 = false;
-        if (st.state == ST_FRAMESYNC && syncd && match0)
+        // window 0 of a call (:157-172), or window 1 of a parked one (:189-206: `int ft = _fineTuneIndex` starts from the committed
+        // index and is not committed itself)
+        detect(!second && (fs || st.state == ST_DATASYMBOLS), second ? 2 : (fs ? 1 : 0), base + st.pos + (second ? N : 0), st.downTable != 0,
+               st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
+        float snr = power - powerAvg;                                                   // :173 (squelched = snr < thresh, :174, comes from detect)
+        if (!second) st.fineTuneIndex = idxEnd;                                         // :160-162
+        bool syncd = !squelched && (st.prevValue + 4) / 8 == 0;                        // :183
+        bool match0 = (value + 4) / 8 == (s.sync >> 4);                                // :184
+        bool match1 = false, step = true;
+        if (second)
         {
-            int value1, idxEnd1;
-            // `int ft = _fineTuneIndex` (:191): starts from the committed index, is not committed itself
-            bool sq1;
-            detect(false, 2, base + st.pos + N, st.downTable != 0, st.fineTuneIndex, st.finefreqError, value1, power, powerAvg, fIndex, idxEnd1, sq1);
-            match1 = (value1 + 4) / 8 == (s.sync & 0xf);                               // :205; snr is not recomputed
+            match1 = (value + 4) / 8 == (s.sync & 0xf);                                // :205
+            // detect() overwrote power / powerAvg / fIndex (:203); value, snr and what follows from them are window 0's
+            value = value0; snr = snr0; squelched = false; syncd = true; match0 = true;
+            pend = false;
         }
-        frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
+        else if (fs && syncd && match0)
+        {
+            pend = true; step = false;
+            value0 = value; snr0 = snr; fineIdxBefore0 = fineIdxBefore; fineErrBefore0 = fineErrBefore;
+        }
+        if (step)
+        {
+            frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
+            st.finefreqError = uniF(st.finefreqError);                                  // a float add runs on the vector unit: back to a scalar
+        }
     }
     if (t == 0)
     {

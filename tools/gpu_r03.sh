@@ -14,3 +14,30 @@ fi
 if [[ $what == *bench* ]]; then
   timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench exit $?"; tail -c 6000 $O/bench_default.json; tail -25 $O/bench_default.err
 fi
+if [[ $what == *quicktests* ]]; then
+  timeout 900 python -m pytest tests/test_gpu_demod.py tests/test_gpu_dropin.py tests/test_gpu_codec.py tests/test_gpu_bench.py -m gpu -x -q > $O/pytest_quick.log 2>&1; echo "pytest exit $?" >> $O/pytest_quick.log; tail -4 $O/pytest_quick.log
+fi
+if [[ $what == *ab* ]]; then
+  bash tools/gpu_ab.sh 2>&1 | tee $O/ab.txt
+fi
+if [[ $what == *ldsconf* ]]; then
+  # LDS bank conflicts and LDS / VALU activity of the locked-receiver shape, the steady state and the streaming kernel
+  for sf in ${CSF:-7 10 12}; do
+    case $sf in 7) CH=16384;; 8|9) CH=8192;; 10) CH=4096;; 11) CH=2048;; *) CH=1024;; esac
+    for shape in moving steady stream; do
+      case $shape in
+        moving) CMD="python $R/bench.py --sf $sf --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline --moving"; KEY=detect;;
+        steady) CMD="python $R/bench.py --sf $sf --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline"; KEY=detect;;
+        stream) CMD="python $R/tools/bench_demod.py --sf $sf --channels $CH --modes 1 --reps 2 --ramp-seconds 0"; KEY=demodStream;;
+      esac
+      i=0
+      for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+                 "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INST_CYCLES_SALU SQ_WAVES"; do
+        i=$((i+1))
+        ( cd /tmp && timeout 300 rocprofv3 --pmc $set -d $O/pmc_${shape}_sf${sf}_$i -o pmc --output-format csv -- $CMD > $O/pmc_${shape}_sf${sf}_$i.log 2>&1 )
+      done
+      python tools/pmc_kernels.py $O/pmc_${shape}_sf${sf}_1 $KEY "== $shape SF$sf (LDS)" | tee -a $O/ldsconf.txt
+      python tools/pmc_kernels.py $O/pmc_${shape}_sf${sf}_2 $KEY "== $shape SF$sf (issue)" | tee -a $O/ldsconf.txt
+    done
+  done
+fi
