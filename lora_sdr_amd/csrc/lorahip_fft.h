@@ -256,14 +256,6 @@ __device__ __forceinline__ void fineIssue(d2v &a, d2v &b, const unsigned y, cons
     asm volatile("ds_read_b128 %0, %1" : "=v"(b) : "v"(entryAddress16(y & ((1u << LH) - 1u), baseB)));
 }
 
-//! wait until at most LATER of this wave's LDS reads are outstanding: LDS returns in order, so the four values named here (a
-//! pair's) have arrived; naming them makes every use wait for this instruction
-template <int LATER>
-__device__ __forceinline__ void finePairWait(d2v &a0, d2v &b0, d2v &a1, d2v &b1)
-{
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1) : "n"(LATER));
-}
-
 //! CONJ: chirp(i) is the DOWN-chirp table's entry and the window wants the up-chirp table, its conjugate (LoRaDemod.cpp:103): the
 //! conjugation rides on the multiply's sign modifiers (cmulConjv: the same products, the same roundings) instead of costing a
 //! packed multiply by (1, -1) per sample
@@ -277,29 +269,99 @@ __device__ __forceinline__ void fineApply(v2f &x, CHIRP chirp, const int i, cons
     x = (!SELECT || keep) ? v : x;
 }
 
-//! the split-table path of dechirpFine as a software pipeline over pairs of samples: the four LDS reads of the next pair are in
-//! flight while this pair's two fp64 products and four complex multiplies issue. The reads and the waits are written out
-//! (inline asm) because the compiler otherwise sinks every read to its use and waits for it at once.
+/*! (x0 * c0) * f0 and (x1 * c1) * f1 -- twelve packed operations -- as ONE asm statement with the two samples interleaved. The
+ * compiler cannot see inside an asm statement and pads an s_nop after every one whose result is consumed by the next instruction;
+ * written out like this there is no such boundary inside the pair (and by the compiler's own hazard rule for packed results --
+ * a wait state when the very next instruction reads them -- none is needed: no result is read by its immediate successor except
+ * the mulHi products, which that rule exempts). Same operations, same operands, same roundings as cmulv / cmulConjv. */
+template <bool CONJ>
+__device__ __forceinline__ void cmulPair(v2f &x0, v2f &x1, const v2f c0, const v2f c1, const v2f f0, const v2f f1)
+{
+    v2f p0, q0, p1, q1, r0, r1;
+    if (CONJ)
+        asm("v_pk_mul_f32 %0, %6, %8 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %6, %8 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 %2, %7, %9 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %3, %7, %9 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+            "v_pk_add_f32 %4, %0, %1 neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %5, %2, %3 neg_hi:[0,1]\n\t"
+            "v_pk_mul_f32 %0, %4, %10 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %4, %10 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 %2, %5, %11 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %3, %5, %11 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+            "v_pk_add_f32 %4, %0, %1 neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %5, %2, %3 neg_lo:[0,1]"
+            : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1), "v"(c0), "v"(c1), "v"(f0), "v"(f1));
+    else
+        asm("v_pk_mul_f32 %0, %6, %8 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %6, %8 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 %2, %7, %9 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %3, %7, %9 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+            "v_pk_add_f32 %4, %0, %1 neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %5, %2, %3 neg_lo:[0,1]\n\t"
+            "v_pk_mul_f32 %0, %4, %10 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %4, %10 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 %2, %5, %11 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %3, %5, %11 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+            "v_pk_add_f32 %4, %0, %1 neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %5, %2, %3 neg_lo:[0,1]"
+            : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1), "v"(c0), "v"(c1), "v"(f0), "v"(f1));
+    x0 = r0; x1 = r1;
+}
+
+#ifndef LORAHIP_FINE_GROUP
+#define LORAHIP_FINE_GROUP 2            // samples per pipeline step of dechirpFineSplit (A/B: 4 keeps twice the reads in flight)
+#endif
+//! wait until at most LATER of this wave's LDS reads are outstanding (in-order return): the 2 G values named here have arrived
+template <int LATER, int G>
+__device__ __forceinline__ void fineGroupWait(d2v (&a)[G], d2v (&b)[G])
+{
+    if constexpr (G == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]) : "n"(LATER));
+    else asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]) : "n"(LATER));
+}
+
+//! the split-table path of dechirpFine as a software pipeline over groups of G samples: the 2 G LDS reads of the next group are in
+//! flight while this group's fp64 products and complex multiplies issue. The reads and the waits are written out (inline asm)
+//! because the compiler otherwise sinks every read to its use and waits for it at once.
 template <int LH, int CNT, bool SELECT, bool CONJ, class CHIRP>
 __device__ __forceinline__ void dechirpFineSplit(v2f *x, CHIRP chirp, const unsigned *y, const FineLds &s, const bool keep)
 {
+    constexpr int G = LORAHIP_FINE_GROUP;
+    static_assert(G == 2 || G == 4, "pairs or quads");
+    static_assert(CNT % G == 0, "whole groups");
     const unsigned baseA = __builtin_amdgcn_readfirstlane(ldsByteAddress(s.A)), baseB = __builtin_amdgcn_readfirstlane(ldsByteAddress(s.B));
-    d2v a[2][2], b[2][2];
-    fineIssue<LH>(a[0][0], b[0][0], y[0], baseA, baseB);
-    fineIssue<LH>(a[0][1], b[0][1], y[1], baseA, baseB);
+    d2v a[2][G], b[2][G];
 #pragma unroll
-    for (int i = 0; i < CNT; i += 2)
+    for (int j = 0; j < G; j++) fineIssue<LH>(a[0][j], b[0][j], y[j], baseA, baseB);
+#pragma unroll
+    for (int i = 0; i < CNT; i += G)
     {
-        const int cur = (i >> 1) & 1;
-        if (i + 2 < CNT)
+        const int cur = (i / G) & 1;
+        if (i + G < CNT)
         {
-            fineIssue<LH>(a[cur ^ 1][0], b[cur ^ 1][0], y[i + 2], baseA, baseB);
-            fineIssue<LH>(a[cur ^ 1][1], b[cur ^ 1][1], y[i + 3], baseA, baseB);
-            finePairWait<4>(a[cur][0], b[cur][0], a[cur][1], b[cur][1]);
+#pragma unroll
+            for (int j = 0; j < G; j++) fineIssue<LH>(a[cur ^ 1][j], b[cur ^ 1][j], y[i + G + j], baseA, baseB);
+            fineGroupWait<2 * G, G>(a[cur], b[cur]);
         }
-        else finePairWait<0>(a[cur][0], b[cur][0], a[cur][1], b[cur][1]);
-        fineApply<SELECT, CONJ>(x[i], chirp, i, a[cur][0], b[cur][0], keep);
-        fineApply<SELECT, CONJ>(x[i + 1], chirp, i + 1, a[cur][1], b[cur][1], keep);
+        else fineGroupWait<0, G>(a[cur], b[cur]);
+#ifndef LORAHIP_NO_FUSED_CMUL
+        if constexpr (!SELECT)
+        {
+#pragma unroll
+            for (int j = 0; j < G; j += 2)
+            {
+                const d2v a0 = a[cur][j], b0 = b[cur][j], a1 = a[cur][j + 1], b1 = b[cur][j + 1];
+                const v2f f0 = v2f{(float)__builtin_fma(a0.x, b0.x, -(a0.y * b0.y)), (float)__builtin_fma(a0.x, b0.y, a0.y * b0.x)};
+                const v2f f1 = v2f{(float)__builtin_fma(a1.x, b1.x, -(a1.y * b1.y)), (float)__builtin_fma(a1.x, b1.y, a1.y * b1.x)};
+                cmulPair<CONJ>(x[i + j], x[i + j + 1], chirp(i + j), chirp(i + j + 1), f0, f1);
+            }
+        }
+        else
+#endif
+        {
+#pragma unroll
+            for (int j = 0; j < G; j++) fineApply<SELECT, CONJ>(x[i + j], chirp, i + j, a[cur][j], b[cur][j], keep);
+        }
     }
 }
 

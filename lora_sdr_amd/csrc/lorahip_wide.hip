@@ -288,13 +288,18 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         unsigned yv[R][VEC];
         if constexpr (!UNI)
         {
-            anyMoving = __syncthreads_or(moving);
+            // one window per workgroup (the default shapes): `moving` is the same in every thread, no vote needed
+            if constexpr (WPB == 1) anyMoving = moving;
+            else anyMoving = __syncthreads_or(moving);
             if (anyMoving)
             {
                 const FinePlan pl = finePlan(moving ? d : 0.0f, M);
                 const unsigned ymax = fineLaneIndices<LOG2N, VEC, T, R>(idx0, pl, t, yv);
                 int idxEnd = fineEndIndex(idx0, pl, LOG2N, LOG2N + 7);
-                usedChain = __syncthreads_or(!pl.regular || ymax == (unsigned)M);
+                // the closed form can only reach the value M under the modulus M + 1 (a positive non-integer step that is not the
+                // walk-down-and-stay case, lorahip_fine.h): every other window of a one-window workgroup skips the vote and its barrier
+                if (WPB == 1 && (pl.mod == (unsigned)M || pl.sat)) usedChain = !pl.regular;
+                else usedChain = __syncthreads_or(!pl.regular || ymax == (unsigned)M);
                 if (usedChain)
                 {
                     idxEnd = fineChainBlock<T, M>(idx0, moving ? d : 0.0f, t, t >> 6, sIdx, sChain);
@@ -467,6 +472,8 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         // ---- neighbours of the peak for fIndex (LoRaDetector.hpp:56-57): the owners post them. Only the
         // wavefront(s) that hold bin k-1 / k+1 walk the register-select tree.
         {
+            // (a tree of scalar branches on the wave-uniform bin number instead of the per-lane select tree measured 1 % SLOWER:
+            // profiles/r03/s6_ab_scalar_pick_negative.txt)
             const int bl = (bestI + N - 1) & (N - 1), br = (bestI + 1) & (N - 1);
             const bool ownL = (bl & (T - 1)) == t, ownR = (br & (T - 1)) == t;
             if (__any(ownL | ownR))
@@ -732,7 +739,8 @@ demodStreamWide(const StreamArgs s)
             pl.q = (unsigned)uniI((int)pl.q); pl.mod = (unsigned)uniI((int)pl.mod); pl.regular = uniI(pl.regular); pl.sat = uniI(pl.sat);
             const unsigned ymax = fineLaneIndices<LOG2N, VEC, T, R>(idx0, pl, t, yv);
             idxEnd = uniI(fineEndIndex(idx0, pl, LOG2N, LOG2N + 7));
-            usedChain = !pl.regular || __syncthreads_or(ymax == (unsigned)M);
+            // the closed form can only reach the value M under the modulus M + 1 (lorahip_fine.h): no vote, no barrier otherwise
+            usedChain = !pl.regular || ((pl.mod != (unsigned)M && !pl.sat) && __syncthreads_or(ymax == (unsigned)M));
             if (t == 0 && nearStep(d)) atomicAdd(s.near + 1, 1u);                    // counted, not changed (lorahip_internal.h)
             if (usedChain)
             {

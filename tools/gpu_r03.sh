@@ -41,3 +41,6 @@ if [[ $what == *ldsconf* ]]; then
     done
   done
 fi
+if [[ $what == *e2e* ]]; then
+  for sf in ${ESF:-7 8}; do LORAHIP_DEMOD_TIMING=1 timeout 300 python tools/e2e_breakdown.py --sf $sf 2>&1 | tail -14 | tee -a $O/e2e_breakdown.txt; done
+fi
