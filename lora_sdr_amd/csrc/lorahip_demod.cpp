@@ -87,6 +87,8 @@ struct lorahip_demod
     bool activatePending;            // activate() since the last run, not yet applied to the device state / the mirrors
     bool uniform; size_t uniSpc;     // the streams of the current run are n_channels x uniSpc samples back to back (lorahip_demod_run_device)
     bool geomApplied;                // ch[].base / len / pos hold the current run's placement
+    bool posOnDevice;                // the pinned state copy's `pos` belongs to the CURRENT placement (a streaming run filled it; a new
+                                     // lorahip_demod_run[_device] call invalidates it: its streams start at sample 0)
     bool portCountsDirty;            // ch[].portFft / portDec / portRaw may be non-zero
     void *pending;                   // PendingLaunch (records of the last streaming launch still on the device)
     std::vector<size_t> carry;       // per channel: symbols of a packet begun before the launch being drained
@@ -527,7 +529,7 @@ static void syncMirrors(lorahip_demod *dm)
             const StreamState &st = hs[c];
             k.state = st.state; k.downTable = st.downTable != 0; k.prevValue = short(st.prevValue); k.freqError = st.freqError;
             k.fineTuneIndex = st.fineTuneIndex; k.finefreqError = st.finefreqError; k.symCount = size_t(st.symCount);
-            k.pos = size_t(st.pos);
+            if (dm->posOnDevice) k.pos = size_t(st.pos);
         }
     }
     dm->mirrorsStale = false;
@@ -713,6 +715,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     }
     if (anyCarryIn || lastPending) for (size_t c = 0; c < B; c++) carriedIn += carry[c];
     dm->devStateFresh = true;                         // the device holds what the pinned copy says; the mirrors lag (mirrorsStale)
+    dm->posOnDevice = true;
     PendingLaunch &P = pendingOf(dm);
     if (lastPending)
     {
@@ -936,7 +939,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->workCalls = 0;
     dm->nNearSquelch = dm->nNearStep = 0;
     dm->devStateFresh = false; dm->mirrorsStale = false; dm->activatePending = false;
-    dm->uniform = false; dm->uniSpc = 0; dm->geomApplied = true; dm->portCountsDirty = true;
+    dm->uniform = false; dm->uniSpc = 0; dm->geomApplied = true; dm->portCountsDirty = true; dm->posOnDevice = false;
     dm->ch.resize(n_channels);
     for (auto &k : dm->ch) { k.traceStart = 0; k.traceSymCount0 = 0; k.portFft = k.portDec = k.portRaw = 0; }
     dm->stageBytes = carve(nullptr, n_channels).total;
@@ -1043,7 +1046,7 @@ int lorahip_demod_run_device(lorahip_demod *dm, const float *iq_dev, const size_
     if (dm == nullptr || iq_dev == nullptr) return LORAHIP_E_INVALID;
     // n_channels streams of equal length back to back: the placement is two numbers, not 3 * n_channels (ch[].base / len / pos are
     // filled only for the paths that read them, applyGeometry)
-    dm->uniform = true; dm->uniSpc = samples_per_channel; dm->geomApplied = false;
+    dm->uniform = true; dm->uniSpc = samples_per_channel; dm->geomApplied = false; dm->posOnDevice = false;
     return runAny(dm, iq_dev, rounds);
 }
 
@@ -1052,7 +1055,7 @@ int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size
     if (dm == nullptr || streams == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
     const DeviceGuard guard(dm->ctx->device);
     size_t total = 0;
-    dm->uniform = false; dm->geomApplied = true;
+    dm->uniform = false; dm->geomApplied = true; dm->posOnDevice = false;
     for (size_t c = 0; c < dm->B; c++)
     {
         if (n_samples[c] && streams[c] == nullptr) return LORAHIP_E_INVALID;
@@ -1225,7 +1228,8 @@ int lorahip_demod_near_threshold(const lorahip_demod *dm, int64_t *near_squelch,
 int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
 {
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
-    if (dm->mirrorsStale && dm->sHost) return int64_t(hostStates(const_cast<lorahip_demod *>(dm))[channel].pos);
+    if (dm->mirrorsStale && dm->posOnDevice && dm->sHost) return int64_t(hostStates(const_cast<lorahip_demod *>(dm))[channel].pos);
+    if (!dm->posOnDevice && dm->uniform && !dm->geomApplied) return 0;     // placement set, nothing run on it yet
     return int64_t(dm->ch[channel].pos);
 }
 

@@ -639,3 +639,79 @@ def test_untraced_prefix_leaves_the_state_a_traced_run_has(gpu, oracle, sf):
                     assert g[k] == w[k], (cut, c, k)
                 assert np.float32(g["fine_err_before"]).tobytes() == np.float32(w["fine_err_before"]).tobytes(), (cut, c)
         d.close()
+
+
+def test_state_stays_on_the_device_between_streaming_runs(gpu, oracle):
+    """Streaming mode keeps the frame-machine state on the device from run to run (no per-run upload; the host mirrors are brought
+    up to date lazily). A receiver fed chunk by chunk, switching between the streaming kernel and host-driven rounds, with an
+    activate() in the middle, must deliver what a receiver that runs host-driven rounds throughout delivers: the same packets,
+    the same consumption per chunk. The first chunk is handed over as a device tensor (equal lengths: the uniform placement the
+    kernel computes itself), the later ones as per-channel host buffers of different lengths."""
+    import lora_sdr_amd as L
+    sf, N, B, mtu = 8, 256, 6, 10
+    rng = np.random.default_rng(4242)
+    streams = [frames(oracle, rng, sf, 4, mtu, off=rng.uniform(-0.4, 0.4), noise=0.05, lead=int(rng.integers(0, N)))[0] for _ in range(B)]
+    plan = [(1, False), (1, False), (2, False), (1, True), (1, False), (0, False), (1, False), (1, False)]     # (mode, activate() first)
+    n = min(len(s) for s in streams)
+    chunk = n // len(plan)
+
+    def run(modes):
+        d = L.LoRaDemod(sf, n_channels=B)
+        d.setMTU(mtu)
+        rest = [np.zeros(0, np.complex64) for _ in range(B)]
+        out, consumed = [[] for _ in range(B)], []
+        for k, (mode, act) in enumerate(modes):
+            bufs = [np.concatenate([rest[c], streams[c][k * chunk:(k + 1) * chunk if k + 1 < len(modes) else len(streams[c])]]) for c in range(B)]
+            d.set_mode(mode)
+            if act:
+                d.activate()
+            if k == 0:
+                d.work(gpu.from_numpy(np.stack(bufs)).to("cuda:0"))
+            else:
+                d.work(bufs)
+            for ch, _r, s in d.packets():
+                out[ch].append(s)
+            consumed.append([d.consumed(c) for c in range(B)])
+            for c in range(B):
+                rest[c] = bufs[c][d.consumed(c):]
+        d.close()
+        return out, consumed
+
+    want, cw = run([(2, a) for _m, a in plan])
+    got, cg = run(plan)
+    assert cg == cw
+    for c in range(B):
+        assert len(got[c]) == len(want[c]) >= 2 and all(np.array_equal(a, b) for a, b in zip(got[c], want[c]))
+
+
+@pytest.mark.parametrize("sf", [7, 11])
+def test_near_threshold_counters(gpu, oracle, sf):
+    """lorahip_demod_near_threshold: decisions within float rounding of their boundary are COUNTED (never altered). With the
+    threshold placed exactly on the lowest snr a squelch decision sees, the call that consumed it is counted, by the streaming kernel (traced and
+    untraced) and by the host-driven rounds alike; at the block's default threshold nothing is near; activate() restarts the count."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(31 + sf)
+    st, _ = frames(oracle, rng, sf, 2, 12, off=0.2, noise=0.3)
+    r0 = oracle.demod_run(sf, st, mtu=64, keep=False)
+    # the LOWEST snr any call sees whose squelch decision is consumed (FRAMESYNC / DATASYMBOLS): with the threshold exactly there
+    # that call sits on the boundary (`snr < thresh` is false at equality) and every other decision keeps its side
+    th = float(np.float32(min(c["snr"] for c in r0["calls"] if c["state"] in (0, 4) and np.isfinite(c["snr"]))))
+    dev = gpu.from_numpy(st.reshape(1, -1)).to("cuda:0")
+    seen = []
+    for mode, trace in ((1, False), (1, True), (2, False)):
+        d = L.LoRaDemod(sf, n_channels=1)
+        d.set_mode(mode); d.setMTU(64); d.set_trace(trace)
+        d.work(dev)
+        assert d.near_threshold()[0] == 0                        # default threshold -30 dB: nothing near
+        step0 = d.near_threshold()[1]
+        d.close()
+        d = L.LoRaDemod(sf, n_channels=1)
+        d.set_mode(mode); d.setMTU(64); d.set_trace(trace); d.setThreshold(th)
+        d.work(dev)
+        ns, nstep = d.near_threshold()
+        assert ns >= 1
+        seen.append((ns, nstep, step0))
+        d.activate()
+        assert d.near_threshold() == (0, 0)
+        d.close()
+    assert seen[0] == seen[1] == seen[2]
