@@ -360,6 +360,21 @@ template <unsigned O>
 using Fast11q = FastCfg<11, 6, 1, 3, 5, 7, (O & W1) ? 1 : (O & W2) ? 2 : (O & W4) ? 4 : 3, 0, 1, 0, 0, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
                         (O & NT) != 0, (O & NB_SEL) != 0, false, (O & TWM_REG) != 0, false>;
 
+// one LDS exchange less for the long windows, as two-phase geometries of 64 points per lane (profiling variants;
+// profiles/r03/README.md has their register / scratch / LDS-instruction counts and the A/B):
+//   SF10: 16 lanes x 64 points, [4,4,4] X [4,4]            (4 windows per wavefront)
+//   SF11: 32 lanes x 64 points, [R2,4,4] X [4,4,4]         (2 windows per wavefront)
+//   SF12: 64 lanes x 64 points, [4,4,4] X [4,4,4]          (1 window per wavefront, no workgroup barrier)
+template <unsigned O>
+using Fast10b = FastCfg<10, 4, 1, 2, 6, 10, (O & W1) ? 1 : (O & W2) ? 2 : 3, 0, 1, 0, 0, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
+                        (O & NT) != 0, (O & NB_SEL) != 0, false, false, false>;
+template <unsigned O>
+using Fast11b = FastCfg<11, 5, 2, 2, 5, 11, (O & W1) ? 1 : (O & W2) ? 2 : 3, 0, 1, 0, 0, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
+                        (O & NT) != 0, (O & NB_SEL) != 0, false, false, false>;
+template <unsigned O>
+using Fast12b = FastCfg<12, 6, 1, 2, 6, 12, (O & W1) ? 1 : (O & W2) ? 2 : 3, 0, 1, 0, 0, !(O & CH_REG), !(O & TW_REG), (O & PF_NONE) ? 0 : (O & PF_EARLY) ? 2 : 1,
+                        (O & NT) != 0, (O & NB_SEL) != 0, false, false, false>;
+
 bool fastAvailable(const int sf) { return sf >= 6 && sf <= 10; }
 
 //! host-side check of a configuration's exchange-0 layout: every (row, window, element) has its own word inside the
@@ -383,7 +398,7 @@ bool fastLayoutsOk()
 {
     bool ok = layoutOk<Fast<6, 0>>() && layoutOk<Fast<7, 0>>() && layoutOk<Fast<8, 0>>() && layoutOk<Fast<9, 0>>() && layoutOk<Fast9b<0>>() && layoutOk<Fast<10, 0>>();
 #ifdef LORAHIP_ALL_VARIANTS
-    ok = ok && layoutOk<Fast11q<0>>();
+    ok = ok && layoutOk<Fast11q<0>>() && layoutOk<Fast10b<0>>() && layoutOk<Fast11b<0>>() && layoutOk<Fast12b<0>>();
 #endif
     return ok;
 }
@@ -448,6 +463,10 @@ static const FastVariant kFastVariants[] = {
     { 11, 20, &launchCfg<Fast11q<W2 | NT | PF_NONE>> }, { 11, 21, &launchCfg<Fast11q<W2 | TW_REG | NT | PF_NONE>> },
     { 11, 22, &launchCfg<Fast11q<W2 | CH_REG | TW_REG | NT | PF_NONE>> }, { 11, 23, &launchCfg<Fast11q<W2 | NT>> },
     { 11, 24, &launchCfg<Fast11q<W2 | TW_REG | TWM_REG | NT | PF_NONE>> },
+    // round 3: two-phase geometries of 64 points per lane (all tables from LDS: 64 points leave no registers for them)
+    { 10, 25, &launchCfg<Fast10b<W2 | NT | PF_NONE>> }, { 10, 26, &launchCfg<Fast10b<W1 | NT | PF_NONE>> },
+    { 11, 25, &launchCfg<Fast11b<W2 | NT | PF_NONE>> }, { 11, 26, &launchCfg<Fast11b<W1 | NT | PF_NONE>> },
+    { 12, 25, &launchCfg<Fast12b<W2 | NT | PF_NONE>> }, { 12, 26, &launchCfg<Fast12b<W1 | NT | PF_NONE>> },
     V(10, 6, PF_EARLY), V(10, 7, TW_REG), V(10, 8, NT), V(10, 9, TW_REG | NT), V(10, 11, CH_REG | TW_REG | NT),
     V(10, 12, CH_REG | TW_REG | NT | X1_SWAP), V(10, 13, CH_REG | TW_REG | NT | NB_SEL), V(10, 14, CH_REG | TW_REG | NT | NB_SEL | X1_SWAP),
     V(10, 15, CH_REG | TW_REG | NT | X1_SWAP | TWM_REG | PF_NONE), V(10, 16, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG),

@@ -183,6 +183,7 @@ hipError_t launchDetect(const int sf, const int variant, const DetectArgs &a, co
 {
     if (variant != 1 && fastAvailable(sf)) return launchFast(sf, variant, a, ft, stream);
     if (sf == 11 && variant >= 20 && variant <= 24) return launchFast(sf, variant, a, ft, stream);          // window-per-wavefront SF11 (variants 20+)
+    if ((sf == 11 || sf == 12) && (variant == 25 || variant == 26)) return launchFast(sf, variant, a, ft, stream);   // 64 points per lane (profiling builds)
     if (variant != 1 && wideAvailable(sf)) return launchWide(sf, variant, a, ft, stream);
     switch (sf)
     {

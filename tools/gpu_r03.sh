@@ -44,3 +44,19 @@ fi
 if [[ $what == *e2e* ]]; then
   for sf in ${ESF:-7 8}; do LORAHIP_DEMOD_TIMING=1 timeout 300 python tools/e2e_breakdown.py --sf $sf 2>&1 | tail -14 | tee -a $O/e2e_breakdown.txt; done
 fi
+if [[ $what == *geo64* ]]; then
+  # the two-phase geometries of 64 points per lane (variants 40 / 41 of an --all-variants build) against the defaults
+  for sf in 10 11 12; do
+    for v in 0 25 26; do
+      LORAHIP_LIB=$R/lora_sdr_amd/liblorahip_AV.so timeout 200 python bench.py --sf $sf --variant $v --no-cpu-baseline > $O/geo64_sf${sf}_v$v.json 2> $O/geo64_sf${sf}_v$v.err
+      python - <<EOF2 | tee -a $O/geo64.txt
+import json
+try:
+    d = json.loads(open("$O/geo64_sf${sf}_v$v.json").read().strip().splitlines()[-1])
+    print("SF$sf variant $v:", round(d["value"], 1), "Msym/s frac", round(d["roofline"]["frac"], 3), "launch_us", d["roofline"]["launch_us"], "index mismatches vs oracle", d["oracle"]["index_mismatches"])
+except Exception as e:
+    print("SF$sf variant $v failed:", open("$O/geo64_sf${sf}_v$v.err").read().strip().splitlines()[-1][:200])
+EOF2
+    done
+  done
+fi
