@@ -21,6 +21,9 @@
 #ifndef STREAM_SCAN_CHAINS
 #define STREAM_SCAN_CHAINS 1
 #endif
+#ifndef STREAM_TWLDS
+#define STREAM_TWLDS false      // last-phase twiddles from the LDS table instead of registers (A/B: frees ~30 registers)
+#endif
 #ifndef STREAM_WPS
 #define STREAM_WPS 2            // wavefronts per SIMD the register budget is set for (3 = 168 VGPRs: A/B builds, profiles/r03)
 #endif
@@ -91,7 +94,7 @@ demodStream(const StreamArgs s)
     // the branches are wave-uniform.
     const bool all = s.calls != nullptr;
 #ifdef LORAHIP_STREAM_TIMING
-    unsigned long long tsec[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    unsigned long long tsec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #define TMARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsec[i] += now_ - tlast; tlast = now_; } while (0)
 #define TMARK_NOWAIT(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsec[i] += now_ - tlast; tlast = now_; } while (0)
 #else
@@ -202,11 +205,13 @@ demodStream(const StreamArgs s)
             float totF;
             if (staged) K::template scanQuick<true>(vl, F, t, bestV, bestI, totF);
             else K::template scanQuick<false>(vl, F, t, bestV, bestI, totF);
+            TMARK(6);
             bool sure;
             squelched = squelchQuickF(bestV, totF, s.thresh, K::QUICK_REL_ERR, sure);
             power = powerAvg = fIndex = 0.0f;                                           // not consumed without a trace
             const bool exact = on && wantSq && !sure;
             const bool fi = on && (wantFi == 2 || (wantFi == 1 && (!sure || !squelched)));
+            TMARK(7);
             if (__any(exact || fi))
             {
                 if (staged) K::neighbours(vl, F, bestI, lane, t, l, r);
@@ -288,6 +293,7 @@ demodStream(const StreamArgs s)
         }
 
         // ---- the frame machine (:176-312) ----
+        TMARK(8);
         if (step)
         {
             frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
@@ -296,8 +302,9 @@ demodStream(const StreamArgs s)
     }
 #ifdef LORAHIP_STREAM_TIMING
     if (blockIdx.x == 7 && threadIdx.x == 0)
-        printf("stream timing (s_memtime ticks): index math %llu, load wait %llu, chirp+dechirp %llu, fft %llu, scan+tail %llu, frame machine+loop %llu; calls %d\n",
-               tsec[0], tsec[1], tsec[2], tsec[3], tsec[4], tsec[5], o.calls);
+        printf("stream timing (s_memtime ticks): index math %llu, load wait %llu, chirp+dechirp %llu, fft %llu, scan+reductions %llu, squelch estimate %llu, neighbours+fIndex+exact tail %llu, "
+               "uniform/epilogue of detect %llu, sync/match logic %llu, frame step+records+loop top %llu; calls %d\n",
+               tsec[0], tsec[1], tsec[2], tsec[3], tsec[6], tsec[7], tsec[4], 0ull, tsec[8], tsec[5], o.calls);
 #endif
     if (mine && t == 0)
     {
@@ -328,8 +335,8 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
 // chirp table from LDS (both selections share it), last-phase twiddles in registers (+3-10 % over the LDS table, session 10)
 //             LOG2N T VEC NPH PB1 PB2 w/SIMD  X0: ROT PAD S  D   chLDS twLDS prefetch
 typedef FastCfg<6,  2, 4,  2,  2,  6,  STREAM_WPS,          2,  1,  0, 0,  true,  false,  0> Stream6;
-typedef FastCfg<7,  3, 2,  2,  3,  7,  STREAM_WPS,          1,  1,  0, 0,  true,  false,  0> Stream7;
-typedef FastCfg<8,  4, 1,  2,  4,  8,  STREAM_WPS,          0,  1,  0, 0,  true,  false,  0> Stream8;
+typedef FastCfg<7,  3, 2,  2,  3,  7,  STREAM_WPS,          1,  1,  0, 0,  true,  STREAM_TWLDS,  0> Stream7;
+typedef FastCfg<8,  4, 1,  2,  4,  8,  STREAM_WPS,          0,  1,  0, 0,  true,  STREAM_TWLDS,  0> Stream8;
 typedef FastCfg<9,  5, 2,  3,  3,  7,  STREAM_WPS,          2,  1,  1, 8,  true,  false,  0, false, false, true> Stream9;    // 32 lanes x 16 points, three phases, exchange 1 as row swaps:
                                                                                                                  // with the per-sample fine-tune arithmetic the 32-point geometry spills (0.20 -> 0.26 of the roofline)
 typedef FastCfg<10, 6, 1,  3,  4,  8,  STREAM_WPS,          0,  1,  0, 0,  true,  false,  0, false, false, true> Stream10;   // exchange 1 as register row swaps
