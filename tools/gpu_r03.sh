@@ -60,3 +60,6 @@ EOF2
     done
   done
 fi
+if [[ $what == *smoke* ]]; then
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee $O/smoke.txt
+fi
