@@ -70,7 +70,9 @@ __device__ __forceinline__ void frameStep(StreamState &st, const StreamArgs &s, 
         break;
     default: // ST_DATASYMBOLS
         total = N;
+#ifndef LORAHIP_TIMING_NO_RECORD_STORES     // timing-only build (profiles/r03): what the per-call record stores cost
         if (writer) o.symOut[o.nSym] = (short)value;                                                     // out[_symCount++] = value  :290
+#endif
         o.nSym++;
         st.symCount++;
         if ((unsigned)st.symCount >= s.mtu || squelched)                                                 // :291
