@@ -417,22 +417,39 @@ __device__ __forceinline__ int laneScan(BIN bin, float &bestV, double &tot)
 
 /*! laneScan with the total in fp32: the arg-max part is the reference's scan unchanged (same comparisons, same winner); the total is
  * only good for the streaming kernels' QUICK squelch estimate (squelchQuickF below), never for a value that leaves the kernel. */
+#ifndef LORAHIP_QUICK_SCAN_CHAINS
+#define LORAHIP_QUICK_SCAN_CHAINS 1
+#endif
 template <int CNT, class BIN>
 __device__ __forceinline__ int laneScanQuick(BIN bin, float &bestV, float &totF)
 {
-    float cv = 0.0f, ct[2] = {0.0f, 0.0f};
-    int cj = 0;
+    constexpr int CH = LORAHIP_QUICK_SCAN_CHAINS, PER = CNT / CH;
+    float cv[CH], ct[CH];
+    int cj[CH];
 #pragma unroll
-    for (int j = 0; j < CNT; j++)
-    {
-        const auto b = bin(j);
-        const float mag2 = b.x * b.x + b.y * b.y;
-        ct[j & 1] += mag2;
-        if (mag2 > cv) { cv = mag2; cj = j; }
-    }
-    bestV = cv;
-    totF = ct[0] + ct[1];
-    return cj;
+    for (int c = 0; c < CH; c++) { cv[c] = 0.0f; ct[c] = 0.0f; cj[c] = 0; }
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+        {
+            const int j = c * PER + k;                      // chain c walks bins [c PER, (c + 1) PER) in ascending order
+            const auto b = bin(j);
+            const float mag2 = b.x * b.x + b.y * b.y;
+            ct[c] += mag2;
+            if (mag2 > cv[c]) { cv[c] = mag2; cj[c] = j; }
+        }
+#pragma unroll
+    for (int w = 1; w < CH; w <<= 1)
+#pragma unroll
+        for (int c = 0; c + w < CH; c += 2 * w)
+        {
+            if (cv[c + w] > cv[c]) { cv[c] = cv[c + w]; cj[c] = cj[c + w]; }      // strict: the lower chain (lower bins) keeps a tie
+            ct[c] += ct[c + w];
+        }
+    bestV = cv[0];
+    totF = ct[0];
+    return cj[0];
 }
 
 //! fIndex alone, for the same replicated lanes: the fIndex operations of tailValuesPaired (hence its bits) without the two
