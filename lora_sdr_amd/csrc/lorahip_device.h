@@ -491,8 +491,9 @@ __device__ __forceinline__ bool squelchQuick(const float maxValue, const double 
 __device__ __forceinline__ bool squelchQuickF(const float maxValue, const float totalF, const float thresh, const float relErr, bool &sure)
 {
     const float noise2 = totalF - maxValue;
-    const float ratio = maxValue / noise2;
-    const float snrApprox = 3.01029995664f * (__builtin_amdgcn_logf(maxValue) - __builtin_amdgcn_logf(noise2));   // 10 log10 = 3.0103 log2
+    const float l2 = __builtin_amdgcn_logf(maxValue) - __builtin_amdgcn_logf(noise2);                              // log2(maxValue / noise2)
+    const float snrApprox = 3.01029995664f * l2;                                                                    // 10 log10 = 3.0103 log2
+    const float ratio = __builtin_amdgcn_exp2f(l2);                  // maxValue / noise2, to the accuracy a band width needs (one instruction, no division)
     const float band = 0.01f + 8.7f * relErr * (1.0f + ratio);
     sure = maxValue > 0.0f && noise2 > 0.0f && __builtin_fabsf(snrApprox - thresh) > band && snrApprox == snrApprox &&
            __builtin_fabsf(snrApprox) < 1e30f && band == band && band < 1e30f;

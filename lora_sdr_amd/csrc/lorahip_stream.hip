@@ -16,7 +16,7 @@
 #include <cstdlib>
 
 #ifndef STREAM_STAGE_BINS
-#define STREAM_STAGE_BINS 1
+#define STREAM_STAGE_BINS 0       // untraced path: neighbours by register select (1: all bins staged in LDS whenever a channel is in FRAMESYNC; 1-1.7 % slower, profiles/r03)
 #endif
 #ifndef STREAM_SCAN_CHAINS
 #define STREAM_SCAN_CHAINS 1
