@@ -715,3 +715,65 @@ def test_near_threshold_counters(gpu, oracle, sf):
         assert d.near_threshold() == (0, 0)
         d.close()
     assert seen[0] == seen[1] == seen[2]
+
+
+@pytest.mark.parametrize("sf,sigma,pct", [(7, 2.0, None), (8, 1.2, 8), (9, 3.5, None), (10, 2.2, 5), (11, 3.5, 10)])
+def test_many_noisy_channels_against_the_reference_runner(gpu, oracle, sf, sigma, pct):
+    """Level-3 identity away from the clean bench workload: hundreds of channels with heavy noise (down to the sensitivity limit of
+    the SF, where the sync search mis-fires, squelch decisions sit close to a raised threshold and packets are cut short), random
+    leads and carrier offsets, the default threshold or one placed at a low percentile of the data symbols' own snr (so that
+    squelch decisions fall on both sides all the time) -- every channel's packets AND every work() call's consumption / label kind
+    against the all-channel CPU runner (the verbatim LoRaDemod.cpp where oracle/_ref travelled, else the pinned restatement),
+    traced and untraced; the near-threshold counters of the two passes agree."""
+    import lora_sdr_amd as L
+    from oracle.oracle import Ref
+    impl = Ref() if Ref.available() else oracle
+    rng = np.random.default_rng(1234 + sf)
+    N, mtu = 1 << sf, 16
+    B = 384 if sf <= 9 else 96
+    sts = []
+    for c in range(B):
+        st, _ = frames(oracle, rng, sf, 2, mtu, off=rng.uniform(-0.45, 0.45), noise=0.0, lead=int(rng.integers(0, 2 * N)))
+        sts.append(st)
+    n = max(len(s) for s in sts) + N
+    x = np.zeros((B, n), np.complex64)
+    for c, st in enumerate(sts):
+        x[c, :len(st)] = st
+    x += (sigma * (rng.standard_normal(x.shape) + 1j * rng.standard_normal(x.shape))).astype(np.complex64)
+    thresh = -30.0
+    if pct is not None:
+        snr = [k["snr"] for c in range(3) for k in oracle.demod_run(sf, x[c], mtu=mtu, keep=False)["calls"] if k["state"] == 4]
+        thresh = float(np.float32(np.percentile(snr, pct)))
+    r = impl.demod_run_many(sf, x, thresh=thresh, mtu=mtu, nthreads=8, calls=True)
+    dev = gpu.from_numpy(x).to("cuda:0")
+    near = []
+    for trace in (False, True):
+        d = L.LoRaDemod(sf, n_channels=B)
+        d.set_mode(1); d.setMTU(mtu); d.setThreshold(thresh); d.set_trace(trace)
+        d.work(dev)
+        near.append(d.near_threshold())
+        ch, _rd, ln, sy = d.packets_arrays()
+        start = np.concatenate([[0], np.cumsum(ln)])[:-1]
+        for c in range(B):
+            mine = np.nonzero(ch == c)[0]
+            assert len(mine) == r["n_packets"][c], (sf, c, trace)
+            at = 0
+            for j, p in enumerate(mine):
+                m = int(ln[p])
+                assert m == r["pkt_lens"][c, j]
+                assert np.array_equal(sy[start[p]:start[p] + m], r["pkt_syms"][c, at:at + m]), (sf, c, j, trace)
+                at += m
+        if trace:
+            th = np.float32(thresh)
+            for c in range(B):
+                t = d.trace_array(c)
+                k = int(r["n_calls"][c])
+                assert t.size == k, (sf, c)
+                st_, co = t["state_before"], t["consumed"]
+                cls = np.where(st_ == 0, np.where(co == 2 * N, 1, np.where(~(t["snr"] < th), 2, 0)),
+                               np.where(st_ == 1, 3, np.where(st_ == 2, 0, np.where(st_ == 3, 4, 5))))
+                assert np.array_equal(co, r["consumed"][c, :k]) and np.array_equal(cls, r["cls"][c, :k]), (sf, c)
+        d.close()
+    assert near[0] == near[1]
+    lens = r["pkt_lens"][r["pkt_lens"] > 0]
+    assert lens.size >= B // 4 and (pct is None or np.unique(lens).size >= 8)     # hard, not hopeless; thresholds really cut packets short
