@@ -92,8 +92,10 @@ extern "C" {
 
 int lorahip_shard_plan(const int32_t *channel_sf, const size_t n_channels, const size_t n_shards, int32_t *shard_of_channel)
 {
-    if ((n_channels && (channel_sf == nullptr || shard_of_channel == nullptr)) || n_shards == 0 || n_shards > 0x7fffffffu) return LORAHIP_E_INVALID;
+    if ((n_channels && (channel_sf == nullptr || shard_of_channel == nullptr)) || n_shards == 0 || n_shards > (size_t(1) << 20)) return LORAHIP_E_INVALID;
     for (size_t c = 0; c < n_channels; c++) if (channel_sf[c] < 1 || channel_sf[c] > 24) return LORAHIP_E_INVALID;
+    try
+    {
     // lora_sdr_amd/shard.py::shard_channels, statement for statement: SF buckets from the largest windows down, each cut into
     // n_shards contiguous ranges of floor(count / n_shards) channels; the count % n_shards left-overs go to the shards that would
     // hold the fewest bytes (8*2^SF + 14 per symbol window), lowest shard first among equals
@@ -120,6 +122,8 @@ int lorahip_shard_plan(const int32_t *channel_sf, const size_t n_channels, const
             load[r] += counts[r] * w;
         }
     }
+    }
+    catch (const std::exception &) { return LORAHIP_E_NOMEM; }   // no exception crosses the C ABI
     return LORAHIP_OK;
 }
 
