@@ -777,3 +777,74 @@ def test_many_noisy_channels_against_the_reference_runner(gpu, oracle, sf, sigma
     assert near[0] == near[1]
     lens = r["pkt_lens"][r["pkt_lens"] > 0]
     assert lens.size >= B // 4 and (pct is None or np.unique(lens).size >= 8)     # hard, not hopeless; thresholds really cut packets short
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sf", [7, 10, 11])
+def test_streams_with_non_finite_and_extreme_samples(gpu, oracle, sf, mode):
+    """A front end that hands over a NaN, an infinity, or a burst that overflows |X|^2. In the down-chirp, quarter-chirp and data
+    states the reference's block goes through it by the rules of IEEE arithmetic (NaN never wins the arg-max: index 0; snr NaN is
+    not < threshold: NOT squelched) and so must the device's frame machine -- call by call with a trace, and packet by packet without
+    one, where the squelch decision comes from the quick estimate and has to fall back to the exact chain on such windows.
+    In FRAMESYNC the reference has NO defined behaviour for such a window: fIndex is NaN, `_finefreqError += fIndex`
+    (LoRaDemod.cpp:221) makes the step NaN, `_fineTuneIndex -= NaN` (:162) converts NaN to int and the next table read is out
+    of bounds -- the reference block (and the restatement) segfault on channels 1, 2 and 6 of this test, so nothing is compared
+    there. What IS required of them: the launch completes, and the channels that share their wavefront are untouched."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(900 + sf)
+    N = 1 << sf
+    B = 10
+    streams = []
+    for c in range(B):
+        st, _ = frames(oracle, rng, sf, 2, 9, off=rng.uniform(-0.4, 0.4), noise=0.05, lead=int(rng.integers(0, N)))
+        lead = st.size - (2 * (N * (10 + 2 + 2 + 9 + 3) + N // 4)) - 3 * N        # not exact, only to aim the faults into the frames
+        first = max(lead, 0)
+        spots = {0: [], 1: [first + 3 * N + 11], 2: [first + 11 * N + 5], 3: [first + 13 * N + 77], 4: [first + 16 * N + 1, first + 18 * N + 9],
+                 5: [first + 15 * N + 3], 6: [first + 2 * N, first + 40 * N], 7: [first + 17 * N], 8: [5], 9: [first + 14 * N + N // 3]}[c]
+        for k, p in enumerate(spots):
+            p = min(p, st.size - 1)
+            if c in (1, 2, 3, 4):
+                st[p] = np.nan if (c + k) % 2 else complex(0.0, np.nan)
+            elif c in (5, 6):
+                st[p] = complex(np.inf, 0.0) if k == 0 else complex(-np.inf, np.inf)
+            elif c == 7:
+                st[p:p + N] *= np.float32(3e19)                    # |X|^2 overflows to +Inf in every bin's neighbourhood
+            elif c == 8:
+                st[:] *= np.float32(1e-21)                          # subnormal squares throughout
+            elif c == 9:
+                st[p] = complex(3e38, -3e38)
+        streams.append(st)
+    undefined = (1, 2, 6)                                           # the fault lands in FRAMESYNC: see above
+    refs = []
+    with np.errstate(all="ignore"):
+        for c in range(B):
+            refs.append(None if c in undefined else oracle.demod_run(sf, streams[c], mtu=12))
+    assert sum(1 for r in refs if r is not None for x in r["calls"] if not np.isfinite(x["power"]) or not np.isfinite(x["fIndex"])) >= 6
+    for traced in (True, False):
+        d = L.LoRaDemod(sf, n_channels=B)
+        d.set_mode(mode)
+        d.setMTU(12)
+        d.set_trace(traced)
+        d.work(streams)
+        pk = d.packets()
+        for c in range(B):
+            r = refs[c]
+            if r is None:
+                continue
+            where = "sf%d mode %d channel %d traced %d" % (sf, mode, c, traced)
+            if traced:
+                tr = d.trace(c)
+                assert len(tr) == len(r["calls"]), where
+                for i, (a, b) in enumerate(zip(tr, r["calls"])):
+                    assert (a["consumed"], a["state_before"], a["value"]) == (b["consumed"], b["state"], b["value"]), "%s call %d" % (where, i)
+                    for ka, kb, tol in (("power", "power", TOL_DB), ("f_index", "fIndex", 2e-6)):
+                        va, vb = float(a[ka]), float(b[kb])
+                        assert (np.isnan(va), np.isposinf(va), np.isneginf(va)) == (np.isnan(vb), np.isposinf(vb), np.isneginf(vb)), "%s call %d %s" % (where, i, ka)
+                        if np.isfinite(vb):
+                            assert abs(va - vb) <= max(tol, 2 * float(np.spacing(np.float32(abs(vb))))), "%s call %d %s" % (where, i, ka)
+            assert d.consumed(c) == int(sum(x["consumed"] for x in r["calls"])), where
+            mine = [p[2] for p in pk if p[0] == c]
+            assert len(mine) == len(r["packets"]), where
+            for a, (_, b) in zip(mine, r["packets"]):
+                assert np.array_equal(a, b), where
+        assert all(d.consumed(c) > streams[c].size - 2 * N for c in undefined)      # they ran to the end of their streams

@@ -438,3 +438,70 @@ def test_synth_symbols_is_genchirp(gpu, oracle, sf):
     a, b = oracle.detect_batch(sf, got.reshape(-1)), oracle.detect_batch(sf, refs.reshape(-1))
     assert np.array_equal(a["sym"], b["sym"]) and np.array_equal(a["sym"], (sym.astype(np.int64) + 1) % N)   # the +1 bin of SURVEY.md section 7h
     ctx.close()
+
+
+def _bits_differ(a, b):
+    """floats that differ bit for bit, NaN against NaN not counted (payloads are not part of the contract)"""
+    a = np.ascontiguousarray(a).view(np.float32).ravel()
+    b = np.ascontiguousarray(b).view(np.float32).ravel()
+    return int(np.count_nonzero((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))))
+
+
+@pytest.mark.parametrize("sf", [7, 9, 10, 12])
+def test_inputs_at_the_edges_of_fp32(gpu, oracle, sf):
+    """Amplitudes whose squares are subnormal (1e-19 .. 3e-39) or overflow (1e17 .. 3e37), windows that hold a NaN sample and
+    windows that hold an infinite one, with and without a moving fine-tune index. The kernels keep subnormals (no flush to zero)
+    and follow the reference's operation graph, so dechirped samples, FFT bins and the index are identical bit for bit, +-Inf /
+    NaN included, and power / powerAvg / fIndex are of the same class (finite, +Inf, -Inf, NaN) and within two float ulps.
+    ONE deliberate difference, stated in DESIGN.md section 2: kissfft multiplies by the twiddle (1, 0) where the kernels skip the
+    multiplication, and Inf * 0 = NaN -- in a window that holds an INFINITE sample some bin components are Inf here and NaN in
+    the reference. Every bin of such a window is non-finite either way (a non-finite sample leaves the two dechirp
+    multiplications with a NaN component), so |X|^2 is NaN for every bin in both and everything detect() returns is the same."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(50 + sf)
+    N, W = 1 << sf, 36
+    t = np.arange(N)
+    down = L.host_tables(sf, fine=False)[1].astype(np.complex128)
+    sym = rng.integers(0, N, W)
+    base = down[None, :] * np.exp(2j * np.pi * sym[:, None] * t[None, :] / N)
+    base = base + 0.1 * (rng.standard_normal((W, N)) + 1j * rng.standard_normal((W, N)))
+    cases = []
+    with np.errstate(over="ignore"):
+        for scale in (1e-19, 1e-21, 1e-23, 3e-39, 1e17, 1e18, 3e19, 3e37):
+            cases.append(("scale %g" % scale, (base * scale).astype(np.complex64), False))
+    x = base.astype(np.complex64); x[::3, 5] = np.nan; cases.append(("NaN sample", x, False))
+    x = base.astype(np.complex64); x[::2, :] = 0; x[::2, 3] = 1e-30; cases.append(("lone 1e-30 sample", x, False))
+    x = base.astype(np.complex64); x[::3, N // 2] = np.inf; cases.append(("+Inf real part", x, True))
+    x = base.astype(np.complex64); x[::3, 7] = complex(0.0, -np.inf); cases.append(("-Inf imaginary part", x, True))
+    x = base.astype(np.complex64); x[::3, N - 1] = complex(np.inf, np.inf); cases.append(("Inf in both parts", x, True))
+    ctx = L.Context(sf)
+    for err in (0.0, 0.31):
+        fe = np.full(W, err, np.float32)
+        for name, iq, infinite in cases:
+            where = "sf%d err %g %s" % (sf, err, name)
+            g = ctx.detect_batch(gpu.from_numpy(iq).cuda(), fine_err=gpu.from_numpy(fe).cuda() if err else None, want_fft=True, want_dec=True)
+            gpu.cuda.synchronize()
+            with np.errstate(all="ignore"):
+                o = oracle.detect_batch(sf, iq, fine_err=fe if err else None, want_fft=True, want_dec=True)
+            assert np.array_equal(sym_np(g["sym"]), o["sym"]), where
+            assert _bits_differ(to_np(g["dec"]), o["dec"]) == 0, where
+            gf, of = to_np(g["fft"]).reshape(W, N), o["fft"].reshape(W, N)
+            if infinite:
+                hit = ~np.isfinite(iq).all(axis=1)
+                assert hit.sum() == len(range(0, W, 3))
+                assert _bits_differ(gf[~hit], of[~hit]) == 0, where
+                for f in (gf[hit], of[hit]):                      # every bin non-finite, |X|^2 NaN: nothing can win the arg-max
+                    with np.errstate(all="ignore"):
+                        m = f.real.astype(np.float32) ** 2 + f.imag.astype(np.float32) ** 2
+                    assert np.isnan(m).all(), where
+                assert np.all(o["sym"][hit] == 0)
+            else:
+                assert _bits_differ(gf, of) == 0, where
+            for k in ("power", "powerAvg", "fIndex"):
+                a, b = to_np(g[k]), o[k]
+                for cls in (np.isnan, np.isposinf, np.isneginf):
+                    assert np.array_equal(cls(a), cls(b)), where + " " + k
+                f = np.isfinite(b)
+                if f.any():
+                    tol = np.maximum(2 * np.spacing(np.abs(b[f]).astype(np.float32)), np.float32(TOL_DB if k != "fIndex" else TOL_FIDX))
+                    assert np.all(np.abs(a[f].astype(np.float64) - b[f]) <= tol), where + " " + k
