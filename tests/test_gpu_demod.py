@@ -848,3 +848,45 @@ def test_streams_with_non_finite_and_extreme_samples(gpu, oracle, sf, mode):
             for a, (_, b) in zip(mine, r["packets"]):
                 assert np.array_equal(a, b), where
         assert all(d.consumed(c) > streams[c].size - 2 * N for c in undefined)      # they ran to the end of their streams
+
+
+@pytest.mark.parametrize("sf", [10, 12])
+def test_streams_beyond_2_pow_31_samples(gpu, oracle, sf):
+    """Three channels of 2^30 + 2^26 samples each in one device buffer (27 GB of the 288): the third channel starts beyond sample
+    2^31 of the buffer and every channel's own position passes 2^30 -- the streaming kernels' 64-bit positions and addresses. The
+    streams are zeros with two frames at the very end; an all-zero window is not squelched (snr = -inf - -inf = NaN is not < thresh),
+    does not sync (value 0 does not match the sync word) and consumes N - 0 samples (LoRaDemod.cpp:219), so the reference on the
+    last part of the stream, started on a window boundary, sees exactly what the device sees there."""
+    import lora_sdr_amd as L
+    if gpu.cuda.get_device_properties(0).total_memory < 64 * 2**30:
+        pytest.skip("needs 27 GB of device memory")
+    rng = np.random.default_rng(31 + sf)
+    N = 1 << sf
+    LEN = 2**30 + 2**26
+    B = 3
+    buf = gpu.zeros((B, LEN), dtype=gpu.complex64, device="cuda")
+    tails, zeros = [], []
+    for c in range(B):
+        st, _ = frames(oracle, rng, sf, 2, 7 + c, off=0.3 * c - 0.2, noise=0.02, lead=N // 3 + 17 * c)
+        z = ((LEN - st.size) // N) * N                       # a whole number of windows of zeros in front
+        tail = np.concatenate([st, np.zeros(LEN - z - st.size, np.complex64)])
+        buf[c, z:] = gpu.from_numpy(tail).cuda()
+        tails.append(tail)
+        zeros.append(z)
+    assert 2 * LEN > 2**31
+    d = L.LoRaDemod(sf, n_channels=B)
+    d.set_mode(1)
+    d.setMTU(7)
+    d.work(buf)
+    pk = d.packets()
+    calls = 0
+    for c in range(B):
+        r = oracle.demod_run(sf, tails[c], mtu=7)
+        assert len(r["packets"]) >= 2
+        mine = [p[2] for p in pk if p[0] == c]
+        assert len(mine) == len(r["packets"]), "channel %d" % c
+        for a, (_, b) in zip(mine, r["packets"]):
+            assert np.array_equal(a, b), "channel %d" % c
+        assert d.consumed(c) == zeros[c] + int(sum(x["consumed"] for x in r["calls"])), "channel %d" % c
+        calls += zeros[c] // N + len(r["calls"])
+    assert d.work_calls() == calls
