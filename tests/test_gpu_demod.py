@@ -890,3 +890,43 @@ def test_streams_beyond_2_pow_31_samples(gpu, oracle, sf):
         assert d.consumed(c) == zeros[c] + int(sum(x["consumed"] for x in r["calls"])), "channel %d" % c
         calls += zeros[c] // N + len(r["calls"])
     assert d.work_calls() == calls
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sf", [8, 11])
+def test_extreme_settings(gpu, oracle, sf, mode):
+    """The setters are plain stores without validation (LoRaDemod.cpp:124-137): sync words 0x00 (the preamble itself matches the
+    first nibble), 0xff, 0x0f, 0xf0; thresholds -inf (nothing squelched), +inf (everything with a finite snr squelched), NaN (`snr
+    < NaN` is false: nothing squelched), +-1e30; an MTU larger than the stream has symbols. With a trace (exact chain) and without
+    (quick squelch estimate) the calls, packets and consumption are the reference's."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(77 + sf)
+    N = 1 << sf
+    streams = {}
+    for sync in (0x00, 0xff, 0x0f, 0xf0, 0x12):
+        syms = rng.integers(0, N, 7).astype(np.uint16)
+        fr = oracle.mod_frame(sf, syms, sync=sync, padding=3)
+        st = np.concatenate([np.zeros(N // 2 + 9, np.complex64), fr, fr, np.zeros(2 * N, np.complex64)])
+        st = (st * np.exp(2j * np.pi * 0.21 / N * np.arange(st.size))).astype(np.complex64)
+        st += (0.02 * (rng.standard_normal(st.size) + 1j * rng.standard_normal(st.size))).astype(np.complex64)
+        streams[sync] = st
+    inf = float("inf")
+    cases = [(0x00, 64, 3.0), (0xff, 64, 3.0), (0x0f, 5, 3.0), (0xf0, 64, 3.0), (0x12, 5, -inf), (0x12, 64, inf), (0x12, 5, float("nan")),
+             (0x12, 3, 1e30), (0x12, 6, -1e30), (0x12, 100000, 3.0), (0x00, 1, inf)]
+    for sync, mtu, thresh in cases:
+        st = streams[sync]
+        with np.errstate(all="ignore"):
+            r = oracle.demod_run(sf, st, sync=sync, mtu=mtu, thresh=thresh)
+        for traced in (True, False):
+            d = L.LoRaDemod(sf)
+            d.set_mode(mode); d.setSync(sync); d.setMTU(mtu); d.setThreshold(thresh); d.set_trace(traced)
+            d.work([st])
+            where = "sf%d mode %d sync %#x mtu %d thresh %r traced %d" % (sf, mode, sync, mtu, thresh, traced)
+            if traced:
+                compare_channel(d.trace(0), r["calls"])
+            assert d.work_calls() == len(r["calls"]), where
+            assert d.consumed(0) == int(sum(x["consumed"] for x in r["calls"])), where
+            pk = d.packets()
+            assert len(pk) == len(r["packets"]), where
+            assert all(np.array_equal(p[2], q) for p, (_, q) in zip(pk, r["packets"])), where
+            d.close()
