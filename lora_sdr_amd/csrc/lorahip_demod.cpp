@@ -558,9 +558,12 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     // work() calls per channel per launch: enough for a clean stream in one launch, bounded so that the
     // per-launch buffers stay moderate (the launch is resumable)
     const size_t perCall = sizeof(short) + (dm->tracing ? sizeof(lorahip_work_result) : 0) + sizeof(StreamPacket) / 4 + 1;
-    size_t cap = maxLen / N + 64;
+    // a call consumes N samples except around a frame's sync (N - value, N/4 + error/2: LoRaDemod.cpp:219, :278), a handful of short
+    // calls per frame: an eighth on top of len / N keeps a stream of many short frames in one launch (a resumed launch costs a
+    // drain of the records in between; measured 9.7 ms instead of 7.3 ms per run at SF7, 16384 channels x 16 frames)
+    size_t cap = maxLen / N + maxLen / (8 * N) + 64;
     if (cap > 65536) cap = 65536;
-    const size_t capMem = (size_t(256) << 20) / (B * perCall);
+    const size_t capMem = (size_t(1) << 30) / (B * perCall);
     if (cap > capMem) cap = capMem;
     if (cap < 8) cap = 8;
     // test hook: a small per-launch record capacity forces the resume path (several launches per run)
