@@ -297,6 +297,10 @@ int64_t lorahip_demod_work_calls(const lorahip_demod *d);
 /* device time of the streaming kernel launches of the last lorahip_demod_run[_device] (HIP events on the launch stream; 0 in the
  * host-driven mode): what the level-3 roofline line of bench.py is computed from */
 double lorahip_demod_kernel_ms(const lorahip_demod *d);
+/* streaming kernel launches the last lorahip_demod_run[_device] took (0 in the host-driven mode). One is the rule; a run whose
+ * per-launch record buffers filled is resumed (records drained in between, which costs more than the launch), and the capacity the
+ * following runs of this object are given grows with what the run needed -- a receiver settles at one launch per run */
+int lorahip_demod_last_launches(const lorahip_demod *d);
 /* The runtime signal for the caveat at the top of this section: how many decisions since the last activate() sat so close to their
  * boundary that the last-place differences between this library's power / powerAvg / fIndex and a CPU build's could have flipped
  * them. Counted, never altered.

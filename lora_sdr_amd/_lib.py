@@ -134,6 +134,7 @@ SIGNATURES = {
     "lorahip_demod_consumed": (C.c_int64, [C.c_void_p, C.c_size_t]),
     "lorahip_demod_work_calls": (C.c_int64, [C.c_void_p]),
     "lorahip_demod_kernel_ms": (C.c_double, [C.c_void_p]),
+    "lorahip_demod_last_launches": (C.c_int, [C.c_void_p]),
     "lorahip_demod_near_threshold": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "lorahip_demod_set_trace": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_set_ports": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -671,6 +671,10 @@ class LoRaDemod:
         """device time of the streaming kernel launches of the last work() (HIP events on the launch stream)"""
         return float(self._lib.lorahip_demod_kernel_ms(self._h))
 
+    def last_launches(self):
+        """streaming kernel launches the last work() took (1 unless its record buffers filled and the run was resumed)"""
+        return int(self._lib.lorahip_demod_last_launches(self._h))
+
     def near_threshold(self):
         """(near_squelch, near_step): decisions since activate() that sat within float rounding of their boundary -- |snr - thresh|
         <= 4e-5 dB where the squelch is consumed, fine-tune steps within 6e-5 of an integer (include/lorahip.h). Counted, not changed."""

@@ -74,6 +74,7 @@ struct lorahip_demod
     char *dDense, *hDense; size_t denseBytes;   // the used part of the record arrays, packed for the copy back
     hipEvent_t evK0, evK1;           // around the streaming kernel launches of a run (lorahip_demod_kernel_ms)
     double kernelMs;
+    int lastLaunches;                // streaming kernel launches of the last run
     lorahip_demod_ports ports;       // level-3 debug ports (all pointers null: off); DEVICE pointers (the library's own when the caller's are host buffers)
     lorahip_demod_ports hostPorts;   // the caller's host buffers (host_buffers == 1)
     float *ownFft, *ownDec, *ownRaw; // device mirrors owned by the library for host_buffers
@@ -90,6 +91,7 @@ struct lorahip_demod
     bool posOnDevice;                // the pinned state copy's `pos` belongs to the CURRENT placement (a streaming run filled it; a new
                                      // lorahip_demod_run[_device] call invalidates it: its streams start at sample 0)
     bool portCountsDirty;            // ch[].portFft / portDec / portRaw may be non-zero
+    size_t callsPerWindowQ8;         // streaming runs: work() calls per N samples the record buffers are sized for, in 1/256 (adapts, see runStream)
     void *pending;                   // PendingLaunch (records of the last streaming launch still on the device)
     std::vector<size_t> carry;       // per channel: symbols of a packet begun before the launch being drained
 };
@@ -558,10 +560,12 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     // work() calls per channel per launch: enough for a clean stream in one launch, bounded so that the
     // per-launch buffers stay moderate (the launch is resumable)
     const size_t perCall = sizeof(short) + (dm->tracing ? sizeof(lorahip_work_result) : 0) + sizeof(StreamPacket) / 4 + 1;
-    // a call consumes N samples except around a frame's sync (N - value, N/4 + error/2: LoRaDemod.cpp:219, :278), a handful of short
-    // calls per frame: an eighth on top of len / N keeps a stream of many short frames in one launch (a resumed launch costs a
-    // drain of the records in between; measured 9.7 ms instead of 7.3 ms per run at SF7, 16384 channels x 16 frames)
-    size_t cap = maxLen / N + maxLen / (8 * N) + 64;
+    // A call consumes N samples except around a frame's sync (N - value, N/4 + error/2: LoRaDemod.cpp:219, :278) -- a handful of short
+    // calls per frame -- and in an unsquelched FRAMESYNC window that does not sync (N - value every call: a receiver idling on noise
+    // above its threshold makes about two calls per N samples). A launch whose record buffers fill is resumed, but the records have
+    // to be drained in between (measured: 9.7 ms instead of 7.0 ms per run at SF7, 16384 channels x 16 frames), so the capacity
+    // starts with an eighth of headroom and follows what the runs of this receiver actually needed (never shrinks).
+    size_t cap = (maxLen / N) * dm->callsPerWindowQ8 / 256 + 64;
     if (cap > 65536) cap = 65536;
     const size_t capMem = (size_t(1) << 30) / (B * perCall);
     if (cap > capMem) cap = capMem;
@@ -665,6 +669,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     if (dm->evK0 == nullptr) { LORAHIP_TRY(hipEventCreate(&dm->evK0)); LORAHIP_TRY(hipEventCreate(&dm->evK1)); }
     bool lastPending = false;
     size_t pendPackets = 0, pendNSym = 0;
+    int launches = 0;
     while (true)
     {
         const Clock::time_point ta = Clock::now();
@@ -693,6 +698,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
             more = more || hN[c] == icap || hNPkt[c] == icapPkt;
         }
         dm->workCalls += calls;
+        launches++;
         // a launch that must be resumed hands its records over now (the next one reuses the buffers); so does a traced run (its
         // callers read the trace next). Otherwise the records wait on the device.
         if (more || dm->tracing)
@@ -717,6 +723,13 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         if (st.state == ST_DATASYMBOLS) { anyOpen = true; openSyms += size_t(st.symCount); }
     }
     if (anyCarryIn || lastPending) for (size_t c = 0; c < B; c++) carriedIn += carry[c];
+    dm->lastLaunches = launches;
+    if (launches > 1 && maxLen >= N)
+    {
+        // the run had to be resumed: size the record buffers of the runs to come for the fullest channel's rate of calls, a quarter on top
+        const size_t q8 = (size_t(rounds) * 256 / (maxLen / N)) * 5 / 4 + 16;
+        if (q8 > dm->callsPerWindowQ8) dm->callsPerWindowQ8 = q8 > size_t(256) * 64 ? size_t(256) * 64 : q8;
+    }
     dm->devStateFresh = true;                         // the device holds what the pinned copy says; the mirrors lag (mirrorsStale)
     dm->posOnDevice = true;
     PendingLaunch &P = pendingOf(dm);
@@ -909,6 +922,7 @@ static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         for (auto &k : dm->ch) { k.traceStart = k.trace.size(); k.portFft = k.portDec = k.portRaw = 0; }
         dm->portCountsDirty = dm->portsOn;                       // a run without ports leaves them at zero: nothing to reset next time
     }
+    if (!stream) { dm->kernelMs = 0.0; dm->lastLaunches = 0; }       // what the accessors say of a host-driven run
     int rc = stream ? runStream(dm, iqDev, roundsOut) : runRounds(dm, iqDev, roundsOut);
     if (rc == LORAHIP_OK && dm->portsOn) rc = fillPorts(dm, iqDev);
     if (internalTrace) for (auto &k : dm->ch) { std::vector<lorahip_work_result>().swap(k.trace); k.traceStart = 0; }
@@ -943,6 +957,8 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->nNearSquelch = dm->nNearStep = 0;
     dm->devStateFresh = false; dm->mirrorsStale = false; dm->activatePending = false;
     dm->uniform = false; dm->uniSpc = 0; dm->geomApplied = true; dm->portCountsDirty = true; dm->posOnDevice = false;
+    dm->lastLaunches = 0;
+    dm->callsPerWindowQ8 = 288;                                 // 1.125 calls per N samples to begin with
     dm->ch.resize(n_channels);
     for (auto &k : dm->ch) { k.traceStart = 0; k.traceSymCount0 = 0; k.portFft = k.portDec = k.portRaw = 0; }
     dm->stageBytes = carve(nullptr, n_channels).total;
@@ -1219,6 +1235,7 @@ void lorahip_demod_clear_packets(lorahip_demod *dm)
 int64_t lorahip_demod_work_calls(const lorahip_demod *dm) { return dm ? dm->workCalls : 0; }
 
 double lorahip_demod_kernel_ms(const lorahip_demod *dm) { return dm ? dm->kernelMs : 0.0; }
+int lorahip_demod_last_launches(const lorahip_demod *dm) { return dm ? dm->lastLaunches : 0; }
 
 int lorahip_demod_near_threshold(const lorahip_demod *dm, int64_t *near_squelch, int64_t *near_step)
 {

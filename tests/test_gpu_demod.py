@@ -930,3 +930,38 @@ def test_extreme_settings(gpu, oracle, sf, mode):
             assert len(pk) == len(r["packets"]), where
             assert all(np.array_equal(p[2], q) for p, (_, q) in zip(pk, r["packets"])), where
             d.close()
+
+
+@pytest.mark.parametrize("sf", [7, 11])
+def test_record_capacity_follows_what_a_receiver_needs(gpu, oracle, sf):
+    """A receiver idling on noise above its threshold makes a work() call per N - value samples, about two per N (LoRaDemod.cpp:219)
+    -- more than the per-launch record buffers hold at first, so the first run is resumed (several launches, records drained in
+    between: correct, slower); the capacity then follows what the run needed and the next runs take ONE launch. The first run
+    (fresh blocks) is compared with the reference; activate() keeps everything but the state and the table (LoRaDemod.cpp:139-143),
+    so the later runs are compared with the host-driven mode of a second object that has been through the same runs."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(5 + sf)
+    N, B, S = 1 << sf, 6, 400 * (1 << sf) + 77
+    x = (rng.standard_normal((B, S)) + 1j * rng.standard_normal((B, S))).astype(np.complex64)
+    refs = [oracle.demod_run(sf, x[c], mtu=16) for c in range(B)]
+    assert max(len(r["calls"]) for r in refs) > 1.5 * (S // N)
+    d, h = L.LoRaDemod(sf, n_channels=B), L.LoRaDemod(sf, n_channels=B)
+    d.set_mode(1); h.set_mode(2)
+    launches = []
+    for run in range(3):
+        got = []
+        for o in (d, h):
+            o.setMTU(16)
+            o.activate()
+            o.work(gpu.from_numpy(x).cuda())
+            got.append((o.work_calls(), [o.consumed(c) for c in range(B)], [(p[0], p[2].tolist()) for p in sorted(o.packets(), key=lambda p: (p[0], p[1]))]))
+            o.clear_packets()
+        launches.append(d.last_launches())
+        assert got[0] == got[1], run
+        assert len(got[0][2]) > 0 or sf > 7                 # noise makes false packets at SF7 (the test compares them too)
+        if run == 0:
+            assert got[0][0] == sum(len(r["calls"]) for r in refs)
+            assert got[0][1] == [int(sum(k["consumed"] for k in r["calls"])) for r in refs]
+            assert got[0][2] == [(c, q.tolist()) for c in range(B) for _, q in refs[c]["packets"]]
+    assert launches[0] > 1 and launches[1] == 1 and launches[2] == 1, launches
+    assert h.last_launches() == 0 and h.kernel_ms() == 0.0
