@@ -271,6 +271,14 @@ int lorahip_demod_run(lorahip_demod *d, const float *const *streams, const size_
 /* Same, but `iq` is one DEVICE buffer holding n_channels streams of samples_per_channel each. */
 int lorahip_demod_run_device(lorahip_demod *d, const float *iq_dev, size_t samples_per_channel,
                              int64_t *rounds);
+/* Same for a caller that keeps its channels' samples in ONE device buffer at places of its own -- the running receiver behind a
+ * channeliser: channel c's stream is the n_samples[c] samples that start at sample first_sample[c] of iq_dev (HOST arrays of
+ * n_channels entries; segments may have any lengths, including 0, and need not be ordered). work() leaves fewer than 2N samples
+ * of a channel unconsumed (LoRaDemod.cpp:148) and how many it consumed differs from channel to channel (lorahip_demod_consumed), so
+ * a caller that appends each new chunk behind the last one advances first_sample[c] by what channel c consumed and presents the
+ * remainder together with the new samples -- nothing is copied, nothing is lost at the chunk boundaries. */
+int lorahip_demod_run_device_segments(lorahip_demod *d, const float *iq_dev, const int64_t *first_sample, const size_t *n_samples,
+                                      int64_t *rounds);
 
 size_t lorahip_demod_num_packets(const lorahip_demod *d);
 /* packet i: channel, round index it was posted in, and length; symbols copied if out != NULL */

@@ -125,6 +125,7 @@ SIGNATURES = {
     "lorahip_demod_packets_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lorahip_demod_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "lorahip_demod_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
+    "lorahip_demod_run_device_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "lorahip_demod_num_packets": (C.c_size_t, [C.c_void_p]),
     "lorahip_demod_get_packet": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]),

@@ -470,12 +470,15 @@ class Channelizer:
         n_out = self.out_count(wide.numel())
         if out is None:
             out = torch.empty((self.n_channels, n_out), dtype=torch.complex64, device=wide.device)
-        elif out.dim() != 2 or out.shape[0] != self.n_channels or out.shape[1] < n_out or out.dtype != torch.complex64 or not out.is_contiguous():
-            raise ValueError("out must be a contiguous (K, >= n_out) complex64 tensor")
+        elif (out.dim() != 2 or out.shape[0] != self.n_channels or out.shape[1] < n_out or out.dtype != torch.complex64
+              or (out.numel() and (out.stride(1) != 1 or out.stride(0) < out.shape[1]))):
+            raise ValueError("out must be a (K, >= n_out) complex64 tensor with unit column stride (rows may be a slice of a wider buffer)")
         self._ctx.use_torch_stream()
         got = C.c_size_t()
+        # the row stride is the tensor's own: `out` may be the columns [w, w + n) of a (K, capacity) buffer that fills chunk by chunk
         check(self._lib.lorahip_channelizer_run(self._h, C.c_void_p(wide.data_ptr()) if wide.numel() else None, wide.numel(),
-                                                C.c_void_p(out.data_ptr()) if out.numel() else None, int(out.shape[1]), C.byref(got)),
+                                                C.c_void_p(out.data_ptr()) if out.numel() else None,
+                                                int(out.stride(0)) if out.numel() and out.shape[0] > 1 else int(out.shape[1]), C.byref(got)),
               "lorahip_channelizer_run")
         return out[:, :got.value]
 
@@ -577,6 +580,28 @@ class LoRaDemod:
 
     def set_trace(self, on=True):
         check(self._lib.lorahip_demod_set_trace(self._h, int(bool(on))), "lorahip_demod_set_trace")
+
+    def work_segments(self, buf, first_sample, n_samples):
+        """lorahip_demod_run_device_segments: channel c's stream is buf.view(-1)[first_sample[c] : first_sample[c] + n_samples[c]] of ONE
+        torch complex64 device tensor -- the running receiver behind a channeliser, which advances first_sample[c] by consumed(c)
+        and re-presents the remainder with the new samples, without copying anything. Returns the number of lock-step rounds."""
+        import torch
+        if not _is_torch(buf) or buf.dtype != torch.complex64 or not buf.is_contiguous():
+            raise ValueError("expected a contiguous complex64 device tensor")
+        first = np.ascontiguousarray(first_sample, np.int64)
+        cnt = np.ascontiguousarray(n_samples, np.uint64)
+        if first.shape != (self.n_channels,) or cnt.shape != (self.n_channels,):
+            raise ValueError("first_sample and n_samples need one entry per channel")
+        if cnt.size and int((first + cnt.astype(np.int64)).max()) > buf.numel():
+            raise ValueError("a segment ends beyond the buffer")
+        rounds = C.c_int64()
+        check(self._lib.lorahip_demod_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)), "lorahip_demod_set_stream")
+        try:
+            check(self._lib.lorahip_demod_run_device_segments(self._h, _dptr(buf), first.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                              cnt.ctypes.data_as(C.POINTER(C.c_size_t)), C.byref(rounds)), "lorahip_demod_run_device_segments")
+        finally:
+            self._lib.lorahip_demod_reset_stream(self._h)
+        return rounds.value
 
     def work(self, streams):
         """Feed one complete input stream per channel and run work() until < 2N samples remain

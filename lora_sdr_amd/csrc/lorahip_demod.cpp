@@ -1069,6 +1069,27 @@ int lorahip_demod_run_device(lorahip_demod *dm, const float *iq_dev, const size_
     return runAny(dm, iq_dev, rounds);
 }
 
+int lorahip_demod_run_device_segments(lorahip_demod *dm, const float *iq_dev, const int64_t *first_sample, const size_t *n_samples, int64_t *rounds)
+{
+    if (dm == nullptr || first_sample == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
+    bool any = false;
+    for (size_t c = 0; c < dm->B; c++)
+    {
+        if (first_sample[c] < 0 || n_samples[c] > size_t(0x7fffffffffffffffLL) - size_t(first_sample[c])) return LORAHIP_E_INVALID;
+        any = any || n_samples[c] != 0;
+    }
+    if (any && iq_dev == nullptr) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(dm->ctx->device);
+    dm->uniform = false; dm->geomApplied = true; dm->posOnDevice = false;
+    for (size_t c = 0; c < dm->B; c++)
+    {
+        dm->ch[c].base = size_t(first_sample[c]);
+        dm->ch[c].len = n_samples[c];
+        dm->ch[c].pos = 0;
+    }
+    return runAny(dm, iq_dev, rounds);
+}
+
 int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size_t *n_samples, int64_t *rounds)
 {
     if (dm == nullptr || streams == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;

@@ -965,3 +965,47 @@ def test_record_capacity_follows_what_a_receiver_needs(gpu, oracle, sf):
             assert got[0][2] == [(c, q.tolist()) for c in range(B) for _, q in refs[c]["packets"]]
     assert launches[0] > 1 and launches[1] == 1 and launches[2] == 1, launches
     assert h.last_launches() == 0 and h.kernel_ms() == 0.0
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sf", [7, 11])
+def test_running_receiver_on_segments_of_one_device_buffer(gpu, oracle, sf, mode):
+    """lorahip_demod_run_device_segments: the receiver behind a channeliser. All channels live in one (channels, capacity) device
+    buffer that fills chunk by chunk; every work() is given, per channel, the samples between what that channel has consumed so far
+    and what has been written so far -- the remainder of the last call (up to 2N - 1 samples, different from channel to channel)
+    together with the new chunk, nothing copied. Packets, and the total consumption, are those of one work() over the whole stream
+    and of the reference; with ports on, the traced consumption is too."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(300 + sf)
+    N, B = 1 << sf, 6
+    streams = [frames(oracle, rng, sf, 3, 8 + c, off=rng.uniform(-0.4, 0.4), noise=0.05, lead=int(rng.integers(0, 2 * N)))[0] for c in range(B)]
+    cap = max(s.size for s in streams)
+    host = np.zeros((B, cap), np.complex64)
+    for c, s in enumerate(streams):
+        host[c, :s.size] = s
+    refs = [oracle.demod_run(sf, host[c], mtu=8) for c in range(B)]
+    buf = gpu.zeros((B, cap), dtype=gpu.complex64, device="cuda")
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(mode); d.setMTU(8)
+    read = np.zeros(B, np.int64)
+    written, got, calls = 0, [[] for _ in range(B)], 0
+    with pytest.raises(ValueError):
+        d.work_segments(buf, np.arange(B) * cap, np.full(B, cap + 1))
+    while written < cap:
+        n = min(cap - written, int(rng.integers(N // 2, 6 * N)))
+        buf[:, written:written + n] = gpu.from_numpy(host[:, written:written + n]).cuda()      # "the channeliser's next chunk"
+        written += n
+        d.work_segments(buf, np.arange(B) * cap + read, written - read)
+        for ch, _, s in d.packets():
+            got[ch].append(s)
+        for c in range(B):
+            k = d.consumed(c)
+            assert 0 <= k <= written - read[c]
+            assert written - read[c] - k < 2 * N or k == 0 and written - read[c] < 2 * N      # LoRaDemod.cpp:148
+            read[c] += k
+        calls = d.work_calls()
+    for c in range(B):
+        r = refs[c]
+        assert len(got[c]) == len(r["packets"]) >= 3, "channel %d" % c
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
+        assert read[c] == int(sum(k["consumed"] for k in r["calls"])), "channel %d" % c
+    assert calls == sum(len(r["calls"]) for r in refs)
