@@ -300,7 +300,9 @@ void lorahip_demod_clear_packets(lorahip_demod *d);
 /* samples of `channel`'s stream the last lorahip_demod_run[_device] consumed (the sum of its consume() calls, :320): a
  * streaming caller presents the unconsumed remainder again in front of the next chunk, as the framework's port buffer does */
 int64_t lorahip_demod_consumed(const lorahip_demod *d, size_t channel);
-/* total work() calls made (sum over channels) since create/activate */
+/* the same for every channel at once: out[n_channels] */
+int lorahip_demod_consumed_all(const lorahip_demod *d, int64_t *out);
+/* total work() calls made (sum over channels) since lorahip_demod_create */
 int64_t lorahip_demod_work_calls(const lorahip_demod *d);
 /* device time of the streaming kernel launches of the last lorahip_demod_run[_device] (HIP events on the launch stream; 0 in the
  * host-driven mode): what the level-3 roofline line of bench.py is computed from */

@@ -133,6 +133,7 @@ SIGNATURES = {
     "lorahip_demod_get_packets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "lorahip_demod_clear_packets": (None, [C.c_void_p]),
     "lorahip_demod_consumed": (C.c_int64, [C.c_void_p, C.c_size_t]),
+    "lorahip_demod_consumed_all": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "lorahip_demod_work_calls": (C.c_int64, [C.c_void_p]),
     "lorahip_demod_kernel_ms": (C.c_double, [C.c_void_p]),
     "lorahip_demod_last_launches": (C.c_int, [C.c_void_p]),

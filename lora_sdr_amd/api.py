@@ -689,6 +689,12 @@ class LoRaDemod:
         """samples of the channel's stream consumed by the last work()"""
         return int(self._lib.lorahip_demod_consumed(self._h, int(channel)))
 
+    def consumed_all(self):
+        """consumed(c) of every channel: an int64 numpy array (one call into the library)"""
+        out = np.empty(self.n_channels, np.int64)
+        check(self._lib.lorahip_demod_consumed_all(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))), "lorahip_demod_consumed_all")
+        return out
+
     def work_calls(self):
         return int(self._lib.lorahip_demod_work_calls(self._h))
 

@@ -91,6 +91,12 @@ struct lorahip_demod
     bool posOnDevice;                // the pinned state copy's `pos` belongs to the CURRENT placement (a streaming run filled it; a new
                                      // lorahip_demod_run[_device] call invalidates it: its streams start at sample 0)
     bool portCountsDirty;            // ch[].portFft / portDec / portRaw may be non-zero
+    // The symbols of the packet a channel is INSIDE when a streaming run ends stay on the device too: carrySave leaves them in dCarry,
+    // carryLoad puts them at the head of the channel's symbol row before the next run, whose kernel appends behind them -- a packet
+    // that spans runs is assembled without the host (the running receiver: lorahip_demod_run_device_segments + packets_to_device).
+    short *dCarry; size_t carryCap;  // [B][carryCap]
+    bool devCarryValid;              // dCarry holds the open packets of the state on the device
+    bool hostCarryStale;             // ch[].outSymbols lack what the runs since the last drain received (implies devCarryValid)
     size_t callsPerWindowQ8;         // streaming runs: work() calls per N samples the record buffers are sized for, in 1/256 (adapts, see runStream)
     void *pending;                   // PendingLaunch (records of the last streaming launch still on the device)
     std::vector<size_t> carry;       // per channel: symbols of a packet begun before the launch being drained
@@ -166,6 +172,7 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     syncMirrors(dm);
     applyGeometry(dm);
     dm->devStateFresh = false;                                  // the mirrors are about to change: the device copy goes stale
+    dm->devCarryValid = false;                                  // ... and so do the open packets' symbols it holds (syncMirrors fetched them)
     const DeviceGuard guard(dm->ctx->device);
     const Round hr = carve(dm->h, B);
     std::vector<uint32_t> live, second;
@@ -360,12 +367,13 @@ static int growDense(lorahip_demod *dm, const size_t bytes)
 //! where the pieces of one streaming launch live inside dm->sDev (device) / dm->sHost (host mirror of the head)
 struct StreamLayout
 {
-    size_t B, cap, capPkt;
+    size_t B, cap, capPkt, symStride;
     bool tracing;
     size_t oBase, oLen, oState, oN, oNSym, oNPkt, oNear, oPkt, oSym, oCalls, total;
-    void make(const size_t B_, const size_t cap_, const size_t capPkt_, const bool tracing_)
+    void make(const size_t B_, const size_t cap_, const size_t capPkt_, const bool tracing_, const size_t carryCap_ = 0)
     {
         B = B_; cap = cap_; capPkt = capPkt_; tracing = tracing_;
+        symStride = cap_ + carryCap_;                    // a channel's symbol row: what the launch may add behind what it was handed
         size_t cur = 0;
         auto carve = [&cur](const size_t bytes) { const size_t o = cur; cur += align256(bytes); return o; };
         oBase = carve(B * sizeof(long long)); oLen = carve(B * sizeof(long long));
@@ -373,7 +381,7 @@ struct StreamLayout
         oN = carve(B * sizeof(int)); oNSym = carve(B * sizeof(int)); oNPkt = carve(B * sizeof(int));
         oNear = carve(2 * sizeof(unsigned));
         oPkt = carve(B * capPkt * sizeof(StreamPacket));
-        oSym = carve(B * cap * sizeof(short));
+        oSym = carve(B * symStride * sizeof(short));
         oCalls = carve(tracing ? B * cap * sizeof(lorahip_work_result) : 0);
         total = cur;
     }
@@ -447,7 +455,7 @@ static int drainLaunch(lorahip_demod *dm, const StreamLayout &L)
     const size_t nbDense = nbPkt + nbSym + nbCalls;
     { const int grc = growDense(dm, nbDense); if (grc != LORAHIP_OK) return grc; }
     LORAHIP_TRY(launchCompactRows(dm->dDense, d + L.oPkt, B, L.capPkt * sizeof(StreamPacket), maxPkt * sizeof(StreamPacket), ctx->stream));
-    LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt, d + L.oSym, B, L.cap * sizeof(short), maxSym * sizeof(short), ctx->stream));
+    LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt, d + L.oSym, B, L.symStride * sizeof(short), maxSym * sizeof(short), ctx->stream));
     if (L.tracing)
         LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt + nbSym, d + L.oCalls, B, L.cap * sizeof(lorahip_work_result),
                                       maxCalls * sizeof(lorahip_work_result), ctx->stream));
@@ -504,6 +512,7 @@ static int drainPending(lorahip_demod *dm)
     const int rc = drainLaunch(dm, P.lay);
     if (rc != LORAHIP_OK) return rc;
     P.valid = false;
+    dm->hostCarryStale = false;                       // drainLaunch has written the open packets' symbols of this launch into the mirrors
     orderNewPackets(dm, P.firstNewPacket, P.rounds);
     P.drainMs = std::chrono::duration<double>(Clock::now() - t0).count() * 1e3;
     static const bool timing = std::getenv("LORAHIP_DEMOD_TIMING") != nullptr;
@@ -517,6 +526,32 @@ static StreamState *hostStates(lorahip_demod *dm)
     StreamLayout L;
     L.make(dm->B, 8, 4, false);
     return reinterpret_cast<StreamState *>(dm->sHost + L.oState);
+}
+
+//! the open packets' symbols the device holds (dCarry) into the mirrors' outSymbols; the mirrors' state must be current
+static int fetchCarry(lorahip_demod *dm)
+{
+    if (!dm->hostCarryStale) return LORAHIP_OK;
+    const size_t B = dm->B, cap = dm->carryCap;
+    bool any = false;
+    for (size_t c = 0; c < B && !any; c++) any = dm->ch[c].state == ST_DATASYMBOLS && dm->ch[c].symCount != 0;
+    if (any && dm->dCarry && dm->devCarryValid)
+    {
+        const DeviceGuard guard(dm->ctx->device);
+        std::vector<short> rows(B * cap);
+        LORAHIP_TRY(hipMemcpyAsync(rows.data(), dm->dCarry, B * cap * sizeof(short), hipMemcpyDeviceToHost, dm->ctx->stream));
+        LORAHIP_TRY(hipStreamSynchronize(dm->ctx->stream));
+        for (size_t c = 0; c < B; c++)
+        {
+            Channel &k = dm->ch[c];
+            if (k.state != ST_DATASYMBOLS || k.symCount == 0) continue;
+            const size_t n = k.symCount < cap ? k.symCount : cap;
+            if (k.outSymbols.size() < k.symCount) k.outSymbols.resize(k.symCount, 0);
+            std::memcpy(k.outSymbols.data(), rows.data() + c * cap, n * sizeof(short));
+        }
+    }
+    dm->hostCarryStale = false;
+    return LORAHIP_OK;
 }
 
 //! bring the Channel mirrors up to date with the device's state (its pinned copy): only the paths that read them pay for it
@@ -535,6 +570,7 @@ static void syncMirrors(lorahip_demod *dm)
         }
     }
     dm->mirrorsStale = false;
+    (void)fetchCarry(dm);                               // before a deferred activate() hides which channels were inside a packet: a failure leaves the flag set
     if (dm->activatePending)
     {
         for (auto &k : dm->ch) { k.state = ST_FRAMESYNC; k.downTable = false; }     // activate() (:139-143), deferred
@@ -574,8 +610,21 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     if (const char *e = std::getenv("LORAHIP_STREAM_CAP")) { const long v = std::atol(e); if (v >= 1) cap = size_t(v); }
     const size_t capPkt = cap / 4 + 2;               // a packet costs at least 5 calls (3 sync, quarter, 1 symbol)
 
+    // open packets on the device (dCarry): rows of mtu + 1 symbols; receivers with longer packets than this keep the host path
+    const size_t kCarryLimit = 4096;
+    bool useDevCarry = dm->mtu <= kCarryLimit;
+    if (useDevCarry && dm->mtu + 1 > dm->carryCap)
+    {
+        syncMirrors(dm);                             // what the device holds of open packets goes to the mirrors first
+        if (dm->dCarry) { (void)hipFree(dm->dCarry); dm->dCarry = nullptr; }
+        dm->carryCap = 0; dm->devCarryValid = false;
+        const size_t rows = dm->mtu + 1 < 64 ? 64 : dm->mtu + 1;
+        LORAHIP_TRY(hipMalloc((void **)&dm->dCarry, B * rows * sizeof(short)));
+        dm->carryCap = rows;
+    }
+
     StreamLayout L;
-    L.make(B, cap, capPkt, dm->tracing);
+    L.make(B, cap, capPkt, dm->tracing, dm->carryCap);
     if (L.total > dm->sBytes)
     {
         syncMirrors(dm);                             // the pinned copy of the state goes away with the buffers
@@ -583,9 +632,12 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         if (dm->sHost) { (void)hipHostFree(dm->sHost); dm->sHost = nullptr; }
         dm->sBytes = 0;
         dm->devStateFresh = false;
-        LORAHIP_TRY(hipMalloc((void **)&dm->sDev, L.total));
+        // a quarter more than this run needs: the chunks of a running receiver differ by the remainders they start with, and every
+        // growth costs two allocations and an upload of the state
+        const size_t want = L.total + L.total / 4;
+        LORAHIP_TRY(hipMalloc((void **)&dm->sDev, want));
         LORAHIP_TRY(hipHostMalloc((void **)&dm->sHost, L.oPkt, hipHostMallocDefault));       // the host mirrors only the head: placement, state, counts
-        dm->sBytes = L.total;
+        dm->sBytes = want;
     }
     char *h = dm->sHost, *d = dm->sDev;
     long long *hBase = reinterpret_cast<long long *>(h + L.oBase), *hLen = reinterpret_cast<long long *>(h + L.oLen);
@@ -605,11 +657,6 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         if (!activate)
             for (size_t c = 0; c < B; c++)
                 if (hState[c].state == ST_DATASYMBOLS && hState[c].symCount) { carry[c] = size_t(hState[c].symCount); anyCarryIn = true; }
-        if (anyCarryIn)
-        {
-            // the open packet's symbols so far were kept in the mirrors' outSymbols by the drain of the run that received them
-            for (size_t c = 0; c < B; c++) if (carry[c] && dm->ch[c].outSymbols.size() < carry[c]) dm->ch[c].outSymbols.resize(carry[c], 0);
-        }
     }
     else
     {
@@ -629,6 +676,37 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         }
         LORAHIP_TRY(hipMemcpyAsync(d + L.oState, h + L.oState, L.oN - L.oState, hipMemcpyHostToDevice, ctx->stream));
     }
+    // Where do the symbols of those packets come from? From the device's own copy (dCarry: carryLoad puts them at the head of the
+    // channels' symbol rows and the kernel appends behind them: the host sees packets without a past), unless a packet is longer
+    // than its rows -- then from the mirrors' outSymbols, as the launches of a resumed run do among themselves.
+    size_t maxCarry = 0;
+    for (size_t c = 0; c < B; c++) if (carry[c] > maxCarry) maxCarry = carry[c];
+    if (useDevCarry && maxCarry >= dm->carryCap) useDevCarry = false;
+    bool loadCarry = false;
+    if (useDevCarry)
+    {
+        if (anyCarryIn && !dm->devCarryValid)
+        {
+            // the mirrors hold them (a host-driven run, or a resumed one, came before): up they go
+            const size_t cc = dm->carryCap;
+            { const int grc = growDense(dm, B * cc * sizeof(short)); if (grc != LORAHIP_OK) return grc; }
+            short *stage = reinterpret_cast<short *>(dm->hDense);
+            for (size_t c = 0; c < B; c++)
+                if (carry[c]) std::memcpy(stage + c * cc, dm->ch[c].outSymbols.data(), (carry[c] < dm->ch[c].outSymbols.size() ? carry[c] : dm->ch[c].outSymbols.size()) * sizeof(short));
+            LORAHIP_TRY(hipMemcpyAsync(dm->dCarry, stage, B * cc * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
+            LORAHIP_TRY(hipStreamSynchronize(ctx->stream));       // the pinned scratch is reused
+        }
+        loadCarry = anyCarryIn;
+        carry.assign(B, 0);
+        anyCarryIn = false;                           // as far as the host's assembly of packets is concerned
+    }
+    else
+    {
+        if (dm->hostCarryStale) syncMirrors(dm);      // (a deferred activate() then travels with the state upload: see syncMirrors)
+        if (anyCarryIn)
+            for (size_t c = 0; c < B; c++) if (carry[c] && dm->ch[c].outSymbols.size() < carry[c]) dm->ch[c].outSymbols.resize(carry[c], 0);
+        dm->devCarryValid = false;
+    }
     if (!dm->uniform)
     {
         for (size_t c = 0; c < B; c++) { hBase[c] = (long long)dm->ch[c].base; hLen[c] = (long long)dm->ch[c].len; }
@@ -640,7 +718,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.base = reinterpret_cast<const long long *>(d + L.oBase);
     a.len = reinterpret_cast<const long long *>(d + L.oLen);
     a.uniformLen = dm->uniform ? (long long)dm->uniSpc : -1;
-    a.flags = 1 | (activate ? 2 : 0);                 // first launch of the run: every channel starts at sample 0, call 0
+    a.flags = 1 | (activate ? 2 : 0) | (useDevCarry ? 4 : 0);   // first launch of the run: every channel starts at sample 0, call 0, behind its open packet's symbols
     a.state = reinterpret_cast<StreamState *>(d + L.oState);
     a.nCalls = reinterpret_cast<int *>(d + L.oN);
     a.nSym = reinterpret_cast<int *>(d + L.oNSym);
@@ -653,6 +731,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.fineB = ctx->fineGather ? nullptr : ctx->dFineB;
     a.nChannels = unsigned(B);
     a.cap = int(cap);
+    a.symStride = int(L.symStride);
     a.capPkt = int(capPkt);
     a.powerScale = ctx->powerScale;
     a.thresh = dm->thresh;
@@ -670,6 +749,8 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     bool lastPending = false;
     size_t pendPackets = 0, pendNSym = 0;
     int launches = 0;
+    if (loadCarry)
+        LORAHIP_TRY(launchCarryLoad(a.state, dm->dCarry, int(dm->carryCap), a.symOut, a.symStride, B, ctx->stream));
     while (true)
     {
         const Clock::time_point ta = Clock::now();
@@ -732,6 +813,14 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     }
     dm->devStateFresh = true;                         // the device holds what the pinned copy says; the mirrors lag (mirrorsStale)
     dm->posOnDevice = true;
+    if (useDevCarry && launches == 1)
+    {
+        // the packets the channels are inside now: the last symCount entries of their symbol rows, kept for the next run
+        if (anyOpen) LORAHIP_TRY(launchCarrySave(a.state, a.nSym, a.symOut, a.symStride, dm->dCarry, int(dm->carryCap), B, ctx->stream));
+        dm->devCarryValid = true;
+        dm->hostCarryStale = lastPending;             // a drain (traced runs) has brought the mirrors' outSymbols up to date already
+    }
+    else { dm->devCarryValid = false; dm->hostCarryStale = false; }      // a resumed run: its launches handed the symbols on through the mirrors
     PendingLaunch &P = pendingOf(dm);
     if (lastPending)
     {
@@ -958,6 +1047,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->devStateFresh = false; dm->mirrorsStale = false; dm->activatePending = false;
     dm->uniform = false; dm->uniSpc = 0; dm->geomApplied = true; dm->portCountsDirty = true; dm->posOnDevice = false;
     dm->lastLaunches = 0;
+    dm->dCarry = nullptr; dm->carryCap = 0; dm->devCarryValid = false; dm->hostCarryStale = false;
     dm->callsPerWindowQ8 = 288;                                 // 1.125 calls per N samples to begin with
     dm->ch.resize(n_channels);
     for (auto &k : dm->ch) { k.traceStart = 0; k.traceSymCount0 = 0; k.portFft = k.portDec = k.portRaw = 0; }
@@ -988,6 +1078,7 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->dIq) (void)hipFree(dm->dIq);
     if (dm->sDev) (void)hipFree(dm->sDev);
     if (dm->sHost) (void)hipHostFree(dm->sHost);
+    if (dm->dCarry) (void)hipFree(dm->dCarry);
     if (dm->dDense) (void)hipFree(dm->dDense);
     if (dm->hDense) (void)hipHostFree(dm->hDense);
     if (dm->dPort) (void)hipFree(dm->dPort);
@@ -1205,7 +1296,7 @@ int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const
             hipStream_t st = dm->ctx->stream;
             LORAHIP_TRY(hipMemcpyAsync(dm->dDense, hRow, L.B * sizeof(int), hipMemcpyHostToDevice, st));
             LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(dm->sDev + L.oPkt), reinterpret_cast<const int *>(dm->sDev + L.oNPkt),
-                                          reinterpret_cast<const short *>(dm->sDev + L.oSym), reinterpret_cast<const int *>(dm->dDense), L.B, int(L.cap),
+                                          reinterpret_cast<const short *>(dm->sDev + L.oSym), reinterpret_cast<const int *>(dm->dDense), L.B, int(L.symStride),
                                           int(L.capPkt), n, reinterpret_cast<long long *>(dm->dDense + nbRow), syms_dev, int(sym_stride), nsyms_dev,
                                           channel_dev, st));
             LORAHIP_TRY(hipStreamSynchronize(st));                          // the pinned scratch is reused by the next call
@@ -1246,8 +1337,8 @@ void lorahip_demod_clear_packets(lorahip_demod *dm)
     {
         // records still on the device: they can simply be dropped unless a channel is inside a packet -- the symbols it has
         // received so far open the first packet of the next run
-        if (P.anyOpen) (void)drainPending(dm);
-        else P.valid = false;
+        if (P.anyOpen && !dm->devCarryValid) (void)drainPending(dm);
+        else P.valid = false;                                   // (with the open packets kept on the device nothing is lost)
     }
     dm->packets.clear();
     dm->pktSyms.clear();
@@ -1272,6 +1363,13 @@ int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
     if (dm->mirrorsStale && dm->posOnDevice && dm->sHost) return int64_t(hostStates(const_cast<lorahip_demod *>(dm))[channel].pos);
     if (!dm->posOnDevice && dm->uniform && !dm->geomApplied) return 0;     // placement set, nothing run on it yet
     return int64_t(dm->ch[channel].pos);
+}
+
+int lorahip_demod_consumed_all(const lorahip_demod *dm, int64_t *out)
+{
+    if (dm == nullptr || out == nullptr) return LORAHIP_E_INVALID;
+    for (size_t c = 0; c < dm->B; c++) out[c] = lorahip_demod_consumed(dm, c);
+    return LORAHIP_OK;
 }
 
 int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)

@@ -20,9 +20,14 @@ struct StreamOut
     __device__ __forceinline__ void init(const StreamArgs &s, const unsigned channel)
     {
         out = s.calls ? s.calls + (size_t)channel * s.cap : nullptr;
-        symOut = s.symOut + (size_t)channel * s.cap;
+        symOut = s.symOut + (size_t)channel * s.symStride;
         pktOut = s.pktOut + (size_t)channel * s.capPkt;
         calls = nSym = nPkt = 0;
+    }
+    //! the packet the channel is inside continues behind the symbols it has already (flag bit 2; `st` with the launch's flags applied)
+    __device__ __forceinline__ void carryIn(const StreamArgs &s, const StreamState &st)
+    {
+        if ((s.flags & 4) && st.state == ST_DATASYMBOLS) nSym = st.symCount;
     }
 };
 

@@ -111,21 +111,24 @@ struct StreamArgs
     StreamState *state;         // [nChannels] in/out
     lorahip_work_result *calls; // [nChannels][cap] one record per work() call; nullptr unless tracing
     int *nCalls;                // [nChannels] work() calls made by this launch
-    short *symOut;              // [nChannels][cap] the DATASYMBOLS values of this launch, in order
-    int *nSym;                  // [nChannels]
+    short *symOut;              // [nChannels][symStride] the DATASYMBOLS values of this launch, in order; with flag bit 2 the symbols of the
+                                // packet the channel was inside when the launch began come first (carryLoad put them there)
+    int *nSym;                  // [nChannels] entries of the channel's symOut row that are valid after the launch (carried ones included)
     StreamPacket *pktOut;       // [nChannels][capPkt]
     int *nPkt;                  // [nChannels]
     int capPkt;
     const float2 *down, *fine, *twStage;
     const double2 *fineA, *fineB;   // split of the fine-tune table (lorahip_fine.h); nullptr: gather from `fine`
     unsigned nChannels;
-    int cap;
+    int cap;                    // work() calls per channel this launch may make
+    int symStride;              // entries per channel in symOut: cap + the longest carried packet
     float powerScale;
     float thresh;
     int sync;
     unsigned mtu;
     long long uniformLen;       // >= 0: channel c's stream is the uniformLen samples at c * uniformLen (base / len are not read)
-    int flags;                  // bit 0: first launch of a run -- every channel starts at sample 0, call 0; bit 1: activate() first
+    int flags;                  // bit 0: first launch of a run -- every channel starts at sample 0, call 0; bit 1: activate() first;
+                                // bit 2: a channel in DATASYMBOLS finds its packet's first symCount symbols at the head of its symOut row
     unsigned *near;             // [2] decisions float rounding could flip (lorahip_demod_near_threshold): squelch margins, fine-tune steps
 };
 
@@ -156,6 +159,10 @@ bool streamAvailable(int sf);
 hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchStreamWide(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchCompactRows(void *dst, const void *src, size_t rows, size_t srcPitchBytes, size_t rowBytes, hipStream_t stream);
+//! the symbols of the packets the channels are inside: carryLoad puts them at the head of the symOut rows before a run's first launch,
+//! carrySave takes the last symCount entries of every row afterwards (rows of carryCap entries; lorahip_stream.hip)
+hipError_t launchCarryLoad(const StreamState *state, const short *carry, int carryCap, short *symOut, int symStride, size_t nChannels, hipStream_t stream);
+hipError_t launchCarrySave(const StreamState *state, const int *nSym, const short *symOut, int symStride, short *carry, int carryCap, size_t nChannels, hipStream_t stream);
 hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, const int *rowStart, size_t nChannels, int cap, int capPkt,
                              size_t nPackets, long long *srcOff, unsigned short *symsOut, int stride, int *nsymsOut, int *channelOut, hipStream_t stream);
 hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *srcOff, const long long *dstOff, const int *len, size_t nSeg,

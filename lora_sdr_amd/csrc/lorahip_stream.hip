@@ -81,6 +81,7 @@ demodStream(const StreamArgs s)
     const long long len = !mine ? 0 : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]);
     StreamOut o;
     o.init(s, cc);
+    o.carryIn(s, st);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
     // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
@@ -418,6 +419,46 @@ __global__ void packCopy(const short *__restrict__ symOut, const long long *__re
     const int len = nsyms[p] < stride ? nsyms[p] : stride;
     const short *src = symOut + srcOff[p];
     for (int i = threadIdx.x; i < stride; i += blockDim.x) dst[p * stride + i] = i < len ? (unsigned short)src[i] : (unsigned short)0;
+}
+
+__global__ void carryLoad(const StreamState *__restrict__ state, const short *__restrict__ carry, const int carryCap, short *__restrict__ symOut,
+                          const int symStride, const unsigned nChannels)
+{
+    // one wavefront per channel: the open packets are a few hundred symbols at most
+    const unsigned c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= nChannels) return;
+    const StreamState st = state[c];
+    int k = st.state == ST_DATASYMBOLS ? st.symCount : 0;
+    if (k > carryCap) k = carryCap;
+    for (int i = threadIdx.x & 63; i < k; i += 64) symOut[(size_t)c * symStride + i] = carry[(size_t)c * carryCap + i];
+}
+
+__global__ void carrySave(const StreamState *__restrict__ state, const int *__restrict__ nSym, const short *__restrict__ symOut, const int symStride,
+                          short *__restrict__ carry, const int carryCap, const unsigned nChannels)
+{
+    const unsigned c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= nChannels) return;
+    const StreamState st = state[c];
+    int k = st.state == ST_DATASYMBOLS ? st.symCount : 0;       // the open packet's symbols are the last k of the row (LoRaDemod.cpp:279, :290)
+    const int n = nSym[c];
+    if (k > n) k = n;
+    if (k > carryCap) k = carryCap;
+    for (int i = threadIdx.x & 63; i < k; i += 64) carry[(size_t)c * carryCap + i] = symOut[(size_t)c * symStride + (n - k) + i];
+}
+
+hipError_t launchCarryLoad(const StreamState *state, const short *carry, const int carryCap, short *symOut, const int symStride, const size_t nChannels, hipStream_t stream)
+{
+    if (nChannels == 0) return hipSuccess;
+    hipLaunchKernelGGL(carryLoad, dim3(unsigned((nChannels + 3) / 4)), dim3(256), 0, stream, state, carry, carryCap, symOut, symStride, unsigned(nChannels));
+    return hipGetLastError();
+}
+
+hipError_t launchCarrySave(const StreamState *state, const int *nSym, const short *symOut, const int symStride, short *carry, const int carryCap, const size_t nChannels,
+                           hipStream_t stream)
+{
+    if (nChannels == 0) return hipSuccess;
+    hipLaunchKernelGGL(carrySave, dim3(unsigned((nChannels + 3) / 4)), dim3(256), 0, stream, state, nSym, symOut, symStride, carry, carryCap, unsigned(nChannels));
+    return hipGetLastError();
 }
 
 hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, const int *rowStart, const size_t nChannels,

@@ -702,6 +702,7 @@ demodStreamWide(const StreamArgs s)
     const long long len = s.uniformLen >= 0 ? s.uniformLen : s.len[c];
     StreamOut o;
     o.init(s, c);
+    o.carryIn(s, st);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect; every argument is workgroup-uniform
     // What a work() call consumes of the float outputs depends on its state (see demodStream, lorahip_stream.hip): without a

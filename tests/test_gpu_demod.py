@@ -967,9 +967,10 @@ def test_record_capacity_follows_what_a_receiver_needs(gpu, oracle, sf):
     assert h.last_launches() == 0 and h.kernel_ms() == 0.0
 
 
+@pytest.mark.parametrize("via", ["host queue", "device rows", "switching"])
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("sf", [7, 11])
-def test_running_receiver_on_segments_of_one_device_buffer(gpu, oracle, sf, mode):
+def test_running_receiver_on_segments_of_one_device_buffer(gpu, oracle, sf, mode, via):
     """lorahip_demod_run_device_segments: the receiver behind a channeliser. All channels live in one (channels, capacity) device
     buffer that fills chunk by chunk; every work() is given, per channel, the samples between what that channel has consumed so far
     and what has been written so far -- the remainder of the last call (up to 2N - 1 samples, different from channel to channel)
@@ -987,16 +988,33 @@ def test_running_receiver_on_segments_of_one_device_buffer(gpu, oracle, sf, mode
     buf = gpu.zeros((B, cap), dtype=gpu.complex64, device="cuda")
     d = L.LoRaDemod(sf, n_channels=B); d.set_mode(mode); d.setMTU(8)
     read = np.zeros(B, np.int64)
-    written, got, calls = 0, [[] for _ in range(B)], 0
+    written, got, calls, step = 0, [[] for _ in range(B)], 0, 0
     with pytest.raises(ValueError):
         d.work_segments(buf, np.arange(B) * cap, np.full(B, cap + 1))
     while written < cap:
         n = min(cap - written, int(rng.integers(N // 2, 6 * N)))
         buf[:, written:written + n] = gpu.from_numpy(host[:, written:written + n]).cuda()      # "the channeliser's next chunk"
         written += n
+        if via == "switching":
+            # a packet that is open across work() calls is handed on by whichever side holds its symbols: the device's copy (streaming
+            # mode), the mirrors (host-driven mode, traced runs, the host queue) -- every transition between them, mid-packet
+            step += 1
+            d.set_mode([1, 1, 2, 1, 2, 2, 1][step % 7] if mode == 1 else [2, 1, 1, 2][step % 4])
+            d.set_trace(step % 5 == 3)
+            if step % 6 == 4:
+                d.setMTU(8)                                     # a setter in between: nothing changes
         d.work_segments(buf, np.arange(B) * cap + read, written - read)
-        for ch, _, s in d.packets():
-            got[ch].append(s)
+        if via == "device rows" or (via == "switching" and step % 3):
+            # the decoder's input, packed on the device: in streaming mode the packets -- those that began in an earlier work() too --
+            # never visit the host
+            sy, ns, chn = d.packets_device()
+            sy, ns, chn = sy.cpu().numpy(), ns.cpu().numpy(), chn.cpu().numpy()
+            for i in range(len(ns)):
+                got[int(chn[i])].append(sy[i, :ns[i]].copy())
+        else:
+            for ch, _, s in d.packets():
+                got[ch].append(s)
+        assert d.consumed_all().tolist() == [d.consumed(c) for c in range(B)]
         for c in range(B):
             k = d.consumed(c)
             assert 0 <= k <= written - read[c]
