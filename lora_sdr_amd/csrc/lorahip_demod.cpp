@@ -624,7 +624,9 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     }
 
     StreamLayout L;
-    L.make(B, cap, capPkt, dm->tracing, dm->carryCap);
+    long rowPad = 0;                                  // measurement hook: entries per symbol row more (or, for streams without open packets, fewer) than cap + carryCap
+    if (const char *e = std::getenv("LORAHIP_SYM_PAD")) { const long v = std::atol(e); if (v >= -long(dm->carryCap) && v < (1 << 20)) rowPad = v; }
+    L.make(B, cap, capPkt, dm->tracing, size_t(long(dm->carryCap) + rowPad));
     if (L.total > dm->sBytes)
     {
         syncMirrors(dm);                             // the pinned copy of the state goes away with the buffers
