@@ -289,8 +289,10 @@ size_t lorahip_demod_num_packet_symbols(const lorahip_demod *d);
 int lorahip_demod_get_packets(const lorahip_demod *d, int32_t *channels, int64_t *rounds, int64_t *lens, size_t cap_packets,
                               int16_t *syms, size_t cap_syms);
 /* The queued packets in the batched decoder's input layout, on the device. Straight after a run of the streaming mode -- nothing
- * read back to the host yet, no packet begun in an earlier run -- the rows are packed on the device from the kernel's records
- * (no host round trip; rows ordered by channel, then time); otherwise from the host queue in lorahip_demod_get_packets' order: packet p's
+ * read back to the host yet -- the rows are packed on the device from the kernel's records (no host round trip; rows ordered by
+ * channel, then time). That includes packets begun in an earlier run: the symbols of a packet a channel is inside when a run ends
+ * stay on the device and the next run's records continue them (packets of at most 4096 symbols; longer ones are handed on through
+ * the host queue). Otherwise the rows come from the host queue in lorahip_demod_get_packets' order. Either way: packet p's
  * symbols at syms_dev + p*sym_stride (zero padded), its length in nsyms_dev[p] -- a packet longer than sym_stride keeps its true
  * length there and lorahip_decode_packets() reports -2 for it --, its channel in channel_dev[p] (nullable). *n_packets = number of
  * queued packets (also when cap_packets is too small: LORAHIP_E_INVALID then). Does not clear the queue. */

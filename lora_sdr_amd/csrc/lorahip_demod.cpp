@@ -1278,8 +1278,9 @@ int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const
     if (dm == nullptr) return LORAHIP_E_INVALID;
     {
         // The records of the last streaming launch are still on the device and nothing else is queued: pack them there
-        // (rows: channels ascending, time ascending inside a channel). A channel that entered the launch inside a packet
-        // needs symbols held on the host: those runs take the queue path below.
+        // (rows: channels ascending, time ascending inside a channel). A channel that entered the launch inside a packet found
+        // its symbols at the head of its row (carryLoad); only a run that had to take them from the mirrors (anyCarryIn: packets
+        // longer than the carry rows, launches of a resumed run) takes the queue path below.
         PendingLaunch &Q = pendingOf(dm);
         if (Q.valid && dm->packets.empty() && !Q.anyCarryIn)
         {
