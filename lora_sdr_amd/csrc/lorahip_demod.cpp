@@ -538,7 +538,8 @@ static int fetchCarry(lorahip_demod *dm)
     if (any && dm->dCarry && dm->devCarryValid)
     {
         const DeviceGuard guard(dm->ctx->device);
-        std::vector<short> rows(B * cap);
+        std::vector<short> rows;
+        try { rows.resize(B * cap); } catch (...) { setLastError("no memory for the open packets' symbols"); return LORAHIP_E_NOMEM; }   // nothing may cross the C ABI
         LORAHIP_TRY(hipMemcpyAsync(rows.data(), dm->dCarry, B * cap * sizeof(short), hipMemcpyDeviceToHost, dm->ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(dm->ctx->stream));
         for (size_t c = 0; c < B; c++)
@@ -818,6 +819,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     if (useDevCarry && launches == 1)
     {
         // the packets the channels are inside now: the last symCount entries of their symbol rows, kept for the next run
+        dm->devCarryValid = false;                    // (should the launch below fail: neither side holds them then, and the caller is told)
         if (anyOpen) LORAHIP_TRY(launchCarrySave(a.state, a.nSym, a.symOut, a.symStride, dm->dCarry, int(dm->carryCap), B, ctx->stream));
         dm->devCarryValid = true;
         dm->hostCarryStale = lastPending;             // a drain (traced runs) has brought the mirrors' outSymbols up to date already
