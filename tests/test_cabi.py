@@ -46,6 +46,11 @@ def test_version_and_errors():
     assert lib.lorahip_host_tables(13, None, None, None, None) == -1
     assert lib.lorahip_create(None, 0, 7) == -1
     assert lib.lorahip_detect_batch(None, None) == -1
+    # level 3 without an object: an error code or a neutral value, never a crash (no compute call without a GPU)
+    assert lib.lorahip_demod_run_device_segments(None, None, None, None, None) == -1
+    assert lib.lorahip_demod_consumed_all(None, None) == -1
+    assert lib.lorahip_demod_last_launches(None) == 0
+    assert lib.lorahip_demod_kernel_ms(None) == 0.0
 
 
 @pytest.mark.parametrize("sf", range(6, 13))
