@@ -783,8 +783,9 @@ def test_many_noisy_channels_against_the_reference_runner(gpu, oracle, sf, sigma
 @pytest.mark.parametrize("sf", [7, 10, 11])
 def test_streams_with_non_finite_and_extreme_samples(gpu, oracle, sf, mode):
     """A front end that hands over a NaN, an infinity, or a burst that overflows |X|^2. In the down-chirp, quarter-chirp and data
-    states the reference's block goes through it by the rules of IEEE arithmetic (NaN never wins the arg-max: index 0; snr NaN is
-    not < threshold: NOT squelched) and so must the device's frame machine -- call by call with a trace, and packet by packet without
+    states the reference's block (its -fcx-limited-range build: the textbook complex product, see
+    tests/test_oracle_vs_ref.py::test_non_finite_samples_where_the_reference_is_defined) goes through it by the rules of IEEE
+    arithmetic (NaN never wins the arg-max: index 0; snr NaN is not < threshold: NOT squelched) and so must the device's frame machine -- call by call with a trace, and packet by packet without
     one, where the squelch decision comes from the quick estimate and has to fall back to the exact chain on such windows.
     In FRAMESYNC the reference has NO defined behaviour for such a window: fIndex is NaN, `_finefreqError += fIndex`
     (LoRaDemod.cpp:221) makes the step NaN, `_fineTuneIndex -= NaN` (:162) converts NaN to int and the next table read is out

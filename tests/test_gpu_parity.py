@@ -451,8 +451,10 @@ def _bits_differ(a, b):
 def test_inputs_at_the_edges_of_fp32(gpu, oracle, sf):
     """Amplitudes whose squares are subnormal (1e-19 .. 3e-39) or overflow (1e17 .. 3e37), windows that hold a NaN sample and
     windows that hold an infinite one, with and without a moving fine-tune index. The kernels keep subnormals (no flush to zero)
-    and follow the reference's operation graph, so dechirped samples, FFT bins and the index are identical bit for bit, +-Inf /
-    NaN included, and power / powerAvg / fIndex are of the same class (finite, +Inf, -Inf, NaN) and within two float ulps.
+    and follow the reference's operation graph -- with the textbook complex product, i.e. the reference as built with
+    -fcx-limited-range once infinities appear (a plain -O2 build goes through libgcc's Annex G recovery there:
+    tests/test_oracle_vs_ref.py::test_non_finite_samples_where_the_reference_is_defined) -- so dechirped samples, FFT bins and the
+    index are identical bit for bit, +-Inf / NaN included, and power / powerAvg / fIndex are of the same class (finite, +Inf, -Inf, NaN) and within two float ulps.
     ONE deliberate difference, stated in DESIGN.md section 2: kissfft multiplies by the twiddle (1, 0) where the kernels skip the
     multiplication, and Inf * 0 = NaN -- in a window that holds an INFINITE sample some bin components are Inf here and NaN in
     the reference. Every bin of such a window is non-finite either way (a non-finite sample leaves the two dechirp
