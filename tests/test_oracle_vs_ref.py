@@ -313,3 +313,28 @@ def test_non_finite_samples_where_the_reference_is_defined(oracle, sf):
         n_lr += not same(a, b)
         n_o2 += not same(a, c)
     assert n_lr == 0 and n_o2 > 0
+
+
+@pytest.mark.parametrize("sf", [8, 11])
+def test_extreme_settings_identical(oracle, ref, sf):
+    """sync words 0x00 / 0xff / 0x0f / 0xf0, thresholds +-inf / NaN / +-1e30, an MTU beyond the stream, MTU 1: the settings
+    tests/test_gpu_demod.py::test_extreme_settings runs through the device, restatement against the verbatim block"""
+    rng = np.random.default_rng(77 + sf)
+    N = 1 << sf
+    inf = float("inf")
+    streams = {}
+    for sync in (0x00, 0xff, 0x0f, 0xf0, 0x12):
+        syms = rng.integers(0, N, 7).astype(np.uint16)
+        fr = oracle.mod_frame(sf, syms, sync=sync, padding=3)
+        st = np.concatenate([np.zeros(N // 2 + 9, np.complex64), fr, fr, np.zeros(2 * N, np.complex64)])
+        st = (st * np.exp(2j * np.pi * 0.21 / N * np.arange(st.size))).astype(np.complex64)
+        st += (0.02 * (rng.standard_normal(st.size) + 1j * rng.standard_normal(st.size))).astype(np.complex64)
+        streams[sync] = st
+    posted = 0
+    for sync, mtu, thresh in [(0x00, 64, 3.0), (0xff, 64, 3.0), (0x0f, 5, 3.0), (0xf0, 64, 3.0), (0x12, 5, -inf), (0x12, 64, inf), (0x12, 5, float("nan")),
+                              (0x12, 3, 1e30), (0x12, 6, -1e30), (0x12, 100000, 3.0), (0x00, 1, inf)]:
+        with np.errstate(all="ignore"):
+            A, B = oracle.demod_run(sf, streams[sync], sync=sync, mtu=mtu, thresh=thresh), ref.demod_run(sf, streams[sync], sync=sync, mtu=mtu, thresh=thresh)
+        _same_run(A, B, N)
+        posted += len(A["packets"])
+    assert posted >= 10
