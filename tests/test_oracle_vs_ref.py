@@ -338,3 +338,22 @@ def test_extreme_settings_identical(oracle, ref, sf):
         _same_run(A, B, N)
         posted += len(A["packets"])
     assert posted >= 10
+
+
+def test_leading_zero_windows_change_nothing(oracle, ref):
+    """The premise of tests/test_gpu_demod.py::test_streams_beyond_2_pow_31_samples: an all-zero window is not squelched (snr = -inf
+    - -inf = NaN), does not sync and consumes N samples (LoRaDemod.cpp:219 with value 0), so whole windows of zeros in front of a
+    stream shift the calls and change nothing else -- in the verbatim block as in the restatement."""
+    sf, N = 10, 1024
+    rng = np.random.default_rng(41)
+    syms = [rng.integers(0, N, 7).astype(np.uint16) for _ in range(2)]
+    st = np.concatenate([np.zeros(N // 3, np.complex64)] + [oracle.mod_frame(sf, s, padding=3) for s in syms] + [np.zeros(3 * N, np.complex64)])
+    st = (st * np.exp(2j * np.pi * 0.1 / N * np.arange(st.size))).astype(np.complex64)
+    st += (0.02 * (rng.standard_normal(st.size) + 1j * rng.standard_normal(st.size))).astype(np.complex64)
+    shifted = np.concatenate([np.zeros(5 * N, np.complex64), st])
+    with np.errstate(all="ignore"):
+        a, b = ref.demod_run(sf, st, mtu=7), ref.demod_run(sf, shifted, mtu=7)
+        _same_run(oracle.demod_run(sf, shifted, mtu=7), b, N)
+    assert b["consumed"].tolist() == [N] * 5 + a["consumed"].tolist()
+    assert len(a["packets"]) == len(b["packets"]) >= 2
+    assert all(np.array_equal(p[1], q[1]) for p, q in zip(a["packets"], b["packets"]))
