@@ -30,6 +30,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -134,6 +136,13 @@ class Env:
             return vals
         t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return tuple(float(v) for v in t)
+
+    def sum_over_ranks(self, *vals):
+        if self.dist is None:
+            return vals
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return tuple(float(v) for v in t)
 
     def close(self):
@@ -295,22 +304,48 @@ def cpu_baseline(sf, iq_host, samples_per_stream, n_streams, seconds, flags="-O2
             "sample": "%d ch x %d samples of the same SF%d IQ, %d work() calls in %.1f s" % (n_streams, samples_per_stream, sf, calls, dt)}
 
 
-def roofline_obj(sf, W, launch_s, traffic, L):
+def roofline_obj(sf, W, launch_s, traffic, L, traffic_src=True):
     alg = W * L.bytes_per_symbol(sf)
     ach = alg / launch_s / 1e9
     return {"bound": "hbm", "achieved": r4(ach), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r4(ach / HBM_PEAK_GBS), "traffic": traffic,
+            "traffic_source": traffic_table()[1] if traffic_src else None,
             "kernel": "lorahip detect (dechirp+FFT+detect fused)", "launch_us": r4(launch_s * 1e6), "algorithmic_bytes_per_launch": alg,
             "bytes_per_symbol": L.bytes_per_symbol(sf)}
 
 
+_traffic_cache = {}
+
+
+def traffic_table():
+    """profiles/traffic.json: HBM bytes per launch from separate rocprofv3 --pmc passes of `bench.py --sf S` (committed). The counters are
+    NOT collected in this run: the table is replayed, and only while the kernels it was measured on are the ones being timed --
+    its `sources_sha16` (lora_sdr_amd.build.kernel_digest() of the build that was profiled) must equal this tree's digest."""
+    if "t" not in _traffic_cache:
+        t, src = None, {"file": "profiles/traffic.json", "collected": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, replayed here"}
+        try:
+            from lora_sdr_amd.build import kernel_digest
+            t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            src["sources_sha16"], src["session"] = t.get("sources_sha16"), t.get("session")
+            src["this_tree_sha16"] = kernel_digest()          # over the files the detect kernels are compiled from
+            src["matches_this_tree"] = src["sources_sha16"] == src["this_tree_sha16"]
+            if not src["matches_this_tree"]:
+                t = None                                    # measured on other kernels: say so, report null
+        except Exception as e:
+            src["error"] = str(e)[:80]
+            t = None
+        _traffic_cache["t"], _traffic_cache["src"] = t, src
+    return _traffic_cache["t"], _traffic_cache["src"]
+
+
 def traffic_for(sf, a):
-    """HBM bytes per launch measured in a separate rocprofv3 --pmc pass of this command (profiles/traffic.json, committed)"""
+    """HBM bytes per launch: --traffic if given (a PMC pass of this very command), else the committed table while it is current"""
     if a.traffic is not None:
         return a.traffic
     if a.channels is not None or a.symbols is not None:
         return None
+    t, _ = traffic_table()
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["per_sf"][str(sf)].get("total_bytes")
+        return t["per_sf"][str(sf)].get("total_bytes") if t else None
     except Exception:
         return None
 
@@ -389,6 +424,50 @@ def level3_parity(L, sf, iq, host, nsyms, gpu_packets, data, gpu_not_ok, threads
     return out
 
 
+def pothos_block(sf, host, nsyms, calls_expected, packets_expected, chunk_windows=128):
+    """What a Pothos user gets from /lora/lora_demod_batch (lora_sdr_amd/pothos/LoRaDemodBatch.cpp, the product's reference-side binding,
+    compiled against the fake Pothos of oracle/stub and linked with liblorahip.so: oracle/_ref/libloradrop.so): the level-3 workload
+    handed over as ORDINARY HOST buffers that arrive 128 windows per channel at a time, a scheduler loop in C around work()
+    (oracle/dropin_driver.cpp::loradrop_batch_bench), packets and signals posted like the reference block posts them. Debug ports off
+    (the default) and on (the reference block's raw / dec / fft outputs, on a subset of the channels: they need 3 staging arrays per
+    channel). Beside it the verbatim CPU block on the same samples with as many host threads as the block keeps busy."""
+    from oracle.oracle import DropInBatch, Ref
+    if not (DropInBatch.available() and Ref.available()):
+        return {"error": "oracle/_ref/libloradrop.so did not travel"}
+    B, n = host.shape
+    chunk = chunk_windows << sf
+    up = int(os.environ.get("LORAHIP_UPLOAD_THREADS", "6" if (os.cpu_count() or 1) >= 16 else "3"))
+    out = {"what": "LoRaDemodBatch.cpp over host buffers, %d windows per channel per arrival" % chunk_windows, "host_threads": 1 + up}
+    for name, ports, nch in (("ports_off", False, B), ("ports_on", True, min(B, max(64, (1 << 21) >> sf)))):
+        blk = DropInBatch(sf, nch, max_windows=chunk_windows + 2)
+        blk.set("setMTU", nsyms)
+        if ports:
+            blk.set("setDebugPorts", 1)
+        sub = host if nch == B else np.ascontiguousarray(host[:nch])
+        blk.bench(sub, chunk)                                # first touch: contexts, staging, device buffers (every channel ends idle: the
+        best = None                                          # streams close with silence, so the timed passes start from a clean receiver)
+        for _ in range(2):
+            r = blk.bench(sub, chunk)
+            if best is None or r["seconds"] < best["seconds"]:
+                best = r
+        blk.close()
+        calls = calls_expected * nch // B                   # work() calls of the reference block on these channels (equal per channel set)
+        out[name] = {"channels": nch, "Msym_s": r4(calls / best["seconds"] / 1e6), "GB_s_in": r4(sub.size * 8 / best["seconds"] / 1e9),
+                     "block_work_calls": best["works"], "packets": best["packets"], "signals": best["signals"], "seconds": r4(best["seconds"])}
+        if not ports:
+            out[name]["packets_expected"] = packets_expected
+    # the CPU it replaces: the verbatim block, same samples, 1 thread and as many threads as the GPU block's host side uses
+    ref = Ref("-O2")
+    nst = min(B, 256)
+    sample = np.ascontiguousarray(host[:nst]).reshape(-1)
+    for thr in (1, 1 + up):
+        t0 = time.perf_counter()
+        c_ = ref.demod_bench(sf, sample, n, nst, thr, 1)
+        out["cpu_reference_%d_thread%s_Msym_s" % (thr, "" if thr == 1 else "s")] = r4(c_ / (time.perf_counter() - t0) / 1e6)
+    out["vs_cpu_same_threads"] = r4(out["ports_off"]["Msym_s"] / max(out["cpu_reference_%d_threads_Msym_s" % (1 + up)], 1e-9))
+    return out
+
+
 def section_level3(env, L, sf, threads=32):
     """B channels of the LoRaDemod block over whole frames through the streaming kernel (tools/bench_demod.py's workload)"""
     import numpy as np
@@ -405,6 +484,9 @@ def section_level3(env, L, sf, threads=32):
     near = d.near_threshold()
     ps, pn, pc = d.packets_device(clear=False)
     calls = d.work_calls()
+    # frac_kernel counts 8*2^SF + 14 per work() call; FRAMESYNC / QUARTERCHIRP calls advance by less than the
+    # window they read, so the same samples are counted by several calls. What the channels actually consumed, once:
+    unique_bytes = int(d.consumed_all().sum()) * 8 + 14 * calls
     ch_, rd_, ln_, sy_ = d.packets_arrays()
     pk = list(zip(ch_.tolist(), rd_.tolist(), np.split(sy_, np.cumsum(ln_)[:-1]) if ch_.size else []))
     n_dev = int(ps.shape[0])
@@ -435,33 +517,44 @@ def section_level3(env, L, sf, threads=32):
         if best is None or r_[0] < best[0]:
             best = r_
     best = (best[0], best[1], one_pass(to_host=True)[2])
-    # the RUNNING receiver: the same capture arrives in chunks of 128 windows; every work() is given, per channel, the samples it has not
-    # consumed yet (lorahip_demod_run_device_segments), packets -- those that span chunks too -- are packed on the device per chunk
+    # the RUNNING receiver: the same capture arrives in chunks of 128 (and of 8) windows. One call into the library per chunk
+    # (lorahip_demod_receive): the append run -- every channel continues at its own read position, which lives on the device --, the
+    # packets that completed (those that span chunks too) packed on the device, the queue cleared. No Python per channel.
     running = None
     try:
-        chunk, cap_ = 128 << sf, int(iq.shape[1])
-        row = np.arange(B, dtype=np.int64) * cap_
+        cap_ = int(iq.shape[1])
+        rows_ = d.receiver_rows(cap_packets=B * (frames + 1), stride=max(8, min(nsyms, 512)))
 
-        def running_pass():
+        def running_pass(chunk_windows):
+            chunk = chunk_windows << sf
             d.clear_packets()
+            d.rewind()
             d.activate()
-            read = np.zeros(B, np.int64)
-            w = n_pk_ = n_work = 0
-            c0 = d.work_calls()
+            w = n_pk_ = n_work = calls_ = 0
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             while w < cap_:
                 w = min(cap_, w + chunk)
-                d.work_segments(iq, row + read, w - read)
-                n_pk_ += int(d.packets_device()[1].numel())
-                read += d.consumed_all()
+                n_, k_ = d.receive(iq, w, rows_, async_=True)
+                n_pk_ += n_
+                calls_ += k_
                 n_work += 1
             torch.cuda.synchronize()
-            return time.perf_counter() - t0, d.work_calls() - c0, n_pk_, n_work
-        running_pass()                              # sizes the buffers of the chunked shape
-        rb = min((running_pass() for _ in range(3)), key=lambda r_: r_[0])
-        running = {"chunk_windows": 128, "work_per_capture": rb[3], "ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6),
-                   "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / HBM_PEAK_GBS), "work_calls": int(rb[1]), "packets": int(rb[2])}
+            return time.perf_counter() - t0, calls_, n_pk_, n_work
+        running = {}
+        for cw in (128, 8):
+            running_pass(cw)                        # sizes the buffers of the chunked shape
+            rb = min((running_pass(cw) for _ in range(3)), key=lambda r_: r_[0])
+            ent_ = {"chunk_windows": cw, "work_per_capture": rb[3], "ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6),
+                    "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / HBM_PEAK_GBS), "work_calls": int(rb[1]), "packets": int(rb[2])}
+            if cw == 128:
+                running = ent_
+                running["entry"] = "lorahip_demod_receive (C ABI): one call per chunk"
+                running["near_squelch"], running["near_step"] = d.near_threshold()     # of the last pass (activate() resets the counters)
+                running["same_calls_and_packets_as_one_shot"] = bool(rb[1] == calls and rb[2] == n_dev)
+            else:
+                running["chunk8"] = ent_
+        d.rewind()
     except Exception as e:                          # a measurement beside the contract line: report, do not fail the bench
         running = {"error": repr(e)}
     # the same streams handed over as ordinary HOST buffers, one per channel (what a Pothos port gives the block): gathered through
@@ -481,12 +574,19 @@ def section_level3(env, L, sf, threads=32):
            "frac_e2e": r4(calls * L.bytes_per_symbol(sf) / best[0] / 1e9 / HBM_PEAK_GBS), "e2e_host_ms": r4(best[2] * 1e3),
            "kernel_us": r4(best[1] * 1e3), "Msym_s_kernel": r4(calls / (best[1] / 1e3) / 1e6),
            "frac_kernel": r4(calls * L.bytes_per_symbol(sf) / (best[1] / 1e3) / 1e9 / HBM_PEAK_GBS),
+           "unique_stream_bytes": int(unique_bytes), "counted_bytes": int(calls * L.bytes_per_symbol(sf)),
+           "frac_unique": r4(unique_bytes / (best[1] / 1e3) / 1e9 / HBM_PEAK_GBS),
            "packets": n_pk, "packets_device": n_dev, "packets_expected": B * frames, "packets_ok": ok, "staggered_starts": True,
            "from_host_ms": r4(from_host * 1e3), "from_host_GB_s": r4(iq.numel() * 8 / from_host / 1e9), "from_host_Msym_s": r4(calls / from_host / 1e6)}
     res["near_squelch"], res["near_step"] = near                       # decisions within float rounding of their boundary (pass 0)
     res["running"] = running
     if env.rank == 0 and env.world == 1:
         res.update(level3_parity(L, sf, iq, host, nsyms, (ch_, rd_, ln_, sy_), data, n_pk - ok, threads))
+        if sf in (7, 10, 12):
+            try:
+                res["pothos_block"] = pothos_block(sf, host, nsyms, calls, n_pk)
+            except Exception as e:                  # beside the contract line: report, do not fail the bench
+                res["pothos_block"] = {"error": repr(e)[:160]}
     del host
     d.close()
     ctx.close()
@@ -527,7 +627,7 @@ def section_mixed(env, L, a, S=16, n_channels=16384, rccl_single=False):
     # this rank's channels behind the C-level scheduler (lorahip_mixed_*): buckets by SF, a stream per bucket, event join
     mixed = L.MixedDetector(sfs[mine], device=env.local)
     mixed.set_variant(a.variant)
-    parts, offsets, at = [], np.zeros(mine.size, np.int64), 0
+    parts, offsets, at, spans = [], np.zeros(mine.size, np.int64), 0, []
     for sf, first_row, n_ch in mixed.buckets:
         local = np.nonzero(sfs[mine] == sf)[0]                       # ascending: the order of the bucket's rows
         sym = sent_all[torch.from_numpy(mine[local]).to(env.dev)].to(torch.int16).reshape(-1).contiguous()
@@ -537,6 +637,7 @@ def section_mixed(env, L, a, S=16, n_channels=16384, rccl_single=False):
         torch.cuda.synchronize()
         gen.close()
         offsets[local] = at + np.arange(n_ch, dtype=np.int64) * (S << sf)
+        spans.append((sf, first_row, n_ch, at))
         at += n_ch * (S << sf)
     iq = torch.cat(parts) if parts else torch.zeros(2, dtype=torch.float32, device=env.dev)
     del parts
@@ -567,6 +668,24 @@ def section_mixed(env, L, a, S=16, n_channels=16384, rccl_single=False):
     # ---- end of run: the 2 B/symbol results to every rank (north_star: RCCL only as an embarrassingly parallel split) ----
     mixed.synchronize()
     local_sym = out["sym"]
+    # every window of this rank's channels against the CPU oracle, like every other section (the ranks check their own shards side by side)
+    try:
+        from oracle.oracle import Oracle
+        orc, bad, n_win, max_db = Oracle(), 0, 0, 0.0
+        thr = max(1, min(32, (os.cpu_count() or 1) // env.world))
+        for sf, first_row, n_ch, start in spans:
+            host = iq[start:start + n_ch * (S << sf)].cpu().numpy()
+            o = orc.detect_batch(sf, host, nthreads=thr)
+            rows = slice(first_row, first_row + n_ch)
+            bad += int((o["sym"] != out["sym"][rows].reshape(-1).cpu().numpy().view(np.uint16)).sum())
+            fin = np.isfinite(o["power"])
+            max_db = max(max_db, float(np.abs(out["power"][rows].reshape(-1).cpu().numpy() - o["power"])[fin].max()))
+            n_win += n_ch * S
+        bad_all, win_all = env.sum_over_ranks(bad, n_win)
+        (db_all,) = env.max_over_ranks(max_db)
+        res["oracle"] = {"windows": int(win_all), "index_mismatches": int(bad_all), "max_dB": r4(db_all)}
+    except Exception as e:                                           # pragma: no cover - the checker may not have travelled
+        res["oracle"] = {"error": str(e)[:100]}
     dist, made = env.dist, False
     try:
         if dist is None and not rccl_single:

@@ -62,7 +62,8 @@ extern "C" {
 
 const char *lorahip_strerror(int code);
 const char *lorahip_last_error(void);       /* thread-local text of the last LORAHIP_E_HIP */
-int lorahip_version(void);                  /* ABI version, currently 2 (1 -> 2: lorahip_work_result grew, level-3 ports and labels) */
+int lorahip_version(void);                  /* ABI version, currently 3 (1 -> 2: lorahip_work_result grew, level-3 ports and labels;
+                                               2 -> 3, additions only: level-3 signals, append runs / lorahip_demod_receive, lorahip_rx_*) */
 int lorahip_device_count(void);             /* number of usable gfx950 devices, 0 if none */
 int lorahip_selfcheck(void);                /* host-only: the kernels' compile-time LDS layouts are consistent; no device needed */
 
@@ -228,6 +229,27 @@ typedef struct lorahip_demod lorahip_demod;
 
 int lorahip_demod_create(lorahip_demod **d, int device, int sf, size_t n_channels); /* make(sf) LoRaDemod.cpp:119 */
 void lorahip_demod_destroy(lorahip_demod *d);
+/* One level-3 object whose channels each have their own SF, over several devices of the node: what n_channels calls of the
+ * reference's make(sf) with different sf give a flow graph (LoRaDemod.cpp:119-122), as ONE handle (BASELINE configs[3]: 16384
+ * channels, SF 7..12, 8 GPUs). lorahip_shard_plan assigns every channel a device (devices[] may repeat: two shards on one GPU); on
+ * each device the channels of one SF form a PART -- a plain single-SF object with its own context, HIP stream and host thread, so
+ * the parts of a device overlap on it and the devices run side by side; there is no data-path collective. Every lorahip_demod_*
+ * setter and accessor works on the handle with GLOBAL channel numbers (packets, signals, traces, labels, consumed); the packet
+ * queue lists the parts one after the other (device slot ascending, SF ascending inside one), each in its own order. Runs:
+ *   lorahip_demod_run                       one host buffer per channel (any SF mix, any number of devices)
+ *   lorahip_demod_run_device_segments       all channels' segments in ONE device buffer (objects on one device)
+ *   lorahip_demod_run_device_segments_multi iq_dev[n_devices]: channel c's segment lies in the buffer of ITS device slot
+ *                                           (lorahip_demod_part_of / lorahip_demod_part say which)
+ * Not offered on such a handle (LORAHIP_E_INVALID; use the part's own handle, lorahip_demod_part_handle): lorahip_demod_run_device,
+ * the append runs, lorahip_demod_packets_to_device (one decoder configuration per SF), lorahip_demod_set_stream when the object
+ * spans several devices; debug ports only for one SF and host buffers. lorahip_demod_kernel_ms / _last_launches report the maximum
+ * over the parts, lorahip_demod_work_calls / _near_threshold the sums. On a plain object the part accessors report one part. */
+int lorahip_demod_create_mixed(lorahip_demod **d, const int *devices, size_t n_devices, const int32_t *channel_sf, size_t n_channels);
+size_t lorahip_demod_num_channels(const lorahip_demod *d);
+size_t lorahip_demod_num_parts(const lorahip_demod *d);
+int lorahip_demod_part(const lorahip_demod *d, size_t i, int32_t *device, int32_t *sf, size_t *n_channels, int32_t *device_slot);
+int lorahip_demod_part_of(const lorahip_demod *d, int32_t *part_of_channel, int32_t *local_channel);   /* [n_channels] each, nullable */
+lorahip_demod *lorahip_demod_part_handle(const lorahip_demod *d, size_t i);                             /* borrowed */
 int lorahip_demod_set_sync(lorahip_demod *d, unsigned char sync);        /* setSync       :124 */
 int lorahip_demod_set_threshold(lorahip_demod *d, double thresh_dB);     /* setThreshold  :129 */
 int lorahip_demod_set_mtu(lorahip_demod *d, size_t mtu);                 /* setMTU        :134 */
@@ -279,6 +301,46 @@ int lorahip_demod_run_device(lorahip_demod *d, const float *iq_dev, size_t sampl
  * remainder together with the new samples -- nothing is copied, nothing is lost at the chunk boundaries. */
 int lorahip_demod_run_device_segments(lorahip_demod *d, const float *iq_dev, const int64_t *first_sample, const size_t *n_samples,
                                       int64_t *rounds);
+/* the same for an object that spans several devices (lorahip_demod_create_mixed): one buffer per entry of its device list */
+int lorahip_demod_run_device_segments_multi(lorahip_demod *d, const float *const *iq_dev, size_t n_devices, const int64_t *first_sample,
+                                            const size_t *n_samples, int64_t *rounds);
+
+/* The RUNNING receiver: channel c's stream is row c of a (n_channels, row_stride) device array of which the first n_valid samples
+ * are valid -- a capture, or the output array of a channeliser, that fills chunk by chunk. Each call is one work() of every channel
+ * over what has arrived: a channel continues at ITS OWN read position (work() leaves fewer than 2N samples of it unconsumed,
+ * LoRaDemod.cpp:148; the positions live on the device, nothing is uploaded per call), its frame machine, fine-tune state and any
+ * open packet carry over. n_valid must not shrink from call to call; lorahip_demod_rewind() -- or any other kind of run -- starts
+ * new streams at sample 0. After an append run lorahip_demod_consumed() is the channel's absolute read position in its row and the
+ * packets' `round` counts the channel's work() calls since the streams began. */
+int lorahip_demod_run_device_append(lorahip_demod *d, const float *iq_dev, size_t row_stride, size_t n_valid, int64_t *rounds);
+int lorahip_demod_rewind(lorahip_demod *d);
+/* One receiver step in ONE call: lorahip_demod_run_device_append, then the packets that completed -- those begun in earlier calls
+ * included -- packed ON THE DEVICE into the batched decoder's rows (as lorahip_demod_packets_to_device, rows numbered there too:
+ * no upload, no host copy of any symbol), then the queue cleared. *n_packets = packets delivered (LORAHIP_E_INVALID and the packets
+ * left queued if that exceeds cap_packets), *work_calls = LoRaDemod::work() calls made by this step, summed over the channels.
+ * With async = 1 the call returns without waiting for the packing kernels: the rows are valid in stream order on the object's
+ * launch stream (lorahip_demod_set_stream), which is where a decoder that follows would be queued. Signals kept by
+ * lorahip_demod_set_signals are dropped by this call (read them with the ordinary run + accessors instead). */
+typedef struct lorahip_packet_rows {
+    size_t struct_size;     /* = sizeof(lorahip_packet_rows) */
+    uint16_t *syms_dev; size_t sym_stride;      /* [cap_packets][sym_stride], zero padded */
+    int32_t *nsyms_dev;                          /* [cap_packets] */
+    int32_t *channel_dev;                        /* [cap_packets], nullable */
+    size_t cap_packets;
+    int32_t async;
+    int32_t reserved;
+} lorahip_packet_rows;
+int lorahip_demod_receive(lorahip_demod *d, const float *iq_dev, size_t row_stride, size_t n_valid, const lorahip_packet_rows *rows,
+                          size_t *n_packets, int64_t *work_calls);
+
+/* The block's signals "error" (int), "power" (float), "snr" (float), emitted once per packet at DOWNCHIRP1 (LoRaDemod.cpp:85-87,
+ * 267-269), WITHOUT a per-call trace: with enable = 1 the following runs keep one record per emission -- the kernels evaluate
+ * power / snr for that one call of a packet, nothing else changes -- queued like the packets (channels ascending, time ascending
+ * inside a channel after a streaming run) and cleared with them by lorahip_demod_clear_packets. `rounds` as for packets. Off by
+ * default. Values equal the traced run's sig_error / sig_power / sig_snr. */
+int lorahip_demod_set_signals(lorahip_demod *d, int enable);
+size_t lorahip_demod_num_signals(const lorahip_demod *d);
+int lorahip_demod_get_signals(const lorahip_demod *d, int32_t *channels, int64_t *rounds, int32_t *errors, float *powers, float *snrs, size_t cap);
 
 size_t lorahip_demod_num_packets(const lorahip_demod *d);
 /* packet i: channel, round index it was posted in, and length; symbols copied if out != NULL */

@@ -46,6 +46,12 @@ class DemodPorts(C.Structure):
                 ("host_buffers", C.c_int32), ("reserved", C.c_int32)]
 
 
+class PacketRows(C.Structure):
+    """struct lorahip_packet_rows"""
+    _fields_ = [("struct_size", C.c_size_t), ("syms_dev", C.c_void_p), ("sym_stride", C.c_size_t), ("nsyms_dev", C.c_void_p),
+                ("channel_dev", C.c_void_p), ("cap_packets", C.c_size_t), ("async_", C.c_int32), ("reserved", C.c_int32)]
+
+
 class WorkResult(C.Structure):
     """struct lorahip_work_result"""
     _fields_ = [("consumed", C.c_int64), ("state_before", C.c_int32), ("value", C.c_int32),
@@ -104,6 +110,19 @@ SIGNATURES = {
     "lorahip_detector_detect": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), _f32p, _f32p, _f32p, C.c_void_p]),
     "lorahip_demod_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_size_t]),
     "lorahip_demod_destroy": (None, [C.c_void_p]),
+    "lorahip_demod_create_mixed": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "lorahip_demod_num_channels": (C.c_size_t, [C.c_void_p]),
+    "lorahip_demod_num_parts": (C.c_size_t, [C.c_void_p]),
+    "lorahip_demod_part": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]),
+    "lorahip_demod_part_of": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lorahip_demod_part_handle": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "lorahip_demod_run_device_segments_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
+    "lorahip_demod_run_device_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int64)]),
+    "lorahip_demod_rewind": (C.c_int, [C.c_void_p]),
+    "lorahip_demod_receive": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(PacketRows), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
+    "lorahip_demod_set_signals": (C.c_int, [C.c_void_p, C.c_int]),
+    "lorahip_demod_num_signals": (C.c_size_t, [C.c_void_p]),
+    "lorahip_demod_get_signals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "lorahip_demod_set_sync": (C.c_int, [C.c_void_p, C.c_ubyte]),
     "lorahip_demod_set_threshold": (C.c_int, [C.c_void_p, C.c_double]),
     "lorahip_demod_set_mtu": (C.c_int, [C.c_void_p, C.c_size_t]),

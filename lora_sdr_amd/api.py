@@ -540,19 +540,43 @@ class LoRaDemod:
 
     STATES = ("FRAMESYNC", "DOWNCHIRP0", "DOWNCHIRP1", "QUARTERCHIRP", "DATASYMBOLS")
 
-    def __init__(self, sf=10, n_channels=1, device=0):
+    def __init__(self, sf=10, n_channels=1, device=0, channel_sf=None, devices=None):
+        """channel_sf (one SF per channel) and devices (a list of device indices) make the mixed-SF / multi-device form
+        (lorahip_demod_create_mixed): one handle, global channel numbers; sf / n_channels / device are ignored then"""
         self._lib = load()
         self._h = C.c_void_p()
-        check(self._lib.lorahip_demod_create(C.byref(self._h), int(device), int(sf), int(n_channels)),
-              "lorahip_demod_create")
-        self.sf, self.N, self.n_channels = int(sf), 1 << int(sf), int(n_channels)
-        self._device = int(device)
         self._port_bufs = dict(fft=None, dec=None, raw=None)
         self._mtu = 256                                                 # LoRaDemod.cpp:73
+        if channel_sf is None:
+            check(self._lib.lorahip_demod_create(C.byref(self._h), int(device), int(sf), int(n_channels)),
+                  "lorahip_demod_create")
+            self.sf, self.N, self.n_channels = int(sf), 1 << int(sf), int(n_channels)
+            self._device = int(device)
+            self.channel_sf, self.devices = None, [int(device)]
+            return
+        csf = np.ascontiguousarray(channel_sf, np.int32).reshape(-1)
+        dv = np.ascontiguousarray([0] if devices is None else devices, np.int32).reshape(-1)
+        check(self._lib.lorahip_demod_create_mixed(C.byref(self._h), dv.ctypes.data, dv.size, csf.ctypes.data, csf.size), "lorahip_demod_create_mixed")
+        self.channel_sf, self.devices, self.n_channels = csf.copy(), [int(x) for x in dv], int(csf.size)
+        self.sf = int(csf[0]) if (csf == csf[0]).all() else None
+        self.N = None if self.sf is None else 1 << self.sf
+        self._device = int(dv[0])
+        self.part_of = np.empty(csf.size, np.int32)
+        self.local_of = np.empty(csf.size, np.int32)
+        check(self._lib.lorahip_demod_part_of(self._h, self.part_of.ctypes.data, self.local_of.ctypes.data), "lorahip_demod_part_of")
+        self.parts = []                                                 # (device, sf, n_channels, device_slot)
+        for i in range(self._lib.lorahip_demod_num_parts(self._h)):
+            d_, s_, n_, k_ = C.c_int32(), C.c_int32(), C.c_size_t(), C.c_int32()
+            check(self._lib.lorahip_demod_part(self._h, i, C.byref(d_), C.byref(s_), C.byref(n_), C.byref(k_)), "lorahip_demod_part")
+            self.parts.append((d_.value, s_.value, n_.value, k_.value))
 
     @staticmethod
     def make(sf):
         return LoRaDemod(sf)
+
+    def device_slot_of(self):
+        """mixed form: for every channel the index into `devices` of the GPU that holds it"""
+        return np.array([self.parts[p][3] for p in self.part_of], np.int32)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -602,6 +626,81 @@ class LoRaDemod:
         finally:
             self._lib.lorahip_demod_reset_stream(self._h)
         return rounds.value
+
+    def work_segments_multi(self, bufs, first_sample, n_samples):
+        """lorahip_demod_run_device_segments_multi: bufs[s] is the complex64 device tensor on devices[s] that holds the segments of the
+        channels of device slot s (None for a slot without channels)"""
+        first = np.ascontiguousarray(first_sample, np.int64)
+        cnt = np.ascontiguousarray(n_samples, np.uint64)
+        if first.shape != (self.n_channels,) or cnt.shape != (self.n_channels,):
+            raise ValueError("first_sample and n_samples need one entry per channel")
+        import torch
+        for b in bufs:
+            if b is not None:
+                torch.cuda.synchronize(b.device)                    # the parts launch on private streams
+        ptrs = (C.c_void_p * len(bufs))(*[(b.data_ptr() if b is not None and b.numel() else None) for b in bufs])
+        rounds = C.c_int64()
+        check(self._lib.lorahip_demod_run_device_segments_multi(self._h, ptrs, len(bufs), first.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                                cnt.ctypes.data_as(C.POINTER(C.c_size_t)), C.byref(rounds)),
+              "lorahip_demod_run_device_segments_multi")
+        return rounds.value
+
+    def set_signals(self, on=True):
+        """keep the block's error / power / snr signals (LoRaDemod.cpp:267-269) without a per-call trace"""
+        check(self._lib.lorahip_demod_set_signals(self._h, int(bool(on))), "lorahip_demod_set_signals")
+
+    def signals(self):
+        """the queued signal emissions as arrays: channel, round, error, power, snr (cleared with the packets)"""
+        n = int(self._lib.lorahip_demod_num_signals(self._h))
+        ch, rd, er = np.empty(n, np.int32), np.empty(n, np.int64), np.empty(n, np.int32)
+        pw, sn = np.empty(n, np.float32), np.empty(n, np.float32)
+        check(self._lib.lorahip_demod_get_signals(self._h, ch.ctypes.data, rd.ctypes.data, er.ctypes.data, pw.ctypes.data, sn.ctypes.data, n),
+              "lorahip_demod_get_signals")
+        return ch, rd, er, pw, sn
+
+    def rewind(self):
+        check(self._lib.lorahip_demod_rewind(self._h), "lorahip_demod_rewind")
+
+    def work_append(self, buf, n_valid):
+        """lorahip_demod_run_device_append: buf is a (n_channels, capacity) complex64 device tensor of which the first n_valid columns are
+        valid; every channel continues at its own read position"""
+        import torch
+        if not _is_torch(buf) or buf.dim() != 2 or buf.shape[0] != self.n_channels or buf.dtype != torch.complex64 or not buf.is_contiguous():
+            raise ValueError("expected a contiguous (n_channels, capacity) complex64 device tensor")
+        rounds = C.c_int64()
+        check(self._lib.lorahip_demod_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)), "lorahip_demod_set_stream")
+        try:
+            check(self._lib.lorahip_demod_run_device_append(self._h, _dptr(buf), int(buf.shape[1]), int(n_valid), C.byref(rounds)), "lorahip_demod_run_device_append")
+        finally:
+            self._lib.lorahip_demod_reset_stream(self._h)
+        return rounds.value
+
+    def receiver_rows(self, cap_packets, stride=None):
+        """device tensors for receive(): (cap_packets, stride) int16 symbols, (cap_packets,) int32 lengths and channels"""
+        import torch
+        dev = torch.device("cuda", int(self._device))
+        if stride is None:
+            stride = max(8, min(self._mtu, 512))
+        return (torch.empty((int(cap_packets), int(stride)), dtype=torch.int16, device=dev), torch.empty(int(cap_packets), dtype=torch.int32, device=dev),
+                torch.empty(int(cap_packets), dtype=torch.int32, device=dev))
+
+    def receive(self, buf, n_valid, rows, async_=True):
+        """lorahip_demod_receive: one receiver step in one call into the library -- the append run, the completed packets packed into
+        `rows` (receiver_rows()) on the device, the queue cleared. Returns (n_packets, work_calls). Runs on torch's current stream; with
+        async_ the rows are valid in that stream's order."""
+        import torch
+        syms, nsyms, chan = rows
+        r = _lib.PacketRows()
+        r.struct_size = C.sizeof(_lib.PacketRows)
+        r.syms_dev, r.sym_stride, r.nsyms_dev, r.channel_dev = syms.data_ptr(), int(syms.shape[1]), nsyms.data_ptr(), chan.data_ptr()
+        r.cap_packets, r.async_ = int(syms.shape[0]), int(bool(async_))
+        n, calls = C.c_size_t(), C.c_int64()
+        check(self._lib.lorahip_demod_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)), "lorahip_demod_set_stream")
+        try:
+            check(self._lib.lorahip_demod_receive(self._h, _dptr(buf), int(buf.shape[1]), int(n_valid), C.byref(r), C.byref(n), C.byref(calls)), "lorahip_demod_receive")
+        finally:
+            self._lib.lorahip_demod_reset_stream(self._h)
+        return n.value, calls.value
 
     def work(self, streams):
         """Feed one complete input stream per channel and run work() until < 2N samples remain

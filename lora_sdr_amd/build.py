@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblorahip.so")
 SOURCES = ["lorahip_kernels.hip", "lorahip_fast.hip", "lorahip_wide.hip", "lorahip_stream.hip", "lorahip_codec.hip", "lorahip_chan.hip", "lorahip_api.cpp", "lorahip_tables.cpp",
-           "lorahip_demod.cpp", "lorahip_mixed.cpp", "lorahip_upload.cpp"]
+           "lorahip_demod.cpp", "lorahip_mixed.cpp", "lorahip_upload.cpp", "lorahip_rx.cpp"]
 HEADERS = ["lorahip_internal.h", "lorahip_device.h", "lorahip_fft.h", "lorahip_fastcore.h", "lorahip_framemachine.h", "lorahip_fine.h", os.path.join("..", "..", "include", "lorahip.h")]
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -30,6 +30,20 @@ def source_digest():
     import hashlib
     h = hashlib.sha256()
     for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+DETECT_KERNEL_FILES = ["lorahip_fast.hip", "lorahip_wide.hip", "lorahip_kernels.hip", "lorahip_fastcore.h", "lorahip_fft.h", "lorahip_device.h", "lorahip_fine.h"]
+
+
+def kernel_digest():
+    """sha256 over the files the batch detect kernels are compiled from: what a committed counter measurement (profiles/traffic.json)
+    is stamped with, so that bench.py replays it only while those kernels are the ones it times"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(DETECT_KERNEL_FILES):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

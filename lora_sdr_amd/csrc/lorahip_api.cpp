@@ -84,7 +84,7 @@ const char *lorahip_strerror(const int code)
 
 const char *lorahip_last_error(void) { return g_lastError.c_str(); }
 
-int lorahip_version(void) { return 2; }
+int lorahip_version(void) { return 3; }
 
 int lorahip_selfcheck(void)
 {

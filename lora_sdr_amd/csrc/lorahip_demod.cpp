@@ -35,6 +35,8 @@ struct Channel
     size_t symCount;
     std::vector<int16_t> outSymbols;
     size_t base, len, pos;  // stream placement in the device buffer, read position
+    int64_t callCount;      // work() calls since the stream began (a run that does not continue a stream starts it at 0)
+    size_t runStart;        // read position when the last run began (append runs continue; the port replay starts there)
     std::vector<lorahip_work_result> trace;
     size_t traceStart;      // first trace entry of the last run
     size_t traceSymCount0;  // _symCount when the trace began (labels "S<n>" continue a packet that was open then)
@@ -50,10 +52,20 @@ struct Packet
     size_t off, len;
 };
 
+//! one emission of the block's "error" / "power" / "snr" signals (LoRaDemod.cpp:267-269)
+struct Signal
+{
+    int32_t channel;
+    int64_t round;
+    int32_t error;
+    float power, snr;
+};
+
 } // namespace
 
 struct lorahip_demod
 {
+    lorahip::Composite *comp;        // non-null: the handle is a container of (device, SF) parts (lorahip_rx.cpp); nothing below is used then
     lorahip_ctx *ctx;
     size_t N, B;
     unsigned char sync;
@@ -64,6 +76,8 @@ struct lorahip_demod
     std::vector<Channel> ch;
     std::vector<Packet> packets;
     std::vector<int16_t> pktSyms;
+    bool wantSignals;                // keep a record per DOWNCHIRP1 call (lorahip_demod_set_signals)
+    std::vector<Signal> signals;
     // per-round staging (host pinned + device), sized for B windows
     char *h, *d;
     size_t stageBytes;
@@ -86,7 +100,13 @@ struct lorahip_demod
     bool devStateFresh;              // the device holds the current state: the next streaming run need not upload it
     bool mirrorsStale;               // ch[].state .. ch[].pos lag behind the pinned copy of the device state
     bool activatePending;            // activate() since the last run, not yet applied to the device state / the mirrors
-    bool uniform; size_t uniSpc;     // the streams of the current run are n_channels x uniSpc samples back to back (lorahip_demod_run_device)
+    bool uniform; size_t uniSpc;     // the streams of the current run are n_channels x uniSpc samples, uniStride apart (lorahip_demod_run_device[_append])
+    size_t uniStride;
+    bool append;                     // the current run continues every channel's stream where the last append run left it
+    bool appendFresh;                // ... unless nothing has been appended yet (create, rewind, any other kind of run in between)
+    size_t appendPrev;               // samples per channel the last append run was given
+    hipEvent_t evCarry;              // recorded behind carrySave: a later switch of the launch stream waits on it (cross-stream order of dCarry)
+    bool carryEvValid;
     bool geomApplied;                // ch[].base / len / pos hold the current run's placement
     bool posOnDevice;                // the pinned state copy's `pos` belongs to the CURRENT placement (a streaming run filled it; a new
                                      // lorahip_demod_run[_device] call invalidates it: its streams start at sample 0)
@@ -160,17 +180,23 @@ static int launchRound(lorahip_demod *dm, const float *iqDev, const size_t n)
 static void applyGeometry(lorahip_demod *dm)
 {
     if (dm->geomApplied) return;
-    for (size_t c = 0; c < dm->B; c++) { dm->ch[c].base = c * dm->uniSpc; dm->ch[c].len = dm->uniSpc; dm->ch[c].pos = 0; }
+    const bool cont = dm->append && !dm->appendFresh;           // an append run continues at the mirrors' read positions (synced by the caller)
+    for (size_t c = 0; c < dm->B; c++)
+    {
+        dm->ch[c].base = c * dm->uniStride; dm->ch[c].len = dm->uniSpc;
+        if (!cont) { dm->ch[c].pos = 0; dm->ch[c].callCount = 0; }
+    }
     dm->geomApplied = true;
 }
 
-static void syncMirrors(lorahip_demod *dm);
+static int syncMirrors(lorahip_demod *dm);
 
 static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     const size_t N = dm->N, B = dm->B;
-    syncMirrors(dm);
+    { const int rc = syncMirrors(dm); if (rc != LORAHIP_OK) return rc; }       // (a failed fetch of the open packets' symbols: nothing is invalidated)
     applyGeometry(dm);
+    if (!(dm->append && !dm->appendFresh)) for (auto &k : dm->ch) k.callCount = 0;
     dm->devStateFresh = false;                                  // the mirrors are about to change: the device copy goes stale
     dm->devCarryValid = false;                                  // ... and so do the open packets' symbols it holds (syncMirrors fetched them)
     const DeviceGuard guard(dm->ctx->device);
@@ -304,6 +330,12 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
                 k.freqError = (k.freqError + error) / 2;
                 r.signals = 1;
                 r.sig_error = k.freqError; r.sig_power = r.power; r.sig_snr = r.snr;
+                if (dm->wantSignals)
+                {
+                    Signal g;
+                    g.channel = int32_t(c); g.round = k.callCount; g.error = k.freqError; g.power = r.power; g.snr = r.snr;
+                    dm->signals.push_back(g);
+                }
             } break;
             case ST_QUARTERCHIRP:
             {
@@ -321,7 +353,7 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
                 {
                     Packet p;
                     p.channel = int32_t(c);
-                    p.round = rounds;
+                    p.round = k.callCount;                                       // = the lock-step round where every stream began with the run
                     p.off = dm->pktSyms.size();
                     p.len = k.symCount;
                     dm->pktSyms.insert(dm->pktSyms.end(), k.outSymbols.begin(), k.outSymbols.begin() + long(k.symCount));
@@ -335,6 +367,7 @@ static int runRounds(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
             k.prevValue = short(value);                                          // :326
             r.consumed = int64_t(total);
             k.pos += total;                                                      // consume(total)  :320
+            k.callCount++;
             dm->workCalls++;
             if (dm->tracing) k.trace.push_back(r);
         }
@@ -368,20 +401,21 @@ static int growDense(lorahip_demod *dm, const size_t bytes)
 struct StreamLayout
 {
     size_t B, cap, capPkt, symStride;
-    bool tracing;
-    size_t oBase, oLen, oState, oN, oNSym, oNPkt, oNear, oPkt, oSym, oCalls, total;
-    void make(const size_t B_, const size_t cap_, const size_t capPkt_, const bool tracing_, const size_t carryCap_ = 0)
+    bool tracing, signals;
+    size_t oBase, oLen, oState, oN, oNSym, oNPkt, oNSig, oNear, oPkt, oSym, oSig, oCalls, total;
+    void make(const size_t B_, const size_t cap_, const size_t capPkt_, const bool tracing_, const size_t carryCap_ = 0, const bool signals_ = false)
     {
-        B = B_; cap = cap_; capPkt = capPkt_; tracing = tracing_;
+        B = B_; cap = cap_; capPkt = capPkt_; tracing = tracing_; signals = signals_;
         symStride = cap_ + carryCap_;                    // a channel's symbol row: what the launch may add behind what it was handed
         size_t cur = 0;
         auto carve = [&cur](const size_t bytes) { const size_t o = cur; cur += align256(bytes); return o; };
         oBase = carve(B * sizeof(long long)); oLen = carve(B * sizeof(long long));
         oState = carve(B * sizeof(StreamState));
-        oN = carve(B * sizeof(int)); oNSym = carve(B * sizeof(int)); oNPkt = carve(B * sizeof(int));
+        oN = carve(B * sizeof(int)); oNSym = carve(B * sizeof(int)); oNPkt = carve(B * sizeof(int)); oNSig = carve(B * sizeof(int));
         oNear = carve(2 * sizeof(unsigned));
         oPkt = carve(B * capPkt * sizeof(StreamPacket));
         oSym = carve(B * symStride * sizeof(short));
+        oSig = carve(signals ? B * capPkt * sizeof(StreamSignal) : 0);
         oCalls = carve(tracing ? B * cap * sizeof(lorahip_work_result) : 0);
         total = cur;
     }
@@ -397,6 +431,7 @@ struct PendingLaunch
     size_t firstNewPacket;          // index in dm->packets of the first packet of the run this launch belongs to
     int64_t rounds;
     size_t packets, packetSyms;     // what draining will append
+    size_t signals;
     bool anyCarryIn, anyOpen;       // a channel entered the launch inside a packet / leaves it inside one
     double drainMs;                 // LORAHIP_DEMOD_TIMING
 };
@@ -443,30 +478,43 @@ static int drainLaunch(lorahip_demod *dm, const StreamLayout &L)
     std::vector<size_t> &carry = carryOf(dm);
     // only as many columns of the [channel][capacity] record arrays as the fullest channel used cross PCIe: the capacities are
     // worst-case bounds, several times what a run fills
-    size_t maxSym = 0, maxPkt = 0, maxCalls = 0;
+    const int *hNSig = reinterpret_cast<int *>(h + L.oNSig);
+    size_t maxSym = 0, maxPkt = 0, maxCalls = 0, maxSig = 0;
     for (size_t c = 0; c < B; c++)
     {
         if (size_t(hNSym[c]) > maxSym) maxSym = size_t(hNSym[c]);
         if (size_t(hNPkt[c]) > maxPkt) maxPkt = size_t(hNPkt[c]);
         if (size_t(hN[c]) > maxCalls) maxCalls = size_t(hN[c]);
+        if (L.signals && size_t(hNSig[c]) > maxSig) maxSig = size_t(hNSig[c]);
     }
     const size_t nbPkt = align256(B * maxPkt * sizeof(StreamPacket)), nbSym = align256(B * maxSym * sizeof(short));
     const size_t nbCalls = L.tracing ? align256(B * maxCalls * sizeof(lorahip_work_result)) : 0;
-    const size_t nbDense = nbPkt + nbSym + nbCalls;
+    const size_t nbSig = align256(B * maxSig * sizeof(StreamSignal));
+    const size_t nbDense = nbPkt + nbSym + nbCalls + nbSig;
     { const int grc = growDense(dm, nbDense); if (grc != LORAHIP_OK) return grc; }
     LORAHIP_TRY(launchCompactRows(dm->dDense, d + L.oPkt, B, L.capPkt * sizeof(StreamPacket), maxPkt * sizeof(StreamPacket), ctx->stream));
     LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt, d + L.oSym, B, L.symStride * sizeof(short), maxSym * sizeof(short), ctx->stream));
     if (L.tracing)
         LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt + nbSym, d + L.oCalls, B, L.cap * sizeof(lorahip_work_result),
                                       maxCalls * sizeof(lorahip_work_result), ctx->stream));
+    if (maxSig)
+        LORAHIP_TRY(launchCompactRows(dm->dDense + nbPkt + nbSym + nbCalls, d + L.oSig, B, L.capPkt * sizeof(StreamSignal), maxSig * sizeof(StreamSignal), ctx->stream));
     if (nbDense) LORAHIP_TRY(hipMemcpyAsync(dm->hDense, dm->dDense, nbDense, hipMemcpyDeviceToHost, ctx->stream));
     LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
     const StreamPacket *hPkt = reinterpret_cast<const StreamPacket *>(dm->hDense);
     const short *hSym = reinterpret_cast<const short *>(dm->hDense + nbPkt);
     const lorahip_work_result *hCalls = reinterpret_cast<const lorahip_work_result *>(dm->hDense + nbPkt + nbSym);
+    const StreamSignal *hSig = reinterpret_cast<const StreamSignal *>(dm->hDense + nbPkt + nbSym + nbCalls);
     for (size_t c = 0; c < B; c++)
     {
         Channel &k = dm->ch[c];
+        for (int j = 0; L.signals && j < hNSig[c]; j++)
+        {
+            const StreamSignal &q = hSig[c * maxSig + size_t(j)];
+            Signal g;
+            g.channel = int32_t(c); g.round = q.callIndex; g.error = q.error; g.power = q.power; g.snr = q.snr;
+            dm->signals.push_back(g);
+        }
         // symbols of this launch continue the packet the previous launches left open (k.outSymbols[0..carry[c]))
         const short *sy = hSym + c * maxSym;
         size_t p = 0;
@@ -556,7 +604,7 @@ static int fetchCarry(lorahip_demod *dm)
 }
 
 //! bring the Channel mirrors up to date with the device's state (its pinned copy): only the paths that read them pay for it
-static void syncMirrors(lorahip_demod *dm)
+static int syncMirrors(lorahip_demod *dm)
 {
     if (dm->mirrorsStale && dm->sHost)
     {
@@ -567,17 +615,20 @@ static void syncMirrors(lorahip_demod *dm)
             const StreamState &st = hs[c];
             k.state = st.state; k.downTable = st.downTable != 0; k.prevValue = short(st.prevValue); k.freqError = st.freqError;
             k.fineTuneIndex = st.fineTuneIndex; k.finefreqError = st.finefreqError; k.symCount = size_t(st.symCount);
-            if (dm->posOnDevice) k.pos = size_t(st.pos);
+            if (dm->posOnDevice) { k.pos = size_t(st.pos); k.callCount = st.callCount; }
         }
     }
     dm->mirrorsStale = false;
-    (void)fetchCarry(dm);                               // before a deferred activate() hides which channels were inside a packet: a failure leaves the flag set
+    // before a deferred activate() hides which channels were inside a packet. A failed copy leaves hostCarryStale set and the
+    // device's copy valid: the caller must not invalidate it (it returns the error instead)
+    { const int rc = fetchCarry(dm); if (rc != LORAHIP_OK) return rc; }
     if (dm->activatePending)
     {
         for (auto &k : dm->ch) { k.state = ST_FRAMESYNC; k.downTable = false; }     // activate() (:139-143), deferred
         dm->activatePending = false;
         dm->devStateFresh = false;                      // the device copy does not have it: the next streaming run uploads
     }
+    return LORAHIP_OK;
 }
 
 static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
@@ -592,11 +643,13 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     typedef std::chrono::steady_clock Clock;
     const Clock::time_point t0 = Clock::now();
     double tDev = 0, tAsm = 0;
-    size_t maxLen = dm->uniform ? dm->uniSpc : 0;
+    const bool cont = dm->append && !dm->appendFresh;           // the channels continue where the last append run left them
+    // an append run works through what is new since the last one plus what that one left (fewer than 2N samples per channel)
+    size_t maxLen = dm->uniform ? (cont && dm->appendPrev <= dm->uniSpc ? dm->uniSpc - dm->appendPrev + 2 * N : dm->uniSpc) : 0;
     if (!dm->uniform) for (size_t c = 0; c < B; c++) if (dm->ch[c].len - dm->ch[c].pos > maxLen) maxLen = dm->ch[c].len - dm->ch[c].pos;
     // work() calls per channel per launch: enough for a clean stream in one launch, bounded so that the
     // per-launch buffers stay moderate (the launch is resumable)
-    const size_t perCall = sizeof(short) + (dm->tracing ? sizeof(lorahip_work_result) : 0) + sizeof(StreamPacket) / 4 + 1;
+    const size_t perCall = sizeof(short) + (dm->tracing ? sizeof(lorahip_work_result) : 0) + sizeof(StreamPacket) / 4 + 1 + (dm->wantSignals ? sizeof(StreamSignal) / 4 : 0);
     // A call consumes N samples except around a frame's sync (N - value, N/4 + error/2: LoRaDemod.cpp:219, :278) -- a handful of short
     // calls per frame -- and in an unsquelched FRAMESYNC window that does not sync (N - value every call: a receiver idling on noise
     // above its threshold makes about two calls per N samples). A launch whose record buffers fill is resumed, but the records have
@@ -612,11 +665,12 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     const size_t capPkt = cap / 4 + 2;               // a packet costs at least 5 calls (3 sync, quarter, 1 symbol)
 
     // open packets on the device (dCarry): rows of mtu + 1 symbols; receivers with longer packets than this keep the host path
+    // (the carry rows and their share of the symbol rows stay inside the memory bound of the record buffers above)
     const size_t kCarryLimit = 4096;
-    bool useDevCarry = dm->mtu <= kCarryLimit;
+    bool useDevCarry = dm->mtu <= kCarryLimit && B * (dm->mtu + 1 < 64 ? 64 : dm->mtu + 1) * sizeof(short) <= (size_t(1) << 29);
     if (useDevCarry && dm->mtu + 1 > dm->carryCap)
     {
-        syncMirrors(dm);                             // what the device holds of open packets goes to the mirrors first
+        { const int rc = syncMirrors(dm); if (rc != LORAHIP_OK) return rc; }      // what the device holds of open packets goes to the mirrors first
         if (dm->dCarry) { (void)hipFree(dm->dCarry); dm->dCarry = nullptr; }
         dm->carryCap = 0; dm->devCarryValid = false;
         const size_t rows = dm->mtu + 1 < 64 ? 64 : dm->mtu + 1;
@@ -625,12 +679,15 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     }
 
     StreamLayout L;
-    long rowPad = 0;                                  // measurement hook: entries per symbol row more (or, for streams without open packets, fewer) than cap + carryCap
-    if (const char *e = std::getenv("LORAHIP_SYM_PAD")) { const long v = std::atol(e); if (v >= -long(dm->carryCap) && v < (1 << 20)) rowPad = v; }
-    L.make(B, cap, capPkt, dm->tracing, size_t(long(dm->carryCap) + rowPad));
+    long rowPad = 0;
+#ifdef LORAHIP_ALL_VARIANTS
+    // measurement hook of the profiling build only (tools/row_stride.sh): extra entries per symbol row; never fewer than cap + carryCap
+    if (const char *e = std::getenv("LORAHIP_SYM_PAD")) { const long v = std::atol(e); if (v >= 0 && v < (1 << 20)) rowPad = v; }
+#endif
+    L.make(B, cap, capPkt, dm->tracing, size_t(long(useDevCarry ? dm->carryCap : 0) + rowPad), dm->wantSignals);
     if (L.total > dm->sBytes)
     {
-        syncMirrors(dm);                             // the pinned copy of the state goes away with the buffers
+        { const int rc = syncMirrors(dm); if (rc != LORAHIP_OK) return rc; }      // the pinned copy of the state goes away with the buffers
         if (dm->sDev) { (void)hipFree(dm->sDev); dm->sDev = nullptr; }
         if (dm->sHost) { (void)hipHostFree(dm->sHost); dm->sHost = nullptr; }
         dm->sBytes = 0;
@@ -663,14 +720,15 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     }
     else
     {
-        syncMirrors(dm);
+        { const int rc = syncMirrors(dm); if (rc != LORAHIP_OK) return rc; }
         for (size_t c = 0; c < B; c++)
         {
             Channel &k = dm->ch[c];
             StreamState &st = hState[c];
             st.state = k.state; st.downTable = k.downTable ? 1 : 0; st.prevValue = k.prevValue; st.freqError = k.freqError;
-            st.fineTuneIndex = k.fineTuneIndex; st.finefreqError = k.finefreqError; st.symCount = int(k.symCount); st.callCount = 0;
-            st.pos = 0;
+            st.fineTuneIndex = k.fineTuneIndex; st.finefreqError = k.finefreqError; st.symCount = int(k.symCount);
+            st.callCount = cont ? int(k.callCount) : 0;
+            st.pos = cont ? (long long)k.pos : 0;
             if (k.outSymbols.size() < k.symCount) k.outSymbols.resize(k.symCount, 0);
             // symbols of a packet that is still being received when the run starts. _symCount itself is only reset at
             // QUARTERCHIRP (:279), so outside DATASYMBOLS it still holds the length of the LAST packet: nothing is carried then
@@ -705,7 +763,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     }
     else
     {
-        if (dm->hostCarryStale) syncMirrors(dm);      // (a deferred activate() then travels with the state upload: see syncMirrors)
+        if (dm->hostCarryStale) { const int rc = syncMirrors(dm); if (rc != LORAHIP_OK) return rc; }      // (a deferred activate() then travels with the state upload: see syncMirrors)
         if (anyCarryIn)
             for (size_t c = 0; c < B; c++) if (carry[c] && dm->ch[c].outSymbols.size() < carry[c]) dm->ch[c].outSymbols.resize(carry[c], 0);
         dm->devCarryValid = false;
@@ -721,13 +779,17 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.base = reinterpret_cast<const long long *>(d + L.oBase);
     a.len = reinterpret_cast<const long long *>(d + L.oLen);
     a.uniformLen = dm->uniform ? (long long)dm->uniSpc : -1;
-    a.flags = 1 | (activate ? 2 : 0) | (useDevCarry ? 4 : 0);   // first launch of the run: every channel starts at sample 0, call 0, behind its open packet's symbols
+    a.uniformStride = (long long)dm->uniStride;
+    // first launch of the run: every channel starts at sample 0, call 0 (unless the run continues the streams), behind its open packet's symbols
+    a.flags = (cont ? 0 : 1) | (activate ? 2 : 0) | (useDevCarry ? 4 : 0);
     a.state = reinterpret_cast<StreamState *>(d + L.oState);
     a.nCalls = reinterpret_cast<int *>(d + L.oN);
     a.nSym = reinterpret_cast<int *>(d + L.oNSym);
     a.nPkt = reinterpret_cast<int *>(d + L.oNPkt);
     a.pktOut = reinterpret_cast<StreamPacket *>(d + L.oPkt);
     a.symOut = reinterpret_cast<short *>(d + L.oSym);
+    a.sigOut = dm->wantSignals ? reinterpret_cast<StreamSignal *>(d + L.oSig) : nullptr;
+    a.nSig = reinterpret_cast<int *>(d + L.oNSig);
     a.calls = dm->tracing ? reinterpret_cast<lorahip_work_result *>(d + L.oCalls) : nullptr;
     a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
     a.fineA = ctx->fineGather ? nullptr : ctx->dFineA;
@@ -750,8 +812,10 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     dm->kernelMs = 0.0;
     if (dm->evK0 == nullptr) { LORAHIP_TRY(hipEventCreate(&dm->evK0)); LORAHIP_TRY(hipEventCreate(&dm->evK1)); }
     bool lastPending = false;
-    size_t pendPackets = 0, pendNSym = 0;
+    size_t pendPackets = 0, pendNSym = 0, pendSignals = 0;
+    const int *hNSig = reinterpret_cast<int *>(h + L.oNSig);
     int launches = 0;
+    size_t runCalls = 0;                              // calls of the fullest channel, launch by launch
     if (loadCarry)
         LORAHIP_TRY(launchCarryLoad(a.state, dm->dCarry, int(dm->carryCap), a.symOut, a.symStride, B, ctx->stream));
     while (true)
@@ -769,19 +833,23 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         const Clock::time_point tb = Clock::now();
         tDev += std::chrono::duration<double>(tb - ta).count();
         bool more = false;
-        pendPackets = pendNSym = 0;
+        pendPackets = pendNSym = pendSignals = 0;
         dm->nNearSquelch += reinterpret_cast<const unsigned *>(h + L.oNear)[0];
         dm->nNearStep += reinterpret_cast<const unsigned *>(h + L.oNear)[1];
         const int icap = int(cap), icapPkt = int(capPkt);
         int64_t calls = 0;
+        int fullest = 0;
         for (size_t c = 0; c < B; c++)
         {
             calls += hN[c];
+            if (hN[c] > fullest) fullest = hN[c];
             pendPackets += size_t(hNPkt[c]);
             pendNSym += size_t(hNSym[c]);
-            more = more || hN[c] == icap || hNPkt[c] == icapPkt;
+            if (dm->wantSignals) pendSignals += size_t(hNSig[c]);
+            more = more || hN[c] == icap || hNPkt[c] == icapPkt || (dm->wantSignals && hNSig[c] == icapPkt);
         }
         dm->workCalls += calls;
+        runCalls += size_t(fullest);
         launches++;
         // a launch that must be resumed hands its records over now (the next one reuses the buffers); so does a traced run (its
         // callers read the trace next). Otherwise the records wait on the device.
@@ -811,7 +879,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     if (launches > 1 && maxLen >= N)
     {
         // the run had to be resumed: size the record buffers of the runs to come for the fullest channel's rate of calls, a quarter on top
-        const size_t q8 = (size_t(rounds) * 256 / (maxLen / N)) * 5 / 4 + 16;
+        const size_t q8 = (runCalls * 256 / (maxLen / N)) * 5 / 4 + 16;
         if (q8 > dm->callsPerWindowQ8) dm->callsPerWindowQ8 = q8 > size_t(256) * 64 ? size_t(256) * 64 : q8;
     }
     dm->devStateFresh = true;                         // the device holds what the pinned copy says; the mirrors lag (mirrorsStale)
@@ -820,7 +888,14 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     {
         // the packets the channels are inside now: the last symCount entries of their symbol rows, kept for the next run
         dm->devCarryValid = false;                    // (should the launch below fail: neither side holds them then, and the caller is told)
-        if (anyOpen) LORAHIP_TRY(launchCarrySave(a.state, a.nSym, a.symOut, a.symStride, dm->dCarry, int(dm->carryCap), B, ctx->stream));
+        if (anyOpen)
+        {
+            LORAHIP_TRY(launchCarrySave(a.state, a.nSym, a.symOut, a.symStride, dm->dCarry, int(dm->carryCap), B, ctx->stream));
+            // carrySave is not followed by a synchronisation: whoever moves this object to another stream waits on this event there
+            if (dm->evCarry == nullptr) LORAHIP_TRY(hipEventCreateWithFlags(&dm->evCarry, hipEventDisableTiming));
+            LORAHIP_TRY(hipEventRecord(dm->evCarry, ctx->stream));
+            dm->carryEvValid = true;
+        }
         dm->devCarryValid = true;
         dm->hostCarryStale = lastPending;             // a drain (traced runs) has brought the mirrors' outSymbols up to date already
     }
@@ -834,11 +909,13 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         P.rounds = rounds;
         P.packets = pendPackets;
         P.packetSyms = carriedIn + pendNSym - openSyms;     // symbols of the packets completed by this launch
+        P.signals = pendSignals;
         P.anyCarryIn = anyCarryIn;
         P.anyOpen = anyOpen;
         P.drainMs = 0.0;
     }
     else orderNewPackets(dm, firstNewPacket, rounds);
+    if (dm->append) { dm->appendFresh = false; dm->appendPrev = dm->uniSpc; }
     if (roundsOut) *roundsOut = rounds;
     if (timing)
         std::fprintf(stderr, "lorahip demod run: setup+H2D %.3f ms%s, kernel+state D2H+sync %.3f ms, record drain %.3f ms%s, state scan %.3f ms\n",
@@ -881,7 +958,7 @@ static int fillPorts(lorahip_demod *dm, const float *iqDev)
             const lorahip_work_result &r = k.trace[i];
             const bool down = r.state_before == ST_DOWNCHIRP0 || r.state_before == ST_DOWNCHIRP1;   // _chirpTable == _downChirpTable
             const size_t w = wOff.size();
-            wOff.push_back(int64_t(k.base + decPos));             // the run starts at the head of the channel's stream: pos == produced
+            wOff.push_back(int64_t(k.base + k.runStart + decPos));  // from where the run began (the head of the stream unless it continues one)
             wSel.push_back(down ? LORAHIP_CHIRP_DOWN : LORAHIP_CHIRP_UP);
             wIdx.push_back(r.fine_idx_before);
             wErr.push_back(r.fine_err_before);
@@ -897,7 +974,7 @@ static int fillPorts(lorahip_demod *dm, const float *iqDev)
             {
                 // the sync check dechirped window 1 too (:189-206): it starts from the committed index and is part of what `dec` produces
                 const size_t w1 = wOff.size();
-                wOff.push_back(int64_t(k.base + decPos + N));
+                wOff.push_back(int64_t(k.base + k.runStart + decPos + N));
                 wSel.push_back(LORAHIP_CHIRP_UP);
                 wIdx.push_back(r.fine_idx_after);
                 wErr.push_back(r.fine_err_before);
@@ -908,7 +985,7 @@ static int fillPorts(lorahip_demod *dm, const float *iqDev)
             decPos += total;
         }
         k.portFft = frame; k.portDec = decPos; k.portRaw = decPos;
-        if (P.raw_dev && decPos) segRaw.push_back({ (long long)k.base, (long long)(c * P.raw_cap_samples), int(decPos <= P.raw_cap_samples ? decPos : P.raw_cap_samples) });
+        if (P.raw_dev && decPos) segRaw.push_back({ (long long)(k.base + k.runStart), (long long)(c * P.raw_cap_samples), int(decPos <= P.raw_cap_samples ? decPos : P.raw_cap_samples) });
     }
     hipStream_t st = ctx->stream;
     auto scatter = [&](float *dst, const float *src, const std::vector<Seg> &segs, const size_t first, const size_t last, const long long srcBias, char *scratch) -> int
@@ -1008,7 +1085,10 @@ static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     // the port replay reads the per-call trace; a trace the caller did not ask for lives for this run only (it must neither grow
     // without bound in a long-running receiver nor show up in lorahip_demod_get_trace / _trace_len / _get_labels)
     const bool internalTrace = dm->portsOn && !dm->userTracing;
-    if (internalTrace) { syncMirrors(dm); for (auto &k : dm->ch) { k.trace.clear(); k.traceSymCount0 = k.symCount; } }
+    const bool cont = dm->append && !dm->appendFresh;
+    if (internalTrace || (dm->portsOn && cont)) { const int rc = syncMirrors(dm); if (rc != LORAHIP_OK) return rc; }
+    if (internalTrace) for (auto &k : dm->ch) { k.trace.clear(); k.traceSymCount0 = k.symCount; }
+    if (dm->portsOn) for (auto &k : dm->ch) k.runStart = cont ? k.pos : 0;      // where the port replay starts reading
     dm->tracing = dm->userTracing || dm->portsOn;
     if (dm->tracing || dm->portCountsDirty)
     {
@@ -1032,6 +1112,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     *out = nullptr;
     lorahip_demod *dm = new (std::nothrow) lorahip_demod();
     if (dm == nullptr) return LORAHIP_E_NOMEM;
+    dm->comp = nullptr;
     dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
     dm->evK0 = nullptr; dm->evK1 = nullptr; dm->kernelMs = 0.0;
     dm->pending = new (std::nothrow) PendingLaunch();
@@ -1049,12 +1130,14 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->workCalls = 0;
     dm->nNearSquelch = dm->nNearStep = 0;
     dm->devStateFresh = false; dm->mirrorsStale = false; dm->activatePending = false;
-    dm->uniform = false; dm->uniSpc = 0; dm->geomApplied = true; dm->portCountsDirty = true; dm->posOnDevice = false;
+    dm->uniform = false; dm->uniSpc = 0; dm->uniStride = 0; dm->geomApplied = true; dm->portCountsDirty = true; dm->posOnDevice = false;
+    dm->append = false; dm->appendFresh = true; dm->appendPrev = 0; dm->evCarry = nullptr; dm->carryEvValid = false;
+    dm->wantSignals = false;
     dm->lastLaunches = 0;
     dm->dCarry = nullptr; dm->carryCap = 0; dm->devCarryValid = false; dm->hostCarryStale = false;
     dm->callsPerWindowQ8 = 288;                                 // 1.125 calls per N samples to begin with
     dm->ch.resize(n_channels);
-    for (auto &k : dm->ch) { k.traceStart = 0; k.traceSymCount0 = 0; k.portFft = k.portDec = k.portRaw = 0; }
+    for (auto &k : dm->ch) { k.traceStart = 0; k.traceSymCount0 = 0; k.portFft = k.portDec = k.portRaw = 0; k.callCount = 0; k.runStart = 0; }
     dm->stageBytes = carve(nullptr, n_channels).total;
     bool staged;
     {
@@ -1072,9 +1155,55 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     return LORAHIP_OK;
 }
 
+int lorahip_demod_create_mixed(lorahip_demod **out, const int *devices, const size_t n_devices, const int32_t *channel_sf, const size_t n_channels)
+{
+    if (out == nullptr) return LORAHIP_E_INVALID;
+    *out = nullptr;
+    Composite *k = nullptr;
+    const int rc = Composite::create(&k, devices, n_devices, channel_sf, n_channels);
+    if (rc != LORAHIP_OK) return rc;
+    lorahip_demod *dm = new (std::nothrow) lorahip_demod();         // value-initialised: every pointer null
+    if (dm == nullptr) { delete k; return LORAHIP_E_NOMEM; }
+    dm->comp = k;
+    dm->B = n_channels;
+    *out = dm;
+    return LORAHIP_OK;
+}
+
+size_t lorahip_demod_num_channels(const lorahip_demod *dm) { return dm ? dm->B : 0; }
+size_t lorahip_demod_num_parts(const lorahip_demod *dm) { return dm == nullptr ? 0 : (dm->comp ? dm->comp->numParts() : 1); }
+
+int lorahip_demod_part(const lorahip_demod *dm, const size_t i, int32_t *device, int32_t *sf, size_t *n_channels, int32_t *device_slot)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->partInfo(i, device, sf, n_channels, device_slot);
+    if (i != 0) return LORAHIP_E_INVALID;
+    if (device) *device = dm->ctx->device;
+    if (sf) *sf = dm->ctx->sf;
+    if (n_channels) *n_channels = dm->B;
+    if (device_slot) *device_slot = 0;
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_part_of(const lorahip_demod *dm, int32_t *part_of_channel, int32_t *local_channel)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->partOf(part_of_channel, local_channel);
+    for (size_t c = 0; c < dm->B; c++) { if (part_of_channel) part_of_channel[c] = 0; if (local_channel) local_channel[c] = int32_t(c); }
+    return LORAHIP_OK;
+}
+
+lorahip_demod *lorahip_demod_part_handle(const lorahip_demod *dm, const size_t i)
+{
+    if (dm == nullptr) return nullptr;
+    if (dm->comp) return dm->comp->part(i);
+    return i == 0 ? const_cast<lorahip_demod *>(dm) : nullptr;
+}
+
 void lorahip_demod_destroy(lorahip_demod *dm)
 {
     if (dm == nullptr) return;
+    if (dm->comp) { delete dm->comp; delete dm; return; }
     {
     const DeviceGuard guard(dm->ctx ? dm->ctx->device : 0);   // the caller's current device is restored on return
     if (dm->d) (void)hipFree(dm->d);
@@ -1091,6 +1220,7 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->ownRaw) (void)hipFree(dm->ownRaw);
     if (dm->evK0) (void)hipEventDestroy(dm->evK0);
     if (dm->evK1) (void)hipEventDestroy(dm->evK1);
+    if (dm->evCarry) (void)hipEventDestroy(dm->evCarry);
     }
     lorahip_destroy(dm->ctx);
     delete static_cast<PendingLaunch *>(dm->pending);
@@ -1100,6 +1230,7 @@ void lorahip_demod_destroy(lorahip_demod *dm)
 int lorahip_demod_set_sync(lorahip_demod *dm, const unsigned char sync)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->setSync(sync);
     dm->sync = sync;
     return LORAHIP_OK;
 }
@@ -1107,6 +1238,7 @@ int lorahip_demod_set_sync(lorahip_demod *dm, const unsigned char sync)
 int lorahip_demod_set_threshold(lorahip_demod *dm, const double thresh_dB)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->setThreshold(thresh_dB);
     dm->thresh = float(thresh_dB);
     return LORAHIP_OK;
 }
@@ -1114,6 +1246,7 @@ int lorahip_demod_set_threshold(lorahip_demod *dm, const double thresh_dB)
 int lorahip_demod_set_mtu(lorahip_demod *dm, const size_t mtu)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->setMtu(mtu);
     dm->mtu = mtu;
     return LORAHIP_OK;
 }
@@ -1121,36 +1254,58 @@ int lorahip_demod_set_mtu(lorahip_demod *dm, const size_t mtu)
 int lorahip_demod_set_mode(lorahip_demod *dm, const int mode)
 {
     if (dm == nullptr || mode < 0 || mode > 2) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->setMode(mode);
     dm->mode = mode;
+    return LORAHIP_OK;
+}
+
+//! a run leaves one kernel behind that nothing has waited for (carrySave, which writes dCarry from the symbol rows): work queued on
+//! the stream the object moves to -- carryLoad, the next streaming kernel, a copy of dCarry to the host -- is ordered behind it
+static int orderBehindCarry(lorahip_demod *dm)
+{
+    if (!dm->carryEvValid) return LORAHIP_OK;
+    const DeviceGuard guard(dm->ctx->device);
+    LORAHIP_TRY(hipStreamWaitEvent(dm->ctx->stream, dm->evCarry, 0));
     return LORAHIP_OK;
 }
 
 int lorahip_demod_set_stream(lorahip_demod *dm, void *hip_stream)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
-    return lorahip_set_stream(dm->ctx, hip_stream);
+    if (dm->comp) return dm->comp->setStream(hip_stream);
+    const int rc = lorahip_set_stream(dm->ctx, hip_stream);
+    return rc != LORAHIP_OK ? rc : orderBehindCarry(dm);
 }
 
 int lorahip_demod_reset_stream(lorahip_demod *dm)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
-    return lorahip_reset_stream(dm->ctx);
+    if (dm->comp) return dm->comp->resetStream();
+    const int rc = lorahip_reset_stream(dm->ctx);
+    return rc != LORAHIP_OK ? rc : orderBehindCarry(dm);
 }
 
 int lorahip_demod_set_fine_gather(lorahip_demod *dm, const int enable)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->setFineGather(enable);
     return lorahip_set_fine_gather(dm->ctx, enable);
 }
 
 int lorahip_demod_activate(lorahip_demod *dm)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->activate();
     // activate() resets only _state and _chirpTable (:139-143); everything else keeps the
     // constructor / zero state, or whatever the previous activation left. While the state lives on the device (streaming mode)
     // the reset travels with the next launch as a flag; the mirrors get it when they are next brought up to date.
     if (dm->devStateFresh) dm->activatePending = true;
-    else { syncMirrors(dm); for (auto &k : dm->ch) { k.state = ST_FRAMESYNC; k.downTable = false; } }
+    else
+    {
+        const int rc = syncMirrors(dm);
+        if (rc != LORAHIP_OK) return rc;
+        for (auto &k : dm->ch) { k.state = ST_FRAMESYNC; k.downTable = false; }
+    }
     dm->nNearSquelch = dm->nNearStep = 0;
     return LORAHIP_OK;
 }
@@ -1158,15 +1313,39 @@ int lorahip_demod_activate(lorahip_demod *dm)
 int lorahip_demod_run_device(lorahip_demod *dm, const float *iq_dev, const size_t samples_per_channel, int64_t *rounds)
 {
     if (dm == nullptr || iq_dev == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) { setLastError("lorahip_demod_run_device: an object made by lorahip_demod_create_mixed takes per-channel segments"); return LORAHIP_E_INVALID; }
     // n_channels streams of equal length back to back: the placement is two numbers, not 3 * n_channels (ch[].base / len / pos are
     // filled only for the paths that read them, applyGeometry)
-    dm->uniform = true; dm->uniSpc = samples_per_channel; dm->geomApplied = false; dm->posOnDevice = false;
+    dm->uniform = true; dm->uniSpc = dm->uniStride = samples_per_channel; dm->geomApplied = false; dm->posOnDevice = false;
+    dm->append = false; dm->appendFresh = true;
     return runAny(dm, iq_dev, rounds);
+}
+
+int lorahip_demod_run_device_append(lorahip_demod *dm, const float *iq_dev, const size_t row_stride, const size_t n_valid, int64_t *rounds)
+{
+    if (dm == nullptr || n_valid > row_stride || (n_valid && iq_dev == nullptr)) return LORAHIP_E_INVALID;
+    if (dm->comp) { setLastError("append runs are per part: lorahip_demod_part_handle"); return LORAHIP_E_INVALID; }
+    if (!dm->appendFresh && n_valid < dm->appendPrev) { setLastError("an append run was given fewer samples than the one before it (lorahip_demod_rewind starts a new stream)"); return LORAHIP_E_INVALID; }
+    // every channel's stream is the first n_valid samples of its row; a channel continues at its own read position (the device's
+    // copy of the state holds it: nothing is uploaded per run)
+    dm->uniform = true; dm->uniSpc = n_valid; dm->uniStride = row_stride; dm->geomApplied = false;
+    if (dm->appendFresh) dm->posOnDevice = false;
+    dm->append = true;
+    return runAny(dm, iq_dev, rounds);
+}
+
+int lorahip_demod_rewind(lorahip_demod *dm)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) { for (size_t i = 0; i < dm->comp->numParts(); i++) (void)lorahip_demod_rewind(dm->comp->part(i)); return LORAHIP_OK; }
+    dm->appendFresh = true; dm->appendPrev = 0;
+    return LORAHIP_OK;
 }
 
 int lorahip_demod_run_device_segments(lorahip_demod *dm, const float *iq_dev, const int64_t *first_sample, const size_t *n_samples, int64_t *rounds)
 {
     if (dm == nullptr || first_sample == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->runSegments(&iq_dev, 1, first_sample, n_samples, rounds);
     bool any = false;
     for (size_t c = 0; c < dm->B; c++)
     {
@@ -1176,11 +1355,12 @@ int lorahip_demod_run_device_segments(lorahip_demod *dm, const float *iq_dev, co
     if (any && iq_dev == nullptr) return LORAHIP_E_INVALID;
     const DeviceGuard guard(dm->ctx->device);
     dm->uniform = false; dm->geomApplied = true; dm->posOnDevice = false;
+    dm->append = false; dm->appendFresh = true;
     for (size_t c = 0; c < dm->B; c++)
     {
         dm->ch[c].base = size_t(first_sample[c]);
         dm->ch[c].len = n_samples[c];
-        dm->ch[c].pos = 0;
+        dm->ch[c].pos = 0; dm->ch[c].callCount = 0;
     }
     return runAny(dm, iq_dev, rounds);
 }
@@ -1188,22 +1368,32 @@ int lorahip_demod_run_device_segments(lorahip_demod *dm, const float *iq_dev, co
 int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size_t *n_samples, int64_t *rounds)
 {
     if (dm == nullptr || streams == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
-    const DeviceGuard guard(dm->ctx->device);
-    size_t total = 0;
-    dm->uniform = false; dm->geomApplied = true; dm->posOnDevice = false;
-    for (size_t c = 0; c < dm->B; c++)
+    if (dm->comp)
     {
-        if (n_samples[c] && streams[c] == nullptr) return LORAHIP_E_INVALID;
-        dm->ch[c].base = total;
-        dm->ch[c].len = n_samples[c];
-        dm->ch[c].pos = 0;
-        total += n_samples[c];
+        for (size_t c = 0; c < dm->B; c++) if (n_samples[c] && streams[c] == nullptr) return LORAHIP_E_INVALID;
+        return dm->comp->run(streams, n_samples, rounds);
     }
+    const DeviceGuard guard(dm->ctx->device);
+    // every argument is checked before anything of the object changes: a refused call leaves consumed() of the last run intact
+    for (size_t c = 0; c < dm->B; c++)
+        if ((n_samples[c] && streams[c] == nullptr) || n_samples[c] > (size_t(1) << 48)) return LORAHIP_E_INVALID;
+    size_t total = 0;
+    for (size_t c = 0; c < dm->B; c++) total += n_samples[c];
     if (total > dm->dIqSamples)
     {
         if (dm->dIq) { (void)hipFree(dm->dIq); dm->dIq = nullptr; dm->dIqSamples = 0; }
         LORAHIP_TRY(hipMalloc((void **)&dm->dIq, (total ? total : 1) * sizeof(cf32)));
         dm->dIqSamples = total;
+    }
+    dm->uniform = false; dm->geomApplied = true; dm->posOnDevice = false;
+    dm->append = false; dm->appendFresh = true;
+    total = 0;
+    for (size_t c = 0; c < dm->B; c++)
+    {
+        dm->ch[c].base = total;
+        dm->ch[c].len = n_samples[c];
+        dm->ch[c].pos = 0; dm->ch[c].callCount = 0;
+        total += n_samples[c];
     }
     {
         // the channels' buffers gathered into one device array back to back (base = running total): pinned double-buffered upload
@@ -1222,12 +1412,23 @@ int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size
 static int drained(const lorahip_demod *dm)
 {
     lorahip_demod *m = const_cast<lorahip_demod *>(dm);
+    if (m && m->comp) return LORAHIP_OK;                        // the parts drain their own
     return m ? drainPending(m) : LORAHIP_E_INVALID;
+}
+
+int lorahip_demod_run_device_segments_multi(lorahip_demod *dm, const float *const *iq_dev, const size_t n_devices, const int64_t *first_sample,
+                                            const size_t *n_samples, int64_t *rounds)
+{
+    if (dm == nullptr || iq_dev == nullptr || first_sample == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->runSegments(iq_dev, n_devices, first_sample, n_samples, rounds);
+    if (n_devices != 1) return LORAHIP_E_INVALID;
+    return lorahip_demod_run_device_segments(dm, iq_dev[0], first_sample, n_samples, rounds);
 }
 
 size_t lorahip_demod_num_packets(const lorahip_demod *dm)
 {
     if (dm == nullptr) return 0;
+    if (dm->comp) return dm->comp->numPackets();
     const PendingLaunch &P = pendingOf(const_cast<lorahip_demod *>(dm));
     return dm->packets.size() + (P.valid ? P.packets : 0);      // known from the per-channel counts: no drain needed
 }
@@ -1236,6 +1437,7 @@ int lorahip_demod_get_packet(const lorahip_demod *dm, const size_t i, int32_t *c
                              size_t *len, int16_t *out, const size_t cap)
 {
     { const int rc = drained(dm); if (rc != LORAHIP_OK) return rc; }
+    if (dm->comp) return dm->comp->getPacket(i, channel, round, len, out, cap);
     if (dm == nullptr || i >= dm->packets.size()) return LORAHIP_E_INVALID;
     const Packet &p = dm->packets[i];
     if (channel) *channel = p.channel;
@@ -1252,6 +1454,7 @@ int lorahip_demod_get_packet(const lorahip_demod *dm, const size_t i, int32_t *c
 size_t lorahip_demod_num_packet_symbols(const lorahip_demod *dm)
 {
     if (dm == nullptr) return 0;
+    if (dm->comp) return dm->comp->numPacketSymbols();
     const PendingLaunch &P = pendingOf(const_cast<lorahip_demod *>(dm));
     return dm->pktSyms.size() + (P.valid ? P.packetSyms : 0);
 }
@@ -1260,6 +1463,7 @@ int lorahip_demod_get_packets(const lorahip_demod *dm, int32_t *channels, int64_
                               int16_t *syms, const size_t cap_syms)
 {
     { const int rc = drained(dm); if (rc != LORAHIP_OK) return rc; }
+    if (dm->comp) return dm->comp->getPackets(channels, rounds, lens, cap_packets, syms, cap_syms);
     if (dm == nullptr || cap_packets < dm->packets.size() || cap_syms < dm->pktSyms.size()) return LORAHIP_E_INVALID;
     size_t o = 0;
     for (size_t i = 0; i < dm->packets.size(); i++)
@@ -1274,10 +1478,11 @@ int lorahip_demod_get_packets(const lorahip_demod *dm, int32_t *channels, int64_
     return LORAHIP_OK;
 }
 
-int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const size_t sym_stride, int32_t *nsyms_dev, int32_t *channel_dev,
-                                    const size_t cap_packets, size_t *n_packets)
+static int packetsToDevice(lorahip_demod *dm, uint16_t *syms_dev, const size_t sym_stride, int32_t *nsyms_dev, int32_t *channel_dev,
+                           const size_t cap_packets, size_t *n_packets, const bool sync)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) { setLastError("packets on the device are per part (one decoder per SF): lorahip_demod_part_handle"); return LORAHIP_E_INVALID; }
     {
         // The records of the last streaming launch are still on the device and nothing else is queued: pack them there
         // (rows: channels ascending, time ascending inside a channel). A channel that entered the launch inside a packet found
@@ -1292,19 +1497,16 @@ int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const
             if (syms_dev == nullptr || nsyms_dev == nullptr || sym_stride == 0 || sym_stride > 0x7fffffffu || cap_packets < n) return LORAHIP_E_INVALID;
             const DeviceGuard guard(dm->ctx->device);
             const StreamLayout &L = Q.lay;
-            const int *hNPkt = reinterpret_cast<const int *>(dm->sHost + L.oNPkt);
             const size_t nbRow = align256(L.B * sizeof(int));
             { const int grc = growDense(dm, nbRow + n * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
-            int *hRow = reinterpret_cast<int *>(dm->hDense);
-            int acc = 0;
-            for (size_t c = 0; c < L.B; c++) { hRow[c] = acc; acc += hNPkt[c]; }
             hipStream_t st = dm->ctx->stream;
-            LORAHIP_TRY(hipMemcpyAsync(dm->dDense, hRow, L.B * sizeof(int), hipMemcpyHostToDevice, st));
+            // the rows are numbered on the device (scanCounts: exclusive prefix sum of the per-channel packet counts): nothing is
+            // uploaded, and nothing on the host is reused, so the caller decides whether to wait
             LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(dm->sDev + L.oPkt), reinterpret_cast<const int *>(dm->sDev + L.oNPkt),
-                                          reinterpret_cast<const short *>(dm->sDev + L.oSym), reinterpret_cast<const int *>(dm->dDense), L.B, int(L.symStride),
+                                          reinterpret_cast<const short *>(dm->sDev + L.oSym), reinterpret_cast<int *>(dm->dDense), L.B, int(L.symStride),
                                           int(L.capPkt), n, reinterpret_cast<long long *>(dm->dDense + nbRow), syms_dev, int(sym_stride), nsyms_dev,
                                           channel_dev, st));
-            LORAHIP_TRY(hipStreamSynchronize(st));                          // the pinned scratch is reused by the next call
+            if (sync) LORAHIP_TRY(hipStreamSynchronize(st));
             return LORAHIP_OK;
         }
     }
@@ -1334,9 +1536,66 @@ int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const
     return LORAHIP_OK;
 }
 
+int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const size_t sym_stride, int32_t *nsyms_dev, int32_t *channel_dev,
+                                    const size_t cap_packets, size_t *n_packets)
+{
+    return packetsToDevice(dm, syms_dev, sym_stride, nsyms_dev, channel_dev, cap_packets, n_packets, true);
+}
+
+int lorahip_demod_receive(lorahip_demod *dm, const float *iq_dev, const size_t row_stride, const size_t n_valid, const lorahip_packet_rows *rows,
+                          size_t *n_packets, int64_t *work_calls)
+{
+    if (dm == nullptr || rows == nullptr || rows->struct_size != sizeof(lorahip_packet_rows)) return LORAHIP_E_INVALID;
+    if (n_packets) *n_packets = 0;
+    const int64_t calls0 = dm->workCalls;
+    int rc = lorahip_demod_run_device_append(dm, iq_dev, row_stride, n_valid, nullptr);
+    if (rc != LORAHIP_OK) return rc;
+    if (work_calls) *work_calls = dm->workCalls - calls0;
+    size_t n = 0;
+    rc = packetsToDevice(dm, rows->syms_dev, rows->sym_stride, rows->nsyms_dev, rows->channel_dev, rows->cap_packets, &n, rows->async == 0);
+    if (n_packets) *n_packets = n;
+    if (rc != LORAHIP_OK) return rc;                                    // (the packets stay queued: a caller with too few rows can fetch them)
+    lorahip_demod_clear_packets(dm);
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_set_signals(lorahip_demod *dm, const int enable)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->setSignals(enable);
+    dm->wantSignals = enable != 0;
+    return LORAHIP_OK;
+}
+
+size_t lorahip_demod_num_signals(const lorahip_demod *dm)
+{
+    if (dm == nullptr) return 0;
+    if (dm->comp) return dm->comp->numSignals();
+    const PendingLaunch &P = pendingOf(const_cast<lorahip_demod *>(dm));
+    return dm->signals.size() + (P.valid ? P.signals : 0);
+}
+
+int lorahip_demod_get_signals(const lorahip_demod *dm, int32_t *channels, int64_t *rounds, int32_t *errors, float *powers, float *snrs, const size_t cap)
+{
+    { const int rc = drained(dm); if (rc != LORAHIP_OK) return rc; }
+    if (dm->comp) return dm->comp->getSignals(channels, rounds, errors, powers, snrs, cap);
+    if (dm == nullptr || cap < dm->signals.size()) return LORAHIP_E_INVALID;
+    for (size_t i = 0; i < dm->signals.size(); i++)
+    {
+        const Signal &g = dm->signals[i];
+        if (channels) channels[i] = g.channel;
+        if (rounds) rounds[i] = g.round;
+        if (errors) errors[i] = g.error;
+        if (powers) powers[i] = g.power;
+        if (snrs) snrs[i] = g.snr;
+    }
+    return LORAHIP_OK;
+}
+
 void lorahip_demod_clear_packets(lorahip_demod *dm)
 {
     if (dm == nullptr) return;
+    if (dm->comp) { dm->comp->clearPackets(); return; }
     PendingLaunch &P = pendingOf(dm);
     if (P.valid)
     {
@@ -1347,16 +1606,18 @@ void lorahip_demod_clear_packets(lorahip_demod *dm)
     }
     dm->packets.clear();
     dm->pktSyms.clear();
+    dm->signals.clear();
 }
 
-int64_t lorahip_demod_work_calls(const lorahip_demod *dm) { return dm ? dm->workCalls : 0; }
+int64_t lorahip_demod_work_calls(const lorahip_demod *dm) { return dm ? (dm->comp ? dm->comp->workCalls() : dm->workCalls) : 0; }
 
-double lorahip_demod_kernel_ms(const lorahip_demod *dm) { return dm ? dm->kernelMs : 0.0; }
-int lorahip_demod_last_launches(const lorahip_demod *dm) { return dm ? dm->lastLaunches : 0; }
+double lorahip_demod_kernel_ms(const lorahip_demod *dm) { return dm ? (dm->comp ? dm->comp->kernelMs() : dm->kernelMs) : 0.0; }
+int lorahip_demod_last_launches(const lorahip_demod *dm) { return dm ? (dm->comp ? dm->comp->lastLaunches() : dm->lastLaunches) : 0; }
 
 int lorahip_demod_near_threshold(const lorahip_demod *dm, int64_t *near_squelch, int64_t *near_step)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->nearThreshold(near_squelch, near_step);
     if (near_squelch) *near_squelch = dm->nNearSquelch;
     if (near_step) *near_step = dm->nNearStep;
     return LORAHIP_OK;
@@ -1365,6 +1626,7 @@ int lorahip_demod_near_threshold(const lorahip_demod *dm, int64_t *near_squelch,
 int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
 {
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->consumed(channel);
     if (dm->mirrorsStale && dm->posOnDevice && dm->sHost) return int64_t(hostStates(const_cast<lorahip_demod *>(dm))[channel].pos);
     if (!dm->posOnDevice && dm->uniform && !dm->geomApplied) return 0;     // placement set, nothing run on it yet
     return int64_t(dm->ch[channel].pos);
@@ -1373,6 +1635,7 @@ int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
 int lorahip_demod_consumed_all(const lorahip_demod *dm, int64_t *out)
 {
     if (dm == nullptr || out == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->consumedAll(out);
     for (size_t c = 0; c < dm->B; c++) out[c] = lorahip_demod_consumed(dm, c);
     return LORAHIP_OK;
 }
@@ -1380,6 +1643,7 @@ int lorahip_demod_consumed_all(const lorahip_demod *dm, int64_t *out)
 int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->setTrace(enable);
     const bool was = dm->tracing;
     syncMirrors(dm);                                            // traceSymCount0 is read from the mirrors
     dm->userTracing = enable != 0;
@@ -1393,12 +1657,14 @@ size_t lorahip_demod_trace_len(const lorahip_demod *dm, const size_t channel)
 {
     if (drained(dm) != LORAHIP_OK) return 0;                    // lorahip_last_error() says why
     if (dm == nullptr || channel >= dm->B) return 0;
+    if (dm->comp) return dm->comp->traceLen(channel);
     return dm->ch[channel].trace.size();
 }
 
 int lorahip_demod_set_ports(lorahip_demod *dm, const lorahip_demod_ports *p)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->setPorts(p);
     const DeviceGuard guard(dm->ctx->device);
     if (dm->ownFft) { (void)hipFree(dm->ownFft); dm->ownFft = nullptr; }
     if (dm->ownDec) { (void)hipFree(dm->ownDec); dm->ownDec = nullptr; }
@@ -1430,6 +1696,7 @@ int lorahip_demod_set_ports(lorahip_demod *dm, const lorahip_demod_ports *p)
 int lorahip_demod_port_counts(const lorahip_demod *dm, const size_t channel, size_t *fft_frames, size_t *dec_samples, size_t *raw_samples)
 {
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->portCounts(channel, fft_frames, dec_samples, raw_samples);
     const Channel &k = dm->ch[channel];
     if (fft_frames) *fft_frames = k.portFft;
     if (dec_samples) *dec_samples = k.portDec;
@@ -1462,6 +1729,7 @@ int lorahip_demod_get_labels(const lorahip_demod *dm, const size_t channel, char
 {
     { const int rc = drained(dm); if (rc != LORAHIP_OK) return rc; }
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->getLabels(channel, buf, cap, n_calls, bytes);
     const auto &t = dm->ch[channel].trace;
     // _symCount is only reset at QUARTERCHIRP (:279): a trace that starts inside a packet continues the count the channel held then
     size_t symCount = dm->ch[channel].traceSymCount0;
@@ -1481,6 +1749,7 @@ int lorahip_demod_get_trace(const lorahip_demod *dm, const size_t channel, lorah
 {
     { const int rc = drained(dm); if (rc != LORAHIP_OK) return rc; }
     if (dm == nullptr || channel >= dm->B || out == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->getTrace(channel, out, cap);
     const auto &t = dm->ch[channel].trace;
     if (cap < t.size()) return LORAHIP_E_INVALID;
     if (!t.empty()) std::memcpy(out, t.data(), t.size() * sizeof(lorahip_work_result));

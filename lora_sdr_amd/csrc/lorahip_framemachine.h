@@ -16,13 +16,15 @@ struct StreamOut
     lorahip_work_result *out;
     short *symOut;
     StreamPacket *pktOut;
-    int calls, nSym, nPkt;
+    StreamSignal *sigOut;
+    int calls, nSym, nPkt, nSig;
     __device__ __forceinline__ void init(const StreamArgs &s, const unsigned channel)
     {
         out = s.calls ? s.calls + (size_t)channel * s.cap : nullptr;
         symOut = s.symOut + (size_t)channel * s.symStride;
         pktOut = s.pktOut + (size_t)channel * s.capPkt;
-        calls = nSym = nPkt = 0;
+        sigOut = s.sigOut ? s.sigOut + (size_t)channel * s.capPkt : nullptr;
+        calls = nSym = nPkt = nSig = 0;
     }
     //! the packet the channel is inside continues behind the symbols it has already (flag bit 2; `st` with the launch's flags applied)
     __device__ __forceinline__ void carryIn(const StreamArgs &s, const StreamState &st)
@@ -66,6 +68,12 @@ __device__ __forceinline__ void frameStep(StreamState &st, const StreamArgs &s, 
         if (value > N / 2) error -= N;
         st.freqError = (st.freqError + error) / 2;                                                       // :262-265
         signals = 1; sigError = st.freqError;                                                            // :267-269
+        if (o.sigOut)
+        {
+            // emitSignal("error" / "power" / "snr") as a record of its own: the caller evaluated the logarithms for this call
+            if (writer) { StreamSignal g; g.callIndex = st.callCount; g.error = sigError; g.power = power; g.snr = snr; o.sigOut[o.nSig] = g; }
+            o.nSig++;
+        }
     } break;
     case ST_QUARTERCHIRP:
         st.state = ST_DATASYMBOLS;

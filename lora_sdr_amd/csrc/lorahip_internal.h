@@ -101,6 +101,9 @@ __host__ __device__ inline bool nearStep(const float d)
 //! one posted packet: the call (round) it was posted in and its length; its symbols are the next `len` entries
 //! of the channel's symbol stream (after what earlier launches carried over)
 struct StreamPacket { int callIndex; int len; };
+//! what the block emits on its "error" / "power" / "snr" signals at DOWNCHIRP1 (LoRaDemod.cpp:267-269), one record per emission:
+//! kept only when the caller asked for signals (lorahip_demod_set_signals) -- a receiver without a per-call trace still gets them
+struct StreamSignal { int callIndex; int error; float power; float snr; };
 
 //! argument block of the streaming demod kernel (lorahip_stream.hip); all pointers are device pointers
 struct StreamArgs
@@ -117,6 +120,8 @@ struct StreamArgs
     StreamPacket *pktOut;       // [nChannels][capPkt]
     int *nPkt;                  // [nChannels]
     int capPkt;
+    StreamSignal *sigOut;       // [nChannels][capPkt] one record per DOWNCHIRP1 call; nullptr unless signals are kept
+    int *nSig;                  // [nChannels]
     const float2 *down, *fine, *twStage;
     const double2 *fineA, *fineB;   // split of the fine-tune table (lorahip_fine.h); nullptr: gather from `fine`
     unsigned nChannels;
@@ -126,7 +131,8 @@ struct StreamArgs
     float thresh;
     int sync;
     unsigned mtu;
-    long long uniformLen;       // >= 0: channel c's stream is the uniformLen samples at c * uniformLen (base / len are not read)
+    long long uniformLen;       // >= 0: channel c's stream is the uniformLen samples at c * uniformStride (base / len are not read)
+    long long uniformStride;    // samples between the first samples of consecutive channels' streams (uniformLen >= 0)
     int flags;                  // bit 0: first launch of a run -- every channel starts at sample 0, call 0; bit 1: activate() first;
                                 // bit 2: a channel in DATASYMBOLS finds its packet's first symCount symbols at the head of its symOut row
     unsigned *near;             // [2] decisions float rounding could flip (lorahip_demod_near_threshold): squelch margins, fine-tune steps
@@ -163,7 +169,7 @@ hipError_t launchCompactRows(void *dst, const void *src, size_t rows, size_t src
 //! carrySave takes the last symCount entries of every row afterwards (rows of carryCap entries; lorahip_stream.hip)
 hipError_t launchCarryLoad(const StreamState *state, const short *carry, int carryCap, short *symOut, int symStride, size_t nChannels, hipStream_t stream);
 hipError_t launchCarrySave(const StreamState *state, const int *nSym, const short *symOut, int symStride, short *carry, int carryCap, size_t nChannels, hipStream_t stream);
-hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, const int *rowStart, size_t nChannels, int cap, int capPkt,
+hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, int *rowStart, size_t nChannels, int cap, int capPkt,
                              size_t nPackets, long long *srcOff, unsigned short *symsOut, int stride, int *nsymsOut, int *channelOut, hipStream_t stream);
 hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *srcOff, const long long *dstOff, const int *len, size_t nSeg,
                               hipStream_t stream);
@@ -228,6 +234,40 @@ struct lorahip_ctx
 };
 
 namespace lorahip {
+//! A level-3 object over several (device, SF) parts behind one lorahip_demod handle (lorahip_rx.cpp; lorahip_demod_create_mixed).
+//! The entry points of lorahip_demod.cpp hand over to it when the handle carries one; it speaks global channel numbers.
+class Composite
+{
+public:
+    static int create(Composite **out, const int *devices, size_t nDev, const int32_t *channelSf, size_t n);
+    ~Composite();
+    size_t numChannels() const;
+    size_t numParts() const;
+    int partInfo(size_t i, int32_t *device, int32_t *sf, size_t *nChannels, int32_t *deviceSlot) const;
+    int partOf(int32_t *part, int32_t *local) const;
+    lorahip_demod *part(size_t i) const;
+    int setSync(unsigned char v); int setThreshold(double v); int setMtu(size_t v); int setMode(int v); int setFineGather(int v);
+    int setTrace(int v); int setSignals(int v); int activate(); int setStream(void *stream); int resetStream();
+    int run(const float *const *streams, const size_t *nSamples, int64_t *rounds);
+    int runSegments(const float *const *iqPerDevice, size_t nDev, const int64_t *first, const size_t *nSamples, int64_t *rounds);
+    size_t numPackets() const; size_t numPacketSymbols() const; size_t numSignals() const;
+    int getPacket(size_t i, int32_t *channel, int64_t *round, size_t *len, int16_t *out, size_t cap) const;
+    int getPackets(int32_t *channels, int64_t *rounds, int64_t *lens, size_t capPackets, int16_t *syms, size_t capSyms) const;
+    int getSignals(int32_t *channels, int64_t *rounds, int32_t *errors, float *powers, float *snrs, size_t cap) const;
+    void clearPackets();
+    int64_t consumed(size_t c) const; int consumedAll(int64_t *out) const;
+    int64_t workCalls() const; double kernelMs() const; int lastLaunches() const; int nearThreshold(int64_t *sq, int64_t *st) const;
+    int setPorts(const lorahip_demod_ports *ports);
+    int portCounts(size_t c, size_t *f, size_t *d, size_t *r) const;
+    int getLabels(size_t c, char *buf, size_t cap, size_t *n, size_t *bytes) const;
+    int getTrace(size_t c, lorahip_work_result *out, size_t cap) const;
+    size_t traceLen(size_t c) const;
+private:
+    Composite();
+    struct Impl;
+    Impl *p;
+};
+
 //! n host pieces -> device memory back to back from dDst, asynchronous on ctx->stream (pinned pieces by DMA straight away, the
 //! others through the context's double-buffered pinned staging); the caller synchronises the stream
 int gatherUpload(lorahip_ctx *ctx, void *dDst, const void *const *src, const size_t *bytes, size_t n);

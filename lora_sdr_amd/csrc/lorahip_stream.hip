@@ -77,7 +77,7 @@ demodStream(const StreamArgs s)
     StreamState st = s.state[cc];
     if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
     if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
-    const long long base = s.uniformLen >= 0 ? (long long)cc * s.uniformLen : s.base[cc];
+    const long long base = s.uniformLen >= 0 ? (long long)cc * s.uniformStride : s.base[cc];
     const long long len = !mine ? 0 : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]);
     StreamOut o;
     o.init(s, cc);
@@ -93,7 +93,11 @@ demodStream(const StreamArgs s)
     // with wantFi = 1 whose window is not squelched -- or in any case for wantFi = 2: the second window of a FRAMESYNC call, whose
     // fIndex the reference consumes without looking at that window's own snr (:203, :217-221). wantSq / wantFi are per lane group;
     // the branches are wave-uniform.
+    // Signals without a trace (lorahip_demod_set_signals): the one call per packet that emits them (DOWNCHIRP1, :267-269) takes the
+    // traced path -- power and snr evaluated -- in the passes where some channel of the wave is in that state; every decision is
+    // the same on either path.
     const bool all = s.calls != nullptr;
+    const bool sig = s.sigOut != nullptr;
 #ifdef LORAHIP_STREAM_TIMING
     unsigned long long tsec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #define TMARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsec[i] += now_ - tlast; tlast = now_; } while (0)
@@ -102,7 +106,7 @@ demodStream(const StreamArgs s)
 #define TMARK(i)
 #define TMARK_NOWAIT(i)
 #endif
-    auto detect = [&](const bool on, const bool wantSq, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
+    auto detect = [&](const bool full, const bool on, const bool wantSq, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
@@ -188,8 +192,8 @@ demodStream(const StreamArgs s)
         double tot;
         v2f l, r;
         value = 0;
-        const bool staged = all || (STREAM_STAGE_BINS && __any(on && wantFi != 0));       // bins to LDS for the neighbour fetch (else: register select)
-        if (all)
+        const bool staged = full || (STREAM_STAGE_BINS && __any(on && wantFi != 0));       // bins to LDS for the neighbour fetch (else: register select)
+        if (full)
         {
             K::template scan<true, STREAM_SCAN_CHAINS>(vl, F, nullptr, t, bestV, bestI, tot);
             K::neighbours(vl, F, bestI, lane, t, l, r);
@@ -258,7 +262,7 @@ demodStream(const StreamArgs s)
     float snr0 = 0.0f, fineErrBefore0 = 0.0f;
     while (true)
     {
-        const bool live = mine && (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt));   // LoRaDemod.cpp:148
+        const bool live = mine && (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt && o.nSig < s.capPkt));   // LoRaDemod.cpp:148
         if (!__any(live)) break;
 
         // ---- this pass's window: window 0 of a call (:157-172), or window 1 of a parked one (:189-206) ----
@@ -270,7 +274,8 @@ demodStream(const StreamArgs s)
         const long long here = base + st.pos + (second ? N : 0);
         const bool fs = st.state == ST_FRAMESYNC;
         bool squelched;
-        detect(live, !second && (fs || st.state == ST_DATASYMBOLS), second ? 2 : (fs ? 1 : 0), here, st.downTable != 0, st.fineTuneIndex,
+        const bool full = all || (sig && __any(live && !second && st.state == ST_DOWNCHIRP1));
+        detect(full, live, !second && (fs || st.state == ST_DATASYMBOLS), second ? 2 : (fs ? 1 : 0), here, st.downTable != 0, st.fineTuneIndex,
                st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
         float snr = power - powerAvg;                                                   // :173 (squelched = snr < thresh, :174, comes from detect)
         // window 0: the loop commits the member (:160-162); window 1: `int ft = _fineTuneIndex` (:191) starts from the committed
@@ -313,6 +318,7 @@ demodStream(const StreamArgs s)
         s.nCalls[c] = o.calls;
         s.nSym[c] = o.nSym;
         s.nPkt[c] = o.nPkt;
+        if (s.nSig) s.nSig[c] = o.nSig;
     }
 }
 
@@ -461,11 +467,33 @@ hipError_t launchCarrySave(const StreamState *state, const int *nSym, const shor
     return hipGetLastError();
 }
 
-hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, const int *rowStart, const size_t nChannels,
+//! rowStart = exclusive prefix sum of nPkt (one workgroup; the channel counts are tens of thousands at most): the packets' rows are
+//! numbered on the device, so that packing them needs neither an upload nor a host synchronisation
+__global__ void __launch_bounds__(1024) scanCounts(const int *__restrict__ nPkt, int *__restrict__ rowStart, const unsigned nChannels)
+{
+    __shared__ int sPart[1024];
+    const unsigned per = (nChannels + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < nChannels ? lo + per : nChannels;
+    int sum = 0;
+    for (unsigned c = lo; c < hi; c++) sum += nPkt[c];
+    sPart[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1)
+    {
+        const int v = (int)threadIdx.x >= d ? sPart[threadIdx.x - d] : 0;
+        __syncthreads();
+        sPart[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int acc = sPart[threadIdx.x] - sum;
+    for (unsigned c = lo; c < hi; c++) { rowStart[c] = acc; acc += nPkt[c]; }
+}
+
+hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, int *rowStart, const size_t nChannels,
                              const int cap, const int capPkt, const size_t nPackets, long long *srcOff, unsigned short *symsOut, const int stride,
                              int *nsymsOut, int *channelOut, hipStream_t stream)
 {
     if (nPackets == 0) return hipSuccess;
+    hipLaunchKernelGGL(scanCounts, dim3(1), dim3(1024), 0, stream, nPkt, rowStart, unsigned(nChannels));
     hipLaunchKernelGGL(packDescribe, dim3(unsigned((nChannels + 255) / 256)), dim3(256), 0, stream, pktOut, nPkt, rowStart, unsigned(nChannels), cap, capPkt,
                        srcOff, nsymsOut, channelOut);
     hipLaunchKernelGGL(packCopy, dim3(unsigned(nPackets)), dim3(64), 0, stream, symOut, srcOff, nsymsOut, symsOut, stride);

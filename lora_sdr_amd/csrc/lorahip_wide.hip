@@ -698,7 +698,7 @@ demodStreamWide(const StreamArgs s)
     StreamState st = s.state[c];
     if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
     if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
-    const long long base = s.uniformLen >= 0 ? (long long)c * s.uniformLen : s.base[c];
+    const long long base = s.uniformLen >= 0 ? (long long)c * s.uniformStride : s.base[c];
     const long long len = s.uniformLen >= 0 ? s.uniformLen : s.len[c];
     StreamOut o;
     o.init(s, c);
@@ -709,8 +709,10 @@ demodStreamWide(const StreamArgs s)
     // trace the squelch decision comes from a quick estimate (squelchQuick) with the exact chain as the fallback near the
     // threshold, fIndex is evaluated only for an unsquelched FRAMESYNC window, and the neighbour fetch with its barrier is skipped
     // whenever neither is needed
-    const bool all = s.calls != nullptr;
-    auto detect = [&](const bool wantSq, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
+    // Signals without a trace (lorahip_demod_set_signals): the DOWNCHIRP1 call of a packet takes the traced path (`full`), see demodStream
+    const bool traced = s.calls != nullptr;
+    const bool sig = s.sigOut != nullptr;
+    auto detect = [&](const bool all, const bool wantSq, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
@@ -897,7 +899,7 @@ demodStreamWide(const StreamArgs s)
     bool pend = false;
     int value0 = 0, fineIdxBefore0 = 0;
     float snr0 = 0.0f, fineErrBefore0 = 0.0f;
-    while (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt))          // LoRaDemod.cpp:148
+    while (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt && o.nSig < s.capPkt))          // LoRaDemod.cpp:148
     {
         const bool second = pend;
         int value, idxEnd;
@@ -908,7 +910,7 @@ demodStreamWide(const StreamArgs s)
         bool squelched;
         // window 0 of a call (:157-172), or window 1 of a parked one (:189-206: `int ft = _fineTuneIndex` starts from the committed
         // index and is not committed itself)
-        detect(!second && (fs || st.state == ST_DATASYMBOLS), second ? 2 : (fs ? 1 : 0), base + st.pos + (second ? N : 0), st.downTable != 0,
+        detect(traced || (sig && !second && st.state == ST_DOWNCHIRP1), !second && (fs || st.state == ST_DATASYMBOLS), second ? 2 : (fs ? 1 : 0), base + st.pos + (second ? N : 0), st.downTable != 0,
                st.fineTuneIndex, st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
         float snr = power - powerAvg;                                                   // :173 (squelched = snr < thresh, :174, comes from detect)
         if (!second) st.fineTuneIndex = idxEnd;                                         // :160-162
@@ -939,6 +941,7 @@ demodStreamWide(const StreamArgs s)
         s.nCalls[c] = o.calls;
         s.nSym[c] = o.nSym;
         s.nPkt[c] = o.nPkt;
+        if (s.nSig) s.nSig[c] = o.nSig;
     }
 }
 

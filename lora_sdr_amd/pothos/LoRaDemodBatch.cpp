@@ -1,29 +1,37 @@
-// LoRaDemodBatch.cpp -- a Pothos block that runs B channels of the reference's /lora/lora_demod on one MI355X through
+// LoRaDemodBatch.cpp -- a Pothos block that runs B channels of the reference's /lora/lora_demod on the MI355X GPUs of a node through
 // level 3 of the C ABI (include/lorahip.h). The reference-side binding of INTEGRATION.md section 2, as a real translation unit:
 // it compiles against <Pothos/Framework.hpp> and links liblorahip.so; nothing else.
 //
-// Same parameters and defaults as LoRaDemod (LoRaDemod.cpp:68-74, setters :124-137), same state machine, packets, signals,
-// labels and debug ports per channel -- what changes is the shape: one block instance owns B inputs.
+// Same parameters and defaults as LoRaDemod (LoRaDemod.cpp:68-74, setters :124-137), same state machine, packets and signals per
+// channel -- what changes is the shape: one block instance owns B inputs, each channel with its own SF if asked.
 //
 //   factory   /lora/lora_demod_batch(sf, channels)
-//   setDevices("0,1,2,3,4,5,6,7")  spread the B channels over several GPUs of the node: contiguous ranges
-//             from lorahip_shard_plan, one level-3 object per device, each run from its own host thread inside work(); the
-//             default is device 0 alone. Channels are independent: per-channel outputs do not depend on the split.
+//   setSpreadFactors("7,8,9,10,11,12")  one SF per channel (a shorter list repeats: this one is SF = 7 + c mod 6); the reference makes
+//             one block per channel with its own sf (LoRaDemod.cpp:119-122). Before activate().
+//   setDevices("0,1,2,3,4,5,6,7")  spread the channels over several GPUs of the node: lorahip_demod_create_mixed
+//             splits them with lorahip_shard_plan, one part per (device, SF) with its own stream and host thread; the default is
+//             device 0 alone. Channels are independent: per-channel outputs do not depend on the split. Before activate().
+//   setDebugPorts(bool)  the reference's three debug outputs raw / dec / fft (LoRaDemod.cpp:81-83,163-164,172,316-324) and the labels
+//             on them. OFF by default: they triple the traffic, need a per-call trace (a full record drain per run) and are for a
+//             plotter, not for a receiver. One SF only.
+//   setSignals(bool)  the "error" / "power" / "snr" signals (default on)
 //   inputs    0 .. B-1            complex float streams, reserve 2N each                       (LoRaDemod.cpp:79,90)
 //   outputs   "0" .. "B-1"        Pothos::Packet messages of int16 symbols                     (:80,295-298)
-//             "raw<c>" "dec<c>"   complex float streams, `total` elements per work() call      (:81-82,163-164,321-322)
-//             "fft<c>"            complex float stream, N bins per work() call                 (:83,172,324)
+//             "raw<c>" "dec<c>"   complex float streams, `total` elements per work() call      (:81-82,163-164,321-322)   [debug ports]
+//             "fft<c>"            complex float stream, N bins per work() call                 (:83,172,324)              [debug ports]
 //   signals   "channel" followed by "error", "power", "snr" once per packet at DOWNCHIRP1     (:85-87,267-269)
-//   labels    "SYNC", "P x", "DC", "QC", "S<n> x" on raw<c> / dec<c> / fft<c> at the first element each call produced (:314-319)
+//   labels    "SYNC", "P x", "DC", "QC", "S<n> x" on raw<c> / dec<c> / fft<c> at the first element each call produced (:314-319) [debug ports]
 //
 // One work() of this block performs, per channel, as many LoRaDemod::work() calls as the channel's input buffer allows
-// (each needs 2N samples, :148) inside ONE device launch. Output buffers must therefore hold what several calls produce:
+// (each needs 2N samples, :148) inside ONE device launch per (device, SF) part. Without the debug ports a work() is: gather the
+// input buffers (pinned double-buffered upload), the streaming kernels, 52 B of state per channel back, the packets that
+// completed and the signals; nothing per call crosses PCIe. With them, output buffers must hold what several calls produce:
 // setMaxWindows(K) sizes them (raw/dec: the samples consumed; fft: 2K frames per work(), more are dropped and counted).
 #include <Pothos/Framework.hpp>
 #include <complex>
+#include <cstdlib>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 #include "lorahip.h"
 
@@ -33,104 +41,167 @@ class LoRaDemodBatch : public Pothos::Block
 
 public:
     LoRaDemodBatch(const size_t sf, const size_t channels) :
-        N(size_t(1) << sf), B(channels), _sf(sf), _sync(0x12), _thresh(-30.0), _mtu(256), _maxWindows(64), _fftDropped(0)
+        B(channels), _d(nullptr), _sfs(channels, int32_t(sf)), _devices(1, 0), _sync(0x12), _thresh(-30.0), _mtu(256), _maxWindows(64),
+        _fftCap(128), _fftDropped(0), _debugPorts(false), _signals(true), _active(false)
     {
-        createShards(std::vector<int>(1, 0));
+        _d = makeDemod(_sfs, _devices);
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setSync));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setDevices));
+        this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setSpreadFactors));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setThreshold));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setMTU));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setMaxWindows));
+        this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setDebugPorts));
+        this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setSignals));
+        _in.resize(B); _msg.resize(B); _raw.resize(B); _dec.resize(B); _fft.resize(B);
         for (size_t c = 0; c < B; c++)
         {
+            const std::string s = std::to_string(c);
             this->setupInput(int(c), typeid(cf32));
             this->setupOutput(int(c));
-            this->setupOutput("raw" + std::to_string(c), typeid(cf32));
-            this->setupOutput("dec" + std::to_string(c), typeid(cf32));
-            this->setupOutput("fft" + std::to_string(c), typeid(cf32));
-            this->input(int(c))->setReserve(N * 2);                         // use at most two input symbols available (:90)
+            this->setupOutput("raw" + s, typeid(cf32));
+            this->setupOutput("dec" + s, typeid(cf32));
+            this->setupOutput("fft" + s, typeid(cf32));
+            // the ports are looked up once: B can be tens of thousands, and work() touches every one of them
+            _in[c] = this->input(int(c)); _msg[c] = this->output(int(c));
+            _raw[c] = this->output("raw" + s); _dec[c] = this->output("dec" + s); _fft[c] = this->output("fft" + s);
         }
         this->registerSignal("channel");
         this->registerSignal("error");
         this->registerSignal("power");
         this->registerSignal("snr");
-        sizeBuffers();
+        applyReserves();
     }
 
-    ~LoRaDemodBatch(void) { destroyShards(); }
+    ~LoRaDemodBatch(void) { lorahip_demod_destroy(_d); }
 
     static Block *make(const size_t sf, const size_t channels) { return new LoRaDemodBatch(sf, channels); }
 
-    void setSync(const unsigned char sync) { _sync = sync; for (auto &s : _shards) lorahip_demod_set_sync(s.d, sync); }
-    void setThreshold(const double thresh_dB) { _thresh = thresh_dB; for (auto &s : _shards) lorahip_demod_set_threshold(s.d, thresh_dB); }
-    void setMTU(const size_t mtu) { _mtu = mtu; for (auto &s : _shards) lorahip_demod_set_mtu(s.d, mtu); }
-    void setMaxWindows(const size_t k) { _maxWindows = k ? k : 1; sizeBuffers(); }
+    void setSync(const unsigned char sync) { _sync = sync; lorahip_demod_set_sync(_d, sync); }
+    void setThreshold(const double thresh_dB) { _thresh = thresh_dB; lorahip_demod_set_threshold(_d, thresh_dB); }
+    void setMTU(const size_t mtu) { _mtu = mtu; lorahip_demod_set_mtu(_d, mtu); }
+    void setMaxWindows(const size_t k) { _maxWindows = k ? k : 1; if (_debugPorts) attachPorts(_d); }
+    void setSignals(const bool on) { _signals = on; lorahip_demod_set_signals(_d, on ? 1 : 0); }
     size_t fftFramesDropped(void) const { return _fftDropped; }
+
+    //! the reference block's raw / dec / fft outputs and their labels; off unless asked for (see the head of this file)
+    void setDebugPorts(const bool on)
+    {
+        if (on)
+        {
+            for (size_t c = 1; c < B; c++)
+                if (_sfs[c] != _sfs[0]) throw Pothos::InvalidArgumentException("LoRaDemodBatch::setDebugPorts(true)", "the debug ports need one spreading factor for all channels");
+            attachPorts(_d);
+        }
+        else if (lorahip_demod_set_ports(_d, nullptr) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch::setDebugPorts(false)", lorahip_last_error());
+        _debugPorts = on;
+    }
 
     //! comma-separated device indices, e.g. "0,1,2,3,4,5,6,7"; an index may repeat (two shards on one GPU)
     void setDevices(const std::string &list)
     {
-        std::vector<int> devs;
-        size_t at = 0;
-        while (at < list.size())
-        {
-            size_t end = list.find(',', at);
-            if (end == std::string::npos) end = list.size();
-            const std::string tok = list.substr(at, end - at);
-            if (tok.empty() || tok.find_first_not_of("0123456789 ") != std::string::npos) throw Pothos::InvalidArgumentException("LoRaDemodBatch::setDevices(" + list + ")", "not a list of device indices");
-            devs.push_back(std::atoi(tok.c_str()));
-            at = end + 1;
-        }
-        if (devs.empty()) throw Pothos::InvalidArgumentException("LoRaDemodBatch::setDevices()", "empty list");
-        createShards(devs);
-        sizeBuffers();
+        const std::vector<int> devs = parseList(list, "LoRaDemodBatch::setDevices", 0, 4095);
+        rebuild(_sfs, devs, "LoRaDemodBatch::setDevices(" + list + ")");
     }
 
-    void activate(void) { for (auto &s : _shards) lorahip_demod_activate(s.d); }
+    //! comma-separated spreading factors, one per channel; a shorter list repeats ("7,8,9,10,11,12" is SF = 7 + c mod 6)
+    void setSpreadFactors(const std::string &list)
+    {
+        const std::vector<int> pat = parseList(list, "LoRaDemodBatch::setSpreadFactors", LORAHIP_SF_MIN, LORAHIP_SF_MAX);
+        if (pat.size() > B) throw Pothos::InvalidArgumentException("LoRaDemodBatch::setSpreadFactors(" + list + ")", "more entries than channels");
+        std::vector<int32_t> sfs(B);
+        for (size_t c = 0; c < B; c++) sfs[c] = int32_t(pat[c % pat.size()]);
+        if (_debugPorts) for (size_t c = 1; c < B; c++)
+            if (sfs[c] != sfs[0]) throw Pothos::InvalidArgumentException("LoRaDemodBatch::setSpreadFactors(" + list + ")", "the debug ports need one spreading factor for all channels");
+        rebuild(sfs, _devices, "LoRaDemodBatch::setSpreadFactors(" + list + ")");
+        applyReserves();
+    }
+
+    void activate(void) { lorahip_demod_activate(_d); _active = true; }
+    void deactivate(void) { _active = false; }
 
     void work(void)
     {
-        std::vector<const float *> streams(B);
-        std::vector<size_t> avail(B);
+        _streams.resize(B); _avail.resize(B);
         bool any = false;
-        const size_t capSamples = _maxWindows * N;
         for (size_t c = 0; c < B; c++)
         {
-            auto in = this->input(int(c));
-            streams[c] = reinterpret_cast<const float *>(in->buffer().template as<const cf32 *>());
-            avail[c] = in->elements() < capSamples ? in->elements() : capSamples;       // never produce more than the output buffers hold
-            any = any || avail[c] >= 2 * N;                                             // :148
+            const size_t N = size_t(1) << _sfs[c], capSamples = _maxWindows * N;
+            _streams[c] = reinterpret_cast<const float *>(_in[c]->buffer().template as<const cf32 *>());
+            // with the debug ports: never produce more than the output buffers hold
+            _avail[c] = (_debugPorts && _in[c]->elements() > capSamples) ? capSamples : _in[c]->elements();
+            any = any || _avail[c] >= 2 * N;                                            // :148
         }
         if (!any) return;
+        if (_debugPorts) lorahip_demod_set_trace(_d, 1);                                // labels and per-call signals come from the trace
 
-        // every device's channels in one launch on that device; several devices run side by side, each from its own host thread
-        std::vector<int> rcs(_shards.size(), LORAHIP_OK);
-        std::vector<std::string> errs(_shards.size());
-        auto runShard = [&](const size_t i)
+        // every part's channels in one launch on its device; the parts run side by side, each from its own host thread (inside the library)
+        if (lorahip_demod_run(_d, _streams.data(), _avail.data(), nullptr) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
+
+        _consumed.resize(B);
+        lorahip_demod_consumed_all(_d, _consumed.data());
+        for (size_t c = 0; c < B; c++) if (_consumed[c] > 0) _in[c]->consume(size_t(_consumed[c]));   // the sum of consume(total), :320
+
+        if (_debugPorts) producePorts();
+        else if (_signals)
         {
-            Shard &s = _shards[i];
-            lorahip_demod_set_trace(s.d, 1);
-            rcs[i] = lorahip_demod_run(s.d, streams.data() + s.first, avail.data() + s.first, nullptr);
-            if (rcs[i] != LORAHIP_OK) errs[i] = lorahip_last_error();                    // the text is per thread
-        };
-        if (_shards.size() == 1) runShard(0);
-        else
-        {
-            std::vector<std::thread> pool;
-            for (size_t i = 0; i < _shards.size(); i++) pool.emplace_back(runShard, i);
-            for (auto &t : pool) t.join();
+            // once per packet at DOWNCHIRP1 (:267-269): the kernels kept a record per emission
+            const size_t n = lorahip_demod_num_signals(_d);
+            _sigCh.resize(n); _sigErr.resize(n); _sigPow.resize(n); _sigSnr.resize(n);
+            if (n && lorahip_demod_get_signals(_d, _sigCh.data(), nullptr, _sigErr.data(), _sigPow.data(), _sigSnr.data(), n) != LORAHIP_OK)
+                throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
+            for (size_t i = 0; i < n; i++)
+            {
+                this->emitSignal("channel", int(_sigCh[i]));
+                this->emitSignal("error", int(_sigErr[i]));
+                this->emitSignal("power", _sigPow[i]);
+                this->emitSignal("snr", _sigSnr[i]);
+            }
         }
-        for (size_t i = 0; i < _shards.size(); i++)
-            if (rcs[i] != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch::work()", errs[i]);
 
+        // packets (:295-298): all of them in one call; every channel has its own message port
+        const size_t nPackets = lorahip_demod_num_packets(_d), nSyms = lorahip_demod_num_packet_symbols(_d);
+        _pkCh.resize(nPackets); _pkLen.resize(nPackets); _pkSyms.resize(nSyms);
+        if (nPackets && lorahip_demod_get_packets(_d, _pkCh.data(), nullptr, _pkLen.data(), nPackets, _pkSyms.data(), nSyms) != LORAHIP_OK)
+            throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
+        size_t at = 0;
+        for (size_t i = 0; i < nPackets; i++)
+        {
+            const size_t len = size_t(_pkLen[i]);
+            Pothos::Packet pkt;
+            pkt.payload = Pothos::BufferChunk(typeid(int16_t), len ? len : 1);
+            pkt.payload.length = len * sizeof(int16_t);
+            if (len) std::memcpy(pkt.payload.template as<int16_t *>(), _pkSyms.data() + at, len * sizeof(int16_t));
+            at += len;
+            _msg[size_t(_pkCh[i])]->postMessage(pkt);
+        }
+        lorahip_demod_clear_packets(_d);
+        if (_debugPorts) lorahip_demod_set_trace(_d, 0);                                // the next work() starts a fresh trace
+    }
+
+    //! output buffers large enough for what one work() produces (the reference does the same for its 2N / N, :330-358)
+    Pothos::BufferManager::Sptr getOutputBufferManager(const std::string &name, const std::string &domain)
+    {
+        if (name.compare(0, 3, "raw") == 0 || name.compare(0, 3, "dec") == 0 || name.compare(0, 3, "fft") == 0)
+        {
+            const size_t c = size_t(std::atol(name.c_str() + 3));
+            const size_t N = size_t(1) << _sfs[c < B ? c : 0];
+            Pothos::BufferManagerArgs args;
+            args.bufferSize = (name.compare(0, 3, "fft") == 0 ? _fftCap : _maxWindows) * N * sizeof(cf32);
+            return Pothos::BufferManager::make("generic", args);
+        }
+        return Pothos::Block::getOutputBufferManager(name, domain);
+    }
+
+private:
+    //! what the reference block does on its three stream outputs, from the per-call trace (one SF: checked by setDebugPorts)
+    void producePorts(void)
+    {
+        const size_t N = size_t(1) << _sfs[0], capSamples = _maxWindows * N;
         std::vector<lorahip_work_result> tr;
         std::vector<char> labels;
-        for (size_t cg = 0; cg < B; cg++)
+        for (size_t c = 0; c < B; c++)
         {
-            // channel cg of the block = channel c of the shard that owns it
-            const Shard &sh = _shards[_shardOf[cg]];
-            lorahip_demod *_d = sh.d;
-            const size_t c = cg - sh.first;
             const size_t nCalls = lorahip_demod_trace_len(_d, c);
             if (nCalls == 0) continue;
             tr.resize(nCalls);
@@ -144,10 +215,9 @@ public:
             lorahip_demod_port_counts(_d, c, &nf, &nd, &nr);
             const size_t frames = nf < _fftCap ? nf : _fftCap;
             _fftDropped += nf - frames;
-            auto raw = this->output("raw" + std::to_string(cg)), dec = this->output("dec" + std::to_string(cg)), fft = this->output("fft" + std::to_string(cg));
-            std::memcpy(raw->buffer().template as<cf32 *>(), _raw.data() + cg * capSamples, nr * sizeof(cf32));
-            std::memcpy(dec->buffer().template as<cf32 *>(), _dec.data() + cg * capSamples, nd * sizeof(cf32));
-            std::memcpy(fft->buffer().template as<cf32 *>(), _fft.data() + cg * _fftCap * N, frames * N * sizeof(cf32));
+            std::memcpy(_raw[c]->buffer().template as<cf32 *>(), _stRaw.data() + c * capSamples, nr * sizeof(cf32));
+            std::memcpy(_dec[c]->buffer().template as<cf32 *>(), _stDec.data() + c * capSamples, nd * sizeof(cf32));
+            std::memcpy(_fft[c]->buffer().template as<cf32 *>(), _stFft.data() + c * _fftCap * N, frames * N * sizeof(cf32));
 
             // labels at the first element each call produced (:314-319); signals (:267-269)
             size_t pos = 0;
@@ -158,114 +228,108 @@ public:
                 lab += id.size() + 1;
                 if (!id.empty())
                 {
-                    raw->postLabel(Pothos::Label(id, Pothos::Object(), pos));
-                    dec->postLabel(Pothos::Label(id, Pothos::Object(), pos));
-                    if (k < frames) fft->postLabel(Pothos::Label(id, Pothos::Object(), k * N));
+                    _raw[c]->postLabel(Pothos::Label(id, Pothos::Object(), pos));
+                    _dec[c]->postLabel(Pothos::Label(id, Pothos::Object(), pos));
+                    if (k < frames) _fft[c]->postLabel(Pothos::Label(id, Pothos::Object(), k * N));
                 }
-                if (tr[k].signals)
+                if (tr[k].signals && _signals)
                 {
-                    this->emitSignal("channel", int(cg));
+                    this->emitSignal("channel", int(c));
                     this->emitSignal("error", tr[k].sig_error);
                     this->emitSignal("power", tr[k].sig_power);
                     this->emitSignal("snr", tr[k].sig_snr);
                 }
                 pos += size_t(tr[k].consumed);
             }
-            this->input(int(cg))->consume(size_t(lorahip_demod_consumed(_d, c)));       // the sum of consume(total), :320
-            raw->produce(nr);
-            dec->produce(nd);
-            fft->produce(frames * N);
-        }
-        // packets, in the order the channels posted them (:295-298); every channel has its own message port
-        for (const Shard &sh : _shards)
-        {
-            lorahip_demod *_d = sh.d;
-            const size_t nPackets = lorahip_demod_num_packets(_d);
-            for (size_t i = 0; i < nPackets; i++)
-            {
-                int32_t ch = 0;
-                size_t len = 0;
-                lorahip_demod_get_packet(_d, i, &ch, nullptr, &len, nullptr, 0);
-                Pothos::Packet pkt;
-                pkt.payload = Pothos::BufferChunk(typeid(int16_t), len ? len : 1);
-                pkt.payload.length = len * sizeof(int16_t);
-                lorahip_demod_get_packet(_d, i, nullptr, nullptr, nullptr, pkt.payload.template as<int16_t *>(), len);
-                this->output(int(sh.first + size_t(ch)))->postMessage(pkt);
-            }
-            lorahip_demod_clear_packets(_d);
-            lorahip_demod_set_trace(_d, 0);                                              // the next work() starts a fresh trace
+            _raw[c]->produce(nr);
+            _dec[c]->produce(nd);
+            _fft[c]->produce(frames * N);
         }
     }
 
-    //! output buffers large enough for what one work() produces (the reference does the same for its 2N / N, :330-358)
-    Pothos::BufferManager::Sptr getOutputBufferManager(const std::string &name, const std::string &domain)
+    static std::vector<int> parseList(const std::string &list, const std::string &what, const int lo, const int hi)
     {
-        if (name.compare(0, 3, "raw") == 0 || name.compare(0, 3, "dec") == 0 || name.compare(0, 3, "fft") == 0)
+        std::vector<int> out;
+        size_t at = 0;
+        while (at < list.size())
         {
-            Pothos::BufferManagerArgs args;
-            args.bufferSize = (name.compare(0, 3, "fft") == 0 ? _fftCap : _maxWindows) * N * sizeof(cf32);
-            return Pothos::BufferManager::make("generic", args);
+            size_t end = list.find(',', at);
+            if (end == std::string::npos) end = list.size();
+            const std::string tok = list.substr(at, end - at);
+            if (tok.empty() || tok.find_first_not_of("0123456789 ") != std::string::npos || tok.find_first_of("0123456789") == std::string::npos)
+                throw Pothos::InvalidArgumentException(what + "(" + list + ")", "not a list of non-negative integers");
+            const long v = std::atol(tok.c_str());
+            if (v < lo || v > hi) throw Pothos::InvalidArgumentException(what + "(" + list + ")", "value out of range");
+            out.push_back(int(v));
+            at = end + 1;
         }
-        return Pothos::Block::getOutputBufferManager(name, domain);
+        if (out.empty()) throw Pothos::InvalidArgumentException(what + "()", "empty list");
+        return out;
     }
 
-private:
-    void sizeBuffers(void)
+    //! a level-3 object with this block's settings applied; throws (and leaves the block as it was) if it cannot be made
+    lorahip_demod *makeDemod(const std::vector<int32_t> &sfs, const std::vector<int> &devices)
     {
+        lorahip_demod *d = nullptr;
+        const int rc = lorahip_demod_create_mixed(&d, devices.data(), devices.size(), sfs.data(), sfs.size());
+        if (rc != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch", std::string(lorahip_strerror(rc)) + " " + lorahip_last_error());
+        lorahip_demod_set_sync(d, _sync); lorahip_demod_set_threshold(d, _thresh); lorahip_demod_set_mtu(d, _mtu);
+        lorahip_demod_set_signals(d, _signals ? 1 : 0);
+        return d;
+    }
+
+    //! Another device list or SF list: the NEW object is made first, with the settings and ports of the old one; only when all of that
+    //! has succeeded does it replace the old one (a failure leaves the block exactly as it was). Refused while the block is active:
+    //! the channels' frame machines and open packets live in the object that would be thrown away.
+    void rebuild(const std::vector<int32_t> &sfs, const std::vector<int> &devices, const std::string &what)
+    {
+        if (_active) throw Pothos::Exception(what, "not while the block is active (the channels' receiver state would be lost)");
+        lorahip_demod *d = makeDemod(sfs, devices);
+        const std::vector<int32_t> oldSfs = _sfs;
+        _sfs = sfs;                                                 // attachPorts sizes by the new list
+        if (_debugPorts)
+        {
+            try { attachPorts(d); }
+            catch (...) { _sfs = oldSfs; lorahip_demod_destroy(d); if (_debugPorts) attachPorts(_d); throw; }
+        }
+        lorahip_demod_destroy(_d);
+        _d = d;
+        _devices = devices;
+    }
+
+    void applyReserves(void) { for (size_t c = 0; c < B; c++) _in[c]->setReserve((size_t(1) << _sfs[c]) * 2); }   // at most two input symbols (:90)
+
+    //! host staging of the three debug ports, [channel][capacity], handed to the library as host buffers
+    void attachPorts(lorahip_demod *d)
+    {
+        const size_t N = size_t(1) << _sfs[0], capSamples = _maxWindows * N;
         _fftCap = 2 * _maxWindows;
-        const size_t capSamples = _maxWindows * N;
-        _raw.assign(B * capSamples, cf32());
-        _dec.assign(B * capSamples, cf32());
-        _fft.assign(B * _fftCap * N, cf32());
-        for (const Shard &sh : _shards)
-        {
-            // a shard's channels are a contiguous range of the block's: its port buffers are that range of the staging arrays
-            lorahip_demod_ports p;
-            std::memset(&p, 0, sizeof(p));
-            p.struct_size = sizeof(p);
-            p.fft_dev = reinterpret_cast<float *>(_fft.data() + sh.first * _fftCap * N); p.fft_cap_frames = _fftCap;
-            p.dec_dev = reinterpret_cast<float *>(_dec.data() + sh.first * capSamples); p.dec_cap_samples = capSamples;
-            p.raw_dev = reinterpret_cast<float *>(_raw.data() + sh.first * capSamples); p.raw_cap_samples = capSamples;
-            p.host_buffers = 1;
-            if (lorahip_demod_set_ports(sh.d, &p) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch", lorahip_last_error());
-        }
+        _stRaw.assign(B * capSamples, cf32());
+        _stDec.assign(B * capSamples, cf32());
+        _stFft.assign(B * _fftCap * N, cf32());
+        lorahip_demod_ports p;
+        std::memset(&p, 0, sizeof(p));
+        p.struct_size = sizeof(p);
+        p.fft_dev = reinterpret_cast<float *>(_stFft.data()); p.fft_cap_frames = _fftCap;
+        p.dec_dev = reinterpret_cast<float *>(_stDec.data()); p.dec_cap_samples = capSamples;
+        p.raw_dev = reinterpret_cast<float *>(_stRaw.data()); p.raw_cap_samples = capSamples;
+        p.host_buffers = 1;
+        if (lorahip_demod_set_ports(d, &p) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch", lorahip_last_error());
     }
 
-    struct Shard { lorahip_demod *d; size_t first, count; int device; };
-
-    void destroyShards(void)
-    {
-        for (auto &s : _shards) lorahip_demod_destroy(s.d);
-        _shards.clear();
-    }
-
-    //! B channels of one SF over the given devices: lorahip_shard_plan (equal weights: contiguous ranges, sizes differing by <= 1)
-    void createShards(const std::vector<int> &devices)
-    {
-        std::vector<int32_t> sfs(B, int32_t(_sf)), plan(B, 0);
-        if (lorahip_shard_plan(sfs.data(), B, devices.size(), plan.data()) != LORAHIP_OK) throw Pothos::InvalidArgumentException("LoRaDemodBatch::setDevices()", "bad device list");
-        destroyShards();
-        _shardOf.assign(B, 0);
-        for (size_t i = 0; i < devices.size(); i++)
-        {
-            size_t first = B, count = 0;
-            for (size_t c = 0; c < B; c++) if (size_t(plan[c]) == i) { if (first == B) first = c; count++; }
-            if (count == 0) continue;
-            Shard s; s.d = nullptr; s.first = first; s.count = count; s.device = devices[i];
-            const int rc = lorahip_demod_create(&s.d, devices[i], int(_sf), count);
-            if (rc != LORAHIP_OK) { destroyShards(); throw Pothos::Exception("LoRaDemodBatch", std::string(lorahip_strerror(rc)) + " " + lorahip_last_error()); }
-            lorahip_demod_set_sync(s.d, _sync); lorahip_demod_set_threshold(s.d, _thresh); lorahip_demod_set_mtu(s.d, _mtu);
-            for (size_t c = first; c < first + count; c++) _shardOf[c] = _shards.size();
-            _shards.push_back(s);
-        }
-    }
-
-    const size_t N, B, _sf;
-    unsigned char _sync; double _thresh; size_t _mtu;       // the setters' values, re-applied when the device list changes
-    std::vector<Shard> _shards;
-    std::vector<size_t> _shardOf;                           // per channel: index into _shards
+    const size_t B;
+    lorahip_demod *_d;                                      // one handle: (device, SF) parts inside the library
+    std::vector<int32_t> _sfs;                              // per channel
+    std::vector<int> _devices;
+    unsigned char _sync; double _thresh; size_t _mtu;       // the setters' values, re-applied when the object is rebuilt
     size_t _maxWindows, _fftCap, _fftDropped;
-    std::vector<cf32> _raw, _dec, _fft;          // host staging of the three ports, [channel][capacity]
+    bool _debugPorts, _signals, _active;
+    std::vector<Pothos::InputPort *> _in;
+    std::vector<Pothos::OutputPort *> _msg, _raw, _dec, _fft;
+    std::vector<const float *> _streams; std::vector<size_t> _avail; std::vector<int64_t> _consumed;
+    std::vector<int32_t> _pkCh; std::vector<int64_t> _pkLen; std::vector<int16_t> _pkSyms;
+    std::vector<int32_t> _sigCh, _sigErr; std::vector<float> _sigPow, _sigSnr;
+    std::vector<cf32> _stRaw, _stDec, _stFft;               // host staging of the three ports, [channel][capacity]
 };
 
 static Pothos::BlockRegistry registerLoRaDemodBatch("/lora/lora_demod_batch", &LoRaDemodBatch::make);

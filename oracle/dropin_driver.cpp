@@ -7,8 +7,10 @@
 // so the `loraref_demod_*` entry points of this library run the verbatim block on the HIP detector.
 // tests/test_gpu_dropin.py compares both with the recorded behaviour of the unpatched reference.
 #include <Pothos/Framework.hpp>
+#include <chrono>
 #include <complex>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,7 +34,28 @@ struct BatchHandle
     std::vector<std::vector<cf32>> rawBuf, decBuf, fftBuf;      // the framework's port buffers
     std::vector<ChanLog> log;
     int64_t works;
+    bool ports, ready;
+    std::vector<size_t> need;                                   // per channel: 2N, what a work() call of that channel wants (LoRaDemod.cpp:148)
 };
+
+//! after the last setter, before the first work(): the framework allocates the port buffers the block's buffer-manager hook asks for
+//! (only where the debug ports are on: 3 x B buffers), then activates the block
+static void prepare(BatchHandle *h)
+{
+    if (h->ready) return;
+    for (size_t c = 0; c < h->B && h->ports; c++)
+    {
+        const std::string s = std::to_string(c);
+        const size_t nbRaw = h->block->getOutputBufferManager("raw" + s, "")->args.bufferSize;
+        const size_t nbFft = h->block->getOutputBufferManager("fft" + s, "")->args.bufferSize;
+        h->rawBuf[c].resize(nbRaw / sizeof(cf32)); h->decBuf[c].resize(nbRaw / sizeof(cf32)); h->fftBuf[c].resize(nbFft / sizeof(cf32));
+        h->block->output("raw" + s)->_buff = Pothos::BufferChunk::view(h->rawBuf[c].data(), nbRaw);
+        h->block->output("dec" + s)->_buff = Pothos::BufferChunk::view(h->decBuf[c].data(), nbRaw);
+        h->block->output("fft" + s)->_buff = Pothos::BufferChunk::view(h->fftBuf[c].data(), nbFft);
+    }
+    h->block->activate();
+    h->ready = true;
+}
 
 } // namespace
 
@@ -45,22 +68,11 @@ void *loradrop_batch_new(const size_t sf, const size_t channels, const size_t ma
     auto h = new BatchHandle();
     try { h->block = it->second(sf, channels); }
     catch (const std::exception &) { delete h; return nullptr; }
-    h->N = size_t(1) << sf; h->B = channels; h->maxWindows = maxWindows; h->works = 0;
+    h->N = size_t(1) << sf; h->B = channels; h->maxWindows = maxWindows; h->works = 0; h->ports = false; h->ready = false;
     h->block->calls.at("setMaxWindows")(double(maxWindows));
     h->rawBuf.resize(channels); h->decBuf.resize(channels); h->fftBuf.resize(channels); h->log.resize(channels);
-    for (size_t c = 0; c < channels; c++)
-    {
-        const std::string s = std::to_string(c);
-        // buffers of the size the block's buffer-manager hook asks for, like the framework would allocate them
-        const size_t nbRaw = h->block->getOutputBufferManager("raw" + s, "")->args.bufferSize;
-        const size_t nbFft = h->block->getOutputBufferManager("fft" + s, "")->args.bufferSize;
-        h->rawBuf[c].resize(nbRaw / sizeof(cf32)); h->decBuf[c].resize(nbRaw / sizeof(cf32)); h->fftBuf[c].resize(nbFft / sizeof(cf32));
-        h->block->output("raw" + s)->_buff = Pothos::BufferChunk::view(h->rawBuf[c].data(), nbRaw);
-        h->block->output("dec" + s)->_buff = Pothos::BufferChunk::view(h->decBuf[c].data(), nbRaw);
-        h->block->output("fft" + s)->_buff = Pothos::BufferChunk::view(h->fftBuf[c].data(), nbFft);
-        h->log[c].consumed = 0;
-    }
-    h->block->activate();
+    for (size_t c = 0; c < channels; c++) h->log[c].consumed = 0;
+    h->need.assign(channels, 2 * h->N);
     return h;
 }
 
@@ -76,7 +88,8 @@ int loradrop_batch_set(void *p, const char *name, const double v)
     auto h = reinterpret_cast<BatchHandle *>(p);
     auto it = h->block->calls.find(name);
     if (it == h->block->calls.end()) return -1;
-    it->second(v);
+    try { it->second(v); } catch (const std::exception &) { return -2; }
+    if (std::string(name) == "setDebugPorts") h->ports = v != 0.0;
     return 0;
 }
 
@@ -87,6 +100,13 @@ int loradrop_batch_set_string(void *p, const char *name, const char *v)
     auto it = h->block->stringCalls.find(name);
     if (it == h->block->stringCalls.end()) return -1;
     try { it->second(v); } catch (const std::exception &) { return -2; }
+    if (std::string(name) == "setSpreadFactors")
+    {
+        // the same list the block parsed (comma separated, repeating): the scheduler's per-channel reserve
+        std::vector<size_t> pat;
+        for (const char *q = v; *q; ) { pat.push_back(size_t(std::strtol(q, nullptr, 10))); while (*q && *q != ',') q++; if (*q == ',') q++; }
+        for (size_t c = 0; c < h->B && !pat.empty(); c++) h->need[c] = size_t(2) << pat[c % pat.size()];
+    }
     return 0;
 }
 
@@ -95,7 +115,8 @@ int loradrop_batch_set_string(void *p, const char *name, const char *v)
 int64_t loradrop_batch_run(void *p, const float *iq, const size_t samplesPerChannel)
 {
     auto h = reinterpret_cast<BatchHandle *>(p);
-    const size_t N = h->N, B = h->B;
+    const size_t B = h->B;
+    prepare(h);
     std::vector<size_t> pos(B, 0);
     while (true)
     {
@@ -106,7 +127,7 @@ int64_t loradrop_batch_run(void *p, const float *iq, const size_t samplesPerChan
             in->_elems = samplesPerChannel - pos[c];
             in->_buff = Pothos::BufferChunk::view(const_cast<float *>(iq) + 2 * (c * samplesPerChannel + pos[c]), in->_elems * sizeof(cf32));
             in->consumed = 0;
-            any = any || in->_elems >= 2 * N;
+            any = any || in->_elems >= h->need[c];
             const std::string s = std::to_string(c);
             for (const char *port : { "raw", "dec", "fft" }) { auto o = h->block->output(port + s); o->produced = 0; o->labels.clear(); }
         }
@@ -138,6 +159,66 @@ int64_t loradrop_batch_run(void *p, const float *iq, const size_t samplesPerChan
         if (progressed == 0) break;     // cannot happen; guards the loop
     }
     return h->works;
+}
+
+/*! The block as a receiver, timed: the channels' samples ARRIVE in chunks of `chunk` per channel (a source block upstream); after every
+ * arrival the scheduler calls work() with what each input holds -- the unconsumed remainder and the new samples, in ordinary host
+ * memory -- until no input has 2N left. Messages and signals are counted and dropped (a sink downstream). Nothing is recorded.
+ * out[0] = seconds inside the loop, out[1] = work() calls of the block, out[2] = packets posted, out[3] = samples consumed (all
+ * channels), out[4] = signal emissions. */
+int loradrop_batch_bench(void *p, const float *iq, const size_t samplesPerChannel, const size_t chunk, double *out)
+{
+    auto h = reinterpret_cast<BatchHandle *>(p);
+    const size_t B = h->B;
+    prepare(h);
+    std::vector<size_t> pos(B, 0);
+    std::vector<Pothos::InputPort *> in(B);
+    std::vector<Pothos::OutputPort *> msg(B);
+    for (size_t c = 0; c < B; c++) { in[c] = h->block->input(int(c)); msg[c] = h->block->output(int(c)); }
+    double works = 0, packets = 0, consumed = 0;
+    const size_t sig0 = h->block->signals.size();
+    const auto t0 = std::chrono::steady_clock::now();
+    try
+    {
+        for (size_t w = chunk < samplesPerChannel ? chunk : samplesPerChannel; ; w = w + chunk < samplesPerChannel ? w + chunk : samplesPerChannel)
+        {
+            while (true)
+            {
+                bool any = false;
+                for (size_t c = 0; c < B; c++)
+                {
+                    in[c]->_elems = w - pos[c];
+                    in[c]->_buff = Pothos::BufferChunk::view(const_cast<float *>(iq) + 2 * (c * samplesPerChannel + pos[c]), in[c]->_elems * sizeof(cf32));
+                    in[c]->consumed = 0;
+                    any = any || in[c]->_elems >= h->need[c];
+                }
+                if (!any) break;
+                if (h->ports)
+                    for (size_t c = 0; c < B; c++)
+                    {
+                        const std::string s = std::to_string(c);
+                        for (const char *port : { "raw", "dec", "fft" }) { auto o = h->block->output(port + s); o->produced = 0; o->labels.clear(); }
+                    }
+                h->block->work();
+                works += 1;
+                size_t progressed = 0;
+                for (size_t c = 0; c < B; c++)
+                {
+                    packets += double(msg[c]->messages.size());
+                    msg[c]->messages.clear();
+                    pos[c] += in[c]->consumed; progressed += in[c]->consumed;
+                }
+                consumed += double(progressed);
+                if (progressed == 0) break;
+            }
+            if (w >= samplesPerChannel) break;
+        }
+    }
+    catch (const std::exception &) { return -2; }
+    out[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    out[1] = works; out[2] = packets; out[3] = consumed; out[4] = double(h->block->signals.size() - sig0);
+    h->block->signals.clear();
+    return 0;
 }
 
 size_t loradrop_batch_count(void *p, const size_t c, const char *what)

@@ -456,6 +456,8 @@ class DropInBatch:
         L.loradrop_batch_set_string.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.loradrop_batch_run.restype = C.c_int64
         L.loradrop_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.loradrop_batch_bench.restype = C.c_int
+        L.loradrop_batch_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]
         L.loradrop_batch_count.restype = C.c_size_t
         L.loradrop_batch_count.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p]
         L.loradrop_batch_get_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_void_p]
@@ -480,8 +482,23 @@ class DropInBatch:
 
     __del__ = close
 
-    def set(self, name, v):
-        assert self.L.loradrop_batch_set(self.h, name.encode(), float(v)) == 0, name
+    def set(self, name, v, may_fail=False):
+        """a registered call with a numeric / bool argument; with may_fail the code is returned (0, -1 unknown call, -2 the block threw)"""
+        rc = int(self.L.loradrop_batch_set(self.h, name.encode(), float(v)))
+        if not may_fail:
+            assert rc == 0, (name, rc)
+        return rc
+
+    def bench(self, iq, chunk):
+        """the block as a receiver, timed (oracle/dropin_driver.cpp::loradrop_batch_bench): iq (channels, samples) complex64 in ordinary
+        host memory arrives `chunk` samples per channel at a time. -> dict(seconds, works, packets, consumed, signals)"""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        assert iq.shape[0] == self.B
+        out = (C.c_double * 5)()
+        rc = self.L.loradrop_batch_bench(self.h, iq.ctypes.data, iq.shape[1], int(chunk), out)
+        if rc != 0:
+            raise RuntimeError("LoRaDemodBatch::work() threw")
+        return dict(seconds=out[0], works=int(out[1]), packets=int(out[2]), consumed=int(out[3]), signals=int(out[4]))
 
     def set_string(self, name, v):
         """a registered call with a string argument (setDevices); returns 0, -1 unknown call, -2 the block threw"""

@@ -38,7 +38,7 @@ def test_struct_layout_matches_header():
 
 def test_version_and_errors():
     lib = L.load()
-    assert lib.lorahip_version() == 2
+    assert lib.lorahip_version() == 3
     assert lib.lorahip_selfcheck() == 0, lib.lorahip_last_error()     # every kernel's LDS exchange layout is injective
     assert lib.lorahip_strerror(0) == b"ok"
     assert lib.lorahip_strerror(-5) == b"device is not gfx950"

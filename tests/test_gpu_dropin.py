@@ -110,7 +110,9 @@ def test_batch_block_posts_what_the_reference_block_posts(gpu, golden, oracle, s
     blk = DropInBatch(sf, 3, max_windows=16)                    # small buffers: several work() calls of the block per stream
     if devices:
         assert blk.set_string("setDevices", "0,x") == -2        # Pothos::InvalidArgumentException, like the sibling blocks' setters
-        assert blk.set_string("setDevices", devices) == 0
+        assert blk.set_string("setDevices", "0,99") == -2       # a device that does not exist: the block keeps what it had ...
+        assert blk.set_string("setDevices", devices) == 0       # ... and can still be configured
+    blk.set("setDebugPorts", 1)                                 # the reference's raw / dec / fft outputs are opt-in here
     blk.set("setMTU", mtu)
     chans, signals, works = blk.run(iq)
     assert works > 1
@@ -160,3 +162,115 @@ def test_oracle_equals_the_reference_on_this_box(gpu, oracle, ref):
     T.test_demod_sync_word_and_squelch(oracle, ref)
     for sf in (7, 10, 12):
         T.test_decoder_matches_verbatim_block(oracle, ref, sf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sf,devices", [(7, None), (10, "0,0"), (12, None)])
+def test_batch_block_without_debug_ports(gpu, golden, oracle, sf, devices):
+    """The block as a receiver -- its default: no raw / dec / fft outputs, no per-call trace, nothing per call across PCIe. What it
+    consumes, the packets it posts and the signals it emits (from the kernels' per-packet records, lorahip_demod_set_signals) equal
+    the unpatched reference block's; the stream outputs stay untouched."""
+    from oracle.oracle import Ref, REF_VARIANTS, DropInBatch
+    _need(REF_VARIANTS["dropin"])
+    _need(REF_VARIANTS["-O2"])
+    rng = np.random.default_rng(100 + sf)
+    if sf == 10:
+        N, mtu = 1 << sf, 11
+        parts = [np.zeros(N // 3 + 5, np.complex64)]
+        for _ in range(3):
+            parts.append(oracle.mod_frame(sf, rng.integers(0, N, mtu).astype(np.uint16), padding=3))
+        x = np.concatenate(parts + [np.zeros(2 * N, np.complex64)])
+        x = (x * np.exp(2j * np.pi * 0.21 / N * np.arange(x.size))).astype(np.complex64)
+        x += (0.05 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))).astype(np.complex64)
+        iq = np.stack([x, np.roll(x, 57), np.roll(x, 411)])
+    else:
+        iq, mtu = streams_for(golden, oracle, sf, rng)
+    blk = DropInBatch(sf, 3, max_windows=16)
+    if devices:
+        assert blk.set_string("setDevices", devices) == 0
+    blk.set("setMTU", mtu)
+    chans, signals, works = blk.run(iq)
+    assert works == 1                                           # everything an input holds in ONE work() of the block
+    ref = Ref("-O2")
+    sig_by_channel = {}
+    cur = None
+    for name, v in signals:
+        if name == "channel":
+            cur = int(v)
+        else:
+            sig_by_channel.setdefault(cur, []).append((name, v))
+    for c in range(3):
+        want = ref.demod_run(sf, iq[c], mtu=mtu)
+        got = chans[c]
+        assert got["consumed"] == int(want["consumed"].sum())
+        assert got["raw"].size == 0 and got["dec"].size == 0 and got["fft"].size == 0
+        assert got["raw_labels"] == [] and got["fft_labels"] == []
+        assert len(got["packets"]) == len(want["packets"]) >= 2
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got["packets"], want["packets"]))
+        ws = want["signals"]
+        gs = sig_by_channel.get(c, [])
+        assert [n for n, _ in gs] == [n for n, _ in ws]
+        assert np.allclose([v for _, v in gs], [v for _, v in ws], rtol=0, atol=TOL_DB)
+    # the same samples arriving in pieces (the receiver shape the bench times): same packets, same consumption
+    blk2 = DropInBatch(sf, 3, max_windows=16)
+    blk2.set("setMTU", mtu)
+    r = blk2.bench(iq, 5 << sf)
+    assert r["works"] > 2
+    assert r["packets"] == sum(len(ch["packets"]) for ch in chans)
+    assert r["consumed"] == sum(ch["consumed"] for ch in chans)
+    assert r["signals"] == len(signals)
+    # a device list cannot change under a running receiver (the channels' state would be lost): refused, block intact
+    assert blk2.set_string("setDevices", "0,0") == -2
+    blk.close()
+    blk2.close()
+
+
+@pytest.mark.gpu
+def test_batch_block_with_a_spreading_factor_per_channel(gpu, oracle):
+    """setSpreadFactors: six channels SF7..12 behind ONE block (lorahip_demod_create_mixed inside), over two "devices"; every
+    channel's packets, signals and consumption equal a reference block of that channel's SF"""
+    from oracle.oracle import Ref, REF_VARIANTS, DropInBatch
+    _need(REF_VARIANTS["dropin"])
+    _need(REF_VARIANTS["-O2"])
+    rng = np.random.default_rng(77)
+    sfs = [7, 8, 9, 10, 11, 12]
+    mtu = 6
+    streams = []
+    for sf in sfs:
+        N = 1 << sf
+        parts = [np.zeros(N // 2 + 3, np.complex64)]
+        for _ in range(2):
+            parts.append(oracle.mod_frame(sf, rng.integers(0, N, mtu).astype(np.uint16), padding=3))
+        x = np.concatenate(parts + [np.zeros(2 * N, np.complex64)])
+        x = (x * np.exp(2j * np.pi * 0.17 / N * np.arange(x.size))).astype(np.complex64)
+        x += (0.04 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))).astype(np.complex64)
+        streams.append(x)
+    n = max(s.size for s in streams)
+    iq = np.zeros((6, n), np.complex64)
+    for i, s in enumerate(streams):
+        iq[i, :s.size] = s
+    blk = DropInBatch(7, 6, max_windows=16)
+    assert blk.set_string("setSpreadFactors", "7,8,x") == -2
+    assert blk.set_string("setSpreadFactors", "7,8,9,10,11,12") == 0
+    assert blk.set_string("setDevices", "0,0") == 0
+    assert blk.set("setDebugPorts", 1, may_fail=True) == -2       # one SF only
+    blk.set("setMTU", mtu)
+    chans, signals, works = blk.run(iq)
+    ref = Ref("-O2")
+    sig_by_channel = {}
+    cur = None
+    for name, v in signals:
+        if name == "channel":
+            cur = int(v)
+        else:
+            sig_by_channel.setdefault(cur, []).append((name, v))
+    for c, sf in enumerate(sfs):
+        want = ref.demod_run(sf, iq[c], mtu=mtu)
+        got = chans[c]
+        assert got["consumed"] == int(want["consumed"].sum())
+        assert len(got["packets"]) == len(want["packets"]) == 2
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got["packets"], want["packets"]))
+        gs = sig_by_channel.get(c, [])
+        assert [n_ for n_, _ in gs] == [n_ for n_, _ in want["signals"]]
+        assert np.allclose([v for _, v in gs], [v for _, v in want["signals"]], rtol=0, atol=TOL_DB)
+    blk.close()

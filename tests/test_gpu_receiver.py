@@ -1,0 +1,230 @@
+"""GPU: the round-4 additions to level 3 of the C ABI -- signals without a trace (lorahip_demod_set_signals), the running receiver in
+one call (lorahip_demod_run_device_append / lorahip_demod_receive) and ONE object over mixed spreading factors and several devices
+(lorahip_demod_create_mixed) -- against the CPU oracle's restated block (pinned to the verbatim LoRaDemod.cpp) and against the
+paths that were there before."""
+import numpy as np
+import pytest
+
+from test_gpu_demod import frames, MODES, TOL_DB
+
+pytestmark = pytest.mark.gpu
+
+
+def _streams(oracle, rng, sf, B, n_frames=3, nsyms0=8):
+    N = 1 << sf
+    streams = [frames(oracle, rng, sf, n_frames, nsyms0 + c % 5, off=rng.uniform(-0.4, 0.4), noise=0.05, lead=int(rng.integers(0, 2 * N)))[0]
+               for c in range(B)]
+    cap = max(s.size for s in streams)
+    host = np.zeros((B, cap), np.complex64)
+    for c, s in enumerate(streams):
+        host[c, :s.size] = s
+    return host
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sf", [7, 9, 10, 11, 12])
+def test_signals_without_a_trace(gpu, oracle, sf, mode):
+    """error / power / snr at DOWNCHIRP1 (LoRaDemod.cpp:267-269) from the kernels' per-emission records: equal to the traced run's
+    sig_* fields and to the reference's values, and nothing else about the run changes (packets, consumption, call count)"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(500 + sf)
+    B = 9
+    host = _streams(oracle, rng, sf, B)
+    iq = gpu.from_numpy(host).cuda()
+    refs = [oracle.demod_run(sf, host[c], mtu=8) for c in range(B)]
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(mode); d.setMTU(8)
+    d.set_signals(True)
+    d.work(iq)
+    ch, rd, er, pw, sn = d.signals()
+    pk = d.packets(clear=False)
+    assert len(d.signals()[0]) == len(ch)                           # reading does not consume
+    d.clear_packets()
+    assert len(d.signals()[0]) == 0                                 # ... clearing does
+    calls_plain = d.work_calls()
+    # the traced run of the same object (a fresh activation on the same streams)
+    t = L.LoRaDemod(sf, n_channels=B); t.set_mode(mode); t.setMTU(8); t.set_trace(True)
+    t.work(iq)
+    assert t.work_calls() == calls_plain == sum(len(r["calls"]) for r in refs)
+    n_sig = 0
+    for c in range(B):
+        tr = t.trace_array(c)
+        want = tr[tr["signals"] != 0]
+        mine = ch == c
+        assert mine.sum() == want.size >= 3
+        assert rd[mine].tolist() == np.nonzero(tr["signals"])[0].tolist()       # the call (round) that emitted
+        assert er[mine].tolist() == want["sig_error"].tolist()
+        assert np.array_equal(pw[mine], want["sig_power"]) and np.array_equal(sn[mine], want["sig_snr"])
+        ref_sig = refs[c]["signals"]                                # (error, power, snr) per emission
+        assert er[mine].tolist() == [g[0] for g in ref_sig]
+        assert np.allclose(pw[mine], [g[1] for g in ref_sig], rtol=0, atol=TOL_DB)
+        assert np.allclose(sn[mine], [g[2] for g in ref_sig], rtol=0, atol=2 * TOL_DB)
+        n_sig += int(mine.sum())
+        assert [q.tolist() for cc, _, q in pk if cc == c] == [q.tolist() for _, q in refs[c]["packets"]]
+    assert n_sig == ch.size
+    assert t.signals()[0].size == 0                                 # signals are kept only when asked for
+    d.close(); t.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sf", [7, 10, 11])
+def test_append_runs_continue_every_channel(gpu, oracle, sf, mode):
+    """lorahip_demod_run_device_append: the (channels, capacity) buffer fills chunk by chunk, each run is given the new fill level and
+    nothing else; every channel continues at its own read position. Packets, consumption and calls are the one-shot run's and the
+    reference's; a rewind starts over and gives the same again."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(600 + sf)
+    N, B = 1 << sf, 7
+    host = _streams(oracle, rng, sf, B)
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=8) for c in range(B)]
+    buf = gpu.zeros((B, cap + 3), dtype=gpu.complex64, device="cuda")       # a row stride that is not the fill level
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(mode); d.setMTU(8)
+    for rep in range(2):
+        written, got = 0, [[] for _ in range(B)]
+        c0 = d.work_calls()
+        while written < cap:
+            n = min(cap - written, int(rng.integers(N // 2, 7 * N)))
+            buf[:, written:written + n] = gpu.from_numpy(host[:, written:written + n]).cuda()
+            written += n
+            d.work_append(buf, written)
+            for ch, _, s in d.packets():
+                got[ch].append(s)
+            pos = d.consumed_all()
+            assert ((written - pos < 2 * N) & (pos >= 0)).all()             # LoRaDemod.cpp:148: fewer than 2N left everywhere
+        for c in range(B):
+            r = refs[c]
+            assert len(got[c]) == len(r["packets"]) >= 3
+            assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"]))
+            assert d.consumed(c) == int(sum(k["consumed"] for k in r["calls"]))
+        assert d.work_calls() - c0 == sum(len(r["calls"]) for r in refs)
+        with pytest.raises(L.LoraHipError):
+            d.work_append(buf, written - 1)                                 # the fill level cannot shrink
+        d.rewind(); d.activate()
+    d.close()
+
+
+@pytest.mark.parametrize("sf", [7, 10, 12])
+def test_receive_packs_the_packets_of_every_step_on_the_device(gpu, oracle, sf):
+    """lorahip_demod_receive: append run + device-side packing (rows numbered on the device) + clear, one call per chunk; the rows of
+    all steps together are the reference's packets, those that span chunks included"""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(700 + sf)
+    N, B = 1 << sf, 11
+    host = _streams(oracle, rng, sf, B, n_frames=4)
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
+    iq = gpu.from_numpy(host).cuda()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
+    rows = d.receiver_rows(cap_packets=64, stride=16)
+    got, calls, w = [[] for _ in range(B)], 0, 0
+    while w < cap:
+        w = min(cap, w + int(rng.integers(N, 9 * N)))
+        n, k = d.receive(iq, w, rows, async_=bool(rng.integers(0, 2)))
+        gpu.cuda.synchronize()
+        calls += k
+        sy, ns, chn = rows[0][:n].cpu().numpy(), rows[1][:n].cpu().numpy(), rows[2][:n].cpu().numpy()
+        assert (np.diff(chn) >= 0).all()                                    # rows: channels ascending
+        for i in range(n):
+            assert (sy[i, ns[i]:] == 0).all()
+            got[int(chn[i])].append(sy[i, :ns[i]].copy())
+        assert d.packets() == []                                            # the queue is cleared by the call
+    for c in range(B):
+        r = refs[c]
+        assert len(got[c]) == len(r["packets"]) >= 4
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"]))
+    assert calls == sum(len(r["calls"]) for r in refs) == d.work_calls()
+    # too few rows: refused, the packets stay queued
+    d.rewind(); d.activate()
+    small = d.receiver_rows(cap_packets=1, stride=16)
+    with pytest.raises(L.LoraHipError):
+        d.receive(iq, cap, small)
+    assert len(d.packets()) == sum(len(r["packets"]) for r in refs)
+    d.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_mixed_object_equals_single_sf_objects(gpu, oracle, devices):
+    """lorahip_demod_create_mixed: 19 channels with SF = 7 + c mod 6 behind ONE handle, over one / two / three "devices" (all device
+    0: the split, the parts' threads and streams are real, the GPU is the one a test box has). Packets, signals, consumption, call
+    counts and per-call traces with GLOBAL channel numbers equal six single-SF objects' bit for bit, and the reference's."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(900 + len(devices))
+    B = 19
+    sfs = 7 + np.arange(B) % 6
+    streams, refs = [], []
+    for c in range(B):
+        sf = int(sfs[c])
+        N = 1 << sf
+        st, _ = frames(oracle, rng, sf, 2, 6 + c % 3, off=rng.uniform(-0.4, 0.4), noise=0.05, lead=int(rng.integers(0, 2 * N)))
+        streams.append(st)
+        refs.append(oracle.demod_run(sf, st, mtu=7))
+    m = L.LoRaDemod(channel_sf=sfs, devices=devices)
+    assert m.n_channels == B and len(m.parts) == 6 * len(devices) and sorted(set(p[1] for p in m.parts)) == [7, 8, 9, 10, 11, 12]
+    assert sum(p[2] for p in m.parts) == B
+    m.setMTU(7); m.set_signals(True); m.set_trace(True)
+    m.work(streams)                                                         # host buffers, one per channel
+    pk = m.packets(clear=False)
+    sg = m.signals()
+    singles = {}
+    for sf in range(7, 13):
+        idx = np.nonzero(sfs == sf)[0]
+        s1 = L.LoRaDemod(sf, n_channels=idx.size); s1.setMTU(7); s1.set_signals(True); s1.set_trace(True)
+        s1.work([streams[c] for c in idx])
+        singles[sf] = (idx, s1)
+    for sf, (idx, s1) in singles.items():
+        pk1 = s1.packets(clear=False)
+        sg1 = s1.signals()
+        for j, c in enumerate(idx):
+            assert [q.tolist() for cc, _, q in pk if cc == c] == [q.tolist() for cc, _, q in pk1 if cc == j] == [q.tolist() for _, q in refs[c]["packets"]]
+            assert len(refs[c]["packets"]) == 2
+            a, b = sg[0] == c, sg1[0] == j
+            for f in range(1, 5):
+                assert np.array_equal(sg[f][a], sg1[f][b])
+            assert m.consumed(int(c)) == s1.consumed(j) == int(sum(k["consumed"] for k in refs[c]["calls"]))
+            assert np.array_equal(m.trace_array(int(c)), s1.trace_array(j))
+            assert m.labels(int(c)) == s1.labels(j)
+    assert m.consumed_all().tolist() == [m.consumed(c) for c in range(B)]
+    assert m.work_calls() == sum(s1.work_calls() for _, s1 in singles.values()) == sum(len(r["calls"]) for r in refs)
+    assert m.near_threshold() == tuple(sum(s1.near_threshold()[i] for _, s1 in singles.values()) for i in range(2))
+    m.clear_packets()
+    assert m.packets() == [] and m.signals()[0].size == 0
+
+    # the same channels as segments of device buffers: one buffer per device slot, every channel where its slot says
+    slot = m.device_slot_of()
+    bufs, first, cnt = [], np.zeros(B, np.int64), np.zeros(B, np.uint64)
+    for s in range(len(devices)):
+        mine = np.nonzero(slot == s)[0]
+        at, parts = 5, [np.zeros(5, np.complex64)]
+        for c in mine:
+            first[c], cnt[c] = at, streams[c].size
+            parts.append(streams[c]); at += streams[c].size
+        bufs.append(gpu.from_numpy(np.concatenate(parts)).cuda())
+    m.set_trace(False); m.activate()
+    if len(devices) == 1:
+        m.work_segments(bufs[0], first, cnt)
+    else:
+        with pytest.raises(L.LoraHipError):
+            m.work_segments(bufs[0], first, cnt)                            # one buffer cannot serve several device slots
+        m.work_segments_multi(bufs, first, cnt)
+    pk2 = m.packets()
+    for c in range(B):
+        assert [q.tolist() for cc, _, q in pk2 if cc == c] == [q.tolist() for _, q in refs[c]["packets"]]
+    # what a mixed object does not offer says so
+    with pytest.raises(L.LoraHipError):
+        m.work(gpu.zeros((B, 64), dtype=gpu.complex64, device="cuda"))      # lorahip_demod_run_device: one uniform array
+    with pytest.raises(L.LoraHipError):
+        m.set_ports(fft_frames=4)
+    for _, s1 in singles.values():
+        s1.close()
+    m.close()
+
+
+def test_mixed_object_rejects_bad_arguments(gpu):
+    import lora_sdr_amd as L
+    with pytest.raises(L.LoraHipError):
+        L.LoRaDemod(channel_sf=[7, 13], devices=[0])
+    with pytest.raises(L.LoraHipError):
+        L.LoRaDemod(channel_sf=[7, 8], devices=[99])
+    m = L.LoRaDemod(channel_sf=[9, 9, 9, 9, 9], devices=[0, 0])             # one SF over two "devices": debug ports are offered
+    assert m.sf == 9 and len(m.parts) == 2
+    m.close()
