@@ -551,7 +551,7 @@ def section_level3(env, L, sf, threads=32):
                 running = ent_
                 running["entry"] = "lorahip_demod_receive (C ABI): one call per chunk"
                 running["near_squelch"], running["near_step"] = d.near_threshold()     # of the last pass (activate() resets the counters)
-                running["same_calls_and_packets_as_one_shot"] = bool(rb[1] == calls and rb[2] == n_dev)
+                running["same_packets_as_one_shot"] = bool(rb[2] == n_dev)
             else:
                 running["chunk8"] = ent_
         d.rewind()
