@@ -105,14 +105,15 @@ struct lorahip_demod
     bool append;                     // the current run continues every channel's stream where the last append run left it
     bool appendFresh;                // ... unless nothing has been appended yet (create, rewind, any other kind of run in between)
     size_t appendPrev;               // samples per channel the last append run was given
-    hipEvent_t evCarry;              // recorded behind carrySave: a later switch of the launch stream waits on it (cross-stream order of dCarry)
-    bool carryEvValid;
+    bool headStale;                  // the pinned copy of the per-channel state and counts (sHost) lags the device: ensureHead() fetches it
+    StreamSummary lastSum;           // of the last streaming launch (valid while devStateFresh)
+    unsigned nearSeen[2];            // the kernels' running near-threshold counters as last read
     bool geomApplied;                // ch[].base / len / pos hold the current run's placement
     bool posOnDevice;                // the pinned state copy's `pos` belongs to the CURRENT placement (a streaming run filled it; a new
                                      // lorahip_demod_run[_device] call invalidates it: its streams start at sample 0)
     bool portCountsDirty;            // ch[].portFft / portDec / portRaw may be non-zero
-    // The symbols of the packet a channel is INSIDE when a streaming run ends stay on the device too: carrySave leaves them in dCarry,
-    // carryLoad puts them at the head of the channel's symbol row before the next run, whose kernel appends behind them -- a packet
+    // The symbols of the packet a channel is INSIDE when a streaming run ends stay on the device too: the kernel leaves them in dCarry
+    // and copies them to the head of the channel's symbol row at the start of the next run, then appends behind them -- a packet
     // that spans runs is assembled without the host (the running receiver: lorahip_demod_run_device_segments + packets_to_device).
     short *dCarry; size_t carryCap;  // [B][carryCap]
     bool devCarryValid;              // dCarry holds the open packets of the state on the device
@@ -402,7 +403,7 @@ struct StreamLayout
 {
     size_t B, cap, capPkt, symStride;
     bool tracing, signals;
-    size_t oBase, oLen, oState, oN, oNSym, oNPkt, oNSig, oNear, oPkt, oSym, oSig, oCalls, total;
+    size_t oBase, oLen, oState, oN, oNSym, oNPkt, oNSig, oNear, oSum, oPkt, oSym, oSig, oCalls, total;
     void make(const size_t B_, const size_t cap_, const size_t capPkt_, const bool tracing_, const size_t carryCap_ = 0, const bool signals_ = false)
     {
         B = B_; cap = cap_; capPkt = capPkt_; tracing = tracing_; signals = signals_;
@@ -413,6 +414,7 @@ struct StreamLayout
         oState = carve(B * sizeof(StreamState));
         oN = carve(B * sizeof(int)); oNSym = carve(B * sizeof(int)); oNPkt = carve(B * sizeof(int)); oNSig = carve(B * sizeof(int));
         oNear = carve(2 * sizeof(unsigned));
+        oSum = carve(sizeof(StreamSummary));
         oPkt = carve(B * capPkt * sizeof(StreamPacket));
         oSym = carve(B * symStride * sizeof(short));
         oSig = carve(signals ? B * capPkt * sizeof(StreamSignal) : 0);
@@ -468,11 +470,33 @@ static void orderNewPackets(lorahip_demod *dm, const size_t firstNewPacket, cons
                          [](const Packet &x, const Packet &y) { return x.round != y.round ? x.round < y.round : x.channel < y.channel; });
 }
 
+//! the head of the streaming buffers inside dm->sHost: offsets that depend on the channel count only (StreamLayout::make)
+static StreamLayout headLayout(const lorahip_demod *dm)
+{
+    StreamLayout L;
+    L.make(dm->B, 8, 4, false);
+    return L;
+}
+
+//! The per-channel state and counts of the last streaming launch into their pinned copy (52 B per channel): a run itself reads back
+//! only its summary; whoever needs the arrays -- the Channel mirrors, consumed(), a drain of the records -- asks here first.
+static int ensureHead(lorahip_demod *dm)
+{
+    if (!dm->headStale || dm->sHost == nullptr || dm->sDev == nullptr) return LORAHIP_OK;
+    const StreamLayout L = headLayout(dm);
+    const DeviceGuard guard(dm->ctx->device);
+    LORAHIP_TRY(hipMemcpyAsync(dm->sHost + L.oState, dm->sDev + L.oState, L.oPkt - L.oState, hipMemcpyDeviceToHost, dm->ctx->stream));
+    LORAHIP_TRY(hipStreamSynchronize(dm->ctx->stream));
+    dm->headStale = false;
+    return LORAHIP_OK;
+}
+
 //! records of one launch (still in dm->sDev; the counts in dm->sHost) -> the host queue, the per-channel traces and open packets
 static int drainLaunch(lorahip_demod *dm, const StreamLayout &L)
 {
     lorahip_ctx *ctx = dm->ctx;
     const size_t B = L.B;
+    { const int rc = ensureHead(dm); if (rc != LORAHIP_OK) return rc; }
     char *h = dm->sHost, *d = dm->sDev;
     const int *hN = reinterpret_cast<int *>(h + L.oN), *hNSym = reinterpret_cast<int *>(h + L.oNSym), *hNPkt = reinterpret_cast<int *>(h + L.oNPkt);
     std::vector<size_t> &carry = carryOf(dm);
@@ -568,12 +592,9 @@ static int drainPending(lorahip_demod *dm)
     return LORAHIP_OK;
 }
 
-//! the head of the streaming buffers inside dm->sHost: offsets that depend on the channel count only (StreamLayout::make)
 static StreamState *hostStates(lorahip_demod *dm)
 {
-    StreamLayout L;
-    L.make(dm->B, 8, 4, false);
-    return reinterpret_cast<StreamState *>(dm->sHost + L.oState);
+    return reinterpret_cast<StreamState *>(dm->sHost + headLayout(dm).oState);
 }
 
 //! the open packets' symbols the device holds (dCarry) into the mirrors' outSymbols; the mirrors' state must be current
@@ -608,6 +629,7 @@ static int syncMirrors(lorahip_demod *dm)
 {
     if (dm->mirrorsStale && dm->sHost)
     {
+        { const int rc = ensureHead(dm); if (rc != LORAHIP_OK) return rc; }
         const StreamState *hs = hostStates(dm);
         for (size_t c = 0; c < dm->B; c++)
         {
@@ -692,31 +714,42 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         if (dm->sHost) { (void)hipHostFree(dm->sHost); dm->sHost = nullptr; }
         dm->sBytes = 0;
         dm->devStateFresh = false;
+        dm->headStale = false;                       // (syncMirrors has read what there was)
         // a quarter more than this run needs: the chunks of a running receiver differ by the remainders they start with, and every
         // growth costs two allocations and an upload of the state
         const size_t want = L.total + L.total / 4;
         LORAHIP_TRY(hipMalloc((void **)&dm->sDev, want));
         LORAHIP_TRY(hipHostMalloc((void **)&dm->sHost, L.oPkt, hipHostMallocDefault));       // the host mirrors only the head: placement, state, counts
         dm->sBytes = want;
+        // the kernels' near-threshold counters only ever add: they start at zero with the buffers
+        LORAHIP_TRY(hipMemsetAsync(dm->sDev + L.oNear, 0, 2 * sizeof(unsigned), ctx->stream));
+        dm->nearSeen[0] = dm->nearSeen[1] = 0;
     }
     char *h = dm->sHost, *d = dm->sDev;
     long long *hBase = reinterpret_cast<long long *>(h + L.oBase), *hLen = reinterpret_cast<long long *>(h + L.oLen);
     StreamState *hState = reinterpret_cast<StreamState *>(h + L.oState);
-    const int *hN = reinterpret_cast<int *>(h + L.oN), *hNSym = reinterpret_cast<int *>(h + L.oNSym), *hNPkt = reinterpret_cast<int *>(h + L.oNPkt);
+    const StreamSummary *hSum = reinterpret_cast<const StreamSummary *>(h + L.oSum);
     std::vector<size_t> &carry = carryOf(dm);
     carry.assign(B, 0);
     bool anyCarryIn = false;
-    // A steady receiver -- run after run in this mode, device buffers, nothing touched in between -- uploads nothing: the state is
-    // where the last run left it on the device, the placement of uniform streams is computed by the kernel, every run starts at
-    // sample 0 of its buffer (flag `fresh`), and an activate() in between travels as a flag too.
+    size_t maxCarry = 0;
+    // A steady receiver -- run after run in this mode, device buffers, nothing touched in between -- uploads nothing and reads back
+    // 64 bytes: the state is where the last run left it on the device, the placement of uniform streams is computed by the kernel,
+    // an activate() in between travels as a flag, the open packets' symbols are in the device's carry rows, and what the host needs
+    // to know of the last run is its summary (streamSummary). The per-channel state and counts are fetched when somebody asks.
     const bool resident = dm->devStateFresh;
     const bool activate = resident && dm->activatePending;
     if (resident)
     {
-        // symbols of a packet that is still being received when the run starts (see below): from the pinned copy of the state
-        if (!activate)
-            for (size_t c = 0; c < B; c++)
-                if (hState[c].state == ST_DATASYMBOLS && hState[c].symCount) { carry[c] = size_t(hState[c].symCount); anyCarryIn = true; }
+        // symbols of packets that are still being received when the run starts: the last summary says whether there are any
+        if (!activate && dm->lastSum.anyOpen && dm->lastSum.openSyms > 0) { anyCarryIn = true; maxCarry = size_t(dm->lastSum.maxOpen); }
+        // which channels, and how many symbols each, only matters where the HOST hands them on
+        const bool perChannel = anyCarryIn && (!useDevCarry || maxCarry >= dm->carryCap || !dm->devCarryValid);
+        if (perChannel)
+        {
+            { const int rc = ensureHead(dm); if (rc != LORAHIP_OK) return rc; }
+            for (size_t c = 0; c < B; c++) if (hState[c].state == ST_DATASYMBOLS && hState[c].symCount) carry[c] = size_t(hState[c].symCount);
+        }
     }
     else
     {
@@ -734,16 +767,15 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
             // QUARTERCHIRP (:279), so outside DATASYMBOLS it still holds the length of the LAST packet: nothing is carried then
             carry[c] = k.state == ST_DATASYMBOLS ? k.symCount : 0;
             anyCarryIn = anyCarryIn || carry[c] != 0;
+            if (carry[c] > maxCarry) maxCarry = carry[c];
         }
         LORAHIP_TRY(hipMemcpyAsync(d + L.oState, h + L.oState, L.oN - L.oState, hipMemcpyHostToDevice, ctx->stream));
+        dm->headStale = false;                        // the pinned copy IS what the device is being given
     }
-    // Where do the symbols of those packets come from? From the device's own copy (dCarry: carryLoad puts them at the head of the
-    // channels' symbol rows and the kernel appends behind them: the host sees packets without a past), unless a packet is longer
-    // than its rows -- then from the mirrors' outSymbols, as the launches of a resumed run do among themselves.
-    size_t maxCarry = 0;
-    for (size_t c = 0; c < B; c++) if (carry[c] > maxCarry) maxCarry = carry[c];
+    // Where do the symbols of those packets come from? From the device's own copy (the carry rows: the kernel copies a channel's open
+    // packet to the head of its symbol row and appends behind it, so the host sees packets without a past), unless a packet is
+    // longer than those rows -- then from the mirrors' outSymbols, as the launches of a resumed run do among themselves.
     if (useDevCarry && maxCarry >= dm->carryCap) useDevCarry = false;
-    bool loadCarry = false;
     if (useDevCarry)
     {
         if (anyCarryIn && !dm->devCarryValid)
@@ -757,7 +789,6 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
             LORAHIP_TRY(hipMemcpyAsync(dm->dCarry, stage, B * cc * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
             LORAHIP_TRY(hipStreamSynchronize(ctx->stream));       // the pinned scratch is reused
         }
-        loadCarry = anyCarryIn;
         carry.assign(B, 0);
         anyCarryIn = false;                           // as far as the host's assembly of packets is concerned
     }
@@ -780,8 +811,13 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.len = reinterpret_cast<const long long *>(d + L.oLen);
     a.uniformLen = dm->uniform ? (long long)dm->uniSpc : -1;
     a.uniformStride = (long long)dm->uniStride;
-    // first launch of the run: every channel starts at sample 0, call 0 (unless the run continues the streams), behind its open packet's symbols
-    a.flags = (cont ? 0 : 1) | (activate ? 2 : 0) | (useDevCarry ? 4 : 0);
+    // first launch of the run: every channel starts at sample 0, call 0 (unless the run continues the streams), behind its open packet's
+    // symbols, and leaves the packet it is inside at the end in the carry rows
+    a.flags = (cont ? 0 : 1) | (activate ? 2 : 0) | (useDevCarry ? 4 | 8 : 0);
+    a.carry = dm->dCarry; a.carryCap = int(dm->carryCap);
+    // the resident number of workgroups (two wavefronts per SIMD: 256 threads x 2 per CU, or 512 threads' worth of smaller ones)
+    a.maxBlocks = ctx->cuCount > 0 ? ctx->cuCount * (ctx->sf == 11 ? 4 : 2) : 0;
+    if (const char *e = std::getenv("LORAHIP_STREAM_BLOCKS")) a.maxBlocks = std::atoi(e);        // measurement hook: 0 = one workgroup per channel set
     a.state = reinterpret_cast<StreamState *>(d + L.oState);
     a.nCalls = reinterpret_cast<int *>(d + L.oN);
     a.nSym = reinterpret_cast<int *>(d + L.oNSym);
@@ -812,44 +848,33 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     dm->kernelMs = 0.0;
     if (dm->evK0 == nullptr) { LORAHIP_TRY(hipEventCreate(&dm->evK0)); LORAHIP_TRY(hipEventCreate(&dm->evK1)); }
     bool lastPending = false;
-    size_t pendPackets = 0, pendNSym = 0, pendSignals = 0;
-    const int *hNSig = reinterpret_cast<int *>(h + L.oNSig);
     int launches = 0;
     size_t runCalls = 0;                              // calls of the fullest channel, launch by launch
-    if (loadCarry)
-        LORAHIP_TRY(launchCarryLoad(a.state, dm->dCarry, int(dm->carryCap), a.symOut, a.symStride, B, ctx->stream));
+    StreamSummary sum;
     while (true)
     {
         const Clock::time_point ta = Clock::now();
-        LORAHIP_TRY(hipMemsetAsync(d + L.oNear, 0, 2 * sizeof(unsigned), ctx->stream));
         LORAHIP_TRY(hipEventRecord(dm->evK0, ctx->stream));
         LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
         LORAHIP_TRY(hipEventRecord(dm->evK1, ctx->stream));
         a.flags = 0;                                  // a resumed launch continues where the state says
-        // the per-channel state and counts come back after every launch (52 B per channel); the record arrays only when needed
-        LORAHIP_TRY(hipMemcpyAsync(h + L.oState, d + L.oState, L.oPkt - L.oState, hipMemcpyDeviceToHost, ctx->stream));
+        // what the host needs of the launch, reduced on the device: 64 bytes come back, not 52 per channel
+        LORAHIP_TRY(launchStreamSummary(a.state, a.nCalls, a.nSym, a.nPkt, dm->wantSignals ? a.nSig : nullptr, B, int(cap), int(capPkt), a.near,
+                                        reinterpret_cast<StreamSummary *>(d + L.oSum), ctx->stream));
+        LORAHIP_TRY(hipMemcpyAsync(h + L.oSum, d + L.oSum, sizeof(StreamSummary), hipMemcpyDeviceToHost, ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+        dm->headStale = true;                         // the pinned copy of the per-channel state and counts lags the device now
         { float ms = 0.0f; if (hipEventElapsedTime(&ms, dm->evK0, dm->evK1) == hipSuccess) dm->kernelMs += ms; }
         const Clock::time_point tb = Clock::now();
         tDev += std::chrono::duration<double>(tb - ta).count();
-        bool more = false;
-        pendPackets = pendNSym = pendSignals = 0;
-        dm->nNearSquelch += reinterpret_cast<const unsigned *>(h + L.oNear)[0];
-        dm->nNearStep += reinterpret_cast<const unsigned *>(h + L.oNear)[1];
-        const int icap = int(cap), icapPkt = int(capPkt);
-        int64_t calls = 0;
-        int fullest = 0;
-        for (size_t c = 0; c < B; c++)
-        {
-            calls += hN[c];
-            if (hN[c] > fullest) fullest = hN[c];
-            pendPackets += size_t(hNPkt[c]);
-            pendNSym += size_t(hNSym[c]);
-            if (dm->wantSignals) pendSignals += size_t(hNSig[c]);
-            more = more || hN[c] == icap || hNPkt[c] == icapPkt || (dm->wantSignals && hNSig[c] == icapPkt);
-        }
-        dm->workCalls += calls;
-        runCalls += size_t(fullest);
+        sum = *hSum;
+        // the kernels' counters run on (they only add): what this launch added
+        dm->nNearSquelch += int64_t(unsigned(sum.nearSquelch - dm->nearSeen[0]));
+        dm->nNearStep += int64_t(unsigned(sum.nearStep - dm->nearSeen[1]));
+        dm->nearSeen[0] = sum.nearSquelch; dm->nearSeen[1] = sum.nearStep;
+        const bool more = sum.more != 0;
+        dm->workCalls += sum.calls;
+        runCalls += size_t(sum.fullest);
         launches++;
         // a launch that must be resumed hands its records over now (the next one reuses the buffers); so does a traced run (its
         // callers read the trace next). Otherwise the records wait on the device.
@@ -865,16 +890,12 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         if (!more) break;
     }
     const Clock::time_point t2 = Clock::now();
-    int64_t rounds = 0;
-    bool anyOpen = false;
-    size_t openSyms = 0, carriedIn = 0;
-    for (size_t c = 0; c < B; c++)
-    {
-        const StreamState &st = hState[c];
-        if (st.callCount > rounds) rounds = st.callCount;
-        if (st.state == ST_DATASYMBOLS) { anyOpen = true; openSyms += size_t(st.symCount); }
-    }
+    const int64_t rounds = sum.maxCallCount;
+    const bool anyOpen = sum.anyOpen != 0;
+    const size_t openSyms = size_t(sum.openSyms);
+    size_t carriedIn = 0;
     if (anyCarryIn || lastPending) for (size_t c = 0; c < B; c++) carriedIn += carry[c];
+    dm->lastSum = sum;
     dm->lastLaunches = launches;
     if (launches > 1 && maxLen >= N)
     {
@@ -882,20 +903,11 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         const size_t q8 = (runCalls * 256 / (maxLen / N)) * 5 / 4 + 16;
         if (q8 > dm->callsPerWindowQ8) dm->callsPerWindowQ8 = q8 > size_t(256) * 64 ? size_t(256) * 64 : q8;
     }
-    dm->devStateFresh = true;                         // the device holds what the pinned copy says; the mirrors lag (mirrorsStale)
+    dm->devStateFresh = true;                         // the device holds the current state; the pinned copy (headStale) and the mirrors lag
     dm->posOnDevice = true;
     if (useDevCarry && launches == 1)
     {
-        // the packets the channels are inside now: the last symCount entries of their symbol rows, kept for the next run
-        dm->devCarryValid = false;                    // (should the launch below fail: neither side holds them then, and the caller is told)
-        if (anyOpen)
-        {
-            LORAHIP_TRY(launchCarrySave(a.state, a.nSym, a.symOut, a.symStride, dm->dCarry, int(dm->carryCap), B, ctx->stream));
-            // carrySave is not followed by a synchronisation: whoever moves this object to another stream waits on this event there
-            if (dm->evCarry == nullptr) LORAHIP_TRY(hipEventCreateWithFlags(&dm->evCarry, hipEventDisableTiming));
-            LORAHIP_TRY(hipEventRecord(dm->evCarry, ctx->stream));
-            dm->carryEvValid = true;
-        }
+        // the packets the channels are inside now: the kernel left the last symCount entries of their symbol rows in the carry rows
         dm->devCarryValid = true;
         dm->hostCarryStale = lastPending;             // a drain (traced runs) has brought the mirrors' outSymbols up to date already
     }
@@ -907,19 +919,18 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         P.lay = L;
         P.firstNewPacket = firstNewPacket;
         P.rounds = rounds;
-        P.packets = pendPackets;
-        P.packetSyms = carriedIn + pendNSym - openSyms;     // symbols of the packets completed by this launch
-        P.signals = pendSignals;
+        P.packets = size_t(sum.packets);
+        P.packetSyms = carriedIn + size_t(sum.syms) - openSyms;     // symbols of the packets completed by this launch
+        P.signals = size_t(sum.signals);
         P.anyCarryIn = anyCarryIn;
         P.anyOpen = anyOpen;
         P.drainMs = 0.0;
     }
     else orderNewPackets(dm, firstNewPacket, rounds);
-    if (dm->append) { dm->appendFresh = false; dm->appendPrev = dm->uniSpc; }
     if (roundsOut) *roundsOut = rounds;
     if (timing)
-        std::fprintf(stderr, "lorahip demod run: setup+H2D %.3f ms%s, kernel+state D2H+sync %.3f ms, record drain %.3f ms%s, state scan %.3f ms\n",
-                     std::chrono::duration<double>(t1 - t0).count() * 1e3, resident ? " (state resident on the device)" : "", tDev * 1e3, tAsm * 1e3,
+        std::fprintf(stderr, "lorahip demod run: setup+H2D %.3f ms%s, kernel+summary D2H+sync %.3f ms (kernel %.3f), record drain %.3f ms%s, rest %.3f ms\n",
+                     std::chrono::duration<double>(t1 - t0).count() * 1e3, resident ? " (state resident on the device)" : "", tDev * 1e3, dm->kernelMs, tAsm * 1e3,
                      lastPending ? " (last launch left on the device)" : "", std::chrono::duration<double>(Clock::now() - t2).count() * 1e3);
     return LORAHIP_OK;
 }
@@ -1098,6 +1109,7 @@ static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     if (!stream) { dm->kernelMs = 0.0; dm->lastLaunches = 0; }       // what the accessors say of a host-driven run
     int rc = stream ? runStream(dm, iqDev, roundsOut) : runRounds(dm, iqDev, roundsOut);
     if (rc == LORAHIP_OK && dm->portsOn) rc = fillPorts(dm, iqDev);
+    if (rc == LORAHIP_OK && dm->append) { dm->appendFresh = false; dm->appendPrev = dm->uniSpc; }    // the next append run continues this one
     if (internalTrace) for (auto &k : dm->ch) { std::vector<lorahip_work_result>().swap(k.trace); k.traceStart = 0; }
     return rc;
 }
@@ -1131,7 +1143,8 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->nNearSquelch = dm->nNearStep = 0;
     dm->devStateFresh = false; dm->mirrorsStale = false; dm->activatePending = false;
     dm->uniform = false; dm->uniSpc = 0; dm->uniStride = 0; dm->geomApplied = true; dm->portCountsDirty = true; dm->posOnDevice = false;
-    dm->append = false; dm->appendFresh = true; dm->appendPrev = 0; dm->evCarry = nullptr; dm->carryEvValid = false;
+    dm->append = false; dm->appendFresh = true; dm->appendPrev = 0; dm->headStale = false; dm->nearSeen[0] = dm->nearSeen[1] = 0;
+    std::memset(&dm->lastSum, 0, sizeof(dm->lastSum));
     dm->wantSignals = false;
     dm->lastLaunches = 0;
     dm->dCarry = nullptr; dm->carryCap = 0; dm->devCarryValid = false; dm->hostCarryStale = false;
@@ -1220,7 +1233,6 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->ownRaw) (void)hipFree(dm->ownRaw);
     if (dm->evK0) (void)hipEventDestroy(dm->evK0);
     if (dm->evK1) (void)hipEventDestroy(dm->evK1);
-    if (dm->evCarry) (void)hipEventDestroy(dm->evCarry);
     }
     lorahip_destroy(dm->ctx);
     delete static_cast<PendingLaunch *>(dm->pending);
@@ -1259,30 +1271,20 @@ int lorahip_demod_set_mode(lorahip_demod *dm, const int mode)
     return LORAHIP_OK;
 }
 
-//! a run leaves one kernel behind that nothing has waited for (carrySave, which writes dCarry from the symbol rows): work queued on
-//! the stream the object moves to -- carryLoad, the next streaming kernel, a copy of dCarry to the host -- is ordered behind it
-static int orderBehindCarry(lorahip_demod *dm)
-{
-    if (!dm->carryEvValid) return LORAHIP_OK;
-    const DeviceGuard guard(dm->ctx->device);
-    LORAHIP_TRY(hipStreamWaitEvent(dm->ctx->stream, dm->evCarry, 0));
-    return LORAHIP_OK;
-}
-
+// (A streaming run leaves nothing in flight: the open packets' symbols are saved by the streaming kernel itself and the run ends with
+// its stream drained, so moving the object to another stream needs no ordering.)
 int lorahip_demod_set_stream(lorahip_demod *dm, void *hip_stream)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) return dm->comp->setStream(hip_stream);
-    const int rc = lorahip_set_stream(dm->ctx, hip_stream);
-    return rc != LORAHIP_OK ? rc : orderBehindCarry(dm);
+    return lorahip_set_stream(dm->ctx, hip_stream);
 }
 
 int lorahip_demod_reset_stream(lorahip_demod *dm)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) return dm->comp->resetStream();
-    const int rc = lorahip_reset_stream(dm->ctx);
-    return rc != LORAHIP_OK ? rc : orderBehindCarry(dm);
+    return lorahip_reset_stream(dm->ctx);
 }
 
 int lorahip_demod_set_fine_gather(lorahip_demod *dm, const int enable)
@@ -1627,7 +1629,12 @@ int64_t lorahip_demod_consumed(const lorahip_demod *dm, const size_t channel)
 {
     if (dm == nullptr || channel >= dm->B) return LORAHIP_E_INVALID;
     if (dm->comp) return dm->comp->consumed(channel);
-    if (dm->mirrorsStale && dm->posOnDevice && dm->sHost) return int64_t(hostStates(const_cast<lorahip_demod *>(dm))[channel].pos);
+    if (dm->mirrorsStale && dm->posOnDevice && dm->sHost)
+    {
+        lorahip_demod *m = const_cast<lorahip_demod *>(dm);
+        if (ensureHead(m) != LORAHIP_OK) return LORAHIP_E_HIP;
+        return int64_t(hostStates(m)[channel].pos);
+    }
     if (!dm->posOnDevice && dm->uniform && !dm->geomApplied) return 0;     // placement set, nothing run on it yet
     return int64_t(dm->ch[channel].pos);
 }

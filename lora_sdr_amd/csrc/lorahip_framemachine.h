@@ -26,15 +26,42 @@ struct StreamOut
         sigOut = s.sigOut ? s.sigOut + (size_t)channel * s.capPkt : nullptr;
         calls = nSym = nPkt = nSig = 0;
     }
-    //! the packet the channel is inside continues behind the symbols it has already (flag bit 2; `st` with the launch's flags applied)
-    __device__ __forceinline__ void carryIn(const StreamArgs &s, const StreamState &st)
+    //! The packet the channel is inside continues behind the symbols it has already (flag bit 2; `st` with the launch's flags
+    //! applied): the channel's lanes (lane `t` of `T`) copy them from the carry rows to the head of the symbol row.
+    __device__ __forceinline__ void carryIn(const StreamArgs &s, const StreamState &st, const unsigned channel, const int t, const int T)
     {
-        if ((s.flags & 4) && st.state == ST_DATASYMBOLS) nSym = st.symCount;
+        if (!(s.flags & 4) || st.state != ST_DATASYMBOLS) return;
+        const int k = st.symCount < s.carryCap ? st.symCount : s.carryCap;
+        const short *src = s.carry + (size_t)channel * s.carryCap;
+        for (int i = t; i < k; i += T) symOut[i] = src[i];
+        nSym = st.symCount;
+    }
+    //! ... and a channel that ends the launch inside a packet leaves the packet's symbols -- the last symCount entries of its row,
+    //! written by the writer lane -- in the carry rows (flag bit 3).
+    __device__ __forceinline__ void carryOut(const StreamArgs &s, const StreamState &st, const unsigned channel, const int t, const int T, const bool mine = true)
+    {
+        if (!(s.flags & 8)) return;                                 // uniform over the launch
+        // The writer lane's stores have to be seen by its neighbours' loads. They are lanes of ONE wavefront (or workgroup: the caller's
+        // barrier), whose memory operations go through one L1 in order: a wavefront-scope fence -- the wait for the stores -- orders
+        // them, and the loads are made at agent scope (they read L2, where the stores have landed), so no stale L1 line can be hit.
+        // An agent-scope FENCE would do too, but it writes the whole L2 back (buffer_wbl2): 90 us per launch at 2048 wavefronts.
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (!mine || st.state != ST_DATASYMBOLS) return;
+        int k = st.symCount < nSym ? st.symCount : nSym;
+        k = k < s.carryCap ? k : s.carryCap;
+        short *dst = s.carry + (size_t)channel * s.carryCap;
+        for (int i = t; i < k; i += T) dst[i] = __hip_atomic_load(symOut + (nSym - k + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
 
 /*! One work() call after its detect(s): `value` .. `fIndex` are the locals of LoRaDemod::work() as they stand after the
- * optional second detect (:203 overwrites power / powerAvg / fIndex, not snr), `match1` the second sync-word test. */
+ * optional second detect (:203 overwrites power / powerAvg / fIndex, not snr), `match1` the second sync-word test.
+ *
+ * Written WITHOUT branches on the state: where a wavefront carries several channels (demodStream, SF6-9) they are in different
+ * states at the same time, and a switch over the five states executes every arm present in the wave one after the other under
+ * exec masks (~200 instructions per call, profiles/r04). As selects it is ~40 operations whatever the mix; where the state is
+ * wave-uniform (one channel per wavefront / workgroup) the same expressions run on the scalar unit. Only the record stores
+ * remain predicated. Each line cites the statement of the reference it stands for. */
 template <int N>
 __device__ __forceinline__ void frameStep(StreamState &st, const StreamArgs &s, StreamOut &o, const bool writer,
                                           const int value, const float power, const float powerAvg, const float snr,
@@ -43,63 +70,43 @@ __device__ __forceinline__ void frameStep(StreamState &st, const StreamArgs &s, 
 {
     const int stateBefore = st.state;
     const int fineIdxAfter = st.fineTuneIndex;      // the caller has committed window 0's steps (:160-162)
-    int total = 0, packetLen = 0, signals = 0, sigError = 0;
-    switch (st.state)
-    {
-    case ST_FRAMESYNC:
-        if (syncd && match0 && match1) { total = 2 * N; st.state = ST_DOWNCHIRP0; st.downTable = 1; }   // :209-213
-        else if (!squelched) { total = N - value; st.finefreqError += fIndex; }                          // :217-221
-        else { total = N; st.finefreqError = 0.0f; st.fineTuneIndex = 0; }                               // :228-233
-        break;
-    case ST_DOWNCHIRP0:
-    {
-        st.state = ST_DOWNCHIRP1;
-        total = N;
-        int error = value;
-        if (value > N / 2) error -= N;
-        st.freqError = error;                                                                            // :246-249
-    } break;
-    case ST_DOWNCHIRP1:
-    {
-        st.state = ST_QUARTERCHIRP;
-        total = N;
-        st.downTable = 0;
-        int error = value;
-        if (value > N / 2) error -= N;
-        st.freqError = (st.freqError + error) / 2;                                                       // :262-265
-        signals = 1; sigError = st.freqError;                                                            // :267-269
-        if (o.sigOut)
-        {
-            // emitSignal("error" / "power" / "snr") as a record of its own: the caller evaluated the logarithms for this call
-            if (writer) { StreamSignal g; g.callIndex = st.callCount; g.error = sigError; g.power = power; g.snr = snr; o.sigOut[o.nSig] = g; }
-            o.nSig++;
-        }
-    } break;
-    case ST_QUARTERCHIRP:
-        st.state = ST_DATASYMBOLS;
-        total = N / 4 + st.freqError / 2;                                                                // :278
-        st.finefreqError += (float)(st.freqError / 2);
-        st.symCount = 0;
-        break;
-    default: // ST_DATASYMBOLS
-        total = N;
+    const bool isFS = stateBefore == ST_FRAMESYNC, isD0 = stateBefore == ST_DOWNCHIRP0, isD1 = stateBefore == ST_DOWNCHIRP1;
+    const bool isQC = stateBefore == ST_QUARTERCHIRP, isDA = stateBefore == ST_DATASYMBOLS;
+    const bool sync3 = isFS && syncd && match0 && match1;                                                // :209
+    const bool fsOpen = isFS && !sync3 && !squelched;                                                    // :217
+    const bool fsQuiet = isFS && !sync3 && squelched;                                                    // :228
+    const int error = value > N / 2 ? value - N : value;                                                 // :246-248, :262-264
+    const int halfError = st.freqError / 2;                                                              // :278 (int division: towards zero)
+
+    int total = N;
+    total = sync3 ? 2 * N : total;                                                                       // :210
+    total = fsOpen ? N - value : total;                                                                  // :219
+    total = isQC ? N / 4 + halfError : total;                                                            // :278
+
+    const int symCount = isQC ? 0 : st.symCount + (isDA ? 1 : 0);                                        // :279, out[_symCount++]  :290
+    const bool post = isDA && ((unsigned)symCount >= s.mtu || squelched);                                // :291
+
+    float ffe = st.finefreqError;
+    ffe = fsOpen ? ffe + fIndex : ffe;                                                                   // :221
+    ffe = isQC ? ffe + (float)halfError : ffe;                                                           // :277
+    ffe = (fsQuiet || post) ? 0.0f : ffe;                                                                // :230, :299
+    const int fti = fsQuiet ? 0 : st.fineTuneIndex;                                                      // :231
+    const int freqError = isD0 ? error : (isD1 ? (st.freqError + error) / 2 : st.freqError);             // :249, :265
+    // FRAMESYNC stays unless the sync words matched (:211); the chirp states and QUARTERCHIRP step on (:243, :256, :276); DATASYMBOLS
+    // stays until the packet is posted (:300)
+    const int next = isFS ? (sync3 ? ST_DOWNCHIRP0 : ST_FRAMESYNC) : (isDA ? (post ? ST_FRAMESYNC : ST_DATASYMBOLS) : stateBefore + 1);
+    const int downTable = sync3 ? 1 : (isD1 ? 0 : st.downTable);                                        // :212, :257
+
 #ifndef LORAHIP_TIMING_NO_RECORD_STORES     // timing-only build (profiles/r03): what the per-call record stores cost
-        if (writer) o.symOut[o.nSym] = (short)value;                                                     // out[_symCount++] = value  :290
+    if (writer && isDA) o.symOut[o.nSym] = (short)value;                                                 // out[_symCount++] = value  :290
 #endif
-        o.nSym++;
-        st.symCount++;
-        if ((unsigned)st.symCount >= s.mtu || squelched)                                                 // :291
-        {
-            packetLen = st.symCount;
-            if (writer) { o.pktOut[o.nPkt].callIndex = st.callCount; o.pktOut[o.nPkt].len = packetLen; } // postMessage  :295-298
-            o.nPkt++;
-            st.finefreqError = 0.0f;
-            st.state = ST_FRAMESYNC;
-        }
-        break;
+    if (writer && post) { StreamPacket q; q.callIndex = st.callCount; q.len = symCount; o.pktOut[o.nPkt] = q; }   // postMessage  :295-298
+    if (o.sigOut)                                                                                        // uniform over the launch
+    {
+        // emitSignal("error" / "power" / "snr") as a record of its own (:267-269): the caller evaluated the logarithms for this call
+        if (writer && isD1) { StreamSignal g; g.callIndex = st.callCount; g.error = freqError; g.power = power; g.snr = snr; o.sigOut[o.nSig] = g; }
+        o.nSig += isD1 ? 1 : 0;
     }
-    st.prevValue = (short)value;                                                                         // :326
-    st.pos += total;                                                                                     // consume(total)  :320
     if (writer && o.out)
     {
         lorahip_work_result r;
@@ -108,15 +115,21 @@ __device__ __forceinline__ void frameStep(StreamState &st, const StreamArgs &s, 
         r.value = value;
         r.power = power; r.power_avg = powerAvg; r.snr = snr; r.f_index = fIndex;
         r.worked = 1;
-        r.packet_len = packetLen;
-        r.signals = signals;
-        r.sig_error = sigError;
-        r.sig_power = signals ? power : 0.0f;
-        r.sig_snr = signals ? snr : 0.0f;
+        r.packet_len = post ? symCount : 0;
+        r.signals = isD1 ? 1 : 0;
+        r.sig_error = isD1 ? freqError : 0;
+        r.sig_power = isD1 ? power : 0.0f;
+        r.sig_snr = isD1 ? snr : 0.0f;
         r.fine_idx_before = fineIdxBefore; r.fine_idx_after = fineIdxAfter; r.fine_err_before = fineErrBefore; r.reserved = 0;
         o.out[o.calls] = r;
     }
+    o.nSym += isDA ? 1 : 0;
+    o.nPkt += post ? 1 : 0;
     o.calls++;
+    st.state = next; st.downTable = downTable; st.freqError = freqError; st.fineTuneIndex = fti; st.finefreqError = ffe;
+    st.symCount = symCount;
+    st.prevValue = (short)value;                                                                         // :326
+    st.pos += total;                                                                                     // consume(total)  :320
     st.callCount++;
 }
 

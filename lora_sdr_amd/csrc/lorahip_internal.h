@@ -115,7 +115,7 @@ struct StreamArgs
     lorahip_work_result *calls; // [nChannels][cap] one record per work() call; nullptr unless tracing
     int *nCalls;                // [nChannels] work() calls made by this launch
     short *symOut;              // [nChannels][symStride] the DATASYMBOLS values of this launch, in order; with flag bit 2 the symbols of the
-                                // packet the channel was inside when the launch began come first (carryLoad put them there)
+                                // packet the channel was inside when the launch began come first (copied there from `carry`)
     int *nSym;                  // [nChannels] entries of the channel's symOut row that are valid after the launch (carried ones included)
     StreamPacket *pktOut;       // [nChannels][capPkt]
     int *nPkt;                  // [nChannels]
@@ -134,9 +134,32 @@ struct StreamArgs
     long long uniformLen;       // >= 0: channel c's stream is the uniformLen samples at c * uniformStride (base / len are not read)
     long long uniformStride;    // samples between the first samples of consecutive channels' streams (uniformLen >= 0)
     int flags;                  // bit 0: first launch of a run -- every channel starts at sample 0, call 0; bit 1: activate() first;
-                                // bit 2: a channel in DATASYMBOLS finds its packet's first symCount symbols at the head of its symOut row
-    unsigned *near;             // [2] decisions float rounding could flip (lorahip_demod_near_threshold): squelch margins, fine-tune steps
+                                // bit 2: a channel in DATASYMBOLS first copies its open packet's symCount symbols from `carry` to the head of
+                                //        its symOut row and appends behind them; bit 3: a channel that ends the launch in DATASYMBOLS leaves
+                                //        the last symCount entries of its row in `carry` (the open packets stay on the device, no extra launch)
+    short *carry;               // [nChannels][carryCap] symbols of the packets the channels are inside, between launches (bits 2 / 3)
+    int carryCap;
+    int maxBlocks;              // > 0: at most this many workgroups, each looping over channel sets (the resident number: no second round)
+    unsigned *near;             // [2] decisions float rounding could flip (lorahip_demod_near_threshold): squelch margins, fine-tune steps.
+                                //     Running counters: the kernels only add, the host takes differences
 };
+
+//! what the host needs to know after a streaming launch -- reduced on the device (streamSummary), so that 64 bytes cross PCIe per run
+//! instead of the per-channel state and counts (52 B per channel), which are fetched only when somebody asks for them
+struct StreamSummary
+{
+    long long calls, packets, syms, signals;    // sums over the channels of this launch's counts
+    long long openSyms;                         // sum of symCount over the channels that are inside a packet now
+    int more;                                   // some channel filled a record buffer: the launch must be resumed
+    int anyOpen;                                // some channel is in DATASYMBOLS
+    int maxCallCount;                           // largest callCount (= lock-step rounds so far)
+    int maxOpen;                                // largest symCount among the open packets
+    int fullest;                                // most calls any channel made in this launch
+    unsigned nearSquelch, nearStep;             // the running counters (StreamArgs::near)
+    int pad;
+};
+hipError_t launchStreamSummary(const StreamState *state, const int *nCalls, const int *nSym, const int *nPkt, const int *nSig, size_t nChannels,
+                               int cap, int capPkt, const unsigned *near, StreamSummary *out, hipStream_t stream);
 
 //! argument block of the batched decoder (lorahip_codec.hip); device pointers
 struct DecodeArgs
@@ -165,10 +188,6 @@ bool streamAvailable(int sf);
 hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchStreamWide(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchCompactRows(void *dst, const void *src, size_t rows, size_t srcPitchBytes, size_t rowBytes, hipStream_t stream);
-//! the symbols of the packets the channels are inside: carryLoad puts them at the head of the symOut rows before a run's first launch,
-//! carrySave takes the last symCount entries of every row afterwards (rows of carryCap entries; lorahip_stream.hip)
-hipError_t launchCarryLoad(const StreamState *state, const short *carry, int carryCap, short *symOut, int symStride, size_t nChannels, hipStream_t stream);
-hipError_t launchCarrySave(const StreamState *state, const int *nSym, const short *symOut, int symStride, short *carry, int carryCap, size_t nChannels, hipStream_t stream);
 hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, int *rowStart, size_t nChannels, int cap, int capPkt,
                              size_t nPackets, long long *srcOff, unsigned short *symsOut, int stride, int *nsymsOut, int *channelOut, hipStream_t stream);
 hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *srcOff, const long long *dstOff, const int *len, size_t nSeg,

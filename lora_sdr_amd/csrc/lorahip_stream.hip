@@ -29,7 +29,10 @@
 #endif
 namespace lorahip {
 
-template <class C>
+//! PERSIST: a grid of at most s.maxBlocks workgroups, each looping over channel sets -- for launches over more channels than are
+//! resident at once. The loop costs registers (96 / 112 B of scratch at SF7 / SF9 against 20 / 28), so a launch that fits the
+//! device takes the instance without it (one workgroup per channel set).
+template <class C, bool PERSIST>
 __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD)
 demodStream(const StreamArgs s)
 {
@@ -70,8 +73,15 @@ demodStream(const StreamArgs s)
     const auto uniI = [](const int v) { return UNI ? __builtin_amdgcn_readfirstlane(v) : v; };
     const auto uniF = [](const float v) { return UNI ? __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))) : v; };
 
+    // The grid is PERSISTENT: at most the resident number of workgroups (s.maxBlocks), each walking one set of WAVES * WPW channels
+    // after the other -- the tables above are loaded once, and a launch over more channels than fit the device does not run a second,
+    // half-empty round of workgroups. From here on the wavefronts of a workgroup are independent (no workgroup barrier below).
+    const unsigned nSets = (s.nChannels + WAVES * WPW - 1) / (WAVES * WPW);
+    unsigned cset = blockIdx.x;                             // (the grid never exceeds the number of sets)
+    do
+    {
     // ---- this lane group's channel and its state (replicated in the T lanes) ----------------------
-    const unsigned c = UNI ? (unsigned)uniI(int((blockIdx.x * WAVES + wave) * WPW)) : (blockIdx.x * WAVES + wave) * WPW + wsub;
+    const unsigned c = UNI ? (unsigned)uniI(int((cset * WAVES + wave) * WPW)) : (cset * WAVES + wave) * WPW + wsub;
     const bool mine = c < s.nChannels;
     const unsigned cc = mine ? c : 0;
     StreamState st = s.state[cc];
@@ -81,7 +91,7 @@ demodStream(const StreamArgs s)
     const long long len = !mine ? 0 : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]);
     StreamOut o;
     o.init(s, cc);
-    o.carryIn(s, st);
+    if (mine) o.carryIn(s, st, cc, t, T);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
     // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
@@ -282,21 +292,20 @@ demodStream(const StreamArgs s)
         // index and is not committed itself
         if (live && !second) st.fineTuneIndex = idxEnd;
 
-        bool syncd = !squelched && (st.prevValue + 4) / 8 == 0;                        // :183
-        bool match0 = (value + 4) / 8 == (s.sync >> 4);                                // :184
-        bool match1 = false, step = live;
-        if (second)
-        {
-            match1 = (value + 4) / 8 == (s.sync & 0xf);                                // :205
-            // detect() overwrote power / powerAvg / fIndex (:203); value, snr and what follows from them are window 0's
-            value = value0; snr = snr0; squelched = false; syncd = true; match0 = true;
-            pend = false;
-        }
-        else if (live && fs && syncd && match0)
-        {
-            pend = true; step = false;
-            value0 = value; snr0 = snr; fineIdxBefore0 = fineIdxBefore; fineErrBefore0 = fineErrBefore;
-        }
+        // (selects, not branches: the wave's channels are in different states at once, see frameStep)
+        const bool syncdW = !squelched && (st.prevValue + 4) / 8 == 0;                 // :183
+        const int word = (value + 4) / 8;
+        // window 0 of a sync'd FRAMESYNC call that matches the first sync word: park it, its window 1 comes in the next pass
+        const bool park = live && !second && fs && syncdW && word == (s.sync >> 4);    // :184
+        const bool match1 = second && word == (s.sync & 0xf);                          // :205
+        // detect() of window 1 overwrote power / powerAvg / fIndex (:203); value, snr and what follows from them are window 0's
+        value0 = park ? value : value0; snr0 = park ? snr : snr0;
+        fineIdxBefore0 = park ? fineIdxBefore : fineIdxBefore0; fineErrBefore0 = park ? fineErrBefore : fineErrBefore0;
+        value = second ? value0 : value; snr = second ? snr0 : snr;
+        squelched = second ? false : squelched;
+        const bool syncd = second || syncdW, match0 = second || word == (s.sync >> 4);
+        pend = park;
+        const bool step = live && !park;
 
         // ---- the frame machine (:176-312) ----
         TMARK(8);
@@ -312,6 +321,7 @@ demodStream(const StreamArgs s)
                "uniform/epilogue of detect %llu, sync/match logic %llu, frame step+records+loop top %llu; calls %d\n",
                tsec[0], tsec[1], tsec[2], tsec[3], tsec[6], tsec[7], tsec[4], 0ull, tsec[8], tsec[5], o.calls);
 #endif
+    o.carryOut(s, st, cc, t, T, mine);
     if (mine && t == 0)
     {
         s.state[c] = st;
@@ -320,6 +330,7 @@ demodStream(const StreamArgs s)
         s.nPkt[c] = o.nPkt;
         if (s.nSig) s.nSig[c] = o.nSig;
     }
+    } while (PERSIST && (cset += gridDim.x) < nSets);       // without PERSIST there is no loop at all (it would cost registers)
 }
 
 template <class C>
@@ -327,15 +338,20 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
 {
     constexpr int WAVES = 4;
     const size_t smem = size_t(C::TWN + C::N) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2) + FineDims<C::LOG2N>::BYTES;
-    static unsigned long long attrDone = 0;
-    {
-        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C>), smem, attrDone);
-        if (e != hipSuccess) return e;
-    }
+    static unsigned long long attrDone = 0, attrDoneP = 0;
     const unsigned perBlock = WAVES * C::WPW;
     const unsigned grid = (s.nChannels + perBlock - 1) / perBlock;
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL((demodStream<C>), dim3(grid), dim3(WAVES * 64), smem, stream, s);
+    if (s.maxBlocks > 0 && grid > unsigned(s.maxBlocks))
+    {
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, true>), smem, attrDoneP);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((demodStream<C, true>), dim3(unsigned(s.maxBlocks)), dim3(WAVES * 64), smem, stream, s);
+        return hipGetLastError();
+    }
+    const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, false>), smem, attrDone);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((demodStream<C, false>), dim3(grid), dim3(WAVES * 64), smem, stream, s);
     return hipGetLastError();
 }
 
@@ -427,46 +443,6 @@ __global__ void packCopy(const short *__restrict__ symOut, const long long *__re
     for (int i = threadIdx.x; i < stride; i += blockDim.x) dst[p * stride + i] = i < len ? (unsigned short)src[i] : (unsigned short)0;
 }
 
-__global__ void carryLoad(const StreamState *__restrict__ state, const short *__restrict__ carry, const int carryCap, short *__restrict__ symOut,
-                          const int symStride, const unsigned nChannels)
-{
-    // one wavefront per channel: the open packets are a few hundred symbols at most
-    const unsigned c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (c >= nChannels) return;
-    const StreamState st = state[c];
-    int k = st.state == ST_DATASYMBOLS ? st.symCount : 0;
-    if (k > carryCap) k = carryCap;
-    for (int i = threadIdx.x & 63; i < k; i += 64) symOut[(size_t)c * symStride + i] = carry[(size_t)c * carryCap + i];
-}
-
-__global__ void carrySave(const StreamState *__restrict__ state, const int *__restrict__ nSym, const short *__restrict__ symOut, const int symStride,
-                          short *__restrict__ carry, const int carryCap, const unsigned nChannels)
-{
-    const unsigned c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (c >= nChannels) return;
-    const StreamState st = state[c];
-    int k = st.state == ST_DATASYMBOLS ? st.symCount : 0;       // the open packet's symbols are the last k of the row (LoRaDemod.cpp:279, :290)
-    const int n = nSym[c];
-    if (k > n) k = n;
-    if (k > carryCap) k = carryCap;
-    for (int i = threadIdx.x & 63; i < k; i += 64) carry[(size_t)c * carryCap + i] = symOut[(size_t)c * symStride + (n - k) + i];
-}
-
-hipError_t launchCarryLoad(const StreamState *state, const short *carry, const int carryCap, short *symOut, const int symStride, const size_t nChannels, hipStream_t stream)
-{
-    if (nChannels == 0) return hipSuccess;
-    hipLaunchKernelGGL(carryLoad, dim3(unsigned((nChannels + 3) / 4)), dim3(256), 0, stream, state, carry, carryCap, symOut, symStride, unsigned(nChannels));
-    return hipGetLastError();
-}
-
-hipError_t launchCarrySave(const StreamState *state, const int *nSym, const short *symOut, const int symStride, short *carry, const int carryCap, const size_t nChannels,
-                           hipStream_t stream)
-{
-    if (nChannels == 0) return hipSuccess;
-    hipLaunchKernelGGL(carrySave, dim3(unsigned((nChannels + 3) / 4)), dim3(256), 0, stream, state, nSym, symOut, symStride, carry, carryCap, unsigned(nChannels));
-    return hipGetLastError();
-}
-
 //! rowStart = exclusive prefix sum of nPkt (one workgroup; the channel counts are tens of thousands at most): the packets' rows are
 //! numbered on the device, so that packing them needs neither an upload nor a host synchronisation
 __global__ void __launch_bounds__(1024) scanCounts(const int *__restrict__ nPkt, int *__restrict__ rowStart, const unsigned nChannels)
@@ -497,6 +473,69 @@ hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const 
     hipLaunchKernelGGL(packDescribe, dim3(unsigned((nChannels + 255) / 256)), dim3(256), 0, stream, pktOut, nPkt, rowStart, unsigned(nChannels), cap, capPkt,
                        srcOff, nsymsOut, channelOut);
     hipLaunchKernelGGL(packCopy, dim3(unsigned(nPackets)), dim3(64), 0, stream, symOut, srcOff, nsymsOut, symsOut, stride);
+    return hipGetLastError();
+}
+
+/***********************************************************************
+ * What the host needs after a streaming launch, reduced on the device: one workgroup reads the per-channel state and counts
+ * (a few hundred KiB in HBM) and leaves 64 bytes. The per-channel arrays cross PCIe only when an accessor asks for them.
+ **********************************************************************/
+__global__ void __launch_bounds__(1024) streamSummary(const StreamState *__restrict__ state, const int *__restrict__ nCalls, const int *__restrict__ nSym,
+                                                      const int *__restrict__ nPkt, const int *__restrict__ nSig, const unsigned nChannels, const int cap,
+                                                      const int capPkt, const unsigned *__restrict__ near, StreamSummary *__restrict__ out)
+{
+    long long calls = 0, packets = 0, syms = 0, signals = 0, openSyms = 0;
+    int more = 0, anyOpen = 0, maxCall = 0, maxOpen = 0, fullest = 0;
+    for (unsigned c = threadIdx.x; c < nChannels; c += blockDim.x)
+    {
+        const int n = nCalls[c], p = nPkt[c], g = nSig ? nSig[c] : 0;
+        calls += n; packets += p; syms += nSym[c]; signals += g;
+        more |= (n == cap || p == capPkt || (nSig && g == capPkt)) ? 1 : 0;
+        fullest = n > fullest ? n : fullest;
+        const StreamState st = state[c];
+        maxCall = st.callCount > maxCall ? st.callCount : maxCall;
+        if (st.state == ST_DATASYMBOLS) { anyOpen = 1; openSyms += st.symCount; maxOpen = st.symCount > maxOpen ? st.symCount : maxOpen; }
+    }
+    __shared__ long long sL[5][16];
+    __shared__ int sI[5][16];
+    // wavefront reductions, then the 16 wavefronts' partial results by the first lanes
+    for (int d = 32; d >= 1; d >>= 1)
+    {
+        calls += __shfl_xor(calls, d); packets += __shfl_xor(packets, d); syms += __shfl_xor(syms, d); signals += __shfl_xor(signals, d);
+        openSyms += __shfl_xor(openSyms, d);
+        more |= __shfl_xor(more, d); anyOpen |= __shfl_xor(anyOpen, d);
+        const int a = __shfl_xor(maxCall, d), b = __shfl_xor(maxOpen, d), f = __shfl_xor(fullest, d);
+        maxCall = a > maxCall ? a : maxCall; maxOpen = b > maxOpen ? b : maxOpen; fullest = f > fullest ? f : fullest;
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+    {
+        sL[0][w] = calls; sL[1][w] = packets; sL[2][w] = syms; sL[3][w] = signals; sL[4][w] = openSyms;
+        sI[0][w] = more; sI[1][w] = anyOpen; sI[2][w] = maxCall; sI[3][w] = maxOpen; sI[4][w] = fullest;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        StreamSummary r;
+        r.calls = r.packets = r.syms = r.signals = r.openSyms = 0;
+        r.more = r.anyOpen = r.maxCallCount = r.maxOpen = r.fullest = 0;
+        for (int k = 0; k < int(blockDim.x >> 6); k++)
+        {
+            r.calls += sL[0][k]; r.packets += sL[1][k]; r.syms += sL[2][k]; r.signals += sL[3][k]; r.openSyms += sL[4][k];
+            r.more |= sI[0][k]; r.anyOpen |= sI[1][k];
+            r.maxCallCount = sI[2][k] > r.maxCallCount ? sI[2][k] : r.maxCallCount;
+            r.maxOpen = sI[3][k] > r.maxOpen ? sI[3][k] : r.maxOpen;
+            r.fullest = sI[4][k] > r.fullest ? sI[4][k] : r.fullest;
+        }
+        r.nearSquelch = near[0]; r.nearStep = near[1]; r.pad = 0;
+        *out = r;
+    }
+}
+
+hipError_t launchStreamSummary(const StreamState *state, const int *nCalls, const int *nSym, const int *nPkt, const int *nSig, const size_t nChannels,
+                               const int cap, const int capPkt, const unsigned *near, StreamSummary *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(streamSummary, dim3(1), dim3(1024), 0, stream, state, nCalls, nSym, nPkt, nSig, unsigned(nChannels), cap, capPkt, near, out);
     return hipGetLastError();
 }
 

@@ -641,7 +641,7 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
  * window after window -- the level-3 twin of lorahip_stream.hip, same frame machine (lorahip_framemachine.h), the
  * in-place three-phase FFT of detectWide. Five workgroup barriers per window (two more while the fine-tune index moves).
  **********************************************************************/
-template <class C>
+template <class C, bool PERSIST>
 __global__ void __launch_bounds__(C::T, 2)
 demodStreamWide(const StreamArgs s)
 {
@@ -694,7 +694,10 @@ demodStreamWide(const StreamArgs s)
     // in every lane's vector registers.
     const auto uniI = [](const int v) { return __builtin_amdgcn_readfirstlane(v); };
     const auto uniF = [](const float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
-    const unsigned c = blockIdx.x;
+    // persistent grid (s.maxBlocks workgroups at most), a workgroup takes one channel after the other: see demodStream
+    unsigned c = blockIdx.x;                                // (the grid never exceeds the channel count)
+    do
+    {
     StreamState st = s.state[c];
     if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
     if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
@@ -702,7 +705,7 @@ demodStreamWide(const StreamArgs s)
     const long long len = s.uniformLen >= 0 ? s.uniformLen : s.len[c];
     StreamOut o;
     o.init(s, c);
-    o.carryIn(s, st);
+    o.carryIn(s, st, c, t, T);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect; every argument is workgroup-uniform
     // What a work() call consumes of the float outputs depends on its state (see demodStream, lorahip_stream.hip): without a
@@ -935,6 +938,7 @@ demodStreamWide(const StreamArgs s)
             st.finefreqError = uniF(st.finefreqError);                                  // a float add runs on the vector unit: back to a scalar
         }
     }
+    o.carryOut(s, st, c, t, T);
     if (t == 0)
     {
         s.state[c] = st;
@@ -943,6 +947,8 @@ demodStreamWide(const StreamArgs s)
         s.nPkt[c] = o.nPkt;
         if (s.nSig) s.nSig[c] = o.nSig;
     }
+    if (PERSIST) __syncthreads();                           // the next channel reuses the exchange region and the reduction records
+    } while (PERSIST && (c += gridDim.x) < s.nChannels);    // without PERSIST there is no loop at all (it would cost registers)
 }
 
 
@@ -950,13 +956,18 @@ template <class C>
 static hipError_t launchStreamWideCfg(const StreamArgs &s, hipStream_t stream)
 {
     const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2) + 12 * sizeof(int) + FineDims<C::LOG2N>::BYTES;
-    static unsigned long long attrDone = 0;
-    {
-        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C>), smem, attrDone);
-        if (e != hipSuccess) return e;
-    }
+    static unsigned long long attrDone = 0, attrDoneP = 0;
     if (s.nChannels == 0) return hipSuccess;
-    hipLaunchKernelGGL((demodStreamWide<C>), dim3(s.nChannels), dim3(C::T), smem, stream, s);
+    if (s.maxBlocks > 0 && s.nChannels > unsigned(s.maxBlocks))
+    {
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, true>), smem, attrDoneP);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((demodStreamWide<C, true>), dim3(unsigned(s.maxBlocks)), dim3(C::T), smem, stream, s);
+        return hipGetLastError();
+    }
+    const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, false>), smem, attrDone);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((demodStreamWide<C, false>), dim3(s.nChannels), dim3(C::T), smem, stream, s);
     return hipGetLastError();
 }
 

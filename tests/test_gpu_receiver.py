@@ -202,7 +202,10 @@ def test_mixed_object_equals_single_sf_objects(gpu, oracle, devices):
             first[c], cnt[c] = at, streams[c].size
             parts.append(streams[c]); at += streams[c].size
         bufs.append(gpu.from_numpy(np.concatenate(parts)).cuda())
-    m.set_trace(False); m.activate()
+    # (a fresh object: a re-activated one starts from the _finefreqError / _prevValue the last stream left, like the reference block)
+    m.close()
+    m = L.LoRaDemod(channel_sf=sfs, devices=devices)
+    m.setMTU(7)
     if len(devices) == 1:
         m.work_segments(bufs[0], first, cnt)
     else:
