@@ -832,6 +832,8 @@ class LoRaDemod:
         FFT bins (one per work() call), `dec_samples` dechirped samples, `raw_samples` consumed samples; 0 = that port off,
         all 0 = ports off. The buffers are device tensors owned by this object; read them with ports(channel)."""
         import torch
+        if self.N is None:
+            raise ValueError("the debug ports need one spreading factor for all channels (include/lorahip.h)")
         dev = torch.device("cuda", int(self._device))
         B = self.n_channels
         self._port_bufs = dict(

@@ -815,9 +815,15 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     // symbols, and leaves the packet it is inside at the end in the carry rows
     a.flags = (cont ? 0 : 1) | (activate ? 2 : 0) | (useDevCarry ? 4 | 8 : 0);
     a.carry = dm->dCarry; a.carryCap = int(dm->carryCap);
-    // the resident number of workgroups (two wavefronts per SIMD: 256 threads x 2 per CU, or 512 threads' worth of smaller ones)
-    a.maxBlocks = ctx->cuCount > 0 ? ctx->cuCount * (ctx->sf == 11 ? 4 : 2) : 0;
-    if (const char *e = std::getenv("LORAHIP_STREAM_BLOCKS")) a.maxBlocks = std::atoi(e);        // measurement hook: 0 = one workgroup per channel set
+    // One workgroup per channel set, however many there are: the dispatcher hands a free slot the next set, which balances channels of
+    // different length. A PERSISTENT grid (the resident number of workgroups, each looping over sets) was built and measured and lost:
+    // 0.31 against 0.39 of the roofline at 32768 SF7 channels, 0.29 against 0.31 at 4096 SF12 channels -- static assignment leaves a
+    // tail, and the loop costs registers (profiles/r04/s4_level3_scaling_persistent_vs_plain_negative.txt). The instances are kept
+    // in the profiling build only.
+    a.maxBlocks = 0;
+#ifdef LORAHIP_ALL_VARIANTS
+    if (const char *e = std::getenv("LORAHIP_STREAM_BLOCKS")) a.maxBlocks = std::atoi(e);        // e.g. 512: two workgroups of 256 threads per CU
+#endif
     a.state = reinterpret_cast<StreamState *>(d + L.oState);
     a.nCalls = reinterpret_cast<int *>(d + L.oN);
     a.nSym = reinterpret_cast<int *>(d + L.oNSym);

@@ -342,6 +342,7 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
     const unsigned perBlock = WAVES * C::WPW;
     const unsigned grid = (s.nChannels + perBlock - 1) / perBlock;
     if (grid == 0) return hipSuccess;
+#ifdef LORAHIP_ALL_VARIANTS      // the persistent grid: measured, negative (lorahip_demod.cpp::runStream); profiling build only
     if (s.maxBlocks > 0 && grid > unsigned(s.maxBlocks))
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, true>), smem, attrDoneP);
@@ -349,6 +350,8 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
         hipLaunchKernelGGL((demodStream<C, true>), dim3(unsigned(s.maxBlocks)), dim3(WAVES * 64), smem, stream, s);
         return hipGetLastError();
     }
+#endif
+    (void)attrDoneP;
     const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, false>), smem, attrDone);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((demodStream<C, false>), dim3(grid), dim3(WAVES * 64), smem, stream, s);

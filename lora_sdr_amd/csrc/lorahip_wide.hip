@@ -958,6 +958,7 @@ static hipError_t launchStreamWideCfg(const StreamArgs &s, hipStream_t stream)
     const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2) + 12 * sizeof(int) + FineDims<C::LOG2N>::BYTES;
     static unsigned long long attrDone = 0, attrDoneP = 0;
     if (s.nChannels == 0) return hipSuccess;
+#ifdef LORAHIP_ALL_VARIANTS      // the persistent grid: measured, negative (lorahip_demod.cpp::runStream); profiling build only
     if (s.maxBlocks > 0 && s.nChannels > unsigned(s.maxBlocks))
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, true>), smem, attrDoneP);
@@ -965,6 +966,8 @@ static hipError_t launchStreamWideCfg(const StreamArgs &s, hipStream_t stream)
         hipLaunchKernelGGL((demodStreamWide<C, true>), dim3(unsigned(s.maxBlocks)), dim3(C::T), smem, stream, s);
         return hipGetLastError();
     }
+#endif
+    (void)attrDoneP;
     const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, false>), smem, attrDone);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((demodStreamWide<C, false>), dim3(s.nChannels), dim3(C::T), smem, stream, s);

@@ -218,8 +218,8 @@ def test_mixed_object_equals_single_sf_objects(gpu, oracle, devices):
     # what a mixed object does not offer says so
     with pytest.raises(L.LoraHipError):
         m.work(gpu.zeros((B, 64), dtype=gpu.complex64, device="cuda"))      # lorahip_demod_run_device: one uniform array
-    with pytest.raises(L.LoraHipError):
-        m.set_ports(fft_frames=4)
+    with pytest.raises(ValueError):
+        m.set_ports(fft_frames=4)                                           # one SF only
     for _, s1 in singles.values():
         s1.close()
     m.close()
