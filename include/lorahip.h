@@ -93,8 +93,13 @@ int lorahip_set_stream(lorahip_ctx *ctx, void *hip_stream);
 int lorahip_reset_stream(lorahip_ctx *ctx);          /* back to the private stream */
 int lorahip_synchronize(lorahip_ctx *ctx);
 
-/* Kernel variant: 0 = auto (fastest validated for this SF), 1 = generic LDS kernel.
- * All variants produce identical symbol indices and FFT bins. */
+/* Kernel variant: 0 = auto (fastest validated for this SF), 1 = generic LDS kernel, 10 = the tuned kernel with every table in LDS.
+ * These produce identical symbol indices and FFT bins (the reference's operation graph, no FMA).
+ * LORAHIP_VARIANT_FMA (opt-in, level 2 only) is NOT one of them: the same tuned kernels with every complex multiply contracted to
+ * one multiply + one FMA. Its bins differ from the CPU build's in the last place or two (far inside the 1e-4 relative tolerance
+ * north_star states, symbol indices identical wherever the peak's margin exceeds that), and it is ~20 % fewer vector instructions.
+ * It exists to measure what bit-exact bins cost (profiles/r04); nothing selects it by default and level 3 cannot reach it. */
+#define LORAHIP_VARIANT_FMA 40
 int lorahip_set_variant(lorahip_ctx *ctx, int variant);
 
 /* How the kernels obtain _fineTuneTable[_fineTuneIndex] for windows whose index moves (LoRaDemod.cpp:159-162). Default (0): no
@@ -264,6 +269,9 @@ int lorahip_demod_set_mode(lorahip_demod *d, int mode);
  * run -- a channeliser, a modulator, a copy -- is ordered before the run's kernels. A run returns with the stream drained. */
 int lorahip_demod_set_stream(lorahip_demod *d, void *hip_stream);
 int lorahip_demod_reset_stream(lorahip_demod *d);    /* back to the private stream */
+/* kernel variant of the host-driven mode's batch launches (lorahip_set_variant: 0, 1, 10 -- identical results); LORAHIP_VARIANT_FMA
+ * is refused (LORAHIP_E_INVALID): level 3 runs the reference's operation graph only */
+int lorahip_demod_set_variant(lorahip_demod *d, int variant);
 /* same switch as lorahip_set_fine_gather, for the demodulator's kernels */
 int lorahip_demod_set_fine_gather(lorahip_demod *d, int enable);
 

@@ -602,6 +602,10 @@ class LoRaDemod:
         """0 auto, 1 streaming kernel (frame machine on the device), 2 host-driven lock-step rounds"""
         check(self._lib.lorahip_demod_set_mode(self._h, int(mode)), "lorahip_demod_set_mode")
 
+    def set_variant(self, variant):
+        """kernel variant of the host-driven mode's batch launches; the contracted build (40) is refused at this level"""
+        check(self._lib.lorahip_demod_set_variant(self._h, int(variant)), "lorahip_demod_set_variant")
+
     def set_trace(self, on=True):
         check(self._lib.lorahip_demod_set_trace(self._h, int(bool(on))), "lorahip_demod_set_trace")
 

@@ -14,8 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblorahip.so")
 SOURCES = ["lorahip_kernels.hip", "lorahip_fast.hip", "lorahip_wide.hip", "lorahip_stream.hip", "lorahip_codec.hip", "lorahip_chan.hip", "lorahip_api.cpp", "lorahip_tables.cpp",
-           "lorahip_demod.cpp", "lorahip_mixed.cpp", "lorahip_upload.cpp", "lorahip_rx.cpp"]
+           "lorahip_demod.cpp", "lorahip_mixed.cpp", "lorahip_upload.cpp", "lorahip_rx.cpp", "lorahip_fma_fast.hip", "lorahip_fma_wide.hip"]
 HEADERS = ["lorahip_internal.h", "lorahip_device.h", "lorahip_fft.h", "lorahip_fastcore.h", "lorahip_framemachine.h", "lorahip_fine.h", os.path.join("..", "..", "include", "lorahip.h")]
+INCLUDED_SOURCES = {"lorahip_fma_fast.hip": ["lorahip_fast.hip"], "lorahip_fma_wide.hip": ["lorahip_wide.hip"]}
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result", "-x", "hip"]
@@ -82,6 +83,9 @@ def build_lib(force=False, verbose=False, extra=()):
         h1 = hh.copy()
         with open(src, "rb") as f:
             h1.update(f.read())
+        for dep in INCLUDED_SOURCES.get(s, ()):             # a translation unit that #includes another one's source
+            with open(os.path.join(CSRC, dep), "rb") as f:
+                h1.update(f.read())
         want = h1.hexdigest()
         have = open(obj + ".stamp").read().strip() if os.path.exists(obj + ".stamp") and os.path.exists(obj) else ""
         if force or have != want:

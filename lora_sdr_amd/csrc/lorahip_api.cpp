@@ -213,7 +213,7 @@ int lorahip_synchronize(lorahip_ctx *ctx)
 
 int lorahip_set_variant(lorahip_ctx *ctx, const int variant)
 {
-    if (ctx == nullptr || variant < 0 || variant > 31) return LORAHIP_E_INVALID;
+    if (ctx == nullptr || variant < 0 || variant > LORAHIP_VARIANT_FMA) return LORAHIP_E_INVALID;
     ctx->variant = variant;
     return LORAHIP_OK;
 }

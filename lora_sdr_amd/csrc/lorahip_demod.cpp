@@ -1293,6 +1293,19 @@ int lorahip_demod_reset_stream(lorahip_demod *dm)
     return lorahip_reset_stream(dm->ctx);
 }
 
+int lorahip_demod_set_variant(lorahip_demod *dm, const int variant)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    // level 3 promises the reference block's packets, traces and ports: only kernels on the reference's operation graph qualify
+    if (variant == LORAHIP_VARIANT_FMA) { setLastError("the contracted kernels (LORAHIP_VARIANT_FMA) are not offered at level 3: their bins are not the reference's"); return LORAHIP_E_INVALID; }
+    if (dm->comp)
+    {
+        for (size_t i = 0; i < dm->comp->numParts(); i++) { const int rc = lorahip_demod_set_variant(dm->comp->part(i), variant); if (rc != LORAHIP_OK) return rc; }
+        return LORAHIP_OK;
+    }
+    return lorahip_set_variant(dm->ctx, variant);
+}
+
 int lorahip_demod_set_fine_gather(lorahip_demod *dm, const int enable)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;

@@ -75,6 +75,27 @@ __device__ __forceinline__ void bfly2unit(float2 &f0, float2 &f1)
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifdef LORAHIP_FMA
+/* The opt-in CONTRACTED build of the batch kernels (lorahip_fma_*.hip; lorahip_set_variant(ctx, LORAHIP_VARIANT_FMA)): every complex
+ * multiply is one packed multiply and one packed FMA -- a.x*b.x - (a.y*b.y) with the inner product rounded once and the outer one not
+ * at all -- instead of two multiplies and an add. NOT the reference's operation graph: bins differ from the CPU build's in the last
+ * place or two. It exists to measure what the bit-exact graph costs (profiles/r04); nothing selects it by default and level 3
+ * refuses it. */
+__device__ __forceinline__ v2f cmulv(const v2f a, const v2f b)
+{
+    v2f q, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(q) : "v"(a), "v"(b));                                      // (a.y*b.y, a.x*b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(q));     // (a.x*b.x - q.x, a.y*b.x + q.y)
+    return r;
+}
+__device__ __forceinline__ v2f cmulConjv(const v2f a, const v2f b)
+{
+    v2f q, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(q) : "v"(a), "v"(b));                                      // (a.y*b.y, a.x*b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(q));     // (a.x*b.x + q.x, a.y*b.x - q.y)
+    return r;
+}
+#else
 //! (a.x*b.x - a.y*b.y, a.y*b.x + a.x*b.y): 3 instructions
 __device__ __forceinline__ v2f cmulv(const v2f a, const v2f b)
 {
@@ -93,6 +114,7 @@ __device__ __forceinline__ v2f cmulConjv(const v2f a, const v2f b)
     asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(p), "v"(q));                   // (p.x+q.x, p.y-q.y)
     return r;
 }
+#endif
 //! s5 + (s4.y, -s4.x)  and  s5 - (s4.y, -s4.x): kissfft.hh:150,153-154 without materialising the rotation
 __device__ __forceinline__ v2f addRotv(const v2f s5, const v2f s4)
 {
@@ -141,6 +163,39 @@ __device__ __forceinline__ v2f subAddV(const v2f p, const v2f q)    // (p.x-q.x,
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));
     return r;
 }
+//! (a.x*b.x - q.x, a.y*b.x + q.y) for q = mulHiV(a, b): the second half of the contracted complex product (LORAHIP_FMA builds)
+__device__ __forceinline__ v2f fmaLoV(const v2f a, const v2f b, const v2f q)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(q));
+    return r;
+}
+#ifdef LORAHIP_FMA
+__device__ __forceinline__ void bfly4v(v2f &f0, v2f &f1, v2f &f2, v2f &f3, const v2f t1, const v2f t2, const v2f t3)
+{
+    const v2f q1 = mulHiV(f1, t1), q2 = mulHiV(f2, t2), q3 = mulHiV(f3, t3);
+    const v2f s0 = fmaLoV(f1, t1, q1), s1 = fmaLoV(f2, t2, q2), s2 = fmaLoV(f3, t3, q3);
+    bfly4corev(f0, f1, f2, f3, s0, s1, s2);
+}
+template <int CNT>
+__device__ __forceinline__ void dechirpMany(v2f *x, const v2f *c, const v2f f)
+{
+    static_assert(CNT % 4 == 0, "four values per round");
+#pragma unroll
+    for (int i = 0; i < CNT; i += 4)
+    {
+        v2f q[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = mulHiV(x[i + j], c[i + j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) y[j] = fmaLoV(x[i + j], c[i + j], q[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = mulHiV(y[j], f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[i + j] = fmaLoV(y[j], f, q[j]);
+    }
+}
+#else
 __device__ __forceinline__ void bfly4v(v2f &f0, v2f &f1, v2f &f2, v2f &f3, const v2f t1, const v2f t2, const v2f t3)
 {
     const v2f p1 = mulLoV(f1, t1), q1 = mulHiV(f1, t1), p2 = mulLoV(f2, t2), q2 = mulHiV(f2, t2), p3 = mulLoV(f3, t3), q3 = mulHiV(f3, t3);
@@ -166,6 +221,7 @@ __device__ __forceinline__ void dechirpMany(v2f *x, const v2f *c, const v2f f)
         for (int j = 0; j < 4; j++) x[i + j] = subAddV(p[j], q[j]);
     }
 }
+#endif
 __device__ __forceinline__ void bfly4unitv(v2f &f0, v2f &f1, v2f &f2, v2f &f3) { bfly4corev(f0, f1, f2, f3, f1, f2, f3); }
 __device__ __forceinline__ void bfly2unitv(v2f &f0, v2f &f1)
 {
@@ -398,7 +454,11 @@ __device__ __forceinline__ int laneScan(BIN bin, float &bestV, double &tot)
         {
             const int j = c * PER + k;
             const auto b = bin(j);
+#ifdef LORAHIP_FMA
+            const float mag2 = __builtin_fmaf(b.x, b.x, b.y * b.y);
+#else
             const float mag2 = b.x * b.x + b.y * b.y;
+#endif
             ct[c] += (double)mag2;
             if (mag2 > cv[c]) { cv[c] = mag2; cj[c] = j; }
         }
@@ -435,7 +495,11 @@ __device__ __forceinline__ int laneScanQuick(BIN bin, float &bestV, float &totF)
         {
             const int j = c * PER + k;                      // chain c walks bins [c PER, (c + 1) PER) in ascending order
             const auto b = bin(j);
+#ifdef LORAHIP_FMA
+            const float mag2 = __builtin_fmaf(b.x, b.x, b.y * b.y);
+#else
             const float mag2 = b.x * b.x + b.y * b.y;
+#endif
             ct[c] += mag2;
             if (mag2 > cv[c]) { cv[c] = mag2; cj[c] = j; }
         }

@@ -431,21 +431,34 @@ struct FastVariant { int sf, variant; FastLaunch launch; };
 // round-1 tuning (profiles/r01/s8_variants.txt keeps every A/B pair) are compiled only with -DLORAHIP_ALL_VARIANTS
 // (python -m lora_sdr_amd.build --all-variants), under their old numbers.
 static const FastVariant kFastVariants[] = {
-    V(6, 0, 0),                                            // default: 16 windows per wave keep the LDS copies of chirp / twiddles cheap
-    V(6, 10, CH_REG | NT),
-    V(7, 0, CH_REG | NT),                                  // default (every shape)
-    V(7, 10, 0),
+    // The debug-port instances (dec / fft outputs, 3x the traffic: not occupancy-bound) and, from SF8 up, the per-window-settings
+    // instances run at the 256-register budget of two waves per SIMD: at three (168 registers) they spilled up to 296 B (SF9 / SF10
+    // debug ports; tools/kernel_resources.py, profiles/r04). Every shipped instance now keeps <= 32 B of scratch.
+    { 6, 0, &launchByShape<Fast<6, 0>, Fast<6, 0>, Fast<6, W2>> },                      // default: 16 windows per wave keep the LDS copies of chirp / twiddles cheap
+#ifndef LORAHIP_FMA      // (the contracted build carries the defaults only)
+    { 6, 10, &launchByShape<Fast<6, CH_REG | NT>, Fast<6, CH_REG | NT>, Fast<6, W2 | CH_REG | NT>> },
+#endif
+    { 7, 0, &launchByShape<Fast<7, CH_REG | NT>, Fast<7, CH_REG | NT>, Fast<7, W2 | CH_REG | NT>> },   // default
+#ifndef LORAHIP_FMA
+    { 7, 10, &launchByShape<Fast<7, 0>, Fast<7, 0>, Fast<7, W2>> },
+#endif
     // default SF8: uniform batches with the tables in registers at three waves per SIMD, per-window settings with them at two (no
     // prefetch: the third wave's latency hiding is worth less than the spills it costs -- session 30)
-    { 8, 0, &launchByShape<Fast<8, CH_REG | TW_REG | NT>, Fast<8, W2 | CH_REG | TW_REG | NT | PF_NONE>, Fast<8, CH_REG | TW_REG | NT>> },
-    V(8, 10, 0),
+    { 8, 0, &launchByShape<Fast<8, CH_REG | TW_REG | NT>, Fast<8, W2 | CH_REG | TW_REG | NT | PF_NONE>, Fast<8, W2 | CH_REG | TW_REG | NT | PF_NONE>> },
+#ifndef LORAHIP_FMA
+    { 8, 10, &launchByShape<Fast<8, 0>, Fast<8, W2>, Fast<8, W2>> },
+#endif
     // default SF9: uniform batches on the two-phase geometry (16 lanes x 32 points), per-window settings and the debug ports on the
     // three-phase one (32 lanes x 16 points) at two waves per SIMD
-    { 9, 0, &launchByShape<Fast9b<W2 | CH_REG | TW_REG | NT | PF_NONE>, Fast<9, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>, Fast<9, CH_REG | TW_REG | NT | X1_SWAP>> },
-    V(9, 10, 0),
+    { 9, 0, &launchByShape<Fast9b<W2 | CH_REG | TW_REG | NT | PF_NONE>, Fast<9, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>, Fast<9, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>> },
+#ifndef LORAHIP_FMA
+    { 9, 10, &launchByShape<Fast<9, 0>, Fast<9, W2>, Fast<9, W2>> },
+#endif
     // default SF10: per-window settings at two waves per SIMD with the middle-phase twiddles in registers too
-    { 10, 0, &launchByShape<Fast<10, CH_REG | TW_REG | NT | X1_SWAP>, Fast<10, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>, Fast<10, CH_REG | TW_REG | NT | X1_SWAP>> },
-    V(10, 10, 0),
+    { 10, 0, &launchByShape<Fast<10, CH_REG | TW_REG | NT | X1_SWAP>, Fast<10, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>, Fast<10, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>> },
+#ifndef LORAHIP_FMA
+    { 10, 10, &launchByShape<Fast<10, 0>, Fast<10, W2>, Fast<10, W2>> },
+#endif
 #ifdef LORAHIP_ALL_VARIANTS
     V(6, 7, TW_REG), V(6, 8, NT), V(6, 11, CH_REG | NT), V(6, 12, CH_REG | TW_REG | NT), V(6, 15, CH_REG | TW_REG | NT | PF_NONE),
     V(7, 2, PF_NONE), V(7, 3, W2), V(7, 4, W4 | PF_NONE), V(7, 5, W2 | CH_REG | TW_REG), V(7, 6, PF_EARLY), V(7, 7, TW_REG),

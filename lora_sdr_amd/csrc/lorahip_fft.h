@@ -274,6 +274,15 @@ __device__ __forceinline__ void fineApply(v2f &x, CHIRP chirp, const int i, cons
  * written out like this there is no such boundary inside the pair (and by the compiler's own hazard rule for packed results --
  * a wait state when the very next instruction reads them -- none is needed: no result is read by its immediate successor except
  * the mulHi products, which that rule exempts). Same operations, same operands, same roundings as cmulv / cmulConjv. */
+#ifdef LORAHIP_FMA
+template <bool CONJ>
+__device__ __forceinline__ void cmulPair(v2f &x0, v2f &x1, const v2f c0, const v2f c1, const v2f f0, const v2f f1)
+{
+    // the contracted build (lorahip_device.h): eight packed operations instead of twelve
+    x0 = cmulv(CONJ ? cmulConjv(x0, c0) : cmulv(x0, c0), f0);
+    x1 = cmulv(CONJ ? cmulConjv(x1, c1) : cmulv(x1, c1), f1);
+}
+#else
 template <bool CONJ>
 __device__ __forceinline__ void cmulPair(v2f &x0, v2f &x1, const v2f c0, const v2f c1, const v2f f0, const v2f f1)
 {
@@ -308,6 +317,7 @@ __device__ __forceinline__ void cmulPair(v2f &x0, v2f &x1, const v2f c0, const v
             : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1), "v"(c0), "v"(c1), "v"(f0), "v"(f1));
     x0 = r0; x1 = r1;
 }
+#endif
 
 #ifndef LORAHIP_FINE_GROUP
 #define LORAHIP_FINE_GROUP 2            // samples per pipeline step of dechirpFineSplit (A/B: 4 keeps twice the reads in flight)

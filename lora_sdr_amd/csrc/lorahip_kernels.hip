@@ -179,8 +179,20 @@ static hipError_t launchGeneric(const DetectArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+} // namespace lorahip
+// the contracted build's entry points (lorahip_fma_fast.hip / lorahip_fma_wide.hip: their own namespace, plain C hand-over)
+extern "C" int lorahip_fma_fast_launch(int sf, const void *args, const void *tables, void *stream);
+extern "C" int lorahip_fma_wide_launch(int sf, const void *args, const void *tables, void *stream);
+namespace lorahip {
+
 hipError_t launchDetect(const int sf, const int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
+    if (variant == LORAHIP_VARIANT_FMA)
+    {
+        if (sf >= 6 && sf <= 10) return hipError_t(lorahip_fma_fast_launch(sf, &a, &ft, stream));
+        if (sf == 11 || sf == 12) return hipError_t(lorahip_fma_wide_launch(sf, &a, &ft, stream));
+        return hipErrorInvalidValue;
+    }
     if (variant != 1 && fastAvailable(sf)) return launchFast(sf, variant, a, ft, stream);
     if (sf == 11 && variant >= 20 && variant <= 24) return launchFast(sf, variant, a, ft, stream);          // window-per-wavefront SF11 (variants 20+)
     if ((sf == 11 || sf == 12) && (variant == 25 || variant == 26)) return launchFast(sf, variant, a, ft, stream);   // 64 points per lane (profiling builds)

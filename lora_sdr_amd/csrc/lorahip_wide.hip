@@ -559,6 +559,9 @@ using Wide = WideCfg<SF, WGeo<SF, (O & WINPLACE) != 0>::VEC, (O & WW2) ? 2 : (O 
 // streaming demodulator configurations (demodStreamWide below): one channel per workgroup, in-place middle phase
 typedef Wide<11, WW2 | WPF_NONE | WONE | WINPLACE> StreamWide11;
 typedef Wide<12, WW2 | WPF_NONE | WINPLACE> StreamWide12;
+#ifdef LORAHIP_FMA
+#define LORAHIP_NO_STREAM_WIDE 1        // the contracted build holds batch kernels only: level 3 stays on the reference's operation graph
+#endif
 
 bool wideAvailable(const int sf) { return sf == 11 || sf == 12; }
 
@@ -591,7 +594,9 @@ struct WideVariant { int sf, variant; WideLaunch launch; bool (*layoutOk)(); };
 template <class UNI_CFG, class MOVING_CFG>
 static hipError_t launchWideByShape(const DetectArgs &a, const FastTables &ft, hipStream_t stream)
 {
-    if (a.decOut || a.fftOut) return launchOneWide<UNI_CFG, true, false>(a, ft, stream);
+    // the debug ports (dec / fft outputs, 3x the traffic: not occupancy-bound) at the two-waves-per-SIMD register budget too: at three
+    // they kept 408-508 B of scratch (tools/kernel_resources.py, profiles/r04)
+    if (a.decOut || a.fftOut) return launchOneWide<MOVING_CFG, true, false>(a, ft, stream);
     const bool uni = a.chirpSel == nullptr && a.fineErr == nullptr;
     return uni ? launchOneWide<UNI_CFG, false, true>(a, ft, stream) : launchOneWide<MOVING_CFG, false, false>(a, ft, stream);
 }
@@ -602,9 +607,13 @@ static bool defaultLayoutsOk()
 }
 static const WideVariant kWideVariants[] = {
     { 11, 0, &launchWideByShape<Wide<11, WPF_NONE | WNT | WONE | WINPLACE>, Wide<11, WW2 | WNT | WONE | WINPLACE>>, &defaultLayoutsOk },   // default
-    V(11, 10, 0),
+#ifndef LORAHIP_FMA      // (the contracted build carries the defaults only)
+    { 11, 10, &launchWideByShape<Wide<11, 0>, Wide<11, WW2>>, &layoutOk<Wide<11, 0>> },
+#endif
     { 12, 0, &launchWideByShape<Wide<12, WNT | WINPLACE>, Wide<12, WW2 | WNT | WINPLACE>>, &defaultLayoutsOk },                            // default
-    V(12, 10, 0),
+#ifndef LORAHIP_FMA
+    { 12, 10, &launchWideByShape<Wide<12, 0>, Wide<12, WW2>>, &layoutOk<Wide<12, 0>> },
+#endif
 #ifdef LORAHIP_ALL_VARIANTS
     V(11, 2, WW2), V(11, 3, WW2 | WCH_LDS), V(11, 4, WW2 | WTW_LDS), V(11, 5, WW2 | WCH_LDS | WTW_LDS), V(11, 6, WW4 | WPF_NONE),
     V(11, 7, WPF_NONE), V(11, 8, WNT), V(11, 9, WPF_NONE | WNT), V(11, 11, WPF_NONE | WNT | WONE), V(11, 12, WNT | WONE),
@@ -614,6 +623,8 @@ static const WideVariant kWideVariants[] = {
     // round 2: the defaults at the 256-register budget of two waves per SIMD
     V(11, 30, WW2 | WPF_NONE | WNT | WONE | WINPLACE), V(11, 31, WW2 | WNT | WINPLACE), V(11, 29, WW2 | WNT | WONE | WINPLACE),
     V(12, 30, WW2 | WNT | WINPLACE), V(12, 31, WW2 | WPF_NONE | WNT | WINPLACE),
+    // round 4: the two-waves-per-SIMD kernels with the chirp values from an LDS copy (32 registers back: no scratch)
+    V(11, 32, WW2 | WNT | WONE | WINPLACE | WCH_LDS), V(12, 32, WW2 | WNT | WINPLACE | WCH_LDS), V(12, 33, WW2 | WPF_NONE | WNT | WINPLACE | WCH_LDS),
 #endif
 };
 #undef V
@@ -636,6 +647,7 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
     return def ? def->launch(a, ft, stream) : hipErrorInvalidValue;     // unknown numbers run the default
 }
 
+#ifndef LORAHIP_NO_STREAM_WIDE
 /***********************************************************************
  * Streaming demodulator for the long windows: a workgroup OWNS a channel (T = 128 / 256 lanes) and walks its stream
  * window after window -- the level-3 twin of lorahip_stream.hip, same frame machine (lorahip_framemachine.h), the
@@ -978,5 +990,7 @@ hipError_t launchStreamWide(const int sf, const StreamArgs &s, hipStream_t strea
 {
     return sf == 11 ? launchStreamWideCfg<StreamWide11>(s, stream) : launchStreamWideCfg<StreamWide12>(s, stream);
 }
+
+#endif // LORAHIP_NO_STREAM_WIDE
 
 } // namespace lorahip
