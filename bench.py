@@ -351,20 +351,10 @@ def traffic_for(sf, a):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def level3_parity(L, sf, iq, host, nsyms, gpu_packets, data, gpu_not_ok, threads):
-    """EVERY channel of the level-3 workload through the CPU reference block (oracle/_ref: the verbatim LoRaDemod.cpp, one fresh
-    block per channel; the pinned restatement where _ref did not travel) on the same IQ: packets compared symbol for symbol, then --
-    from one extra, untimed, traced pass of the streaming kernel -- every work() call's consumption and label kind
-    (LoRaDemod.cpp:213-232,245,282,302-320), i.e. the frame machine's path call by call. Also answers why packets_ok < packets:
-    the reference's own packets are held to the same "carries the sent symbols" test."""
-    import numpy as np
-    from lora_sdr_amd import workloads as WL
-    from oracle.oracle import Oracle, Ref
-    impl, kind = (Ref(), "reference") if Ref.available() else (Oracle(), "port")
-    B, N = host.shape[0], 1 << sf
-    t0 = time.perf_counter()
-    r = impl.demod_run_many(sf, host, mtu=nsyms, nthreads=threads, calls=True)
-    cpu_s = time.perf_counter() - t0
+def packets_vs_reference(gpu_packets, r, B):
+    """the device's packets (channel, round, length, symbols back to back) against a run_many() result of the CPU reference over the
+    same B streams: per channel the number of packets, their lengths and every symbol. -> (bool array of differing channels, packets
+    that did not even fit the reference's arrays)"""
     ch, _rd, ln, sy = gpu_packets
     # the device's packets per channel in time order, laid out like the reference's arrays
     order = np.argsort(ch, kind="stable")
@@ -384,6 +374,23 @@ def level3_parity(L, sf, iq, host, nsyms, gpu_packets, data, gpu_not_ok, threads
         g_syms[c, fill[c]:fill[c] + n] = sy[start[p]:start[p] + n]
         fill[c] += n
     bad_ch = (n_gpu != r["n_packets"]) | (g_lens != r["pkt_lens"]).any(axis=1) | (g_syms != r["pkt_syms"]).any(axis=1)
+    return bad_ch, overflow
+
+
+def level3_parity(L, sf, iq, host, nsyms, gpu_packets, data, gpu_not_ok, threads):
+    """EVERY channel of the level-3 workload through the CPU reference block (oracle/_ref: the verbatim LoRaDemod.cpp, one fresh
+    block per channel; the pinned restatement where _ref did not travel) on the same IQ: packets compared symbol for symbol, then --
+    from one extra, untimed, traced pass of the streaming kernel -- every work() call's consumption and label kind
+    (LoRaDemod.cpp:213-232,245,282,302-320), i.e. the frame machine's path call by call. Also answers why packets_ok < packets:
+    the reference's own packets are held to the same "carries the sent symbols" test."""
+    from lora_sdr_amd import workloads as WL
+    from oracle.oracle import Oracle, Ref
+    impl, kind = (Ref(), "reference") if Ref.available() else (Oracle(), "port")
+    B, N = host.shape[0], 1 << sf
+    t0 = time.perf_counter()
+    r = impl.demod_run_many(sf, host, mtu=nsyms, nthreads=threads, calls=True)
+    cpu_s = time.perf_counter() - t0
+    bad_ch, overflow = packets_vs_reference(gpu_packets, r, B)
     # the reference's packets under the test packets_ok applies to the device's
     ref_pk = []
     for c in range(B):
@@ -491,10 +498,13 @@ def section_level3(env, L, sf, threads=32):
     pk = list(zip(ch_.tolist(), rd_.tolist(), np.split(sy_, np.cumsum(ln_)[:-1]) if ch_.size else []))
     n_dev = int(ps.shape[0])
 
-    def one_pass(to_host=False):
+    def one_pass(to_host=False, together=True):
         d.clear_packets()
         d.activate()
-        torch.cuda.synchronize()
+        if together:
+            env.barrier()                           # (several ranks: every rank's pass starts together; one rank: a device synchronise)
+        else:
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         d.work(iq)                                  # the streaming kernel + per-channel state back: packets stay on the device
         t1 = time.perf_counter()
@@ -510,13 +520,17 @@ def section_level3(env, L, sf, threads=32):
     # ~40 ms of work to leave its idle clocks) -- passes back to back, no host drain in between
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.25:
-        one_pass()
+        one_pass(together=False)                    # (the ranks' ramps take different numbers of passes: no barrier inside)
     best = None
     for _ in range(5):
         r_ = one_pass()
         if best is None or r_[0] < best[0]:
             best = r_
     best = (best[0], best[1], one_pass(to_host=True)[2])
+    # several ranks (bench.py --gpus N): every rank demodulates its own B channels; times are the slowest rank's, counts are sums
+    best = env.max_over_ranks(*best)
+    (calls_all, unique_all) = env.sum_over_ranks(calls, unique_bytes)
+    peak_all = HBM_PEAK_GBS * env.world
     # the RUNNING receiver: the same capture arrives in chunks of 128 (and of 8) windows. One call into the library per chunk
     # (lorahip_demod_receive): the append run -- every channel continues at its own read position, which lives on the device --, the
     # packets that completed (those that span chunks too) packed on the device, the queue cleared. No Python per channel.
@@ -531,7 +545,7 @@ def section_level3(env, L, sf, threads=32):
             d.rewind()
             d.activate()
             w = n_pk_ = n_work = calls_ = 0
-            torch.cuda.synchronize()
+            env.barrier()
             t0 = time.perf_counter()
             while w < cap_:
                 w = min(cap_, w + chunk)
@@ -540,18 +554,20 @@ def section_level3(env, L, sf, threads=32):
                 calls_ += k_
                 n_work += 1
             torch.cuda.synchronize()
-            return time.perf_counter() - t0, calls_, n_pk_, n_work
+            (dt_,) = env.max_over_ranks(time.perf_counter() - t0)
+            (calls_all_, pk_all_) = env.sum_over_ranks(calls_, n_pk_)
+            return dt_, calls_all_, pk_all_, n_work
         running = {}
         for cw in (128, 8):
             running_pass(cw)                        # sizes the buffers of the chunked shape
             rb = min((running_pass(cw) for _ in range(3)), key=lambda r_: r_[0])
             ent_ = {"chunk_windows": cw, "work_per_capture": rb[3], "ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6),
-                    "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / HBM_PEAK_GBS), "work_calls": int(rb[1]), "packets": int(rb[2])}
+                    "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)), "work_calls": int(rb[1]), "packets": int(rb[2])}
             if cw == 128:
                 running = ent_
                 running["entry"] = "lorahip_demod_receive (C ABI): one call per chunk"
                 running["near_squelch"], running["near_step"] = d.near_threshold()     # of the last pass (activate() resets the counters)
-                running["same_packets_as_one_shot"] = bool(rb[2] == n_dev)
+                running["same_packets_as_one_shot"] = bool(rb[2] == n_dev * env.world)
             else:
                 running["chunk8"] = ent_
         d.rewind()
@@ -570,12 +586,12 @@ def section_level3(env, L, sf, threads=32):
     d.activate()
     n_pk, ok = WL.check_frame_packets(pk, data, 1 << sf, nsyms)
     # e2e = host wall clock from IQ in HBM to packets in the decoder's layout in HBM; e2e_host = the same to packets in host memory
-    res = {"sf": sf, "channels": B, "work_calls": int(calls), "Msym_s_e2e": r4(calls / best[0] / 1e6), "e2e_ms": r4(best[0] * 1e3),
-           "frac_e2e": r4(calls * L.bytes_per_symbol(sf) / best[0] / 1e9 / HBM_PEAK_GBS), "e2e_host_ms": r4(best[2] * 1e3),
-           "kernel_us": r4(best[1] * 1e3), "Msym_s_kernel": r4(calls / (best[1] / 1e3) / 1e6),
-           "frac_kernel": r4(calls * L.bytes_per_symbol(sf) / (best[1] / 1e3) / 1e9 / HBM_PEAK_GBS),
-           "unique_stream_bytes": int(unique_bytes), "counted_bytes": int(calls * L.bytes_per_symbol(sf)),
-           "frac_unique": r4(unique_bytes / (best[1] / 1e3) / 1e9 / HBM_PEAK_GBS),
+    res = {"sf": sf, "channels": B * env.world, "channels_per_gpu": B, "work_calls": int(calls_all), "Msym_s_e2e": r4(calls_all / best[0] / 1e6), "e2e_ms": r4(best[0] * 1e3),
+           "frac_e2e": r4(calls_all * L.bytes_per_symbol(sf) / best[0] / 1e9 / peak_all), "e2e_host_ms": r4(best[2] * 1e3),
+           "kernel_us": r4(best[1] * 1e3), "Msym_s_kernel": r4(calls_all / (best[1] / 1e3) / 1e6),
+           "frac_kernel": r4(calls_all * L.bytes_per_symbol(sf) / (best[1] / 1e3) / 1e9 / peak_all),
+           "unique_stream_bytes": int(unique_all), "counted_bytes": int(calls_all * L.bytes_per_symbol(sf)),
+           "frac_unique": r4(unique_all / (best[1] / 1e3) / 1e9 / peak_all),
            "packets": n_pk, "packets_device": n_dev, "packets_expected": B * frames, "packets_ok": ok, "staggered_starts": True,
            "from_host_ms": r4(from_host * 1e3), "from_host_GB_s": r4(iq.numel() * 8 / from_host / 1e9), "from_host_Msym_s": r4(calls / from_host / 1e6)}
     res["near_squelch"], res["near_step"] = near                       # decisions within float rounding of their boundary (pass 0)
@@ -767,6 +783,92 @@ def section_mixed(env, L, a, S=16, n_channels=16384, rccl_single=False):
     return res
 
 
+def section_mixed_level3(env, L, n_channels=16384, frames=1, nsyms=16, threads=32):
+    """BASELINE configs[3] as RECEIVERS: 16384 channels, SF(c) = 7 + c mod 6, every channel a whole LoRaDemod block (frame sync,
+    frequency estimate, packets) behind ONE level-3 handle per rank (lorahip_demod_create_mixed: one part per SF with its own stream
+    and host thread, all parts of the device running side by side), the channels sharded over the ranks by lora_sdr_amd/shard.py (no
+    data-path collective). Every channel carries `frames` frame(s) of `nsyms` data symbols; all of a rank's channels live in one
+    device buffer (lorahip_demod_run_device_segments). Every channel's packets are compared with the verbatim CPU block."""
+    from lora_sdr_amd import workloads as WL
+    torch = env.torch
+    sfs = WL.mixed_sf_channels(n_channels)
+    mine = L.shard_channels(sfs, env.world)[env.rank]
+    my_sf = sfs[mine]
+    parts, first, cnt, at, datas, hosts = [], np.zeros(mine.size, np.int64), np.zeros(mine.size, np.uint64), 0, {}, {}
+    for sf in range(7, 13):
+        local = np.nonzero(my_sf == sf)[0]
+        if local.size == 0:
+            continue
+        ctx = L.Context(sf, device=env.local)
+        iq, data = WL.frame_streams(ctx, local.size, frames, nsyms, sigma=0.05, seed=3 + sf)
+        ctx.close()
+        n = int(iq.shape[1])
+        first[local] = at + np.arange(local.size, dtype=np.int64) * n
+        cnt[local] = n
+        at += local.size * n
+        parts.append(iq.reshape(-1))
+        datas[sf] = (local, data, n)
+    buf = torch.cat(parts)
+    del parts
+    d = L.LoRaDemod(channel_sf=my_sf, devices=[env.local])
+    d.setMTU(nsyms)
+    d.work_segments(buf, first, cnt)                        # pass 0: what the receivers deliver (checked below)
+    calls = d.work_calls()
+    ch_, rd_, ln_, sy_ = d.packets_arrays()
+    calls_sf = {}
+    for i in range(len(d.parts)):
+        calls_sf[d.parts[i][1]] = 0
+    best = None
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.2:
+        d.clear_packets(); d.activate(); d.work_segments(buf, first, cnt)
+    for _ in range(4):
+        d.clear_packets(); d.activate()
+        env.barrier()
+        t0 = time.perf_counter()
+        d.work_segments(buf, first, cnt)
+        env.barrier()
+        dt, km = env.max_over_ranks(time.perf_counter() - t0, d.kernel_ms())
+        if best is None or dt < best[0]:
+            best = (dt, km)
+    d.clear_packets()
+    # byte-weighted: every work() call counts the bytes of its SF (SURVEY.md section 8d)
+    bytes_rank = 0.0
+    from oracle.oracle import Oracle, Ref
+    impl, kind = (Ref(), "reference") if Ref.available() else (Oracle(), "port")
+    bad = checked = n_pk = ok_pk = 0
+    thr = max(1, min(threads, (os.cpu_count() or 1) // env.world))
+    for sf, (local, data, n) in datas.items():
+        host = buf[int(first[local[0]]):int(first[local[0]]) + local.size * n].reshape(local.size, n).cpu().numpy()
+        r = impl.demod_run_many(sf, host, mtu=nsyms, nthreads=thr)
+        bytes_rank += float(r["total_calls"]) * L.bytes_per_symbol(sf)
+        sel = np.isin(ch_, local)
+        remap = np.full(mine.size, -1, np.int64)
+        remap[local] = np.arange(local.size)
+        lens_sel = ln_[sel]
+        starts = np.concatenate([[0], np.cumsum(ln_)])[:-1][sel]
+        sy_sel = np.concatenate([sy_[a_:a_ + b_] for a_, b_ in zip(starts.tolist(), lens_sel.tolist())]) if lens_sel.size else np.zeros(0, np.int16)
+        bad_ch, overflow = packets_vs_reference((remap[ch_[sel]].astype(np.int32), rd_[sel], lens_sel, sy_sel), r, local.size)
+        bad += int(bad_ch.sum()) + overflow
+        checked += local.size
+        pk = list(zip(remap[ch_[sel]].tolist(), rd_[sel].tolist(), np.split(sy_sel, np.cumsum(lens_sel)[:-1]) if lens_sel.size else []))
+        a_, b_ = WL.check_frame_packets(pk, data, 1 << sf, nsyms)
+        n_pk += a_; ok_pk += b_
+        del host
+    calls_all, bad_all, checked_all, bytes_all, npk_all, ok_all = env.sum_over_ranks(calls, bad, checked, bytes_rank, n_pk, ok_pk)
+    res = {"channels": n_channels, "sf_rule": "7 + c mod 6", "frames_per_channel": frames, "data_symbols_per_frame": nsyms,
+           "object": "lorahip_demod_create_mixed: %d parts on rank 0 (one per SF, own stream + host thread)" % len(d.parts),
+           "work_calls": int(calls_all), "e2e_ms": r4(best[0] * 1e3), "kernel_ms_slowest_part": r4(best[1]),
+           "Msym_s_e2e": r4(calls_all / best[0] / 1e6),
+           "frac_byte_weighted_e2e": r4(bytes_all / best[0] / 1e9 / (HBM_PEAK_GBS * env.world)),
+           "oracle_kind": kind, "oracle_channels_checked": int(checked_all), "oracle_channel_mismatches": int(bad_all),
+           "packets": int(npk_all), "packets_expected": n_channels * frames, "packets_ok": int(ok_all)}
+    d.close()
+    del buf
+    torch.cuda.empty_cache()
+    return res
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def respawn_under_torchrun(a):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run would silently measure ONE rank: start the N ranks ourselves
@@ -930,20 +1032,34 @@ def main():
         sh.close()
         del sh
         env.torch.cuda.empty_cache()
-        if env.world == 1:
-            for sf in range(7, 13):
-                level3.append(section_level3(env, L, sf, threads))
-                env.torch.cuda.empty_cache()
-        c5 = section_config5(env, L, a, threads) if env.world == 1 else None
+        # every rank runs its own channels of every section (weak scaling, barriers around the timed regions, MAX over ranks for times,
+        # sums for counts); the CPU-side checks that need the whole box (reference block on every channel) run on one rank alone
+        for sf in range(7, 13):
+            level3.append(section_level3(env, L, sf, threads))
+            env.torch.cuda.empty_cache()
+        c5 = section_config5(env, L, a, threads)
         env.torch.cuda.empty_cache()
         mixed = section_mixed(env, L, a)
+        env.torch.cuda.empty_cache()
+        try:
+            mixed_l3 = section_mixed_level3(env, L, threads=threads)
+        except Exception as e:                          # beside the contract line: report, do not fail the bench
+            mixed_l3 = {"error": repr(e)[:200]}
+        env.torch.cuda.empty_cache()
+        scaling = None
+        if env.world == 1:
+            try:
+                scaling = section_level3_scaling(env, L)
+            except Exception as e:
+                scaling = {"error": repr(e)[:200]}
         if rank0:
             line["per_sf"], line["moving"] = per_sf, moving
-            if level3:
-                line["level3"] = level3
-            if c5:
-                line["config5"] = c5
+            line["level3"] = level3
+            line["config5"] = c5
             line["mixed"] = mixed
+            line["mixed_level3"] = mixed_l3
+            if scaling is not None:
+                line["level3_scaling"] = scaling
     emit(env, line if rank0 else None)
 
 

@@ -52,3 +52,13 @@ fi
 if [[ $what == *smoke* ]]; then
   timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.txt 2>&1; tail -3 $O/${TAG}_smoke.txt
 fi
+if [[ $what == *fma* ]]; then
+  timeout 300 python tools/fma_report.py ${FMASFS:-7 10 12} > $O/${TAG}_fma_report.txt 2> $O/${TAG}_fma_report.err; cat $O/${TAG}_fma_report.txt; tail -2 $O/${TAG}_fma_report.err
+  for sf in ${FMASFS:-7 10 12}; do
+    for v in 0 40; do
+      ( cd /tmp && timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY -d $O/${TAG}_pmc_fma_sf${sf}_v$v -o pmc --output-format csv -- \
+          python $R/bench.py --sf $sf --variant $v --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $O/${TAG}_pmc_fma_sf${sf}_v$v.log 2>&1 )
+      python tools/pmc_kernels.py "$O/${TAG}_pmc_fma_sf${sf}_v$v" detect "SF$sf variant $v" | tee -a $O/${TAG}_fma_counters.txt
+    done
+  done
+fi
