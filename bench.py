@@ -524,8 +524,7 @@ def section_level3(env, L, sf, threads=32):
     best = None
     for _ in range(5):
         r_ = one_pass()
-        if best is None or r_[0] < best[0]:
-            best = r_
+        best = r_ if best is None else (min(best[0], r_[0]), min(best[1], r_[1]), r_[2])     # best wall clock, best device time
     best = (best[0], best[1], one_pass(to_host=True)[2])
     # several ranks (bench.py --gpus N): every rank demodulates its own B channels; times are the slowest rank's, counts are sums
     best = env.max_over_ranks(*best)

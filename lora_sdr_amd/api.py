@@ -623,6 +623,13 @@ class LoRaDemod:
         if cnt.size and int((first + cnt.astype(np.int64)).max()) > buf.numel():
             raise ValueError("a segment ends beyond the buffer")
         rounds = C.c_int64()
+        if self.channel_sf is not None:
+            # an object of several (device, SF) parts: each part launches on its OWN stream so that they overlap on the device; one
+            # common stream would run them one after the other. What torch's stream still has queued -- the producer of `buf` -- ends first.
+            torch.cuda.current_stream(buf.device).synchronize()
+            check(self._lib.lorahip_demod_run_device_segments(self._h, _dptr(buf), first.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                              cnt.ctypes.data_as(C.POINTER(C.c_size_t)), C.byref(rounds)), "lorahip_demod_run_device_segments")
+            return rounds.value
         check(self._lib.lorahip_demod_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)), "lorahip_demod_set_stream")
         try:
             check(self._lib.lorahip_demod_run_device_segments(self._h, _dptr(buf), first.ctypes.data_as(C.POINTER(C.c_int64)),

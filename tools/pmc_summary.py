@@ -62,6 +62,10 @@ for sf, t in traffic.items():
         t["total_bytes"] = t["fetch_bytes"] + t["write_bytes"]
 if traffic:
     out = os.path.join(root, "traffic.json")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from lora_sdr_amd.build import kernel_digest
+    # stamped with the digest of the files the detect kernels are compiled from: bench.py replays these numbers only for that build
     json.dump({"note": "HBM bytes per launch of the detect kernel at bench.py's default geometry; rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate passes",
+               "sources_sha16": kernel_digest(), "session": os.environ.get("TAG", "?"),
                "per_sf": traffic}, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out)
