@@ -20,6 +20,9 @@
 #ifndef SCAN_CHAINS_WIDE
 #define SCAN_CHAINS_WIDE 1
 #endif
+#ifndef STREAM_WIDE_PREFETCH
+#define STREAM_WIDE_PREFETCH 0  // 1: demodStreamWide requests the window at off + N while this one is transformed. Measured 2-3 % SLOWER (profiles/r04/s10_*): kept as the A/B
+#endif
 namespace lorahip {
 
 template <int LOG2N_, int VEC_, int MINW_, int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, bool PREFETCH_ = true, bool NT_ = false, int WPB_ = 0,
@@ -727,10 +730,16 @@ demodStreamWide(const StreamArgs s)
     // Signals without a trace (lorahip_demod_set_signals): the DOWNCHIRP1 call of a packet takes the traced path (`full`), see demodStream
     const bool traced = s.calls != nullptr;
     const bool sig = s.sigOut != nullptr;
-    auto detect = [&](const bool all, const bool wantSq, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
-                      int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
+    // The window's samples are PREFETCHED: most calls consume N samples (both down-chirp states, every data symbol, a squelched
+    // FRAMESYNC window; the second sync window sits at pos + N too), so the window at off + N is requested as soon as this one's
+    // samples have left their registers for phase 0 -- the loads stay in flight across the window's barriers (which wait for LDS
+    // only) and hide the HBM latency the frame machine otherwise exposes once per call. A call that consumed something else
+    // (N - value while acquiring, the quarter chirp) finds another offset than the prefetched one and loads its own window.
+    v2f x[R][VEC];
+    long long preOff = -1;                                   // workgroup-uniform: which window x holds (or is about to hold)
+    const long long endOff = base + len;
+    auto loadWindow = [&](const long long off)
     {
-        v2f x[R][VEC];
         const v2f *win = gIq + off;                          // scalar base, per-lane offsets
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -744,6 +753,11 @@ demodStreamWide(const StreamArgs s)
             }
             else x[r][0] = *p;
         }
+    };
+    auto detect = [&](const bool all, const bool wantSq, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
+                      int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
+    {
+        if (!STREAM_WIDE_PREFETCH || off != preOff) loadWindow(off);
         const float d = err * (float)LORAHIP_FINE_STEPS;
         const bool moving = d != 0.0f;                       // workgroup-uniform
         int *sIdx = reinterpret_cast<int *>(X);
@@ -795,6 +809,12 @@ demodStreamWide(const StreamArgs s)
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int u = 0; u < VEC; u++) v0[u][Plan<LOG2N>::pos(VEC * T * r) & (R - 1)] = x[r][u];
+        if (STREAM_WIDE_PREFETCH)
+        {
+            // x is free: the next window, speculatively (it must lie inside the stream: the call's own 2N are checked, the third N is not)
+            if (off + 2 * N <= endOff) { preOff = off + N; loadWindow(preOff); }
+            else preOff = -1;
+        }
 #pragma unroll
         for (int u = 0; u < VEC; u++) runPhase<LOG2N, 0, B1, false>(v0[u], 0, sTw, nullptr);
 #pragma unroll
