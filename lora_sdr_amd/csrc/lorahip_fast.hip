@@ -455,7 +455,7 @@ static const FastVariant kFastVariants[] = {
     { 9, 10, &launchByShape<Fast<9, 0>, Fast<9, W2>, Fast<9, W2>> },
 #endif
     // default SF10: per-window settings at two waves per SIMD with the middle-phase twiddles in registers too
-    { 10, 0, &launchByShape<Fast<10, CH_REG | TW_REG | NT | X1_SWAP>, Fast<10, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>, Fast<10, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>> },
+    { 10, 0, &launchByShape<Fast<10, CH_REG | TW_REG | NT | X1_SWAP>, Fast<10, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>, Fast<10, W2>> },   // (debug ports: every table from LDS, no scratch)
 #ifndef LORAHIP_FMA
     { 10, 10, &launchByShape<Fast<10, 0>, Fast<10, W2>, Fast<10, W2>> },
 #endif
