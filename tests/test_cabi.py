@@ -53,6 +53,36 @@ def test_version_and_errors():
     assert lib.lorahip_demod_kernel_ms(None) == 0.0
 
 
+def test_round4_entries_refuse_bad_arguments_and_fail_loudly_without_a_gpu():
+    """lorahip_demod_create_mixed / _receive / _run_device_append / signals / part accessors: NULL and out-of-range arguments are
+    LORAHIP_E_INVALID (never a crash), and without a gfx950 device the mixed object cannot be made (no CPU path behind it)"""
+    import torch
+    lib = L.load()
+    h = C.c_void_p()
+    sfs = np.array([7, 8, 9], np.int32)
+    dev = np.array([0], np.int32)
+    assert lib.lorahip_demod_create_mixed(None, dev.ctypes.data, 1, sfs.ctypes.data, 3) == -1
+    assert lib.lorahip_demod_create_mixed(C.byref(h), None, 1, sfs.ctypes.data, 3) == -1
+    assert lib.lorahip_demod_create_mixed(C.byref(h), dev.ctypes.data, 0, sfs.ctypes.data, 3) == -1
+    assert lib.lorahip_demod_create_mixed(C.byref(h), dev.ctypes.data, 1, sfs.ctypes.data, 0) == -1
+    bad = np.array([7, 13], np.int32)
+    assert lib.lorahip_demod_create_mixed(C.byref(h), dev.ctypes.data, 1, bad.ctypes.data, 2) == -1 and not h.value
+    if not torch.cuda.is_available():
+        rc = lib.lorahip_demod_create_mixed(C.byref(h), dev.ctypes.data, 1, sfs.ctypes.data, 3)
+        assert rc in (-2, -5) and not h.value, rc                  # LORAHIP_E_NODEVICE / _ARCH: loud, nothing half-made
+    assert lib.lorahip_demod_receive(None, None, 0, 0, None, None, None) == -1
+    assert lib.lorahip_demod_run_device_append(None, None, 0, 0, None) == -1
+    assert lib.lorahip_demod_rewind(None) == -1
+    assert lib.lorahip_demod_set_signals(None, 1) == -1
+    assert lib.lorahip_demod_num_signals(None) == 0
+    assert lib.lorahip_demod_num_parts(None) == 0 and lib.lorahip_demod_num_channels(None) == 0
+    assert lib.lorahip_demod_part(None, 0, None, None, None, None) == -1
+    assert lib.lorahip_demod_part_handle(None, 0) is None
+    assert lib.lorahip_demod_set_variant(None, 0) == -1
+    assert lib.lorahip_set_variant(None, 40) == -1
+    assert C.sizeof(_lib.PacketRows) == 7 * 8          # struct lorahip_packet_rows: 6 pointer-sized fields + 2 x int32
+
+
 @pytest.mark.parametrize("sf", range(6, 13))
 def test_host_tables_match_oracle(oracle, sf):
     up, down, fine, tw = L.host_tables(sf)
