@@ -569,6 +569,31 @@ def section_level3(env, L, sf, threads=32):
                 running["same_packets_as_one_shot"] = bool(rb[2] == n_dev * env.world)
             else:
                 running["chunk8"] = ent_
+        # the same with the steps PIPELINED (async = 2: step k launched before step k-1's summary is read; packets one step late)
+        def piped_pass(chunk_windows):
+            chunk = chunk_windows << sf
+            d.clear_packets()
+            d.rewind()
+            d.activate()
+            w = n_pk_ = n_work = calls_ = 0
+            env.barrier()
+            t0 = time.perf_counter()
+            while w < cap_:
+                w = min(cap_, w + chunk)
+                n_, k_ = d.receive(iq, w, rows_, async_=2)
+                n_pk_ += n_
+                calls_ += k_
+                n_work += 1
+            n_, k_ = d.receive_flush(rows_)
+            (dt_,) = env.max_over_ranks(time.perf_counter() - t0)
+            (calls_all_, pk_all_) = env.sum_over_ranks(calls_ + k_, n_pk_ + n_)
+            return dt_, calls_all_, pk_all_, n_work
+        for cw in (128, 8):
+            piped_pass(cw)
+            rb = min((piped_pass(cw) for _ in range(3)), key=lambda r_: r_[0])
+            (running if cw == 128 else running["chunk8"])["pipelined"] = {
+                "ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6),
+                "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)), "packets": int(rb[2])}
         d.rewind()
     except Exception as e:                          # a measurement beside the contract line: report, do not fail the bench
         running = {"error": repr(e)}

@@ -328,18 +328,27 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * left queued if that exceeds cap_packets), *work_calls = LoRaDemod::work() calls made by this step, summed over the channels.
  * With async = 1 the call returns without waiting for the packing kernels: the rows are valid in stream order on the object's
  * launch stream (lorahip_demod_set_stream), which is where a decoder that follows would be queued. Signals kept by
- * lorahip_demod_set_signals are dropped by this call (read them with the ordinary run + accessors instead). */
+ * lorahip_demod_set_signals are dropped by this call (read them with the ordinary run + accessors instead).
+ * With async = 2 the steps are PIPELINED: this step's kernel is launched before the previous step's summary is read, so the host's
+ * share of a step (launch latencies, the wait for the summary, the packing launches: ~60 us) overlaps the kernel instead of
+ * following it. The price is one step of latency: *n_packets / *work_calls and the rows are those of the PREVIOUS step (0 for the
+ * first); lorahip_demod_receive_flush() delivers the last step's and leaves the pipeline. The first call after anything else touched
+ * the object is an ordinary step (its packets delivered at once). While a step is in flight every other entry point that needs the
+ * object's state returns LORAHIP_E_INVALID ("flush first"); no trace / ports / signals in this mode; a step whose packets do not fit
+ * the rows loses them (LORAHIP_E_INVALID) -- size the rows for a step. */
 typedef struct lorahip_packet_rows {
     size_t struct_size;     /* = sizeof(lorahip_packet_rows) */
     uint16_t *syms_dev; size_t sym_stride;      /* [cap_packets][sym_stride], zero padded */
     int32_t *nsyms_dev;                          /* [cap_packets] */
     int32_t *channel_dev;                        /* [cap_packets], nullable */
     size_t cap_packets;
-    int32_t async;
+    int32_t async;          /* 0 wait, 1 rows valid in stream order, 2 pipelined (see above) */
     int32_t reserved;
 } lorahip_packet_rows;
 int lorahip_demod_receive(lorahip_demod *d, const float *iq_dev, size_t row_stride, size_t n_valid, const lorahip_packet_rows *rows,
                           size_t *n_packets, int64_t *work_calls);
+int lorahip_demod_receive_flush(lorahip_demod *d, const lorahip_packet_rows *rows /* nullable: the last step's packets are dropped */,
+                                size_t *n_packets, int64_t *work_calls);
 
 /* The block's signals "error" (int), "power" (float), "snr" (float), emitted once per packet at DOWNCHIRP1 (LoRaDemod.cpp:85-87,
  * 267-269), WITHOUT a per-call trace: with enable = 1 the following runs keep one record per emission -- the kernels evaluate

@@ -121,6 +121,7 @@ SIGNATURES = {
     "lorahip_demod_run_device_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int64)]),
     "lorahip_demod_rewind": (C.c_int, [C.c_void_p]),
     "lorahip_demod_receive": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(PacketRows), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
+    "lorahip_demod_receive_flush": (C.c_int, [C.c_void_p, C.POINTER(PacketRows), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "lorahip_demod_set_signals": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_num_signals": (C.c_size_t, [C.c_void_p]),
     "lorahip_demod_get_signals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -695,22 +695,40 @@ class LoRaDemod:
         return (torch.empty((int(cap_packets), int(stride)), dtype=torch.int16, device=dev), torch.empty(int(cap_packets), dtype=torch.int32, device=dev),
                 torch.empty(int(cap_packets), dtype=torch.int32, device=dev))
 
-    def receive(self, buf, n_valid, rows, async_=True):
-        """lorahip_demod_receive: one receiver step in one call into the library -- the append run, the completed packets packed into
-        `rows` (receiver_rows()) on the device, the queue cleared. Returns (n_packets, work_calls). Runs on torch's current stream; with
-        async_ the rows are valid in that stream's order."""
-        import torch
+    def _rows_struct(self, rows, async_):
         syms, nsyms, chan = rows
         r = _lib.PacketRows()
         r.struct_size = C.sizeof(_lib.PacketRows)
         r.syms_dev, r.sym_stride, r.nsyms_dev, r.channel_dev = syms.data_ptr(), int(syms.shape[1]), nsyms.data_ptr(), chan.data_ptr()
-        r.cap_packets, r.async_ = int(syms.shape[0]), int(bool(async_))
+        r.cap_packets, r.async_ = int(syms.shape[0]), int(async_)
+        return r
+
+    def receive(self, buf, n_valid, rows, async_=True):
+        """lorahip_demod_receive: one receiver step in one call into the library -- the append run, the completed packets packed into
+        `rows` (receiver_rows()) on the device, the queue cleared. Returns (n_packets, work_calls). async_: False = wait; True = the
+        rows are valid in the order of the stream the object launches on; 2 = PIPELINED: the step is launched and the packets of
+        the previous step are returned (receive_flush() delivers the last step's). A pipelined receiver keeps its private stream
+        (the steps must stay in flight across calls): whatever produced `buf` on torch's stream is waited for first."""
+        import torch
+        r = self._rows_struct(rows, 2 if async_ == 2 else int(bool(async_)))
         n, calls = C.c_size_t(), C.c_int64()
+        if async_ == 2:
+            torch.cuda.current_stream(buf.device).synchronize()
+            check(self._lib.lorahip_demod_receive(self._h, _dptr(buf), int(buf.shape[1]), int(n_valid), C.byref(r), C.byref(n), C.byref(calls)), "lorahip_demod_receive")
+            return n.value, calls.value
         check(self._lib.lorahip_demod_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)), "lorahip_demod_set_stream")
         try:
             check(self._lib.lorahip_demod_receive(self._h, _dptr(buf), int(buf.shape[1]), int(n_valid), C.byref(r), C.byref(n), C.byref(calls)), "lorahip_demod_receive")
         finally:
             self._lib.lorahip_demod_reset_stream(self._h)
+        return n.value, calls.value
+
+    def receive_flush(self, rows=None):
+        """lorahip_demod_receive_flush: the last pipelined step's packets into `rows` (None: dropped); returns (n_packets, work_calls)
+        with the launch stream drained"""
+        n, calls = C.c_size_t(), C.c_int64()
+        r = self._rows_struct(rows, 0) if rows is not None else None
+        check(self._lib.lorahip_demod_receive_flush(self._h, C.byref(r) if r is not None else None, C.byref(n), C.byref(calls)), "lorahip_demod_receive_flush")
         return n.value, calls.value
 
     def work(self, streams):

@@ -119,6 +119,7 @@ struct lorahip_demod
     bool devCarryValid;              // dCarry holds the open packets of the state on the device
     bool hostCarryStale;             // ch[].outSymbols lack what the runs since the last drain received (implies devCarryValid)
     size_t callsPerWindowQ8;         // streaming runs: work() calls per N samples the record buffers are sized for, in 1/256 (adapts, see runStream)
+    void *pipe;                      // Pipe: the two record sets and events of the pipelined receiver (lorahip_demod_receive, async = 2)
     void *pending;                   // PendingLaunch (records of the last streaming launch still on the device)
     std::vector<size_t> carry;       // per channel: symbols of a packet begun before the launch being drained
 };
@@ -439,6 +440,14 @@ struct PendingLaunch
 };
 
 static PendingLaunch &pendingOf(lorahip_demod *dm) { return *static_cast<PendingLaunch *>(dm->pending); }
+//! a pipelined receiver step is in flight (lorahip_demod_receive with async = 2): only receive / receive_flush may touch the object
+static bool pipeBusy(const lorahip_demod *dm);
+static int refuseWhilePiped(const lorahip_demod *dm)
+{
+    if (!pipeBusy(dm)) return LORAHIP_OK;
+    setLastError("a pipelined receiver step is in flight: lorahip_demod_receive_flush first");
+    return LORAHIP_E_INVALID;
+}
 static std::vector<size_t> &carryOf(lorahip_demod *dm) { return dm->carry; }
 
 //! packets of one run in the order the host-driven path posts them: round by round, channels ascending inside a round
@@ -627,6 +636,7 @@ static int fetchCarry(lorahip_demod *dm)
 //! bring the Channel mirrors up to date with the device's state (its pinned copy): only the paths that read them pay for it
 static int syncMirrors(lorahip_demod *dm)
 {
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
     if (dm->mirrorsStale && dm->sHost)
     {
         { const int rc = ensureHead(dm); if (rc != LORAHIP_OK) return rc; }
@@ -942,6 +952,178 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 }
 
 /***********************************************************************
+ * The PIPELINED receiver step (lorahip_demod_receive with async = 2). A receiver step is: streaming kernel, 64-byte summary back,
+ * packets packed for the decoder. Run strictly one after the other, the host's share (launch latencies, the wait for the summary,
+ * the packing launches: ~60 us) is exposed once per step -- half the step at chunks of 8 windows. Here step k's kernel is launched
+ * BEFORE step k-1's summary is read: the host waits for summary k-1 and packs step k-1's packets while kernel k runs, and the
+ * caller gets every packet one step later (lorahip_demod_receive_flush delivers the last step's). Nothing the host learns from
+ * summary k-1 is needed to launch kernel k: the per-channel state, the read positions and the open packets' symbols are on the
+ * device, in stream order; a channel that filled its record buffer in step k-1 is simply continued by kernel k (the kernels are
+ * resumable by design). The per-launch record arrays exist twice (kernel k writes one set while step k-1's are packed from the other).
+ **********************************************************************/
+struct Pipe
+{
+    bool active;                    // steps are in flight: only receive / flush may touch the object
+    unsigned k;                     // steps launched since the pipeline was entered
+    char *dev[2]; size_t bytes[2];  // record sets (a StreamLayout each; the state and the carry rows are the object's own)
+    StreamLayout lay[2];
+    StreamSummary *hSum;            // [2] pinned and mapped: the summary kernel writes here directly (no copy to enqueue)
+    hipEvent_t ev[2];
+    bool pending[2];
+};
+static Pipe &pipeOf(lorahip_demod *dm) { return *static_cast<Pipe *>(dm->pipe); }
+static bool pipeBusy(const lorahip_demod *dm) { return dm->pipe != nullptr && static_cast<const Pipe *>(dm->pipe)->active; }
+
+//! per-launch record capacity (work() calls per channel) for streams of at most maxLen samples: see runStream
+static void streamCapacity(const lorahip_demod *dm, const size_t maxLen, size_t &cap, size_t &capPkt)
+{
+    const size_t perCall = sizeof(short) + (dm->tracing ? sizeof(lorahip_work_result) : 0) + sizeof(StreamPacket) / 4 + 1 + (dm->wantSignals ? sizeof(StreamSignal) / 4 : 0);
+    cap = (maxLen / dm->N) * dm->callsPerWindowQ8 / 256 + 64;
+    if (cap > 65536) cap = 65536;
+    const size_t capMem = (size_t(1) << 30) / (dm->B * perCall);
+    if (cap > capMem) cap = capMem;
+    if (cap < 8) cap = 8;
+    capPkt = cap / 4 + 2;
+}
+
+//! what summary `set` says, into the object's books; packs that step's packets into `rows` (stream-ordered; no wait)
+static int pipeDeliver(lorahip_demod *dm, const int set, const lorahip_packet_rows *rows, size_t *nPackets, int64_t *calls)
+{
+    Pipe &P = pipeOf(dm);
+    lorahip_ctx *ctx = dm->ctx;
+    LORAHIP_TRY(hipEventSynchronize(P.ev[set]));
+    P.pending[set] = false;
+    const StreamSummary sum = P.hSum[set];
+    dm->nNearSquelch += int64_t(unsigned(sum.nearSquelch - dm->nearSeen[0]));
+    dm->nNearStep += int64_t(unsigned(sum.nearStep - dm->nearSeen[1]));
+    dm->nearSeen[0] = sum.nearSquelch; dm->nearSeen[1] = sum.nearStep;
+    dm->workCalls += sum.calls;
+    dm->lastSum = sum;
+    if (calls) *calls = sum.calls;
+    const size_t n = size_t(sum.packets);
+    if (nPackets) *nPackets = n;
+    if (n == 0) return LORAHIP_OK;
+    if (rows->syms_dev == nullptr || rows->nsyms_dev == nullptr || rows->sym_stride == 0 || rows->sym_stride > 0x7fffffffu || rows->cap_packets < n)
+    {
+        setLastError("lorahip_demod_receive (pipelined): the rows cannot hold the step's packets (they are lost: the pipeline does not keep a host queue)");
+        return LORAHIP_E_INVALID;
+    }
+    const StreamLayout &L = P.lay[set];
+    const size_t nbRow = align256(L.B * sizeof(int));
+    { const int grc = growDense(dm, nbRow + n * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
+    char *d = P.dev[set];
+    LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(d + L.oPkt), reinterpret_cast<const int *>(d + L.oNPkt),
+                                  reinterpret_cast<const short *>(d + L.oSym), reinterpret_cast<int *>(dm->dDense), L.B, int(L.symStride), int(L.capPkt), n,
+                                  reinterpret_cast<long long *>(dm->dDense + nbRow), rows->syms_dev, int(rows->sym_stride), rows->nsyms_dev, rows->channel_dev,
+                                  ctx->stream));
+    return LORAHIP_OK;
+}
+
+//! leave the pipeline: the last step's packets into `rows` (nullable: they are dropped), the object back in the state a streaming run leaves
+static int pipeFlush(lorahip_demod *dm, const lorahip_packet_rows *rows, size_t *nPackets, int64_t *calls)
+{
+    Pipe &P = pipeOf(dm);
+    if (nPackets) *nPackets = 0;
+    if (calls) *calls = 0;
+    if (!P.active) return LORAHIP_OK;
+    const DeviceGuard guard(dm->ctx->device);
+    int rc = LORAHIP_OK;
+    const int last = int((P.k - 1) & 1);
+    if (P.k > 0 && P.pending[last])
+    {
+        lorahip_packet_rows none;
+        std::memset(&none, 0, sizeof(none));
+        rc = pipeDeliver(dm, last, rows ? rows : &none, nPackets, calls);
+        if (rows == nullptr && rc == LORAHIP_E_INVALID) rc = LORAHIP_OK;      // dropped on request
+    }
+    LORAHIP_TRY(hipStreamSynchronize(dm->ctx->stream));
+    P.active = false;
+    dm->kernelMs = 0.0;                               // (the pipelined steps are not timed one by one: an event pair per step is two more calls)
+    // what a streaming run leaves: the state (and the open packets' symbols) on the device, the pinned copy and the mirrors behind
+    dm->devStateFresh = true; dm->posOnDevice = true; dm->mirrorsStale = true; dm->headStale = true;
+    dm->devCarryValid = true; dm->hostCarryStale = true;
+    pendingOf(dm).valid = false;
+    return rc;
+}
+
+static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStride, const size_t nValid, const lorahip_packet_rows *rows, size_t *nPackets,
+                    int64_t *calls, bool &handled)
+{
+    handled = false;
+    Pipe &P = pipeOf(dm);
+    lorahip_ctx *ctx = dm->ctx;
+    const size_t N = dm->N, B = dm->B;
+    const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(ctx->sf));
+    // What the pipeline needs in place: the streaming mode, no trace / ports / signals, the state and the open packets on the device
+    // with carry rows long enough, a continuing append stream. Anything else takes the ordinary step (which establishes exactly that).
+    const bool compatible = stream && !dm->tracing && !dm->portsOn && !dm->wantSignals && !dm->activatePending && dm->sDev != nullptr &&
+                            dm->append && !dm->appendFresh && dm->uniStride == rowStride && nValid >= dm->appendPrev &&
+                            dm->dCarry != nullptr && dm->mtu + 1 <= dm->carryCap;
+    const bool ready = compatible && dm->devStateFresh && (dm->devCarryValid || !dm->lastSum.anyOpen) && !pendingOf(dm).valid;
+    if (!P.active && !ready) return LORAHIP_OK;
+    if (P.active && !compatible) { setLastError("lorahip_demod_receive (pipelined): a setting or the rows changed under a running pipeline (lorahip_demod_receive_flush first)"); return LORAHIP_E_INVALID; }
+    handled = true;
+    const DeviceGuard guard(ctx->device);
+    if (!P.active)
+    {
+        if (P.hSum == nullptr)
+        {
+            LORAHIP_TRY(hipHostMalloc((void **)&P.hSum, 2 * sizeof(StreamSummary), hipHostMallocMapped));
+            for (int i = 0; i < 2; i++) LORAHIP_TRY(hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming));
+        }
+        P.active = true; P.k = 0; P.pending[0] = P.pending[1] = false;
+        dm->devStateFresh = false;                    // until the pipeline is flushed, only it knows where the state stands
+    }
+    const int set = int(P.k & 1);
+    size_t cap, capPkt;
+    streamCapacity(dm, nValid - dm->appendPrev + 2 * N, cap, capPkt);
+    StreamLayout L;
+    L.make(B, cap, capPkt, false, dm->carryCap, false);
+    if (L.total > P.bytes[set])
+    {
+        // (this set's last use, step k - 2, was packed during step k - 1's call, stream-ordered before kernel k - 1: freeing waits for it)
+        if (P.dev[set]) { (void)hipFree(P.dev[set]); P.dev[set] = nullptr; P.bytes[set] = 0; }
+        const size_t want = L.total + L.total / 4;
+        LORAHIP_TRY(hipMalloc((void **)&P.dev[set], want));
+        P.bytes[set] = want;
+    }
+    P.lay[set] = L;
+    const StreamLayout H = headLayout(dm);
+    char *d = P.dev[set];
+    StreamArgs a;
+    a.iq = reinterpret_cast<const float2 *>(iqDev);
+    a.base = nullptr; a.len = nullptr;
+    a.uniformLen = (long long)nValid; a.uniformStride = (long long)rowStride;
+    a.flags = 4 | 8;                                  // continue the streams; open packets in from / out to the carry rows
+    a.carry = dm->dCarry; a.carryCap = int(dm->carryCap); a.maxBlocks = 0;
+    a.state = reinterpret_cast<StreamState *>(dm->sDev + H.oState);          // the object's own: every launch continues it
+    a.nCalls = reinterpret_cast<int *>(d + L.oN); a.nSym = reinterpret_cast<int *>(d + L.oNSym); a.nPkt = reinterpret_cast<int *>(d + L.oNPkt);
+    a.nSig = reinterpret_cast<int *>(d + L.oNSig);
+    a.pktOut = reinterpret_cast<StreamPacket *>(d + L.oPkt); a.symOut = reinterpret_cast<short *>(d + L.oSym);
+    a.sigOut = nullptr; a.calls = nullptr;
+    a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
+    a.fineA = ctx->fineGather ? nullptr : ctx->dFineA; a.fineB = ctx->fineGather ? nullptr : ctx->dFineB;
+    a.nChannels = unsigned(B); a.cap = int(cap); a.symStride = int(L.symStride); a.capPkt = int(capPkt);
+    a.powerScale = ctx->powerScale; a.thresh = dm->thresh; a.sync = dm->sync;
+    a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
+    a.near = reinterpret_cast<unsigned *>(dm->sDev + H.oNear);
+    // four calls per step: the kernel, its summary (written straight into pinned host memory), the event the next call waits on -- and
+    // the previous step's packing below
+    LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
+    LORAHIP_TRY(launchStreamSummary(a.state, a.nCalls, a.nSym, a.nPkt, nullptr, B, int(cap), int(capPkt), a.near, &P.hSum[set], ctx->stream));
+    LORAHIP_TRY(hipEventRecord(P.ev[set], ctx->stream));
+    P.pending[set] = true;
+    P.k++;
+    dm->uniform = true; dm->uniSpc = nValid; dm->uniStride = rowStride; dm->appendPrev = nValid; dm->geomApplied = false;
+    dm->mirrorsStale = true; dm->headStale = true;
+    // ... and while it runs: the step before
+    if (nPackets) *nPackets = 0;
+    if (calls) *calls = 0;
+    if (P.k >= 2 && P.pending[set ^ 1]) return pipeDeliver(dm, set ^ 1, rows, nPackets, calls);
+    return LORAHIP_OK;
+}
+
+/***********************************************************************
  * Level-3 debug ports: the block's "raw" / "dec" / "fft" outputs (LoRaDemod.cpp:81-83). The run records, per work() call, the
  * dechirp state it started from (lorahip_work_result.fine_*); the ports are then REPLAYED from that trace with the batch
  * kernels -- the same arithmetic on the same inputs, hence the same bits -- and scattered into the caller's per-channel
@@ -1098,6 +1280,7 @@ static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(dm->ctx->sf));
     if (stream && !streamAvailable(dm->ctx->sf)) { setLastError("no streaming kernel for this SF"); return LORAHIP_E_INVALID; }
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
     { const int rc = drainPending(dm); if (rc != LORAHIP_OK) return rc; }       // the previous run's records, if still on the device
     // the port replay reads the per-call trace; a trace the caller did not ask for lives for this run only (it must neither grow
     // without bound in a long-running receiver nor show up in lorahip_demod_get_trace / _trace_len / _get_labels)
@@ -1134,8 +1317,10 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
     dm->evK0 = nullptr; dm->evK1 = nullptr; dm->kernelMs = 0.0;
     dm->pending = new (std::nothrow) PendingLaunch();
-    if (dm->pending == nullptr) { delete dm; return LORAHIP_E_NOMEM; }
+    dm->pipe = new (std::nothrow) Pipe();
+    if (dm->pending == nullptr || dm->pipe == nullptr) { delete static_cast<PendingLaunch *>(dm->pending); delete static_cast<Pipe *>(dm->pipe); delete dm; return LORAHIP_E_NOMEM; }
     pendingOf(dm).valid = false;
+    std::memset(dm->pipe, 0, sizeof(Pipe));
     std::memset(&dm->ports, 0, sizeof(dm->ports)); dm->portsOn = false; dm->userTracing = false; dm->dPort = nullptr; dm->dPortBytes = 0;
     std::memset(&dm->hostPorts, 0, sizeof(dm->hostPorts)); dm->ownFft = dm->ownDec = dm->ownRaw = nullptr;
     dm->mode = 0; dm->sDev = nullptr; dm->sHost = nullptr; dm->sBytes = 0; dm->dDense = nullptr; dm->hDense = nullptr; dm->denseBytes = 0;
@@ -1239,9 +1424,21 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->ownRaw) (void)hipFree(dm->ownRaw);
     if (dm->evK0) (void)hipEventDestroy(dm->evK0);
     if (dm->evK1) (void)hipEventDestroy(dm->evK1);
+    if (dm->pipe)
+    {
+        Pipe &P = pipeOf(dm);
+        (void)hipStreamSynchronize(dm->ctx ? dm->ctx->stream : nullptr);
+        for (int i = 0; i < 2; i++)
+        {
+            if (P.dev[i]) (void)hipFree(P.dev[i]);
+            if (P.hSum) (void)hipEventDestroy(P.ev[i]);
+        }
+        if (P.hSum) (void)hipHostFree(P.hSum);
+    }
     }
     lorahip_destroy(dm->ctx);
     delete static_cast<PendingLaunch *>(dm->pending);
+    delete static_cast<Pipe *>(dm->pipe);
     delete dm;
 }
 
@@ -1335,6 +1532,7 @@ int lorahip_demod_run_device(lorahip_demod *dm, const float *iq_dev, const size_
 {
     if (dm == nullptr || iq_dev == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) { setLastError("lorahip_demod_run_device: an object made by lorahip_demod_create_mixed takes per-channel segments"); return LORAHIP_E_INVALID; }
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }         // before anything of the object changes
     // n_channels streams of equal length back to back: the placement is two numbers, not 3 * n_channels (ch[].base / len / pos are
     // filled only for the paths that read them, applyGeometry)
     dm->uniform = true; dm->uniSpc = dm->uniStride = samples_per_channel; dm->geomApplied = false; dm->posOnDevice = false;
@@ -1346,6 +1544,7 @@ int lorahip_demod_run_device_append(lorahip_demod *dm, const float *iq_dev, cons
 {
     if (dm == nullptr || n_valid > row_stride || (n_valid && iq_dev == nullptr)) return LORAHIP_E_INVALID;
     if (dm->comp) { setLastError("append runs are per part: lorahip_demod_part_handle"); return LORAHIP_E_INVALID; }
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
     if (!dm->appendFresh && n_valid < dm->appendPrev) { setLastError("an append run was given fewer samples than the one before it (lorahip_demod_rewind starts a new stream)"); return LORAHIP_E_INVALID; }
     // every channel's stream is the first n_valid samples of its row; a channel continues at its own read position (the device's
     // copy of the state holds it: nothing is uploaded per run)
@@ -1359,6 +1558,7 @@ int lorahip_demod_rewind(lorahip_demod *dm)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) { for (size_t i = 0; i < dm->comp->numParts(); i++) (void)lorahip_demod_rewind(dm->comp->part(i)); return LORAHIP_OK; }
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
     dm->appendFresh = true; dm->appendPrev = 0;
     return LORAHIP_OK;
 }
@@ -1367,6 +1567,7 @@ int lorahip_demod_run_device_segments(lorahip_demod *dm, const float *iq_dev, co
 {
     if (dm == nullptr || first_sample == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) return dm->comp->runSegments(&iq_dev, 1, first_sample, n_samples, rounds);
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
     bool any = false;
     for (size_t c = 0; c < dm->B; c++)
     {
@@ -1394,6 +1595,7 @@ int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size
         for (size_t c = 0; c < dm->B; c++) if (n_samples[c] && streams[c] == nullptr) return LORAHIP_E_INVALID;
         return dm->comp->run(streams, n_samples, rounds);
     }
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
     const DeviceGuard guard(dm->ctx->device);
     // every argument is checked before anything of the object changes: a refused call leaves consumed() of the last run intact
     for (size_t c = 0; c < dm->B; c++)
@@ -1434,6 +1636,7 @@ static int drained(const lorahip_demod *dm)
 {
     lorahip_demod *m = const_cast<lorahip_demod *>(dm);
     if (m && m->comp) return LORAHIP_OK;                        // the parts drain their own
+    if (m) { const int rc = refuseWhilePiped(m); if (rc != LORAHIP_OK) return rc; }
     return m ? drainPending(m) : LORAHIP_E_INVALID;
 }
 
@@ -1521,7 +1724,7 @@ static int packetsToDevice(lorahip_demod *dm, uint16_t *syms_dev, const size_t s
             const size_t nbRow = align256(L.B * sizeof(int));
             { const int grc = growDense(dm, nbRow + n * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
             hipStream_t st = dm->ctx->stream;
-            // the rows are numbered on the device (scanCounts: exclusive prefix sum of the per-channel packet counts): nothing is
+            // the rows are numbered on the device (packIndex: exclusive prefix sum of the per-channel packet counts): nothing is
             // uploaded, and nothing on the host is reused, so the caller decides whether to wait
             LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(dm->sDev + L.oPkt), reinterpret_cast<const int *>(dm->sDev + L.oNPkt),
                                           reinterpret_cast<const short *>(dm->sDev + L.oSym), reinterpret_cast<int *>(dm->dDense), L.B, int(L.symStride),
@@ -1568,6 +1771,17 @@ int lorahip_demod_receive(lorahip_demod *dm, const float *iq_dev, const size_t r
 {
     if (dm == nullptr || rows == nullptr || rows->struct_size != sizeof(lorahip_packet_rows)) return LORAHIP_E_INVALID;
     if (n_packets) *n_packets = 0;
+    if (work_calls) *work_calls = 0;
+    if (dm->comp) { setLastError("append runs are per part: lorahip_demod_part_handle"); return LORAHIP_E_INVALID; }
+    if (rows->async == 2)
+    {
+        if (n_valid > row_stride || (n_valid && iq_dev == nullptr)) return LORAHIP_E_INVALID;
+        bool handled = false;
+        const int prc = pipeStep(dm, iq_dev, row_stride, n_valid, rows, n_packets, work_calls, handled);
+        if (handled || prc != LORAHIP_OK) return prc;
+        // not in place yet (first step, or something else touched the object): an ordinary step, its packets delivered at once
+    }
+    else { const int frc = refuseWhilePiped(dm); if (frc != LORAHIP_OK) return frc; }
     const int64_t calls0 = dm->workCalls;
     int rc = lorahip_demod_run_device_append(dm, iq_dev, row_stride, n_valid, nullptr);
     if (rc != LORAHIP_OK) return rc;
@@ -1578,6 +1792,15 @@ int lorahip_demod_receive(lorahip_demod *dm, const float *iq_dev, const size_t r
     if (rc != LORAHIP_OK) return rc;                                    // (the packets stay queued: a caller with too few rows can fetch them)
     lorahip_demod_clear_packets(dm);
     return LORAHIP_OK;
+}
+
+int lorahip_demod_receive_flush(lorahip_demod *dm, const lorahip_packet_rows *rows, size_t *n_packets, int64_t *work_calls)
+{
+    if (dm == nullptr || (rows != nullptr && rows->struct_size != sizeof(lorahip_packet_rows))) return LORAHIP_E_INVALID;
+    if (n_packets) *n_packets = 0;
+    if (work_calls) *work_calls = 0;
+    if (dm->comp) return LORAHIP_OK;
+    return pipeFlush(dm, rows, n_packets, work_calls);
 }
 
 int lorahip_demod_set_signals(lorahip_demod *dm, const int enable)
@@ -1671,7 +1894,7 @@ int lorahip_demod_set_trace(lorahip_demod *dm, const int enable)
     if (dm == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) return dm->comp->setTrace(enable);
     const bool was = dm->tracing;
-    syncMirrors(dm);                                            // traceSymCount0 is read from the mirrors
+    { const int rc = syncMirrors(dm); if (rc != LORAHIP_OK) return rc; }       // traceSymCount0 is read from the mirrors
     dm->userTracing = enable != 0;
     dm->tracing = dm->userTracing || dm->portsOn;
     if (!dm->userTracing) for (auto &k : dm->ch) { k.trace.clear(); k.traceStart = 0; k.traceSymCount0 = k.symCount; }
@@ -1714,7 +1937,7 @@ int lorahip_demod_set_ports(lorahip_demod *dm, const lorahip_demod_ports *p)
         }
         dm->portsOn = dm->ports.fft_dev || dm->ports.dec_dev || dm->ports.raw_dev;
     }
-    if (dm->portsOn && !dm->tracing) { syncMirrors(dm); for (auto &k : dm->ch) k.traceSymCount0 = k.symCount; }
+    if (dm->portsOn && !dm->tracing) { const int rc = syncMirrors(dm); if (rc != LORAHIP_OK) return rc; for (auto &k : dm->ch) k.traceSymCount0 = k.symCount; }
     dm->tracing = dm->userTracing || dm->portsOn;
     return LORAHIP_OK;
 }

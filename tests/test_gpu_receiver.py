@@ -145,6 +145,64 @@ def test_receive_packs_the_packets_of_every_step_on_the_device(gpu, oracle, sf):
     d.close()
 
 
+@pytest.mark.parametrize("sf", [7, 9, 10, 12])
+def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf):
+    """lorahip_demod_receive with async = 2: step k's kernel is launched before step k-1's summary is read; the packets of a step
+    arrive with the next call (the last ones with receive_flush). All steps together: the reference's packets, calls and read
+    positions -- whatever the chunking, including chunks so small that a step posts nothing. While a step is in flight everything
+    else is refused; after the flush the object is an ordinary one again."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(800 + sf)
+    N, B = 1 << sf, 13
+    host = _streams(oracle, rng, sf, B, n_frames=4)
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
+    iq = gpu.from_numpy(host).cuda()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
+    rows = [d.receiver_rows(cap_packets=64, stride=16) for _ in range(2)]
+    got, calls, w, k = [[] for _ in range(B)], 0, 0, 0
+
+    def take(n, r):
+        gpu.cuda.synchronize()
+        sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
+        for i in range(n):
+            got[int(chn[i])].append(sy[i, :ns[i]].copy())
+    piped = 0
+    while w < cap:
+        w = min(cap, w + int(rng.integers(N // 2, 6 * N)))
+        n, c_ = d.receive(iq, w, rows[k & 1], async_=2)
+        take(n, rows[k & 1])
+        calls += c_
+        k += 1
+        if k == 3:
+            # a step is in flight: runs and accessors say so instead of racing it
+            for fn in (lambda: d.work(iq), lambda: d.packets(), lambda: d.activate(), lambda: d.set_trace(True), lambda: d.receive(iq, w, rows[0], async_=True)):
+                with pytest.raises(L.LoraHipError):
+                    fn()
+            # (the read positions may be asked for: the copy is ordered behind the step in flight)
+            pos = d.consumed_all()
+            assert ((w - pos < 2 * N) & (pos >= 0)).all()
+            piped += 1
+    n, c_ = d.receive_flush(rows[k & 1])
+    take(n, rows[k & 1])
+    calls += c_
+    assert piped == 1 and k > 8
+    for c in range(B):
+        r = refs[c]
+        assert len(got[c]) == len(r["packets"]) >= 4, "channel %d" % c
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
+        assert d.consumed(c) == int(sum(q["consumed"] for q in r["calls"]))
+    assert calls == sum(len(r["calls"]) for r in refs) == d.work_calls()
+    assert d.receive_flush() == (0, 0)                                      # nothing in flight: a no-op
+    # the flushed object is an ordinary one: a rewound one-shot run gives the same again
+    d.rewind(); d.activate()
+    refs2 = None
+    d.work_append(iq, cap)
+    pk = d.packets()
+    assert sum(len(r["packets"]) for r in refs) == len(pk)
+    d.close()
+
+
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
 def test_mixed_object_equals_single_sf_objects(gpu, oracle, devices):
     """lorahip_demod_create_mixed: 19 channels with SF = 7 + c mod 6 behind ONE handle, over one / two / three "devices" (all device
