@@ -1724,7 +1724,7 @@ static int packetsToDevice(lorahip_demod *dm, uint16_t *syms_dev, const size_t s
             const size_t nbRow = align256(L.B * sizeof(int));
             { const int grc = growDense(dm, nbRow + n * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
             hipStream_t st = dm->ctx->stream;
-            // the rows are numbered on the device (packIndex: exclusive prefix sum of the per-channel packet counts): nothing is
+            // the rows are numbered on the device (scanCounts: exclusive prefix sum of the per-channel packet counts): nothing is
             // uploaded, and nothing on the host is reused, so the caller decides whether to wait
             LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(dm->sDev + L.oPkt), reinterpret_cast<const int *>(dm->sDev + L.oNPkt),
                                           reinterpret_cast<const short *>(dm->sDev + L.oSym), reinterpret_cast<int *>(dm->dDense), L.B, int(L.symStride),

@@ -421,7 +421,7 @@ hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *s
  * Packets of a streaming launch straight into the batched decoder's input layout, device to device (no host round trip):
  * channel c posted nPkt[c] packets, packet j = the next pktOut[c][j].len entries of the channel's symbol stream symOut[c][..];
  * its row in the output is rowStart[c] + j (rowStart = exclusive scan of nPkt: channels ascending, time ascending inside one;
- * packIndex below).
+ * scanCounts below).
  **********************************************************************/
 __global__ void packCopy(const short *__restrict__ symOut, const long long *__restrict__ srcOff, const int *__restrict__ nsyms,
                          unsigned short *__restrict__ dst, const int stride)
@@ -432,12 +432,10 @@ __global__ void packCopy(const short *__restrict__ symOut, const long long *__re
     for (int i = threadIdx.x; i < stride; i += blockDim.x) dst[p * stride + i] = i < len ? (unsigned short)src[i] : (unsigned short)0;
 }
 
-//! One workgroup numbers the packets' rows -- rowStart = exclusive prefix sum of the per-channel packet counts (channels ascending,
-//! time ascending inside one) -- and describes every packet (where its symbols start in the channel's row, its length, its
-//! channel): packing needs neither an upload nor a host synchronisation, and one launch less than scan + describe.
-__global__ void __launch_bounds__(1024) packIndex(const StreamPacket *__restrict__ pktOut, const int *__restrict__ nPkt, int *__restrict__ rowStart,
-                                                  const unsigned nChannels, const int cap, const int capPkt, long long *__restrict__ srcOff,
-                                                  int *__restrict__ nsyms, int *__restrict__ channel)
+//! rowStart = exclusive prefix sum of nPkt (one workgroup; the channel counts are tens of thousands at most): the packets' rows are
+//! numbered on the device, so that packing needs neither an upload nor a host synchronisation. (Describing the packets in the same
+//! workgroup -- one launch less -- was tried and is slower by far: 65536 packets walked by 1024 lanes, profiles/r04.)
+__global__ void __launch_bounds__(1024) scanCounts(const int *__restrict__ nPkt, int *__restrict__ rowStart, const unsigned nChannels)
 {
     __shared__ int sPart[1024];
     const unsigned per = (nChannels + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < nChannels ? lo + per : nChannels;
@@ -453,20 +451,24 @@ __global__ void __launch_bounds__(1024) packIndex(const StreamPacket *__restrict
         __syncthreads();
     }
     int acc = sPart[threadIdx.x] - sum;
-    for (unsigned c = lo; c < hi; c++)
+    for (unsigned c = lo; c < hi; c++) { rowStart[c] = acc; acc += nPkt[c]; }
+}
+
+__global__ void packDescribe(const StreamPacket *__restrict__ pktOut, const int *__restrict__ nPkt, const int *__restrict__ rowStart,
+                             const unsigned nChannels, const int cap, const int capPkt, long long *__restrict__ srcOff,
+                             int *__restrict__ nsyms, int *__restrict__ channel)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nChannels) return;
+    long long off = (long long)c * cap;
+    const int row0 = rowStart[c];
+    for (int j = 0; j < nPkt[c]; j++)
     {
-        rowStart[c] = acc;
-        long long off = (long long)c * cap;
-        const int n = nPkt[c];
-        for (int j = 0; j < n; j++)
-        {
-            const int len = pktOut[(size_t)c * capPkt + j].len;
-            srcOff[acc + j] = off;
-            nsyms[acc + j] = len;
-            if (channel) channel[acc + j] = (int)c;
-            off += len;
-        }
-        acc += n;
+        const int len = pktOut[(size_t)c * capPkt + j].len;
+        srcOff[row0 + j] = off;
+        nsyms[row0 + j] = len;
+        if (channel) channel[row0 + j] = (int)c;
+        off += len;
     }
 }
 
@@ -475,7 +477,9 @@ hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const 
                              int *nsymsOut, int *channelOut, hipStream_t stream)
 {
     if (nPackets == 0) return hipSuccess;
-    hipLaunchKernelGGL(packIndex, dim3(1), dim3(1024), 0, stream, pktOut, nPkt, rowStart, unsigned(nChannels), cap, capPkt, srcOff, nsymsOut, channelOut);
+    hipLaunchKernelGGL(scanCounts, dim3(1), dim3(1024), 0, stream, nPkt, rowStart, unsigned(nChannels));
+    hipLaunchKernelGGL(packDescribe, dim3(unsigned((nChannels + 255) / 256)), dim3(256), 0, stream, pktOut, nPkt, rowStart, unsigned(nChannels), cap, capPkt,
+                       srcOff, nsymsOut, channelOut);
     hipLaunchKernelGGL(packCopy, dim3(unsigned(nPackets)), dim3(64), 0, stream, symOut, srcOff, nsymsOut, symsOut, stride);
     return hipGetLastError();
 }
