@@ -193,38 +193,46 @@ int Composite::resetStream() { return p->each([](lorahip_demod *d) { return lora
 
 int Composite::run(const float *const *streams, const size_t *nSamples, int64_t *rounds)
 {
-    Impl &I = *p;
-    std::vector<std::vector<const float *>> ptr(I.parts.size());
-    std::vector<std::vector<size_t>> len(I.parts.size());
-    std::vector<int64_t> rd(I.parts.size(), 0);
-    for (size_t i = 0; i < I.parts.size(); i++)
+    try
     {
-        const auto &ch = I.parts[i].chan;
-        ptr[i].resize(ch.size()); len[i].resize(ch.size());
-        for (size_t j = 0; j < ch.size(); j++) { ptr[i][j] = streams[ch[j]]; len[i][j] = nSamples[ch[j]]; }
+        Impl &I = *p;
+        std::vector<std::vector<const float *>> ptr(I.parts.size());
+        std::vector<std::vector<size_t>> len(I.parts.size());
+        std::vector<int64_t> rd(I.parts.size(), 0);
+        for (size_t i = 0; i < I.parts.size(); i++)
+        {
+            const auto &ch = I.parts[i].chan;
+            ptr[i].resize(ch.size()); len[i].resize(ch.size());
+            for (size_t j = 0; j < ch.size(); j++) { ptr[i][j] = streams[ch[j]]; len[i][j] = nSamples[ch[j]]; }
+        }
+        const int rc = I.onAll([&](const size_t i) { return lorahip_demod_run(I.parts[i].d, ptr[i].data(), len[i].data(), &rd[i]); });
+        if (rounds) *rounds = *std::max_element(rd.begin(), rd.end());
+        return rc;
     }
-    const int rc = I.onAll([&](const size_t i) { return lorahip_demod_run(I.parts[i].d, ptr[i].data(), len[i].data(), &rd[i]); });
-    if (rounds) *rounds = *std::max_element(rd.begin(), rd.end());
-    return rc;
+    catch (const std::bad_alloc &) { setLastError("out of host memory"); return LORAHIP_E_NOMEM; }        // nothing may cross the C ABI
 }
 
 int Composite::runSegments(const float *const *iqPerDevice, const size_t nDev, const int64_t *first, const size_t *nSamples, int64_t *rounds)
 {
-    Impl &I = *p;
-    if (nDev != I.devices.size()) { setLastError("one device buffer per entry of the device list"); return LORAHIP_E_INVALID; }
-    std::vector<std::vector<int64_t>> fs(I.parts.size());
-    std::vector<std::vector<size_t>> len(I.parts.size());
-    std::vector<int64_t> rd(I.parts.size(), 0);
-    for (size_t i = 0; i < I.parts.size(); i++)
+    try
     {
-        const auto &ch = I.parts[i].chan;
-        fs[i].resize(ch.size()); len[i].resize(ch.size());
-        for (size_t j = 0; j < ch.size(); j++) { fs[i][j] = first[ch[j]]; len[i][j] = nSamples[ch[j]]; }
+        Impl &I = *p;
+        if (nDev != I.devices.size()) { setLastError("one device buffer per entry of the device list"); return LORAHIP_E_INVALID; }
+        std::vector<std::vector<int64_t>> fs(I.parts.size());
+        std::vector<std::vector<size_t>> len(I.parts.size());
+        std::vector<int64_t> rd(I.parts.size(), 0);
+        for (size_t i = 0; i < I.parts.size(); i++)
+        {
+            const auto &ch = I.parts[i].chan;
+            fs[i].resize(ch.size()); len[i].resize(ch.size());
+            for (size_t j = 0; j < ch.size(); j++) { fs[i][j] = first[ch[j]]; len[i][j] = nSamples[ch[j]]; }
+        }
+        const int rc = I.onAll([&](const size_t i) {
+            return lorahip_demod_run_device_segments(I.parts[i].d, iqPerDevice[I.parts[i].deviceSlot], fs[i].data(), len[i].data(), &rd[i]); });
+        if (rounds) *rounds = *std::max_element(rd.begin(), rd.end());
+        return rc;
     }
-    const int rc = I.onAll([&](const size_t i) {
-        return lorahip_demod_run_device_segments(I.parts[i].d, iqPerDevice[I.parts[i].deviceSlot], fs[i].data(), len[i].data(), &rd[i]); });
-    if (rounds) *rounds = *std::max_element(rd.begin(), rd.end());
-    return rc;
+    catch (const std::bad_alloc &) { setLastError("out of host memory"); return LORAHIP_E_NOMEM; }        // nothing may cross the C ABI
 }
 
 size_t Composite::numPackets() const { size_t n = 0; for (const auto &q : p->parts) n += lorahip_demod_num_packets(q.d); return n; }
@@ -250,37 +258,45 @@ int Composite::getPacket(size_t i, int32_t *channel, int64_t *round, size_t *len
 
 int Composite::getPackets(int32_t *channels, int64_t *rounds, int64_t *lens, const size_t capPackets, int16_t *syms, const size_t capSyms) const
 {
-    if (capPackets < numPackets() || capSyms < numPacketSymbols()) return LORAHIP_E_INVALID;
-    size_t at = 0, sat = 0;
-    std::vector<int32_t> ch;
-    for (const auto &q : p->parts)
+    try
     {
-        const size_t n = lorahip_demod_num_packets(q.d), ns = lorahip_demod_num_packet_symbols(q.d);
-        ch.resize(n);
-        const int rc = lorahip_demod_get_packets(q.d, ch.data(), rounds ? rounds + at : nullptr, lens ? lens + at : nullptr, n, syms ? syms + sat : nullptr, ns);
-        if (rc != LORAHIP_OK) return rc;
-        if (channels) for (size_t j = 0; j < n; j++) channels[at + j] = int32_t(q.chan[size_t(ch[j])]);
-        at += n; sat += ns;
+        if (capPackets < numPackets() || capSyms < numPacketSymbols()) return LORAHIP_E_INVALID;
+        size_t at = 0, sat = 0;
+        std::vector<int32_t> ch;
+        for (const auto &q : p->parts)
+        {
+            const size_t n = lorahip_demod_num_packets(q.d), ns = lorahip_demod_num_packet_symbols(q.d);
+            ch.resize(n);
+            const int rc = lorahip_demod_get_packets(q.d, ch.data(), rounds ? rounds + at : nullptr, lens ? lens + at : nullptr, n, syms ? syms + sat : nullptr, ns);
+            if (rc != LORAHIP_OK) return rc;
+            if (channels) for (size_t j = 0; j < n; j++) channels[at + j] = int32_t(q.chan[size_t(ch[j])]);
+            at += n; sat += ns;
+        }
+        return LORAHIP_OK;
     }
-    return LORAHIP_OK;
+    catch (const std::bad_alloc &) { setLastError("out of host memory"); return LORAHIP_E_NOMEM; }        // nothing may cross the C ABI
 }
 
 int Composite::getSignals(int32_t *channels, int64_t *rounds, int32_t *errors, float *powers, float *snrs, const size_t cap) const
 {
-    if (cap < numSignals()) return LORAHIP_E_INVALID;
-    size_t at = 0;
-    std::vector<int32_t> ch;
-    for (const auto &q : p->parts)
+    try
     {
-        const size_t n = lorahip_demod_num_signals(q.d);
-        ch.resize(n);
-        const int rc = lorahip_demod_get_signals(q.d, ch.data(), rounds ? rounds + at : nullptr, errors ? errors + at : nullptr, powers ? powers + at : nullptr,
-                                                 snrs ? snrs + at : nullptr, n);
-        if (rc != LORAHIP_OK) return rc;
-        if (channels) for (size_t j = 0; j < n; j++) channels[at + j] = int32_t(q.chan[size_t(ch[j])]);
-        at += n;
+        if (cap < numSignals()) return LORAHIP_E_INVALID;
+        size_t at = 0;
+        std::vector<int32_t> ch;
+        for (const auto &q : p->parts)
+        {
+            const size_t n = lorahip_demod_num_signals(q.d);
+            ch.resize(n);
+            const int rc = lorahip_demod_get_signals(q.d, ch.data(), rounds ? rounds + at : nullptr, errors ? errors + at : nullptr, powers ? powers + at : nullptr,
+                                                     snrs ? snrs + at : nullptr, n);
+            if (rc != LORAHIP_OK) return rc;
+            if (channels) for (size_t j = 0; j < n; j++) channels[at + j] = int32_t(q.chan[size_t(ch[j])]);
+            at += n;
+        }
+        return LORAHIP_OK;
     }
-    return LORAHIP_OK;
+    catch (const std::bad_alloc &) { setLastError("out of host memory"); return LORAHIP_E_NOMEM; }        // nothing may cross the C ABI
 }
 
 void Composite::clearPackets() { for (auto &q : p->parts) lorahip_demod_clear_packets(q.d); }
@@ -293,15 +309,19 @@ int64_t Composite::consumed(const size_t c) const
 
 int Composite::consumedAll(int64_t *out) const
 {
-    std::vector<int64_t> tmp;
-    for (const auto &q : p->parts)
+    try
     {
-        tmp.resize(q.chan.size());
-        const int rc = lorahip_demod_consumed_all(q.d, tmp.data());
-        if (rc != LORAHIP_OK) return rc;
-        for (size_t j = 0; j < q.chan.size(); j++) out[q.chan[j]] = tmp[j];
+        std::vector<int64_t> tmp;
+        for (const auto &q : p->parts)
+        {
+            tmp.resize(q.chan.size());
+            const int rc = lorahip_demod_consumed_all(q.d, tmp.data());
+            if (rc != LORAHIP_OK) return rc;
+            for (size_t j = 0; j < q.chan.size(); j++) out[q.chan[j]] = tmp[j];
+        }
+        return LORAHIP_OK;
     }
-    return LORAHIP_OK;
+    catch (const std::bad_alloc &) { setLastError("out of host memory"); return LORAHIP_E_NOMEM; }        // nothing may cross the C ABI
 }
 
 int64_t Composite::workCalls() const { int64_t n = 0; for (const auto &q : p->parts) n += lorahip_demod_work_calls(q.d); return n; }
