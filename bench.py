@@ -634,7 +634,7 @@ def section_level3(env, L, sf, threads=32):
     return res
 
 
-def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 32768)), (12, (256, 512, 1024, 2048, 4096))), both_grids=False):
+def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 32768)), (12, (256, 512, 1024, 2048, 4096))), both_grids=False, passes=4):
     """The streaming kernels against the channel count (whole LoRaDemod blocks, the level-3 workload): below the resident set (two
     wavefronts per SIMD: 16384 channels at SF7, 512 at SF12) the device is not full; above it the dispatcher hands every free slot the
     next channel set. (both_grids: also a persistent grid -- LORAHIP_STREAM_BLOCKS, profiling build only -- which measured worse:
@@ -648,27 +648,31 @@ def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 
             iq, _ = WL.frame_streams(ctx, B, 4, 48, sigma=0.05)
             ent = {"sf": sf, "channels": B}
             for grid in (("library default", None), ("persistent", "512" if sf != 11 else "1024")) if both_grids else (("library default", None),):
-                if grid[1] is None:
-                    os.environ.pop("LORAHIP_STREAM_BLOCKS", None)
-                else:
-                    os.environ["LORAHIP_STREAM_BLOCKS"] = grid[1]
+                if both_grids:
+                    if grid[1] is None:
+                        os.environ.pop("LORAHIP_STREAM_BLOCKS", None)
+                    else:
+                        os.environ["LORAHIP_STREAM_BLOCKS"] = grid[1]
                 d = L.LoRaDemod(sf, n_channels=B, device=env.local)
                 d.set_mode(1); d.setMTU(48)
                 d.work(iq)
                 calls = d.work_calls()
-                best = None
                 t_ramp = time.perf_counter()
                 while time.perf_counter() - t_ramp < 0.15:
                     d.clear_packets(); d.activate(); d.work(iq)
-                for _ in range(4):
+                kms = []
+                for _ in range(passes):
                     d.clear_packets(); d.activate(); d.work(iq)
-                    best = d.kernel_ms() if best is None else min(best, d.kernel_ms())
+                    kms.append(d.kernel_ms())
+                best = min(kms)
                 d.close()
                 key = "default" if grid[1] is None else grid[0]
                 ent[key + "_Msym_s"] = r4(calls / (best / 1e3) / 1e6)
                 ent[key + "_frac"] = r4(calls * L.bytes_per_symbol(sf) / (best / 1e3) / 1e9 / HBM_PEAK_GBS)
                 ent[key + "_kernel_ms"] = r4(best)
-            os.environ.pop("LORAHIP_STREAM_BLOCKS", None)
+                ent[key + "_kernel_ms_median"] = r4(sorted(kms)[len(kms) // 2])
+            if both_grids:
+                os.environ.pop("LORAHIP_STREAM_BLOCKS", None)
             out.append(ent)
             del iq
             torch.cuda.empty_cache()

@@ -272,6 +272,11 @@ int lorahip_demod_reset_stream(lorahip_demod *d);    /* back to the private stre
 /* kernel variant of the host-driven mode's batch launches (lorahip_set_variant: 0, 1, 10 -- identical results); LORAHIP_VARIANT_FMA
  * is refused (LORAHIP_E_INVALID): level 3 runs the reference's operation graph only */
 int lorahip_demod_set_variant(lorahip_demod *d, int variant);
+/* The streaming kernels' grid (scheduling only: every result is the same). 0 = the library's choice (one workgroup per channel set;
+ * at SF11 the resident number of workgroups, each walking channel after channel: lorahip_wide.hip), < 0 = one workgroup per
+ * channel set always, n > 0 = at most n workgroups each walking several sets -- honoured where the build holds such an instance
+ * (SF11 and SF12), the default elsewhere. For measurements and tests. */
+int lorahip_demod_set_stream_grid(lorahip_demod *d, int max_workgroups);
 /* same switch as lorahip_set_fine_gather, for the demodulator's kernels */
 int lorahip_demod_set_fine_gather(lorahip_demod *d, int enable);
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "lorahip_fine_indices_host": (C.c_int, [C.c_int, C.c_int32, C.c_float, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lorahip_demod_set_fine_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "lorahip_demod_set_stream_grid": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_detect_batch": (C.c_int, [C.c_void_p, C.POINTER(Batch)]),
     "lorahip_detect_batch_host": (C.c_int, [C.c_void_p, C.POINTER(Batch)]),
     "lorahip_mixed_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]),

@@ -606,6 +606,11 @@ class LoRaDemod:
         """kernel variant of the host-driven mode's batch launches; the contracted build (40) is refused at this level"""
         check(self._lib.lorahip_demod_set_variant(self._h, int(variant)), "lorahip_demod_set_variant")
 
+    def set_stream_grid(self, max_workgroups):
+        """the streaming kernels' grid (scheduling only, same results): 0 the library's choice, < 0 one workgroup per channel set
+        always, n > 0 at most n workgroups each walking several channels (SF11 / SF12)"""
+        check(self._lib.lorahip_demod_set_stream_grid(self._h, int(max_workgroups)), "lorahip_demod_set_stream_grid")
+
     def set_trace(self, on=True):
         check(self._lib.lorahip_demod_set_trace(self._h, int(bool(on))), "lorahip_demod_set_trace")
 

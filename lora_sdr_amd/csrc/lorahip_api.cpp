@@ -36,6 +36,14 @@ hipError_t ensureDynamicLds(const void *kernel, const size_t bytes, unsigned lon
     return hipSuccess;
 }
 
+int residentWorkgroups(const void *kernel, const int threads, const size_t smem)
+{
+    int dev = 0, cus = 0, perCu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, smem) != hipSuccess) return 0;
+    return perCu > 0 && cus > 0 ? perCu * cus : 0;
+}
+
 static bool isGfx950(const int device)
 {
     hipDeviceProp_t prop;

@@ -65,6 +65,7 @@ struct Signal
 
 struct lorahip_demod
 {
+    int streamGrid;                  // lorahip_demod_set_stream_grid: 0 default, < 0 one workgroup per channel set, > 0 at most that many workgroups
     lorahip::Composite *comp;        // non-null: the handle is a container of (device, SF) parts (lorahip_rx.cpp); nothing below is used then
     lorahip_ctx *ctx;
     size_t N, B;
@@ -825,13 +826,13 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     // symbols, and leaves the packet it is inside at the end in the carry rows
     a.flags = (cont ? 0 : 1) | (activate ? 2 : 0) | (useDevCarry ? 4 | 8 : 0);
     a.carry = dm->dCarry; a.carryCap = int(dm->carryCap);
-    // One workgroup per channel set, however many there are: the dispatcher hands a free slot the next set, which balances channels of
-    // different length. A PERSISTENT grid (the resident number of workgroups, each looping over sets) was built and measured and lost:
-    // 0.31 against 0.39 of the roofline at 32768 SF7 channels, 0.29 against 0.31 at 4096 SF12 channels -- static assignment leaves a
-    // tail, and the loop costs registers (profiles/r04/s4_level3_scaling_persistent_vs_plain_negative.txt). The instances are kept
-    // in the profiling build only.
-    a.maxBlocks = 0;
-#ifdef LORAHIP_ALL_VARIANTS
+    // The grid (lorahip_demod_set_stream_grid; 0 = the kernels' own default). One workgroup per channel set, however many there are,
+    // at every SF but 11: the dispatcher hands a free slot the next set. A PERSISTENT grid (the resident number of workgroups, each
+    // looping over sets) lost there even with the alternating priority (profiles/r04/s22_*: SF7 32768 channels 0.34 against 0.44,
+    // SF9 0.36 against 0.40; SF8 / 10 / 12 equal) -- the loop costs the wave-per-channel-set kernels registers -- and is the default
+    // only where one-by-one placement leaves slots unusable: SF11 (lorahip_wide.hip::launchStreamWideCfg).
+    a.maxBlocks = dm->streamGrid; a.lastRoundFrom = 0;
+#if defined(LORAHIP_ALL_VARIANTS) || defined(LORAHIP_STREAM_PERSIST)
     if (const char *e = std::getenv("LORAHIP_STREAM_BLOCKS")) a.maxBlocks = std::atoi(e);        // e.g. 512: two workgroups of 256 threads per CU
 #endif
     a.state = reinterpret_cast<StreamState *>(d + L.oState);
@@ -1095,7 +1096,7 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     a.base = nullptr; a.len = nullptr;
     a.uniformLen = (long long)nValid; a.uniformStride = (long long)rowStride;
     a.flags = 4 | 8;                                  // continue the streams; open packets in from / out to the carry rows
-    a.carry = dm->dCarry; a.carryCap = int(dm->carryCap); a.maxBlocks = 0;
+    a.carry = dm->dCarry; a.carryCap = int(dm->carryCap); a.maxBlocks = dm->streamGrid; a.lastRoundFrom = 0;
     a.state = reinterpret_cast<StreamState *>(dm->sDev + H.oState);          // the object's own: every launch continues it
     a.nCalls = reinterpret_cast<int *>(d + L.oN); a.nSym = reinterpret_cast<int *>(d + L.oNSym); a.nPkt = reinterpret_cast<int *>(d + L.oNPkt);
     a.nSig = reinterpret_cast<int *>(d + L.oNSig);
@@ -1325,7 +1326,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     std::memset(&dm->hostPorts, 0, sizeof(dm->hostPorts)); dm->ownFft = dm->ownDec = dm->ownRaw = nullptr;
     dm->mode = 0; dm->sDev = nullptr; dm->sHost = nullptr; dm->sBytes = 0; dm->dDense = nullptr; dm->hDense = nullptr; dm->denseBytes = 0;
     int rc = lorahip_create(&dm->ctx, device, sf);
-    if (rc != LORAHIP_OK) { delete dm; return rc; }
+    if (rc != LORAHIP_OK) { const std::string e = lorahip_last_error(); lorahip_demod_destroy(dm); setLastError(e); return rc; }
     dm->N = size_t(1) << sf;
     dm->B = n_channels;
     dm->sync = 0x12; dm->thresh = -30.0f; dm->mtu = 256;        // LoRaDemod.cpp:71-73
@@ -1337,10 +1338,12 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->append = false; dm->appendFresh = true; dm->appendPrev = 0; dm->headStale = false; dm->nearSeen[0] = dm->nearSeen[1] = 0;
     std::memset(&dm->lastSum, 0, sizeof(dm->lastSum));
     dm->wantSignals = false;
+    dm->streamGrid = 0;
     dm->lastLaunches = 0;
     dm->dCarry = nullptr; dm->carryCap = 0; dm->devCarryValid = false; dm->hostCarryStale = false;
     dm->callsPerWindowQ8 = 288;                                 // 1.125 calls per N samples to begin with
-    dm->ch.resize(n_channels);
+    try { dm->ch.resize(n_channels); }
+    catch (const std::bad_alloc &) { lorahip_demod_destroy(dm); return LORAHIP_E_NOMEM; }
     for (auto &k : dm->ch) { k.traceStart = 0; k.traceSymCount0 = 0; k.portFft = k.portDec = k.portRaw = 0; k.callCount = 0; k.runStart = 0; }
     dm->stageBytes = carve(nullptr, n_channels).total;
     bool staged;
@@ -1410,6 +1413,7 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->comp) { delete dm->comp; delete dm; return; }
     {
     const DeviceGuard guard(dm->ctx ? dm->ctx->device : 0);   // the caller's current device is restored on return
+    if (dm->ctx) (void)hipStreamSynchronize(dm->ctx->stream);  // a pipelined step may still be writing into what is freed below
     if (dm->d) (void)hipFree(dm->d);
     if (dm->h) (void)hipHostFree(dm->h);
     if (dm->dIq) (void)hipFree(dm->dIq);
@@ -1427,7 +1431,6 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->pipe)
     {
         Pipe &P = pipeOf(dm);
-        (void)hipStreamSynchronize(dm->ctx ? dm->ctx->stream : nullptr);
         for (int i = 0; i < 2; i++)
         {
             if (P.dev[i]) (void)hipFree(P.dev[i]);
@@ -1501,6 +1504,19 @@ int lorahip_demod_set_variant(lorahip_demod *dm, const int variant)
         return LORAHIP_OK;
     }
     return lorahip_set_variant(dm->ctx, variant);
+}
+
+int lorahip_demod_set_stream_grid(lorahip_demod *dm, const int max_workgroups)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp)
+    {
+        for (size_t i = 0; i < dm->comp->numParts(); i++) { const int rc = lorahip_demod_set_stream_grid(dm->comp->part(i), max_workgroups); if (rc != LORAHIP_OK) return rc; }
+        return LORAHIP_OK;
+    }
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
+    dm->streamGrid = max_workgroups;
+    return LORAHIP_OK;
 }
 
 int lorahip_demod_set_fine_gather(lorahip_demod *dm, const int enable)

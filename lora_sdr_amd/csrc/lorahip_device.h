@@ -14,6 +14,55 @@
 
 namespace lorahip {
 
+// Wavefronts that share a SIMD are issued OLDEST FIRST: of two co-resident wavefronts of the streaming kernels (256 registers each)
+// the older runs at nearly its solo speed and the other takes what is left -- workgroups of one launch that do the same work finish
+// 25-30 % apart (tools/wg_timeline.py: 1.5 ms against 2.0-2.3 ms per SF11 channel) -- and a launch of long-running wavefronts ends
+// in a tail where the late ones run alone, latency-bound, on half-empty SIMDs. rotatePriority(), once per work() call / window set,
+// hands the SIMD's priority round on a clock counter its wavefronts see alike (s_setprio): they advance at the same rate and
+// finish together. Measured (profiles/r04/s22_*, s23_*): level-3 kernels +3-9 % at SF7-10, +6 % at SF12, +27 % at SF11 together
+// with the persistent grid (lorahip_wide.hip); the half period (2^16 / 2^18 clocks: 27 / 110 us) does not matter within the
+// noise, 2^14 is too short.
+// Only wavefronts that are NOT REPLACED when they finish take part (the last resident set of a grid, every wavefront of a persistent
+// one): earlier workgroups hold a priority above them, oldest first as the hardware has it -- one of two finishes early and its slot
+// goes to the next workgroup, which is what a grid of 1.5 resident sets wants (LORAHIP_PRIO_HOLD 0: everybody rotates, the A/B).
+#ifndef LORAHIP_PRIO_ALTERNATE
+#define LORAHIP_PRIO_ALTERNATE 18       // streaming kernels: log2 of the period per wavefront in shader clocks; 0: off (the A/B)
+#endif
+#ifndef LORAHIP_PRIO_HOLD
+#define LORAHIP_PRIO_HOLD 1
+#endif
+// The batch kernels are persistent too (a wavefront walks window sets first, first + waveCount, ...: a static share each), two to
+// three wavefronts per SIMD: the same rotation once per set, +2-3 % at SF7-11 and +5 % at SF12 in both shapes
+// (profiles/r04/s25_ab_batch_priority.txt).
+#ifndef LORAHIP_PRIO_BATCH
+#define LORAHIP_PRIO_BATCH 16           // batch kernels: log2 of the period per wavefront in shader clocks (launches last 0.2-0.4 ms); 0: off
+#endif
+__device__ __forceinline__ int wavefrontSlot()
+{
+    return int(__builtin_amdgcn_s_getreg((3 << 11) | 4));      // HW_ID.wave_id: the wavefront's slot on its SIMD
+}
+//! a wavefront whose slot goes to another workgroup when it finishes: ahead of the ones that rotate (oldest first among its like)
+template <int K>
+__device__ __forceinline__ void holdPriority(const bool hold)
+{
+    if (K > 0 && hold) __builtin_amdgcn_s_setprio(3);
+}
+template <int WPS, int K>
+__device__ __forceinline__ void rotatePriority(const int slot)
+{
+    if (K > 0 && WPS >= 2)
+    {
+        unsigned p = unsigned(__builtin_amdgcn_s_memtime() >> K);
+        unsigned me = unsigned(slot);
+        if (WPS == 2) { p &= 1u; me &= 1u; }
+        else if (WPS == 4) { p &= 3u; me &= 3u; }
+        else { p &= 1023u; p -= WPS * ((p * (2048u / WPS + 1u)) >> 11); me = me >= unsigned(WPS) ? me - unsigned(WPS) : me; }   // p mod 3 (exact below 1024)
+        if (p == me) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+
 //! (ac - bd, ad + bc): std::complex<float>::operator* for finite operands, no FMA
 __device__ __forceinline__ float2 cmul(const float2 a, const float2 b)
 {

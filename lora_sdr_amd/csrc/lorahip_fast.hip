@@ -134,8 +134,10 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     if (C::PREFETCH && waveId < setEnd) issueLoads(waveId);
     const v2f fconst0 = gFine[0];
 
+    const int prioSlot = wavefrontSlot();
     for (unsigned set = waveId; set < setEnd; set += waveCount)
     {
+        rotatePriority<C::WAVES_PER_SIMD, LORAHIP_PRIO_BATCH>(prioSlot);
         const unsigned w = set * WPW + wsub;
         const bool active = w < a.nWindows;
         const unsigned wc = active ? w : a.nWindows - 1;  // inactive lanes redo the last window, results dropped

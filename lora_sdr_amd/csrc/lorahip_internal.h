@@ -139,7 +139,8 @@ struct StreamArgs
                                 //        the last symCount entries of its row in `carry` (the open packets stay on the device, no extra launch)
     short *carry;               // [nChannels][carryCap] symbols of the packets the channels are inside, between launches (bits 2 / 3)
     int carryCap;
-    int maxBlocks;              // > 0: at most this many workgroups, each looping over channel sets (the resident number: no second round)
+    int maxBlocks;              // the grid: 0 = the kernel's default, < 0 = one workgroup per channel set always, > 0 = at most this many workgroups, each looping over channel sets
+    unsigned lastRoundFrom;     // set by the launcher: workgroups from this blockIdx on are not followed by another one in their slot (lorahip_device.h::rotatePriority)
     unsigned *near;             // [2] decisions float rounding could flip (lorahip_demod_near_threshold): squelch margins, fine-tune steps.
                                 //     Running counters: the kernels only add, the host takes differences
 };
@@ -203,6 +204,19 @@ hipError_t launchMembw(const float2 *iq, size_t nBytes, int pattern, int blocks,
 //! hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes are per device, and one
 //! process may drive several contexts on several devices from several threads
 hipError_t ensureDynamicLds(const void *kernel, size_t bytes, unsigned long long &doneMask);
+//! StreamArgs::lastRoundFrom of a grid of `grid` workgroups on a device that holds `resident` of them. Workgroups of the last resident
+//! set are not replaced when they finish: they share the SIMD's priority in turns (lorahip_device.h::rotatePriority) and finish
+//! together; the ones before them keep a priority above, oldest first, so that one of two co-resident workgroups finishes early and
+//! its slot goes to the next one. A grid of WHOLE resident sets rotates from the first workgroup on: every set then ends at once and
+//! nothing runs alone (profiles/r04/s27_*: 2.0 sets +6-9 % over no priorities at all against +3-5 % with the split rule; 1.5 / 2.5
+//! sets -8 % against +1-2 %).
+inline unsigned lastRoundFrom(const unsigned grid, const int resident)
+{
+    if (resident <= 0 || grid <= unsigned(resident) || grid % unsigned(resident) == 0) return 0u;
+    return grid - unsigned(resident);
+}
+//! how many workgroups of `kernel` the current device holds at once (occupancy x compute units); 0 if the runtime will not say
+int residentWorkgroups(const void *kernel, int threads, size_t smem);
 
 //! makes a context's device current for the duration of an entry point and restores the caller's afterwards (a process
 //! may hold contexts on several devices; torch keeps its own notion of the current device)

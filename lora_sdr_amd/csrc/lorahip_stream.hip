@@ -273,8 +273,12 @@ demodStream(const StreamArgs s)
     bool pend = false;
     int value0 = 0, fineIdxBefore0 = 0;
     float snr0 = 0.0f, fineErrBefore0 = 0.0f;
+    const int slot = wavefrontSlot();
+    const bool lastRound = PERSIST || !LORAHIP_PRIO_HOLD || blockIdx.x >= s.lastRoundFrom;
+    holdPriority<LORAHIP_PRIO_ALTERNATE>(!lastRound);
     while (true)
     {
+        if (lastRound) rotatePriority<2, LORAHIP_PRIO_ALTERNATE>(slot);
         const bool live = mine && (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt && o.nSig < s.capPkt));   // LoRaDemod.cpp:148
         if (!__any(live)) break;
 
@@ -337,19 +341,22 @@ demodStream(const StreamArgs s)
 }
 
 template <class C>
-static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
+static hipError_t launchStreamCfg(const StreamArgs &args, hipStream_t stream)
 {
     constexpr int WAVES = 4;
     const size_t smem = size_t(C::TWN + C::N) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2) + FineDims<C::LOG2N>::BYTES;
     static unsigned long long attrDone = 0, attrDoneP = 0;
+    static int resident = -1;
+    StreamArgs s = args;
     const unsigned perBlock = WAVES * C::WPW;
     const unsigned grid = (s.nChannels + perBlock - 1) / perBlock;
     if (grid == 0) return hipSuccess;
-#ifdef LORAHIP_ALL_VARIANTS      // the persistent grid: measured, negative (lorahip_demod.cpp::runStream); profiling build only
+#if defined(LORAHIP_ALL_VARIANTS) || defined(LORAHIP_STREAM_PERSIST)      // the persistent grid: profiling builds only (lorahip_demod.cpp::runStream)
     if (s.maxBlocks > 0 && grid > unsigned(s.maxBlocks))
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, true>), smem, attrDoneP);
         if (e != hipSuccess) return e;
+        s.lastRoundFrom = 0;
         hipLaunchKernelGGL((demodStream<C, true>), dim3(unsigned(s.maxBlocks)), dim3(WAVES * 64), smem, stream, s);
         return hipGetLastError();
     }
@@ -357,6 +364,8 @@ static hipError_t launchStreamCfg(const StreamArgs &s, hipStream_t stream)
     (void)attrDoneP;
     const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, false>), smem, attrDone);
     if (e != hipSuccess) return e;
+    if (resident < 0) resident = residentWorkgroups(reinterpret_cast<const void *>(demodStream<C, false>), WAVES * 64, smem);
+    s.lastRoundFrom = lastRoundFrom(grid, resident);
     hipLaunchKernelGGL((demodStream<C, false>), dim3(grid), dim3(WAVES * 64), smem, stream, s);
     return hipGetLastError();
 }

@@ -265,8 +265,10 @@ detectWide(const DetectArgs a, const FastTables ft, const unsigned nSets)
         }
     };
 
+    const int prioSlot = wavefrontSlot();
     for (unsigned set = blockIdx.x; set < nSets; set += gridDim.x)
     {
+        rotatePriority<C::MINW, LORAHIP_PRIO_BATCH>(prioSlot);
         const unsigned w = set * WPB + wsub;
         const bool active = w < a.nWindows;
         const unsigned wc = active ? w : a.nWindows - 1;  // an inactive half redoes the last window, results dropped
@@ -656,10 +658,26 @@ hipError_t launchWide(const int sf, const int variant, const DetectArgs &a, cons
  * window after window -- the level-3 twin of lorahip_stream.hip, same frame machine (lorahip_framemachine.h), the
  * in-place three-phase FFT of detectWide. Five workgroup barriers per window (two more while the fine-tune index moves).
  **********************************************************************/
+#ifdef LORAHIP_WG_TIMELINE     // profiling build (tools/wg_timeline.py): when and where every workgroup of the last streaming launch ran
+__device__ unsigned long long gWgTimeline[16384][4];
+__device__ unsigned gWgWaveHwId[16384][4];
+extern "C" int lorahip_debug_wg_timeline(void *out, const size_t bytes)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gWgTimeline), bytes < sizeof(gWgTimeline) ? bytes : sizeof(gWgTimeline)) == hipSuccess ? 0 : -1;
+}
+extern "C" int lorahip_debug_wg_waves(void *out, const size_t bytes)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gWgWaveHwId), bytes < sizeof(gWgWaveHwId) ? bytes : sizeof(gWgWaveHwId)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 template <class C, bool PERSIST>
 __global__ void __launch_bounds__(C::T, 2)
 demodStreamWide(const StreamArgs s)
 {
+#ifdef LORAHIP_WG_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+#endif
     static_assert(C::INPLACE && C::WPB == 1 && !C::CH_LDS && !C::TW_ALL_LDS, "stream configs: one channel per workgroup, in-place middle phase");
     constexpr int N = C::N, T = C::T, VEC = C::VEC, R = C::R, WPWIN = C::WPWIN;
     constexpr int LOG2N = C::LOG2N, LOG2T = C::LOG2T, B1 = C::B1, B2 = C::B2, HB = C::HB;
@@ -934,8 +952,12 @@ demodStreamWide(const StreamArgs s)
     bool pend = false;
     int value0 = 0, fineIdxBefore0 = 0;
     float snr0 = 0.0f, fineErrBefore0 = 0.0f;
+    const int slot = wavefrontSlot();
+    const bool lastRound = PERSIST || !LORAHIP_PRIO_HOLD || blockIdx.x >= s.lastRoundFrom;
+    holdPriority<LORAHIP_PRIO_ALTERNATE>(!lastRound);
     while (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt && o.nSig < s.capPkt))          // LoRaDemod.cpp:148
     {
+        if (lastRound) rotatePriority<2, LORAHIP_PRIO_ALTERNATE>(slot);
         const bool second = pend;
         int value, idxEnd;
         float power, powerAvg, fIndex;
@@ -971,6 +993,9 @@ demodStreamWide(const StreamArgs s)
         }
     }
     o.carryOut(s, st, c, t, T);
+#ifdef LORAHIP_WG_TIMELINE
+    if ((t & 63) == 0 && c < 16384) gWgWaveHwId[c][(t >> 6) & 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
     if (t == 0)
     {
         s.state[c] = st;
@@ -978,30 +1003,59 @@ demodStreamWide(const StreamArgs s)
         s.nSym[c] = o.nSym;
         s.nPkt[c] = o.nPkt;
         if (s.nSig) s.nSig[c] = o.nSig;
+#ifdef LORAHIP_WG_TIMELINE
+        if (c < 16384)
+        {
+            gWgTimeline[c][0] = tl0; gWgTimeline[c][1] = wall_clock64();
+            gWgTimeline[c][2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // HW_ID, XCC_ID
+            gWgTimeline[c][3] = (unsigned long long)o.calls;
+        }
+#endif
     }
     if (PERSIST) __syncthreads();                           // the next channel reuses the exchange region and the reduction records
     } while (PERSIST && (c += gridDim.x) < s.nChannels);    // without PERSIST there is no loop at all (it would cost registers)
 }
 
 
+// The grid. One workgroup per channel by default: the dispatcher hands every free slot the next channel. SF11 is the exception: its
+// workgroup is TWO wavefronts, four workgroups per compute unit, and when workgroups of a second round are placed as slots free up
+// one by one the unit can end with its two free wavefront slots on the SAME SIMD -- where the hardware does not place a workgroup
+// (tools/wg_timeline.py, profiles/r04/s19_*: a slot stayed empty for 1.1 ms with a workgroup waiting for it; 2048 channels took
+// 4.1-5.6 ms from launch to launch). There the grid is PERSISTENT: the resident number of workgroups, placed once on an empty
+// device, each taking channel after channel (c += gridDim.x) -- with the alternating priority (lorahip_framemachine.h) they advance
+// alike, so the static split leaves no tail: 3.94-3.97 ms every launch. s.maxBlocks: 0 = this default, < 0 = never persistent,
+// > 0 = at most that many workgroups (lorahip_demod_set_stream_grid: tests, A/B).
 template <class C>
-static hipError_t launchStreamWideCfg(const StreamArgs &s, hipStream_t stream)
+static hipError_t launchStreamWideCfg(const StreamArgs &args, hipStream_t stream)
 {
     const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2) + 12 * sizeof(int) + FineDims<C::LOG2N>::BYTES;
     static unsigned long long attrDone = 0, attrDoneP = 0;
+    static int resident = -1, residentP = -1;
+    StreamArgs s = args;
     if (s.nChannels == 0) return hipSuccess;
-#ifdef LORAHIP_ALL_VARIANTS      // the persistent grid: measured, negative (lorahip_demod.cpp::runStream); profiling build only
-    if (s.maxBlocks > 0 && s.nChannels > unsigned(s.maxBlocks))
+    int cap = s.maxBlocks;
+    if (cap == 0 && C::LOG2N == 11)
+    {
+        if (residentP < 0)
+        {
+            const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, true>), smem, attrDoneP);
+            if (e != hipSuccess) return e;
+            residentP = residentWorkgroups(reinterpret_cast<const void *>(demodStreamWide<C, true>), C::T, smem);
+        }
+        cap = residentP;
+    }
+    if (cap > 0 && s.nChannels > unsigned(cap))
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, true>), smem, attrDoneP);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((demodStreamWide<C, true>), dim3(unsigned(s.maxBlocks)), dim3(C::T), smem, stream, s);
+        s.lastRoundFrom = 0;                                    // nobody is replaced: every workgroup takes its turn at the priority
+        hipLaunchKernelGGL((demodStreamWide<C, true>), dim3(unsigned(cap)), dim3(C::T), smem, stream, s);
         return hipGetLastError();
     }
-#endif
-    (void)attrDoneP;
     const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, false>), smem, attrDone);
     if (e != hipSuccess) return e;
+    if (resident < 0) resident = residentWorkgroups(reinterpret_cast<const void *>(demodStreamWide<C, false>), C::T, smem);
+    s.lastRoundFrom = lastRoundFrom(s.nChannels, resident);
     hipLaunchKernelGGL((demodStreamWide<C, false>), dim3(s.nChannels), dim3(C::T), smem, stream, s);
     return hipGetLastError();
 }

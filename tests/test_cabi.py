@@ -79,6 +79,7 @@ def test_round4_entries_refuse_bad_arguments_and_fail_loudly_without_a_gpu():
     assert lib.lorahip_demod_part(None, 0, None, None, None, None) == -1
     assert lib.lorahip_demod_part_handle(None, 0) is None
     assert lib.lorahip_demod_set_variant(None, 0) == -1
+    assert lib.lorahip_demod_set_stream_grid(None, 0) == -1
     assert lib.lorahip_set_variant(None, 40) == -1
     assert C.sizeof(_lib.PacketRows) == 7 * 8          # struct lorahip_packet_rows: 6 pointer-sized fields + 2 x int32
 

@@ -145,6 +145,49 @@ def test_receive_packs_the_packets_of_every_step_on_the_device(gpu, oracle, sf):
     d.close()
 
 
+@pytest.mark.parametrize("sf", [7, 11, 12])
+def test_stream_grid_is_scheduling_only(gpu, oracle, sf):
+    """lorahip_demod_set_stream_grid: however the channels are spread over workgroups -- one workgroup per channel, a few workgroups
+    each walking channel after channel (the default at SF11 once the channels outnumber the resident workgroups), chunked or in one
+    run -- packets, signals, call counts and read positions are the reference's."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(900 + sf)
+    N, B = 1 << sf, 11
+    host = _streams(oracle, rng, sf, B, n_frames=3)
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
+    iq = gpu.from_numpy(host).cuda()
+    want_calls = sum(len(r["calls"]) for r in refs)
+    for grid in (0, -1, 1, 3, 8, 64):
+        d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9); d.set_signals(True)
+        d.set_stream_grid(grid)
+        d.work(iq)
+        assert d.work_calls() == want_calls, "grid %d" % grid
+        pk = d.packets(clear=False)
+        ch, rd, er, pw, sn = d.signals()
+        for c in range(B):
+            assert [q.tolist() for cc, _, q in pk if cc == c] == [q.tolist() for _, q in refs[c]["packets"]], "grid %d channel %d" % (grid, c)
+            assert d.consumed(c) == int(sum(k["consumed"] for k in refs[c]["calls"]))
+            assert er[ch == c].tolist() == [g[0] for g in refs[c]["signals"]]
+        d.close()
+    # the running receiver in chunks, three workgroups for eleven channels: open packets cross both chunk and channel-walk boundaries
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9); d.set_stream_grid(3)
+    rows = d.receiver_rows(cap_packets=64, stride=16)
+    got, calls, w = [[] for _ in range(B)], 0, 0
+    while w < cap:
+        w = min(cap, w + int(rng.integers(N, 7 * N)))
+        n, c_ = d.receive(iq, w, rows)
+        calls += c_
+        sy, ns, chn = rows[0][:n].cpu().numpy(), rows[1][:n].cpu().numpy(), rows[2][:n].cpu().numpy()
+        for i in range(n):
+            got[int(chn[i])].append(sy[i, :ns[i]].copy())
+    assert calls == want_calls
+    for c, r in enumerate(refs):
+        assert len(got[c]) == len(r["packets"]) >= 3
+        assert all(np.array_equal(a_, b_) for a_, (_, b_) in zip(got[c], r["packets"]))
+    d.close()
+
+
 @pytest.mark.parametrize("sf", [7, 9, 10, 12])
 def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf):
     """lorahip_demod_receive with async = 2: step k's kernel is launched before step k-1's summary is read; the packets of a step
