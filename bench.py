@@ -634,11 +634,13 @@ def section_level3(env, L, sf, threads=32):
     return res
 
 
-def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 32768)), (12, (256, 512, 1024, 2048, 4096))), both_grids=False, passes=4):
+def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 32768)), (11, (1024, 2048, 4096)), (12, (256, 512, 1024, 2048, 4096))), both_grids=False, passes=4):
     """The streaming kernels against the channel count (whole LoRaDemod blocks, the level-3 workload): below the resident set (two
-    wavefronts per SIMD: 16384 channels at SF7, 512 at SF12) the device is not full; above it the dispatcher hands every free slot the
-    next channel set. (both_grids: also a persistent grid -- LORAHIP_STREAM_BLOCKS, profiling build only -- which measured worse:
-    profiles/r04/s4_level3_scaling_persistent_vs_plain_negative.txt.) Kernel time = HIP events around the launch."""
+    wavefronts per SIMD: 16384 channels at SF7, 1024 at SF11, 512 at SF12) the device is not full; above it the dispatcher hands every
+    free slot the next channel set (SF11: the resident workgroups walk channel after channel, lorahip_wide.hip). A grid that is not a
+    whole number of resident sets runs its last partial set on half-empty SIMDs (24576 SF7 channels = 1.5 sets). (both_grids: also a
+    persistent grid where it is not the default -- LORAHIP_STREAM_BLOCKS, profiling builds only: profiles/r04/s22_*.) Kernel time =
+    HIP events around the launch, the best and the median of `passes` launches."""
     from lora_sdr_amd import workloads as WL
     torch = env.torch
     out = []
