@@ -33,7 +33,8 @@ namespace lorahip {
 #endif
 // The batch kernels are persistent too (a wavefront walks window sets first, first + waveCount, ...: a static share each), two to
 // three wavefronts per SIMD: the same rotation once per set, +2-3 % at SF7-11 and +5 % at SF12 in both shapes
-// (profiles/r04/s25_ab_batch_priority.txt).
+// (profiles/r04/s25_ab_batch_priority.txt; tools/wave_timeline.py: without it the three slots of a SIMD end a 226 us SF7 launch after
+// 122 / 172 / 219 us), another +1.5-2.5 % at SF7 / 10 / 12 with the whole order rotating (s31_ab_batch_priority_full_order.txt).
 #ifndef LORAHIP_PRIO_BATCH
 #define LORAHIP_PRIO_BATCH 16           // batch kernels: log2 of the period per wavefront in shader clocks (launches last 0.2-0.4 ms); 0: off
 #endif
@@ -57,7 +58,17 @@ __device__ __forceinline__ void rotatePriority(const int slot)
         if (WPS == 2) { p &= 1u; me &= 1u; }
         else if (WPS == 4) { p &= 3u; me &= 3u; }
         else { p &= 1023u; p -= WPS * ((p * (2048u / WPS + 1u)) >> 11); me = me >= unsigned(WPS) ? me - unsigned(WPS) : me; }   // p mod 3 (exact below 1024)
-        if (p == me) __builtin_amdgcn_s_setprio(2);
+        // the whole ORDER rotates, not only who is first: with three wavefronts "one high, two equal" leaves the older of the two
+        // ahead whenever the first one waits, and the slots still finish 15 % apart (tools/wave_timeline.py)
+        const unsigned rank = me >= p ? me - p : me + unsigned(WPS) - p;        // 0: first this turn
+        if (WPS == 2)
+        {
+            if (rank == 0) __builtin_amdgcn_s_setprio(2);                       // (3 is holdPriority's)
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        else if (rank == 0) __builtin_amdgcn_s_setprio(3);
+        else if (rank == 1) __builtin_amdgcn_s_setprio(2);
+        else if (rank == 2) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
     }
 }

@@ -44,10 +44,23 @@ std::vector<cf32> buildStageTwiddles(const int sf, const std::vector<cf32> &tw)
  * UNI = launch-uniform batch: one chirp selection for all windows and no moving fine-tune index
  *       (chirp_sel == NULL, fine_err == NULL): the steady-state shape, compiled without the rare paths.
  **********************************************************************/
+#ifdef LORAHIP_WG_TIMELINE     // profiling build (tools/wave_timeline.py): when and where every wavefront of the last batch launch ran
+__device__ unsigned long long gWaveTimeline[16384][4];
+extern "C" int lorahip_debug_wave_timeline(void *out, const size_t bytes)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gWaveTimeline), bytes < sizeof(gWaveTimeline) ? bytes : sizeof(gWaveTimeline)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 template <class C, bool DBG, bool UNI>
 __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD)
 detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
 {
+#ifdef LORAHIP_WG_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+    unsigned long long tlLoop = 0;
+    unsigned tlSets = 0;
+#endif
     typedef FastCore<C> K;
     constexpr int N = C::N, T = C::T, VEC = C::VEC, R = C::R, WPW = C::WPW;
     constexpr int LOG2T = C::LOG2T;
@@ -135,8 +148,14 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
     const v2f fconst0 = gFine[0];
 
     const int prioSlot = wavefrontSlot();
+#ifdef LORAHIP_WG_TIMELINE
+    tlLoop = wall_clock64();
+#endif
     for (unsigned set = waveId; set < setEnd; set += waveCount)
     {
+#ifdef LORAHIP_WG_TIMELINE
+        tlSets++;
+#endif
         rotatePriority<C::WAVES_PER_SIMD, LORAHIP_PRIO_BATCH>(prioSlot);
         const unsigned w = set * WPW + wsub;
         const bool active = w < a.nWindows;
@@ -280,6 +299,15 @@ detectFast(const DetectArgs a, const FastTables ft, const unsigned nSets)
         const unsigned ww = lane < pending ? tr.w[lane] : 0xffffffffu;
         if (ww < a.nWindows) detectTail(a, ww, tr.idx[lane], tr.val[lane], tr.tot[lane], tr.l[lane], tr.r[lane]);
     }
+#ifdef LORAHIP_WG_TIMELINE
+    if (lane == 0 && blockIdx.x * WAVES + wave < 16384)
+    {
+        unsigned long long *r = gWaveTimeline[blockIdx.x * WAVES + wave];
+        r[0] = tl0; r[1] = wall_clock64();
+        r[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        r[3] = (unsigned long long)tlSets | ((tlLoop - tl0) << 32);
+    }
+#endif
 }
 
 /***********************************************************************
