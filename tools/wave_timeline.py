@@ -34,5 +34,12 @@ for p in range(3):
     for s_ in np.unique(slot):
         m = slot == s_
         print("    slot %d: n %d, end median %.1f (min %.1f max %.1f)" % (s_, m.sum(), np.median(t1[m]), t1[m].min(), t1[m].max()))
+    xcc = ((tl[:, 2] >> np.uint64(32)) & np.uint64(0xf)).astype(np.int64)
+    hw = (tl[:, 2] & np.uint64(0xffffffff)).astype(np.int64)
+    unit = ((xcc * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xf)
+    print("    end by XCC (median):", [round(float(np.median(t1[xcc == x])), 1) for x in np.unique(xcc)])
+    um = np.array([np.median(t1[unit == u]) for u in np.unique(unit)])
+    print("    end by compute unit (median of its wavefronts): min %.1f p10 %.1f median %.1f p90 %.1f max %.1f;  spread inside a unit (max - min), median %.1f" %
+          (um.min(), np.percentile(um, 10), np.median(um), np.percentile(um, 90), um.max(), np.median([t1[unit == u].max() - t1[unit == u].min() for u in np.unique(unit)])))
     ts = np.linspace(0, t1.max(), 21)
     print("    resident wavefronts over the span:", [int(((t0 <= x) & (t1 > x)).sum()) for x in ts])
