@@ -188,6 +188,29 @@ def test_stream_grid_is_scheduling_only(gpu, oracle, sf):
     d.close()
 
 
+def test_sf11_beyond_the_resident_set(gpu):
+    """More SF11 channels than the device holds workgroups: the library's own grid (the resident number of workgroups, each walking
+    channel after channel -- lorahip_wide.hip) against one workgroup per channel: the same calls, read positions and packets, and the
+    packets carry the sent symbols."""
+    import lora_sdr_amd as L
+    from lora_sdr_amd import workloads as WL
+    ctx = L.Context(11)
+    B = 1100
+    iq, data = WL.frame_streams(ctx, B, 2, 12, sigma=0.05)
+    res = []
+    for grid in (0, -1):
+        d = L.LoRaDemod(11, n_channels=B); d.set_mode(1); d.setMTU(12); d.set_stream_grid(grid)
+        d.work(iq)
+        pk = d.packets()
+        res.append((d.work_calls(), [d.consumed(c) for c in range(0, B, 53)], sorted((c, r, tuple(q.tolist())) for c, r, q in pk)))
+        if grid == 0:
+            n, ok = WL.check_frame_packets(pk, data, 1 << 11, 12)
+            assert n == 2 * B and ok >= n - 4                       # (a noise-triggered early end is the reference's behaviour too)
+        d.close()
+    assert res[0] == res[1]
+    ctx.close()
+
+
 @pytest.mark.parametrize("sf", [7, 9, 10, 12])
 def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf):
     """lorahip_demod_receive with async = 2: step k's kernel is launched before step k-1's summary is read; the packets of a step
