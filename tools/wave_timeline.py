@@ -23,6 +23,8 @@ for p in range(3):
     tl = np.zeros((16384, 4), dtype=np.uint64)
     assert lib.lorahip_debug_wave_timeline(tl.ctypes.data, tl.nbytes) == 0
     tl = tl[tl[:, 1] != 0]
+    if len(tl) == 0:
+        raise SystemExit("no records: the build lacks -DLORAHIP_WG_TIMELINE, or this SF runs lorahip_wide.hip's kernels (SF11 / SF12), which are not instrumented")
     t0, t1 = tl[:, 0].astype(np.float64) * 0.01, tl[:, 1].astype(np.float64) * 0.01
     setup = (tl[:, 3] >> np.uint64(32)).astype(np.float64) * 0.01
     sets = (tl[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
