@@ -971,6 +971,8 @@ struct Pipe
     StreamSummary *hSum;            // [2] pinned and mapped: the summary kernel writes here directly (no copy to enqueue)
     hipEvent_t ev[2];
     bool pending[2];
+    hipStream_t side;               // step k's packets are packed HERE while step k + 1's kernel runs on the launch stream
+    hipEvent_t packDone;            // ... which waits for this before anything later (the next kernel reuses the record set, the caller reads the rows)
 };
 static Pipe &pipeOf(lorahip_demod *dm) { return *static_cast<Pipe *>(dm->pipe); }
 static bool pipeBusy(const lorahip_demod *dm) { return dm->pipe != nullptr && static_cast<const Pipe *>(dm->pipe)->active; }
@@ -988,7 +990,7 @@ static void streamCapacity(const lorahip_demod *dm, const size_t maxLen, size_t 
 }
 
 //! what summary `set` says, into the object's books; packs that step's packets into `rows` (stream-ordered; no wait)
-static int pipeDeliver(lorahip_demod *dm, const int set, const lorahip_packet_rows *rows, size_t *nPackets, int64_t *calls)
+static int pipeDeliver(lorahip_demod *dm, const int set, const lorahip_packet_rows *rows, size_t *nPackets, int64_t *calls, const bool beside = false)
 {
     Pipe &P = pipeOf(dm);
     lorahip_ctx *ctx = dm->ctx;
@@ -1013,10 +1015,21 @@ static int pipeDeliver(lorahip_demod *dm, const int set, const lorahip_packet_ro
     const size_t nbRow = align256(L.B * sizeof(int));
     { const int grc = growDense(dm, nbRow + n * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
     char *d = P.dev[set];
+    // `beside`: packed on the side stream WHILE the step just launched runs (the host has just waited for this step's summary: its
+    // kernel is complete, no device-side dependency is needed); the launch stream then waits for the packing before anything later --
+    // the next kernel reuses this record set, the caller reads the rows. Worth it for short steps only (profiles/r04/s37_*: 8-window
+    // chunks at SF7 +14 %; at 128-window chunks the packing kernels displace workgroups of a streaming grid that exactly fills the
+    // device, -5 %).
+    hipStream_t packStream = beside ? P.side : ctx->stream;
     LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(d + L.oPkt), reinterpret_cast<const int *>(d + L.oNPkt),
                                   reinterpret_cast<const short *>(d + L.oSym), reinterpret_cast<int *>(dm->dDense), L.B, int(L.symStride), int(L.capPkt), n,
                                   reinterpret_cast<long long *>(dm->dDense + nbRow), rows->syms_dev, int(rows->sym_stride), rows->nsyms_dev, rows->channel_dev,
-                                  ctx->stream));
+                                  packStream));
+    if (beside)
+    {
+        LORAHIP_TRY(hipEventRecord(P.packDone, P.side));
+        LORAHIP_TRY(hipStreamWaitEvent(ctx->stream, P.packDone, 0));
+    }
     return LORAHIP_OK;
 }
 
@@ -1071,11 +1084,14 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
         {
             LORAHIP_TRY(hipHostMalloc((void **)&P.hSum, 2 * sizeof(StreamSummary), hipHostMallocMapped));
             for (int i = 0; i < 2; i++) LORAHIP_TRY(hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming));
+            LORAHIP_TRY(hipEventCreateWithFlags(&P.packDone, hipEventDisableTiming));
+            LORAHIP_TRY(hipStreamCreateWithFlags(&P.side, hipStreamNonBlocking));
         }
         P.active = true; P.k = 0; P.pending[0] = P.pending[1] = false;
         dm->devStateFresh = false;                    // until the pipeline is flushed, only it knows where the state stands
     }
     const int set = int(P.k & 1);
+    const size_t prevValid = dm->appendPrev;
     size_t cap, capPkt;
     streamCapacity(dm, nValid - dm->appendPrev + 2 * N, cap, capPkt);
     StreamLayout L;
@@ -1120,7 +1136,8 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     // ... and while it runs: the step before
     if (nPackets) *nPackets = 0;
     if (calls) *calls = 0;
-    if (P.k >= 2 && P.pending[set ^ 1]) return pipeDeliver(dm, set ^ 1, rows, nPackets, calls);
+    const bool shortStep = (nValid - prevValid) <= 48 * N;    // (the step launched above)
+    if (P.k >= 2 && P.pending[set ^ 1]) return pipeDeliver(dm, set ^ 1, rows, nPackets, calls, shortStep);
     return LORAHIP_OK;
 }
 
@@ -1436,6 +1453,8 @@ void lorahip_demod_destroy(lorahip_demod *dm)
             if (P.dev[i]) (void)hipFree(P.dev[i]);
             if (P.hSum) (void)hipEventDestroy(P.ev[i]);
         }
+        if (P.side) { (void)hipStreamSynchronize(P.side); (void)hipStreamDestroy(P.side); }
+        if (P.packDone) (void)hipEventDestroy(P.packDone);
         if (P.hSum) (void)hipHostFree(P.hSum);
     }
     }
