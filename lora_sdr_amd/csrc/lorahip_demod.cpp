@@ -876,9 +876,13 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         LORAHIP_TRY(hipEventRecord(dm->evK1, ctx->stream));
         a.flags = 0;                                  // a resumed launch continues where the state says
         // what the host needs of the launch, reduced on the device: 64 bytes come back, not 52 per channel
+        // (written by the kernel straight into the pinned staging block when the device can address it: no copy to enqueue)
+        void *sumDev = nullptr;
+        const bool direct = hipHostGetDevicePointer(&sumDev, const_cast<StreamSummary *>(hSum), 0) == hipSuccess && sumDev != nullptr;
+        if (!direct) (void)hipGetLastError();
         LORAHIP_TRY(launchStreamSummary(a.state, a.nCalls, a.nSym, a.nPkt, dm->wantSignals ? a.nSig : nullptr, B, int(cap), int(capPkt), a.near,
-                                        reinterpret_cast<StreamSummary *>(d + L.oSum), ctx->stream));
-        LORAHIP_TRY(hipMemcpyAsync(h + L.oSum, d + L.oSum, sizeof(StreamSummary), hipMemcpyDeviceToHost, ctx->stream));
+                                        direct ? static_cast<StreamSummary *>(sumDev) : reinterpret_cast<StreamSummary *>(d + L.oSum), ctx->stream));
+        if (!direct) LORAHIP_TRY(hipMemcpyAsync(h + L.oSum, d + L.oSum, sizeof(StreamSummary), hipMemcpyDeviceToHost, ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
         dm->headStale = true;                         // the pinned copy of the per-channel state and counts lags the device now
         { float ms = 0.0f; if (hipEventElapsedTime(&ms, dm->evK0, dm->evK1) == hipSuccess) dm->kernelMs += ms; }
