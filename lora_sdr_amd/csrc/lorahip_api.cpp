@@ -39,8 +39,9 @@ hipError_t ensureDynamicLds(const void *kernel, const size_t bytes, unsigned lon
 int residentWorkgroups(const void *kernel, const int threads, const size_t smem)
 {
     int dev = 0, cus = 0, perCu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, smem) != hipSuccess) return 0;
+    // (a refusal here must not be taken for the failure of the launch that follows: hipGetLastError() is read after it)
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, smem) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return perCu > 0 && cus > 0 ? perCu * cus : 0;
 }
 
