@@ -1,0 +1,67 @@
+"""Randomised level-3 soak against the CPU oracle (the restated block, pinned to the verbatim LoRaDemod.cpp): random SF, channel
+count, MTU, threshold, sync word, carrier offset, noise, stream grid and chunking; packets, call counts and read positions must be
+the reference's in every case.   python tools/soak_level3.py [seconds] [first seed]
+(tests/ hold the fixed-seed versions of these cases; this is the same comparison over many more parameter combinations.)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+import lora_sdr_amd as L
+from oracle.oracle import Oracle
+from test_gpu_demod import frames
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+oracle = Oracle()
+t_end = time.time() + budget
+cases = calls_total = packets_total = 0
+per_sf = {}
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    sf = int(rng.integers(7, 13)); N = 1 << sf
+    B = int(rng.integers(1, 24 if sf < 11 else 10))
+    mtu = int(rng.integers(3, 40)); thresh = float(rng.uniform(-40, -5)); sync = int(rng.integers(0, 256)) if rng.random() < 0.3 else 0x12
+    streams = []
+    for c in range(B):
+        s, _ = frames(oracle, rng, sf, int(rng.integers(1, 4)), int(rng.integers(2, 30)), off=float(rng.uniform(-0.45, 0.45)), noise=float(rng.uniform(0.0, 0.3)),
+                      sync=sync, lead=int(rng.integers(0, 3 * N)))
+        streams.append(s)
+    cap = max(s.size for s in streams)
+    host = np.zeros((B, cap), np.complex64)
+    for c, s in enumerate(streams): host[c, :s.size] = s
+    refs = [oracle.demod_run(sf, host[c], sync=sync, thresh=thresh, mtu=mtu) for c in range(B)]
+    iq = torch.from_numpy(host).cuda()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(mtu); d.setThreshold(thresh); d.setSync(sync)
+    d.set_stream_grid(int(rng.choice([0, -1, 1, 2, 5])))
+    how = int(rng.integers(0, 3))
+    got = [[] for _ in range(B)]
+    if how == 0:
+        d.work(iq)
+        for ch, _r, q in d.packets(): got[ch].append(q)
+        ncalls = d.work_calls()
+    else:
+        rows = [d.receiver_rows(cap_packets=B * 40, stride=max(mtu, 8)) for _ in range(2)]
+        w = k = ncalls = 0
+        def take(n, r):
+            torch.cuda.synchronize()
+            sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
+            for i in range(n): got[int(chn[i])].append(sy[i, :ns[i]].copy())
+        while w < cap:
+            w = min(cap, w + int(rng.integers(N // 2, 9 * N)))
+            n, c_ = d.receive(iq, w, rows[k & 1], async_=(2 if how == 2 else True))
+            take(n, rows[k & 1]); ncalls += c_; k += 1
+        if how == 2:
+            n, c_ = d.receive_flush(rows[k & 1]); take(n, rows[k & 1]); ncalls += c_
+    want_calls = sum(len(r["calls"]) for r in refs)
+    assert ncalls == want_calls, ("calls", seed, sf, B, how, ncalls, want_calls)
+    for c, r in enumerate(refs):
+        assert len(got[c]) == len(r["packets"]), ("packet count", seed, sf, c, how)
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), ("packet symbols", seed, sf, c, how)
+        assert d.consumed(c) == int(sum(k_["consumed"] for k_ in r["calls"])), ("consumed", seed, sf, c, how)
+    d.close()
+    cases += 1; calls_total += want_calls; packets_total += sum(len(r["packets"]) for r in refs)
+    per_sf[sf] = per_sf.get(sf, 0) + 1
+    seed += 1
+print("level-3 soak: %d random cases (seeds up to %d; per SF %s), %d work() calls, %d packets: every channel's packets, call count and read position equal the reference's"
+      % (cases, seed - 1, dict(sorted(per_sf.items())), calls_total, packets_total))
