@@ -337,7 +337,9 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * With async = 2 the steps are PIPELINED: this step's kernel is launched before the previous step's summary is read, so the host's
  * share of a step (launch latencies, the wait for the summary, the packing launches: ~60 us) overlaps the kernel instead of
  * following it. The price is one step of latency: *n_packets / *work_calls and the rows are those of the PREVIOUS step (0 for the
- * first); lorahip_demod_receive_flush() delivers the last step's and leaves the pipeline. The first call after anything else touched
+ * first), valid in stream order on the object's launch stream like with async = 1 (short steps are packed on a side stream beside
+ * the running kernel; the launch stream waits for that before anything later); lorahip_demod_receive_flush() delivers the last
+ * step's and leaves the pipeline. The first call after anything else touched
  * the object is an ordinary step (its packets delivered at once). While a step is in flight every other entry point that needs the
  * object's state returns LORAHIP_E_INVALID ("flush first"); no trace / ports / signals in this mode; a step whose packets do not fit
  * the rows loses them (LORAHIP_E_INVALID) -- size the rows for a step. */
