@@ -443,7 +443,8 @@ __global__ void packCopy(const short *__restrict__ symOut, const long long *__re
 
 //! rowStart = exclusive prefix sum of nPkt (one workgroup; the channel counts are tens of thousands at most): the packets' rows are
 //! numbered on the device, so that packing needs neither an upload nor a host synchronisation. (Describing the packets in the same
-//! workgroup -- one launch less -- was tried and is slower by far: 65536 packets walked by 1024 lanes, profiles/r04.)
+//! workgroup -- one launch less -- was tried and is slower by far: 65536 packets walked by 1024 lanes, profiles/r04; doing all three
+//! steps in one workgroup for launches of <= 2048 packets, a receiver step of a few windows, is slower too: s43_*.)
 __global__ void __launch_bounds__(1024) scanCounts(const int *__restrict__ nPkt, int *__restrict__ rowStart, const unsigned nChannels)
 {
     __shared__ int sPart[1024];

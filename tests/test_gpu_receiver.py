@@ -201,7 +201,14 @@ def test_sf11_beyond_the_resident_set(gpu):
     for grid in (0, -1):
         d = L.LoRaDemod(11, n_channels=B); d.set_mode(1); d.setMTU(12); d.set_stream_grid(grid)
         d.work(iq)
+        # 2200 packets of 1100 channels packed on the device (row numbering by prefix sum over the channels): rows by channel, then
+        # time, zero padded
+        ps, pn, pc = d.packets_device(stride=16, clear=False)
         pk = d.packets()
+        by_channel = sorted(pk, key=lambda e: (e[0], e[1]))
+        assert pc.cpu().tolist() == [c for c, _, _ in by_channel] and pn.cpu().tolist() == [len(q) for _, _, q in by_channel]
+        rows_ = ps.cpu().numpy()
+        assert all(np.array_equal(rows_[i, :len(q)], q) and not rows_[i, len(q):].any() for i, (_, _, q) in enumerate(by_channel))
         res.append((d.work_calls(), [d.consumed(c) for c in range(0, B, 53)], sorted((c, r, tuple(q.tolist())) for c, r, q in pk)))
         if grid == 0:
             n, ok = WL.check_frame_packets(pk, data, 1 << 11, 12)
