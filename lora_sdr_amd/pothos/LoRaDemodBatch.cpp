@@ -139,7 +139,7 @@ public:
         if (lorahip_demod_run(_d, _streams.data(), _avail.data(), nullptr) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
 
         _consumed.resize(B);
-        lorahip_demod_consumed_all(_d, _consumed.data());
+        if (lorahip_demod_consumed_all(_d, _consumed.data()) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
         for (size_t c = 0; c < B; c++) if (_consumed[c] > 0) _in[c]->consume(size_t(_consumed[c]));   // the sum of consume(total), :320
 
         if (_debugPorts) producePorts();
