@@ -9,7 +9,8 @@ A "step" is one pass of the hot path (one lorahip_detect_batch launch) over one 
 in HBM: `channels` channels x `symbols` symbol windows of 2^SF cf32 samples. The headline workload (value / config /
 roofline) is BASELINE.json configs[1]: 4096 channels SF7 (N=128 FFT) x 256 windows per channel = 1 GiB of IQ per step.
 With N > 1 every rank demodulates its own channels (independent units, no data-path collective): weak scaling; every
-value is the whole-job aggregate.
+value is the whole-job aggregate. The CPU legs (cpu_baseline, the oracle checks) run on rank 0, on its own shard, after the timed
+regions, while the other ranks wait at a host-side (gloo) barrier; every rank also holds a sample of its shard to the oracle.
 
 Rank 0 prints ONE JSON line. Besides the contract fields it carries
   roofline      HBM roofline of the detect kernel: algorithmic bytes/launch (8*2^SF+14 per window) /
@@ -113,6 +114,7 @@ class Env:
         self.dev = torch.device("cuda", local)
         self.dist = None
         self.rccl_ranks = None
+        self.host_group = None
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -124,12 +126,20 @@ class Env:
             t = torch.ones(1, device=self.dev if self.backend == "nccl" else "cpu")
             dist.all_reduce(t)
             self.rccl_ranks = int(t.item()) if self.backend == "nccl" else None
+            # a HOST-side group for the waits around rank 0's CPU legs (cpu_baseline, the oracle checks): a gloo barrier blocks on a
+            # socket, an RCCL barrier would keep seven host threads and seven GPUs spinning beside the CPU code being timed
+            self.host_group = dist.new_group(backend="gloo") if self.backend == "nccl" else None
 
     def barrier(self):
         self.torch.cuda.synchronize()
         if self.dist is not None:
             self.dist.barrier()
         self.torch.cuda.synchronize()
+
+    def host_barrier(self):
+        """the ranks meet on the host (no device work in flight is waited for, nothing spins): where rank 0 runs its CPU legs"""
+        if self.dist is not None:
+            self.dist.barrier(group=self.host_group)
 
     def max_over_ranks(self, *vals):
         if self.dist is None:
@@ -224,21 +234,33 @@ class Shape:
             self._host = self.iq.cpu().numpy()
         return self._host
 
-    def oracle_check(self, threads, moving=False):
-        """ALL windows of the batch through the CPU oracle (oracle/lora_oracle.c, pinned to the reference): indices must be
-        identical; power / fIndex differences are reported"""
+    def oracle_check(self, threads, moving=False, limit=None):
+        """ALL windows of the batch (or the first `limit`) through the CPU oracle (oracle/lora_oracle.c, pinned to the reference):
+        indices must be identical; power / fIndex differences are reported"""
         import numpy as np
         from oracle.oracle import Oracle
         out = self.out_moving if moving else self.out
+        k = self.W if limit is None else min(self.W, int(limit))
         kw = {}
         if moving:
-            kw = dict(fine_err=self.fine_err.cpu().numpy(), fine_idx0=self.fine_idx0.cpu().numpy())
-        o = Oracle().detect_batch(self.sf, self.host_iq(), nthreads=threads, **kw)
-        gs = out["sym"].cpu().numpy().view(np.uint16)
+            kw = dict(fine_err=self.fine_err[:k].cpu().numpy(), fine_idx0=self.fine_idx0[:k].cpu().numpy())
+        iq = self.host_iq() if k == self.W else self.iq.reshape(-1)[:k * self.N].cpu().numpy()
+        o = Oracle().detect_batch(self.sf, iq, nthreads=threads, **kw)
+        gs = out["sym"][:k].cpu().numpy().view(np.uint16)
         fin = np.isfinite(o["power"])
-        return {"windows": int(self.W), "index_mismatches": int((o["sym"] != gs).sum()),
-                "max_dB": r4(float(np.abs(out["power"].cpu().numpy() - o["power"])[fin].max())),
-                "max_fIndex": r4(float(np.abs(out["fIndex"].cpu().numpy() - o["fIndex"]).max()))}
+        return {"windows": int(k), "index_mismatches": int((o["sym"] != gs).sum()),
+                "max_dB": r4(float(np.abs(out["power"][:k].cpu().numpy() - o["power"])[fin].max())),
+                "max_fIndex": r4(float(np.abs(out["fIndex"][:k].cpu().numpy() - o["fIndex"]).max()))}
+
+    def oracle_check_every_rank(self, limit=65536, moving=False):
+        """several ranks: EVERY rank holds a bounded sample of its own shard to the CPU oracle (its share of the host cores), the
+        counts are summed over the ranks -- beside rank 0's check of its whole batch"""
+        env = self.env
+        thr = max(1, min(32, (os.cpu_count() or 1) // env.world))
+        r = self.oracle_check(thr, moving=moving, limit=limit)
+        win, bad = env.sum_over_ranks(r["windows"], r["index_mismatches"])
+        (db,) = env.max_over_ranks(r["max_dB"])
+        return {"ranks": env.world, "windows": int(win), "index_mismatches": int(bad), "max_dB": r4(db), "threads_per_rank": thr}
 
     def close(self):
         self.ctx.close()
@@ -620,13 +642,14 @@ def section_level3(env, L, sf, threads=32):
            "from_host_ms": r4(from_host * 1e3), "from_host_GB_s": r4(iq.numel() * 8 / from_host / 1e9), "from_host_Msym_s": r4(calls / from_host / 1e6)}
     res["near_squelch"], res["near_step"] = near                       # decisions within float rounding of their boundary (pass 0)
     res["running"] = running
-    if env.rank == 0 and env.world == 1:
+    if env.rank == 0:                                       # (several ranks: rank 0's own B channels, the others wait on the host)
         res.update(level3_parity(L, sf, iq, host, nsyms, (ch_, rd_, ln_, sy_), data, n_pk - ok, threads))
-        if sf in (7, 10, 12):
+        if env.world == 1 and sf in (7, 10, 12):
             try:
                 res["pothos_block"] = pothos_block(sf, host, nsyms, calls, n_pk)
             except Exception as e:                  # beside the contract line: report, do not fail the bench
                 res["pothos_block"] = {"error": repr(e)[:160]}
+    env.host_barrier()
     del host
     d.close()
     ctx.close()
@@ -690,13 +713,15 @@ def section_config5(env, L, a, threads):
     ser, off = sh.ser_vs_sent()
     res = {"sf": 10, "channels": 8192, "symbols": 64, "snr_dB": -10, "Msym_s": r4(sh.W * a.steps * env.world / elapsed / 1e6),
            "frac": r4(sh.W * L.bytes_per_symbol(10) / (kernel_ms / 1e3 / a.steps) / 1e9 / HBM_PEAK_GBS), "ser_gpu": ser, "bin_offset": off}
-    if env.rank == 0 and env.world == 1:
+    if env.rank == 0:                                       # (several ranks: rank 0 checks its own 8192 x 64, the others wait on the host)
         from oracle.oracle import Oracle
         o = Oracle().detect_batch(10, sh.host_iq(), nthreads=threads)
         sent = sh.sym.cpu().numpy().view(np.uint16).astype(np.int64)
         res["ser_cpu"] = float(((o["sym"].astype(np.int64) - sent) % 1024 != off).mean())
         res["gpu_vs_cpu_index_mismatches"] = int((o["sym"] != sh.out["sym"].cpu().numpy().view(np.uint16)).sum())
         res["windows_checked"] = int(sh.W)
+    env.host_barrier()
+    (res["ser_gpu_max_over_ranks"],) = env.max_over_ranks(ser)
     sh.close()
     return res
 
@@ -926,7 +951,10 @@ def main():
     single = a.sf is not None or a.moving or a.alias_windows
     sweep = not single and not a.no_sweep and a.config == "default"
     rank0 = env.rank == 0
-    solo = rank0 and env.world == 1                     # CPU-side work (baseline, oracle) only here
+    # The CPU legs (the reference timed on the host cores, the oracle checks) run on RANK 0, on its own shard, after the timed regions,
+    # while the other ranks wait on the host (env.host_barrier): the line of a --gpus N run carries cpu_baseline and oracle like the
+    # N = 1 line. Only what needs the whole box to itself (the Pothos block, the PCIe-inclusive rates) stays a single-rank measurement.
+    solo = rank0 and env.world == 1
 
     if a.config == "mixed":
         m = section_mixed(env, L, a, rccl_single=True)
@@ -948,6 +976,8 @@ def main():
         sh.ctx.set_fine_gather(True)
     elapsed, kernel_ms = sh.measure(a.steps, a.warmup, a.ramp_seconds, moving=a.moving, alias=a.alias_windows)
     ser, off = sh.ser_vs_sent(sh.out_moving if a.moving else None) if not a.alias_windows else (None, None)
+    if ser is not None:
+        (ser,) = env.max_over_ranks(ser)                # every rank's recovered symbols against the ones it sent: the worst rank
     line = None
     threads = min(os.cpu_count() or 1, 64)
     if rank0:
@@ -966,7 +996,7 @@ def main():
         }
         if env.rccl_ranks is not None:
             line["rccl_ranks"] = env.rccl_ranks
-    if solo and not a.no_cpu_baseline:
+    if rank0 and not a.no_cpu_baseline:
         n_streams = min(B, 512)
         host = sh.host_iq()[:n_streams * S * sh.N]
         cb = cpu_baseline(sf0, host, S * sh.N, n_streams, a.cpu_seconds)
@@ -976,9 +1006,18 @@ def main():
         cb["other_flags"] = [x for x in (cpu_baseline(sf0, host, S * sh.N, n_streams, 2.0, f, probe=False) for f in ("-O3 -fcx-limited-range", "-O3")) if x]
         for x in cb["other_flags"]:
             x.pop("sample", None); x.pop("kind", None); x.pop("unit", None)
+        if env.world > 1:
+            cb["where"] = "rank 0, on its own shard's IQ, the other %d rank(s) idle at a host barrier" % (env.world - 1)
         line["cpu_baseline"] = cb
-    if solo and not a.alias_windows:
+    if rank0 and not a.alias_windows:
         line["oracle"] = sh.oracle_check(threads, moving=a.moving)
+        if env.world > 1:
+            line["oracle"]["where"] = "rank 0: every window of its own batch"
+    env.host_barrier()
+    if env.world > 1 and not a.alias_windows:
+        every = sh.oracle_check_every_rank(moving=a.moving)
+        if rank0:
+            line["oracle"]["every_rank_sample"] = every
     if solo and not single:
         # the same path fed from HOST buffers (lorahip_detect_batch_host: stage, H2D, launch, results D2H): the PCIe-inclusive
         # rate of SURVEY.md section 8d -- reported beside `value`, never as it
@@ -1040,7 +1079,7 @@ def main():
             e3, k3 = cur.measure(a.steps, a.warmup, 0.1, moving=True)
             mv = {"sf": sf, "Msym_s": r4(cur.W * a.steps * env.world / e3 / 1e6), "launch_us": r4(k3 * 1e3 / a.steps),
                   "frac": r4(cur.W * L.bytes_per_symbol(sf) / (k3 / 1e3 / a.steps) / 1e9 / HBM_PEAK_GBS)}
-            if solo:
+            if rank0:
                 if sf != sf0:
                     ent["oracle"] = cur.oracle_check(threads)
                     if not a.no_cpu_baseline:
@@ -1053,6 +1092,7 @@ def main():
                         ent["cpu_baseline"] = {k: line["cpu_baseline"][k] for k in ("value", "cores", "per_core")}
                         ent["cpu_baseline"]["flags"] = "-O2"
                 mv["oracle"] = cur.oracle_check(threads, moving=True)
+            env.host_barrier()
             per_sf.append(ent)
             moving.append(mv)
             if cur is not sh:

@@ -268,6 +268,13 @@ int lorahip_demod_set_mode(lorahip_demod *d, int mode);
 /* Launch on an existing hipStream_t from now on (same meaning as lorahip_set_stream): work queued on that stream before a
  * run -- a channeliser, a modulator, a copy -- is ordered before the run's kernels. A run returns with the stream drained. */
 int lorahip_demod_set_stream(lorahip_demod *d, void *hip_stream);
+/* Make `hip_stream` (a hipStream_t of the object's device; NULL = the null stream) wait for everything queued so far on the object's
+ * launch stream: the way a consumer on a stream of its own reads rows that are "valid in stream order on the launch stream"
+ * (lorahip_demod_receive with async = 1 or 2). Costs an event record and a stream wait; allowed while a pipelined step is in flight. */
+int lorahip_demod_stream_wait(lorahip_demod *d, void *hip_stream);
+/* The other direction: the object's launch stream waits for everything queued so far on `hip_stream` -- the producer of the samples,
+ * or a consumer of rows that the next pipelined step will overwrite -- without a host wait. */
+int lorahip_demod_stream_follow(lorahip_demod *d, void *hip_stream);
 int lorahip_demod_reset_stream(lorahip_demod *d);    /* back to the private stream */
 /* kernel variant of the host-driven mode's batch launches (lorahip_set_variant: 0, 1, 10 -- identical results); LORAHIP_VARIANT_FMA
  * is refused (LORAHIP_E_INVALID): level 3 runs the reference's operation graph only */
@@ -277,6 +284,10 @@ int lorahip_demod_set_variant(lorahip_demod *d, int variant);
  * channel set always, n > 0 = at most n workgroups each walking several sets -- honoured where the build holds such an instance
  * (SF11 and SF12), the default elsewhere. For measurements and tests. */
 int lorahip_demod_set_stream_grid(lorahip_demod *d, int max_workgroups);
+/* A bound on the streaming kernels' per-launch record capacity (work() calls per channel per launch; 0 = none beyond the library's
+ * own sizing). A channel that fills its records stops, and the run resumes it with another launch: results are the same. For tests
+ * of that path (it replaces the environment hook LORAHIP_STREAM_CAP of earlier builds). */
+int lorahip_demod_set_record_capacity(lorahip_demod *d, size_t max_calls_per_launch);
 /* same switch as lorahip_set_fine_gather, for the demodulator's kernels */
 int lorahip_demod_set_fine_gather(lorahip_demod *d, int enable);
 
@@ -341,8 +352,18 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * the running kernel; the launch stream waits for that before anything later); lorahip_demod_receive_flush() delivers the last
  * step's and leaves the pipeline. The first call after anything else touched
  * the object is an ordinary step (its packets delivered at once). While a step is in flight every other entry point that needs the
- * object's state returns LORAHIP_E_INVALID ("flush first"); no trace / ports / signals in this mode; a step whose packets do not fit
- * the rows loses them (LORAHIP_E_INVALID) -- size the rows for a step. */
+ * object's state returns LORAHIP_E_INVALID ("flush first"); no trace / ports / signals in this mode.
+ * Rows that cannot hold the packets that are due (cap_packets too small, null pointers) lose NOTHING: the call returns
+ * LORAHIP_E_INVALID with *n_packets = the rows needed, the packets stay in the step's record set on the device, and the next
+ * lorahip_demod_receive / _flush whose rows hold them delivers them first, together with the packets of the step launched in
+ * between (*n_packets and *work_calls then cover both steps; until then no further kernel is launched -- the samples wait in the
+ * caller's array, a later call covers them). As with async = 0/1 a packet longer than sym_stride keeps its true length in
+ * nsyms_dev and its first sym_stride symbols (the decoder flags it): sym_stride >= the MTU never truncates.
+ * Ordering of the rows: a step's packets are written in stream order AFTER everything that was queued on the launch stream when
+ * the call began, so a consumer (decoder) of the rows handed out by the call before, queued on that stream (or on a stream the
+ * launch stream was told to follow before the call, lorahip_demod_stream_follow), has read them before they are overwritten -- one
+ * set of rows is enough. lorahip_demod_receive_flush also resumes a channel whose record capacity the
+ * last step filled (that step's remaining packets follow the others in the rows). */
 typedef struct lorahip_packet_rows {
     size_t struct_size;     /* = sizeof(lorahip_packet_rows) */
     uint16_t *syms_dev; size_t sym_stride;      /* [cap_packets][sym_stride], zero padded */

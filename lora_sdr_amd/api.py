@@ -611,6 +611,11 @@ class LoRaDemod:
         always, n > 0 at most n workgroups each walking several channels (SF11 / SF12)"""
         check(self._lib.lorahip_demod_set_stream_grid(self._h, int(max_workgroups)), "lorahip_demod_set_stream_grid")
 
+    def set_record_capacity(self, max_calls_per_launch):
+        """bound the streaming kernels' per-launch record capacity (0: the library's own sizing): a channel that fills it is resumed by
+        another launch, results unchanged -- the tests of the resume path"""
+        check(self._lib.lorahip_demod_set_record_capacity(self._h, int(max_calls_per_launch)), "lorahip_demod_set_record_capacity")
+
     def set_trace(self, on=True):
         check(self._lib.lorahip_demod_set_trace(self._h, int(bool(on))), "lorahip_demod_set_trace")
 
@@ -713,13 +718,23 @@ class LoRaDemod:
         `rows` (receiver_rows()) on the device, the queue cleared. Returns (n_packets, work_calls). async_: False = wait; True = the
         rows are valid in the order of the stream the object launches on; 2 = PIPELINED: the step is launched and the packets of
         the previous step are returned (receive_flush() delivers the last step's). A pipelined receiver keeps its private stream
-        (the steps must stay in flight across calls): whatever produced `buf` on torch's stream is waited for first."""
+        (the steps must stay in flight across calls), ordered against torch's current stream on the device, without a host wait:
+        the launch stream follows what torch's stream holds at entry (whatever produced `buf`, whatever still reads the rows of the
+        call before: lorahip_demod_stream_follow), and torch's stream waits for the packing of the rows at exit
+        (lorahip_demod_stream_wait) -- work queued on it after this call sees the rows."""
         import torch
         r = self._rows_struct(rows, 2 if async_ == 2 else int(bool(async_)))
         n, calls = C.c_size_t(), C.c_int64()
         if async_ == 2:
-            torch.cuda.current_stream(buf.device).synchronize()
-            check(self._lib.lorahip_demod_receive(self._h, _dptr(buf), int(buf.shape[1]), int(n_valid), C.byref(r), C.byref(n), C.byref(calls)), "lorahip_demod_receive")
+            ts = C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)
+            check(self._lib.lorahip_demod_stream_follow(self._h, ts), "lorahip_demod_stream_follow")
+            try:
+                check(self._lib.lorahip_demod_receive(self._h, _dptr(buf), int(buf.shape[1]), int(n_valid), C.byref(r), C.byref(n), C.byref(calls)), "lorahip_demod_receive")
+            except Exception as e:
+                e.n_packets = n.value                       # LORAHIP_E_INVALID with rows that are too small: the rows needed (nothing is lost)
+                raise
+            finally:
+                self._lib.lorahip_demod_stream_wait(self._h, ts)
             return n.value, calls.value
         check(self._lib.lorahip_demod_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)), "lorahip_demod_set_stream")
         try:
@@ -733,7 +748,15 @@ class LoRaDemod:
         with the launch stream drained"""
         n, calls = C.c_size_t(), C.c_int64()
         r = self._rows_struct(rows, 0) if rows is not None else None
-        check(self._lib.lorahip_demod_receive_flush(self._h, C.byref(r) if r is not None else None, C.byref(n), C.byref(calls)), "lorahip_demod_receive_flush")
+        if rows is not None:
+            import torch
+            # (whatever on torch's stream still reads the rows of the call before is ordered before this call's packing)
+            check(self._lib.lorahip_demod_stream_follow(self._h, C.c_void_p(torch.cuda.current_stream(rows[0].device).cuda_stream)), "lorahip_demod_stream_follow")
+        try:
+            check(self._lib.lorahip_demod_receive_flush(self._h, C.byref(r) if r is not None else None, C.byref(n), C.byref(calls)), "lorahip_demod_receive_flush")
+        except Exception as e:
+            e.n_packets = n.value
+            raise
         return n.value, calls.value
 
     def work(self, streams):

@@ -66,6 +66,7 @@ struct Signal
 struct lorahip_demod
 {
     int streamGrid;                  // lorahip_demod_set_stream_grid: 0 default, < 0 one workgroup per channel set, > 0 at most that many workgroups
+    size_t streamCapMax;             // lorahip_demod_set_record_capacity: 0 = no bound beyond the library's own
     lorahip::Composite *comp;        // non-null: the handle is a container of (device, SF) parts (lorahip_rx.cpp); nothing below is used then
     lorahip_ctx *ctx;
     size_t N, B;
@@ -88,6 +89,7 @@ struct lorahip_demod
     char *sDev, *sHost; size_t sBytes;
     char *dDense, *hDense; size_t denseBytes;   // the used part of the record arrays, packed for the copy back
     hipEvent_t evK0, evK1;           // around the streaming kernel launches of a run (lorahip_demod_kernel_ms)
+    hipEvent_t evJoin;               // lorahip_demod_stream_wait
     double kernelMs;
     int lastLaunches;                // streaming kernel launches of the last run
     lorahip_demod_ports ports;       // level-3 debug ports (all pointers null: off); DEVICE pointers (the library's own when the caller's are host buffers)
@@ -693,8 +695,8 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     const size_t capMem = (size_t(1) << 30) / (B * perCall);
     if (cap > capMem) cap = capMem;
     if (cap < 8) cap = 8;
-    // test hook: a small per-launch record capacity forces the resume path (several launches per run)
-    if (const char *e = std::getenv("LORAHIP_STREAM_CAP")) { const long v = std::atol(e); if (v >= 1) cap = size_t(v); }
+    // lorahip_demod_set_record_capacity: a bound on the per-launch record capacity (tests force the resume path with it)
+    if (dm->streamCapMax != 0 && cap > dm->streamCapMax) cap = dm->streamCapMax;
     const size_t capPkt = cap / 4 + 2;               // a packet costs at least 5 calls (3 sync, quarter, 1 symbol)
 
     // open packets on the device (dCarry): rows of mtu + 1 symbols; receivers with longer packets than this keep the host path
@@ -974,9 +976,14 @@ struct Pipe
     StreamLayout lay[2];
     StreamSummary *hSum;            // [2] pinned and mapped: the summary kernel writes here directly (no copy to enqueue)
     hipEvent_t ev[2];
-    bool pending[2];
+    bool pending[2];                // the set's kernel has been launched, its summary not read yet
+    bool held[2];                   // the set's summary has been read, its packets are still in the set (rows too small: nothing is lost)
+    size_t nPk[2]; int64_t nCalls[2];   // ... what that summary said
     hipStream_t side;               // step k's packets are packed HERE while step k + 1's kernel runs on the launch stream
     hipEvent_t packDone;            // ... which waits for this before anything later (the next kernel reuses the record set, the caller reads the rows)
+    hipEvent_t entry;               // ... and the side stream for this: where the launch stream stood when the call began (the caller's
+                                    // consumer of the rows handed out by the call before, earlier packing on the launch stream)
+    const float *iq; size_t rowStride;  // the rows the steps read (a flush that has to resume a full channel continues on them)
 };
 static Pipe &pipeOf(lorahip_demod *dm) { return *static_cast<Pipe *>(dm->pipe); }
 static bool pipeBusy(const lorahip_demod *dm) { return dm->pipe != nullptr && static_cast<const Pipe *>(dm->pipe)->active; }
@@ -990,14 +997,14 @@ static void streamCapacity(const lorahip_demod *dm, const size_t maxLen, size_t 
     const size_t capMem = (size_t(1) << 30) / (dm->B * perCall);
     if (cap > capMem) cap = capMem;
     if (cap < 8) cap = 8;
+    if (dm->streamCapMax != 0 && cap > dm->streamCapMax) cap = dm->streamCapMax;      // lorahip_demod_set_record_capacity (tests: resumed launches)
     capPkt = cap / 4 + 2;
 }
 
-//! what summary `set` says, into the object's books; packs that step's packets into `rows` (stream-ordered; no wait)
-static int pipeDeliver(lorahip_demod *dm, const int set, const lorahip_packet_rows *rows, size_t *nPackets, int64_t *calls, const bool beside = false)
+//! summary of record set `set` into the object's books (waits for that step's kernel); its packets stay in the set until packed
+static int pipeRead(lorahip_demod *dm, const int set)
 {
     Pipe &P = pipeOf(dm);
-    lorahip_ctx *ctx = dm->ctx;
     LORAHIP_TRY(hipEventSynchronize(P.ev[set]));
     P.pending[set] = false;
     const StreamSummary sum = P.hSum[set];
@@ -1006,29 +1013,42 @@ static int pipeDeliver(lorahip_demod *dm, const int set, const lorahip_packet_ro
     dm->nearSeen[0] = sum.nearSquelch; dm->nearSeen[1] = sum.nearStep;
     dm->workCalls += sum.calls;
     dm->lastSum = sum;
-    if (calls) *calls = sum.calls;
-    const size_t n = size_t(sum.packets);
-    if (nPackets) *nPackets = n;
+    P.nPk[set] = size_t(sum.packets);
+    P.nCalls[set] = sum.calls;
+    P.held[set] = true;
+    return LORAHIP_OK;
+}
+
+static bool rowsHold(const lorahip_packet_rows *rows, const size_t n)
+{
+    return n == 0 || (rows != nullptr && rows->syms_dev != nullptr && rows->nsyms_dev != nullptr && rows->sym_stride != 0 && rows->sym_stride <= 0x7fffffffu &&
+                      rows->cap_packets >= n);
+}
+
+//! the packets held in record set `set` into `rows` from row `firstRow` on (stream-ordered; no wait); the set is free afterwards
+static int pipePack(lorahip_demod *dm, const int set, const lorahip_packet_rows *rows, const size_t firstRow, const bool beside)
+{
+    Pipe &P = pipeOf(dm);
+    lorahip_ctx *ctx = dm->ctx;
+    const size_t n = P.nPk[set];
+    P.held[set] = false;
     if (n == 0) return LORAHIP_OK;
-    if (rows->syms_dev == nullptr || rows->nsyms_dev == nullptr || rows->sym_stride == 0 || rows->sym_stride > 0x7fffffffu || rows->cap_packets < n)
-    {
-        setLastError("lorahip_demod_receive (pipelined): the rows cannot hold the step's packets (they are lost: the pipeline does not keep a host queue)");
-        return LORAHIP_E_INVALID;
-    }
     const StreamLayout &L = P.lay[set];
     const size_t nbRow = align256(L.B * sizeof(int));
     { const int grc = growDense(dm, nbRow + n * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
     char *d = P.dev[set];
     // `beside`: packed on the side stream WHILE the step just launched runs (the host has just waited for this step's summary: its
-    // kernel is complete, no device-side dependency is needed); the launch stream then waits for the packing before anything later --
-    // the next kernel reuses this record set, the caller reads the rows. Worth it for short steps only (profiles/r04/s37_*: 8-window
-    // chunks at SF7 +14 %; at 128-window chunks the packing kernels displace workgroups of a streaming grid that exactly fills the
-    // device, -5 %).
+    // kernel is complete). The side stream first waits for where the launch stream stood when this call began -- whatever the caller
+    // queued there to read the rows of the call before (a decoder) and any earlier packing, which shares the scratch -- and the launch
+    // stream then waits for the packing before anything later: the next kernel reuses this record set, the caller reads the rows.
+    // Worth it for short steps only (profiles/r04/s37_*: 8-window chunks at SF7 +14 %; at 128-window chunks the packing kernels
+    // displace workgroups of a streaming grid that exactly fills the device, -5 %).
     hipStream_t packStream = beside ? P.side : ctx->stream;
+    if (beside) LORAHIP_TRY(hipStreamWaitEvent(P.side, P.entry, 0));
     LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(d + L.oPkt), reinterpret_cast<const int *>(d + L.oNPkt),
                                   reinterpret_cast<const short *>(d + L.oSym), reinterpret_cast<int *>(dm->dDense), L.B, int(L.symStride), int(L.capPkt), n,
-                                  reinterpret_cast<long long *>(dm->dDense + nbRow), rows->syms_dev, int(rows->sym_stride), rows->nsyms_dev, rows->channel_dev,
-                                  packStream));
+                                  reinterpret_cast<long long *>(dm->dDense + nbRow), rows->syms_dev + firstRow * rows->sym_stride, int(rows->sym_stride),
+                                  rows->nsyms_dev + firstRow, rows->channel_dev ? rows->channel_dev + firstRow : nullptr, packStream));
     if (beside)
     {
         LORAHIP_TRY(hipEventRecord(P.packDone, P.side));
@@ -1037,7 +1057,37 @@ static int pipeDeliver(lorahip_demod *dm, const int set, const lorahip_packet_ro
     return LORAHIP_OK;
 }
 
-//! leave the pipeline: the last step's packets into `rows` (nullable: they are dropped), the object back in the state a streaming run leaves
+/*! Every step whose summary can be read (oldest first) into `rows`, or -- if they do not all fit -- NONE of them: *nPackets = the
+ * rows needed, LORAHIP_E_INVALID, the packets stay in their record sets and the next call (with rows that hold them) delivers
+ * them. `upTo`: number of record sets to consider, oldest first (1: only the older one). */
+static int pipeDeliverHeld(lorahip_demod *dm, const int older, const int sets, const lorahip_packet_rows *rows, size_t *nPackets, int64_t *calls, const bool beside)
+{
+    Pipe &P = pipeOf(dm);
+    size_t need = 0;
+    for (int i = 0; i < sets; i++) if (P.held[older ^ i]) need += P.nPk[older ^ i];
+    if (nPackets) *nPackets = need;
+    if (!rowsHold(rows, need))
+    {
+        setLastError("lorahip_demod_receive (pipelined): the rows cannot hold the packets that are due; they are kept -- call again with rows for *n_packets");
+        return LORAHIP_E_INVALID;
+    }
+    size_t at = 0;
+    int64_t c = 0;
+    for (int i = 0; i < sets; i++)
+    {
+        const int set = older ^ i;
+        if (!P.held[set]) continue;
+        c += P.nCalls[set];
+        const size_t n = P.nPk[set];
+        const int rc = pipePack(dm, set, rows, at, beside);
+        if (rc != LORAHIP_OK) return rc;
+        at += n;
+    }
+    if (calls) *calls = c;
+    return LORAHIP_OK;
+}
+
+//! leave the pipeline: the packets not delivered yet into `rows` (nullable: they are dropped), the object back in the state a streaming run leaves
 static int pipeFlush(lorahip_demod *dm, const lorahip_packet_rows *rows, size_t *nPackets, int64_t *calls)
 {
     Pipe &P = pipeOf(dm);
@@ -1045,15 +1095,20 @@ static int pipeFlush(lorahip_demod *dm, const lorahip_packet_rows *rows, size_t 
     if (calls) *calls = 0;
     if (!P.active) return LORAHIP_OK;
     const DeviceGuard guard(dm->ctx->device);
-    int rc = LORAHIP_OK;
     const int last = int((P.k - 1) & 1);
-    if (P.k > 0 && P.pending[last])
+    for (int i = 1; i >= 0; i--)                      // oldest first: the books follow the steps in order
+        if (P.k > 0 && P.pending[last ^ i]) { const int rc = pipeRead(dm, last ^ i); if (rc != LORAHIP_OK) return rc; }
+    size_t n1 = 0;
+    int64_t c1 = 0;
+    if (rows == nullptr) P.held[0] = P.held[1] = false;                       // dropped on request
+    else
     {
-        lorahip_packet_rows none;
-        std::memset(&none, 0, sizeof(none));
-        rc = pipeDeliver(dm, last, rows ? rows : &none, nPackets, calls);
-        if (rows == nullptr && rc == LORAHIP_E_INVALID) rc = LORAHIP_OK;      // dropped on request
+        LORAHIP_TRY(hipEventRecord(P.entry, dm->ctx->stream));
+        const int rc = pipeDeliverHeld(dm, last ^ 1, 2, rows, &n1, &c1, false);
+        if (nPackets) *nPackets = n1;
+        if (rc != LORAHIP_OK) return rc;              // (the pipeline stays entered: flush again with rows that hold *n_packets)
     }
+    if (calls) *calls = c1;
     LORAHIP_TRY(hipStreamSynchronize(dm->ctx->stream));
     P.active = false;
     dm->kernelMs = 0.0;                               // (the pipelined steps are not timed one by one: an event pair per step is two more calls)
@@ -1061,7 +1116,7 @@ static int pipeFlush(lorahip_demod *dm, const lorahip_packet_rows *rows, size_t 
     dm->devStateFresh = true; dm->posOnDevice = true; dm->mirrorsStale = true; dm->headStale = true;
     dm->devCarryValid = true; dm->hostCarryStale = true;
     pendingOf(dm).valid = false;
-    return rc;
+    return LORAHIP_OK;
 }
 
 static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStride, const size_t nValid, const lorahip_packet_rows *rows, size_t *nPackets,
@@ -1089,12 +1144,28 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
             LORAHIP_TRY(hipHostMalloc((void **)&P.hSum, 2 * sizeof(StreamSummary), hipHostMallocMapped));
             for (int i = 0; i < 2; i++) LORAHIP_TRY(hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming));
             LORAHIP_TRY(hipEventCreateWithFlags(&P.packDone, hipEventDisableTiming));
+            LORAHIP_TRY(hipEventCreateWithFlags(&P.entry, hipEventDisableTiming));
             LORAHIP_TRY(hipStreamCreateWithFlags(&P.side, hipStreamNonBlocking));
         }
-        P.active = true; P.k = 0; P.pending[0] = P.pending[1] = false;
+        P.active = true; P.k = 0; P.pending[0] = P.pending[1] = false; P.held[0] = P.held[1] = false;
         dm->devStateFresh = false;                    // until the pipeline is flushed, only it knows where the state stands
     }
     const int set = int(P.k & 1);
+    if (nPackets) *nPackets = 0;
+    if (calls) *calls = 0;
+    // where the launch stream stands now: behind whatever the caller queued to read the rows of the call before (pipePack)
+    LORAHIP_TRY(hipEventRecord(P.entry, ctx->stream));
+    bool delivered = false;
+    if (P.held[set])
+    {
+        // The call before could not hand over the packets of the step in THIS record set (rows too small), and the kernel about to be
+        // launched would overwrite them: they are due now, together with the packets of the step launched since -- or nothing is
+        // launched and nothing is lost (the caller comes back with rows for *n_packets; the samples wait in its array).
+        if (P.pending[set ^ 1]) { const int rc = pipeRead(dm, set ^ 1); if (rc != LORAHIP_OK) return rc; }
+        const int rc = pipeDeliverHeld(dm, set, 2, rows, nPackets, calls, false);
+        if (rc != LORAHIP_OK) return rc;
+        delivered = true;
+    }
     const size_t prevValid = dm->appendPrev;
     size_t cap, capPkt;
     streamCapacity(dm, nValid - dm->appendPrev + 2 * N, cap, capPkt);
@@ -1135,14 +1206,14 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     LORAHIP_TRY(hipEventRecord(P.ev[set], ctx->stream));
     P.pending[set] = true;
     P.k++;
+    P.iq = iqDev; P.rowStride = rowStride;
     dm->uniform = true; dm->uniSpc = nValid; dm->uniStride = rowStride; dm->appendPrev = nValid; dm->geomApplied = false;
     dm->mirrorsStale = true; dm->headStale = true;
     // ... and while it runs: the step before
-    if (nPackets) *nPackets = 0;
-    if (calls) *calls = 0;
+    if (delivered || P.k < 2 || !P.pending[set ^ 1]) return LORAHIP_OK;
+    { const int rc = pipeRead(dm, set ^ 1); if (rc != LORAHIP_OK) return rc; }
     const bool shortStep = (nValid - prevValid) <= 48 * N;    // (the step launched above)
-    if (P.k >= 2 && P.pending[set ^ 1]) return pipeDeliver(dm, set ^ 1, rows, nPackets, calls, shortStep);
-    return LORAHIP_OK;
+    return pipeDeliverHeld(dm, set ^ 1, 1, rows, nPackets, calls, shortStep);
 }
 
 /***********************************************************************
@@ -1337,7 +1408,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     if (dm == nullptr) return LORAHIP_E_NOMEM;
     dm->comp = nullptr;
     dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
-    dm->evK0 = nullptr; dm->evK1 = nullptr; dm->kernelMs = 0.0;
+    dm->evK0 = nullptr; dm->evK1 = nullptr; dm->evJoin = nullptr; dm->kernelMs = 0.0;
     dm->pending = new (std::nothrow) PendingLaunch();
     dm->pipe = new (std::nothrow) Pipe();
     if (dm->pending == nullptr || dm->pipe == nullptr) { delete static_cast<PendingLaunch *>(dm->pending); delete static_cast<Pipe *>(dm->pipe); delete dm; return LORAHIP_E_NOMEM; }
@@ -1360,6 +1431,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     std::memset(&dm->lastSum, 0, sizeof(dm->lastSum));
     dm->wantSignals = false;
     dm->streamGrid = 0;
+    dm->streamCapMax = 0;
     dm->lastLaunches = 0;
     dm->dCarry = nullptr; dm->carryCap = 0; dm->devCarryValid = false; dm->hostCarryStale = false;
     dm->callsPerWindowQ8 = 288;                                 // 1.125 calls per N samples to begin with
@@ -1449,6 +1521,7 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->ownRaw) (void)hipFree(dm->ownRaw);
     if (dm->evK0) (void)hipEventDestroy(dm->evK0);
     if (dm->evK1) (void)hipEventDestroy(dm->evK1);
+    if (dm->evJoin) (void)hipEventDestroy(dm->evJoin);
     if (dm->pipe)
     {
         Pipe &P = pipeOf(dm);
@@ -1459,6 +1532,7 @@ void lorahip_demod_destroy(lorahip_demod *dm)
         }
         if (P.side) { (void)hipStreamSynchronize(P.side); (void)hipStreamDestroy(P.side); }
         if (P.packDone) (void)hipEventDestroy(P.packDone);
+        if (P.entry) (void)hipEventDestroy(P.entry);
         if (P.hSum) (void)hipHostFree(P.hSum);
     }
     }
@@ -1501,18 +1575,47 @@ int lorahip_demod_set_mode(lorahip_demod *dm, const int mode)
 }
 
 // (A streaming run leaves nothing in flight: the open packets' symbols are saved by the streaming kernel itself and the run ends with
-// its stream drained, so moving the object to another stream needs no ordering.)
+// its stream drained, so moving the object to another stream needs no ordering. A PIPELINED step is in flight by design: refused.)
 int lorahip_demod_set_stream(lorahip_demod *dm, void *hip_stream)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) return dm->comp->setStream(hip_stream);
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }     // the step in flight is ordered on the stream it was launched on
     return lorahip_set_stream(dm->ctx, hip_stream);
+}
+
+// What has been queued on the object's launch stream so far -- packing kernels of an async receive, a pipelined step -- before
+// anything queued on `hip_stream` from now on. Allowed while a pipelined step is in flight (it is how a consumer on another stream
+// reads that mode's rows).
+int lorahip_demod_stream_wait(lorahip_demod *dm, void *hip_stream)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->streamWait(hip_stream);
+    const DeviceGuard guard(dm->ctx->device);
+    if (dm->evJoin == nullptr) LORAHIP_TRY(hipEventCreateWithFlags(&dm->evJoin, hipEventDisableTiming));
+    LORAHIP_TRY(hipEventRecord(dm->evJoin, dm->ctx->stream));
+    LORAHIP_TRY(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), dm->evJoin, 0));
+    return LORAHIP_OK;
+}
+
+// ... and the other direction: the launch stream behind what `hip_stream` holds now (the producer of the samples, the consumer of rows
+// that the next step will overwrite), without a host wait.
+int lorahip_demod_stream_follow(lorahip_demod *dm, void *hip_stream)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) return dm->comp->streamFollow(hip_stream);
+    const DeviceGuard guard(dm->ctx->device);
+    if (dm->evJoin == nullptr) LORAHIP_TRY(hipEventCreateWithFlags(&dm->evJoin, hipEventDisableTiming));
+    LORAHIP_TRY(hipEventRecord(dm->evJoin, reinterpret_cast<hipStream_t>(hip_stream)));
+    LORAHIP_TRY(hipStreamWaitEvent(dm->ctx->stream, dm->evJoin, 0));
+    return LORAHIP_OK;
 }
 
 int lorahip_demod_reset_stream(lorahip_demod *dm)
 {
     if (dm == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) return dm->comp->resetStream();
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
     return lorahip_reset_stream(dm->ctx);
 }
 
@@ -1539,6 +1642,19 @@ int lorahip_demod_set_stream_grid(lorahip_demod *dm, const int max_workgroups)
     }
     { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
     dm->streamGrid = max_workgroups;
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_set_record_capacity(lorahip_demod *dm, const size_t max_calls_per_launch)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp)
+    {
+        for (size_t i = 0; i < dm->comp->numParts(); i++) { const int rc = lorahip_demod_set_record_capacity(dm->comp->part(i), max_calls_per_launch); if (rc != LORAHIP_OK) return rc; }
+        return LORAHIP_OK;
+    }
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
+    dm->streamCapMax = max_calls_per_launch;
     return LORAHIP_OK;
 }
 
@@ -1839,7 +1955,30 @@ int lorahip_demod_receive_flush(lorahip_demod *dm, const lorahip_packet_rows *ro
     if (n_packets) *n_packets = 0;
     if (work_calls) *work_calls = 0;
     if (dm->comp) return LORAHIP_OK;
-    return pipeFlush(dm, rows, n_packets, work_calls);
+    const bool wasPiped = pipeBusy(dm);
+    size_t n1 = 0;
+    int64_t c1 = 0;
+    int rc = pipeFlush(dm, rows, &n1, &c1);
+    if (n_packets) *n_packets = n1;
+    if (work_calls) *work_calls = c1;
+    if (rc != LORAHIP_OK || !wasPiped || dm->lastSum.more == 0) return rc;
+    // The LAST step filled a channel's record or packet capacity: that channel still holds >= 2N samples nobody would look at again.
+    // An ordinary step over the same rows resumes it until dry (the pipeline is left: this is lorahip_demod_receive's own path), its
+    // packets behind the ones above. If THEY do not fit they stay queued like any ordinary step's (LORAHIP_E_INVALID, *n_packets =
+    // all rows needed; the first rows are filled; lorahip_demod_packets_to_device / the next receive delivers the rest).
+    const Pipe &P = pipeOf(dm);
+    const int64_t calls0 = dm->workCalls;
+    rc = lorahip_demod_run_device_append(dm, P.iq, P.rowStride, dm->appendPrev, nullptr);
+    if (rc != LORAHIP_OK) return rc;
+    if (work_calls) *work_calls = c1 + (dm->workCalls - calls0);
+    if (rows == nullptr) { lorahip_demod_clear_packets(dm); return LORAHIP_OK; }
+    size_t n2 = 0;
+    rc = packetsToDevice(dm, rows->syms_dev ? rows->syms_dev + n1 * rows->sym_stride : nullptr, rows->sym_stride, rows->nsyms_dev ? rows->nsyms_dev + n1 : nullptr,
+                         rows->channel_dev ? rows->channel_dev + n1 : nullptr, rows->cap_packets - n1, &n2, true);
+    if (n_packets) *n_packets = n1 + n2;
+    if (rc != LORAHIP_OK) return rc;
+    lorahip_demod_clear_packets(dm);
+    return LORAHIP_OK;
 }
 
 int lorahip_demod_set_signals(lorahip_demod *dm, const int enable)
@@ -1924,7 +2063,18 @@ int lorahip_demod_consumed_all(const lorahip_demod *dm, int64_t *out)
 {
     if (dm == nullptr || out == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) return dm->comp->consumedAll(out);
-    for (size_t c = 0; c < dm->B; c++) out[c] = lorahip_demod_consumed(dm, c);
+    // the one read that can fail -- the per-channel state back from the device -- up front: an error is the call's, not a negative
+    // entry a caller would take for "nothing consumed"
+    if (dm->mirrorsStale && dm->posOnDevice && dm->sHost)
+    {
+        const int rc = ensureHead(const_cast<lorahip_demod *>(dm));
+        if (rc != LORAHIP_OK) return rc;
+    }
+    for (size_t c = 0; c < dm->B; c++)
+    {
+        out[c] = lorahip_demod_consumed(dm, c);
+        if (out[c] < 0) return int(out[c]);
+    }
     return LORAHIP_OK;
 }
 

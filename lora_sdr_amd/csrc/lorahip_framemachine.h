@@ -38,14 +38,19 @@ struct StreamOut
     }
     //! ... and a channel that ends the launch inside a packet leaves the packet's symbols -- the last symCount entries of its row,
     //! written by the writer lane -- in the carry rows (flag bit 3).
-    __device__ __forceinline__ void carryOut(const StreamArgs &s, const StreamState &st, const unsigned channel, const int t, const int T, const bool mine = true)
+    //! `acrossWaves`: the channel's lanes span several wavefronts (demodStreamWide): the other wavefronts must not load before the
+    //! writer's wavefront has waited for its stores -- a workgroup barrier between the two (every thread of the workgroup calls this,
+    //! the flags and the loop exit are workgroup-uniform).
+    __device__ __forceinline__ void carryOut(const StreamArgs &s, const StreamState &st, const unsigned channel, const int t, const int T, const bool mine = true,
+                                             const bool acrossWaves = false)
     {
         if (!(s.flags & 8)) return;                                 // uniform over the launch
-        // The writer lane's stores have to be seen by its neighbours' loads. They are lanes of ONE wavefront (or workgroup: the caller's
-        // barrier), whose memory operations go through one L1 in order: a wavefront-scope fence -- the wait for the stores -- orders
-        // them, and the loads are made at agent scope (they read L2, where the stores have landed), so no stale L1 line can be hit.
+        // The writer lane's stores have to be seen by its neighbours' loads. They are lanes of ONE wavefront, whose memory operations
+        // go through one L1 in order: a fence -- the wait for the stores -- orders them, and the loads are made at agent scope (they
+        // read L2, where the stores have landed), so no stale L1 line can be hit.
         // An agent-scope FENCE would do too, but it writes the whole L2 back (buffer_wbl2): 90 us per launch at 2048 wavefronts.
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (acrossWaves) __syncthreads();                           // ... and the writer's wavefront has got here: its last symbol is in L2
         if (!mine || st.state != ST_DATASYMBOLS) return;
         int k = st.symCount < nSym ? st.symCount : nSym;
         k = k < s.carryCap ? k : s.carryCap;

@@ -280,7 +280,7 @@ public:
     int partOf(int32_t *part, int32_t *local) const;
     lorahip_demod *part(size_t i) const;
     int setSync(unsigned char v); int setThreshold(double v); int setMtu(size_t v); int setMode(int v); int setFineGather(int v);
-    int setTrace(int v); int setSignals(int v); int activate(); int setStream(void *stream); int resetStream();
+    int setTrace(int v); int setSignals(int v); int activate(); int setStream(void *stream); int resetStream(); int streamWait(void *stream); int streamFollow(void *stream);
     int run(const float *const *streams, const size_t *nSamples, int64_t *rounds);
     int runSegments(const float *const *iqPerDevice, size_t nDev, const int64_t *first, const size_t *nSamples, int64_t *rounds);
     size_t numPackets() const; size_t numPacketSymbols() const; size_t numSignals() const;

@@ -137,10 +137,13 @@ int Composite::create(Composite **out, const int *devices, const size_t nDev, co
                 part.device = devices[s]; part.deviceSlot = int(s); part.sf = sf;
                 for (size_t c = 0; c < n; c++) if (size_t(shard[c]) == s && channelSf[c] == sf) part.chan.push_back(uint32_t(c));
                 if (part.chan.empty()) continue;
-                const int rc = lorahip_demod_create(&part.d, part.device, sf, part.chan.size());
-                if (rc != LORAHIP_OK) { const std::string e = lorahip_last_error(); delete k; setLastError(e); return rc; }
-                for (size_t j = 0; j < part.chan.size(); j++) { I.partOf[part.chan[j]] = uint32_t(I.parts.size()); I.localOf[part.chan[j]] = uint32_t(j); }
+                // the slot first, the object into it: a part that exists is always owned by Impl (whose destructor destroys it),
+                // whatever throws afterwards
                 I.parts.push_back(std::move(part));
+                Impl::Part &slot = I.parts.back();
+                const int rc = lorahip_demod_create(&slot.d, slot.device, sf, slot.chan.size());
+                if (rc != LORAHIP_OK) { const std::string e = lorahip_last_error(); delete k; setLastError(e); return rc; }
+                for (size_t j = 0; j < slot.chan.size(); j++) { I.partOf[slot.chan[j]] = uint32_t(I.parts.size() - 1); I.localOf[slot.chan[j]] = uint32_t(j); }
             }
         if (I.parts.size() > 1)
             for (Impl::Part &part : I.parts)
@@ -188,6 +191,16 @@ int Composite::setStream(void *stream)
     // a HIP stream belongs to one device: an object that spans several keeps its parts' private streams
     for (const Impl::Part &q : p->parts) if (q.device != p->parts[0].device) { setLastError("lorahip_demod_set_stream: the object spans several devices"); return LORAHIP_E_INVALID; }
     return p->each([stream](lorahip_demod *d) { return lorahip_demod_set_stream(d, stream); });
+}
+int Composite::streamWait(void *stream)
+{
+    for (const Impl::Part &q : p->parts) if (q.device != p->parts[0].device) { setLastError("lorahip_demod_stream_wait: the object spans several devices"); return LORAHIP_E_INVALID; }
+    return p->each([stream](lorahip_demod *d) { return lorahip_demod_stream_wait(d, stream); });
+}
+int Composite::streamFollow(void *stream)
+{
+    for (const Impl::Part &q : p->parts) if (q.device != p->parts[0].device) { setLastError("lorahip_demod_stream_follow: the object spans several devices"); return LORAHIP_E_INVALID; }
+    return p->each([stream](lorahip_demod *d) { return lorahip_demod_stream_follow(d, stream); });
 }
 int Composite::resetStream() { return p->each([](lorahip_demod *d) { return lorahip_demod_reset_stream(d); }); }
 

@@ -992,7 +992,7 @@ demodStreamWide(const StreamArgs s)
             st.finefreqError = uniF(st.finefreqError);                                  // a float add runs on the vector unit: back to a scalar
         }
     }
-    o.carryOut(s, st, c, t, T);
+    o.carryOut(s, st, c, t, T, true, true);             // T > 64: a barrier between the writer's last store and the other wavefronts' loads
 #ifdef LORAHIP_WG_TIMELINE
     if ((t & 63) == 0 && c < 16384) gWgWaveHwId[c][(t >> 6) & 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif

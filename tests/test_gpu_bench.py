@@ -54,6 +54,22 @@ def test_gpus_n_without_a_launcher_starts_n_ranks(gpu):
     assert "re-launching" in r.stderr
 
 
+def test_two_rank_line_carries_cpu_baseline_and_oracle(gpu):
+    """A --gpus N line is graded like the N = 1 line: rank 0 times the CPU reference and checks its batch against the oracle after the
+    timed region (the other rank waits on the host), every rank checks a sample of its own shard. One GPU here: both ranks share it."""
+    env = dict(os.environ, LORA_BENCH_BACKEND="gloo", LORA_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sf", "7", "--channels", "256", "--symbols", "16", "--steps", "3",
+                        "--warmup", "1", "--ramp-seconds", "0", "--cpu-seconds", "0.3"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0
+    assert d["oracle"]["windows"] == 256 * 16 and d["oracle"]["index_mismatches"] == 0
+    assert d["oracle"]["every_rank_sample"] == dict(d["oracle"]["every_rank_sample"], ranks=2, windows=2 * 256 * 16, index_mismatches=0)
+    assert d["symbol_error_rate_vs_sent"] == 0.0
+
+
 def test_gpus_n_that_contradicts_the_launcher_is_refused(gpu):
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sf", "7", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,

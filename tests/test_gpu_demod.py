@@ -317,15 +317,15 @@ def test_chunked_streaming_equals_one_shot(gpu, oracle, sf, mode):
 
 
 @pytest.mark.parametrize("sf", [7, 10, 12])
-def test_stream_kernel_resumes_when_its_record_buffer_fills(gpu, oracle, sf, monkeypatch):
+def test_stream_kernel_resumes_when_its_record_buffer_fills(gpu, oracle, sf):
     """the streaming launch stops a channel when its per-launch record buffer is full and is relaunched from the saved state:
     with a capacity of 5 calls per launch every frame is cut many times, packets and traces must not change"""
     import lora_sdr_amd as L
     rng = np.random.default_rng(7 * sf)
     B = 6
     streams = [frames(oracle, rng, sf, 2, 7 + c, off=rng.uniform(-0.4, 0.4), noise=0.03, lead=int(rng.integers(0, 100)))[0] for c in range(B)]
-    monkeypatch.setenv("LORAHIP_STREAM_CAP", "5")
     d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(7); d.set_trace(True)
+    d.set_record_capacity(5)
     d.work(streams)
     pk = d.packets()
     for c in range(B):

@@ -365,3 +365,170 @@ def test_mixed_object_rejects_bad_arguments(gpu):
     m = L.LoRaDemod(channel_sf=[9, 9, 9, 9, 9], devices=[0, 0])             # one SF over two "devices": debug ports are offered
     assert m.sf == 9 and len(m.parts) == 2
     m.close()
+
+
+@pytest.mark.parametrize("sf", [7, 12])
+def test_pipelined_receiver_with_rows_that_are_too_small_loses_nothing(gpu, oracle, sf):
+    """Pipelined steps (async = 2) whose rows cannot hold the packets that are due: LORAHIP_E_INVALID with the rows needed, the packets
+    kept in the step's record set, delivered -- with the packets of the step launched in between -- by the next call whose rows hold
+    them; a flush with too few rows likewise. Every packet of the reference arrives, in order, with the reference's call count."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(1200 + sf)
+    N, B = 1 << sf, 11
+    host = _streams(oracle, rng, sf, B, n_frames=4)
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
+    iq = gpu.from_numpy(host).cuda()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
+    small, big = d.receiver_rows(cap_packets=2, stride=16), d.receiver_rows(cap_packets=4 * B, stride=16)
+    got, calls, refused = [[] for _ in range(B)], 0, 0
+
+    def take(n, r):
+        gpu.cuda.synchronize()
+        sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
+        for i in range(n):
+            got[int(chn[i])].append(sy[i, :ns[i]].copy())
+
+    def step(w):
+        """one receiver step the way a caller with too few rows experiences it: refused (nothing lost), then repeated with enough"""
+        nonlocal calls, refused
+        try:
+            n, c_ = d.receive(iq, w, small, async_=2)
+            take(n, small)
+        except L.LoraHipError as e:
+            assert e.n_packets > 2                         # what is needed
+            refused += 1
+            with pytest.raises(L.LoraHipError):            # still too small: still nothing lost, nothing launched
+                d.receive(iq, w, small, async_=2)
+            n, c_ = d.receive(iq, w, big, async_=2)        # both steps' packets
+            assert n >= e.n_packets
+            take(n, big)
+        calls += c_
+    w = 0
+    while w < cap:
+        w = min(cap, w + int(rng.integers(4 * N, 12 * N)))
+        step(w)
+    try:
+        n, c_ = d.receive_flush(small)
+        take(n, small)
+    except L.LoraHipError as e:
+        refused += 1
+        n, c_ = d.receive_flush(big)
+        assert n == e.n_packets
+        take(n, big)
+    calls += c_
+    assert refused >= 2
+    for c in range(B):
+        r = refs[c]
+        assert len(got[c]) == len(r["packets"]) >= 4, "channel %d" % c
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
+        assert d.consumed(c) == int(sum(q["consumed"] for q in r["calls"]))
+    assert calls == sum(len(r["calls"]) for r in refs) == d.work_calls()
+    d.close()
+
+
+@pytest.mark.parametrize("sf", [7, 11])
+def test_pipelined_flush_resumes_a_channel_whose_records_were_full(gpu, oracle, sf):
+    """The last pipelined step fills the channels' per-launch record capacity (bounded to 6 calls here): the flush resumes them until no
+    channel has 2N samples left and delivers those packets too -- the object is left where a one-shot run leaves it."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(1300 + sf)
+    N, B = 1 << sf, 7
+    host = _streams(oracle, rng, sf, B, n_frames=3)
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
+    iq = gpu.from_numpy(host).cuda()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
+    d.set_record_capacity(6)
+    rows = d.receiver_rows(cap_packets=8 * B, stride=16)
+    got, calls = [[] for _ in range(B)], 0
+
+    def take(n):
+        gpu.cuda.synchronize()
+        sy, ns, chn = rows[0][:n].cpu().numpy(), rows[1][:n].cpu().numpy(), rows[2][:n].cpu().numpy()
+        for i in range(n):
+            got[int(chn[i])].append(sy[i, :ns[i]].copy())
+    for w in (4 * N, 8 * N, cap):                           # the last step covers most of the capture: 6 calls per channel are not enough
+        n, c_ = d.receive(iq, w, rows, async_=2)
+        take(n); calls += c_
+    n, c_ = d.receive_flush(rows)
+    take(n); calls += c_
+    for c in range(B):
+        r = refs[c]
+        assert len(got[c]) == len(r["packets"]) >= 3, "channel %d" % c
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
+        assert d.consumed(c) == int(sum(q["consumed"] for q in r["calls"]))
+    assert calls == sum(len(r["calls"]) for r in refs) == d.work_calls()
+    d.close()
+
+
+@pytest.mark.parametrize("async_", [True, 2])
+@pytest.mark.parametrize("sf", [11, 12])
+def test_wide_kernels_carry_long_open_packets_across_chunks(gpu, oracle, sf, async_):
+    """SF11 / SF12: a channel is a workgroup of 2 / 4 wavefronts, and a packet that is open when a launch ends is saved to the carry
+    rows by ALL of them while its last symbol was stored by the first -- packets of 100 symbols cut by chunks of a few windows, so
+    that most launches end inside a packet of more than 64 symbols (the barrier before the save, lorahip_framemachine.h::carryOut)."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(1400 + sf)
+    N, B, nsyms = 1 << sf, 5, 100
+    streams = [frames(oracle, rng, sf, 2, nsyms, off=rng.uniform(-0.4, 0.4), noise=0.05, lead=int(rng.integers(0, 2 * N)))[0] for c in range(B)]
+    cap = max(s.size for s in streams)
+    host = np.zeros((B, cap), np.complex64)
+    for c, s in enumerate(streams):
+        host[c, :s.size] = s
+    refs = [oracle.demod_run(sf, host[c], mtu=nsyms) for c in range(B)]
+    iq = gpu.from_numpy(host).cuda()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(nsyms)
+    rows = d.receiver_rows(cap_packets=4 * B, stride=128)
+    got, w = [[] for _ in range(B)], 0
+
+    def take(n):
+        gpu.cuda.synchronize()
+        sy, ns, chn = rows[0][:n].cpu().numpy(), rows[1][:n].cpu().numpy(), rows[2][:n].cpu().numpy()
+        for i in range(n):
+            got[int(chn[i])].append(sy[i, :ns[i]].copy())
+    while w < cap:
+        w = min(cap, w + int(rng.integers(2 * N, 5 * N)))
+        take(d.receive(iq, w, rows, async_=async_)[0])
+    if async_ == 2:
+        take(d.receive_flush(rows)[0])
+    for c in range(B):
+        r = refs[c]
+        assert len(got[c]) == len(r["packets"]) == 2, "channel %d" % c
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
+    d.close()
+
+
+def test_pipelined_rows_are_ordered_behind_a_consumer_on_the_launch_stream(gpu, oracle):
+    """ONE set of rows, short steps (their packets are packed on the side stream beside the running kernel): torch's stream is made
+    to wait for each call's packing (lorahip_demod_stream_wait) and the copy queued on it -- the 'decoder' -- sees every step's
+    rows before the next step overwrites them; no host synchronise between the steps."""
+    import lora_sdr_amd as L
+    sf = 7
+    rng = np.random.default_rng(1500)
+    N, B = 1 << sf, 64
+    host = _streams(oracle, rng, sf, B, n_frames=6)
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
+    iq = gpu.from_numpy(host).cuda()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
+    rows = d.receiver_rows(cap_packets=4 * B, stride=16)
+    kept, w = [], 0
+    while w < cap:
+        w = min(cap, w + 8 * N)
+        n, _ = d.receive(iq, w, rows, async_=2)
+        if n:
+            kept.append((n, rows[0][:n].clone(), rows[1][:n].clone(), rows[2][:n].clone()))     # on torch's stream, not waited for
+    n, _ = d.receive_flush(rows)
+    kept.append((n, rows[0][:n].clone(), rows[1][:n].clone(), rows[2][:n].clone()))
+    gpu.cuda.synchronize()
+    got = [[] for _ in range(B)]
+    for n, sy, ns, chn in kept:
+        sy, ns, chn = sy.cpu().numpy(), ns.cpu().numpy(), chn.cpu().numpy()
+        for i in range(n):
+            got[int(chn[i])].append(sy[i, :ns[i]].copy())
+    for c in range(B):
+        r = refs[c]
+        assert len(got[c]) == len(r["packets"]) >= 6, "channel %d" % c
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
+    d.close()

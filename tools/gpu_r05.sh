@@ -1,0 +1,60 @@
+#!/bin/bash
+# round-5 GPU sessions: gpurun --timeout N -- 'TAG=s1 bash tools/gpu_r05.sh tests tworank level3 ...'
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R; TAG=${TAG:-r05}
+export TMPDIR=/tmp
+what="$*"
+l3ch() { case $1 in 6|7) echo 16384;; 8|9) echo 8192;; 10) echo 4096;; 11) echo 2048;; *) echo 1024;; esac; }
+if [[ $what == *tests* ]]; then
+  timeout ${TEST_TIMEOUT:-900} python -m pytest ${TESTS:-tests} -m gpu -x -q ${PYTEST_ARGS:-} > $O/${TAG}_pytest.txt 2>&1; tail -${TEST_TAIL:-6} $O/${TAG}_pytest.txt
+fi
+if [[ $what == *tworank* ]]; then
+  # the --gpus 2 code path on one device over gloo: the line must carry cpu_baseline + oracle like the N = 1 line
+  LORA_BENCH_BACKEND=gloo LORA_BENCH_ONE_DEVICE=1 timeout 900 python bench.py --gpus 2 ${TWORANK_ARGS:-} > $O/${TAG}_bench_two_ranks_one_device_gloo.json 2> $O/${TAG}_bench_two_ranks.err
+  tail -c 400 $O/${TAG}_bench_two_ranks.err
+  python tools/bench_digest.py $O/${TAG}_bench_two_ranks_one_device_gloo.json
+fi
+if [[ $what == *level3* ]]; then
+  for sf in ${L3SFS:-7 8 9 10 11 12}; do
+    timeout 200 python tools/bench_demod.py --sf $sf --channels ${L3CH:-$(l3ch $sf)} --modes 1 > $O/${TAG}_level3_sf$sf.txt 2>&1
+    tail -1 $O/${TAG}_level3_sf$sf.txt | cut -c1-260
+  done
+fi
+if [[ $what == *scaling* ]]; then
+  timeout 600 python tools/level3_scaling.py ${SCALING_ARGS:-} > $O/${TAG}_level3_scaling.txt 2>&1; cat $O/${TAG}_level3_scaling.txt
+fi
+if [[ $what == *moving* ]]; then
+  for sf in ${MVSFS:-7 8 9 10 11 12}; do
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline --moving > $O/${TAG}_moving_sf$sf.json 2> $O/${TAG}_moving_sf$sf.err
+    python - $O/${TAG}_moving_sf$sf.json $sf <<'EOP'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("SF%s moving %8.1f Msym/s frac %.3f launch %.1f us oracle %s" % (sys.argv[2], d["value"], d["roofline"]["frac"], d["roofline"]["launch_us"], d.get("oracle", {}).get("index_mismatches")))
+except Exception as e:
+    print("SF", sys.argv[2], "FAILED", e)
+EOP
+  done
+fi
+if [[ $what == *steady* ]]; then
+  for sf in ${STSFS:-7 10 12}; do
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline ${STEADY_ARGS:-} > $O/${TAG}_steady_sf$sf.json 2> $O/${TAG}_steady_sf$sf.err
+    python - $O/${TAG}_steady_sf$sf.json $sf <<'EOP'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("SF%s steady %8.1f Msym/s frac %.3f launch %.1f us" % (sys.argv[2], d["value"], d["roofline"]["frac"], d["roofline"]["launch_us"]))
+except Exception as e:
+    print("SF", sys.argv[2], "FAILED", e)
+EOP
+  done
+fi
+if [[ $what == *bench* ]]; then
+  timeout 700 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -c 600 $O/${TAG}_bench_default.err
+  python tools/bench_digest.py $O/${TAG}_bench_default.json
+fi
+if [[ $what == *smoke* ]]; then
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.txt 2>&1; tail -3 $O/${TAG}_smoke.txt
+fi
+if [[ $what == *custom* ]]; then
+  bash -c "$CUSTOM" > $O/${TAG}_custom.txt 2>&1; tail -${CUSTOM_TAIL:-40} $O/${TAG}_custom.txt
+fi
