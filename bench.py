@@ -543,13 +543,24 @@ def section_level3(env, L, sf, threads=32):
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.25:
         one_pass(together=False)                    # (the ranks' ramps take different numbers of passes: no barrier inside)
-    best = None
+    best, kms_all = None, []
     for _ in range(5):
         r_ = one_pass()
+        kms_all.append(r_[1])
         best = r_ if best is None else (min(best[0], r_[0]), min(best[1], r_[1]), r_[2])     # best wall clock, best device time
     best = (best[0], best[1], one_pass(to_host=True)[2])
+    kms_all.sort()
+    # the same launch with the block's signals kept (error / power / snr once per packet, LoRaDemod.cpp:267-269: the reference block
+    # always emits them; one more pair of logarithms per packet and a 16-byte record)
+    d.set_signals(True)
+    one_pass()
+    sig_pass = one_pass()
+    n_signals = len(d.signals()[0])
+    d.set_signals(False)
+    d.clear_packets()
     # several ranks (bench.py --gpus N): every rank demodulates its own B channels; times are the slowest rank's, counts are sums
     best = env.max_over_ranks(*best)
+    k_mean, k_median, k_sig = env.max_over_ranks(sum(kms_all) / len(kms_all), kms_all[len(kms_all) // 2], sig_pass[1])
     (calls_all, unique_all) = env.sum_over_ranks(calls, unique_bytes)
     peak_all = HBM_PEAK_GBS * env.world
     # the RUNNING receiver: the same capture arrives in chunks of 128 (and of 8) windows. One call into the library per chunk
@@ -636,6 +647,13 @@ def section_level3(env, L, sf, threads=32):
            "frac_e2e": r4(calls_all * L.bytes_per_symbol(sf) / best[0] / 1e9 / peak_all), "e2e_host_ms": r4(best[2] * 1e3),
            "kernel_us": r4(best[1] * 1e3), "Msym_s_kernel": r4(calls_all / (best[1] / 1e3) / 1e6),
            "frac_kernel": r4(calls_all * L.bytes_per_symbol(sf) / (best[1] / 1e3) / 1e9 / peak_all),
+           # frac_kernel is the BEST of 5 launches (device time); the mean and the median of the same five, and the launch with signals kept
+           "kernel_us_mean": r4(k_mean * 1e3), "kernel_us_median": r4(k_median * 1e3),
+           "frac_kernel_mean": r4(calls_all * L.bytes_per_symbol(sf) / (k_mean / 1e3) / 1e9 / peak_all),
+           "frac_kernel_median": r4(calls_all * L.bytes_per_symbol(sf) / (k_median / 1e3) / 1e9 / peak_all),
+           "with_signals": {"kernel_us": r4(k_sig * 1e3), "frac_kernel": r4(calls_all * L.bytes_per_symbol(sf) / (k_sig / 1e3) / 1e9 / peak_all),
+                            "signals_rank0": int(n_signals)},
+           "lanes_log2": d.stream_lanes(),
            "unique_stream_bytes": int(unique_all), "counted_bytes": int(calls_all * L.bytes_per_symbol(sf)),
            "frac_unique": r4(unique_all / (best[1] / 1e3) / 1e9 / peak_all),
            "packets": n_pk, "packets_device": n_dev, "packets_expected": B * frames, "packets_ok": ok, "staggered_starts": True,
@@ -657,7 +675,8 @@ def section_level3(env, L, sf, threads=32):
     return res
 
 
-def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 32768)), (11, (1024, 2048, 4096)), (12, (256, 512, 1024, 2048, 4096))), both_grids=False, passes=4):
+def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 32768)), (8, (2048, 4096)), (9, (1024, 2048)), (10, (512, 1024)), (11, (1024, 2048, 4096)),
+                                           (12, (256, 512, 1024, 2048, 4096))), both_grids=False, passes=4):
     """The streaming kernels against the channel count (whole LoRaDemod blocks, the level-3 workload): below the resident set (two
     wavefronts per SIMD: 16384 channels at SF7, 1024 at SF11, 512 at SF12) the device is not full; above it the dispatcher hands every
     free slot the next channel set (SF11: the resident workgroups walk channel after channel, lorahip_wide.hip). A grid that is not a
@@ -682,6 +701,7 @@ def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 
                 d.set_mode(1); d.setMTU(48)
                 d.work(iq)
                 calls = d.work_calls()
+                ent["lanes_log2"] = d.stream_lanes()           # lanes per channel the library chose for this channel count (SF7-9)
                 t_ramp = time.perf_counter()
                 while time.perf_counter() - t_ramp < 0.15:
                     d.clear_packets(); d.activate(); d.work(iq)

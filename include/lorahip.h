@@ -284,6 +284,17 @@ int lorahip_demod_set_variant(lorahip_demod *d, int variant);
  * channel set always, n > 0 = at most n workgroups each walking several sets -- honoured where the build holds such an instance
  * (SF11 and SF12), the default elsewhere. For measurements and tests. */
 int lorahip_demod_set_stream_grid(lorahip_demod *d, int max_workgroups);
+/* Lanes per channel of the streaming kernels at SF7-9 (scheduling only: every result is the same). A channel is a sequential chain of
+ * work() calls; the default geometry gives a lane 16 points of the window (SF7: 8 lanes per channel), which is the cheapest per
+ * window and fills the device from 16384 (SF7) / 8192 (SF8) / 4096 (SF9) channels up. A receiver with fewer channels leaves
+ * wavefront slots empty, so the library then gives a channel 2x / 4x / 8x the lanes (8 or 4 points per lane: shorter calls, more
+ * wavefronts). log2_lanes: 0 = chosen by the channel count (default), < 0 = 16 points per lane always, 4 / 5 / 6 = 16 / 32 / 64 lanes
+ * per channel where the build holds that instance (SF7: 4, 5; SF8: 5, 6; SF9: 6), the default geometry elsewhere. For measurements
+ * and tests. */
+int lorahip_demod_set_stream_lanes(lorahip_demod *d, int log2_lanes);
+/* log2 of the lanes per channel the object's streaming launches run on (the choice above resolved for its channel count and device;
+ * SF11 / SF12: 7 / 8, a channel is a workgroup); LORAHIP_E_INVALID for a mixed object (per part: lorahip_demod_part_handle) */
+int lorahip_demod_stream_lanes(const lorahip_demod *d);
 /* A bound on the streaming kernels' per-launch record capacity (work() calls per channel per launch; 0 = none beyond the library's
  * own sizing). A channel that fills its records stops, and the run resumes it with another launch: results are the same. For tests
  * of that path (it replaces the environment hook LORAHIP_STREAM_CAP of earlier builds). */

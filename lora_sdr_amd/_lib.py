@@ -85,6 +85,8 @@ SIGNATURES = {
     "lorahip_demod_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_set_stream_grid": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_set_record_capacity": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "lorahip_demod_set_stream_lanes": (C.c_int, [C.c_void_p, C.c_int]),
+    "lorahip_demod_stream_lanes": (C.c_int, [C.c_void_p]),
     "lorahip_demod_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lorahip_demod_stream_follow": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lorahip_detect_batch": (C.c_int, [C.c_void_p, C.POINTER(Batch)]),

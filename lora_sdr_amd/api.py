@@ -611,6 +611,18 @@ class LoRaDemod:
         always, n > 0 at most n workgroups each walking several channels (SF11 / SF12)"""
         check(self._lib.lorahip_demod_set_stream_grid(self._h, int(max_workgroups)), "lorahip_demod_set_stream_grid")
 
+    def set_stream_lanes(self, log2_lanes):
+        """lanes per channel of the streaming kernels at SF7-9 (scheduling only, same results): 0 by channel count (default), < 0
+        always 16 points per lane, 4 / 5 / 6 = 16 / 32 / 64 lanes per channel where the build holds that instance"""
+        check(self._lib.lorahip_demod_set_stream_lanes(self._h, int(log2_lanes)), "lorahip_demod_set_stream_lanes")
+
+    def stream_lanes(self):
+        """log2 of the lanes per channel the streaming launches of this object run on"""
+        v = int(self._lib.lorahip_demod_stream_lanes(self._h))
+        if v < 0:
+            raise _lib.LoraHipError(v, "lorahip_demod_stream_lanes")
+        return v
+
     def set_record_capacity(self, max_calls_per_launch):
         """bound the streaming kernels' per-launch record capacity (0: the library's own sizing): a channel that fills it is resumed by
         another launch, results unchanged -- the tests of the resume path"""

@@ -13,9 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblorahip.so")
-SOURCES = ["lorahip_kernels.hip", "lorahip_fast.hip", "lorahip_wide.hip", "lorahip_stream.hip", "lorahip_codec.hip", "lorahip_chan.hip", "lorahip_api.cpp", "lorahip_tables.cpp",
+SOURCES = ["lorahip_kernels.hip", "lorahip_fast.hip", "lorahip_wide.hip", "lorahip_stream.hip", "lorahip_stream_lanes.hip", "lorahip_codec.hip", "lorahip_chan.hip", "lorahip_api.cpp", "lorahip_tables.cpp",
            "lorahip_demod.cpp", "lorahip_mixed.cpp", "lorahip_upload.cpp", "lorahip_rx.cpp", "lorahip_fma_fast.hip", "lorahip_fma_wide.hip"]
-HEADERS = ["lorahip_internal.h", "lorahip_device.h", "lorahip_fft.h", "lorahip_fastcore.h", "lorahip_framemachine.h", "lorahip_fine.h", os.path.join("..", "..", "include", "lorahip.h")]
+HEADERS = ["lorahip_internal.h", "lorahip_device.h", "lorahip_fft.h", "lorahip_fastcore.h", "lorahip_framemachine.h", "lorahip_streamkernel.h", "lorahip_fine.h", os.path.join("..", "..", "include", "lorahip.h")]
 INCLUDED_SOURCES = {"lorahip_fma_fast.hip": ["lorahip_fast.hip"], "lorahip_fma_wide.hip": ["lorahip_wide.hip"]}
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -121,7 +121,58 @@ def build_lib(force=False, verbose=False, extra=()):
     return LIB
 
 
+HOST_SOURCES = [s_ for s_ in SOURCES if s_.endswith(".cpp")]
+SANITIZERS = {"address": ("asan", ["-fsanitize=address"]), "thread": ("tsan", ["-fsanitize=thread"]), "undefined": ("ubsan", ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"])}
+
+
+def sanitizer_runtime(kind):
+    """the shared sanitizer runtime that has to be preloaded into an uninstrumented python (LD_PRELOAD)"""
+    import glob
+    tag = {"address": "asan", "thread": "tsan", "undefined": "ubsan_standalone"}[kind]
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.%s-x86_64.so" % tag))
+    return hits[-1] if hits else None
+
+
+def build_sanitized(kind, verbose=False):
+    """SURVEY.md section 5's sanitizer pass: ANOTHER build of the library beside the shipped one -- lora_sdr_amd/liblorahip_<asan|tsan|ubsan>.so
+    (git-ignored; loaded through LORAHIP_LIB) -- whose HOST translation units (the stateful C++ with worker threads: lorahip_demod.cpp,
+    lorahip_rx.cpp, lorahip_upload.cpp, lorahip_mixed.cpp, lorahip_api.cpp, lorahip_tables.cpp) are compiled with -fsanitize=<kind>
+    (host side only: device code is what it is in the shipped build), -O1 -g and frame pointers; the kernel objects are the shipped
+    build's. Also reached as LORAHIP_SANITIZE=address|thread|undefined python -m lora_sdr_amd.build. Run with
+    LD_PRELOAD=<sanitizer_runtime(kind)> LORAHIP_LIB=<the result> (tools/gpu_sanitize.sh)."""
+    if kind not in SANITIZERS:
+        raise ValueError("LORAHIP_SANITIZE: one of " + ", ".join(sorted(SANITIZERS)))
+    build_lib(verbose=verbose)                         # the shipped objects are current
+    name, sflags = SANITIZERS[kind]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build_" + name)
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", "-shared-libsan"] + sflags
+    jobs, objs = [], []
+    for s in SOURCES:
+        if s not in HOST_SOURCES:
+            objs.append(os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o"))
+            continue
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((s, subprocess.Popen(cmd)))
+    bad = [s for s, p in jobs if p.wait() != 0]
+    if bad:
+        raise RuntimeError("hipcc failed for " + ", ".join(bad))
+    lib = os.path.join(HERE, "liblorahip_%s.so" % name)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-shared-libsan"] + sflags + objs + ["-o", lib], check=True)
+    print("lorahip sanitized build (%s): %s; host units %s; preload %s" % (kind, lib, ", ".join(HOST_SOURCES), sanitizer_runtime(kind)), flush=True)
+    return lib
+
+
 if __name__ == "__main__":
+    if os.environ.get("LORAHIP_SANITIZE") or "--sanitize" in sys.argv:
+        kind = os.environ.get("LORAHIP_SANITIZE") or sys.argv[sys.argv.index("--sanitize") + 1]
+        print(build_sanitized(kind, verbose=True))
+        sys.exit(0)
     # --all-variants: also compile the round-1 A/B kernel variants (profiling only; the shipped library carries the default,
     # the generic kernel and one alternative per SF)
     build_lib(force="--force" in sys.argv, verbose=True, extra=("-DLORAHIP_ALL_VARIANTS",) if "--all-variants" in sys.argv else ())

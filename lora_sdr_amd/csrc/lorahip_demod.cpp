@@ -67,6 +67,7 @@ struct lorahip_demod
 {
     int streamGrid;                  // lorahip_demod_set_stream_grid: 0 default, < 0 one workgroup per channel set, > 0 at most that many workgroups
     size_t streamCapMax;             // lorahip_demod_set_record_capacity: 0 = no bound beyond the library's own
+    int streamLanes;                 // lorahip_demod_set_stream_lanes: 0 by channel count, < 0 always 16 points per lane, else log2 of the lanes per channel
     lorahip::Composite *comp;        // non-null: the handle is a container of (device, SF) parts (lorahip_rx.cpp); nothing below is used then
     lorahip_ctx *ctx;
     size_t N, B;
@@ -833,7 +834,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     // looping over sets) lost there even with the alternating priority (profiles/r04/s22_*: SF7 32768 channels 0.34 against 0.44,
     // SF9 0.36 against 0.40; SF8 / 10 / 12 equal) -- the loop costs the wave-per-channel-set kernels registers -- and is the default
     // only where one-by-one placement leaves slots unusable: SF11 (lorahip_wide.hip::launchStreamWideCfg).
-    a.maxBlocks = dm->streamGrid; a.lastRoundFrom = 0;
+    a.maxBlocks = dm->streamGrid; a.lanes = dm->streamLanes; a.lastRoundFrom = 0;
 #if defined(LORAHIP_ALL_VARIANTS) || defined(LORAHIP_STREAM_PERSIST)
     if (const char *e = std::getenv("LORAHIP_STREAM_BLOCKS")) a.maxBlocks = std::atoi(e);        // e.g. 512: two workgroups of 256 threads per CU
 #endif
@@ -1187,7 +1188,7 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     a.base = nullptr; a.len = nullptr;
     a.uniformLen = (long long)nValid; a.uniformStride = (long long)rowStride;
     a.flags = 4 | 8;                                  // continue the streams; open packets in from / out to the carry rows
-    a.carry = dm->dCarry; a.carryCap = int(dm->carryCap); a.maxBlocks = dm->streamGrid; a.lastRoundFrom = 0;
+    a.carry = dm->dCarry; a.carryCap = int(dm->carryCap); a.maxBlocks = dm->streamGrid; a.lanes = dm->streamLanes; a.lastRoundFrom = 0;
     a.state = reinterpret_cast<StreamState *>(dm->sDev + H.oState);          // the object's own: every launch continues it
     a.nCalls = reinterpret_cast<int *>(d + L.oN); a.nSym = reinterpret_cast<int *>(d + L.oNSym); a.nPkt = reinterpret_cast<int *>(d + L.oNPkt);
     a.nSig = reinterpret_cast<int *>(d + L.oNSig);
@@ -1432,6 +1433,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->wantSignals = false;
     dm->streamGrid = 0;
     dm->streamCapMax = 0;
+    dm->streamLanes = 0;
     dm->lastLaunches = 0;
     dm->dCarry = nullptr; dm->carryCap = 0; dm->devCarryValid = false; dm->hostCarryStale = false;
     dm->callsPerWindowQ8 = 288;                                 // 1.125 calls per N samples to begin with
@@ -1643,6 +1645,26 @@ int lorahip_demod_set_stream_grid(lorahip_demod *dm, const int max_workgroups)
     { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
     dm->streamGrid = max_workgroups;
     return LORAHIP_OK;
+}
+
+int lorahip_demod_set_stream_lanes(lorahip_demod *dm, const int log2_lanes)
+{
+    if (dm == nullptr || log2_lanes > 6) return LORAHIP_E_INVALID;
+    if (dm->comp)
+    {
+        for (size_t i = 0; i < dm->comp->numParts(); i++) { const int rc = lorahip_demod_set_stream_lanes(dm->comp->part(i), log2_lanes); if (rc != LORAHIP_OK) return rc; }
+        return LORAHIP_OK;
+    }
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
+    dm->streamLanes = log2_lanes;
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_stream_lanes(const lorahip_demod *dm)
+{
+    if (dm == nullptr || dm->comp) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(dm->ctx->device);
+    return streamLanesChosen(dm->ctx->sf, unsigned(dm->B), dm->streamLanes);
 }
 
 int lorahip_demod_set_record_capacity(lorahip_demod *dm, const size_t max_calls_per_launch)

@@ -14,7 +14,8 @@ namespace lorahip {
  *   groups and the readers' ds_read_b64 groups each tile the LDS banks exactly once.
  **********************************************************************/
 template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_,
-          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false, bool X1_SWAP_ = false, bool TW_MID_REG_ = false, bool XCD_CONTIG_ = false>
+          int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false, bool X1_SWAP_ = false, bool TW_MID_REG_ = false, bool XCD_CONTIG_ = false,
+          int PB3_ = 0>
 struct FastCfg
 {
     static constexpr int PREFETCH = PREFETCH_;        // next window set's loads: 0 none (loaded at the top), 1 issued after the dechirp of this set, 2 at the top of this set
@@ -36,10 +37,13 @@ struct FastCfg
     static constexpr bool HAS_R2 = (LOG2N_ & 1);
     static constexpr int NL = VEC * T;                          // distinct n_low
     static constexpr int LOG2NL = LOG2N_ - PB1_;
+    //! first stage bit of phase j (NPH_ = 2, 3 or 4 phases: bits [0, PB1), [PB1, PB2), [PB2, PB3), [.., LOG2N))
     __host__ __device__ static constexpr int bound(const int j)
     {
-        return j <= 0 ? 0 : (j == 1 ? PB1_ : (j == 2 ? (NPH_ == 2 ? LOG2N_ : PB2_) : LOG2N_));
+        return j <= 0 ? 0 : (j >= NPH_ ? LOG2N_ : (j == 1 ? PB1_ : (j == 2 ? PB2_ : PB3_)));
     }
+    static_assert(NPH_ >= 2 && NPH_ <= 4, "two to four phases");
+    static_assert(NPH_ < 4 || (PB3_ > PB2_ && PB3_ < LOG2N_ && ((PB3_ - PB2_) & 1) == 0), "a fourth phase needs its own boundary, whole radix-4 digits");
     static_assert((1 << PB1_) == R, "phase 0 must cover exactly the bits a lane loads");
     static_assert(((LOG2N_ - PB1_) & 1) == 0, "the low sample digits must be whole radix-4 digits");
     static_assert(T <= 64 && T >= 4, "a window lives inside one wavefront");
@@ -54,7 +58,8 @@ struct FastCfg
     // exchange 1 (3 phases): per window, element (rl, rh, col) at rh*X1 + col*R + rl
     static constexpr int G1 = 1 << (bound(2) - bound(1));
     static constexpr int X1 = G1 * R + 8;
-    static constexpr int X1ELEMS = NPH_ == 3 ? WPW * (N / (G1 * R)) * X1 : 0;   // per wave
+    static constexpr int X1ROWS = N / (G1 * R);                 // rows of 2^PB2 positions (+8 pad) per window
+    static constexpr int X1ELEMS = NPH_ >= 3 ? WPW * X1ROWS * X1 : 0;   // per wave
     static constexpr int XELEMS = (X0ELEMS > X1ELEMS ? X0ELEMS : X1ELEMS) + (N > X0ELEMS ? N - X0ELEMS : 0) / 2 * 0;
     //! twiddle entries staged in LDS: all stages below the last phase, or every stage
     static constexpr int TW_LDS = twStageOffset(LOG2N_, TW_ALL_LDS_ ? LOG2N_ : bound(NPH_ - 1));
@@ -63,6 +68,7 @@ struct FastCfg
     static constexpr int BL = bound(NPH_ - 1);                  // first bit of the last phase
     static constexpr int GL = 1 << (LOG2N_ - BL);               // last-phase group size
     static constexpr int NGL = P / GL;                          // last-phase groups per lane
+    static_assert(GL <= P && (NPH_ < 3 || G1 <= P), "a phase's group must fit a lane's points");
     static constexpr int SLOTS = lastPhaseSlots<LOG2N_, BL, LOG2N_>();
     static constexpr int XE = (X0ELEMS > X1ELEMS ? X0ELEMS : X1ELEMS);
     static constexpr int FS = N + 8;                            // final-bin rows of the wave's windows (8 pad: 16-lane write groups tile the banks)
@@ -286,8 +292,8 @@ struct FastCore
             }
             else
             {
-            // exchange 1: element (rl, rh, col) of this window at rh*X1 + col*R + rl
-            v2f *X1w = X + wsub * (GL * C::X1);
+            // exchange 1: the window by POSITION, rows of 2^B2 positions: element (rl, rh, col) at rh*X1 + col*R + rl
+            v2f *X1w = X + wsub * (C::X1ROWS * C::X1);
 #pragma unroll
             for (int g = 0; g < NG1; g++)
             {
@@ -298,11 +304,43 @@ struct FastCore
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // phase 2 = last: ci' = t + T*g = col*R + rl, element e2 = rh
+            if constexpr (NPH == 4)
+            {
+                // phase 2 (second middle phase): bits [B2, B3), in place in the position-indexed rows -- a lane writes back exactly the
+                // elements it read. ci = t + T*g: klow = ci mod 2^B2 (the column), high = ci >> B2; element e at row e + G2*high
+                constexpr int B3 = C::bound(3);
+                constexpr int G2 = 1 << (B3 - B2), NG2 = P / G2;
+                static_assert(G2 <= P, "a phase's group must fit a lane's points");
+                v2f v2[NG2][G2];
+#pragma unroll
+                for (int g = 0; g < NG2; g++)
+                {
+                    const int ci = t + T * g;
+                    const v2f *col = X1w + (ci >> B2) * (G2 * C::X1) + (ci & ((1 << B2) - 1));
+#pragma unroll
+                    for (int e = 0; e < G2; e++) v2[g][e] = col[e * C::X1];
+                }
+#pragma unroll
+                for (int g = 0; g < NG2; g++) runPhase<LOG2N, B2, B3, false>(v2[g], (t + T * g) & ((1 << B2) - 1), sTw, nullptr);
+#pragma unroll
+                for (int g = 0; g < NG2; g++)
+                {
+                    const int ci = t + T * g;
+                    v2f *col = X1w + (ci >> B2) * (G2 * C::X1) + (ci & ((1 << B2) - 1));
+#pragma unroll
+                    for (int e = 0; e < G2; e++) col[e * C::X1] = v2[g][e];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // last phase: position ci + (e << BL), ci = t + T*g < 2^BL: row = position >> B2 (three phases: BL = B2, the row is e)
 #pragma unroll
             for (int g = 0; g < NGL; g++)
+            {
+                const int ci = t + T * g;
 #pragma unroll
-                for (int e = 0; e < GL; e++) vl[g][e] = X1w[e * C::X1 + (t + T * g)];
+                for (int e = 0; e < GL; e++) vl[g][e] = X1w[((ci >> B2) + (e << (BL - B2))) * C::X1 + (ci & ((1 << B2) - 1))];
+            }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

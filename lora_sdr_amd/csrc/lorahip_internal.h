@@ -139,6 +139,8 @@ struct StreamArgs
                                 //        the last symCount entries of its row in `carry` (the open packets stay on the device, no extra launch)
     short *carry;               // [nChannels][carryCap] symbols of the packets the channels are inside, between launches (bits 2 / 3)
     int carryCap;
+    int lanes;                  // log2 of the lanes per channel (SF7-9: lorahip_stream_lanes.hip): 0 = chosen by the channel count, < 0 = the
+                                // 16-points-per-lane geometry always, else that instance if the build holds it
     int maxBlocks;              // the grid: 0 = the kernel's default, < 0 = one workgroup per channel set always, > 0 = at most this many workgroups, each looping over channel sets
     unsigned lastRoundFrom;     // set by the launcher: workgroups from this blockIdx on are not followed by another one in their slot (lorahip_device.h::rotatePriority)
     unsigned *near;             // [2] decisions float rounding could flip (lorahip_demod_near_threshold): squelch margins, fine-tune steps.
@@ -188,6 +190,9 @@ hipError_t launchWide(int sf, int variant, const DetectArgs &a, const FastTables
 bool streamAvailable(int sf);
 hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchStreamWide(int sf, const StreamArgs &s, hipStream_t stream);
+bool streamLanesAvailable(int sf, int log2Lanes);
+int streamLanesChosen(int sf, unsigned nChannels, int forced);
+hipError_t launchStreamLanes(int sf, int log2Lanes, const StreamArgs &s, hipStream_t stream);
 hipError_t launchCompactRows(void *dst, const void *src, size_t rows, size_t srcPitchBytes, size_t rowBytes, hipStream_t stream);
 hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, int *rowStart, size_t nChannels, int cap, int capPkt,
                              size_t nPackets, long long *srcOff, unsigned short *symsOut, int stride, int *nsymsOut, int *channelOut, hipStream_t stream);

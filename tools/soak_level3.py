@@ -1,5 +1,5 @@
 """Randomised level-3 soak against the CPU oracle (the restated block, pinned to the verbatim LoRaDemod.cpp): random SF, channel
-count, MTU, threshold, sync word, carrier offset, noise, stream grid and chunking; packets, call counts and read positions must be
+count, MTU, threshold, sync word, carrier offset, noise, stream grid, lanes per channel and chunking; packets, call counts and read positions must be
 the reference's in every case.   python tools/soak_level3.py [seconds] [first seed]
 (tests/ hold the fixed-seed versions of these cases; this is the same comparison over many more parameter combinations.)"""
 import os, sys, time
@@ -34,6 +34,8 @@ while time.time() < t_end:
     iq = torch.from_numpy(host).cuda()
     d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(mtu); d.setThreshold(thresh); d.setSync(sync)
     d.set_stream_grid(int(rng.choice([0, -1, 1, 2, 5])))
+    lanes = int(rng.choice([0, -1, 4, 5, 6])) if os.environ.get("SOAK_LANES", "1") != "0" else 0     # SF7-9: more lanes per channel (lorahip_stream_lanes.hip)
+    d.set_stream_lanes(lanes)
     how = int(rng.integers(0, 3))
     got = [[] for _ in range(B)]
     if how == 0:
