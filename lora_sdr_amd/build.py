@@ -122,32 +122,46 @@ def build_lib(force=False, verbose=False, extra=()):
 
 
 HOST_SOURCES = [s_ for s_ in SOURCES if s_.endswith(".cpp")]
-SANITIZERS = {"address": ("asan", ["-fsanitize=address"]), "thread": ("tsan", ["-fsanitize=thread"]), "undefined": ("ubsan", ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"])}
+SANITIZERS = {"address": ("asan", ["-fsanitize=address"]), "thread": ("tsan", ["-fsanitize=thread"]), "undefined": ("ubsan", ["-fsanitize=undefined"])}
 
 
 def sanitizer_runtime(kind):
-    """the shared sanitizer runtime that has to be preloaded into an uninstrumented python (LD_PRELOAD)"""
-    import glob
-    tag = {"address": "asan", "thread": "tsan", "undefined": "ubsan_standalone"}[kind]
-    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.%s-x86_64.so" % tag))
-    return hits[-1] if hits else None
+    """the shared sanitizer runtime that has to be preloaded into an uninstrumented python (LD_PRELOAD): gcc's for address / undefined,
+    clang's for thread (see build_sanitized)"""
+    if kind == "thread":
+        import glob
+        hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so"))
+        return hits[-1] if hits else None
+    tag = {"address": "libasan.so", "undefined": "libubsan.so"}[kind]
+    out = subprocess.run([os.environ.get("CXX", "g++"), "-print-file-name=" + tag], capture_output=True, text=True).stdout.strip()
+    return os.path.realpath(out) if os.path.isabs(out) else None
 
 
 def build_sanitized(kind, verbose=False):
     """SURVEY.md section 5's sanitizer pass: ANOTHER build of the library beside the shipped one -- lora_sdr_amd/liblorahip_<asan|tsan|ubsan>.so
     (git-ignored; loaded through LORAHIP_LIB) -- whose HOST translation units (the stateful C++ with worker threads: lorahip_demod.cpp,
-    lorahip_rx.cpp, lorahip_upload.cpp, lorahip_mixed.cpp, lorahip_api.cpp, lorahip_tables.cpp) are compiled with -fsanitize=<kind>
-    (host side only: device code is what it is in the shipped build), -O1 -g and frame pointers; the kernel objects are the shipped
-    build's. Also reached as LORAHIP_SANITIZE=address|thread|undefined python -m lora_sdr_amd.build. Run with
-    LD_PRELOAD=<sanitizer_runtime(kind)> LORAHIP_LIB=<the result> (tools/gpu_sanitize.sh)."""
+    lorahip_rx.cpp, lorahip_upload.cpp, lorahip_mixed.cpp, lorahip_api.cpp, lorahip_tables.cpp) are compiled with -fsanitize=<kind>,
+    -O1 -g and frame pointers; the kernel objects are the shipped build's. The host units are plain C++ over the HIP runtime API, so
+    address / undefined are compiled with g++ and run against gcc's runtimes: ROCm's clang ASan runtime intercepts
+    hsa_amd_memory_pool_allocate for its device-side ASan and aborts in a process that holds a GPU without xnack+ (profiles/r05/
+    s7_*: "allocator is trying to allocate 0x400000 bytes" inside libamdhip64). thread is compiled with hipcc's clang and runs against
+    ITS runtime: gcc 11's ThreadSanitizer does not know this kernel's address-space layout ("unexpected memory mapping"). Also reached as
+    LORAHIP_SANITIZE=address|thread|undefined python -m lora_sdr_amd.build. Run with LD_PRELOAD=<sanitizer_runtime(kind)>
+    LORAHIP_LIB=<the result> (tools/gpu_sanitize.sh)."""
     if kind not in SANITIZERS:
         raise ValueError("LORAHIP_SANITIZE: one of " + ", ".join(sorted(SANITIZERS)))
     build_lib(verbose=verbose)                         # the shipped objects are current
     name, sflags = SANITIZERS[kind]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cxx = os.environ.get("CXX", "g++")
     objdir = os.path.join(HERE, "build_" + name)
     os.makedirs(objdir, exist_ok=True)
-    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", "-shared-libsan"] + sflags
+    clang = kind == "thread"
+    if clang:
+        cxx = hipcc
+        flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", "-shared-libsan"] + sflags
+    else:
+        flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-fno-omit-frame-pointer", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + sflags
     jobs, objs = [], []
     for s in SOURCES:
         if s not in HOST_SOURCES:
@@ -155,16 +169,17 @@ def build_sanitized(kind, verbose=False):
             continue
         obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [cxx] + flags + ["-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         jobs.append((s, subprocess.Popen(cmd)))
     bad = [s for s, p in jobs if p.wait() != 0]
     if bad:
-        raise RuntimeError("hipcc failed for " + ", ".join(bad))
+        raise RuntimeError("%s failed for %s" % (cxx, ", ".join(bad)))
     lib = os.path.join(HERE, "liblorahip_%s.so" % name)
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-shared-libsan"] + sflags + objs + ["-o", lib], check=True)
-    print("lorahip sanitized build (%s): %s; host units %s; preload %s" % (kind, lib, ", ".join(HOST_SOURCES), sanitizer_runtime(kind)), flush=True)
+    # (the sanitizer's own symbols stay undefined in the library: the preloaded runtime provides them)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + (["-shared-libsan"] + sflags if clang else []) + objs + ["-o", lib], check=True)
+    print("lorahip sanitized build (%s): %s; host units %s (%s); preload %s" % (kind, lib, ", ".join(HOST_SOURCES), "clang" if clang else "g++", sanitizer_runtime(kind)), flush=True)
     return lib
 
 

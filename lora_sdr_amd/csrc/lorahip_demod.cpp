@@ -141,19 +141,29 @@ static size_t align256(const size_t x) { return (x + 255) & ~size_t(255); }
 
 static Round carve(char *p, const size_t B)
 {
+    // (offsets first, pointers last: the size of the block is asked for with p == nullptr, and arithmetic on a null pointer is
+    // undefined -- found by the -fsanitize=undefined pass, profiles/r05)
     Round r;
     size_t cur = 0;
-    r.off = reinterpret_cast<int64_t *>(p + cur); cur += align256(B * sizeof(int64_t));
-    r.sel = reinterpret_cast<int32_t *>(p + cur); cur += align256(B * sizeof(int32_t));
-    r.idx0 = reinterpret_cast<int32_t *>(p + cur); cur += align256(B * sizeof(int32_t));
-    r.err = reinterpret_cast<float *>(p + cur); cur += align256(B * sizeof(float));
+    const size_t oOff = cur; cur += align256(B * sizeof(int64_t));
+    const size_t oSel = cur; cur += align256(B * sizeof(int32_t));
+    const size_t oIdx0 = cur; cur += align256(B * sizeof(int32_t));
+    const size_t oErr = cur; cur += align256(B * sizeof(float));
     r.inBytes = cur;
-    r.sym = reinterpret_cast<uint16_t *>(p + cur); cur += align256(B * sizeof(uint16_t));
-    r.power = reinterpret_cast<float *>(p + cur); cur += align256(B * sizeof(float));
-    r.pavg = reinterpret_cast<float *>(p + cur); cur += align256(B * sizeof(float));
-    r.fidx = reinterpret_cast<float *>(p + cur); cur += align256(B * sizeof(float));
-    r.idxOut = reinterpret_cast<int32_t *>(p + cur); cur += align256(B * sizeof(int32_t));
+    const size_t oSym = cur; cur += align256(B * sizeof(uint16_t));
+    const size_t oPower = cur; cur += align256(B * sizeof(float));
+    const size_t oPavg = cur; cur += align256(B * sizeof(float));
+    const size_t oFidx = cur; cur += align256(B * sizeof(float));
+    const size_t oIdxOut = cur; cur += align256(B * sizeof(int32_t));
     r.total = cur;
+    r.off = nullptr; r.sel = nullptr; r.idx0 = nullptr; r.err = nullptr;
+    r.sym = nullptr; r.power = nullptr; r.pavg = nullptr; r.fidx = nullptr; r.idxOut = nullptr;
+    if (p == nullptr) return r;
+    r.off = reinterpret_cast<int64_t *>(p + oOff); r.sel = reinterpret_cast<int32_t *>(p + oSel);
+    r.idx0 = reinterpret_cast<int32_t *>(p + oIdx0); r.err = reinterpret_cast<float *>(p + oErr);
+    r.sym = reinterpret_cast<uint16_t *>(p + oSym); r.power = reinterpret_cast<float *>(p + oPower);
+    r.pavg = reinterpret_cast<float *>(p + oPavg); r.fidx = reinterpret_cast<float *>(p + oFidx);
+    r.idxOut = reinterpret_cast<int32_t *>(p + oIdxOut);
     return r;
 }
 
