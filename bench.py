@@ -485,6 +485,25 @@ def pothos_block(sf, host, nsyms, calls_expected, packets_expected, chunk_window
                      "block_work_calls": best["works"], "packets": best["packets"], "signals": best["signals"], "seconds": r4(best["seconds"])}
         if not ports:
             out[name]["packets_expected"] = packets_expected
+            # the same with the inputs taken from the block's OWN input buffer managers (getInputBufferManager, the counterpart of
+            # LoRaDemod.cpp:346-357): pinned slabs, all ports' slabs in one allocation; every arrival is written into them by the source
+            # (not timed: the upstream block's work) and a work() uploads them as one strided DMA (lorahip_demod_run_host_rows)
+            try:
+                blk = DropInBatch(sf, nch, max_windows=chunk_windows + 2)
+                blk.set("setMTU", nsyms)
+                blk.use_input_slabs(True)
+                blk.bench(sub, chunk)
+                best = None
+                for _ in range(2):
+                    r = blk.bench(sub, chunk)
+                    if best is None or r["seconds"] < best["seconds"]:
+                        best = r
+                active = blk.input_slabs_active()
+                blk.close()
+                out["ports_off_pinned_input_slabs"] = {"channels": nch, "slabs_from_the_block": bool(active), "Msym_s": r4(calls / best["seconds"] / 1e6),
+                                                       "GB_s_in": r4(sub.size * 8 / best["seconds"] / 1e9), "packets": best["packets"], "seconds": r4(best["seconds"])}
+            except Exception as e:
+                out["ports_off_pinned_input_slabs"] = {"error": repr(e)[:160]}
     # the CPU it replaces: the verbatim block, same samples, 1 thread and as many threads as the GPU block's host side uses
     ref = Ref("-O2")
     nst = min(B, 256)

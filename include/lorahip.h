@@ -336,6 +336,15 @@ int lorahip_demod_run_device(lorahip_demod *d, const float *iq_dev, size_t sampl
  * remainder together with the new samples -- nothing is copied, nothing is lost at the chunk boundaries. */
 int lorahip_demod_run_device_segments(lorahip_demod *d, const float *iq_dev, const int64_t *first_sample, const size_t *n_samples,
                                       int64_t *rounds);
+/* HOST buffers that are the rows of ONE block of host memory: channel c's n_samples[c] samples begin at sample first_sample[c] of row c
+ * (rows + 2 * c * row_stride floats), first_sample[c] + n_samples[c] <= row_stride. What a framework hands a block whose input buffer
+ * manager carves every port's slabs out of one pinned allocation (lorahip_host_alloc; lora_sdr_amd/pothos/LoRaDemodBatch.cpp::
+ * getInputBufferManager, the counterpart of LoRaDemod.cpp:346-357): the span of the rows that holds samples crosses PCIe as ONE strided
+ * copy straight from the caller's memory -- no staging copy, no per-channel call -- and the run reads per-channel segments of the
+ * device copy. Results as lorahip_demod_run on the same samples; synchronous (the rows are the caller's again on return). Ordinary
+ * memory works too (the runtime stages it). An object over several parts takes its channels' buffers one by one (lorahip_demod_run). */
+int lorahip_demod_run_host_rows(lorahip_demod *d, const float *rows, size_t row_stride, const int64_t *first_sample, const size_t *n_samples,
+                                int64_t *rounds);
 /* the same for an object that spans several devices (lorahip_demod_create_mixed): one buffer per entry of its device list */
 int lorahip_demod_run_device_segments_multi(lorahip_demod *d, const float *const *iq_dev, size_t n_devices, const int64_t *first_sample,
                                             const size_t *n_samples, int64_t *rounds);
@@ -521,6 +530,13 @@ typedef struct lorahip_decoder_cfg {
 int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, const uint16_t *syms_dev, size_t sym_stride,
                            const int32_t *nsyms_dev, size_t n_packets, uint8_t *out_dev, size_t out_stride,
                            int32_t *out_len_dev, int32_t *dropped_dev);
+/* The same with every buffer in HOST memory (staged through the context's pinned buffer; synchronous): what a host-side block calls
+ * -- lora_sdr_amd/pothos/LoRaDecoderBatch.cpp collects the messages waiting on its inputs into rows and posts the bytes. */
+int lorahip_decode_packets_host(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, const uint16_t *syms, size_t sym_stride,
+                                const int32_t *nsyms, size_t n_packets, uint8_t *out, size_t out_stride, int32_t *out_len,
+                                int32_t *dropped);
+/* the longest packet (symbols) a row may hold in this build: sym_stride <= this; longer packets are reported with out_len = -2 */
+int lorahip_decode_max_symbols(void);
 
 /* -------------------------------------------------------------------------------------
  * Front-end channeliser (the step before the path: SURVEY.md section 8f #4). NOT a reference component: the

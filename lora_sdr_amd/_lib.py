@@ -86,6 +86,7 @@ SIGNATURES = {
     "lorahip_demod_set_stream_grid": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_set_record_capacity": (C.c_int, [C.c_void_p, C.c_size_t]),
     "lorahip_demod_set_stream_lanes": (C.c_int, [C.c_void_p, C.c_int]),
+    "lorahip_demod_run_host_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "lorahip_demod_stream_lanes": (C.c_int, [C.c_void_p]),
     "lorahip_demod_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lorahip_demod_stream_follow": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -139,6 +140,9 @@ SIGNATURES = {
     "lorahip_add_awgn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_uint64]),
     "lorahip_decode_packets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_void_p]),
+    "lorahip_decode_packets_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_void_p]),
+    "lorahip_decode_max_symbols": (C.c_int, []),
     "lorahip_channelizer_phase_inc": (C.c_uint64, [C.c_double]),
     "lorahip_channelizer_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "lorahip_channelizer_destroy": (None, [C.c_void_p]),

@@ -660,6 +660,20 @@ class LoRaDemod:
             self._lib.lorahip_demod_reset_stream(self._h)
         return rounds.value
 
+    def work_host_rows(self, rows, first_sample, n_samples):
+        """lorahip_demod_run_host_rows: `rows` is a (n_channels, row_stride) complex64 HOST array (pinned_empty() for a straight DMA);
+        channel c's stream is rows[c, first_sample[c] : first_sample[c] + n_samples[c]]. One strided copy, then the run."""
+        if not isinstance(rows, np.ndarray) or rows.dtype != np.complex64 or rows.ndim != 2 or rows.shape[0] != self.n_channels or not rows.flags.c_contiguous:
+            raise ValueError("expected a C-contiguous (n_channels, row_stride) complex64 host array")
+        first = np.ascontiguousarray(first_sample, np.int64)
+        cnt = np.ascontiguousarray(n_samples, np.uint64)
+        if first.shape != (self.n_channels,) or cnt.shape != (self.n_channels,):
+            raise ValueError("first_sample and n_samples need one entry per channel")
+        rounds = C.c_int64()
+        check(self._lib.lorahip_demod_run_host_rows(self._h, rows.ctypes.data, int(rows.shape[1]), first.ctypes.data, cnt.ctypes.data, C.byref(rounds)),
+              "lorahip_demod_run_host_rows")
+        return rounds.value
+
     def work_segments_multi(self, bufs, first_sample, n_samples):
         """lorahip_demod_run_device_segments_multi: bufs[s] is the complex64 device tensor on devices[s] that holds the segments of the
         channels of device slot s (None for a slot without channels)"""

@@ -472,6 +472,45 @@ int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, con
     return LORAHIP_OK;
 }
 
+/* The same for a caller in HOST memory (a Pothos block: lora_sdr_amd/pothos/LoRaDecoderBatch.cpp): the rows are staged through the
+ * context's pinned buffer, decoded, and the three outputs copied back; synchronous. */
+int lorahip_decode_packets_host(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, const uint16_t *syms, const size_t sym_stride,
+                                const int32_t *nsyms, const size_t n_packets, uint8_t *out, const size_t out_stride, int32_t *out_len,
+                                int32_t *dropped)
+{
+    if (ctx == nullptr || cfg == nullptr) return LORAHIP_E_INVALID;
+    if (n_packets == 0) return LORAHIP_OK;
+    if (!syms || !nsyms || !out || !out_len || !dropped || n_packets > 0x7fffffffu) return LORAHIP_E_INVALID;
+    if (sym_stride == 0 || sym_stride > size_t(decodeMaxSymbols()) || (out_stride & 1) || out_stride < 2 * (sym_stride + 8)) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(ctx->device);
+    struct Piece { size_t off, bytes; };
+    size_t cur = 0;
+    auto carve = [&cur](const size_t bytes) { Piece p = { cur, bytes }; cur += (bytes + 255) & ~size_t(255); return p; };
+    const Piece pSym = carve(n_packets * sym_stride * sizeof(uint16_t));
+    const Piece pN = carve(n_packets * sizeof(int32_t));
+    const size_t inBytes = cur;
+    const Piece pOut = carve(n_packets * out_stride);
+    const Piece pLen = carve(n_packets * sizeof(int32_t));
+    const Piece pDrop = carve(n_packets * sizeof(int32_t));
+    { const int rc = growStage(ctx, cur, cur); if (rc != LORAHIP_OK) return rc; }
+    char *d = static_cast<char *>(ctx->dStage), *h = static_cast<char *>(ctx->hStage);
+    std::memcpy(h + pSym.off, syms, pSym.bytes);
+    std::memcpy(h + pN.off, nsyms, pN.bytes);
+    LORAHIP_TRY(hipMemcpyAsync(d, h, inBytes, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = lorahip_decode_packets(ctx, cfg, reinterpret_cast<const uint16_t *>(d + pSym.off), sym_stride, reinterpret_cast<const int32_t *>(d + pN.off),
+                                          n_packets, reinterpret_cast<uint8_t *>(d + pOut.off), out_stride, reinterpret_cast<int32_t *>(d + pLen.off),
+                                          reinterpret_cast<int32_t *>(d + pDrop.off));
+    if (rc != LORAHIP_OK) return rc;
+    LORAHIP_TRY(hipMemcpyAsync(h + inBytes, d + inBytes, cur - inBytes, hipMemcpyDeviceToHost, ctx->stream));
+    LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, h + pOut.off, pOut.bytes);
+    std::memcpy(out_len, h + pLen.off, pLen.bytes);
+    std::memcpy(dropped, h + pDrop.off, pDrop.bytes);
+    return LORAHIP_OK;
+}
+
+int lorahip_decode_max_symbols(void) { return decodeMaxSymbols(); }
+
 /***********************************************************************
  * LoRaDetector<float> shim
  **********************************************************************/

@@ -1817,6 +1817,64 @@ int lorahip_demod_run(lorahip_demod *dm, const float *const *streams, const size
     return runAny(dm, dm->dIq, rounds);
 }
 
+/* Host buffers that are the ROWS of one block of host memory -- channel c's n_samples[c] samples begin at sample first_sample[c] of
+ * row c, row_stride samples per row: what a framework hands a block whose input buffer manager carves every port's slabs out of one
+ * pinned allocation (lora_sdr_amd/pothos/LoRaDemodBatch.cpp::getInputBufferManager, the counterpart of LoRaDemod.cpp:346-357). The
+ * span of the rows that holds samples crosses PCIe as ONE strided copy straight from the caller's memory (pinned: a plain DMA, no
+ * staging, no per-channel call), and the run reads its per-channel segments of the device copy. */
+int lorahip_demod_run_host_rows(lorahip_demod *dm, const float *rows, const size_t row_stride, const int64_t *first_sample, const size_t *n_samples, int64_t *rounds)
+{
+    if (dm == nullptr || first_sample == nullptr || n_samples == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp)
+    {
+        // one part holds every channel in order: its rows are the caller's; several parts take their channels' buffers one by one
+        if (dm->comp->numParts() == 1) return lorahip_demod_run_host_rows(dm->comp->part(0), rows, row_stride, first_sample, n_samples, rounds);
+        try
+        {
+            std::vector<const float *> ptr(dm->B);
+            for (size_t c = 0; c < dm->B; c++)
+            {
+                if (first_sample[c] < 0 || size_t(first_sample[c]) + n_samples[c] > row_stride) return LORAHIP_E_INVALID;
+                ptr[c] = rows ? rows + 2 * (c * row_stride + size_t(first_sample[c])) : nullptr;
+            }
+            return lorahip_demod_run(dm, ptr.data(), n_samples, rounds);
+        }
+        catch (const std::bad_alloc &) { setLastError("out of host memory"); return LORAHIP_E_NOMEM; }
+    }
+    { const int rc = refuseWhilePiped(dm); if (rc != LORAHIP_OK) return rc; }
+    size_t lo = row_stride, hi = 0;
+    for (size_t c = 0; c < dm->B; c++)
+    {
+        if (first_sample[c] < 0 || size_t(first_sample[c]) > row_stride || n_samples[c] > row_stride - size_t(first_sample[c])) return LORAHIP_E_INVALID;
+        if (n_samples[c] == 0) continue;
+        lo = size_t(first_sample[c]) < lo ? size_t(first_sample[c]) : lo;
+        hi = size_t(first_sample[c]) + n_samples[c] > hi ? size_t(first_sample[c]) + n_samples[c] : hi;
+    }
+    const size_t width = hi > lo ? hi - lo : 0;
+    if (width && rows == nullptr) return LORAHIP_E_INVALID;
+    if (width > (size_t(1) << 40) / (dm->B ? dm->B : 1)) return LORAHIP_E_INVALID;
+    const DeviceGuard guard(dm->ctx->device);
+    const size_t total = dm->B * width;
+    if (total > dm->dIqSamples)
+    {
+        if (dm->dIq) { (void)hipFree(dm->dIq); dm->dIq = nullptr; dm->dIqSamples = 0; }
+        LORAHIP_TRY(hipMalloc((void **)&dm->dIq, (total ? total : 1) * sizeof(cf32)));
+        dm->dIqSamples = total;
+    }
+    if (width)
+        LORAHIP_TRY(hipMemcpy2DAsync(dm->dIq, width * sizeof(cf32), rows + 2 * lo, row_stride * sizeof(cf32), width * sizeof(cf32), dm->B, hipMemcpyHostToDevice,
+                                     dm->ctx->stream));
+    dm->uniform = false; dm->geomApplied = true; dm->posOnDevice = false;
+    dm->append = false; dm->appendFresh = true;
+    for (size_t c = 0; c < dm->B; c++)
+    {
+        dm->ch[c].base = n_samples[c] ? c * width + (size_t(first_sample[c]) - lo) : 0;
+        dm->ch[c].len = n_samples[c];
+        dm->ch[c].pos = 0; dm->ch[c].callCount = 0;
+    }
+    return runAny(dm, dm->dIq, rounds);               // (in stream order behind the copy; returns with the stream drained: the rows are the caller's again)
+}
+
 //! accessors of the host queue first bring over what the last streaming launch left on the device; a failure there is the
 //! accessor's failure (the records stay pending, see drainPending)
 static int drained(const lorahip_demod *dm)

@@ -22,18 +22,62 @@
 //   signals   "channel" followed by "error", "power", "snr" once per packet at DOWNCHIRP1     (:85-87,267-269)
 //   labels    "SYNC", "P x", "DC", "QC", "S<n> x" on raw<c> / dec<c> / fft<c> at the first element each call produced (:314-319) [debug ports]
 //
+//   input buffers  getInputBufferManager() (the counterpart of LoRaDemod.cpp:346-357, which asks for slabs of >= 2N samples) hands the
+//             framework PINNED slabs: all B ports' slabs are carved out of one lorahip_host_alloc block, slab k of port c at
+//             (k * B + c) * slabBytes, so that a work() whose inputs all sit in slabs of one generation k uploads them as ONE strided
+//             DMA straight from where the upstream blocks wrote them (lorahip_demod_run_host_rows) -- no staging copy, no per-channel
+//             call. Inputs anywhere else (another domain's buffers, mixed generations, several parts) take lorahip_demod_run.
+//
 // One work() of this block performs, per channel, as many LoRaDemod::work() calls as the channel's input buffer allows
 // (each needs 2N samples, :148) inside ONE device launch per (device, SF) part. Without the debug ports a work() is: gather the
 // input buffers (pinned double-buffered upload), the streaming kernels, 52 B of state per channel back, the packets that
 // completed and the signals; nothing per call crosses PCIe. With them, output buffers must hold what several calls produce:
 // setMaxWindows(K) sizes them (raw/dec: the samples consumed; fft: 2K frames per work(), more are dropped and counted).
 #include <Pothos/Framework.hpp>
+#include <algorithm>
 #include <complex>
 #include <cstdlib>
+#include <memory>
 #include <cstring>
 #include <string>
 #include <vector>
 #include "lorahip.h"
+
+//! one pinned allocation for the input slabs of all ports: slab k of port c at (k * ports + c) * slabBytes
+struct PinnedPool
+{
+    PinnedPool(const size_t ports, const size_t numBuffers, const size_t slabBytes) :
+        ports(ports), numBuffers(numBuffers), slabBytes(slabBytes), base(static_cast<char *>(lorahip_host_alloc(ports * numBuffers * slabBytes))) {}
+    ~PinnedPool(void) { if (base) lorahip_host_free(base); }
+    size_t address(const size_t k, const size_t port) const { return size_t(base) + (k * ports + port) * slabBytes; }
+    const size_t ports, numBuffers, slabBytes;
+    char *const base;
+};
+
+//! the buffer manager of ONE input port over its column of the pool: the "generic" manager's behaviour (a queue of free slabs, front()
+//! the next one a producer fills) on memory the DMA engine reads directly
+class PinnedSlabManager : public Pothos::BufferManager
+{
+public:
+    PinnedSlabManager(const std::shared_ptr<PinnedPool> &pool, const size_t port) : _pool(pool), _port(port) {}
+    void init(const Pothos::BufferManagerArgs &a)
+    {
+        args = a;
+        args.numBuffers = _pool->numBuffers; args.bufferSize = _pool->slabBytes;
+        _ready.clear(); _held.clear();
+        for (size_t k = 0; k < _pool->numBuffers; k++)
+        {
+            Pothos::ManagedBuffer b;
+            b.reset(this->shared_from_this(), Pothos::SharedBuffer(_pool->address(k, _port), _pool->slabBytes, _pool), k);
+            _ready.push_back(b);
+        }
+        _initialized = true;
+        this->refreshFront();
+    }
+private:
+    std::shared_ptr<PinnedPool> _pool;
+    const size_t _port;
+};
 
 class LoRaDemodBatch : public Pothos::Block
 {
@@ -136,7 +180,14 @@ public:
         if (_debugPorts) lorahip_demod_set_trace(_d, 1);                                // labels and per-call signals come from the trace
 
         // every part's channels in one launch on its device; the parts run side by side, each from its own host thread (inside the library)
-        if (lorahip_demod_run(_d, _streams.data(), _avail.data(), nullptr) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
+        if (inputsAreOneSlabGeneration())
+        {
+            // all inputs sit in pinned slabs of one generation of this block's own pool: rows of one host block, one strided DMA
+            if (lorahip_demod_run_host_rows(_d, reinterpret_cast<const float *>(_rowBase), _pool->slabBytes / sizeof(cf32), _first.data(), _avail.data(), nullptr) != LORAHIP_OK)
+                throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
+            _rowRuns++;
+        }
+        else if (lorahip_demod_run(_d, _streams.data(), _avail.data(), nullptr) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
 
         _consumed.resize(B);
         if (lorahip_demod_consumed_all(_d, _consumed.data()) != LORAHIP_OK) throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
@@ -179,6 +230,33 @@ public:
         if (_debugPorts) lorahip_demod_set_trace(_d, 0);                                // the next work() starts a fresh trace
     }
 
+    //! work() calls that uploaded their inputs as rows of the pinned pool (one strided DMA)
+    size_t slabRowRuns(void) const { return _rowRuns; }
+
+    /*! Input buffers for the upstream blocks to write into (the reference: "slabs large enough for fft input", LoRaDemod.cpp:346-357).
+     * Here: PINNED slabs of (maxWindows + 2) symbols, all ports' slabs in one allocation (PinnedPool), so that what the framework
+     * presents to work() can cross PCIe as one strided DMA. Another domain's memory is not ours to manage: the framework's default. */
+    Pothos::BufferManager::Sptr getInputBufferManager(const std::string &name, const std::string &domain)
+    {
+        if (!domain.empty() || name.empty() || name.find_first_not_of("0123456789") != std::string::npos) return Pothos::Block::getInputBufferManager(name, domain);
+        const size_t c = size_t(std::atol(name.c_str()));
+        if (c >= B) return Pothos::Block::getInputBufferManager(name, domain);
+        Pothos::BufferManagerArgs args;
+        if (!_pool)
+        {
+            size_t maxN = 0;
+            for (size_t k = 0; k < B; k++) maxN = std::max(maxN, size_t(1) << _sfs[k]);
+            const size_t slabBytes = std::max(args.bufferSize, (_maxWindows + 2) * maxN * sizeof(cf32));     // >= 2N: the reference's bound (:352-353)
+            // two generations: one is being filled by the upstream blocks while the other is inside work()
+            std::shared_ptr<PinnedPool> pool(new PinnedPool(B, 2, slabBytes));
+            if (pool->base == nullptr) return Pothos::Block::getInputBufferManager(name, domain);            // no pinned memory to be had: the default
+            _pool = pool;
+        }
+        std::shared_ptr<PinnedSlabManager> m(new PinnedSlabManager(_pool, c));
+        m->init(args);
+        return m;
+    }
+
     //! output buffers large enough for what one work() produces (the reference does the same for its 2N / N, :330-358)
     Pothos::BufferManager::Sptr getOutputBufferManager(const std::string &name, const std::string &domain)
     {
@@ -194,6 +272,30 @@ public:
     }
 
 private:
+    //! do all inputs with samples lie in slabs of ONE generation of the pool, each in its own port's column? (fills _first, _rowBase)
+    bool inputsAreOneSlabGeneration(void)
+    {
+        if (!_pool || _debugPorts) return false;
+        const size_t gen = _pool->ports * _pool->slabBytes, lo = size_t(_pool->base), hi = lo + _pool->numBuffers * gen;
+        _first.resize(B);
+        size_t k = size_t(-1);
+        for (size_t c = 0; c < B; c++)
+        {
+            _first[c] = 0;
+            if (_avail[c] == 0) continue;
+            const size_t a = size_t(_streams[c]);
+            if (a < lo || a >= hi) return false;
+            const size_t kc = (a - lo) / gen, off = (a - lo) - kc * gen;
+            if (off / _pool->slabBytes != c || (k != size_t(-1) && kc != k)) return false;
+            if (off - c * _pool->slabBytes + _avail[c] * sizeof(cf32) > _pool->slabBytes) return false;
+            k = kc;
+            _first[c] = int64_t((off - c * _pool->slabBytes) / sizeof(cf32));
+        }
+        if (k == size_t(-1)) return false;
+        _rowBase = _pool->base + k * gen;
+        return true;
+    }
+
     //! what the reference block does on its three stream outputs, from the per-call trace (one SF: checked by setDebugPorts)
     void producePorts(void)
     {
@@ -330,6 +432,8 @@ private:
     std::vector<int32_t> _pkCh; std::vector<int64_t> _pkLen; std::vector<int16_t> _pkSyms;
     std::vector<int32_t> _sigCh, _sigErr; std::vector<float> _sigPow, _sigSnr;
     std::vector<cf32> _stRaw, _stDec, _stFft;               // host staging of the three ports, [channel][capacity]
+    std::shared_ptr<PinnedPool> _pool;                      // the input slabs of all ports (getInputBufferManager)
+    std::vector<int64_t> _first; const char *_rowBase = nullptr; size_t _rowRuns = 0;
 };
 
 static Pothos::BlockRegistry registerLoRaDemodBatch("/lora/lora_demod_batch", &LoRaDemodBatch::make);

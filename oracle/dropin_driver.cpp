@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -36,6 +37,65 @@ struct BatchHandle
     int64_t works;
     bool ports, ready;
     std::vector<size_t> need;                                   // per channel: 2N, what a work() call of that channel wants (LoRaDemod.cpp:148)
+    bool slabs;                                                 // inputs through the block's own input buffer managers (getInputBufferManager)
+    std::vector<Pothos::BufferManager::Sptr> mgr;               // ... one per input port
+};
+
+/*! The framework's side of the input ports, two ways. VIEWS: a port's buffer is a window into the caller's array (ordinary host
+ * memory), the unconsumed remainder stays where it is. SLABS: every arrival is written into the next buffer of the port's own
+ * manager -- the one the block returned from getInputBufferManager() -- behind the (< 2N) samples the block left unconsumed, which the
+ * framework's accumulator carries over; the buffer before goes back to its manager. `sourceSeconds` collects the time spent writing
+ * the arriving samples: the upstream block's work, not this block's. */
+struct Feeder
+{
+    BatchHandle *h;
+    const float *iq; size_t spc;
+    std::vector<size_t> pos;                                    // samples consumed so far (absolute)
+    std::vector<size_t> have;                                   // slabs: samples of the channel that have arrived
+    std::vector<char *> cur; std::vector<size_t> curLen, curOff; // slabs: the buffer being presented, its valid samples, the read offset
+    double sourceSeconds;
+    Feeder(BatchHandle *h_, const float *iq_, const size_t spc_) : h(h_), iq(iq_), spc(spc_), pos(h_->B, 0), have(h_->B, 0), cur(h_->B, nullptr), curLen(h_->B, 0), curOff(h_->B, 0), sourceSeconds(0.0) {}
+    //! samples [have, w) of every channel arrive
+    void arrive(const size_t w)
+    {
+        const size_t B = h->B;
+        if (!h->slabs) { for (size_t c = 0; c < B; c++) have[c] = w; return; }
+        for (size_t c = 0; c < B; c++)
+        {
+            Pothos::BufferManager &m = *h->mgr[c];
+            const size_t rem = curLen[c] - curOff[c], add = w - have[c];
+            if (m.empty() || m.front().length < (rem + add) * sizeof(cf32)) throw std::runtime_error("input slab too small for an arrival");
+            char *next = m.front().as<char *>();
+            m.pop((rem + add) * sizeof(cf32));
+            if (rem) std::memcpy(next, cur[c] + curOff[c] * sizeof(cf32), rem * sizeof(cf32));      // the accumulator's carry-over (< 2N samples)
+            const auto t0 = std::chrono::steady_clock::now();
+            std::memcpy(next + rem * sizeof(cf32), iq + 2 * (c * spc + have[c]), add * sizeof(cf32)); // the upstream block produces
+            sourceSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            Pothos::ManagedBuffer old;
+            if (cur[c] && m.popHeld(old)) m.push(old);              // the buffer before is free again
+            cur[c] = next; curLen[c] = rem + add; curOff[c] = 0; have[c] = w;
+        }
+    }
+    //! what the ports show the block now; true if some channel has a call's worth
+    bool present(void)
+    {
+        bool any = false;
+        for (size_t c = 0; c < h->B; c++)
+        {
+            auto in = h->block->input(int(c));
+            if (h->slabs) { in->_elems = curLen[c] - curOff[c]; in->_buff = Pothos::BufferChunk::view(cur[c] + curOff[c] * sizeof(cf32), in->_elems * sizeof(cf32)); }
+            else { in->_elems = have[c] - pos[c]; in->_buff = Pothos::BufferChunk::view(const_cast<float *>(iq) + 2 * (c * spc + pos[c]), in->_elems * sizeof(cf32)); }
+            in->consumed = 0;
+            any = any || in->_elems >= h->need[c];
+        }
+        return any;
+    }
+    size_t consumed(const size_t c)
+    {
+        const size_t used = h->block->input(int(c))->consumed;
+        pos[c] += used; curOff[c] += used;
+        return used;
+    }
 };
 
 //! after the last setter, before the first work(): the framework allocates the port buffers the block's buffer-manager hook asks for
@@ -52,6 +112,16 @@ static void prepare(BatchHandle *h)
         h->block->output("raw" + s)->_buff = Pothos::BufferChunk::view(h->rawBuf[c].data(), nbRaw);
         h->block->output("dec" + s)->_buff = Pothos::BufferChunk::view(h->decBuf[c].data(), nbRaw);
         h->block->output("fft" + s)->_buff = Pothos::BufferChunk::view(h->fftBuf[c].data(), nbFft);
+    }
+    if (h->slabs)
+    {
+        // the framework asks the block for the buffer manager of every input port (LoRaDemod.cpp:346-357 is the reference's answer)
+        h->mgr.resize(h->B);
+        for (size_t c = 0; c < h->B; c++)
+        {
+            h->mgr[c] = h->block->getInputBufferManager(std::to_string(c), "");
+            if (!h->mgr[c]) { h->mgr.clear(); h->slabs = false; break; }
+        }
     }
     h->block->activate();
     h->ready = true;
@@ -73,6 +143,7 @@ void *loradrop_batch_new(const size_t sf, const size_t channels, const size_t ma
     h->rawBuf.resize(channels); h->decBuf.resize(channels); h->fftBuf.resize(channels); h->log.resize(channels);
     for (size_t c = 0; c < channels; c++) h->log[c].consumed = 0;
     h->need.assign(channels, 2 * h->N);
+    h->slabs = false;
     return h;
 }
 
@@ -117,17 +188,19 @@ int64_t loradrop_batch_run(void *p, const float *iq, const size_t samplesPerChan
     auto h = reinterpret_cast<BatchHandle *>(p);
     const size_t B = h->B;
     prepare(h);
-    std::vector<size_t> pos(B, 0);
+    Feeder f(h, iq, samplesPerChannel);
+    // (slabs: the stream arrives in pieces a slab can hold; views: all at once)
+    const size_t piece = h->slabs ? h->maxWindows * h->N : samplesPerChannel;
+    try
+    {
+    for (size_t w = piece < samplesPerChannel ? piece : samplesPerChannel; ; w = w + piece < samplesPerChannel ? w + piece : samplesPerChannel)
+    {
+    f.arrive(w);
     while (true)
     {
-        bool any = false;
+        const bool any = f.present();
         for (size_t c = 0; c < B; c++)
         {
-            auto in = h->block->input(int(c));
-            in->_elems = samplesPerChannel - pos[c];
-            in->_buff = Pothos::BufferChunk::view(const_cast<float *>(iq) + 2 * (c * samplesPerChannel + pos[c]), in->_elems * sizeof(cf32));
-            in->consumed = 0;
-            any = any || in->_elems >= h->need[c];
             const std::string s = std::to_string(c);
             for (const char *port : { "raw", "dec", "fft" }) { auto o = h->block->output(port + s); o->produced = 0; o->labels.clear(); }
         }
@@ -153,13 +226,27 @@ int64_t loradrop_batch_run(void *p, const float *iq, const size_t samplesPerChan
                 L.packets.push_back(syms);
             }
             out->messages.clear();
-            const size_t used = h->block->input(int(c))->consumed;
-            pos[c] += used; L.consumed += used; progressed += used;
+            const size_t used = f.consumed(c);
+            L.consumed += used; progressed += used;
         }
         if (progressed == 0) break;     // cannot happen; guards the loop
     }
+    if (w >= samplesPerChannel) break;
+    }
+    }
+    catch (const std::exception &) { return -2; }
     return h->works;
 }
+
+//! inputs through the block's own input buffer managers from now on (before the first run): returns 1 if the block supplies them
+int loradrop_batch_use_input_slabs(void *p, const int on)
+{
+    auto h = reinterpret_cast<BatchHandle *>(p);
+    if (h->ready) return -1;
+    h->slabs = on != 0;
+    return 0;
+}
+int loradrop_batch_input_slabs_active(void *p) { auto h = reinterpret_cast<BatchHandle *>(p); return h->ready && h->slabs ? 1 : 0; }
 
 /*! The block as a receiver, timed: the channels' samples ARRIVE in chunks of `chunk` per channel (a source block upstream); after every
  * arrival the scheduler calls work() with what each input holds -- the unconsumed remainder and the new samples, in ordinary host
@@ -171,10 +258,9 @@ int loradrop_batch_bench(void *p, const float *iq, const size_t samplesPerChanne
     auto h = reinterpret_cast<BatchHandle *>(p);
     const size_t B = h->B;
     prepare(h);
-    std::vector<size_t> pos(B, 0);
-    std::vector<Pothos::InputPort *> in(B);
+    Feeder f(h, iq, samplesPerChannel);
     std::vector<Pothos::OutputPort *> msg(B);
-    for (size_t c = 0; c < B; c++) { in[c] = h->block->input(int(c)); msg[c] = h->block->output(int(c)); }
+    for (size_t c = 0; c < B; c++) msg[c] = h->block->output(int(c));
     double works = 0, packets = 0, consumed = 0;
     const size_t sig0 = h->block->signals.size();
     const auto t0 = std::chrono::steady_clock::now();
@@ -182,17 +268,10 @@ int loradrop_batch_bench(void *p, const float *iq, const size_t samplesPerChanne
     {
         for (size_t w = chunk < samplesPerChannel ? chunk : samplesPerChannel; ; w = w + chunk < samplesPerChannel ? w + chunk : samplesPerChannel)
         {
+            f.arrive(w);
             while (true)
             {
-                bool any = false;
-                for (size_t c = 0; c < B; c++)
-                {
-                    in[c]->_elems = w - pos[c];
-                    in[c]->_buff = Pothos::BufferChunk::view(const_cast<float *>(iq) + 2 * (c * samplesPerChannel + pos[c]), in[c]->_elems * sizeof(cf32));
-                    in[c]->consumed = 0;
-                    any = any || in[c]->_elems >= h->need[c];
-                }
-                if (!any) break;
+                if (!f.present()) break;
                 if (h->ports)
                     for (size_t c = 0; c < B; c++)
                     {
@@ -206,7 +285,7 @@ int loradrop_batch_bench(void *p, const float *iq, const size_t samplesPerChanne
                 {
                     packets += double(msg[c]->messages.size());
                     msg[c]->messages.clear();
-                    pos[c] += in[c]->consumed; progressed += in[c]->consumed;
+                    progressed += f.consumed(c);
                 }
                 consumed += double(progressed);
                 if (progressed == 0) break;
@@ -215,7 +294,8 @@ int loradrop_batch_bench(void *p, const float *iq, const size_t samplesPerChanne
         }
     }
     catch (const std::exception &) { return -2; }
-    out[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // (the time the SOURCE spent writing the arriving samples into the input buffers is the upstream block's, not this block's)
+    out[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - f.sourceSeconds;
     out[1] = works; out[2] = packets; out[3] = consumed; out[4] = double(h->block->signals.size() - sig0);
     h->block->signals.clear();
     return 0;
@@ -268,6 +348,82 @@ double loradrop_batch_get_signal(void *p, const size_t i, char *buf, const size_
     const auto &r = reinterpret_cast<BatchHandle *>(p)->block->signals.at(i);
     if (cap) { std::strncpy(buf, r.name.c_str(), cap - 1); buf[cap - 1] = 0; }
     return r.value;
+}
+
+
+/***********************************************************************
+ * lora_sdr_amd/pothos/LoRaDecoderBatch.cpp (/lora/lora_decoder_batch): messages in on B inputs, one work(), messages and the
+ * "dropped" signal out. tests/test_gpu_dropin.py compares it, message by message, with the verbatim LoRaDecoder.cpp block.
+ **********************************************************************/
+void *loradrop_decoder_new(const size_t channels)
+{
+    auto it = Pothos::BlockRegistry::table().find("/lora/lora_decoder_batch");
+    if (it == Pothos::BlockRegistry::table().end()) return nullptr;
+    try { return it->second(channels); }
+    catch (const std::exception &) { return nullptr; }
+}
+
+void loradrop_decoder_free(void *p) { delete reinterpret_cast<Pothos::Block *>(p); }
+
+int loradrop_decoder_set(void *p, const char *name, const double v)
+{
+    auto b = reinterpret_cast<Pothos::Block *>(p);
+    auto it = b->calls.find(name);
+    if (it == b->calls.end()) return -1;
+    try { it->second(v); } catch (const std::exception &) { return -2; }
+    return 0;
+}
+
+int loradrop_decoder_set_string(void *p, const char *name, const char *v)
+{
+    auto b = reinterpret_cast<Pothos::Block *>(p);
+    auto it = b->stringCalls.find(name);
+    if (it == b->stringCalls.end()) return -1;
+    try { it->second(v); } catch (const std::exception &) { return -2; }
+    return 0;
+}
+
+int loradrop_decoder_activate(void *p)
+{
+    try { reinterpret_cast<Pothos::Block *>(p)->activate(); } catch (const std::exception &) { return -2; }
+    return 0;
+}
+
+//! one symbol packet onto input `channel` (what /lora/lora_demod_batch posts there)
+void loradrop_decoder_push(void *p, const size_t channel, const uint16_t *syms, const size_t n)
+{
+    Pothos::Packet pkt;
+    pkt.payload = Pothos::BufferChunk(typeid(uint16_t), n ? n : 1);
+    pkt.payload.length = n * sizeof(uint16_t);
+    if (n) std::memcpy(pkt.payload.as<void *>(), syms, n * sizeof(uint16_t));
+    reinterpret_cast<Pothos::Block *>(p)->input(int(channel))->_msgs.push_back(Pothos::Object(pkt));
+}
+
+int loradrop_decoder_work(void *p)
+{
+    try { reinterpret_cast<Pothos::Block *>(p)->work(); } catch (const std::exception &) { return -2; }
+    return 0;
+}
+
+size_t loradrop_decoder_num_out(void *p, const size_t channel) { return reinterpret_cast<Pothos::Block *>(p)->output(int(channel))->messages.size(); }
+size_t loradrop_decoder_out_len(void *p, const size_t channel, const size_t i) { return reinterpret_cast<Pothos::Block *>(p)->output(int(channel))->messages.at(i).size(); }
+void loradrop_decoder_get_out(void *p, const size_t channel, const size_t i, void *out)
+{
+    const auto &m = reinterpret_cast<Pothos::Block *>(p)->output(int(channel))->messages.at(i);
+    if (!m.empty()) std::memcpy(out, m.data(), m.size());
+}
+//! the values the block emitted on "dropped", in order
+size_t loradrop_decoder_num_dropped_signals(void *p)
+{
+    size_t n = 0;
+    for (const auto &sg : reinterpret_cast<Pothos::Block *>(p)->signals) n += sg.name == "dropped";
+    return n;
+}
+double loradrop_decoder_dropped_signal(void *p, const size_t i)
+{
+    size_t n = 0;
+    for (const auto &sg : reinterpret_cast<Pothos::Block *>(p)->signals) if (sg.name == "dropped" && n++ == i) return sg.value;
+    return -1.0;
 }
 
 } // extern "C"

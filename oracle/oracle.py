@@ -466,6 +466,8 @@ class DropInBatch:
         L.loradrop_batch_packet_len.restype = C.c_size_t
         L.loradrop_batch_packet_len.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
         L.loradrop_batch_get_packet.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, _i16p]
+        L.loradrop_batch_use_input_slabs.argtypes = [C.c_void_p, C.c_int]
+        L.loradrop_batch_input_slabs_active.argtypes = [C.c_void_p]
         L.loradrop_batch_num_signals.restype = C.c_size_t
         L.loradrop_batch_num_signals.argtypes = [C.c_void_p]
         L.loradrop_batch_get_signal.restype = C.c_double
@@ -488,6 +490,14 @@ class DropInBatch:
         if not may_fail:
             assert rc == 0, (name, rc)
         return rc
+
+    def use_input_slabs(self, on=True):
+        """before the first run: the inputs arrive through the block's own input buffer managers (getInputBufferManager: pinned slabs)
+        instead of as views into the caller's array"""
+        assert self.L.loradrop_batch_use_input_slabs(self.h, int(bool(on))) == 0
+
+    def input_slabs_active(self):
+        return bool(self.L.loradrop_batch_input_slabs_active(self.h))
 
     def bench(self, iq, chunk):
         """the block as a receiver, timed (oracle/dropin_driver.cpp::loradrop_batch_bench): iq (channels, samples) complex64 in ordinary
@@ -535,3 +545,72 @@ class DropInBatch:
             v = self.L.loradrop_batch_get_signal(self.h, i, buf, 64)
             sig.append((buf.value.decode(), v))
         return out, sig, works
+
+
+class DropInDecoder:
+    """lora_sdr_amd/pothos/LoRaDecoderBatch.cpp (/lora/lora_decoder_batch) compiled against the fake Pothos and linked with
+    liblorahip.so (oracle/_ref/libloradrop.so), driven by oracle/dropin_driver.cpp: symbol packets onto its inputs, one work(),
+    the byte packets and the values of the "dropped" signal back."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(DROPIN_SO)
+
+    def __init__(self, channels):
+        L = self.L = C.CDLL(DROPIN_SO)
+        L.loradrop_decoder_new.restype = C.c_void_p
+        L.loradrop_decoder_new.argtypes = [C.c_size_t]
+        L.loradrop_decoder_free.argtypes = [C.c_void_p]
+        L.loradrop_decoder_set.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.loradrop_decoder_set_string.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.loradrop_decoder_activate.argtypes = [C.c_void_p]
+        L.loradrop_decoder_push.argtypes = [C.c_void_p, C.c_size_t, _u16p, C.c_size_t]
+        L.loradrop_decoder_work.argtypes = [C.c_void_p]
+        L.loradrop_decoder_num_out.restype = C.c_size_t
+        L.loradrop_decoder_num_out.argtypes = [C.c_void_p, C.c_size_t]
+        L.loradrop_decoder_out_len.restype = C.c_size_t
+        L.loradrop_decoder_out_len.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        L.loradrop_decoder_get_out.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.loradrop_decoder_num_dropped_signals.restype = C.c_size_t
+        L.loradrop_decoder_num_dropped_signals.argtypes = [C.c_void_p]
+        L.loradrop_decoder_dropped_signal.restype = C.c_double
+        L.loradrop_decoder_dropped_signal.argtypes = [C.c_void_p, C.c_size_t]
+        self.B = channels
+        self.h = L.loradrop_decoder_new(channels)
+        if not self.h:
+            raise RuntimeError("LoRaDecoderBatch could not be created (the block is not registered)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.loradrop_decoder_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def configure(self, sf, ppm=0, cr="4/8", crcc=False, interleaving=True, error_check=False, explicit=True, hdr=False, data_length=8):
+        for name, v in (("setSpreadFactor", sf), ("setSymbolSize", ppm), ("enableCrcc", crcc), ("enableInterleaving", interleaving), ("enableErrorCheck", error_check),
+                        ("enableExplicit", explicit), ("enableHdr", hdr), ("setDataLength", data_length)):
+            assert self.L.loradrop_decoder_set(self.h, name.encode(), float(v)) == 0, name
+        return self.L.loradrop_decoder_set_string(self.h, b"setCodingRate", cr.encode())
+
+    def activate(self):
+        return int(self.L.loradrop_decoder_activate(self.h))
+
+    def push(self, channel, syms):
+        syms = np.ascontiguousarray(syms, np.uint16)
+        self.L.loradrop_decoder_push(self.h, channel, _ptr(syms, _u16p), syms.size)
+
+    def work(self):
+        """0, or -2 if the block threw"""
+        return int(self.L.loradrop_decoder_work(self.h))
+
+    def outputs(self, channel, interleaving=True):
+        res = []
+        for i in range(self.L.loradrop_decoder_num_out(self.h, channel)):
+            a = np.zeros(self.L.loradrop_decoder_out_len(self.h, channel, i), np.uint8)
+            self.L.loradrop_decoder_get_out(self.h, channel, i, a.ctypes.data)
+            res.append(a if interleaving else a.view(np.uint16))
+        return res
+
+    def dropped_signals(self):
+        return [int(self.L.loradrop_decoder_dropped_signal(self.h, i)) for i in range(self.L.loradrop_decoder_num_dropped_signals(self.h))]

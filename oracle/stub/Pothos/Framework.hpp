@@ -112,18 +112,79 @@ struct BufferManagerArgs
     long nodeAffinity;
 };
 
-struct BufferManager
+//! memory + the thing that keeps it alive (Pothos/Framework/SharedBuffer.hpp: the container form is how a block wraps memory of its own)
+struct SharedBuffer
+{
+    SharedBuffer(void) : _address(0), _length(0) {}
+    SharedBuffer(const size_t address, const size_t length, std::shared_ptr<void> container) : _address(address), _length(length), _container(container) {}
+    size_t getAddress(void) const { return _address; }
+    size_t getLength(void) const { return _length; }
+    size_t _address, _length;
+    std::shared_ptr<void> _container;
+};
+
+struct BufferManager;
+//! a buffer that belongs to a manager's pool (Pothos/Framework/ManagedBuffer.hpp)
+struct ManagedBuffer
+{
+    ManagedBuffer(void) : _slab(0) {}
+    void reset(std::shared_ptr<BufferManager> manager, const SharedBuffer &buff, const size_t slabIndex = 0) { _manager = manager; _buff = buff; _slab = slabIndex; }
+    const SharedBuffer &getBuffer(void) const { return _buff; }
+    size_t getSlabIndex(void) const { return _slab; }
+    std::weak_ptr<BufferManager> _manager;
+    SharedBuffer _buff;
+    size_t _slab;
+};
+
+/*! Pothos/Framework/BufferManager.hpp, the part a custom manager overrides: init() makes the pool, front() is the next buffer a producer
+ * may fill, pop() takes it out of the ready queue, push() gives a buffer back. make("generic", args) is the framework's own: heap
+ * buffers. (The recording driver plays the framework: it asks the block for its managers and moves the buffers.) */
+struct BufferManager : public std::enable_shared_from_this<BufferManager>
 {
     typedef std::shared_ptr<BufferManager> Sptr;
+    BufferManager(void) : _initialized(false), _frontIndex(0) {}
+    virtual ~BufferManager(void) {}
     static Sptr make(const std::string &name, const BufferManagerArgs &args)
     {
         Sptr m(new BufferManager());
         m->name = name;
-        m->args = args;
+        m->init(args);
         return m;
     }
+    virtual void init(const BufferManagerArgs &a)
+    {
+        args = a;
+        _initialized = true;
+        _ready.clear();
+        for (size_t i = 0; i < a.numBuffers; i++)
+        {
+            std::shared_ptr<char> mem(new char[a.bufferSize ? a.bufferSize : 1], std::default_delete<char[]>());
+            ManagedBuffer b;
+            b.reset(shared_from_this(), SharedBuffer(size_t(mem.get()), a.bufferSize, mem), i);
+            _ready.push_back(b);
+        }
+        refreshFront();
+    }
+    bool initialized(void) const { return _initialized; }
+    virtual bool empty(void) const { return _ready.empty(); }
+    const BufferChunk &front(void) const { return _front; }
+    virtual void pop(const size_t) { if (!_ready.empty()) { _held.push_back(_ready.front()); _ready.pop_front(); } refreshFront(); }
+    virtual void push(const ManagedBuffer &buff) { _ready.push_back(buff); refreshFront(); }
+    //! (driver side) the buffer pop() took out most recently but one ... the oldest still held: what goes back first
+    bool popHeld(ManagedBuffer &out) { if (_held.empty()) return false; out = _held.front(); _held.pop_front(); return true; }
     std::string name;
     BufferManagerArgs args;
+protected:
+    void setFrontBuffer(const BufferChunk &b) { _front = b; }
+    void refreshFront(void)
+    {
+        if (_ready.empty()) { _front = BufferChunk(); return; }
+        _front = BufferChunk::view(reinterpret_cast<void *>(_ready.front().getBuffer().getAddress()), _ready.front().getBuffer().getLength());
+    }
+    bool _initialized;
+    size_t _frontIndex;
+    BufferChunk _front;
+    std::deque<ManagedBuffer> _ready, _held;
 };
 
 struct InputPort

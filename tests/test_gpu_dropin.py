@@ -274,3 +274,133 @@ def test_batch_block_with_a_spreading_factor_per_channel(gpu, oracle):
         assert [n_ for n_, _ in gs] == [n_ for n_, _ in want["signals"]]
         assert np.allclose([v for _, v in gs], [v for _, v in want["signals"]], rtol=0, atol=TOL_DB)
     blk.close()
+
+
+@pytest.mark.gpu
+def test_decoder_batch_block_equals_the_verbatim_decoder_block(gpu, ref, golden):
+    """lora_sdr_amd/pothos/LoRaDecoderBatch.cpp (/lora/lora_decoder_batch: the LoRaDecoder setters, B message inputs, one launch per
+    work()) compiled against the fake Pothos: golden symbol packets with fresh random damage on 7 channels, per decoder configuration
+    -- every message it posts, per channel and in order, and every value of its "dropped" signal equal what the verbatim
+    LoRaDecoder.cpp block posts and emits for the same packets one at a time."""
+    from oracle.oracle import DropInDecoder
+    if not DropInDecoder.available():
+        pytest.skip("oracle/_ref/libloradrop.so not built")
+    RDD_TO_CR = {0: "4/4", 1: "4/5", 2: "4/6", 3: "4/7", 4: "4/8"}
+    g = golden("codec_kat.npz")
+    rng = np.random.default_rng(77)
+    B, seen, n_msgs, n_drops = 7, set(), 0, 0
+    for i in range(int(g["count"])):
+        cfg = tuple(int(v) for v in g["cfg_%d" % i])
+        if cfg in seen or len(seen) >= 24 or int(g["res_%d" % i][2]) != 0:
+            continue
+        seen.add(cfg)
+        sf, ppm, rdd, crcc, inter, ec, explicit, hdr, dlen = cfg
+        kw = dict(ppm=ppm, cr=RDD_TO_CR[rdd], crcc=bool(crcc), interleaving=bool(inter), error_check=bool(ec), explicit=bool(explicit), hdr=bool(hdr), data_length=dlen)
+        base = g["syms_%d" % i]
+        blk = DropInDecoder(B)
+        assert blk.configure(sf, **kw) == 0
+        assert blk.activate() == 0
+        want = [[] for _ in range(B)]
+        drops = 0
+        for k in range(60):
+            s = base.copy()
+            for j in rng.integers(0, s.size, int(rng.integers(0, 4))):
+                s[int(j)] = int(rng.integers(0, 1 << sf)) if rng.random() < 0.5 else (int(s[int(j)]) ^ (1 << int(rng.integers(0, sf))))
+            if rng.random() < 0.15:
+                s = s[:int(rng.integers(0, s.size))]                  # truncated (shorter than a header: nothing is posted)
+            c = int(rng.integers(0, B))
+            blk.push(c, s)
+            o, d = ref.decode(sf, s, **kw)                            # a fresh verbatim block per packet: d = 1 if it called drop()
+            drops += d
+            if o is not None:
+                want[c].append(o)
+        assert blk.work() == 0
+        for c in range(B):
+            got = blk.outputs(c, interleaving=bool(inter))
+            assert len(got) == len(want[c]), (cfg, c)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want[c])), (cfg, c)
+            n_msgs += len(got)
+        # activate() emits 0 (LoRaDecoder.cpp:192), every drop() the running count (:403-404)
+        assert blk.dropped_signals() == list(range(0, drops + 1)), cfg
+        n_drops += drops
+        assert blk.work() == 0 and sum(len(blk.outputs(c)) for c in range(B)) == sum(len(w) for w in want)     # nothing waiting: nothing posted
+        blk.close()
+    assert len(seen) >= 16 and n_msgs > 500 and n_drops > 20
+    # the setters' error behaviour is the reference's
+    blk = DropInDecoder(2)
+    assert blk.configure(7, cr="4/9") == -2                           # Pothos::InvalidArgumentException (LoRaDecoder.cpp:150)
+    assert blk.configure(7, ppm=9) == 0
+    blk.push(0, np.zeros(16, np.uint16))
+    assert blk.work() == -2                                           # Pothos::Exception "failed check: PPM <= SF" (:201)
+    blk.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sf", [7, 10, 12])
+def test_batch_block_through_its_own_pinned_input_slabs(gpu, golden, oracle, sf):
+    """The block's getInputBufferManager() (the counterpart of LoRaDemod.cpp:346-357): the driver -- playing the framework -- takes
+    every input's buffers from the manager the block returned (pinned slabs, all ports' slabs in one allocation), writes each arrival
+    behind the unconsumed remainder, and the block uploads a work()'s inputs as rows of that block of memory
+    (lorahip_demod_run_host_rows). Consumption, packets and signals equal the unpatched reference block's."""
+    from oracle.oracle import Ref, REF_VARIANTS, DropInBatch
+    _need(REF_VARIANTS["dropin"])
+    _need(REF_VARIANTS["-O2"])
+    rng = np.random.default_rng(300 + sf)
+    iq, mtu = streams_for(golden, oracle, sf, rng)
+    ref = Ref("-O2")
+    for max_windows in (6, 64):                                 # arrivals of 6 windows (many work() calls, remainders carried over) and of everything at once
+        blk = DropInBatch(sf, 3, max_windows=max_windows)
+        blk.use_input_slabs(True)
+        blk.set("setMTU", mtu)
+        chans, signals, works = blk.run(iq)
+        assert blk.input_slabs_active() and works >= 1
+        sig_by_channel, cur = {}, None
+        for name, v in signals:
+            if name == "channel":
+                cur = int(v)
+            else:
+                sig_by_channel.setdefault(cur, []).append((name, v))
+        for c in range(3):
+            want = ref.demod_run(sf, iq[c], mtu=mtu)
+            got = chans[c]
+            assert got["consumed"] == int(want["consumed"].sum()), (max_windows, c)
+            assert len(got["packets"]) == len(want["packets"]) >= 2
+            assert all(np.array_equal(a, b) for a, (_, b) in zip(got["packets"], want["packets"]))
+            gs, ws = sig_by_channel.get(c, []), want["signals"]
+            assert [n for n, _ in gs] == [n for n, _ in ws]
+            assert np.allclose([v for _, v in gs], [v for _, v in ws], rtol=0, atol=TOL_DB)
+        blk.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sf", [8, 11])
+def test_run_host_rows_equals_run(gpu, oracle, sf):
+    """lorahip_demod_run_host_rows: per-channel segments of the rows of one pinned host block (ragged starts and lengths, an empty
+    channel), one strided copy -- the packets, call counts and read positions of lorahip_demod_run on the same samples"""
+    import lora_sdr_amd as L
+    from test_gpu_demod import frames
+    rng = np.random.default_rng(400 + sf)
+    N, B = 1 << sf, 6
+    streams = [frames(oracle, rng, sf, 2, 8, off=rng.uniform(-0.4, 0.4), noise=0.05, lead=int(rng.integers(0, 2 * N)))[0] for _ in range(B)]
+    streams[3] = streams[3][:0]                                 # a channel with nothing
+    first = rng.integers(0, 3 * N, B).astype(np.int64)
+    stride = int(max(f + s.size for f, s in zip(first, streams))) + 7
+    rows = L.pinned_empty((B, stride))
+    rows[...] = 0
+    for c, s in enumerate(streams):
+        rows[c, first[c]:first[c] + s.size] = s
+    a = L.LoRaDemod(sf, n_channels=B); a.set_mode(1); a.setMTU(8)
+    a.work(streams)
+    b = L.LoRaDemod(sf, n_channels=B); b.set_mode(1); b.setMTU(8)
+    b.work_host_rows(rows, first, [s.size for s in streams])
+    pa, pb = a.packets(), b.packets()
+    assert len(pa) == len(pb) >= 2 * (B - 1) and all(x[0] == y[0] and np.array_equal(x[2], y[2]) for x, y in zip(pa, pb))
+    assert a.work_calls() == b.work_calls() and a.consumed_all().tolist() == b.consumed_all().tolist()
+    # a mixed object over two parts takes the rows one by one (same results); bad geometry is refused
+    m = L.LoRaDemod(channel_sf=[sf] * B, devices=[0, 0]); m.setMTU(8)
+    m.work_host_rows(rows, first, [s.size for s in streams])
+    pm = m.packets()
+    assert sorted((x[0], x[2].tolist()) for x in pm) == sorted((x[0], x[2].tolist()) for x in pa)
+    with pytest.raises(L.LoraHipError):
+        b.work_host_rows(rows, first, [stride] * B)
+    a.close(); b.close(); m.close()
