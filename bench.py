@@ -632,7 +632,9 @@ def section_level3(env, L, sf, threads=32):
             t0 = time.perf_counter()
             while w < cap_:
                 w = min(cap_, w + chunk)
-                n_, k_ = d.receive(iq, w, rows_, async_=2)
+                # (the C entry itself: the rows are not read between the steps here, so the two stream hand-shakes with torch's stream
+                # that LoRaDemod.receive adds for a Python consumer -- an event record and a wait each way -- are left out)
+                n_, k_ = d.receive(iq, w, rows_, async_=2, order_with_torch=False)
                 n_pk_ += n_
                 calls_ += k_
                 n_work += 1

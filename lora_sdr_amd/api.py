@@ -739,7 +739,7 @@ class LoRaDemod:
         r.cap_packets, r.async_ = int(syms.shape[0]), int(async_)
         return r
 
-    def receive(self, buf, n_valid, rows, async_=True):
+    def receive(self, buf, n_valid, rows, async_=True, order_with_torch=True):
         """lorahip_demod_receive: one receiver step in one call into the library -- the append run, the completed packets packed into
         `rows` (receiver_rows()) on the device, the queue cleared. Returns (n_packets, work_calls). async_: False = wait; True = the
         rows are valid in the order of the stream the object launches on; 2 = PIPELINED: the step is launched and the packets of
@@ -747,11 +747,15 @@ class LoRaDemod:
         (the steps must stay in flight across calls), ordered against torch's current stream on the device, without a host wait:
         the launch stream follows what torch's stream holds at entry (whatever produced `buf`, whatever still reads the rows of the
         call before: lorahip_demod_stream_follow), and torch's stream waits for the packing of the rows at exit
-        (lorahip_demod_stream_wait) -- work queued on it after this call sees the rows."""
+        (lorahip_demod_stream_wait) -- work queued on it after this call sees the rows. order_with_torch=False leaves both out (two
+        event records and two stream waits per step): for a caller that orders its own streams, or times the C entry itself."""
         import torch
         r = self._rows_struct(rows, 2 if async_ == 2 else int(bool(async_)))
         n, calls = C.c_size_t(), C.c_int64()
         if async_ == 2:
+            if not order_with_torch:
+                check(self._lib.lorahip_demod_receive(self._h, _dptr(buf), int(buf.shape[1]), int(n_valid), C.byref(r), C.byref(n), C.byref(calls)), "lorahip_demod_receive")
+                return n.value, calls.value
             ts = C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)
             check(self._lib.lorahip_demod_stream_follow(self._h, ts), "lorahip_demod_stream_follow")
             try:

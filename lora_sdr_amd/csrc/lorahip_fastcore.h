@@ -15,7 +15,7 @@ namespace lorahip {
  **********************************************************************/
 template <int LOG2N_, int LOG2T_, int VEC_, int NPH_, int PB1_, int PB2_, int WAVES_PER_SIMD_,
           int X0ROT_, int X0PAD_, int X0S_, int X0D_, bool CH_LDS_, bool TW_ALL_LDS_, int PREFETCH_, bool NT_ = false, bool NB_SELECT_ = false, bool X1_SWAP_ = false, bool TW_MID_REG_ = false, bool XCD_CONTIG_ = false,
-          int PB3_ = 0>
+          int PB3_ = 0, int X1PAD_ = 8>
 struct FastCfg
 {
     static constexpr int PREFETCH = PREFETCH_;        // next window set's loads: 0 none (loaded at the top), 1 issued after the dechirp of this set, 2 at the top of this set
@@ -57,7 +57,7 @@ struct FastCfg
     static constexpr int X0ELEMS = NL * RS0 + X0D_;             // per wave
     // exchange 1 (3 phases): per window, element (rl, rh, col) at rh*X1 + col*R + rl
     static constexpr int G1 = 1 << (bound(2) - bound(1));
-    static constexpr int X1 = G1 * R + 8;
+    static constexpr int X1 = G1 * R + X1PAD_;                  // row pad of the position-indexed exchange (tools/lds_conflicts_lanes.py)
     static constexpr int X1ROWS = N / (G1 * R);                 // rows of 2^PB2 positions (+8 pad) per window
     static constexpr int X1ELEMS = NPH_ >= 3 ? WPW * X1ROWS * X1 : 0;   // per wave
     static constexpr int XELEMS = (X0ELEMS > X1ELEMS ? X0ELEMS : X1ELEMS) + (N > X0ELEMS ? N - X0ELEMS : 0) / 2 * 0;

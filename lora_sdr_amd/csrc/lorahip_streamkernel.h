@@ -97,9 +97,8 @@ demodStream(const StreamArgs s)
     // with wantFi = 1 whose window is not squelched -- or in any case for wantFi = 2: the second window of a FRAMESYNC call, whose
     // fIndex the reference consumes without looking at that window's own snr (:203, :217-221). wantSq / wantFi are per lane group;
     // the branches are wave-uniform.
-    // Signals without a trace (lorahip_demod_set_signals): the one call per packet that emits them (DOWNCHIRP1, :267-269) takes the
-    // traced path -- power and snr evaluated -- in the passes where some channel of the wave is in that state; every decision is
-    // the same on either path.
+    // Signals without a trace (lorahip_demod_set_signals): the one call per packet that emits them (DOWNCHIRP1, :267-269) evaluates
+    // power and snr through the exact chain (wantLogs); every decision is the same on either path.
     const bool all = s.calls != nullptr;
     const bool sig = s.sigOut != nullptr;
 #ifdef LORAHIP_STREAM_TIMING
@@ -115,7 +114,7 @@ demodStream(const StreamArgs s)
     constexpr bool PF = C::PREFETCH != 0;
     v2f xp[PF ? R : 1][PF ? VEC : 1];
     long long pfOff = -1;
-    auto detect = [&](const bool full, const bool on, const bool wantSq, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
+    auto detect = [&](const bool full, const bool on, const bool wantSq, const bool wantLogs, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
         v2f x[R][VEC];
@@ -250,9 +249,10 @@ demodStream(const StreamArgs s)
             squelched = squelchQuickF(bestV, totF, s.thresh, K::QUICK_REL_ERR, sure);
             power = powerAvg = fIndex = 0.0f;                                           // not consumed without a trace
             const bool exact = on && wantSq && !sure;
+            const bool logs = on && wantLogs;                                          // the call of a packet that emits the signals (:267-269)
             const bool fi = on && (wantFi == 2 || (wantFi == 1 && (!sure || !squelched)));
             TMARK(7);
-            if (__any(exact || fi))
+            if (__any(exact || logs || fi))
             {
                 if (staged) K::neighbours(vl, F, bestI, lane, t, l, r);
                 else K::template neighbours<true>(vl, F, bestI, lane, t, l, r);
@@ -261,7 +261,7 @@ demodStream(const StreamArgs s)
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
-                if (__any(exact))
+                if (__any(exact || logs))
                 {
                     // LoRaDetector.hpp:36-48's double total, in scan()'s association (the bins are still in registers)
                     {
@@ -272,7 +272,7 @@ demodStream(const StreamArgs s)
                     tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
                     squelched = (power - powerAvg) < s.thresh;                           // the quick decision where it was sure, by construction
                     if (exact && t == 0 && nearSquelch(power - powerAvg, s.thresh)) atomicAdd(s.near, 1u);
-                    power = powerAvg = 0.0f;
+                    power = logs ? power : 0.0f; powerAvg = logs ? powerAvg : 0.0f;     // (what the signal record takes; nobody else reads them)
                 }
                 else fIndex = fIndexPaired(bestV, l, r, lane);
             }
@@ -313,8 +313,11 @@ demodStream(const StreamArgs s)
         const long long here = base + st.pos + (second ? N : 0);
         const bool fs = st.state == ST_FRAMESYNC;
         bool squelched;
-        const bool full = all || (sig && __any(live && !second && st.state == ST_DOWNCHIRP1));
-        detect(full, live, !second && (fs || st.state == ST_DATASYMBOLS), second ? 2 : (fs ? 1 : 0), here, st.downTable != 0, st.fineTuneIndex,
+        // Signals without a trace: the one call per packet that emits them evaluates power and snr through the exact chain of the
+        // untraced path (the same operations on the same operands as the traced path's: the same bits) -- for the channels that are in
+        // that call, not, as the traced path would, the fp64 scan and both logarithms for every channel of the wavefront whenever one
+        // of them is there (SF7: 8 channels per wavefront, 0.378 -> of the roofline with signals kept against 0.442 without, round 5)
+        detect(all, live, !second && (fs || st.state == ST_DATASYMBOLS), sig && live && !second && st.state == ST_DOWNCHIRP1, second ? 2 : (fs ? 1 : 0), here, st.downTable != 0, st.fineTuneIndex,
                st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
         float snr = power - powerAvg;                                                   // :173 (squelched = snr < thresh, :174, comes from detect)
         // window 0: the loop commits the member (:160-162); window 1: `int ft = _fineTuneIndex` (:191) starts from the committed

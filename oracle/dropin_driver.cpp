@@ -54,7 +54,12 @@ struct Feeder
     std::vector<size_t> have;                                   // slabs: samples of the channel that have arrived
     std::vector<char *> cur; std::vector<size_t> curLen, curOff; // slabs: the buffer being presented, its valid samples, the read offset
     double sourceSeconds;
-    Feeder(BatchHandle *h_, const float *iq_, const size_t spc_) : h(h_), iq(iq_), spc(spc_), pos(h_->B, 0), have(h_->B, 0), cur(h_->B, nullptr), curLen(h_->B, 0), curOff(h_->B, 0), sourceSeconds(0.0) {}
+    Feeder(BatchHandle *h_, const float *iq_, const size_t spc_) : h(h_), iq(iq_), spc(spc_), pos(h_->B, 0), have(h_->B, 0), cur(h_->B, nullptr), curLen(h_->B, 0), curOff(h_->B, 0), sourceSeconds(0.0)
+    {
+        // a new stream on every port: whatever buffer the stream before still held goes back to its manager
+        Pothos::ManagedBuffer old;
+        if (h->slabs) for (auto &m : h->mgr) while (m->popHeld(old)) m->push(old);
+    }
     //! samples [have, w) of every channel arrive
     void arrive(const size_t w)
     {

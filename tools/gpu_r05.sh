@@ -55,6 +55,21 @@ fi
 if [[ $what == *smoke* ]]; then
   timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.txt 2>&1; tail -3 $O/${TAG}_smoke.txt
 fi
+if [[ $what == *pmcl3* ]]; then
+  # SQ counters of the streaming kernel at SF7 by channel count / lanes per channel: separate --pmc passes, no traces
+  : > $O/${TAG}_sq_counters_level3_sf7.txt
+  for cfg in ${PMCL3:-"4096 -1" "4096 0" "16384 -1" "2048 -1" "2048 0"}; do
+    set -- $cfg; cnt=$1; lanes=$2
+    d=$O/${TAG}_pmc_l3_sf7_${cnt}_lanes${lanes}
+    ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU -d ${d}_issue -o pmc --output-format csv -- \
+        python $R/tools/level3_scaling.py --sf 7 --counts $cnt --lanes $lanes --passes 2 > ${d}.log 2>&1 )
+    ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD -d ${d}_lds -o pmc --output-format csv -- \
+        python $R/tools/level3_scaling.py --sf 7 --counts $cnt --lanes $lanes --passes 2 >> ${d}.log 2>&1 )
+    python tools/pmc_kernels.py "${d}_*" demodStream "SF7 level 3, $cnt channels, lanes $lanes" | tee -a $O/${TAG}_sq_counters_level3_sf7.txt
+    grep "^SF7" ${d}.log | tail -1 | tee -a $O/${TAG}_sq_counters_level3_sf7.txt
+    rm -rf ${d}_issue ${d}_lds
+  done
+fi
 if [[ $what == *custom* ]]; then
   bash -c "$CUSTOM" > $O/${TAG}_custom.txt 2>&1; tail -${CUSTOM_TAIL:-40} $O/${TAG}_custom.txt
 fi
