@@ -70,6 +70,34 @@ if [[ $what == *pmcl3* ]]; then
     rm -rf ${d}_issue ${d}_lds
   done
 fi
+if [[ $what == *final* ]]; then
+  # the evidence profiles/r05 keeps (as tools/gpu_r02.sh final): rocprofv3 kernel stats + the average of the timed steps for the shapes
+  # bench.py reports (steady state, locked receiver, streaming demodulator), HBM traffic counters for roofline.traffic
+  for sf in ${FSF:-7 8 9 10 11 12}; do
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_sf$sf -o sf$sf --output-format csv -- \
+        python $R/bench.py --sf $sf --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_prof_sf$sf.log 2>&1 )
+    python tools/trace_tail.py $O/${TAG}_prof_sf$sf 200 | tee $O/${TAG}_sf${sf}_timed_steps.txt
+    find $O/${TAG}_prof_sf$sf -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} $O/${TAG}_sf${sf}_kernel_stats.csv
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_mov_sf$sf -o sf$sf --output-format csv -- \
+        python $R/bench.py --sf $sf --moving --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_prof_mov_sf$sf.log 2>&1 )
+    python tools/trace_tail.py $O/${TAG}_prof_mov_sf$sf 200 | tee $O/${TAG}_moving_sf${sf}_timed_steps.txt
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_str_sf$sf -o sf$sf --output-format csv -- \
+        python $R/tools/bench_demod.py --sf $sf --channels $(l3ch $sf) --modes 1 > $O/${TAG}_level3_sf$sf.txt 2>&1 )
+    find $O/${TAG}_prof_str_sf$sf -name '*kernel_stats.csv' | head -1 | xargs -r head -4 | cut -c1-200 | tee $O/${TAG}_level3_sf${sf}_kernel_stats.txt
+    tail -1 $O/${TAG}_level3_sf$sf.txt
+    rm -rf $O/${TAG}_prof_sf$sf $O/${TAG}_prof_mov_sf$sf $O/${TAG}_prof_str_sf$sf
+  done
+  rm -rf $O/pmc_FETCH_SIZE_sf* $O/pmc_WRITE_SIZE_sf*
+  for sf in ${FSF:-7 8 9 10 11 12}; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && timeout 300 rocprofv3 --pmc $c -d $O/pmc_${c}_sf$sf -o pmc --output-format csv -- \
+          python $R/bench.py --sf $sf --steps 5 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $O/pmc_${c}_sf$sf.log 2>&1 )
+    done
+  done
+  python tools/pmc_summary.py $O > $O/${TAG}_pmc_summary.txt 2>&1
+  tail -25 $O/${TAG}_pmc_summary.txt
+  rm -rf $O/pmc_FETCH_SIZE_sf* $O/pmc_WRITE_SIZE_sf*
+fi
 if [[ $what == *custom* ]]; then
   bash -c "$CUSTOM" > $O/${TAG}_custom.txt 2>&1; tail -${CUSTOM_TAIL:-40} $O/${TAG}_custom.txt
 fi
