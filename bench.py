@@ -573,13 +573,14 @@ def section_level3(env, L, sf, threads=32):
     # always emits them; one more pair of logarithms per packet and a 16-byte record)
     d.set_signals(True)
     one_pass()
-    sig_pass = one_pass()
+    sig_kms = sorted(one_pass()[1] for _ in range(5))
+    sig_pass = (None, sig_kms[0])
     n_signals = len(d.signals()[0])
     d.set_signals(False)
     d.clear_packets()
     # several ranks (bench.py --gpus N): every rank demodulates its own B channels; times are the slowest rank's, counts are sums
     best = env.max_over_ranks(*best)
-    k_mean, k_median, k_sig = env.max_over_ranks(sum(kms_all) / len(kms_all), kms_all[len(kms_all) // 2], sig_pass[1])
+    k_mean, k_median, k_sig, k_sig_median = env.max_over_ranks(sum(kms_all) / len(kms_all), kms_all[len(kms_all) // 2], sig_pass[1], sig_kms[len(sig_kms) // 2])
     (calls_all, unique_all) = env.sum_over_ranks(calls, unique_bytes)
     peak_all = HBM_PEAK_GBS * env.world
     # the RUNNING receiver: the same capture arrives in chunks of 128 (and of 8) windows. One call into the library per chunk
@@ -673,7 +674,8 @@ def section_level3(env, L, sf, threads=32):
            "frac_kernel_mean": r4(calls_all * L.bytes_per_symbol(sf) / (k_mean / 1e3) / 1e9 / peak_all),
            "frac_kernel_median": r4(calls_all * L.bytes_per_symbol(sf) / (k_median / 1e3) / 1e9 / peak_all),
            "with_signals": {"kernel_us": r4(k_sig * 1e3), "frac_kernel": r4(calls_all * L.bytes_per_symbol(sf) / (k_sig / 1e3) / 1e9 / peak_all),
-                            "signals_rank0": int(n_signals)},
+                            "frac_kernel_median": r4(calls_all * L.bytes_per_symbol(sf) / (k_sig_median / 1e3) / 1e9 / peak_all),
+                            "signals_rank0": int(n_signals), "what": "best and median of 5 launches, like frac_kernel / frac_kernel_median"},
            "lanes_log2": d.stream_lanes(),
            "unique_stream_bytes": int(unique_all), "counted_bytes": int(calls_all * L.bytes_per_symbol(sf)),
            "frac_unique": r4(unique_all / (best[1] / 1e3) / 1e9 / peak_all),

@@ -31,6 +31,21 @@ static bool isPinned(const void *p)
     return at.type == hipMemoryTypeHost;
 }
 
+//! the pinned allocation that holds p, as a host address range ([lo, hi)); false if p is not in pinned memory the runtime knows
+static bool pinnedRange(const void *p, const char *&lo, const char *&hi)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (at.type != hipMemoryTypeHost || at.devicePointer == nullptr) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, at.devicePointer) != hipSuccess || size == 0) { (void)hipGetLastError(); return false; }
+    const size_t off = size_t(static_cast<const char *>(at.devicePointer) - static_cast<const char *>(base));
+    lo = static_cast<const char *>(p) - off;
+    hi = lo + size;
+    return true;
+}
+
 struct Seg { char *dst; const char *src; size_t bytes; };
 
 //! the segments of one staging fill, copied by the calling thread and up to T-1 helpers
@@ -105,11 +120,34 @@ int gatherUpload(lorahip_ctx *ctx, void *dDstV, const void *const *src, const si
         return LORAHIP_OK;
     };
     if (u.busy[k]) { LORAHIP_TRY(hipEventSynchronize(u.ev[k])); u.busy[k] = false; }
+    size_t askedUntil = 0;
     for (size_t i = 0; i < n; i++)
     {
         const char *p = static_cast<const char *>(src[i]);
         size_t left = bytes[i];
         if (left == 0) continue;
+        // A RUN of equally long pieces at a constant distance from each other inside ONE pinned allocation -- the rows of a (channels,
+        // samples) array handed over as one pointer per channel, the slabs of a buffer pool -- is one copy: a plain one when the pieces
+        // touch, a strided one otherwise; not a copy (and a pinned-memory query) per piece.
+        if (i >= askedUntil && i + 1 < n && bytes[i + 1] == left && src[i + 1] > src[i])
+        {
+            const size_t stride = size_t(static_cast<const char *>(src[i + 1]) - p);
+            size_t m = i + 1;
+            while (m + 1 < n && bytes[m + 1] == left && static_cast<const char *>(src[m + 1]) == static_cast<const char *>(src[m]) + stride) m++;
+            const size_t rows = m - i + 1;
+            const char *lo = nullptr, *hi = nullptr;
+            if (stride >= left && rows * left >= kDirectMin && pinnedRange(p, lo, hi) && p >= lo && p + (rows - 1) * stride + left <= hi)
+            {
+                const int rc = flush();
+                if (rc != LORAHIP_OK) return rc;
+                if (stride == left) LORAHIP_TRY(hipMemcpyAsync(dDst + done, p, rows * left, hipMemcpyHostToDevice, ctx->stream));
+                else LORAHIP_TRY(hipMemcpy2DAsync(dDst + done, left, p, stride, left, rows, hipMemcpyHostToDevice, ctx->stream));
+                done += rows * left;
+                i = m;
+                continue;
+            }
+            askedUntil = m + 1;                           // (ordinary memory, or not one allocation: the run is asked about once, not per piece)
+        }
         if (left >= kDirectMin && isPinned(p))
         {
             const int rc = flush();

@@ -88,3 +88,30 @@ def test_pinned_allocation_round_trip(gpu):
     a[...] = np.arange(15, dtype=np.float32).reshape(3, 5)
     assert a.sum() == 105.0 and a.flags["C_CONTIGUOUS"]
     del a
+
+
+@pytest.mark.parametrize("pad", [0, 96])
+def test_rows_of_one_pinned_array_as_one_pointer_per_channel(gpu, oracle, pad):
+    """lorahip_demod_run over per-channel pointers that are the rows of ONE pinned array -- touching (pad 0: one plain copy) or at a
+    constant distance (a strided copy) -- instead of a copy and a pinned-memory query per piece; the packets of the list form in
+    ordinary memory"""
+    import lora_sdr_amd as L
+    from test_gpu_demod import frames
+    rng = np.random.default_rng(9 + pad)
+    sf, B = 9, 24
+    rows = [frames(oracle, rng, sf, 6, 7, off=rng.uniform(-0.3, 0.3), noise=0.05, lead=100 + 3 * c)[0] for c in range(B)]
+    n = min(r.size for r in rows)
+    assert B * n * 8 > (2 << 20)
+    pin = L.pinned_empty((B, n + pad))
+    pin[...] = 0
+    for c in range(B):
+        pin[c, :n] = rows[c][:n]
+    a = L.LoRaDemod(sf, n_channels=B); a.set_mode(1); a.setMTU(7)
+    a.work([np.array(rows[c][:n]) for c in range(B)])
+    want = a.packets()
+    b = L.LoRaDemod(sf, n_channels=B); b.set_mode(1); b.setMTU(7)
+    b.work([pin[c, :n] for c in range(B)])
+    got = b.packets()
+    assert len(got) == len(want) >= 6 * B - B
+    assert all(x[0] == y[0] and x[1] == y[1] and np.array_equal(x[2], y[2]) for x, y in zip(want, got))
+    a.close(); b.close()
