@@ -191,3 +191,73 @@ int main()
         assert r.returncode == 0, r.stdout + r.stderr
     else:
         assert r.returncode == 3 and "threw" in r.stdout, r.stdout + r.stderr
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """include/lorahip.h is a C header: a C99 translation unit (gcc -std=c99 -pedantic -Werror) that touches every level of the ABI --
+    the round-5 entry points included -- compiles, links against liblorahip.so and, without a GPU, is told so by return codes (no
+    exception, no abort crosses the boundary)."""
+    import shutil
+    import subprocess
+    import torch
+    cc = shutil.which("gcc")
+    if cc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "cabi.c"
+    src.write_text(r'''
+#include "lorahip.h"
+#include <stdio.h>
+#include <string.h>
+int main(void)
+{
+    lorahip_ctx *ctx = NULL;
+    lorahip_demod *d = NULL;
+    lorahip_decoder_cfg cfg;
+    lorahip_packet_rows rows;
+    int64_t first[2] = { 0, 0 };
+    size_t count[2] = { 0, 0 };
+    uint16_t syms[16]; int32_t nsyms[1] = { 16 }, out_len[1], dropped[1];
+    uint8_t out[48];
+    int rc;
+    memset(&cfg, 0, sizeof cfg); cfg.struct_size = sizeof cfg; cfg.sf = 7; cfg.rdd = 4; cfg.interleaving = 1; cfg.explicit_hdr = 1; cfg.data_length = 8;
+    memset(&rows, 0, sizeof rows); rows.struct_size = sizeof rows;
+    memset(syms, 0, sizeof syms);
+    if (lorahip_version() != 3) return 10;
+    rc = lorahip_create(&ctx, 0, 7);
+    printf("create %d (%s)\n", rc, lorahip_strerror(rc));
+    if (rc != LORAHIP_OK)
+    {
+        /* no device: every entry refuses politely */
+        if (lorahip_decode_packets_host(NULL, &cfg, syms, 16, nsyms, 1, out, 48, out_len, dropped) != LORAHIP_E_INVALID) return 11;
+        if (lorahip_demod_run_host_rows(NULL, NULL, 0, first, count, NULL) != LORAHIP_E_INVALID) return 12;
+        if (lorahip_demod_stream_wait(NULL, NULL) != LORAHIP_E_INVALID || lorahip_demod_stream_follow(NULL, NULL) != LORAHIP_E_INVALID) return 13;
+        if (lorahip_demod_set_stream_lanes(NULL, 0) != LORAHIP_E_INVALID || lorahip_demod_set_record_capacity(NULL, 0) != LORAHIP_E_INVALID) return 14;
+        return rc == LORAHIP_E_NODEVICE ? 3 : 4;
+    }
+    rc = lorahip_demod_create(&d, 0, 7, 2);
+    if (rc != LORAHIP_OK) return 20;
+    if (lorahip_demod_stream_lanes(d) < 3) return 21;
+    if (lorahip_demod_run_host_rows(d, NULL, 0, first, count, NULL) != LORAHIP_OK) return 22;       /* two channels with nothing: a run over nothing */
+    if (lorahip_decode_packets_host(ctx, &cfg, syms, 16, nsyms, 1, out, 48, out_len, dropped) != LORAHIP_OK) return 23;
+    printf("decoded %d dropped %d lanes 2^%d max symbols %d\n", (int)out_len[0], (int)dropped[0], lorahip_demod_stream_lanes(d), lorahip_decode_max_symbols());
+    lorahip_demod_destroy(d);
+    lorahip_destroy(ctx);
+    return 0;
+}
+''')
+    exe = tmp_path / "cabi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([cc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-llorahip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3, (r.returncode, r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_program_runs_on_the_gpu(gpu, tmp_path):
+    """the success branch of the test above, in the -m gpu set"""
+    assert gpu.cuda.is_available()
+    test_header_is_plain_c_and_a_c_program_links(tmp_path)
