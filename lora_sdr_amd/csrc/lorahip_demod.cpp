@@ -91,6 +91,7 @@ struct lorahip_demod
     char *dDense, *hDense; size_t denseBytes;   // the used part of the record arrays, packed for the copy back
     hipEvent_t evK0, evK1;           // around the streaming kernel launches of a run (lorahip_demod_kernel_ms)
     hipEvent_t evJoin;               // lorahip_demod_stream_wait
+    void *dSumScratch;               // streamSummary's partial records (more than 32768 channels)
     double kernelMs;
     int lastLaunches;                // streaming kernel launches of the last run
     lorahip_demod_ports ports;       // level-3 debug ports (all pointers null: off); DEVICE pointers (the library's own when the caller's are host buffers)
@@ -893,7 +894,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         void *sumDev = nullptr;
         const bool direct = hipHostGetDevicePointer(&sumDev, const_cast<StreamSummary *>(hSum), 0) == hipSuccess && sumDev != nullptr;
         if (!direct) (void)hipGetLastError();
-        LORAHIP_TRY(launchStreamSummary(a.state, a.nCalls, a.nSym, a.nPkt, dm->wantSignals ? a.nSig : nullptr, B, int(cap), int(capPkt), a.near,
+        LORAHIP_TRY(launchStreamSummary(a.state, a.nCalls, a.nSym, a.nPkt, dm->wantSignals ? a.nSig : nullptr, B, int(cap), int(capPkt), a.near, dm->dSumScratch,
                                         direct ? static_cast<StreamSummary *>(sumDev) : reinterpret_cast<StreamSummary *>(d + L.oSum), ctx->stream));
         if (!direct) LORAHIP_TRY(hipMemcpyAsync(h + L.oSum, d + L.oSum, sizeof(StreamSummary), hipMemcpyDeviceToHost, ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1213,7 +1214,7 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     // four calls per step: the kernel, its summary (written straight into pinned host memory), the event the next call waits on -- and
     // the previous step's packing below
     LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
-    LORAHIP_TRY(launchStreamSummary(a.state, a.nCalls, a.nSym, a.nPkt, nullptr, B, int(cap), int(capPkt), a.near, &P.hSum[set], ctx->stream));
+    LORAHIP_TRY(launchStreamSummary(a.state, a.nCalls, a.nSym, a.nPkt, nullptr, B, int(cap), int(capPkt), a.near, dm->dSumScratch, &P.hSum[set], ctx->stream));
     LORAHIP_TRY(hipEventRecord(P.ev[set], ctx->stream));
     P.pending[set] = true;
     P.k++;
@@ -1419,7 +1420,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     if (dm == nullptr) return LORAHIP_E_NOMEM;
     dm->comp = nullptr;
     dm->ctx = nullptr; dm->h = nullptr; dm->d = nullptr; dm->dIq = nullptr; dm->dIqSamples = 0;
-    dm->evK0 = nullptr; dm->evK1 = nullptr; dm->evJoin = nullptr; dm->kernelMs = 0.0;
+    dm->evK0 = nullptr; dm->evK1 = nullptr; dm->evJoin = nullptr; dm->kernelMs = 0.0; dm->dSumScratch = nullptr;
     dm->pending = new (std::nothrow) PendingLaunch();
     dm->pipe = new (std::nothrow) Pipe();
     if (dm->pending == nullptr || dm->pipe == nullptr) { delete static_cast<PendingLaunch *>(dm->pending); delete static_cast<Pipe *>(dm->pipe); delete dm; return LORAHIP_E_NOMEM; }
@@ -1456,6 +1457,10 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
         const DeviceGuard guard(device);                    // lorahip_create() restored the caller's device: allocate on OURS
         staged = hipMalloc((void **)&dm->d, dm->stageBytes) == hipSuccess &&
                  hipHostMalloc((void **)&dm->h, dm->stageBytes, hipHostMallocDefault) == hipSuccess;
+        // (more than 32768 channels: the summary of a streaming launch is reduced by one workgroup per 4096 of them and a second launch)
+        if (staged && n_channels > 32768)
+            staged = hipMalloc(&dm->dSumScratch, streamSummaryScratchBytes(n_channels)) == hipSuccess &&
+                     hipMemset(dm->dSumScratch, 0, streamSummaryScratchBytes(n_channels)) == hipSuccess;
     }
     if (!staged)
     {
@@ -1534,6 +1539,7 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->evK0) (void)hipEventDestroy(dm->evK0);
     if (dm->evK1) (void)hipEventDestroy(dm->evK1);
     if (dm->evJoin) (void)hipEventDestroy(dm->evJoin);
+    if (dm->dSumScratch) (void)hipFree(dm->dSumScratch);
     if (dm->pipe)
     {
         Pipe &P = pipeOf(dm);

@@ -161,8 +161,11 @@ struct StreamSummary
     unsigned nearSquelch, nearStep;             // the running counters (StreamArgs::near)
     int pad;
 };
+//! scratch: streamSummaryScratchBytes(nChannels) bytes of device memory (one workgroup per 1024 channels leaves a record, a second small
+//! launch adds them up; nullptr: one workgroup walks every channel)
 hipError_t launchStreamSummary(const StreamState *state, const int *nCalls, const int *nSym, const int *nPkt, const int *nSig, size_t nChannels,
-                               int cap, int capPkt, const unsigned *near, StreamSummary *out, hipStream_t stream);
+                               int cap, int capPkt, const unsigned *near, void *scratch, StreamSummary *out, hipStream_t stream);
+size_t streamSummaryScratchBytes(size_t nChannels);
 
 //! argument block of the batched decoder (lorahip_codec.hip); device pointers
 struct DecodeArgs

@@ -12,6 +12,7 @@
 // Numerics are those of the batch kernels (same FastCore, same tables); the state machine is the one of
 // lorahip_demod.cpp's host path, which tests pin against the verbatim LoRaDemod.cpp.
 #include "lorahip_streamkernel.h"
+#include <cstddef>
 
 namespace lorahip {
 
@@ -86,27 +87,35 @@ __global__ void packCopy(const short *__restrict__ symOut, const long long *__re
     for (int i = threadIdx.x; i < stride; i += blockDim.x) dst[p * stride + i] = i < len ? (unsigned short)src[i] : (unsigned short)0;
 }
 
-//! rowStart = exclusive prefix sum of nPkt (one workgroup; the channel counts are tens of thousands at most): the packets' rows are
-//! numbered on the device, so that packing needs neither an upload nor a host synchronisation. (Describing the packets in the same
-//! workgroup -- one launch less -- was tried and is slower by far: 65536 packets walked by 1024 lanes, profiles/r04; doing all three
-//! steps in one workgroup for launches of <= 2048 packets, a receiver step of a few windows, is slower too: s43_*.)
+//! rowStart = exclusive prefix sum of nPkt: the packets' rows are numbered on the device, so that packing needs neither an upload nor a
+//! host synchronisation. One workgroup per 1024 channels, and no communication between them: a workgroup first adds up the counts of all
+//! channels BEFORE its own (<= 64 KiB of reads from L2 for the last of 16 at 16384 channels), then scans its own 1024, one per lane. (Round 4's
+//! version was ONE workgroup walking every channel: 20.7 us per receiver step at 16384 channels -- a third of an 8-window step's streaming kernel,
+//! 56 us when it ran beside that kernel; profiles/r05/s22_*. Describing the packets in the same workgroup -- one launch less -- was tried and is
+//! slower by far: 65536 packets walked by 1024 lanes, profiles/r04; doing all three steps in one workgroup for launches of <= 2048 packets is
+//! slower too: s43_*.)
 __global__ void __launch_bounds__(1024) scanCounts(const int *__restrict__ nPkt, int *__restrict__ rowStart, const unsigned nChannels)
 {
-    __shared__ int sPart[1024];
-    const unsigned per = (nChannels + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < nChannels ? lo + per : nChannels;
-    int sum = 0;
-    for (unsigned c = lo; c < hi; c++) sum += nPkt[c];
-    sPart[threadIdx.x] = sum;
+    __shared__ int sWave[16];
+    const unsigned first = blockIdx.x * 1024u, c = first + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (1) the channels before this workgroup's
+    int before = 0;
+    for (unsigned i = threadIdx.x; i < first; i += 1024u) before += nPkt[i];
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+    if (lane == 0) sWave[w] = before;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1)
-    {
-        const int v = (int)threadIdx.x >= d ? sPart[threadIdx.x - d] : 0;
-        __syncthreads();
-        sPart[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int acc = sPart[threadIdx.x] - sum;
-    for (unsigned c = lo; c < hi; c++) { rowStart[c] = acc; acc += nPkt[c]; }
+    int base = 0;
+    for (int k = 0; k < 16; k++) base += sWave[k];
+    __syncthreads();
+    // (2) this workgroup's own: inclusive scan inside the wavefront, the wavefronts' totals through LDS
+    const int mine = c < nChannels ? nPkt[c] : 0;
+    int incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) sWave[w] = incl;
+    __syncthreads();
+    for (int k = 0; k < w; k++) base += sWave[k];
+    if (c < nChannels) rowStart[c] = base + incl - mine;
 }
 
 __global__ void packDescribe(const StreamPacket *__restrict__ pktOut, const int *__restrict__ nPkt, const int *__restrict__ rowStart,
@@ -132,7 +141,7 @@ hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const 
                              int *nsymsOut, int *channelOut, hipStream_t stream)
 {
     if (nPackets == 0) return hipSuccess;
-    hipLaunchKernelGGL(scanCounts, dim3(1), dim3(1024), 0, stream, nPkt, rowStart, unsigned(nChannels));
+    hipLaunchKernelGGL(scanCounts, dim3(unsigned((nChannels + 1023) / 1024)), dim3(1024), 0, stream, nPkt, rowStart, unsigned(nChannels));
     hipLaunchKernelGGL(packDescribe, dim3(unsigned((nChannels + 255) / 256)), dim3(256), 0, stream, pktOut, nPkt, rowStart, unsigned(nChannels), cap, capPkt,
                        srcOff, nsymsOut, channelOut);
     hipLaunchKernelGGL(packCopy, dim3(unsigned(nPackets)), dim3(64), 0, stream, symOut, srcOff, nsymsOut, symsOut, stride);
@@ -140,65 +149,152 @@ hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const 
 }
 
 /***********************************************************************
- * What the host needs after a streaming launch, reduced on the device: one workgroup reads the per-channel state and counts
- * (a few hundred KiB in HBM) and leaves 64 bytes. The per-channel arrays cross PCIe only when an accessor asks for them.
+ * What the host needs after a streaming launch, reduced on the device: the per-channel state and counts (a few hundred KiB in HBM) become
+ * 72 bytes. The per-channel arrays cross PCIe only when an accessor asks for them.
+ * One workgroup per 1024 channels leaves a partial record, a second (tiny) launch adds the records up -- the kernel boundary is what makes
+ * the records of workgroups on other XCCs visible (their L2s are not coherent inside a kernel). Round 4: ONE workgroup walked every channel,
+ * 18.4 us per receiver step at 16384 channels (profiles/r05/s22_*); a single launch whose last workgroup adds up behind agent-scope
+ * release / acquire fences was measured too and is SLOWER than that (21.7 us: a fence of that scope writes the XCC's L2 back, s25_*).
  **********************************************************************/
+enum { SUM_CALLS = 0, SUM_PACKETS, SUM_SYMS, SUM_SIGNALS, SUM_OPENSYMS, SUM_MORE, SUM_ANYOPEN, SUM_MAXCALL, SUM_MAXOPEN, SUM_FULLEST, SUM_FIELDS };
+
+__device__ __forceinline__ long long summaryCombine(const int f, const long long a, const long long b)
+{
+    return f < SUM_MORE ? a + b : (f < SUM_MAXCALL ? (a | b) : (b > a ? b : a));      // sums; flags; maxima
+}
+
+//! the workgroup's combination of v over its lanes -> every lane of wavefront 0 (others: undefined); sL: [SUM_FIELDS][16]. Inside a
+//! workgroup of at most 32768 channels every field fits 32 unsigned bits (a channel counts at most 65536 calls per launch): the shuffles
+//! and the LDS traffic are those of 32-bit values, the 64-bit fields are for what several workgroups add up to.
+__device__ __forceinline__ unsigned summaryCombine32(const int f, const unsigned a, const unsigned b)
+{
+    return f < SUM_MORE ? a + b : (f < SUM_MAXCALL ? (a | b) : (b > a ? b : a));
+}
+
+__device__ __forceinline__ void summaryReduce(long long (&v)[SUM_FIELDS], unsigned (*sL)[16])
+{
+    unsigned u[SUM_FIELDS];
+#pragma unroll
+    for (int f = 0; f < SUM_FIELDS; f++) u[f] = (unsigned)v[f];
+    for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+        for (int f = 0; f < SUM_FIELDS; f++) u[f] = summaryCombine32(f, u[f], (unsigned)__shfl_xor((int)u[f], d));
+    const int w = threadIdx.x >> 6, nw = int(blockDim.x >> 6);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int f = 0; f < SUM_FIELDS; f++) sL[f][w] = u[f];
+    __syncthreads();
+    if (w == 0)
+#pragma unroll
+        for (int f = 0; f < SUM_FIELDS; f++)
+        {
+            unsigned r = sL[f][0];
+            for (int k = 1; k < nw; k++) r = summaryCombine32(f, r, sL[f][k]);
+            v[f] = (long long)r;
+        }
+}
+
+__device__ __forceinline__ void summaryWrite(const long long (&v)[SUM_FIELDS], const unsigned *__restrict__ near, StreamSummary *__restrict__ out)
+{
+    StreamSummary r;
+    r.calls = v[SUM_CALLS]; r.packets = v[SUM_PACKETS]; r.syms = v[SUM_SYMS]; r.signals = v[SUM_SIGNALS]; r.openSyms = v[SUM_OPENSYMS];
+    r.more = int(v[SUM_MORE]); r.anyOpen = int(v[SUM_ANYOPEN]); r.maxCallCount = int(v[SUM_MAXCALL]); r.maxOpen = int(v[SUM_MAXOPEN]);
+    r.fullest = int(v[SUM_FULLEST]);
+    r.nearSquelch = near[0]; r.nearStep = near[1]; r.pad = 0;
+    *out = r;
+}
+
+//! partial == nullptr (one workgroup): the summary itself; else workgroup b's record to partial[b][SUM_FIELDS]
+template <int W>
 __global__ void __launch_bounds__(1024) streamSummary(const StreamState *__restrict__ state, const int *__restrict__ nCalls, const int *__restrict__ nSym,
                                                       const int *__restrict__ nPkt, const int *__restrict__ nSig, const unsigned nChannels, const int cap,
-                                                      const int capPkt, const unsigned *__restrict__ near, StreamSummary *__restrict__ out)
+                                                      const int capPkt, const unsigned *__restrict__ near, long long *__restrict__ partial,
+                                                      StreamSummary *__restrict__ out)
 {
-    long long calls = 0, packets = 0, syms = 0, signals = 0, openSyms = 0;
-    int more = 0, anyOpen = 0, maxCall = 0, maxOpen = 0, fullest = 0;
-    for (unsigned c = threadIdx.x; c < nChannels; c += blockDim.x)
+    __shared__ unsigned sL[SUM_FIELDS][16];
+    long long v[SUM_FIELDS];
+#pragma unroll
+    for (int f = 0; f < SUM_FIELDS; f++) v[f] = 0;
+    // W channels per lane and round, every load of the round issued before the first is used (one workgroup walking 16384 channels one
+    // by one is sixteen dependent trips to memory); of the 40-byte state only the three fields the summary needs
+    const unsigned stride = gridDim.x * blockDim.x;
+    const int *const stateWords = reinterpret_cast<const int *>(state);
+    constexpr int SW = int(sizeof(StreamState) / sizeof(int));
+    static_assert(sizeof(StreamState) % sizeof(int) == 0, "the state is read word by word");
+    for (unsigned c0 = blockIdx.x * blockDim.x + threadIdx.x; c0 < nChannels; c0 += unsigned(W) * stride)
     {
-        const int n = nCalls[c], p = nPkt[c], g = nSig ? nSig[c] : 0;
-        calls += n; packets += p; syms += nSym[c]; signals += g;
-        more |= (n == cap || p == capPkt || (nSig && g == capPkt)) ? 1 : 0;
-        fullest = n > fullest ? n : fullest;
-        const StreamState st = state[c];
-        maxCall = st.callCount > maxCall ? st.callCount : maxCall;
-        if (st.state == ST_DATASYMBOLS) { anyOpen = 1; openSyms += st.symCount; maxOpen = st.symCount > maxOpen ? st.symCount : maxOpen; }
-    }
-    __shared__ long long sL[5][16];
-    __shared__ int sI[5][16];
-    // wavefront reductions, then the 16 wavefronts' partial results by the first lanes
-    for (int d = 32; d >= 1; d >>= 1)
-    {
-        calls += __shfl_xor(calls, d); packets += __shfl_xor(packets, d); syms += __shfl_xor(syms, d); signals += __shfl_xor(signals, d);
-        openSyms += __shfl_xor(openSyms, d);
-        more |= __shfl_xor(more, d); anyOpen |= __shfl_xor(anyOpen, d);
-        const int a = __shfl_xor(maxCall, d), b = __shfl_xor(maxOpen, d), f = __shfl_xor(fullest, d);
-        maxCall = a > maxCall ? a : maxCall; maxOpen = b > maxOpen ? b : maxOpen; fullest = f > fullest ? f : fullest;
-    }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0)
-    {
-        sL[0][w] = calls; sL[1][w] = packets; sL[2][w] = syms; sL[3][w] = signals; sL[4][w] = openSyms;
-        sI[0][w] = more; sI[1][w] = anyOpen; sI[2][w] = maxCall; sI[3][w] = maxOpen; sI[4][w] = fullest;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        StreamSummary r;
-        r.calls = r.packets = r.syms = r.signals = r.openSyms = 0;
-        r.more = r.anyOpen = r.maxCallCount = r.maxOpen = r.fullest = 0;
-        for (int k = 0; k < int(blockDim.x >> 6); k++)
+        int n[W], p[W], y[W], g[W], stt[W], sym[W], cc[W];
+#pragma unroll
+        for (int j = 0; j < W; j++)
         {
-            r.calls += sL[0][k]; r.packets += sL[1][k]; r.syms += sL[2][k]; r.signals += sL[3][k]; r.openSyms += sL[4][k];
-            r.more |= sI[0][k]; r.anyOpen |= sI[1][k];
-            r.maxCallCount = sI[2][k] > r.maxCallCount ? sI[2][k] : r.maxCallCount;
-            r.maxOpen = sI[3][k] > r.maxOpen ? sI[3][k] : r.maxOpen;
-            r.fullest = sI[4][k] > r.fullest ? sI[4][k] : r.fullest;
+            const unsigned c = c0 + unsigned(j) * stride;
+            const bool ok = c < nChannels;
+            const unsigned ci = ok ? c : c0;
+            n[j] = nCalls[ci]; p[j] = nPkt[ci]; y[j] = nSym[ci]; g[j] = nSig ? nSig[ci] : 0;
+            stt[j] = stateWords[(size_t)ci * SW + offsetof(StreamState, state) / 4];
+            // (symCount and callCount: neighbours in an 8-byte-aligned pair, one load)
+            static_assert(offsetof(StreamState, symCount) % 8 == 0 && offsetof(StreamState, callCount) == offsetof(StreamState, symCount) + 4 && sizeof(StreamState) % 8 == 0, "");
+            const int2 sc = *reinterpret_cast<const int2 *>(stateWords + (size_t)ci * SW + offsetof(StreamState, symCount) / 4);
+            sym[j] = sc.x; cc[j] = sc.y;
+            if (!ok) { n[j] = p[j] = y[j] = g[j] = 0; stt[j] = ST_FRAMESYNC; sym[j] = cc[j] = 0; }
         }
-        r.nearSquelch = near[0]; r.nearStep = near[1]; r.pad = 0;
-        *out = r;
+#pragma unroll
+        for (int j = 0; j < W; j++)
+        {
+            v[SUM_CALLS] += n[j]; v[SUM_PACKETS] += p[j]; v[SUM_SYMS] += y[j]; v[SUM_SIGNALS] += g[j];
+            v[SUM_MORE] |= (n[j] == cap || p[j] == capPkt || (nSig && g[j] == capPkt)) ? 1 : 0;      // (padding lanes: zeros; cap >= 8, capPkt >= 2)
+            v[SUM_FULLEST] = n[j] > v[SUM_FULLEST] ? n[j] : v[SUM_FULLEST];
+            v[SUM_MAXCALL] = cc[j] > v[SUM_MAXCALL] ? cc[j] : v[SUM_MAXCALL];
+            if (stt[j] == ST_DATASYMBOLS) { v[SUM_ANYOPEN] = 1; v[SUM_OPENSYMS] += sym[j]; v[SUM_MAXOPEN] = sym[j] > v[SUM_MAXOPEN] ? sym[j] : v[SUM_MAXOPEN]; }
+        }
     }
+    summaryReduce(v, sL);
+    if (threadIdx.x != 0) return;
+    if (partial == nullptr) { summaryWrite(v, near, out); return; }
+#pragma unroll
+    for (int f = 0; f < SUM_FIELDS; f++) partial[(size_t)blockIdx.x * SUM_FIELDS + f] = v[f];
+}
+
+//! the records of the workgroups above (a launch of its own: see the head of this section) -> the summary
+__global__ void __launch_bounds__(64) streamSummaryFinal(const long long *__restrict__ partial, const unsigned groups, const unsigned *__restrict__ near,
+                                                         StreamSummary *__restrict__ out)
+{
+    long long v[SUM_FIELDS];
+#pragma unroll
+    for (int f = 0; f < SUM_FIELDS; f++) v[f] = 0;
+    for (unsigned k = threadIdx.x; k < groups; k += 64u)
+#pragma unroll
+        for (int f = 0; f < SUM_FIELDS; f++) v[f] = summaryCombine(f, v[f], partial[(size_t)k * SUM_FIELDS + f]);
+    for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+        for (int f = 0; f < SUM_FIELDS; f++) v[f] = summaryCombine(f, v[f], __shfl_xor(v[f], d));
+    if (threadIdx.x == 0) summaryWrite(v, near, out);
+}
+
+//! bytes of the scratch block launchStreamSummary needs for nChannels channels (the workgroups' partial records)
+size_t streamSummaryScratchBytes(const size_t nChannels)
+{
+    const size_t groups = (nChannels + 4095) / 4096;
+    return groups * SUM_FIELDS * sizeof(long long);
 }
 
 hipError_t launchStreamSummary(const StreamState *state, const int *nCalls, const int *nSym, const int *nPkt, const int *nSig, const size_t nChannels,
-                               const int cap, const int capPkt, const unsigned *near, StreamSummary *out, hipStream_t stream)
+                               const int cap, const int capPkt, const unsigned *near, void *scratch, StreamSummary *out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(streamSummary, dim3(1), dim3(1024), 0, stream, state, nCalls, nSym, nPkt, nSig, unsigned(nChannels), cap, capPkt, near, out);
+    // one launch (one workgroup, four channels per lane and round in flight) up to 32768 channels; beyond that the records of one
+    // workgroup per 4096 channels and a second launch
+    const unsigned groups = (scratch && nChannels > 32768) ? unsigned((nChannels + 4095) / 4096) : 1u;
+    if (groups <= 1)
+    {
+        // (eight channels per lane in flight instead of four: no faster, 14.0 against 13.7 us at 16384 channels -- what is left is one
+        // compute unit fetching three words of every 40-byte state, profiles/r05/s29_receiver_step_kernels_before_after.txt)
+        hipLaunchKernelGGL(streamSummary<4>, dim3(1), dim3(1024), 0, stream, state, nCalls, nSym, nPkt, nSig, unsigned(nChannels), cap, capPkt, near,
+                           static_cast<long long *>(nullptr), out);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(streamSummary<4>, dim3(groups), dim3(1024), 0, stream, state, nCalls, nSym, nPkt, nSig, unsigned(nChannels), cap, capPkt, near,
+                       static_cast<long long *>(scratch), out);
+    hipLaunchKernelGGL(streamSummaryFinal, dim3(1), dim3(64), 0, stream, static_cast<const long long *>(scratch), groups, near, out);
     return hipGetLastError();
 }
 

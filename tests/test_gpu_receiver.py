@@ -532,3 +532,57 @@ def test_pipelined_rows_are_ordered_behind_a_consumer_on_the_launch_stream(gpu, 
         assert len(got[c]) == len(r["packets"]) >= 6, "channel %d" % c
         assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
     d.close()
+
+
+@pytest.mark.parametrize("sf,B", [(7, 2500), (10, 1030), (7, 40000)])
+def test_summary_and_row_numbers_over_several_workgroups(gpu, oracle, sf, B):
+    """Many channels: the packets' rows are numbered by one workgroup per 1024 channels, and beyond 32768 channels the summary of a streaming
+    launch is the sum of one workgroup's record per 4096 channels (a second launch adds them up). Channels with 0 / 1 / 2 / 3 frames in an
+    order that puts different packet counts on both sides of every workgroup boundary: the call and packet totals, the device-packed rows
+    (channel-major, time ascending) and the chunked receiver's per-step totals equal the reference's."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(1600 + sf)
+    N, K = 1 << sf, 8
+    kinds = []
+    for k in range(K):
+        st = frames(oracle, rng, sf, k % 4, 6, off=rng.uniform(-0.4, 0.4), noise=0.05, lead=int(rng.integers(0, 2 * N)))[0] if k % 4 else \
+            (0.05 * (rng.standard_normal(6 * N) + 1j * rng.standard_normal(6 * N))).astype(np.complex64)
+        kinds.append(st)
+    cap = max(s.size for s in kinds)
+    host = np.zeros((K, cap), np.complex64)
+    for k, s_ in enumerate(kinds):
+        host[k, :s_.size] = s_
+    refs = [oracle.demod_run(sf, host[k], mtu=6) for k in range(K)]
+    kind_of = (np.arange(B) * 5 + np.arange(B) // 1024) % K
+    iq = gpu.from_numpy(host).cuda()[gpu.from_numpy(kind_of).cuda()]
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(6)
+    d.work(iq)
+    assert d.work_calls() == sum(len(refs[k]["calls"]) for k in kind_of)
+    sy, ns, ch = d.packets_device(stride=8, clear=False)
+    sy, ns, ch = sy.cpu().numpy(), ns.cpu().numpy(), ch.cpu().numpy()
+    want = [(c, p) for c in range(B) for _, p in refs[kind_of[c]]["packets"]]
+    assert len(want) == ns.size > B // 2
+    assert ch.tolist() == [c for c, _ in want]
+    assert all(np.array_equal(sy[i, :ns[i]], p) for i, (_, p) in enumerate(want))
+    assert d.consumed_all().tolist() == [int(sum(q["consumed"] for q in refs[k]["calls"])) for k in kind_of]
+    # the running receiver: every step's summary (calls, packets) through the same kernels (a fresh block: activate() keeps the frequency
+    # estimate and the previous value of the run before, LoRaDemod.cpp:139-143)
+    d.close()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(6)
+    rows = d.receiver_rows(cap_packets=4 * B, stride=8)
+    calls = npk = w = 0
+    got = [[] for _ in range(B)]
+    while w < cap:
+        w = min(cap, w + 3 * N)
+        n, c_ = d.receive(iq, w, rows, async_=True)
+        gpu.cuda.synchronize()
+        r_sy, r_ns, r_ch = rows[0][:n].cpu().numpy(), rows[1][:n].cpu().numpy(), rows[2][:n].cpu().numpy()
+        assert (np.diff(r_ch) >= 0).all()                           # channel-major inside a step
+        for i in range(n):
+            got[int(r_ch[i])].append(r_sy[i, :r_ns[i]].copy())
+        calls += c_; npk += n
+    assert calls == d.work_calls() == sum(len(refs[k]["calls"]) for k in kind_of)
+    assert npk == len(want)
+    for c in range(0, B, 37):
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], refs[kind_of[c]]["packets"])) and len(got[c]) == len(refs[kind_of[c]]["packets"])
+    d.close()

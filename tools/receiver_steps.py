@@ -18,7 +18,7 @@ for sf in [int(x) for x in sys.argv[1:]] or [7, 10]:
                 w = npk = calls = steps = 0
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 while w < cap:
-                    w = min(cap, w + (cw << sf)); n, k = d.receive(iq, w, rows, async_=mode); npk += n; calls += k; steps += 1
+                    w = min(cap, w + (cw << sf)); n, k = (d.receive(iq, w, rows, async_=2, order_with_torch=False) if mode == 2 else d.receive(iq, w, rows, async_=True)); npk += n; calls += k; steps += 1
                 if mode == 2:
                     n, k = d.receive_flush(rows); npk += n; calls += k
                 torch.cuda.synchronize(); dt = time.perf_counter() - t0
