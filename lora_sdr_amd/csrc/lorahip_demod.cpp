@@ -419,7 +419,7 @@ struct StreamLayout
 {
     size_t B, cap, capPkt, symStride;
     bool tracing, signals;
-    size_t oBase, oLen, oState, oN, oNSym, oNPkt, oNSig, oNear, oSum, oPkt, oSym, oSig, oCalls, total;
+    size_t oBase, oLen, oState, oN, oNSym, oNPkt, oNSig, oNear, oSum, oEnd, oPkt, oSym, oSig, oCalls, total;
     void make(const size_t B_, const size_t cap_, const size_t capPkt_, const bool tracing_, const size_t carryCap_ = 0, const bool signals_ = false)
     {
         B = B_; cap = cap_; capPkt = capPkt_; tracing = tracing_; signals = signals_;
@@ -431,6 +431,7 @@ struct StreamLayout
         oN = carve(B * sizeof(int)); oNSym = carve(B * sizeof(int)); oNPkt = carve(B * sizeof(int)); oNSig = carve(B * sizeof(int));
         oNear = carve(2 * sizeof(unsigned));
         oSum = carve(sizeof(StreamSummary));
+        oEnd = carve(B * sizeof(int2));
         oPkt = carve(B * capPkt * sizeof(StreamPacket));
         oSym = carve(B * symStride * sizeof(short));
         oSig = carve(signals ? B * capPkt * sizeof(StreamSignal) : 0);
@@ -857,6 +858,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     a.symOut = reinterpret_cast<short *>(d + L.oSym);
     a.sigOut = dm->wantSignals ? reinterpret_cast<StreamSignal *>(d + L.oSig) : nullptr;
     a.nSig = reinterpret_cast<int *>(d + L.oNSig);
+    a.end = reinterpret_cast<int2 *>(d + L.oEnd);
     a.calls = dm->tracing ? reinterpret_cast<lorahip_work_result *>(d + L.oCalls) : nullptr;
     a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
     a.fineA = ctx->fineGather ? nullptr : ctx->dFineA;
@@ -894,7 +896,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         void *sumDev = nullptr;
         const bool direct = hipHostGetDevicePointer(&sumDev, const_cast<StreamSummary *>(hSum), 0) == hipSuccess && sumDev != nullptr;
         if (!direct) (void)hipGetLastError();
-        LORAHIP_TRY(launchStreamSummary(a.state, a.nCalls, a.nSym, a.nPkt, dm->wantSignals ? a.nSig : nullptr, B, int(cap), int(capPkt), a.near, dm->dSumScratch,
+        LORAHIP_TRY(launchStreamSummary(a.end, a.nCalls, a.nSym, a.nPkt, dm->wantSignals ? a.nSig : nullptr, B, int(cap), int(capPkt), a.near, dm->dSumScratch,
                                         direct ? static_cast<StreamSummary *>(sumDev) : reinterpret_cast<StreamSummary *>(d + L.oSum), ctx->stream));
         if (!direct) LORAHIP_TRY(hipMemcpyAsync(h + L.oSum, d + L.oSum, sizeof(StreamSummary), hipMemcpyDeviceToHost, ctx->stream));
         LORAHIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1202,7 +1204,7 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     a.carry = dm->dCarry; a.carryCap = int(dm->carryCap); a.maxBlocks = dm->streamGrid; a.lanes = dm->streamLanes; a.lastRoundFrom = 0;
     a.state = reinterpret_cast<StreamState *>(dm->sDev + H.oState);          // the object's own: every launch continues it
     a.nCalls = reinterpret_cast<int *>(d + L.oN); a.nSym = reinterpret_cast<int *>(d + L.oNSym); a.nPkt = reinterpret_cast<int *>(d + L.oNPkt);
-    a.nSig = reinterpret_cast<int *>(d + L.oNSig);
+    a.nSig = reinterpret_cast<int *>(d + L.oNSig); a.end = reinterpret_cast<int2 *>(d + L.oEnd);
     a.pktOut = reinterpret_cast<StreamPacket *>(d + L.oPkt); a.symOut = reinterpret_cast<short *>(d + L.oSym);
     a.sigOut = nullptr; a.calls = nullptr;
     a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
@@ -1212,9 +1214,11 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
     a.near = reinterpret_cast<unsigned *>(dm->sDev + H.oNear);
     // four calls per step: the kernel, its summary (written straight into pinned host memory), the event the next call waits on -- and
-    // the previous step's packing below
+    // the previous step's packing below. (The summary on a stream of its own, behind the kernel's event and beside the NEXT step's kernel
+    // -- it reads only this record set's counts and end words -- was measured: two more API calls and the hand-over between the streams
+    // cost more than the 11 us the next kernel would no longer queue behind, 93 -> 108 us per 8-window step at SF7; profiles/r05/s36_*.)
     LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
-    LORAHIP_TRY(launchStreamSummary(a.state, a.nCalls, a.nSym, a.nPkt, nullptr, B, int(cap), int(capPkt), a.near, dm->dSumScratch, &P.hSum[set], ctx->stream));
+    LORAHIP_TRY(launchStreamSummary(a.end, a.nCalls, a.nSym, a.nPkt, nullptr, B, int(cap), int(capPkt), a.near, dm->dSumScratch, &P.hSum[set], ctx->stream));
     LORAHIP_TRY(hipEventRecord(P.ev[set], ctx->stream));
     P.pending[set] = true;
     P.k++;

@@ -122,6 +122,9 @@ struct StreamArgs
     int capPkt;
     StreamSignal *sigOut;       // [nChannels][capPkt] one record per DOWNCHIRP1 call; nullptr unless signals are kept
     int *nSig;                  // [nChannels]
+    int2 *end;                  // [nChannels] where the channel stands after the launch, as the summary needs it: x = symCount of the packet it is
+                                // inside (-1: in none), y = callCount -- beside the counts, so that streamSummary reads five dense arrays and
+                                // not three words of every 40-byte state
     const float2 *down, *fine, *twStage;
     const double2 *fineA, *fineB;   // split of the fine-tune table (lorahip_fine.h); nullptr: gather from `fine`
     unsigned nChannels;
@@ -163,7 +166,7 @@ struct StreamSummary
 };
 //! scratch: streamSummaryScratchBytes(nChannels) bytes of device memory (one workgroup per 1024 channels leaves a record, a second small
 //! launch adds them up; nullptr: one workgroup walks every channel)
-hipError_t launchStreamSummary(const StreamState *state, const int *nCalls, const int *nSym, const int *nPkt, const int *nSig, size_t nChannels,
+hipError_t launchStreamSummary(const int2 *end, const int *nCalls, const int *nSym, const int *nPkt, const int *nSig, size_t nChannels,
                                int cap, int capPkt, const unsigned *near, void *scratch, StreamSummary *out, hipStream_t stream);
 size_t streamSummaryScratchBytes(size_t nChannels);
 

@@ -76,7 +76,7 @@ hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *s
  * Packets of a streaming launch straight into the batched decoder's input layout, device to device (no host round trip):
  * channel c posted nPkt[c] packets, packet j = the next pktOut[c][j].len entries of the channel's symbol stream symOut[c][..];
  * its row in the output is rowStart[c] + j (rowStart = exclusive scan of nPkt: channels ascending, time ascending inside one;
- * scanCounts below).
+ * scanDescribe below).
  **********************************************************************/
 __global__ void packCopy(const short *__restrict__ symOut, const long long *__restrict__ srcOff, const int *__restrict__ nsyms,
                          unsigned short *__restrict__ dst, const int stride)
@@ -87,14 +87,17 @@ __global__ void packCopy(const short *__restrict__ symOut, const long long *__re
     for (int i = threadIdx.x; i < stride; i += blockDim.x) dst[p * stride + i] = i < len ? (unsigned short)src[i] : (unsigned short)0;
 }
 
-//! rowStart = exclusive prefix sum of nPkt: the packets' rows are numbered on the device, so that packing needs neither an upload nor a
-//! host synchronisation. One workgroup per 1024 channels, and no communication between them: a workgroup first adds up the counts of all
-//! channels BEFORE its own (<= 64 KiB of reads from L2 for the last of 16 at 16384 channels), then scans its own 1024, one per lane. (Round 4's
-//! version was ONE workgroup walking every channel: 20.7 us per receiver step at 16384 channels -- a third of an 8-window step's streaming kernel,
-//! 56 us when it ran beside that kernel; profiles/r05/s22_*. Describing the packets in the same workgroup -- one launch less -- was tried and is
-//! slower by far: 65536 packets walked by 1024 lanes, profiles/r04; doing all three steps in one workgroup for launches of <= 2048 packets is
-//! slower too: s43_*.)
-__global__ void __launch_bounds__(1024) scanCounts(const int *__restrict__ nPkt, int *__restrict__ rowStart, const unsigned nChannels)
+//! The packets' rows are numbered and described on the device, so that packing needs neither an upload nor a host synchronisation:
+//! rowStart = exclusive prefix sum of nPkt, and for packet j of channel c, row rowStart[c] + j, where its symbols start in the
+//! channel's symbol row, how many they are, which channel. One workgroup per 1024 channels, a lane per channel, and no communication
+//! between the workgroups: a workgroup first adds up the counts of all channels BEFORE its own (<= 64 KiB of reads from L2 for the last
+//! of 16 at 16384 channels), scans its own 1024, and every lane then walks its channel's few packets. (Round 4: ONE workgroup walking
+//! every channel for the row numbers, 20.7 us per receiver step at 16384 channels -- a third of an 8-window step's streaming kernel,
+//! 56 us when it ran beside that kernel -- and a second launch, a lane per channel, for the descriptions: profiles/r05/s22_*. Now 6.5 us
+//! and one launch, s29_ / s36_. With ONE workgroup the descriptions in the same launch were slower by far -- 65536 packets walked by
+//! 1024 lanes, profiles/r04 -- and all three steps in one workgroup for launches of <= 2048 packets are slower too: s43_*.)
+__global__ void __launch_bounds__(1024) scanDescribe(const StreamPacket *__restrict__ pktOut, const int *__restrict__ nPkt, const unsigned nChannels, const int cap,
+                                                     const int capPkt, long long *__restrict__ srcOff, int *__restrict__ nsyms, int *__restrict__ channel)
 {
     __shared__ int sWave[16];
     const unsigned first = blockIdx.x * 1024u, c = first + threadIdx.x;
@@ -115,18 +118,10 @@ __global__ void __launch_bounds__(1024) scanCounts(const int *__restrict__ nPkt,
     if (lane == 63) sWave[w] = incl;
     __syncthreads();
     for (int k = 0; k < w; k++) base += sWave[k];
-    if (c < nChannels) rowStart[c] = base + incl - mine;
-}
-
-__global__ void packDescribe(const StreamPacket *__restrict__ pktOut, const int *__restrict__ nPkt, const int *__restrict__ rowStart,
-                             const unsigned nChannels, const int cap, const int capPkt, long long *__restrict__ srcOff,
-                             int *__restrict__ nsyms, int *__restrict__ channel)
-{
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nChannels) return;
+    // (3) the channel's packets, in the order they were posted
+    const int row0 = base + incl - mine;
     long long off = (long long)c * cap;
-    const int row0 = rowStart[c];
-    for (int j = 0; j < nPkt[c]; j++)
+    for (int j = 0; j < mine; j++)
     {
         const int len = pktOut[(size_t)c * capPkt + j].len;
         srcOff[row0 + j] = off;
@@ -141,20 +136,23 @@ hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const 
                              int *nsymsOut, int *channelOut, hipStream_t stream)
 {
     if (nPackets == 0) return hipSuccess;
-    hipLaunchKernelGGL(scanCounts, dim3(unsigned((nChannels + 1023) / 1024)), dim3(1024), 0, stream, nPkt, rowStart, unsigned(nChannels));
-    hipLaunchKernelGGL(packDescribe, dim3(unsigned((nChannels + 255) / 256)), dim3(256), 0, stream, pktOut, nPkt, rowStart, unsigned(nChannels), cap, capPkt,
-                       srcOff, nsymsOut, channelOut);
+    (void)rowStart;                                     // (the row numbers stay in registers since the two steps are one launch)
+    hipLaunchKernelGGL(scanDescribe, dim3(unsigned((nChannels + 1023) / 1024)), dim3(1024), 0, stream, pktOut, nPkt, unsigned(nChannels), cap, capPkt, srcOff,
+                       nsymsOut, channelOut);
     hipLaunchKernelGGL(packCopy, dim3(unsigned(nPackets)), dim3(64), 0, stream, symOut, srcOff, nsymsOut, symsOut, stride);
     return hipGetLastError();
 }
 
 /***********************************************************************
- * What the host needs after a streaming launch, reduced on the device: the per-channel state and counts (a few hundred KiB in HBM) become
- * 72 bytes. The per-channel arrays cross PCIe only when an accessor asks for them.
- * One workgroup per 1024 channels leaves a partial record, a second (tiny) launch adds the records up -- the kernel boundary is what makes
- * the records of workgroups on other XCCs visible (their L2s are not coherent inside a kernel). Round 4: ONE workgroup walked every channel,
- * 18.4 us per receiver step at 16384 channels (profiles/r05/s22_*); a single launch whose last workgroup adds up behind agent-scope
- * release / acquire fences was measured too and is SLOWER than that (21.7 us: a fence of that scope writes the XCC's L2 back, s25_*).
+ * What the host needs after a streaming launch, reduced on the device: the per-channel counts and end-of-launch words (a few hundred KiB
+ * in HBM) become 72 bytes. The per-channel arrays cross PCIe only when an accessor asks for them.
+ * ONE workgroup, one launch, up to 32768 channels: five dense arrays (the four counts and StreamArgs::end, which the streaming kernels
+ * write beside the counts), four channels per lane in flight, a 32-bit reduction. How it got there (16384 SF7 channels, per receiver
+ * step; profiles/r05/s22_*, s29_*, s36_*): one channel per lane and round, three words of every 40-byte state: 18.4 us; loads in flight,
+ * 32-bit reduction: 13.7; without the state: the figure in s36_. Measured and not kept: one workgroup per 4096 channels + a second launch
+ * for their records (11.2 + 4.9 us: the kernel boundary is what makes records of workgroups on other XCCs visible, their L2s are not
+ * coherent inside a kernel) -- kept only beyond 32768 channels; a single launch whose last workgroup adds up behind agent-scope fences
+ * (21.7 us: a fence of that scope writes the XCC's L2 back).
  **********************************************************************/
 enum { SUM_CALLS = 0, SUM_PACKETS, SUM_SYMS, SUM_SIGNALS, SUM_OPENSYMS, SUM_MORE, SUM_ANYOPEN, SUM_MAXCALL, SUM_MAXOPEN, SUM_FULLEST, SUM_FIELDS };
 
@@ -206,7 +204,7 @@ __device__ __forceinline__ void summaryWrite(const long long (&v)[SUM_FIELDS], c
 
 //! partial == nullptr (one workgroup): the summary itself; else workgroup b's record to partial[b][SUM_FIELDS]
 template <int W>
-__global__ void __launch_bounds__(1024) streamSummary(const StreamState *__restrict__ state, const int *__restrict__ nCalls, const int *__restrict__ nSym,
+__global__ void __launch_bounds__(1024) streamSummary(const int2 *__restrict__ end, const int *__restrict__ nCalls, const int *__restrict__ nSym,
                                                       const int *__restrict__ nPkt, const int *__restrict__ nSig, const unsigned nChannels, const int cap,
                                                       const int capPkt, const unsigned *__restrict__ near, long long *__restrict__ partial,
                                                       StreamSummary *__restrict__ out)
@@ -216,14 +214,12 @@ __global__ void __launch_bounds__(1024) streamSummary(const StreamState *__restr
 #pragma unroll
     for (int f = 0; f < SUM_FIELDS; f++) v[f] = 0;
     // W channels per lane and round, every load of the round issued before the first is used (one workgroup walking 16384 channels one
-    // by one is sixteen dependent trips to memory); of the 40-byte state only the three fields the summary needs
+    // by one is sixteen dependent trips to memory)
     const unsigned stride = gridDim.x * blockDim.x;
-    const int *const stateWords = reinterpret_cast<const int *>(state);
-    constexpr int SW = int(sizeof(StreamState) / sizeof(int));
-    static_assert(sizeof(StreamState) % sizeof(int) == 0, "the state is read word by word");
     for (unsigned c0 = blockIdx.x * blockDim.x + threadIdx.x; c0 < nChannels; c0 += unsigned(W) * stride)
     {
-        int n[W], p[W], y[W], g[W], stt[W], sym[W], cc[W];
+        int n[W], p[W], y[W], g[W];
+        int2 e[W];
 #pragma unroll
         for (int j = 0; j < W; j++)
         {
@@ -231,12 +227,8 @@ __global__ void __launch_bounds__(1024) streamSummary(const StreamState *__restr
             const bool ok = c < nChannels;
             const unsigned ci = ok ? c : c0;
             n[j] = nCalls[ci]; p[j] = nPkt[ci]; y[j] = nSym[ci]; g[j] = nSig ? nSig[ci] : 0;
-            stt[j] = stateWords[(size_t)ci * SW + offsetof(StreamState, state) / 4];
-            // (symCount and callCount: neighbours in an 8-byte-aligned pair, one load)
-            static_assert(offsetof(StreamState, symCount) % 8 == 0 && offsetof(StreamState, callCount) == offsetof(StreamState, symCount) + 4 && sizeof(StreamState) % 8 == 0, "");
-            const int2 sc = *reinterpret_cast<const int2 *>(stateWords + (size_t)ci * SW + offsetof(StreamState, symCount) / 4);
-            sym[j] = sc.x; cc[j] = sc.y;
-            if (!ok) { n[j] = p[j] = y[j] = g[j] = 0; stt[j] = ST_FRAMESYNC; sym[j] = cc[j] = 0; }
+            e[j] = end[ci];
+            if (!ok) { n[j] = p[j] = y[j] = g[j] = 0; e[j] = make_int2(-1, 0); }
         }
 #pragma unroll
         for (int j = 0; j < W; j++)
@@ -244,8 +236,8 @@ __global__ void __launch_bounds__(1024) streamSummary(const StreamState *__restr
             v[SUM_CALLS] += n[j]; v[SUM_PACKETS] += p[j]; v[SUM_SYMS] += y[j]; v[SUM_SIGNALS] += g[j];
             v[SUM_MORE] |= (n[j] == cap || p[j] == capPkt || (nSig && g[j] == capPkt)) ? 1 : 0;      // (padding lanes: zeros; cap >= 8, capPkt >= 2)
             v[SUM_FULLEST] = n[j] > v[SUM_FULLEST] ? n[j] : v[SUM_FULLEST];
-            v[SUM_MAXCALL] = cc[j] > v[SUM_MAXCALL] ? cc[j] : v[SUM_MAXCALL];
-            if (stt[j] == ST_DATASYMBOLS) { v[SUM_ANYOPEN] = 1; v[SUM_OPENSYMS] += sym[j]; v[SUM_MAXOPEN] = sym[j] > v[SUM_MAXOPEN] ? sym[j] : v[SUM_MAXOPEN]; }
+            v[SUM_MAXCALL] = e[j].y > v[SUM_MAXCALL] ? e[j].y : v[SUM_MAXCALL];
+            if (e[j].x >= 0) { v[SUM_ANYOPEN] = 1; v[SUM_OPENSYMS] += e[j].x; v[SUM_MAXOPEN] = e[j].x > v[SUM_MAXOPEN] ? e[j].x : v[SUM_MAXOPEN]; }
         }
     }
     summaryReduce(v, sL);
@@ -278,7 +270,7 @@ size_t streamSummaryScratchBytes(const size_t nChannels)
     return groups * SUM_FIELDS * sizeof(long long);
 }
 
-hipError_t launchStreamSummary(const StreamState *state, const int *nCalls, const int *nSym, const int *nPkt, const int *nSig, const size_t nChannels,
+hipError_t launchStreamSummary(const int2 *end, const int *nCalls, const int *nSym, const int *nPkt, const int *nSig, const size_t nChannels,
                                const int cap, const int capPkt, const unsigned *near, void *scratch, StreamSummary *out, hipStream_t stream)
 {
     // one launch (one workgroup, four channels per lane and round in flight) up to 32768 channels; beyond that the records of one
@@ -286,13 +278,11 @@ hipError_t launchStreamSummary(const StreamState *state, const int *nCalls, cons
     const unsigned groups = (scratch && nChannels > 32768) ? unsigned((nChannels + 4095) / 4096) : 1u;
     if (groups <= 1)
     {
-        // (eight channels per lane in flight instead of four: no faster, 14.0 against 13.7 us at 16384 channels -- what is left is one
-        // compute unit fetching three words of every 40-byte state, profiles/r05/s29_receiver_step_kernels_before_after.txt)
-        hipLaunchKernelGGL(streamSummary<4>, dim3(1), dim3(1024), 0, stream, state, nCalls, nSym, nPkt, nSig, unsigned(nChannels), cap, capPkt, near,
+        hipLaunchKernelGGL(streamSummary<4>, dim3(1), dim3(1024), 0, stream, end, nCalls, nSym, nPkt, nSig, unsigned(nChannels), cap, capPkt, near,
                            static_cast<long long *>(nullptr), out);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(streamSummary<4>, dim3(groups), dim3(1024), 0, stream, state, nCalls, nSym, nPkt, nSig, unsigned(nChannels), cap, capPkt, near,
+    hipLaunchKernelGGL(streamSummary<4>, dim3(groups), dim3(1024), 0, stream, end, nCalls, nSym, nPkt, nSig, unsigned(nChannels), cap, capPkt, near,
                        static_cast<long long *>(scratch), out);
     hipLaunchKernelGGL(streamSummaryFinal, dim3(1), dim3(64), 0, stream, static_cast<const long long *>(scratch), groups, near, out);
     return hipGetLastError();

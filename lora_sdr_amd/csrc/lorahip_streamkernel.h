@@ -361,6 +361,7 @@ demodStream(const StreamArgs s)
         s.nSym[c] = o.nSym;
         s.nPkt[c] = o.nPkt;
         if (s.nSig) s.nSig[c] = o.nSig;
+        s.end[c] = make_int2(st.state == ST_DATASYMBOLS ? st.symCount : -1, st.callCount);
     }
     } while (PERSIST && (cset += gridDim.x) < nSets);       // without PERSIST there is no loop at all (it would cost registers)
 }

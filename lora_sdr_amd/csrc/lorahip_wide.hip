@@ -1003,6 +1003,7 @@ demodStreamWide(const StreamArgs s)
         s.nSym[c] = o.nSym;
         s.nPkt[c] = o.nPkt;
         if (s.nSig) s.nSig[c] = o.nSig;
+        s.end[c] = make_int2(st.state == ST_DATASYMBOLS ? st.symCount : -1, st.callCount);
 #ifdef LORAHIP_WG_TIMELINE
         if (c < 16384)
         {
