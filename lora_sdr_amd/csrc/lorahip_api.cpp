@@ -520,8 +520,14 @@ struct lorahip_detector
 {
     lorahip_ctx *ctx;
     size_t N;
-    std::vector<cf32> input;     // _fftInput  LoRaDetector.hpp:68
-    std::vector<cf32> output;    // _fftOutput LoRaDetector.hpp:69
+    // One block of pinned host memory that the device addresses directly (hipHostMalloc: mapped, coherent): the window's samples
+    // (_fftInput, LoRaDetector.hpp:68), its bins (_fftOutput, :69) and detect()'s four results. A detect() is then ONE kernel launch
+    // and one wait -- the kernel reads its 8 N bytes over PCIe and writes 8 N + 14 back -- instead of a staged upload, the kernel and
+    // five downloads (28 -> the figure in DESIGN.md section 5 per call; the verbatim CPU detector takes 1-30 us for N = 2^7 ... 2^12).
+    char *block;
+    cf32 *input, *output;
+    uint16_t *sym;
+    float *res;                   // power, powerAvg, fIndex
 };
 
 extern "C" {
@@ -537,10 +543,22 @@ int lorahip_detector_create(lorahip_detector **out, const int device, const size
     if (det == nullptr) return LORAHIP_E_NOMEM;
     det->ctx = nullptr;
     det->N = N;
+    det->block = nullptr;
     const int rc = lorahip_create(&det->ctx, device, sf);
     if (rc != LORAHIP_OK) { delete det; return rc; }
-    det->input.assign(N, cf32(0, 0));
-    det->output.assign(N, cf32(0, 0));
+    {
+        const DeviceGuard guard(det->ctx->device);
+        const size_t bytes = 2 * N * sizeof(cf32) + 256;
+        void *p = nullptr;
+        const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable);
+        if (e != hipSuccess) { (void)hipGetLastError(); lorahip_destroy(det->ctx); delete det; return hipFail(e, "hipHostMalloc (detector staging)"); }
+        std::memset(p, 0, bytes);
+        det->block = static_cast<char *>(p);
+    }
+    det->input = reinterpret_cast<cf32 *>(det->block);
+    det->output = det->input + N;
+    det->res = reinterpret_cast<float *>(det->output + N);
+    det->sym = reinterpret_cast<uint16_t *>(det->res + 4);
     *out = det;
     return LORAHIP_OK;
 }
@@ -548,6 +566,12 @@ int lorahip_detector_create(lorahip_detector **out, const int device, const size
 void lorahip_detector_destroy(lorahip_detector *det)
 {
     if (det == nullptr) return;
+    if (det->block)
+    {
+        const DeviceGuard guard(det->ctx->device);
+        (void)hipStreamSynchronize(det->ctx->stream);
+        (void)hipHostFree(det->block);
+    }
     lorahip_destroy(det->ctx);
     delete det;
 }
@@ -563,21 +587,26 @@ int lorahip_detector_detect(lorahip_detector *det, size_t *index, float *power, 
                             float *f_index, float *fft_out)
 {
     if (det == nullptr || !index || !power || !power_avg || !f_index) return LORAHIP_E_INVALID;
-    uint16_t sym = 0;
     lorahip_batch b;
     std::memset(&b, 0, sizeof(b));
     b.struct_size = sizeof(b);
-    b.iq = reinterpret_cast<const float *>(det->input.data());
+    b.iq = reinterpret_cast<const float *>(det->input);
     b.n_windows = 1;
     b.chirp_sel_all = LORAHIP_CHIRP_NONE;
-    b.sym = &sym;
-    b.power = power;
-    b.power_avg = power_avg;
-    b.f_index = f_index;
-    b.fft_out = fft_out ? fft_out : reinterpret_cast<float *>(det->output.data());
-    const int rc = lorahip_detect_batch_host(det->ctx, &b);
+    b.sym = det->sym;
+    b.power = det->res;
+    b.power_avg = det->res + 1;
+    b.f_index = det->res + 2;
+    b.fft_out = reinterpret_cast<float *>(det->output);
+    const int rc = lorahip_detect_batch(det->ctx, &b);          // the device-pointer entry: the block is addressable from the device
     if (rc != LORAHIP_OK) return rc;
-    *index = sym;
+    {
+        const DeviceGuard guard(det->ctx->device);
+        LORAHIP_TRY(hipStreamSynchronize(det->ctx->stream));
+    }
+    *index = *det->sym;
+    *power = det->res[0]; *power_avg = det->res[1]; *f_index = det->res[2];
+    if (fft_out) std::memcpy(fft_out, det->output, det->N * sizeof(cf32));
     return LORAHIP_OK;
 }
 
