@@ -1844,7 +1844,7 @@ int lorahip_demod_run_host_rows(lorahip_demod *dm, const float *rows, const size
             std::vector<const float *> ptr(dm->B);
             for (size_t c = 0; c < dm->B; c++)
             {
-                if (first_sample[c] < 0 || size_t(first_sample[c]) + n_samples[c] > row_stride) return LORAHIP_E_INVALID;
+                if (first_sample[c] < 0 || size_t(first_sample[c]) > row_stride || n_samples[c] > row_stride - size_t(first_sample[c])) return LORAHIP_E_INVALID;
                 ptr[c] = rows ? rows + 2 * (c * row_stride + size_t(first_sample[c])) : nullptr;
             }
             return lorahip_demod_run(dm, ptr.data(), n_samples, rounds);

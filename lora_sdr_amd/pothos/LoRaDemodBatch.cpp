@@ -242,11 +242,13 @@ public:
         const size_t c = size_t(std::atol(name.c_str()));
         if (c >= B) return Pothos::Block::getInputBufferManager(name, domain);
         Pothos::BufferManagerArgs args;
-        if (!_pool)
+        size_t maxN = 0;
+        for (size_t k = 0; k < B; k++) maxN = std::max(maxN, size_t(1) << _sfs[k]);
+        const size_t slabBytes = std::max(args.bufferSize, (_maxWindows + 2) * maxN * sizeof(cf32));         // >= 2N: the reference's bound (:352-353)
+        // (a pool of another slab size -- setMaxWindows / setSpreadFactors since the ports were last asked for -- is left to the managers
+        // that hold it; ports on different pools are uploaded piece by piece, see inputsAreOneSlabGeneration)
+        if (!_pool || _pool->slabBytes != slabBytes)
         {
-            size_t maxN = 0;
-            for (size_t k = 0; k < B; k++) maxN = std::max(maxN, size_t(1) << _sfs[k]);
-            const size_t slabBytes = std::max(args.bufferSize, (_maxWindows + 2) * maxN * sizeof(cf32));     // >= 2N: the reference's bound (:352-353)
             // two generations: one is being filled by the upstream blocks while the other is inside work()
             std::shared_ptr<PinnedPool> pool(new PinnedPool(B, 2, slabBytes));
             if (pool->base == nullptr) return Pothos::Block::getInputBufferManager(name, domain);            // no pinned memory to be had: the default
