@@ -760,7 +760,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     bool anyCarryIn = false;
     size_t maxCarry = 0;
     // A steady receiver -- run after run in this mode, device buffers, nothing touched in between -- uploads nothing and reads back
-    // 64 bytes: the state is where the last run left it on the device, the placement of uniform streams is computed by the kernel,
+    // 72 bytes: the state is where the last run left it on the device, the placement of uniform streams is computed by the kernel,
     // an activate() in between travels as a flag, the open packets' symbols are in the device's carry rows, and what the host needs
     // to know of the last run is its summary (streamSummary). The per-channel state and counts are fetched when somebody asks.
     const bool resident = dm->devStateFresh;
@@ -891,7 +891,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
         LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
         LORAHIP_TRY(hipEventRecord(dm->evK1, ctx->stream));
         a.flags = 0;                                  // a resumed launch continues where the state says
-        // what the host needs of the launch, reduced on the device: 64 bytes come back, not 52 per channel
+        // what the host needs of the launch, reduced on the device: 72 bytes come back, not 52 per channel
         // (written by the kernel straight into the pinned staging block when the device can address it: no copy to enqueue)
         void *sumDev = nullptr;
         const bool direct = hipHostGetDevicePointer(&sumDev, const_cast<StreamSummary *>(hSum), 0) == hipSuccess && sumDev != nullptr;
@@ -973,7 +973,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 }
 
 /***********************************************************************
- * The PIPELINED receiver step (lorahip_demod_receive with async = 2). A receiver step is: streaming kernel, 64-byte summary back,
+ * The PIPELINED receiver step (lorahip_demod_receive with async = 2). A receiver step is: streaming kernel, 72-byte summary back,
  * packets packed for the decoder. Run strictly one after the other, the host's share (launch latencies, the wait for the summary,
  * the packing launches: ~60 us) is exposed once per step -- half the step at chunks of 8 windows. Here step k's kernel is launched
  * BEFORE step k-1's summary is read: the host waits for summary k-1 and packs step k-1's packets while kernel k runs, and the
@@ -1979,7 +1979,7 @@ static int packetsToDevice(lorahip_demod *dm, uint16_t *syms_dev, const size_t s
             const size_t nbRow = align256(L.B * sizeof(int));
             { const int grc = growDense(dm, nbRow + n * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
             hipStream_t st = dm->ctx->stream;
-            // the rows are numbered on the device (scanCounts: exclusive prefix sum of the per-channel packet counts): nothing is
+            // the rows are numbered on the device (scanDescribe: exclusive prefix sum of the per-channel packet counts): nothing is
             // uploaded, and nothing on the host is reused, so the caller decides whether to wait
             LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(dm->sDev + L.oPkt), reinterpret_cast<const int *>(dm->sDev + L.oNPkt),
                                           reinterpret_cast<const short *>(dm->sDev + L.oSym), reinterpret_cast<int *>(dm->dDense), L.B, int(L.symStride),

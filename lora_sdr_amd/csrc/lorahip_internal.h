@@ -150,7 +150,7 @@ struct StreamArgs
                                 //     Running counters: the kernels only add, the host takes differences
 };
 
-//! what the host needs to know after a streaming launch -- reduced on the device (streamSummary), so that 64 bytes cross PCIe per run
+//! what the host needs to know after a streaming launch -- reduced on the device (streamSummary), so that 72 bytes cross PCIe per run
 //! instead of the per-channel state and counts (52 B per channel), which are fetched only when somebody asks for them
 struct StreamSummary
 {
@@ -164,8 +164,8 @@ struct StreamSummary
     unsigned nearSquelch, nearStep;             // the running counters (StreamArgs::near)
     int pad;
 };
-//! scratch: streamSummaryScratchBytes(nChannels) bytes of device memory (one workgroup per 1024 channels leaves a record, a second small
-//! launch adds them up; nullptr: one workgroup walks every channel)
+//! scratch: streamSummaryScratchBytes(nChannels) bytes of device memory (beyond 32768 channels one workgroup per 4096 channels leaves a
+//! record there and a second small launch adds them up; up to that, or with nullptr, one workgroup walks every channel)
 hipError_t launchStreamSummary(const int2 *end, const int *nCalls, const int *nSym, const int *nPkt, const int *nSig, size_t nChannels,
                                int cap, int capPkt, const unsigned *near, void *scratch, StreamSummary *out, hipStream_t stream);
 size_t streamSummaryScratchBytes(size_t nChannels);
