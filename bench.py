@@ -572,7 +572,11 @@ def section_level3(env, L, sf, threads=32):
     # the same launch with the block's signals kept (error / power / snr once per packet, LoRaDemod.cpp:267-269: the reference block
     # always emits them; one more pair of logarithms per packet and a 16-byte record)
     d.set_signals(True)
-    one_pass()
+    # (the drain to the host just above let the device fall back towards its idle clocks: ramp again as before the first five passes --
+    # without it this launch read 12 % slower than the one without signals at SF7, where a pass is 2 ms, and 0-3 % at SF11 / SF12)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.25:
+        one_pass(together=False)
     sig_kms = sorted(one_pass()[1] for _ in range(5))
     sig_pass = (None, sig_kms[0])
     n_signals = len(d.signals()[0])
