@@ -210,7 +210,10 @@ int lorahip_timer_stop(lorahip_ctx *ctx, float *elapsed_ms);
 
 /* -------------------------------------------------------------------------------------
  * Level 1: LoRaDetector<float> shim (LoRaDetector.hpp:8-72). N must be 2^sf with sf in
- * [LORAHIP_SF_MIN, LORAHIP_SF_MAX].
+ * [LORAHIP_SF_MIN, LORAHIP_SF_MAX]. The object keeps the window (feed() writes it), the bins and
+ * detect()'s results in one block of pinned host memory that the device addresses directly:
+ * a detect() is one kernel launch and one wait (~19 us; no staged copies). One object is
+ * used by one thread at a time, as the reference's detector is.
  * ------------------------------------------------------------------------------------- */
 typedef struct lorahip_detector lorahip_detector;
 
