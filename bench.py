@@ -71,9 +71,128 @@ def parse():
     return ap.parse_args()
 
 
+LINE_LIMIT = 8000        # bytes of THE line. The driver keeps an ~8 KB tail of stdout and its reader lost round 5's 20.8 KB line
+SECTIONS_FILE = os.path.join("gpurun_out", "bench_sections.json")
+
+
+def _get(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full):
+    """THE line from the full result: the contract keys, roofline, cpu_baseline and oracle as they are; of every sweep section one short
+    row per SF (rates, roofline fractions, oracle mismatch counts, the near-boundary counters). Everything measured stays available:
+    the full sections are printed as earlier `SECTION <name> {...}` lines and written to gpurun_out/bench_sections.json."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data") if k in full}
+    cfg = dict(full.get("config", {}))
+    for k, dflt in (("kernel_variant", 0), ("alias_windows", False), ("moving_fine_index", False), ("fine_gather", False)):
+        if cfg.get(k) == dflt:
+            cfg.pop(k)                                   # (diagnostic switches: named only when they are on)
+    out["config"] = cfg
+    for k in ("symbol_error_rate_vs_sent", "bin_offset", "rccl_ranks"):
+        if k in full:
+            out[k] = full[k]
+    if "roofline" in full:
+        rf = dict(full["roofline"])
+        src = rf.pop("traffic_source", None)
+        if src is not None:
+            rf["traffic_source"] = _pick(src, "file", "session", "matches_this_tree", "error")
+        out["roofline"] = rf
+    if "cpu_baseline" in full:
+        cb = dict(full["cpu_baseline"])
+        cb.pop("affinity", None)
+        if "other_flags" in cb:
+            cb["other_flags"] = [_pick(x, "flags", "value") for x in cb["other_flags"]]
+        out["cpu_baseline"] = cb
+    if "oracle" in full:
+        out["oracle"] = full["oracle"]
+    pc = full.get("pcie_inclusive")
+    if pc:
+        out["pcie_inclusive"] = {"Msym_s": pc.get("Msym_s"), "GB_s": pc.get("GB_s"), "pinned_GB_s": _get(pc, "pinned", "GB_s"),
+                                 "same_symbols": bool(pc.get("same_symbols")) and bool(_get(pc, "pinned", "same_symbols", default=True)),
+                                 "level1_shim_us_per_detect": _get(pc, "level1_shim", "us_per_detect")}
+    if "per_sf" in full:
+        out["per_sf"] = [dict(_pick(e, "sf", "channels", "Msym_s", "frac", "error"), index_mismatches=_get(e, "oracle", "index_mismatches"),
+                              cpu_Msym_s=_get(e, "cpu_baseline", "value")) for e in full["per_sf"]]
+    if "moving" in full:
+        out["moving"] = [dict(_pick(e, "sf", "Msym_s", "frac", "error"), index_mismatches=_get(e, "oracle", "index_mismatches")) for e in full["moving"]]
+    if "level3" in full:
+        rows = []
+        for e in full["level3"]:
+            if "error" in e:
+                rows.append(_pick(e, "sf", "error"))
+                continue
+            run = e.get("running") or {}
+            row = dict(_pick(e, "sf", "channels", "lanes_log2", "frac_kernel", "frac_kernel_median", "frac_e2e", "near_squelch", "near_step",
+                             "oracle_channel_mismatches", "trace_call_mismatches", "parity_error"),
+                       with_signals_frac_kernel_median=_get(e, "with_signals", "frac_kernel_median"))
+            if e.get("oracle_kind", "reference") != "reference":
+                row["oracle_kind"] = e["oracle_kind"]     # (named only when the pinned restatement stood in for oracle/_ref)
+            if "error" in run:
+                row["running"] = {"error": str(run["error"])[:120]}
+            else:
+                row["running"] = dict(_pick(run, "Msym_s", "frac", "same_packets_as_one_shot"), pipelined_frac=_get(run, "pipelined", "frac"),
+                                      with_signals_frac=_get(run, "with_signals", "frac"))
+                c8 = run.get("chunk8") or {}
+                row["chunk8"] = dict(_pick(c8, "Msym_s", "frac"), pipelined_Msym_s=_get(c8, "pipelined", "Msym_s"),
+                                     pipelined_frac=_get(c8, "pipelined", "frac"), with_signals_frac=_get(c8, "with_signals", "frac"),
+                                     resident_Msym_s=_get(c8, "resident", "Msym_s"), resident_frac=_get(c8, "resident", "frac"))
+                for part in (row["running"], row["chunk8"]):
+                    for k in [k for k, v in part.items() if v is None]:
+                        part.pop(k)
+            pb = e.get("pothos_block")
+            if pb:
+                row["pothos_block"] = {"error": pb["error"]} if "error" in pb else {
+                    "ports_off": _get(pb, "ports_off", "Msym_s"), "ports_off_pinned_input_slabs": _get(pb, "ports_off_pinned_input_slabs", "Msym_s"),
+                    "ports_on": _get(pb, "ports_on", "Msym_s"), "vs_cpu_same_threads": pb.get("vs_cpu_same_threads"), "host_threads": pb.get("host_threads")}
+            rows.append(row)
+        out["level3"] = rows
+    if "config5" in full:
+        out["config5"] = full["config5"]
+    if "mixed" in full:
+        m = dict(full["mixed"])
+        for k in ("scheduler", "iq_bytes_per_step", "my_channels_rank0", "sf_rule"):
+            m.pop(k, None)
+        out["mixed"] = m
+    if "mixed_level3" in full:
+        m = dict(full["mixed_level3"])
+        for k in ("object", "sf_rule", "oracle_kind"):
+            m.pop(k, None)
+        out["mixed_level3"] = m
+    sc = full.get("level3_scaling")
+    if isinstance(sc, list):
+        out["level3_scaling"] = {"columns": ["sf", "channels", "lanes_log2", "frac", "frac_median"],
+                                 "rows": [[e.get("sf"), e.get("channels"), e.get("lanes_log2"), e.get("default_frac"), e.get("default_frac_median")] for e in sc]}
+    elif sc is not None:
+        out["level3_scaling"] = sc
+    if any(k in full for k in SECTION_KEYS):
+        out["sections"] = "full sections: the earlier stdout lines `SECTION <name> {...}` and %s" % SECTIONS_FILE
+    n = len(json.dumps(out, separators=(",", ":")))
+    if n > LINE_LIMIT:                                  # never print a line the reader may lose: drop the widest extras first
+        for k in ("level3_scaling", "pcie_inclusive", "moving", "per_sf", "level3"):
+            if k in out and n > LINE_LIMIT:
+                out[k] = "dropped from THE line (%d bytes over): see the SECTION lines" % (n - LINE_LIMIT)
+                n = len(json.dumps(out, separators=(",", ":")))
+    return out
+
+
+SECTION_KEYS = ("config", "roofline", "cpu_baseline", "pcie_inclusive", "per_sf", "moving", "level3", "config5", "mixed", "mixed_level3", "level3_scaling")
+
+
 def emit(env, line):
     """Rank 0 prints THE line -- after the process group is gone and every C-level stdout buffer is flushed (RCCL prints a version
-    banner through C stdio, which would otherwise land after the line when the process exits)"""
+    banner through C stdio, which would otherwise land after the line when the process exits). The line is the compact form
+    (compact_line, under LINE_LIMIT bytes); the full sections go out first, one `SECTION <name> {...}` line each, and into
+    gpurun_out/bench_sections.json."""
     import ctypes
     env.close()
     sys.stdout.flush()
@@ -82,7 +201,16 @@ def emit(env, line):
     except Exception:
         pass
     if line is not None:
-        print(json.dumps(line, separators=(",", ":")), flush=True)
+        for k in SECTION_KEYS:
+            if k in line:
+                print("SECTION %s %s" % (k, json.dumps(line[k], separators=(",", ":"))), flush=True)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, SECTIONS_FILE), "w") as f:
+                json.dump(line, f, indent=1)
+        except OSError:                                   # scratch only: a read-only tree must not cost the line
+            pass
+        print(json.dumps(compact_line(line), separators=(",", ":")), flush=True)
 
 
 def r4(x):
@@ -746,6 +874,7 @@ def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 
                 ent[key + "_frac"] = r4(calls * L.bytes_per_symbol(sf) / (best / 1e3) / 1e9 / HBM_PEAK_GBS)
                 ent[key + "_kernel_ms"] = r4(best)
                 ent[key + "_kernel_ms_median"] = r4(sorted(kms)[len(kms) // 2])
+                ent[key + "_frac_median"] = r4(calls * L.bytes_per_symbol(sf) / (sorted(kms)[len(kms) // 2] / 1e3) / 1e9 / HBM_PEAK_GBS)
             if both_grids:
                 os.environ.pop("LORAHIP_STREAM_BLOCKS", None)
             out.append(ent)
@@ -1049,23 +1178,36 @@ def main():
         }
         if env.rccl_ranks is not None:
             line["rccl_ranks"] = env.rccl_ranks
+    # (rank 0's CPU legs: with several ranks the others are waiting at the host barrier below, which must be reached whatever happens here --
+    # an exception is recorded in the line in place of the object, and one rank fails loudly at the end instead of all hanging)
+    cpu_leg_error = None
     if rank0 and not a.no_cpu_baseline:
-        n_streams = min(B, 512)
-        host = sh.host_iq()[:n_streams * S * sh.N]
-        cb = cpu_baseline(sf0, host, S * sh.N, n_streams, a.cpu_seconds)
-        threads = cb["cores"]
-        cb.update(host_cpu_info())
-        # the other two flag sets beside -O2 (same sources; result-identical for finite input)
-        cb["other_flags"] = [x for x in (cpu_baseline(sf0, host, S * sh.N, n_streams, 2.0, f, probe=False) for f in ("-O3 -fcx-limited-range", "-O3")) if x]
-        for x in cb["other_flags"]:
-            x.pop("sample", None); x.pop("kind", None); x.pop("unit", None)
-        if env.world > 1:
-            cb["where"] = "rank 0, on its own shard's IQ, the other %d rank(s) idle at a host barrier" % (env.world - 1)
-        line["cpu_baseline"] = cb
+        try:
+            n_streams = min(B, 512)
+            host = sh.host_iq()[:n_streams * S * sh.N]
+            cb = cpu_baseline(sf0, host, S * sh.N, n_streams, a.cpu_seconds)
+            threads = cb["cores"]
+            cb.update(host_cpu_info())
+            # the other two flag sets beside -O2 (same sources; result-identical for finite input)
+            cb["other_flags"] = [x for x in (cpu_baseline(sf0, host, S * sh.N, n_streams, 2.0, f, probe=False) for f in ("-O3 -fcx-limited-range", "-O3")) if x]
+            for x in cb["other_flags"]:
+                x.pop("sample", None); x.pop("kind", None); x.pop("unit", None)
+            if env.world > 1:
+                cb["where"] = "rank 0, on its own shard's IQ, the other %d rank(s) idle at a host barrier" % (env.world - 1)
+            line["cpu_baseline"] = cb
+        except Exception as e:
+            if env.world == 1:
+                raise
+            cpu_leg_error = line["cpu_baseline"] = {"error": repr(e)[:200]}
     if rank0 and not a.alias_windows:
-        line["oracle"] = sh.oracle_check(threads, moving=a.moving)
-        if env.world > 1:
-            line["oracle"]["where"] = "rank 0: every window of its own batch"
+        try:
+            line["oracle"] = sh.oracle_check(threads, moving=a.moving)
+            if env.world > 1:
+                line["oracle"]["where"] = "rank 0: every window of its own batch"
+        except Exception as e:
+            if env.world == 1:
+                raise
+            cpu_leg_error = line["oracle"] = {"error": repr(e)[:200]}
     env.host_barrier()
     if env.world > 1 and not a.alias_windows:
         every = sh.oracle_check_every_rank(moving=a.moving)
@@ -1132,19 +1274,24 @@ def main():
             e3, k3 = cur.measure(a.steps, a.warmup, 0.1, moving=True)
             mv = {"sf": sf, "Msym_s": r4(cur.W * a.steps * env.world / e3 / 1e6), "launch_us": r4(k3 * 1e3 / a.steps),
                   "frac": r4(cur.W * L.bytes_per_symbol(sf) / (k3 / 1e3 / a.steps) / 1e9 / HBM_PEAK_GBS)}
-            if rank0:                                           # (an exception here ends the run loudly -- before the barrier, which the launcher then tears down)
-                if sf != sf0:
-                    ent["oracle"] = cur.oracle_check(threads)
-                    if not a.no_cpu_baseline:
-                        n_streams = min(cur.B, 512)
-                        cbs = cpu_baseline(sf, cur.host_iq()[:n_streams * cur.S * cur.N], cur.S * cur.N, n_streams, 2.0, probe=False)
-                        ent["cpu_baseline"] = {"value": cbs["value"], "cores": cbs["cores"], "per_core": cbs["per_core"], "flags": "-O2"}
-                else:
-                    ent["oracle"] = line["oracle"]
-                    if "cpu_baseline" in line:
-                        ent["cpu_baseline"] = {k: line["cpu_baseline"][k] for k in ("value", "cores", "per_core")}
-                        ent["cpu_baseline"]["flags"] = "-O2"
-                mv["oracle"] = cur.oracle_check(threads, moving=True)
+            if rank0:                                           # (rank 0's CPU legs: the barrier below must be reached, see above)
+                try:
+                    if sf != sf0:
+                        ent["oracle"] = cur.oracle_check(threads)
+                        if not a.no_cpu_baseline:
+                            n_streams = min(cur.B, 512)
+                            cbs = cpu_baseline(sf, cur.host_iq()[:n_streams * cur.S * cur.N], cur.S * cur.N, n_streams, 2.0, probe=False)
+                            ent["cpu_baseline"] = {"value": cbs["value"], "cores": cbs["cores"], "per_core": cbs["per_core"], "flags": "-O2"}
+                    else:
+                        ent["oracle"] = line["oracle"]
+                        if "cpu_baseline" in line and "error" not in line["cpu_baseline"]:
+                            ent["cpu_baseline"] = {k: line["cpu_baseline"][k] for k in ("value", "cores", "per_core")}
+                            ent["cpu_baseline"]["flags"] = "-O2"
+                    mv["oracle"] = cur.oracle_check(threads, moving=True)
+                except Exception as e:
+                    if env.world == 1:
+                        raise
+                    cpu_leg_error = ent["error"] = mv["error"] = repr(e)[:200]
             env.host_barrier()
             per_sf.append(ent)
             moving.append(mv)
@@ -1194,6 +1341,8 @@ def main():
             if scaling is not None:
                 line["level3_scaling"] = scaling
     emit(env, line if rank0 else None)
+    if cpu_leg_error is not None:                           # the line is out (with the error in it); the run did not measure what it claims
+        raise SystemExit("bench.py: a CPU leg on rank 0 failed: %s" % (cpu_leg_error,))
 
 
 if __name__ == "__main__":

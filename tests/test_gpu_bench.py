@@ -15,7 +15,20 @@ def run_bench(*args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    return the_line(r.stdout)
+
+
+def the_line(stdout):
+    """THE line is the last line of stdout and the only one that starts with `{`; it must fit the driver's reader (bench.LINE_LIMIT)"""
+    import bench
+    lines = stdout.strip().splitlines()
+    assert lines[-1].startswith("{") and sum(ln.startswith("{") for ln in lines) == 1
+    assert len(lines[-1]) < bench.LINE_LIMIT, len(lines[-1])
+    return json.loads(lines[-1])
+
+
+def sections(stdout):
+    return {ln.split(" ", 2)[1]: json.loads(ln.split(" ", 2)[2]) for ln in stdout.strip().splitlines() if ln.startswith("SECTION ")}
 
 
 def test_mixed_sf_config_one_rank_over_rccl(gpu):
@@ -49,7 +62,7 @@ def test_gpus_n_without_a_launcher_starts_n_ranks(gpu):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sf", "7", "--channels", "256", "--symbols", "16", "--steps", "3",
                         "--warmup", "1", "--ramp-seconds", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    d = the_line(r.stdout)
     assert d["n_gpus"] == 2 and "2 rank(s)" in d["config"]["parallelism"]
     assert "re-launching" in r.stderr
 
@@ -62,7 +75,7 @@ def test_two_rank_line_carries_cpu_baseline_and_oracle(gpu):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sf", "7", "--channels", "256", "--symbols", "16", "--steps", "3",
                         "--warmup", "1", "--ramp-seconds", "0", "--cpu-seconds", "0.3"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    d = the_line(r.stdout)
     assert d["n_gpus"] == 2
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0
     assert d["oracle"]["windows"] == 256 * 16 and d["oracle"]["index_mismatches"] == 0
@@ -75,3 +88,31 @@ def test_gpus_n_that_contradicts_the_launcher_is_refused(gpu):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sf", "7", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                        timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def test_default_line_fits_the_reader_one_rank_and_two(gpu):
+    """The DEFAULT run (headline + every sweep section), at few steps: THE line stays under bench.LINE_LIMIT (round 5's 20.8 KB line was
+    lost by the driver's reader), carries the contract keys with roofline / cpu_baseline / oracle and a row per SF for every sweep; the
+    full sections are the earlier SECTION lines and gpurun_out/bench_sections.json. Then the same over two ranks sharing the GPU (gloo)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    for n, extra in ((1, {}), (2, {"LORA_BENCH_BACKEND": "gloo", "LORA_BENCH_ONE_DEVICE": "1"})):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2", "--cpu-seconds", "1"],
+                           capture_output=True, text=True, timeout=900, env=dict(env, **extra), cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        d = the_line(r.stdout)
+        assert d["n_gpus"] == n and d["roofline"]["frac"] > 0.3 and d["cpu_baseline"]["value"] > 0 and d["oracle"]["index_mismatches"] == 0
+        for k in ("per_sf", "moving", "level3"):
+            assert [e["sf"] for e in d[k]] == list(range(7, 13)), k
+        assert all(e["index_mismatches"] == 0 for e in d["per_sf"] + d["moving"])
+        assert all(e["oracle_channel_mismatches"] == 0 and e["trace_call_mismatches"] == 0 for e in d["level3"])
+        assert d["config5"]["gpu_vs_cpu_index_mismatches"] == 0 and d["mixed"]["oracle"]["index_mismatches"] == 0
+        assert d["mixed_level3"]["oracle_channel_mismatches"] == 0
+        full = sections(r.stdout)
+        assert set(full) >= {"config", "roofline", "cpu_baseline", "per_sf", "moving", "level3", "config5", "mixed", "mixed_level3"}
+        assert full["level3"][0]["running"]["chunk8"]["frac"] == d["level3"][0]["chunk8"]["frac"]
+        saved = json.load(open(os.path.join(ROOT, "gpurun_out", "bench_sections.json")))
+        assert saved["level3"] == full["level3"] and saved["value"] == d["value"]
+        if n == 2:
+            assert d["oracle"]["every_rank_sample"]["ranks"] == 2 and d["cpu_baseline"]["kind"] in ("reference", "port")

@@ -1,6 +1,12 @@
 """one screen of a bench.py line:  python tools/bench_digest.py gpurun_out/x_bench_default.json"""
 import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+lines = open(sys.argv[1]).read().strip().splitlines()
+d = json.loads([ln for ln in lines if ln.startswith("{")][-1])
+print("THE line: %d bytes" % len([ln for ln in lines if ln.startswith("{")][-1]))
+for ln in lines:                                         # the full sections are the earlier `SECTION <name> {...}` lines (bench.py::emit)
+    if ln.startswith("SECTION "):
+        _, name, body = ln.split(" ", 2)
+        d[name] = json.loads(body)
 r = d["roofline"]
 print("headline %.1f Msym/s frac %.4f launch %.1f us traffic %s src %s" % (d["value"], r["frac"], r["launch_us"], r.get("traffic"), (r.get("traffic_source") or {}).get("matches_this_tree")))
 print("cpu", {k: d.get("cpu_baseline", {}).get(k) for k in ("value", "cores", "kind")}, "oracle", d.get("oracle"))
