@@ -54,29 +54,47 @@ struct PinnedPool
     char *const base;
 };
 
-//! the buffer manager of ONE input port over its column of the pool: the "generic" manager's behaviour (a queue of free slabs, front()
-//! the next one a producer fills) on memory the DMA engine reads directly
-class PinnedSlabManager : public Pothos::BufferManager
+/*! The buffer manager of ONE input port over its column of the pool, written against Pothos/Framework/BufferManager.hpp as it is:
+ * empty() / pop() / push() are the three pure virtuals, the front buffer is published with setFrontBuffer(), and buffers come back
+ * through push() when the last reference to their ManagedBuffer is dropped (that is also how init() fills the queue: the buffers it
+ * makes go out of scope). Like the framework's "generic" manager the slabs are handed out in slab order -- slab k+1 only after slab k --
+ * so that ports fed at the same rate stay in the same generation of the pool, which is what makes a work() one strided DMA. */
+class PinnedSlabManager : public Pothos::BufferManager, public std::enable_shared_from_this<PinnedSlabManager>
 {
 public:
-    PinnedSlabManager(const std::shared_ptr<PinnedPool> &pool, const size_t port) : _pool(pool), _port(port) {}
-    void init(const Pothos::BufferManagerArgs &a)
+    PinnedSlabManager(const std::shared_ptr<PinnedPool> &pool, const size_t port) : _pool(pool), _port(port), _next(0) {}
+    void init(const Pothos::BufferManagerArgs &args)
     {
-        args = a;
-        args.numBuffers = _pool->numBuffers; args.bufferSize = _pool->slabBytes;
-        _ready.clear(); _held.clear();
+        Pothos::BufferManager::init(args);
+        _slots.assign(_pool->numBuffers, Pothos::ManagedBuffer());
+        _next = 0;
         for (size_t k = 0; k < _pool->numBuffers; k++)
         {
             Pothos::ManagedBuffer b;
             b.reset(this->shared_from_this(), Pothos::SharedBuffer(_pool->address(k, _port), _pool->slabBytes, _pool), k);
-            _ready.push_back(b);
-        }
-        _initialized = true;
-        this->refreshFront();
+        }                                                       // (out of scope: returned to this manager through push())
+    }
+    bool empty(void) const { return _slots.empty() || !_slots[_next]; }
+    void pop(const size_t)
+    {
+        if (this->empty()) return;
+        _slots[_next].reset();
+        _next = (_next + 1) % _slots.size();
+        if (this->empty()) this->setFrontBuffer(Pothos::BufferChunk::null());
+        else this->setFrontBuffer(_slots[_next]);
+    }
+    void push(const Pothos::ManagedBuffer &buff)
+    {
+        const size_t k = buff.getSlabIndex();
+        if (k >= _slots.size()) return;
+        _slots[k] = buff;
+        if (k == _next) this->setFrontBuffer(buff);
     }
 private:
     std::shared_ptr<PinnedPool> _pool;
     const size_t _port;
+    std::vector<Pothos::ManagedBuffer> _slots;                  // by slab index; the one at _next is the front
+    size_t _next;
 };
 
 class LoRaDemodBatch : public Pothos::Block
@@ -86,7 +104,7 @@ class LoRaDemodBatch : public Pothos::Block
 public:
     LoRaDemodBatch(const size_t sf, const size_t channels) :
         B(channels), _d(nullptr), _sfs(channels, int32_t(sf)), _devices(1, 0), _sync(0x12), _thresh(-30.0), _mtu(256), _maxWindows(64),
-        _fftCap(128), _fftDropped(0), _debugPorts(false), _signals(true), _active(false)
+        _fftCap(128), _fftDropped(0), _pinnedLimitMiB(8192), _debugPorts(false), _signals(true), _active(false)
     {
         _d = makeDemod(_sfs, _devices);
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setSync));
@@ -97,6 +115,10 @@ public:
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setMaxWindows));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setDebugPorts));
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setSignals));
+        this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setPinnedInputLimit));
+        this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, slabRowRuns));
+        this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, workRuns));
+        this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, fftFramesDropped));
         _in.resize(B); _msg.resize(B); _raw.resize(B); _dec.resize(B); _fft.resize(B);
         for (size_t c = 0; c < B; c++)
         {
@@ -127,6 +149,9 @@ public:
     void setMaxWindows(const size_t k) { _maxWindows = k ? k : 1; if (_debugPorts) attachPorts(_d); }
     void setSignals(const bool on) { _signals = on; lorahip_demod_set_signals(_d, on ? 1 : 0); }
     size_t fftFramesDropped(void) const { return _fftDropped; }
+    //! most pinned host memory (MiB) the input slabs of all ports together may take; above it (or at 0) the ports get the framework's
+    //! default buffers and every work() uploads through the library's pinned staging instead. Before the ports are connected.
+    void setPinnedInputLimit(const size_t MiB) { _pinnedLimitMiB = MiB; }
 
     //! the reference block's raw / dec / fft outputs and their labels; off unless asked for (see the head of this file)
     void setDebugPorts(const bool on)
@@ -177,6 +202,7 @@ public:
             any = any || _avail[c] >= 2 * N;                                            // :148
         }
         if (!any) return;
+        _workRuns++;
         if (_debugPorts) lorahip_demod_set_trace(_d, 1);                                // labels and per-call signals come from the trace
 
         // every part's channels in one launch on its device; the parts run side by side, each from its own host thread (inside the library)
@@ -230,8 +256,10 @@ public:
         if (_debugPorts) lorahip_demod_set_trace(_d, 0);                                // the next work() starts a fresh trace
     }
 
-    //! work() calls that uploaded their inputs as rows of the pinned pool (one strided DMA)
+    //! work() calls that uploaded their inputs as rows of the pinned pool (one strided DMA), and those that ran at all: a ratio below
+    //! one means ports out of step (different generations) or inputs that were not this block's slabs
     size_t slabRowRuns(void) const { return _rowRuns; }
+    size_t workRuns(void) const { return _workRuns; }
 
     /*! Input buffers for the upstream blocks to write into (the reference: "slabs large enough for fft input", LoRaDemod.cpp:346-357).
      * Here: PINNED slabs of (maxWindows + 2) symbols, all ports' slabs in one allocation (PinnedPool), so that what the framework
@@ -241,19 +269,27 @@ public:
         if (!domain.empty() || name.empty() || name.find_first_not_of("0123456789") != std::string::npos) return Pothos::Block::getInputBufferManager(name, domain);
         const size_t c = size_t(std::atol(name.c_str()));
         if (c >= B) return Pothos::Block::getInputBufferManager(name, domain);
+        // one row stride for all ports: the pool is for ONE spreading factor (a mixed-SF block would pin the largest SF's slab for every
+        // port -- 32x too much for its SF7 channels); such a block, and one whose pool would not fit the limit, gets the default buffers
+        for (size_t k = 1; k < B; k++) if (_sfs[k] != _sfs[0]) return Pothos::Block::getInputBufferManager(name, domain);
         Pothos::BufferManagerArgs args;
-        size_t maxN = 0;
-        for (size_t k = 0; k < B; k++) maxN = std::max(maxN, size_t(1) << _sfs[k]);
-        const size_t slabBytes = std::max(args.bufferSize, (_maxWindows + 2) * maxN * sizeof(cf32));         // >= 2N: the reference's bound (:352-353)
+        const size_t N = size_t(1) << _sfs[0];
+        const size_t slabBytes = std::max(args.bufferSize, (_maxWindows + 2) * N * sizeof(cf32));            // >= 2N: the reference's bound (:352-353)
         // (a pool of another slab size -- setMaxWindows / setSpreadFactors since the ports were last asked for -- is left to the managers
         // that hold it; ports on different pools are uploaded piece by piece, see inputsAreOneSlabGeneration)
         if (!_pool || _pool->slabBytes != slabBytes)
         {
-            // two generations: one is being filled by the upstream blocks while the other is inside work()
-            std::shared_ptr<PinnedPool> pool(new PinnedPool(B, 2, slabBytes));
+            // generations: one inside work(), one being filled by the upstream blocks, one free so that a producer that runs ahead does
+            // not stall (the framework's default is 4); two if three do not fit the limit
+            const size_t limit = _pinnedLimitMiB << 20;
+            size_t gens = 3;
+            if (B * gens * slabBytes > limit) gens = 2;
+            if (B * gens * slabBytes > limit) return Pothos::Block::getInputBufferManager(name, domain);
+            std::shared_ptr<PinnedPool> pool(new PinnedPool(B, gens, slabBytes));
             if (pool->base == nullptr) return Pothos::Block::getInputBufferManager(name, domain);            // no pinned memory to be had: the default
             _pool = pool;
         }
+        args.numBuffers = _pool->numBuffers; args.bufferSize = _pool->slabBytes;
         std::shared_ptr<PinnedSlabManager> m(new PinnedSlabManager(_pool, c));
         m->init(args);
         return m;
@@ -426,7 +462,7 @@ private:
     std::vector<int32_t> _sfs;                              // per channel
     std::vector<int> _devices;
     unsigned char _sync; double _thresh; size_t _mtu;       // the setters' values, re-applied when the object is rebuilt
-    size_t _maxWindows, _fftCap, _fftDropped;
+    size_t _maxWindows, _fftCap, _fftDropped, _pinnedLimitMiB;
     bool _debugPorts, _signals, _active;
     std::vector<Pothos::InputPort *> _in;
     std::vector<Pothos::OutputPort *> _msg, _raw, _dec, _fft;
@@ -435,7 +471,7 @@ private:
     std::vector<int32_t> _sigCh, _sigErr; std::vector<float> _sigPow, _sigSnr;
     std::vector<cf32> _stRaw, _stDec, _stFft;               // host staging of the three ports, [channel][capacity]
     std::shared_ptr<PinnedPool> _pool;                      // the input slabs of all ports (getInputBufferManager)
-    std::vector<int64_t> _first; const char *_rowBase = nullptr; size_t _rowRuns = 0;
+    std::vector<int64_t> _first; const char *_rowBase = nullptr; size_t _rowRuns = 0, _workRuns = 0;
 };
 
 static Pothos::BlockRegistry registerLoRaDemodBatch("/lora/lora_demod_batch", &LoRaDemodBatch::make);

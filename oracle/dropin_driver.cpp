@@ -50,16 +50,18 @@ struct Feeder
 {
     BatchHandle *h;
     const float *iq; size_t spc;
+    std::vector<Pothos::InputPort *> in;                        // looked up once: the ports live in a map keyed by name
     std::vector<size_t> pos;                                    // samples consumed so far (absolute)
     std::vector<size_t> have;                                   // slabs: samples of the channel that have arrived
-    std::vector<char *> cur; std::vector<size_t> curLen, curOff; // slabs: the buffer being presented, its valid samples, the read offset
+    std::vector<Pothos::BufferChunk> chunk;                     // slabs: the buffer being presented (holding it keeps it out of its manager's pool)
+    std::vector<char *> cur; std::vector<size_t> curLen, curOff; // ... its memory, its valid samples, the read offset
     double sourceSeconds;
-    Feeder(BatchHandle *h_, const float *iq_, const size_t spc_) : h(h_), iq(iq_), spc(spc_), pos(h_->B, 0), have(h_->B, 0), cur(h_->B, nullptr), curLen(h_->B, 0), curOff(h_->B, 0), sourceSeconds(0.0)
+    Feeder(BatchHandle *h_, const float *iq_, const size_t spc_) : h(h_), iq(iq_), spc(spc_), in(h_->B), pos(h_->B, 0), have(h_->B, 0), chunk(h_->B), cur(h_->B, nullptr), curLen(h_->B, 0), curOff(h_->B, 0), sourceSeconds(0.0)
     {
-        // a new stream on every port: whatever buffer the stream before still held goes back to its manager
-        Pothos::ManagedBuffer old;
-        if (h->slabs) for (auto &m : h->mgr) while (m->popHeld(old)) m->push(old);
+        for (size_t c = 0; c < h->B; c++) in[c] = h->block->input(int(c));
     }
+    // (a new stream on every port: the buffers the stream before still held went back to their managers when its Feeder -- the last
+    // holder of their chunks -- was destroyed; that is how the framework returns buffers, ManagedBuffer's reference count)
     //! samples [have, w) of every channel arrive
     void arrive(const size_t w)
     {
@@ -70,14 +72,14 @@ struct Feeder
             Pothos::BufferManager &m = *h->mgr[c];
             const size_t rem = curLen[c] - curOff[c], add = w - have[c];
             if (m.empty() || m.front().length < (rem + add) * sizeof(cf32)) throw std::runtime_error("input slab too small for an arrival");
-            char *next = m.front().as<char *>();
+            Pothos::BufferChunk nextChunk = m.front();              // taken BEFORE pop(): the reference that keeps it out of the pool
+            char *next = nextChunk.as<char *>();
             m.pop((rem + add) * sizeof(cf32));
             if (rem) std::memcpy(next, cur[c] + curOff[c] * sizeof(cf32), rem * sizeof(cf32));      // the accumulator's carry-over (< 2N samples)
             const auto t0 = std::chrono::steady_clock::now();
             std::memcpy(next + rem * sizeof(cf32), iq + 2 * (c * spc + have[c]), add * sizeof(cf32)); // the upstream block produces
             sourceSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            Pothos::ManagedBuffer old;
-            if (cur[c] && m.popHeld(old)) m.push(old);              // the buffer before is free again
+            chunk[c] = nextChunk;                                   // the buffer before is free again: its last reference goes here
             cur[c] = next; curLen[c] = rem + add; curOff[c] = 0; have[c] = w;
         }
     }
@@ -87,17 +89,17 @@ struct Feeder
         bool any = false;
         for (size_t c = 0; c < h->B; c++)
         {
-            auto in = h->block->input(int(c));
-            if (h->slabs) { in->_elems = curLen[c] - curOff[c]; in->_buff = Pothos::BufferChunk::view(cur[c] + curOff[c] * sizeof(cf32), in->_elems * sizeof(cf32)); }
-            else { in->_elems = have[c] - pos[c]; in->_buff = Pothos::BufferChunk::view(const_cast<float *>(iq) + 2 * (c * spc + pos[c]), in->_elems * sizeof(cf32)); }
-            in->consumed = 0;
-            any = any || in->_elems >= h->need[c];
+            Pothos::InputPort *p = in[c];
+            if (h->slabs) { p->_elems = curLen[c] - curOff[c]; p->_buff = Pothos::BufferChunk::view(cur[c] + curOff[c] * sizeof(cf32), p->_elems * sizeof(cf32)); }
+            else { p->_elems = have[c] - pos[c]; p->_buff = Pothos::BufferChunk::view(const_cast<float *>(iq) + 2 * (c * spc + pos[c]), p->_elems * sizeof(cf32)); }
+            p->consumed = 0;
+            any = any || p->_elems >= h->need[c];
         }
         return any;
     }
     size_t consumed(const size_t c)
     {
-        const size_t used = h->block->input(int(c))->consumed;
+        const size_t used = in[c]->consumed;
         pos[c] += used; curOff[c] += used;
         return used;
     }
@@ -111,8 +113,8 @@ static void prepare(BatchHandle *h)
     for (size_t c = 0; c < h->B && h->ports; c++)
     {
         const std::string s = std::to_string(c);
-        const size_t nbRaw = h->block->getOutputBufferManager("raw" + s, "")->args.bufferSize;
-        const size_t nbFft = h->block->getOutputBufferManager("fft" + s, "")->args.bufferSize;
+        const size_t nbRaw = h->block->getOutputBufferManager("raw" + s, "")->front().length;      // (the size of the buffers it hands out)
+        const size_t nbFft = h->block->getOutputBufferManager("fft" + s, "")->front().length;
         h->rawBuf[c].resize(nbRaw / sizeof(cf32)); h->decBuf[c].resize(nbRaw / sizeof(cf32)); h->fftBuf[c].resize(nbFft / sizeof(cf32));
         h->block->output("raw" + s)->_buff = Pothos::BufferChunk::view(h->rawBuf[c].data(), nbRaw);
         h->block->output("dec" + s)->_buff = Pothos::BufferChunk::view(h->decBuf[c].data(), nbRaw);
@@ -167,6 +169,14 @@ int loradrop_batch_set(void *p, const char *name, const double v)
     try { it->second(v); } catch (const std::exception &) { return -2; }
     if (std::string(name) == "setDebugPorts") h->ports = v != 0.0;
     return 0;
+}
+
+//! a registered getter of the block (slabRowRuns, workRuns, fftFramesDropped); -1 if there is none of that name
+double loradrop_batch_get(void *p, const char *name)
+{
+    auto h = reinterpret_cast<BatchHandle *>(p);
+    auto it = h->block->getters.find(name);
+    return it == h->block->getters.end() ? -1.0 : it->second();
 }
 
 //! a registered call that takes a string (setDevices("0,1,..."))

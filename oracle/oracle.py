@@ -470,6 +470,8 @@ class DropInBatch:
         L.loradrop_batch_input_slabs_active.argtypes = [C.c_void_p]
         L.loradrop_batch_num_signals.restype = C.c_size_t
         L.loradrop_batch_num_signals.argtypes = [C.c_void_p]
+        L.loradrop_batch_get.restype = C.c_double
+        L.loradrop_batch_get.argtypes = [C.c_void_p, C.c_char_p]
         L.loradrop_batch_get_signal.restype = C.c_double
         L.loradrop_batch_get_signal.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
         self.sf, self.B = sf, channels
@@ -498,6 +500,12 @@ class DropInBatch:
 
     def input_slabs_active(self):
         return bool(self.L.loradrop_batch_input_slabs_active(self.h))
+
+    def get(self, name):
+        """a registered getter of the block (slabRowRuns, workRuns, fftFramesDropped)"""
+        v = float(self.L.loradrop_batch_get(self.h, name.encode()))
+        assert v >= 0, name
+        return int(v)
 
     def bench(self, iq, chunk):
         """the block as a receiver, timed (oracle/dropin_driver.cpp::loradrop_batch_bench): iq (channels, samples) complex64 in ordinary

@@ -21,6 +21,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <typeinfo>
 #include <vector>
 
@@ -40,7 +41,48 @@ struct DType
     size_t size;
 };
 
-//! shared-ownership buffer, copy = alias (same as the real BufferChunk)
+//! memory + the thing that keeps it alive (Pothos/Framework/SharedBuffer.hpp: the container form is how a block wraps memory of its own)
+struct SharedBuffer
+{
+    SharedBuffer(void) : _address(0), _length(0) {}
+    SharedBuffer(const size_t address, const size_t length, std::shared_ptr<void> container) : _address(address), _length(length), _container(container) {}
+    size_t getAddress(void) const { return _address; }
+    size_t getLength(void) const { return _length; }
+    size_t _address, _length;
+    std::shared_ptr<void> _container;
+};
+
+class BufferManager;
+/*! A buffer that belongs to a manager's pool (Pothos/Framework/ManagedBuffer.hpp). Reference counted like the real one: when the last
+ * copy -- and the last BufferChunk that refers to it -- is gone, the buffer goes back to its manager through BufferManager::push();
+ * that is the ONLY way the framework returns buffers, so a custom manager that relies on anything else does not work here either. */
+class ManagedBuffer
+{
+public:
+    ManagedBuffer(void) : _impl(nullptr) {}
+    ManagedBuffer(const ManagedBuffer &o) : _impl(o._impl) { if (_impl) _impl->counter++; }
+    ManagedBuffer &operator=(const ManagedBuffer &o) { if (o._impl) o._impl->counter++; release(); _impl = o._impl; return *this; }
+    ~ManagedBuffer(void) { release(); }
+    void reset(void) { release(); _impl = nullptr; }
+    void reset(std::shared_ptr<BufferManager> manager, const SharedBuffer &buff, const size_t slabIndex = 0)
+    {
+        release();
+        _impl = new Impl();
+        _impl->counter = 1; _impl->weakManager = manager; _impl->buffer = buff; _impl->slabIndex = slabIndex;
+    }
+    explicit operator bool(void) const { return _impl != nullptr; }
+    const SharedBuffer &getBuffer(void) const { return _impl->buffer; }
+    size_t getSlabIndex(void) const { return _impl->slabIndex; }
+    std::shared_ptr<BufferManager> getBufferManager(void) const { return _impl ? _impl->weakManager.lock() : std::shared_ptr<BufferManager>(); }
+    size_t useCount(void) const { return _impl ? size_t(_impl->counter) : 0; }
+private:
+    struct Impl { int counter; std::weak_ptr<BufferManager> weakManager; SharedBuffer buffer; size_t slabIndex; };
+    inline void release(void);                                  // (defined behind BufferManager)
+    Impl *_impl;
+};
+
+//! shared-ownership buffer, copy = alias (same as the real BufferChunk); a chunk made from a ManagedBuffer keeps that buffer out of its
+//! manager's pool for as long as the chunk (or a copy) lives
 struct BufferChunk
 {
     BufferChunk(void) : address(0), length(0), elemSize(1) {}
@@ -50,6 +92,8 @@ struct BufferChunk
         std::memset(_mem.get(), 0, length + 16);
         address = size_t(_mem.get());
     }
+    BufferChunk(const ManagedBuffer &b) : address(b ? b.getBuffer().getAddress() : 0), length(b ? b.getBuffer().getLength() : 0), elemSize(1), _managed(b) {}
+    static const BufferChunk &null(void) { static const BufferChunk n; return n; }
     //! a request the real framework could never satisfy (a size_t that wrapped around) must fail, not wrap again
     static char *alloc(const size_t elemSize, const size_t numElems)
     {
@@ -66,10 +110,12 @@ struct BufferChunk
     }
     template <typename T> T as(void) const { return reinterpret_cast<T>(address); }
     size_t elements(void) const { return length / elemSize; }
+    const ManagedBuffer &getManagedBuffer(void) const { return _managed; }
     size_t address;
     size_t length;
     size_t elemSize;
     std::shared_ptr<char> _mem;
+    ManagedBuffer _managed;
 };
 
 struct Packet
@@ -112,80 +158,84 @@ struct BufferManagerArgs
     long nodeAffinity;
 };
 
-//! memory + the thing that keeps it alive (Pothos/Framework/SharedBuffer.hpp: the container form is how a block wraps memory of its own)
-struct SharedBuffer
+/*! Pothos/Framework/BufferManager.hpp with the surface of the real class and no more: empty() / pop() / push() are pure virtual, the
+ * front buffer and the initialised flag are private (a manager publishes its front through setFrontBuffer), there are no queues to
+ * inherit. make("generic", args) is the framework's own heap manager (GenericBufferManager below). The recording driver plays the
+ * framework: it asks the block for its managers, takes front() / pop()s, and lets go of the chunks -- which returns them via push(). */
+class BufferManager
 {
-    SharedBuffer(void) : _address(0), _length(0) {}
-    SharedBuffer(const size_t address, const size_t length, std::shared_ptr<void> container) : _address(address), _length(length), _container(container) {}
-    size_t getAddress(void) const { return _address; }
-    size_t getLength(void) const { return _length; }
-    size_t _address, _length;
-    std::shared_ptr<void> _container;
-};
-
-struct BufferManager;
-//! a buffer that belongs to a manager's pool (Pothos/Framework/ManagedBuffer.hpp)
-struct ManagedBuffer
-{
-    ManagedBuffer(void) : _slab(0) {}
-    void reset(std::shared_ptr<BufferManager> manager, const SharedBuffer &buff, const size_t slabIndex = 0) { _manager = manager; _buff = buff; _slab = slabIndex; }
-    const SharedBuffer &getBuffer(void) const { return _buff; }
-    size_t getSlabIndex(void) const { return _slab; }
-    std::weak_ptr<BufferManager> _manager;
-    SharedBuffer _buff;
-    size_t _slab;
-};
-
-/*! Pothos/Framework/BufferManager.hpp, the part a custom manager overrides: init() makes the pool, front() is the next buffer a producer
- * may fill, pop() takes it out of the ready queue, push() gives a buffer back. make("generic", args) is the framework's own: heap
- * buffers. (The recording driver plays the framework: it asks the block for its managers and moves the buffers.) */
-struct BufferManager : public std::enable_shared_from_this<BufferManager>
-{
+public:
     typedef std::shared_ptr<BufferManager> Sptr;
-    BufferManager(void) : _initialized(false), _frontIndex(0) {}
     virtual ~BufferManager(void) {}
-    static Sptr make(const std::string &name, const BufferManagerArgs &args)
+    static inline Sptr make(const std::string &name, const BufferManagerArgs &args);
+    virtual void init(const BufferManagerArgs &) { _initialized = true; }
+    virtual bool empty(void) const = 0;
+    const BufferChunk &front(void) const { return _frontBuffer; }
+    virtual void pop(const size_t numBytes) = 0;
+    virtual void push(const ManagedBuffer &buff) = 0;
+    bool isInitialized(void) const { return _initialized; }
+protected:
+    BufferManager(void) : _initialized(false) {}
+    void setFrontBuffer(const BufferChunk &buff) { _frontBuffer = buff; }
+private:
+    bool _initialized;
+    BufferChunk _frontBuffer;
+};
+
+inline void ManagedBuffer::release(void)
+{
+    if (_impl == nullptr || --_impl->counter != 0) return;
+    Impl *impl = _impl;
+    _impl = nullptr;
+    std::shared_ptr<BufferManager> manager = impl->weakManager.lock();
+    if (!manager) { delete impl; return; }
+    // the last reference is gone: back to the manager (which takes a new reference)
+    ManagedBuffer again;
+    again._impl = impl;
+    impl->counter = 1;
+    manager->push(again);
+    if (--impl->counter == 0) delete impl;                      // (a manager that did not keep it)
+    again._impl = nullptr;
+}
+
+//! the framework's "generic" manager: numBuffers heap buffers handed out in slab order
+class GenericBufferManager : public BufferManager, public std::enable_shared_from_this<GenericBufferManager>
+{
+public:
+    void init(const BufferManagerArgs &a)
     {
-        Sptr m(new BufferManager());
-        m->name = name;
-        m->init(args);
-        return m;
-    }
-    virtual void init(const BufferManagerArgs &a)
-    {
-        args = a;
-        _initialized = true;
-        _ready.clear();
+        BufferManager::init(a);
+        _slots.assign(a.numBuffers, ManagedBuffer()); _next = 0; _count = 0;
+        std::shared_ptr<char> mem(new char[(a.bufferSize ? a.bufferSize : 1) * a.numBuffers], std::default_delete<char[]>());
         for (size_t i = 0; i < a.numBuffers; i++)
         {
-            std::shared_ptr<char> mem(new char[a.bufferSize ? a.bufferSize : 1], std::default_delete<char[]>());
             ManagedBuffer b;
-            b.reset(shared_from_this(), SharedBuffer(size_t(mem.get()), a.bufferSize, mem), i);
-            _ready.push_back(b);
-        }
-        refreshFront();
+            b.reset(this->shared_from_this(), SharedBuffer(size_t(mem.get()) + i * a.bufferSize, a.bufferSize, mem), i);
+        }                                                       // (leaving scope returns each buffer to this manager: push)
     }
-    bool initialized(void) const { return _initialized; }
-    virtual bool empty(void) const { return _ready.empty(); }
-    const BufferChunk &front(void) const { return _front; }
-    virtual void pop(const size_t) { if (!_ready.empty()) { _held.push_back(_ready.front()); _ready.pop_front(); } refreshFront(); }
-    virtual void push(const ManagedBuffer &buff) { _ready.push_back(buff); refreshFront(); }
-    //! (driver side) the buffer pop() took out most recently but one ... the oldest still held: what goes back first
-    bool popHeld(ManagedBuffer &out) { if (_held.empty()) return false; out = _held.front(); _held.pop_front(); return true; }
-    std::string name;
-    BufferManagerArgs args;
-protected:
-    void setFrontBuffer(const BufferChunk &b) { _front = b; }
-    void refreshFront(void)
+    bool empty(void) const { return _slots.empty() || !_slots[_next]; }
+    void pop(const size_t)
     {
-        if (_ready.empty()) { _front = BufferChunk(); return; }
-        _front = BufferChunk::view(reinterpret_cast<void *>(_ready.front().getBuffer().getAddress()), _ready.front().getBuffer().getLength());
+        if (empty()) return;
+        _slots[_next].reset(); _count--;
+        _next = (_next + 1) % _slots.size();
+        this->setFrontBuffer(empty() ? BufferChunk::null() : BufferChunk(_slots[_next]));
     }
-    bool _initialized;
-    size_t _frontIndex;
-    BufferChunk _front;
-    std::deque<ManagedBuffer> _ready, _held;
+    void push(const ManagedBuffer &buff)
+    {
+        _slots.at(buff.getSlabIndex()) = buff; _count++;
+        if (buff.getSlabIndex() == _next) this->setFrontBuffer(BufferChunk(buff));
+    }
+private:
+    std::vector<ManagedBuffer> _slots; size_t _next = 0, _count = 0;
 };
+
+inline BufferManager::Sptr BufferManager::make(const std::string &, const BufferManagerArgs &args)
+{
+    Sptr m(new GenericBufferManager());
+    m->init(args);
+    return m;
+}
 
 struct InputPort
 {
@@ -250,8 +300,14 @@ public:
     {
         stringCalls[name] = [obj, m](const std::string &v) { (obj->*m)(v); };
     }
+    //! getters: the arithmetic ones can be read by the driver (name -> double), the others are not driven
     template <typename C, typename R>
-    void registerCall(C *, const char *, R (C::*)(void) const) {}     // getters are not driven
+    typename std::enable_if<std::is_arithmetic<R>::value>::type registerCall(C *obj, const char *name, R (C::*m)(void) const)
+    {
+        getters[name] = [obj, m](void) { return double((obj->*m)()); };
+    }
+    template <typename C, typename R>
+    typename std::enable_if<!std::is_arithmetic<R>::value>::type registerCall(C *, const char *, R (C::*)(void) const) {}
     void registerSignal(const std::string &name) { signalNames.push_back(name); }
     template <typename T>
     void emitSignal(const std::string &name, const T &v)
@@ -280,6 +336,7 @@ public:
     std::map<std::string, OutputPort> outputs;
     std::map<std::string, std::function<void(double)>> calls;
     std::map<std::string, std::function<void(const std::string &)>> stringCalls;
+    std::map<std::string, std::function<double(void)>> getters;
     std::vector<std::string> signalNames;
     std::vector<SignalRecord> signals;
 };

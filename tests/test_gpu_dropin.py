@@ -354,6 +354,8 @@ def test_batch_block_through_its_own_pinned_input_slabs(gpu, golden, oracle, sf)
         blk.set("setMTU", mtu)
         chans, signals, works = blk.run(iq)
         assert blk.input_slabs_active() and works >= 1
+        # every work() that ran took the one-DMA path: the ports walk the pool's generations in step (slabs handed out in slab order)
+        assert blk.get("workRuns") >= 1 and blk.get("slabRowRuns") == blk.get("workRuns")
         sig_by_channel, cur = {}, None
         for name, v in signals:
             if name == "channel":
@@ -369,6 +371,34 @@ def test_batch_block_through_its_own_pinned_input_slabs(gpu, golden, oracle, sf)
             gs, ws = sig_by_channel.get(c, []), want["signals"]
             assert [n for n, _ in gs] == [n for n, _ in ws]
             assert np.allclose([v for _, v in gs], [v for _, v in ws], rtol=0, atol=TOL_DB)
+        blk.close()
+
+
+@pytest.mark.gpu
+def test_batch_block_pinned_pool_policy(gpu, golden, oracle):
+    """The pinned pool is bounded: a block whose slabs would not fit setPinnedInputLimit (MiB), and a mixed-SF block (one row stride
+    would pin the largest SF's slab for every port), answer getInputBufferManager() like Pothos::Block does -- the framework's default
+    buffers -- and run through lorahip_demod_run instead; results unchanged."""
+    from oracle.oracle import Ref, REF_VARIANTS, DropInBatch
+    _need(REF_VARIANTS["dropin"])
+    _need(REF_VARIANTS["-O2"])
+    rng = np.random.default_rng(77)
+    iq, mtu = streams_for(golden, oracle, 8, rng)
+    want = [Ref("-O2").demod_run(8, iq[c], mtu=mtu) for c in range(3)]
+    for limit, mixed, active in ((0, False, False), (1, False, True), (8192, True, False)):
+        blk = DropInBatch(8, 3, max_windows=64)
+        blk.set("setPinnedInputLimit", limit)
+        if mixed:
+            assert blk.set_string("setSpreadFactors", "8,8,9") == 0
+        blk.use_input_slabs(True)
+        blk.set("setMTU", mtu)
+        chans, _, works = blk.run(iq)
+        assert blk.input_slabs_active() == active, (limit, mixed)
+        assert (blk.get("slabRowRuns") > 0) == active
+        if not mixed:
+            for c in range(3):
+                assert chans[c]["consumed"] == int(want[c]["consumed"].sum())
+                assert all(np.array_equal(a, b) for a, (_, b) in zip(chans[c]["packets"], want[c]["packets"]))
         blk.close()
 
 
