@@ -62,8 +62,11 @@ extern "C" {
 
 const char *lorahip_strerror(int code);
 const char *lorahip_last_error(void);       /* thread-local text of the last LORAHIP_E_HIP */
-int lorahip_version(void);                  /* ABI version, currently 3 (1 -> 2: lorahip_work_result grew, level-3 ports and labels;
-                                               2 -> 3, additions only: level-3 signals, append runs / lorahip_demod_receive, lorahip_rx_*) */
+int lorahip_version(void);                  /* ABI version, currently 4 (1 -> 2: lorahip_work_result grew, level-3 ports and labels;
+                                               2 -> 3, additions only: level-3 signals, append runs / lorahip_demod_receive, lorahip_rx_*;
+                                               3 -> 4, additions only: lorahip_demod_receive_flush, _run_host_rows, _stream_wait / _stream_follow,
+                                               _set_stream_lanes / _stream_lanes, _set_stream_grid, _set_variant, _set_record_capacity,
+                                               lorahip_decode_packets_host, lorahip_decode_max_symbols, lorahip_decode_max_data_length; signals in pipelined receive steps) */
 int lorahip_device_count(void);             /* number of usable gfx950 devices, 0 if none */
 int lorahip_selfcheck(void);                /* host-only: the kernels' compile-time LDS layouts are consistent; no device needed */
 
@@ -512,10 +515,11 @@ int lorahip_add_awgn(lorahip_ctx *ctx, float *iq_dev, size_t n_samples, float si
  * Batched decoder (the step after the path: SURVEY.md section 8f #2): what the LoRaDecoder block does with one symbol
  * message (LoRaDecoder.cpp:196-397 on LoRaCodes.hpp), for n_packets messages at once. Parameters and defaults are the
  * block's (LoRaDecoder.cpp:98-110, setters :134-191): coding rate "4/4".."4/8" = rdd 0..4.
- *   packet p: nsyms_dev[p] symbols at syms_dev + p*sym_stride (sym_stride <= 512)
+ *   packet p: nsyms_dev[p] symbols at syms_dev + p*sym_stride (sym_stride <= lorahip_decode_max_symbols() = 16384)
  *   out_len_dev[p]: number of output elements posted at out_dev + p*out_stride -- bytes, or uint16 symbols when
- *       interleaving is off --, -1 if the block posts nothing (fewer than 8 symbols, or dropped), -2 if the packet is
- *       longer than this build supports or than sym_stride; dropped_dev[p] = 1 where the block calls drop() (the "dropped" signal).
+ *       interleaving is off --, -1 if the block posts nothing (fewer than 8 symbols, or dropped), -2 if the row does not hold the
+ *       symbols the packet's length needs (nsyms_dev[p] > sym_stride: the caller's rows are too short -- an error, see
+ *       lorahip_decode_max_symbols); dropped_dev[p] = 1 where the block calls drop() (the "dropped" signal).
  *   out_stride: even, >= 2*(sym_stride + 8). ctx supplies the device and the stream only (any SF).
  * ------------------------------------------------------------------------------------- */
 typedef struct lorahip_decoder_cfg {
@@ -538,8 +542,14 @@ int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, con
 int lorahip_decode_packets_host(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, const uint16_t *syms, size_t sym_stride,
                                 const int32_t *nsyms, size_t n_packets, uint8_t *out, size_t out_stride, int32_t *out_len,
                                 int32_t *dropped);
-/* the longest packet (symbols) a row may hold in this build: sym_stride <= this; longer packets are reported with out_len = -2 */
+/* the longest row (symbols): sym_stride <= this (16384). A packet of ANY length up to its row decodes as the reference decodes it: the
+ * reference de-interleaves every codeword of a message but only those the announced length needs reach the output (LoRaDecoder.cpp:
+ * 315-361) -- at most 2 * 260 with an explicit header --, so the kernel's working set follows the configuration, not the packet. A packet
+ * LONGER than its row (nsyms_dev[p] > sym_stride) still decodes when the symbols its length needs lie inside the row; otherwise
+ * out_len = -2: the caller's rows are too short, which a caller must treat as an error (LoRaDecoderBatch.cpp throws). */
 int lorahip_decode_max_symbols(void);
+/* without a header: the largest data_length (4096 bytes); a larger one is refused with LORAHIP_E_INVALID */
+int lorahip_decode_max_data_length(void);
 
 /* -------------------------------------------------------------------------------------
  * Front-end channeliser (the step before the path: SURVEY.md section 8f #4). NOT a reference component: the

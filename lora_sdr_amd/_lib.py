@@ -143,6 +143,7 @@ SIGNATURES = {
     "lorahip_decode_packets_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                              C.c_void_p, C.c_void_p]),
     "lorahip_decode_max_symbols": (C.c_int, []),
+    "lorahip_decode_max_data_length": (C.c_int, []),
     "lorahip_channelizer_phase_inc": (C.c_uint64, [C.c_double]),
     "lorahip_channelizer_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "lorahip_channelizer_destroy": (None, [C.c_void_p]),

@@ -727,7 +727,7 @@ class LoRaDemod:
         import torch
         dev = torch.device("cuda", int(self._device))
         if stride is None:
-            stride = max(8, min(self._mtu, 512))
+            stride = max(8, min(self._mtu, int(self._lib.lorahip_decode_max_symbols())))      # no packet is longer than the MTU (LoRaDemod.cpp:291)
         return (torch.empty((int(cap_packets), int(stride)), dtype=torch.int16, device=dev), torch.empty(int(cap_packets), dtype=torch.int32, device=dev),
                 torch.empty(int(cap_packets), dtype=torch.int32, device=dev))
 
@@ -858,7 +858,7 @@ class LoRaDemod:
         n = int(self._lib.lorahip_demod_num_packets(self._h))
         dev = torch.device("cuda", int(self._device))
         if stride is None:
-            stride = max(8, min(self._mtu, 512))                # no packet is longer than the MTU (LoRaDemod.cpp:291)
+            stride = max(8, min(self._mtu, int(self._lib.lorahip_decode_max_symbols())))      # no packet is longer than the MTU (LoRaDemod.cpp:291)
         syms = torch.empty((n, int(stride)), dtype=torch.int16, device=dev)      # every element is written (rows are zero padded)
         nsyms = torch.empty(n, dtype=torch.int32, device=dev)
         chan = torch.empty(n, dtype=torch.int32, device=dev)

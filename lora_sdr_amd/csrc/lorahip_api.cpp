@@ -45,6 +45,20 @@ int residentWorkgroups(const void *kernel, const int threads, const size_t smem)
     return perCu > 0 && cus > 0 ? perCu * cus : 0;
 }
 
+int residentWorkgroupsCached(PerDeviceCount &cache, const void *kernel, const int threads, const size_t smem)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int *slot = &cache.v[dev & 63];
+    int r = __atomic_load_n(slot, __ATOMIC_RELAXED);
+    if (r < 0)
+    {
+        r = residentWorkgroups(kernel, threads, smem);          // (two threads of one device may both ask: they store the same answer)
+        __atomic_store_n(slot, r, __ATOMIC_RELAXED);
+    }
+    return r;
+}
+
 static bool isGfx950(const int device)
 {
     hipDeviceProp_t prop;
@@ -93,7 +107,7 @@ const char *lorahip_strerror(const int code)
 
 const char *lorahip_last_error(void) { return g_lastError.c_str(); }
 
-int lorahip_version(void) { return 3; }
+int lorahip_version(void) { return 4; }
 
 int lorahip_selfcheck(void)
 {
@@ -462,6 +476,13 @@ int lorahip_decode_packets(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg, con
         return LORAHIP_E_INVALID;
     }
     if (sym_stride == 0 || sym_stride > size_t(decodeMaxSymbols()) || (out_stride & 1) || out_stride < 2 * (sym_stride + 8)) return LORAHIP_E_INVALID;
+    // without a header the length of every packet is the setter's: what the decoder's tables reach bounds it (the reference has no bound;
+    // a LoRa length field is one byte). Refused loudly -- never a packet silently not decoded.
+    if (!cfg->explicit_hdr && cfg->interleaving && cfg->data_length > decodeMaxDataLength())
+    {
+        setLastError("data_length beyond what this build decodes (lorahip_decode_max_data_length())");
+        return LORAHIP_E_INVALID;
+    }
     const DeviceGuard guard(ctx->device);
     DecodeArgs a;
     a.syms = syms_dev; a.nsyms = nsyms_dev; a.out = out_dev; a.outLen = out_len_dev; a.dropped = dropped_dev;
@@ -510,6 +531,7 @@ int lorahip_decode_packets_host(lorahip_ctx *ctx, const lorahip_decoder_cfg *cfg
 }
 
 int lorahip_decode_max_symbols(void) { return decodeMaxSymbols(); }
+int lorahip_decode_max_data_length(void) { return decodeMaxDataLength(); }
 
 /***********************************************************************
  * LoRaDetector<float> shim

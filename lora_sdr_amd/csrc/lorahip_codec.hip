@@ -19,7 +19,8 @@
 
 namespace lorahip {
 
-#define LORAHIP_DEC_MAX_SYMBOLS 520            // symbols per packet incl. rounding to a block
+#define LORAHIP_DEC_MAX_SYMBOLS 520            // symbols per packet incl. rounding to a block: the one-lane checker kernel (variant 1) only
+#define LORAHIP_DEC_MAX_DATA_LENGTH 4096       // setDataLength without a header: bytes per packet the tables below reach (a LoRa length field is one byte)
 #define LORAHIP_DEC_MAX_CODEWORDS ((LORAHIP_DEC_MAX_SYMBOLS / 4) * 12 + 4)
 #define LORAHIP_HDR_RDD 4                      // LoRaCodes.hpp:103
 #define LORAHIP_N_HDR_SYMBOLS 8                // :104
@@ -312,7 +313,8 @@ __global__ void __launch_bounds__(64) decodePackets(const DecodeArgs a)
  **********************************************************************/
 namespace {
 
-#define LORAHIP_WHITEN_LEN 800                 // positions per register: (1564 codewords + 5) / 2 rounded up
+#define LORAHIP_WHITEN_LEN 4104                // positions per register: the codewords that can reach the output (LORAHIP_DEC_MAX_DATA_LENGTH
+                                               // bytes + crc = 8196 nibbles + the five header codewords) / 2, and the byte steps of the crc
 
 //! the byte sequences of the two whitening registers for both seed sets, and the CRC helper tables -- none depends on the packet
 struct CodecTables
@@ -380,20 +382,27 @@ template <int G> __device__ __forceinline__ bool groupAny(const bool p)
 
 } // namespace
 
+/*! What of a packet can reach the output. The reference de-interleaves and de-whitens EVERY codeword of the message (LoRaDecoder.cpp:
+ * 225-255), but decodes only those the announced length needs (:315-361): the first PPM of them, the nibble that completes an odd
+ * byte, then two per byte up to dataLength -- at most 2 * (255 + 5) with an explicit header (the length is one byte), 2 * (setDataLength
+ * + 2) without. Codewords behind that, and the symbols they are made of, change nothing (numSymbols / numCodewords enter the checks
+ * as numbers only). So the group's slice of LDS is sized by what the CONFIGURATION can need, not by the length of the row: a packet of
+ * any length the demodulator can produce decodes like the reference decodes it. */
+struct DecodeCaps { int symCap, cwCap; };
+
 template <int G>
-__global__ void __launch_bounds__(256) decodeGroup(const DecodeArgs a, const int symCap)
+__global__ void __launch_bounds__(256) decodeGroup(const DecodeArgs a, const DecodeCaps caps, const int perBlock)
 {
     // per packet: symCap Gray-coded symbols (u16), then the codewords (u8), then the nibbles (u8), 16-byte aligned slices
     extern __shared__ __attribute__((aligned(16))) unsigned char smemDec[];
-    constexpr int PER_BLOCK = 256 / G;
-    const int cwCap = (symCap / 4) * 12 + 16;
+    const int symCap = caps.symCap, cwCap = caps.cwCap;
     const int slice = ((symCap * 2 + 2 * cwCap + 15) & ~15);
     const int g = threadIdx.x / G, t = threadIdx.x % G;
     unsigned short *sSym = reinterpret_cast<unsigned short *>(smemDec + (size_t)g * slice);
     unsigned char *sCw = smemDec + (size_t)g * slice + symCap * 2;
     unsigned char *sNib = sCw + cwCap;
-    const unsigned p = blockIdx.x * PER_BLOCK + g;
-    const bool have = p < a.nPackets;
+    const unsigned p = blockIdx.x * perBlock + g;
+    const bool have = g < perBlock && p < a.nPackets;               // (long slices: fewer packets per workgroup than groups, the rest idle)
     const unsigned pc = have ? p : 0;
     const int nsyms = have ? a.nsyms[pc] : 0;
     const unsigned short *in = a.syms + (size_t)pc * a.symStride;
@@ -405,20 +414,24 @@ __global__ void __launch_bounds__(256) decodeGroup(const DecodeArgs a, const int
     const int bs = 4 + a.rdd;                                                                // symbols per interleaver block
     const int numSymbols = ((nsyms + bs - 1) / bs) * bs;                                     // :210
     const int numCodewords = (numSymbols / bs) * PPM;                                        // :211
-    // group-uniform early outs (:202 throws, :208 too short; larger than this launch's rows / this build supports)
+    // the row holds the first symStride symbols of a longer packet: whether that is enough is known once the length is (below)
+    const int rowSyms = nsyms < a.symStride ? nsyms : a.symStride;
+    const int symLoad = numSymbols < symCap ? numSymbols : symCap;                           // what of it this slice holds
+    const int cwLoad = numCodewords + 4 < cwCap ? numCodewords + 4 : cwCap;
+    // group-uniform early outs (:202 throws, :208 too short)
     bool go = have && !(PPM > sf || nsyms < LORAHIP_N_HDR_SYMBOLS);
-    if (go && (numSymbols > symCap || nsyms > a.symStride || numCodewords + 4 > cwCap)) { outLen = -2; go = false; }
 
     // ---- Gray code with rounding to the symbol size (:218-222) --------------------------------------------------------
+    if (go && !a.interleaving && nsyms > a.symStride) { outLen = -2; go = false; }           // every symbol is output: the row must hold them all
     if (go)
-        for (int i = t; i < numSymbols; i += G)
+        for (int i = t; i < (a.interleaving ? symLoad : numSymbols); i += G)
         {
-            unsigned short sym = i < nsyms ? in[i] : 0;
+            unsigned short sym = i < rowSyms ? in[i] : 0;
             sym = (unsigned short)(sym + (1 << (sf - PPM)) / 2);
             sym = (unsigned short)(sym >> (sf - PPM));
             sym = (unsigned short)(sym ^ (sym >> 1));
-            sSym[i] = sym;
-            if (!a.interleaving) reinterpret_cast<unsigned short *>(out)[i] = sym;          // :264-270
+            if (a.interleaving) sSym[i] = sym;
+            else reinterpret_cast<unsigned short *>(out)[i] = sym;                          // :264-270
         }
     if (go && !a.interleaving) { outLen = numSymbols; go = false; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -428,7 +441,7 @@ __global__ void __launch_bounds__(256) decodeGroup(const DecodeArgs a, const int
     // the first block is always 4/8 over 8 symbols unless the whole packet is (then every block is)
     const bool hdrBlock = a.rdd != LORAHIP_HDR_RDD;
     if (go)
-        for (int c = t; c < numCodewords + 4; c += G)
+        for (int c = t; c < cwLoad; c += G)
         {
             unsigned cw = 0;
             if (c < numCodewords)
@@ -439,7 +452,8 @@ __global__ void __launch_bounds__(256) decodeGroup(const DecodeArgs a, const int
                 else { x = c / PPM; i = c - x * PPM; symOff = x * bs; R = a.rdd; }
                 // with a header block the payload's symbols may end inside a block of `bs`: the reference de-interleaves
                 // (numSymbols - 8) / bs whole blocks and leaves the rest of the codewords zero
-                const bool whole = !hdrBlock || c < PPM || (symOff + (4 + R) <= numSymbols);
+                // (... and a block whose symbols lie behind the slice is behind what any length can need: left zero, never read)
+                const bool whole = (!hdrBlock || c < PPM || (symOff + (4 + R) <= numSymbols)) && symOff + (4 + R) <= symLoad;
                 if (whole)
                     for (int k = 0; k < 4 + R; k++)
                     {
@@ -450,7 +464,8 @@ __global__ void __launch_bounds__(256) decodeGroup(const DecodeArgs a, const int
                 // position in the whitening sequence: codeword index, minus the five header codewords that are not whitened
                 // (with a header block and nothing but it -- exactly 8 symbols -- the reference skips the payload's whitening call)
                 const int pos = a.explicitHdr ? c - LORAHIP_N_HDR_CODEWORDS : c;
-                if (pos >= 0 && !(hdrBlock && c >= PPM && numSymbols <= LORAHIP_N_HDR_SYMBOLS))
+                // (the tables end behind the last codeword any length can need: LORAHIP_DEC_MAX_DATA_LENGTH)
+                if (pos >= 0 && (pos >> 1) < LORAHIP_WHITEN_LEN && !(hdrBlock && c >= PPM && numSymbols <= LORAHIP_N_HDR_SYMBOLS))
                 {
                     const int Rw = (hdrBlock && c < PPM) ? LORAHIP_HDR_RDD : a.rdd;
                     const unsigned keep = 0xffu >> (4 - Rw);
@@ -500,11 +515,20 @@ __global__ void __launch_bounds__(256) decodeGroup(const DecodeArgs a, const int
     // coding rate the HEADER names; decoded are the first block, the nibble that completes its last byte, and what
     // dataLength bytes need -- errors anywhere else do not count, exactly as in the reference's loops
     const int c0 = a.explicitHdr ? LORAHIP_N_HDR_CODEWORDS : 0, shift = a.explicitHdr ? 1 : 0;
+    long long cEnd = 0;
     if (go)
     {
-        long long cEnd = 2 * dataLength - shift;                                             // first codeword NOT needed by the bytes
+        cEnd = 2 * dataLength - shift;                                                       // first codeword NOT needed by the bytes
         const int fill = PPM + (((PPM + shift) & 1) ? 1 : 0);                               // first block + the odd nibble
         if (cEnd < fill) cEnd = fill;
+        // the symbols those codewords are made of: whole interleaver blocks. A packet longer than its row decodes all the same while
+        // they lie inside the row; if not, the caller's rows are too short for this packet (-2: reported, never guessed)
+        const long long nBlocks = (cEnd + PPM - 1) / PPM;
+        const long long needSyms = hdrBlock ? LORAHIP_N_HDR_SYMBOLS + (nBlocks - 1) * bs : nBlocks * bs;
+        if ((nsyms > a.symStride && needSyms > a.symStride) || needSyms > symCap || cEnd + 4 > cwCap) { outLen = -2; go = false; }
+    }
+    if (go)
+    {
         if (a.explicitHdr) { sNib[0] = h0 & 0xf; sNib[1] = h0 >> 4; sNib[2] = h1 & 0xf; sNib[3] = 0; sNib[4] = h2 & 0xf; sNib[5] = h2 >> 4; }
         for (int c = c0 + t; c < cEnd; c += G)
         {
@@ -570,22 +594,38 @@ __global__ void __launch_bounds__(256) decodeGroup(const DecodeArgs a, const int
     }
 }
 
-template <int G>
-static hipError_t launchDecodeGroup(const DecodeArgs &a, hipStream_t stream)
+//! the slice a configuration needs (see DecodeCaps): the symbols / codewords that can reach the output, or the whole row if that is less
+static DecodeCaps decodeCaps(const DecodeArgs &a)
 {
-    // rows of the launch bound the packet length: size the LDS slices for them
-    const int bsMin = 4;
-    const int symCap = ((a.symStride + 7 + bsMin) & ~3) + 8;
-    const int cwCap = (symCap / 4) * 12 + 16;
-    const size_t slice = size_t((symCap * 2 + 2 * cwCap + 15) & ~15);
-    const size_t smem = slice * (256 / G);
+    const int PPM = a.ppm == 0 ? a.sf : a.ppm, bs = 4 + a.rdd;
+    const long long bytesMax = a.explicitHdr ? 255 + 5 : (long long)a.dataLength + 2;
+    long long cEnd = 2 * bytesMax;
+    if (cEnd < PPM + 1) cEnd = PPM + 1;
+    const long long nBlocks = (cEnd + PPM - 1) / PPM + 1;
+    const long long symNeed = LORAHIP_N_HDR_SYMBOLS + nBlocks * bs;
+    const long long symRow = ((a.symStride + 7 + 8) / bs + 1) * bs + LORAHIP_N_HDR_SYMBOLS;       // the row, rounded up to whole blocks
+    DecodeCaps c;
+    c.symCap = int(symNeed < symRow ? symNeed : symRow);
+    // codewords of those symbols (+ the 4 zero entries behind numCodewords the nibble loop may read, + nibble offsets)
+    c.cwCap = int((c.symCap / bs + 2) * PPM + 16);
+    return c;
+}
+
+template <int G>
+static hipError_t launchDecodeGroup(const DecodeArgs &a, const DecodeCaps &caps, hipStream_t stream)
+{
+    const size_t slice = size_t((caps.symCap * 2 + 2 * caps.cwCap + 15) & ~15);
+    const size_t ldsMax = 160 * 1024;
+    unsigned perBlock = 256 / G;
+    if (slice > ldsMax) return hipErrorInvalidValue;                // (lorahip_decode_packets bounds data_length: cannot happen)
+    if (slice * perBlock > ldsMax) perBlock = unsigned(ldsMax / slice);
+    const size_t smem = slice * perBlock;
     static unsigned long long attrDone = 0;
     {
-        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(decodeGroup<G>), 160 * 1024, attrDone);
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(decodeGroup<G>), ldsMax, attrDone);
         if (e != hipSuccess) return e;
     }
-    const unsigned perBlock = 256 / G;
-    hipLaunchKernelGGL((decodeGroup<G>), dim3((a.nPackets + perBlock - 1) / perBlock), dim3(256), smem, stream, a, symCap);
+    hipLaunchKernelGGL((decodeGroup<G>), dim3((a.nPackets + perBlock - 1) / perBlock), dim3(256), smem, stream, a, caps, int(perBlock));
     return hipGetLastError();
 }
 
@@ -597,13 +637,17 @@ hipError_t launchDecode(const DecodeArgs &a, const int variant, hipStream_t stre
         hipLaunchKernelGGL(decodePackets, dim3((a.nPackets + 63) / 64), dim3(64), 0, stream, a);
         return hipGetLastError();
     }
-    // lanes per packet by the row length: a packet of n symbols has about n * PPM / (4 + rdd) codewords
-    if (a.symStride <= 24) return launchDecodeGroup<8>(a, stream);
-    if (a.symStride <= 64) return launchDecodeGroup<16>(a, stream);
-    if (a.symStride <= 160) return launchDecodeGroup<32>(a, stream);
-    return launchDecodeGroup<64>(a, stream);
+    // lanes per packet by what a packet can need: n symbols make about n * PPM / (4 + rdd) codewords
+    const DecodeCaps caps = decodeCaps(a);
+    if (caps.symCap <= 48) return launchDecodeGroup<8>(a, caps, stream);
+    if (caps.symCap <= 96) return launchDecodeGroup<16>(a, caps, stream);
+    if (caps.symCap <= 200) return launchDecodeGroup<32>(a, caps, stream);
+    return launchDecodeGroup<64>(a, caps, stream);
 }
 
-int decodeMaxSymbols() { return LORAHIP_DEC_MAX_SYMBOLS - 8; }
+// rows: the de-whitening takes its length as a uint16_t in the reference (LoRaCodes.hpp: Sx1272ComputeWhiteningLfsr), i.e. messages of
+// up to 65535 codewords are what the reference itself decodes as written; 16384 symbols stay below that at every setting
+int decodeMaxSymbols() { return 16384; }
+int decodeMaxDataLength() { return LORAHIP_DEC_MAX_DATA_LENGTH; }
 
 } // namespace lorahip

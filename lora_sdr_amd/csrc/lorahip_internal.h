@@ -184,6 +184,7 @@ struct DecodeArgs
 };
 hipError_t launchDecode(const DecodeArgs &a, int variant, hipStream_t stream);   // variant 1: the lane-per-packet checker
 int decodeMaxSymbols();
+int decodeMaxDataLength();
 
 //! launchers (lorahip_kernels.hip / lorahip_fast.hip)
 hipError_t launchDetect(int sf, int variant, const DetectArgs &a, const FastTables &ft, hipStream_t stream);
@@ -228,6 +229,14 @@ inline unsigned lastRoundFrom(const unsigned grid, const int resident)
 }
 //! how many workgroups of `kernel` the current device holds at once (occupancy x compute units); 0 if the runtime will not say
 int residentWorkgroups(const void *kernel, int threads, size_t smem);
+//! the same, asked once per (kernel, device) and kept: one value per device, because the per-device host threads of a mixed object
+//! launch the same kernel on different devices at the same time (a single static would be one device's answer for all of them)
+struct PerDeviceCount
+{
+    int v[64];
+    PerDeviceCount(void) { for (int i = 0; i < 64; i++) v[i] = -1; }
+};
+int residentWorkgroupsCached(PerDeviceCount &cache, const void *kernel, int threads, size_t smem);
 
 //! makes a context's device current for the duration of an entry point and restores the caller's afterwards (a process
 //! may hold contexts on several devices; torch keeps its own notion of the current device)

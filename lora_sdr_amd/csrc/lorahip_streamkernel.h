@@ -372,7 +372,7 @@ static hipError_t launchStreamCfg(const StreamArgs &args, hipStream_t stream)
     constexpr int WAVES = 4;
     const size_t smem = size_t(C::TWN + C::N) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2) + FineDims<C::LOG2N>::BYTES;
     static unsigned long long attrDone = 0, attrDoneP = 0;
-    static int resident = -1;
+    static PerDeviceCount resident;
     StreamArgs s = args;
     const unsigned perBlock = WAVES * C::WPW;
     const unsigned grid = (s.nChannels + perBlock - 1) / perBlock;
@@ -390,8 +390,7 @@ static hipError_t launchStreamCfg(const StreamArgs &args, hipStream_t stream)
     (void)attrDoneP;
     const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, false>), smem, attrDone);
     if (e != hipSuccess) return e;
-    if (resident < 0) resident = residentWorkgroups(reinterpret_cast<const void *>(demodStream<C, false>), WAVES * 64, smem);
-    s.lastRoundFrom = lastRoundFrom(grid, resident);
+    s.lastRoundFrom = lastRoundFrom(grid, residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStream<C, false>), WAVES * 64, smem));
     hipLaunchKernelGGL((demodStream<C, false>), dim3(grid), dim3(WAVES * 64), smem, stream, s);
     return hipGetLastError();
 }

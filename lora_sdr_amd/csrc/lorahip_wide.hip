@@ -1031,19 +1031,15 @@ static hipError_t launchStreamWideCfg(const StreamArgs &args, hipStream_t stream
 {
     const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2) + 12 * sizeof(int) + FineDims<C::LOG2N>::BYTES;
     static unsigned long long attrDone = 0, attrDoneP = 0;
-    static int resident = -1, residentP = -1;
+    static PerDeviceCount resident, residentP;
     StreamArgs s = args;
     if (s.nChannels == 0) return hipSuccess;
     int cap = s.maxBlocks;
     if (cap == 0 && C::LOG2N == 11)
     {
-        if (residentP < 0)
-        {
-            const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, true>), smem, attrDoneP);
-            if (e != hipSuccess) return e;
-            residentP = residentWorkgroups(reinterpret_cast<const void *>(demodStreamWide<C, true>), C::T, smem);
-        }
-        cap = residentP;
+        const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, true>), smem, attrDoneP);
+        if (e != hipSuccess) return e;
+        cap = residentWorkgroupsCached(residentP, reinterpret_cast<const void *>(demodStreamWide<C, true>), C::T, smem);
     }
     if (cap > 0 && s.nChannels > unsigned(cap))
     {
@@ -1055,8 +1051,7 @@ static hipError_t launchStreamWideCfg(const StreamArgs &args, hipStream_t stream
     }
     const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, false>), smem, attrDone);
     if (e != hipSuccess) return e;
-    if (resident < 0) resident = residentWorkgroups(reinterpret_cast<const void *>(demodStreamWide<C, false>), C::T, smem);
-    s.lastRoundFrom = lastRoundFrom(s.nChannels, resident);
+    s.lastRoundFrom = lastRoundFrom(s.nChannels, residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStreamWide<C, false>), C::T, smem));
     hipLaunchKernelGGL((demodStreamWide<C, false>), dim3(s.nChannels), dim3(C::T), smem, stream, s);
     return hipGetLastError();
 }

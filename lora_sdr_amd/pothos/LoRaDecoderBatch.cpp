@@ -112,8 +112,10 @@ public:
         if (P == 0) return;
         if (_ctx == nullptr) this->activate();
 
+        // rows as long as the longest message (the reference sizes its vectors from the message, LoRaDecoder.cpp:210-213); one beyond the
+        // library's row limit keeps its length, and is an error below unless the symbols its length needs lie inside the row
         const size_t maxSyms = size_t(lorahip_decode_max_symbols());
-        const size_t stride = longest < maxSyms ? ((longest + 7) & ~size_t(7)) : maxSyms;   // (a longer packet keeps its length: reported as -2)
+        const size_t stride = longest < maxSyms ? ((longest + 7) & ~size_t(7)) : maxSyms;
         const size_t outStride = 2 * (stride + 8);
         _syms.assign(P * stride, 0);
         for (size_t p = 0; p < P; p++)
@@ -135,7 +137,9 @@ public:
         for (size_t p = 0; p < P; p++)
         {
             if (_drop[p]) { _dropped++; this->emitSignal("dropped", _dropped); }
-            if (_outLen[p] < 0) continue;                                   // nothing posted (dropped, or longer than this build decodes: -2)
+            if (_outLen[p] == -2)                                           // never a silent loss: the message could not be decoded as the reference would
+                throw Pothos::Exception("LoRaDecoderBatch::work()", "a message of " + std::to_string(_rowLen[p]) + " symbols is longer than this build decodes (lorahip_decode_max_symbols)");
+            if (_outLen[p] < 0) continue;                                   // nothing posted: too short for a header or dropped, as in the reference
             const size_t n = size_t(_outLen[p]);
             Pothos::Packet out;
             if (_interleaving)

@@ -38,7 +38,7 @@ def test_struct_layout_matches_header():
 
 def test_version_and_errors():
     lib = L.load()
-    assert lib.lorahip_version() == 3
+    assert lib.lorahip_version() == 4
     assert lib.lorahip_selfcheck() == 0, lib.lorahip_last_error()     # every kernel's LDS exchange layout is injective
     assert lib.lorahip_strerror(0) == b"ok"
     assert lib.lorahip_strerror(-5) == b"device is not gfx950"
@@ -222,7 +222,7 @@ int main(void)
     memset(&cfg, 0, sizeof cfg); cfg.struct_size = sizeof cfg; cfg.sf = 7; cfg.rdd = 4; cfg.interleaving = 1; cfg.explicit_hdr = 1; cfg.data_length = 8;
     memset(&rows, 0, sizeof rows); rows.struct_size = sizeof rows;
     memset(syms, 0, sizeof syms);
-    if (lorahip_version() != 3) return 10;
+    if (lorahip_version() != 4) return 10;
     rc = lorahip_create(&ctx, 0, 7);
     printf("create %d (%s)\n", rc, lorahip_strerror(rc));
     if (rc != LORAHIP_OK)

@@ -131,27 +131,80 @@ def test_receive_chain_bytes_in_bytes_out(gpu, golden, sf, cr):
 
 
 def test_longest_packets_and_limits(gpu, oracle):
-    """512 symbols per packet is what one launch accepts (twice the block's default MTU); every coding rate at that size
-    against the oracle, and the C ABI refuses a larger stride instead of truncating"""
+    """Packets of any length the demodulator can produce decode like the reference decodes them (its vectors follow the message,
+    LoRaDecoder.cpp:210-213; setMTU is unchecked, LoRaDemod.cpp:134-137): 512 (TestLoopback.cpp's MTU), 600, 1024 and 2047 symbols at
+    every coding rate, implicit lengths from a few bytes to the 4096 the tables reach, explicit headers on random symbols -- against
+    the oracle; the C ABI refuses what it cannot do (rows beyond 16384 symbols, data_length beyond 4096) instead of truncating."""
     import ctypes as C
     import lora_sdr_amd as L
     from lora_sdr_amd import _lib
     rng = np.random.default_rng(3)
     dec = L.LoRaDecoder()
-    for sf, cr in ((12, "4/4"), (10, "4/5"), (8, "4/6"), (7, "4/7"), (9, "4/8")):
-        dec.setSpreadFactor(sf); dec.setCodingRate(cr); dec.enableExplicit(False); dec.enableCrcc(False); dec.setDataLength(100)
-        pk = [rng.integers(0, 1 << sf, n).astype(np.uint16) for n in (512, 511, 509, 505, 8)]
-        for s, out in zip(pk, dec.work(pk)):
-            o, _ = oracle.decode(sf, s, cr=cr, explicit=False, crcc=False, data_length=100)
-            assert (o is None) == (out is None) and (o is None or np.array_equal(o, out))
     lib = L.load()
+    assert lib.lorahip_decode_max_symbols() == 16384 and lib.lorahip_decode_max_data_length() == 4096
+    n_out = 0
+    for sf, cr in ((12, "4/4"), (10, "4/5"), (8, "4/6"), (7, "4/7"), (9, "4/8")):
+        for explicit, crcc, dlen in ((False, False, 100), (False, True, 700), (False, False, 4096), (True, True, 8), (False, False, 3)):
+            dec.setSpreadFactor(sf); dec.setCodingRate(cr); dec.enableExplicit(explicit); dec.enableCrcc(crcc); dec.setDataLength(dlen)
+            pk = [rng.integers(0, 1 << sf, n).astype(np.uint16) for n in (512, 511, 509, 505, 8, 600, 1024, 2047)]
+            if dlen == 4096:
+                pk.append(rng.integers(0, 1 << sf, 16384).astype(np.uint16))      # a full row: 4096 bytes fit it at every rate but sf 7..9 x 4/7, 4/8
+            for s_, out in zip(pk, dec.work(pk)):
+                o, _ = oracle.decode(sf, s_, cr=cr, explicit=explicit, crcc=crcc, data_length=dlen)
+                assert (o is None) == (out is None), (sf, cr, explicit, dlen, s_.size)
+                assert o is None or np.array_equal(o, out), (sf, cr, explicit, dlen, s_.size)
+                n_out += o is not None
+    assert n_out > 60
+    # interleaving off: every Gray-coded symbol of a long packet comes out
+    dec.setSpreadFactor(9); dec.setSymbolSize(7); dec.setCodingRate("4/6"); dec.enableInterleaving(False)
+    pk = [rng.integers(0, 512, n).astype(np.uint16) for n in (600, 1500)]
+    for s_, out in zip(pk, dec.work(pk)):
+        o, _ = oracle.decode(9, s_, ppm=7, cr="4/6", interleaving=False)
+        assert np.array_equal(o, out)
     cfg = _lib.DecoderCfg(C.sizeof(_lib.DecoderCfg), 10, 0, 4, 0, 1, 0, 1, 0, 8)
     ctx = L.Context(7)
-    z = gpu.zeros(4096, dtype=gpu.int32, device="cuda")
+    z = gpu.zeros(65536, dtype=gpu.int32, device="cuda")
     p = C.c_void_p(z.data_ptr())
-    assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 513, p, 1, p, 2 * (513 + 8), p, p) == -1      # stride too long
+    assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 16385, p, 1, p, 2 * (16385 + 8), p, p) == -1   # row too long
     assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 64, p, 1, p, 2 * 64, p, p) == -1               # output stride too short
     assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 64, p, 0, p, 2 * 72, p, p) == 0                # empty batch
+    cfg = _lib.DecoderCfg(C.sizeof(_lib.DecoderCfg), 10, 0, 4, 0, 1, 0, 0, 0, 4097)                           # implicit, data_length beyond the tables
+    assert lib.lorahip_decode_packets(ctx._h, C.byref(cfg), p, 64, p, 1, p, 2 * 72, p, p) == -1
+    assert b"data_length" in lib.lorahip_last_error()
+
+
+def test_long_encoded_packets_equal_the_verbatim_decoder(gpu, ref):
+    """Real packets longer than 512 symbols: 255 payload bytes through the verbatim LoRaEncoder.cpp at SF7 make 552 (4/7) and 608 (4/8)
+    symbols. Clean, with symbol errors, and padded by the demodulator's trailing noise symbols up to an MTU of 1024: the batched
+    decoder's bytes and drop decisions equal the verbatim LoRaDecoder.cpp's (round 5 reported such packets as out_len = -2)."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(21)
+    dec = L.LoRaDecoder()
+    seen_long = 0
+    for sf, cr, nbytes in ((7, "4/8", 255), (7, "4/7", 255), (8, "4/8", 255), (7, "4/5", 255), (9, "4/8", 200)):
+        data = rng.integers(0, 256, nbytes).astype(np.uint8)
+        syms = ref.encode(sf, data, cr=cr)
+        seen_long += syms.size > 512
+        dec.setSpreadFactor(sf); dec.setCodingRate(cr); dec.enableExplicit(True); dec.enableCrcc(True); dec.enableErrorCheck(False)
+        cases = [syms]
+        for _ in range(6):
+            s_ = syms.copy()
+            for k in rng.integers(0, s_.size, int(rng.integers(1, 5))):
+                s_[int(k)] ^= np.uint16(1 << int(rng.integers(0, sf)))
+            cases.append(s_)
+        cases.append(np.concatenate([syms, rng.integers(0, 1 << sf, 1024 - syms.size).astype(np.uint16)]))      # the demod's MTU-long packet
+        for ec in (False, True):
+            dec.enableErrorCheck(ec)
+            before = dec.getDropped()
+            res = dec.work(cases)
+            drops = 0
+            for s_, out in zip(cases, res):
+                o, d_ = ref.decode(sf, s_, cr=cr, crcc=True, error_check=ec)
+                drops += d_
+                assert (o is None) == (out is None) and (o is None or np.array_equal(o, out)), (sf, cr, ec, s_.size)
+            assert dec.getDropped() - before == drops
+            assert np.array_equal(res[0], data) and np.array_equal(res[-1], data)
+    assert seen_long >= 3
 
 
 def test_decoder_edge_shapes_both_kernels_vs_oracle(gpu, oracle):

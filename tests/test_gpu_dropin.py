@@ -336,6 +336,57 @@ def test_decoder_batch_block_equals_the_verbatim_decoder_block(gpu, ref, golden)
 
 
 @pytest.mark.gpu
+def test_demod_block_mtu_1024_into_the_decoder_block(gpu, ref, oracle):
+    """A demodulator with MTU 1024 (setMTU is an unchecked size_t, LoRaDemod.cpp:134-137) feeds the decoder block messages of 1024
+    symbols -- the packet (608 symbols: 255 bytes at SF7, 4/8) and what followed it up to the MTU. /lora/lora_demod_batch -> /lora/
+    lora_decoder_batch post the bytes the verbatim LoRaDemod.cpp -> LoRaDecoder.cpp post; nothing is lost silently (round 5: out_len -2,
+    no message, no drop counted)."""
+    from oracle.oracle import DropInBatch, DropInDecoder, REF_VARIANTS
+    _need(REF_VARIANTS["dropin"])
+    if not DropInDecoder.available():
+        pytest.skip("oracle/_ref/libloradrop.so not built")
+    sf, mtu, B = 7, 1024, 3
+    N = 1 << sf
+    rng = np.random.default_rng(91)
+    datas = [rng.integers(0, 256, 255).astype(np.uint8) for _ in range(B)]
+    streams = []
+    for c in range(B):
+        syms = ref.encode(sf, datas[c], cr="4/8")
+        assert syms.size == 608
+        tail = rng.integers(0, N, mtu - syms.size + 4).astype(np.uint16)              # the sender keeps transmitting: the demod fills its MTU
+        frame = ref.mod_frame(sf, np.concatenate([syms, tail]), padding=4)
+        st = np.concatenate([np.zeros(N // 2 + 9 * c, np.complex64), frame, np.zeros(3 * N, np.complex64)])
+        streams.append(st + (0.02 * (rng.standard_normal(st.size) + 1j * rng.standard_normal(st.size))).astype(np.complex64))
+    n = max(s_.size for s_ in streams)
+    iq = np.zeros((B, n), np.complex64)
+    for c, s_ in enumerate(streams):
+        iq[c, :s_.size] = s_
+    blk = DropInBatch(sf, B, max_windows=64)
+    blk.set("setMTU", mtu)
+    chans, _, _ = blk.run(iq)
+    dec = DropInDecoder(B)
+    assert dec.configure(sf, cr="4/8", crcc=True) == 0 and dec.activate() == 0
+    want = []
+    for c in range(B):
+        r = ref.demod_run(sf, iq[c], mtu=mtu)
+        assert len(chans[c]["packets"]) == len(r["packets"]) >= 1 and all(np.array_equal(a, b) for a, (_, b) in zip(chans[c]["packets"], r["packets"]))
+        assert chans[c]["packets"][0].size == mtu
+        outs = []
+        for pkt in chans[c]["packets"]:
+            dec.push(c, pkt.astype(np.uint16))
+            o, _ = ref.decode(sf, pkt.astype(np.uint16), cr="4/8", crcc=True)
+            if o is not None:
+                outs.append(o)
+        want.append(outs)
+    assert dec.work() == 0
+    for c in range(B):
+        got = dec.outputs(c)
+        assert len(got) == len(want[c]) >= 1 and all(np.array_equal(a, b) for a, b in zip(got, want[c]))
+        assert np.array_equal(got[0], datas[c])
+    blk.close(); dec.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sf", [7, 10, 12])
 def test_batch_block_through_its_own_pinned_input_slabs(gpu, golden, oracle, sf):
     """The block's getInputBufferManager() (the counterpart of LoRaDemod.cpp:346-357): the driver -- playing the framework -- takes

@@ -1,0 +1,103 @@
+#!/bin/bash
+# round-6 GPU sessions: gpurun --timeout N -- 'TAG=s1 bash tools/gpu_r06.sh tests tworank level3 ...'
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R; TAG=${TAG:-r06}
+export TMPDIR=/tmp
+what="$*"
+l3ch() { case $1 in 6|7) echo 16384;; 8|9) echo 8192;; 10) echo 4096;; 11) echo 2048;; *) echo 1024;; esac; }
+if [[ $what == *tests* ]]; then
+  timeout ${TEST_TIMEOUT:-900} python -m pytest ${TESTS:-tests} -m gpu -x -q ${PYTEST_ARGS:-} > $O/${TAG}_pytest.txt 2>&1; tail -${TEST_TAIL:-6} $O/${TAG}_pytest.txt
+fi
+if [[ $what == *tworank* ]]; then
+  # the --gpus 2 code path on one device over gloo: the line must carry cpu_baseline + oracle like the N = 1 line
+  LORA_BENCH_BACKEND=gloo LORA_BENCH_ONE_DEVICE=1 timeout 900 python bench.py --gpus 2 ${TWORANK_ARGS:-} > $O/${TAG}_bench_two_ranks_one_device_gloo.json 2> $O/${TAG}_bench_two_ranks.err
+  tail -c 400 $O/${TAG}_bench_two_ranks.err
+  python tools/bench_digest.py $O/${TAG}_bench_two_ranks_one_device_gloo.json
+fi
+if [[ $what == *level3* ]]; then
+  for sf in ${L3SFS:-7 8 9 10 11 12}; do
+    timeout 200 python tools/bench_demod.py --sf $sf --channels ${L3CH:-$(l3ch $sf)} --modes 1 > $O/${TAG}_level3_sf$sf.txt 2>&1
+    tail -1 $O/${TAG}_level3_sf$sf.txt | cut -c1-260
+  done
+fi
+if [[ $what == *scaling* ]]; then
+  timeout 600 python tools/level3_scaling.py ${SCALING_ARGS:-} > $O/${TAG}_level3_scaling.txt 2>&1; cat $O/${TAG}_level3_scaling.txt
+fi
+if [[ $what == *moving* ]]; then
+  for sf in ${MVSFS:-7 8 9 10 11 12}; do
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline --moving > $O/${TAG}_moving_sf$sf.json 2> $O/${TAG}_moving_sf$sf.err
+    python - $O/${TAG}_moving_sf$sf.json $sf <<'EOP'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("SF%s moving %8.1f Msym/s frac %.3f launch %.1f us oracle %s" % (sys.argv[2], d["value"], d["roofline"]["frac"], d["roofline"]["launch_us"], d.get("oracle", {}).get("index_mismatches")))
+except Exception as e:
+    print("SF", sys.argv[2], "FAILED", e)
+EOP
+  done
+fi
+if [[ $what == *steady* ]]; then
+  for sf in ${STSFS:-7 10 12}; do
+    timeout 200 python bench.py --sf $sf --no-cpu-baseline ${STEADY_ARGS:-} > $O/${TAG}_steady_sf$sf.json 2> $O/${TAG}_steady_sf$sf.err
+    python - $O/${TAG}_steady_sf$sf.json $sf <<'EOP'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("SF%s steady %8.1f Msym/s frac %.3f launch %.1f us" % (sys.argv[2], d["value"], d["roofline"]["frac"], d["roofline"]["launch_us"]))
+except Exception as e:
+    print("SF", sys.argv[2], "FAILED", e)
+EOP
+  done
+fi
+if [[ $what == *bench* ]]; then
+  timeout 700 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -c 600 $O/${TAG}_bench_default.err
+  python tools/bench_digest.py $O/${TAG}_bench_default.json
+fi
+if [[ $what == *smoke* ]]; then
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.txt 2>&1; tail -3 $O/${TAG}_smoke.txt
+fi
+if [[ $what == *pmcl3* ]]; then
+  # SQ counters of the streaming kernel at SF7 by channel count / lanes per channel: separate --pmc passes, no traces
+  : > $O/${TAG}_sq_counters_level3_sf7.txt
+  for cfg in ${PMCL3:-"4096 -1" "4096 0" "16384 -1" "2048 -1" "2048 0"}; do
+    set -- $cfg; cnt=$1; lanes=$2
+    d=$O/${TAG}_pmc_l3_sf7_${cnt}_lanes${lanes}
+    ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU -d ${d}_issue -o pmc --output-format csv -- \
+        python $R/tools/level3_scaling.py --sf 7 --counts $cnt --lanes $lanes --passes 2 > ${d}.log 2>&1 )
+    ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD -d ${d}_lds -o pmc --output-format csv -- \
+        python $R/tools/level3_scaling.py --sf 7 --counts $cnt --lanes $lanes --passes 2 >> ${d}.log 2>&1 )
+    python tools/pmc_kernels.py "${d}_*" demodStream "SF7 level 3, $cnt channels, lanes $lanes" | tee -a $O/${TAG}_sq_counters_level3_sf7.txt
+    grep "^SF7" ${d}.log | tail -1 | tee -a $O/${TAG}_sq_counters_level3_sf7.txt
+    rm -rf ${d}_issue ${d}_lds
+  done
+fi
+if [[ $what == *final* ]]; then
+  # the evidence profiles/r06 keeps (as tools/gpu_r02.sh final): rocprofv3 kernel stats + the average of the timed steps for the shapes
+  # bench.py reports (steady state, locked receiver, streaming demodulator), HBM traffic counters for roofline.traffic
+  for sf in ${FSF:-7 8 9 10 11 12}; do
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_sf$sf -o sf$sf --output-format csv -- \
+        python $R/bench.py --sf $sf --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_prof_sf$sf.log 2>&1 )
+    python tools/trace_tail.py $O/${TAG}_prof_sf$sf 200 | tee $O/${TAG}_sf${sf}_timed_steps.txt
+    find $O/${TAG}_prof_sf$sf -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} $O/${TAG}_sf${sf}_kernel_stats.csv
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_mov_sf$sf -o sf$sf --output-format csv -- \
+        python $R/bench.py --sf $sf --moving --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_prof_mov_sf$sf.log 2>&1 )
+    python tools/trace_tail.py $O/${TAG}_prof_mov_sf$sf 200 | tee $O/${TAG}_moving_sf${sf}_timed_steps.txt
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_str_sf$sf -o sf$sf --output-format csv -- \
+        python $R/tools/bench_demod.py --sf $sf --channels $(l3ch $sf) --modes 1 > $O/${TAG}_level3_sf$sf.txt 2>&1 )
+    find $O/${TAG}_prof_str_sf$sf -name '*kernel_stats.csv' | head -1 | xargs -r head -4 | cut -c1-200 | tee $O/${TAG}_level3_sf${sf}_kernel_stats.txt
+    tail -1 $O/${TAG}_level3_sf$sf.txt
+    rm -rf $O/${TAG}_prof_sf$sf $O/${TAG}_prof_mov_sf$sf $O/${TAG}_prof_str_sf$sf
+  done
+  rm -rf $O/pmc_FETCH_SIZE_sf* $O/pmc_WRITE_SIZE_sf*
+  for sf in ${FSF:-7 8 9 10 11 12}; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && timeout 300 rocprofv3 --pmc $c -d $O/pmc_${c}_sf$sf -o pmc --output-format csv -- \
+          python $R/bench.py --sf $sf --steps 5 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $O/pmc_${c}_sf$sf.log 2>&1 )
+    done
+  done
+  python tools/pmc_summary.py $O > $O/${TAG}_pmc_summary.txt 2>&1
+  tail -25 $O/${TAG}_pmc_summary.txt
+  rm -rf $O/pmc_FETCH_SIZE_sf* $O/pmc_WRITE_SIZE_sf*
+fi
+if [[ $what == *custom* ]]; then
+  bash -c "$CUSTOM" > $O/${TAG}_custom.txt 2>&1; tail -${CUSTOM_TAIL:-40} $O/${TAG}_custom.txt
+fi
