@@ -106,6 +106,8 @@ def compact_line(full):
         src = rf.pop("traffic_source", None)
         if src is not None:
             rf["traffic_source"] = _pick(src, "file", "session", "matches_this_tree", "error")
+        if rf.get("counters_source") is None:
+            rf.pop("counters_source", None)
         out["roofline"] = rf
     if "cpu_baseline" in full:
         cb = dict(full["cpu_baseline"])
@@ -121,10 +123,10 @@ def compact_line(full):
                                  "same_symbols": bool(pc.get("same_symbols")) and bool(_get(pc, "pinned", "same_symbols", default=True)),
                                  "level1_shim_us_per_detect": _get(pc, "level1_shim", "us_per_detect")}
     if "per_sf" in full:
-        out["per_sf"] = [dict(_pick(e, "sf", "channels", "Msym_s", "frac", "error"), index_mismatches=_get(e, "oracle", "index_mismatches"),
+        out["per_sf"] = [dict(_pick(e, "sf", "channels", "Msym_s", "frac", "valu_busy", "error"), index_mismatches=_get(e, "oracle", "index_mismatches"),
                               cpu_Msym_s=_get(e, "cpu_baseline", "value")) for e in full["per_sf"]]
     if "moving" in full:
-        out["moving"] = [dict(_pick(e, "sf", "Msym_s", "frac", "error"), index_mismatches=_get(e, "oracle", "index_mismatches")) for e in full["moving"]]
+        out["moving"] = [dict(_pick(e, "sf", "Msym_s", "frac", "valu_busy", "error"), index_mismatches=_get(e, "oracle", "index_mismatches")) for e in full["moving"]]
     if "level3" in full:
         rows = []
         for e in full["level3"]:
@@ -141,10 +143,11 @@ def compact_line(full):
                 row["running"] = {"error": str(run["error"])[:120]}
             else:
                 row["running"] = dict(_pick(run, "Msym_s", "frac", "same_packets_as_one_shot"), pipelined_frac=_get(run, "pipelined", "frac"),
-                                      with_signals_frac=_get(run, "with_signals", "frac"))
+                                      with_signals_frac=_get(run, "with_signals", "frac"), with_signals_pipelined_frac=_get(run, "with_signals", "pipelined", "frac"))
                 c8 = run.get("chunk8") or {}
                 row["chunk8"] = dict(_pick(c8, "Msym_s", "frac"), pipelined_Msym_s=_get(c8, "pipelined", "Msym_s"),
                                      pipelined_frac=_get(c8, "pipelined", "frac"), with_signals_frac=_get(c8, "with_signals", "frac"),
+                                     with_signals_pipelined_frac=_get(c8, "with_signals", "pipelined", "frac"),
                                      resident_Msym_s=_get(c8, "resident", "Msym_s"), resident_frac=_get(c8, "resident", "frac"))
                 for part in (row["running"], row["chunk8"]):
                     for k in [k for k, v in part.items() if v is None]:
@@ -454,13 +457,48 @@ def cpu_baseline(sf, iq_host, samples_per_stream, n_streams, seconds, flags="-O2
             "sample": "%d ch x %d samples of the same SF%d IQ, %d work() calls in %.1f s" % (n_streams, samples_per_stream, sf, calls, dt)}
 
 
-def roofline_obj(sf, W, launch_s, traffic, L, traffic_src=True):
+def roofline_obj(sf, W, launch_s, traffic, L, traffic_src=True, shape="steady", default_geometry=True):
     alg = W * L.bytes_per_symbol(sf)
     ach = alg / launch_s / 1e9
-    return {"bound": "hbm", "achieved": r4(ach), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r4(ach / HBM_PEAK_GBS), "traffic": traffic,
-            "traffic_source": traffic_table()[1] if traffic_src else None,
-            "kernel": "lorahip detect (dechirp+FFT+detect fused)", "launch_us": r4(launch_s * 1e6), "algorithmic_bytes_per_launch": alg,
-            "bytes_per_symbol": L.bytes_per_symbol(sf)}
+    r = {"bound": "hbm", "achieved": r4(ach), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r4(ach / HBM_PEAK_GBS), "traffic": traffic,
+         "traffic_source": traffic_table()[1] if traffic_src else None,
+         "kernel": "lorahip detect (dechirp+FFT+detect fused)", "launch_us": r4(launch_s * 1e6), "algorithmic_bytes_per_launch": alg,
+         "bytes_per_symbol": L.bytes_per_symbol(sf)}
+    # north_star: "LDS/VALU utilisation ... against gfx950 peak" -- SQ counters of this kernel at this geometry from separate rocprofv3 --pmc
+    # passes (profiles/counters.json, tools/pmc_counters.py), replayed like `traffic` and only while they were measured on these kernels
+    c = counters_for(sf, shape) if default_geometry else None
+    r["valu_busy"] = c.get("valu_busy") if c else None
+    r["lds_busy"] = c.get("lds_busy") if c else None
+    r["instr_per_sample"] = c.get("instr_per_sample") if c else None
+    if c:
+        r["wait_share"], r["lds_conflict"] = c.get("wait_share"), c.get("lds_conflict")
+    r["counters_source"] = _counters_cache.get("src")
+    return r
+
+
+_counters_cache = {}
+
+
+def counters_for(sf, shape="steady"):
+    """profiles/counters.json entry of (shape, SF), or None when the file is missing or was measured on other kernels"""
+    if "t" not in _counters_cache:
+        t, src = None, {"file": "profiles/counters.json"}
+        try:
+            from lora_sdr_amd.build import kernel_digest
+            t = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+            src["session"] = t.get("session")
+            src["matches_this_tree"] = t.get("sources_sha16") == kernel_digest()
+            if not src["matches_this_tree"]:
+                t = None
+        except Exception as e:
+            src["error"] = str(e)[:80]
+            t = None
+        _counters_cache["t"], _counters_cache["src"] = t, src
+    t = _counters_cache["t"]
+    try:
+        return t[shape][str(sf)] if t else None
+    except Exception:
+        return None
 
 
 _traffic_cache = {}
@@ -593,7 +631,8 @@ def pothos_block(sf, host, nsyms, calls_expected, packets_expected, chunk_window
         return {"error": "oracle/_ref/libloradrop.so did not travel"}
     B, n = host.shape
     chunk = chunk_windows << sf
-    up = int(os.environ.get("LORAHIP_UPLOAD_THREADS", "6" if (os.cpu_count() or 1) >= 16 else "3"))
+    cpus_ = os.cpu_count() or 1                     # (lorahip_upload.cpp::uploadThreads' rule)
+    up = int(os.environ.get("LORAHIP_UPLOAD_THREADS", "8" if cpus_ >= 32 else ("6" if cpus_ >= 16 else "3")))
     out = {"what": "LoRaDemodBatch.cpp over host buffers, %d windows per channel per arrival" % chunk_windows, "host_threads": 1 + up}
     for name, ports, nch in (("ports_off", False, B), ("ports_on", True, min(B, max(64, (1 << 21) >> sf)))):
         blk = DropInBatch(sf, nch, max_windows=chunk_windows + 2)
@@ -723,12 +762,14 @@ def section_level3(env, L, sf, threads=32):
         cap_ = int(iq.shape[1])
         rows_ = d.receiver_rows(cap_packets=B * (frames + 1), stride=max(8, min(nsyms, 512)))
 
+        n_sig_ = [0]                                 # signals delivered by the steps of the last pass (with set_signals + signal rows)
+
         def running_pass(chunk_windows):
             chunk = chunk_windows << sf
             d.clear_packets()
             d.rewind()
             d.activate()
-            w = n_pk_ = n_work = calls_ = 0
+            w = n_pk_ = n_work = calls_ = sg_ = 0
             env.barrier()
             t0 = time.perf_counter()
             while w < cap_:
@@ -737,10 +778,13 @@ def section_level3(env, L, sf, threads=32):
                 n_pk_ += n_
                 calls_ += k_
                 n_work += 1
+                if with_sig_[0]:
+                    sg_ += d.last_signals()
             torch.cuda.synchronize()
             (dt_,) = env.max_over_ranks(time.perf_counter() - t0)
-            (calls_all_, pk_all_) = env.sum_over_ranks(calls_, n_pk_)
+            (calls_all_, pk_all_, n_sig_[0]) = env.sum_over_ranks(calls_, n_pk_, sg_)
             return dt_, calls_all_, pk_all_, n_work
+        with_sig_ = [False]
         running = {}
         for cw in (128, 8):
             running_pass(cw)                        # sizes the buffers of the chunked shape
@@ -760,7 +804,7 @@ def section_level3(env, L, sf, threads=32):
             d.clear_packets()
             d.rewind()
             d.activate()
-            w = n_pk_ = n_work = calls_ = 0
+            w = n_pk_ = n_work = calls_ = sg_ = 0
             env.barrier()
             t0 = time.perf_counter()
             while w < cap_:
@@ -771,9 +815,13 @@ def section_level3(env, L, sf, threads=32):
                 n_pk_ += n_
                 calls_ += k_
                 n_work += 1
+                if with_sig_[0]:
+                    sg_ += d.last_signals()
             n_, k_ = d.receive_flush(rows_)
+            if with_sig_[0]:
+                sg_ += d.last_signals()
             (dt_,) = env.max_over_ranks(time.perf_counter() - t0)
-            (calls_all_, pk_all_) = env.sum_over_ranks(calls_ + k_, n_pk_ + n_)
+            (calls_all_, pk_all_, n_sig_[0]) = env.sum_over_ranks(calls_ + k_, n_pk_ + n_, sg_)
             return dt_, calls_all_, pk_all_, n_work
         for cw in (128, 8):
             piped_pass(cw)
@@ -781,9 +829,32 @@ def section_level3(env, L, sf, threads=32):
             (running if cw == 128 else running["chunk8"])["pipelined"] = {
                 "ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6),
                 "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)), "packets": int(rb[2])}
+        # The same steps delivering what the reference block delivers: packets AND the signals "error" / "power" / "snr" (LoRaDemod.cpp:
+        # 267-269), into rows registered with lorahip_demod_receive_signal_rows (device memory: a consumer on the device, like the rows)
+        d.set_signals(True)
+        d.receiver_signal_rows(B * (frames + 2))
+        with_sig_[0] = True
+        for cw in (128, 8):
+            tgt = running if cw == 128 else running["chunk8"]
+            running_pass(cw)
+            rb = min((running_pass(cw) for _ in range(3)), key=lambda r_: r_[0])
+            ns_ = int(n_sig_[0])
+            piped_pass(cw)
+            rp = min((piped_pass(cw) for _ in range(3)), key=lambda r_: r_[0])
+            tgt["with_signals"] = {"Msym_s": r4(rb[1] / rb[0] / 1e6), "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)),
+                                   "packets": int(rb[2]), "signals": ns_, "signals_pipelined": int(n_sig_[0]),
+                                   "pipelined": {"Msym_s": r4(rp[1] / rp[0] / 1e6), "frac": r4(rp[1] * L.bytes_per_symbol(sf) / rp[0] / 1e9 / (HBM_PEAK_GBS * env.world)),
+                                                 "packets": int(rp[2])}}
+        with_sig_[0] = False
+        d.set_signals(False)
+        d.receiver_signal_rows(0)
         d.rewind()
     except Exception as e:                          # a measurement beside the contract line: report, do not fail the bench
         running = {"error": repr(e)}
+        try:
+            d.receive_flush(None); d.set_signals(False); d.receiver_signal_rows(0); d.rewind()
+        except Exception:
+            pass
     # the same streams handed over as ordinary HOST buffers, one per channel (what a Pothos port gives the block): gathered through
     # the pinned double-buffered upload, then the streaming kernel -- PCIe-bound, reported beside the device-resident figures
     host = iq.cpu().numpy()                         # (B, samples): one buffer per channel for the C ABI (lorahip_demod_run)
@@ -1174,7 +1245,8 @@ def main():
                        "kernel_variant": a.variant, "alias_windows": bool(a.alias_windows), "moving_fine_index": bool(a.moving),
                        "fine_gather": bool(a.fine_gather), "ramp_seconds": a.ramp_seconds},
             "symbol_error_rate_vs_sent": ser, "bin_offset": off,
-            "roofline": roofline_obj(sf0, sh.W, launch_s, None if (a.moving or a.alias_windows) else traffic_for(sf0, a), L),
+            "roofline": roofline_obj(sf0, sh.W, launch_s, None if (a.moving or a.alias_windows) else traffic_for(sf0, a), L,
+                                     shape="moving" if a.moving else "steady", default_geometry=a.channels is None and a.symbols is None and not a.alias_windows),
         }
         if env.rccl_ranks is not None:
             line["rccl_ranks"] = env.rccl_ranks
@@ -1269,11 +1341,13 @@ def main():
             ser2, off2 = cur.ser_vs_sent()
             ent = {"sf": sf, "channels": cur.B, "symbols": cur.S, "Msym_s": r4(cur.W * a.steps * env.world / e2 / 1e6),
                    "launch_us": r4(k2 * 1e3 / a.steps), "frac": r4(cur.W * L.bytes_per_symbol(sf) / (k2 / 1e3 / a.steps) / 1e9 / HBM_PEAK_GBS),
-                   "traffic": traffic_for(sf, a), "ser_vs_sent": ser2}
+                   "traffic": traffic_for(sf, a), "ser_vs_sent": ser2, "valu_busy": (counters_for(sf) or {}).get("valu_busy"),
+                   "lds_busy": (counters_for(sf) or {}).get("lds_busy"), "instr_per_sample": (counters_for(sf) or {}).get("instr_per_sample")}
             # the locked-receiver shape on the same IQ
             e3, k3 = cur.measure(a.steps, a.warmup, 0.1, moving=True)
             mv = {"sf": sf, "Msym_s": r4(cur.W * a.steps * env.world / e3 / 1e6), "launch_us": r4(k3 * 1e3 / a.steps),
-                  "frac": r4(cur.W * L.bytes_per_symbol(sf) / (k3 / 1e3 / a.steps) / 1e9 / HBM_PEAK_GBS)}
+                  "frac": r4(cur.W * L.bytes_per_symbol(sf) / (k3 / 1e3 / a.steps) / 1e9 / HBM_PEAK_GBS),
+                  "valu_busy": (counters_for(sf, "moving") or {}).get("valu_busy"), "instr_per_sample": (counters_for(sf, "moving") or {}).get("instr_per_sample")}
             if rank0:                                           # (rank 0's CPU legs: the barrier below must be reached, see above)
                 try:
                     if sf != sf0:

@@ -66,7 +66,8 @@ int lorahip_version(void);                  /* ABI version, currently 4 (1 -> 2:
                                                2 -> 3, additions only: level-3 signals, append runs / lorahip_demod_receive, lorahip_rx_*;
                                                3 -> 4, additions only: lorahip_demod_receive_flush, _run_host_rows, _stream_wait / _stream_follow,
                                                _set_stream_lanes / _stream_lanes, _set_stream_grid, _set_variant, _set_record_capacity,
-                                               lorahip_decode_packets_host, lorahip_decode_max_symbols, lorahip_decode_max_data_length; signals in pipelined receive steps) */
+                                               lorahip_decode_packets_host, lorahip_decode_max_symbols, lorahip_decode_max_data_length, lorahip_demod_receive_signal_rows /
+                                               _receive_num_signals: signals in receiver steps, pipelined ones included) */
 int lorahip_device_count(void);             /* number of usable gfx950 devices, 0 if none */
 int lorahip_selfcheck(void);                /* host-only: the kernels' compile-time LDS layouts are consistent; no device needed */
 
@@ -370,7 +371,7 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * left queued if that exceeds cap_packets), *work_calls = LoRaDemod::work() calls made by this step, summed over the channels.
  * With async = 1 the call returns without waiting for the packing kernels: the rows are valid in stream order on the object's
  * launch stream (lorahip_demod_set_stream), which is where a decoder that follows would be queued. Signals kept by
- * lorahip_demod_set_signals are dropped by this call (read them with the ordinary run + accessors instead).
+ * lorahip_demod_set_signals go to the rows registered with lorahip_demod_receive_signal_rows (below); without such rows they are dropped.
  * With async = 2 the steps are PIPELINED: this step's kernel is launched before the previous step's summary is read, so the host's
  * share of a step (launch latencies, the wait for the summary, the packing launches: ~60 us) overlaps the kernel instead of
  * following it. The price is one step of latency: *n_packets / *work_calls and the rows are those of the PREVIOUS step (0 for the
@@ -378,7 +379,7 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * the running kernel; the launch stream waits for that before anything later); lorahip_demod_receive_flush() delivers the last
  * step's and leaves the pipeline. The first call after anything else touched
  * the object is an ordinary step (its packets delivered at once). While a step is in flight every other entry point that needs the
- * object's state returns LORAHIP_E_INVALID ("flush first"); no trace / ports / signals in this mode.
+ * object's state returns LORAHIP_E_INVALID ("flush first"); no trace / ports in this mode (signals: lorahip_demod_receive_signal_rows).
  * Rows that cannot hold the packets that are due (cap_packets too small, null pointers) lose NOTHING: the call returns
  * LORAHIP_E_INVALID with *n_packets = the rows needed, the packets stay in the step's record set on the device, and the next
  * lorahip_demod_receive / _flush whose rows hold them delivers them first, together with the packets of the step launched in
@@ -401,6 +402,27 @@ typedef struct lorahip_packet_rows {
 } lorahip_packet_rows;
 int lorahip_demod_receive(lorahip_demod *d, const float *iq_dev, size_t row_stride, size_t n_valid, const lorahip_packet_rows *rows,
                           size_t *n_packets, int64_t *work_calls);
+/* The block's signals in a running receiver (the reference emits "error" / "power" / "snr" once per packet at DOWNCHIRP1, LoRaDemod.cpp:
+ * 267-269). With lorahip_demod_set_signals(d, 1) AND rows registered here, every lorahip_demod_receive / _receive_flush call delivers
+ * the signals of the step whose packets it delivers -- ordinary steps at once, pipelined steps (async = 2) one step late, beside the
+ * packets -- into rows [0, n), n = lorahip_demod_receive_num_signals(d): channel, error, power, snr per emission, channels ascending
+ * and time ascending inside a channel, written in the same stream order as the packet rows. The arrays may be device memory or pinned
+ * host memory (lorahip_host_alloc), which the device writes directly -- what a host consumer (a block's emitSignal) reads after the
+ * stream has passed; any array may be NULL. A step emits at most one signal per packet it completes plus one per channel (a frame whose
+ * packet is still open): cap >= cap_packets + n_channels always suffices. Rows that cannot hold what is due lose nothing: the call
+ * returns LORAHIP_E_INVALID exactly as for packet rows that are too small (pipelined: packets and signals stay in the step's record
+ * set; ordinary: they stay queued for lorahip_demod_get_packets / _get_signals). rows = NULL (or no rows registered): receiver steps
+ * drop the signals, as before version 4. */
+typedef struct lorahip_signal_rows {
+    size_t struct_size;     /* = sizeof(lorahip_signal_rows) */
+    int32_t *channel;       /* [cap] */
+    int32_t *error;         /* [cap]  "error": the frequency error in bins (int)      :267 */
+    float *power;           /* [cap]  "power"                                         :268 */
+    float *snr;             /* [cap]  "snr"                                           :269 */
+    size_t cap;
+} lorahip_signal_rows;
+int lorahip_demod_receive_signal_rows(lorahip_demod *d, const lorahip_signal_rows *rows /* nullable */);
+size_t lorahip_demod_receive_num_signals(const lorahip_demod *d);
 int lorahip_demod_receive_flush(lorahip_demod *d, const lorahip_packet_rows *rows /* nullable: the last step's packets are dropped */,
                                 size_t *n_packets, int64_t *work_calls);
 

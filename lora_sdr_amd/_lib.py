@@ -52,6 +52,11 @@ class PacketRows(C.Structure):
                 ("channel_dev", C.c_void_p), ("cap_packets", C.c_size_t), ("async_", C.c_int32), ("reserved", C.c_int32)]
 
 
+class SignalRows(C.Structure):
+    """struct lorahip_signal_rows"""
+    _fields_ = [("struct_size", C.c_size_t), ("channel", C.c_void_p), ("error", C.c_void_p), ("power", C.c_void_p), ("snr", C.c_void_p), ("cap", C.c_size_t)]
+
+
 class WorkResult(C.Structure):
     """struct lorahip_work_result"""
     _fields_ = [("consumed", C.c_int64), ("state_before", C.c_int32), ("value", C.c_int32),
@@ -129,6 +134,8 @@ SIGNATURES = {
     "lorahip_demod_rewind": (C.c_int, [C.c_void_p]),
     "lorahip_demod_receive": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(PacketRows), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "lorahip_demod_receive_flush": (C.c_int, [C.c_void_p, C.POINTER(PacketRows), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
+    "lorahip_demod_receive_signal_rows": (C.c_int, [C.c_void_p, C.POINTER(SignalRows)]),
+    "lorahip_demod_receive_num_signals": (C.c_size_t, [C.c_void_p]),
     "lorahip_demod_set_signals": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_num_signals": (C.c_size_t, [C.c_void_p]),
     "lorahip_demod_get_signals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

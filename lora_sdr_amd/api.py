@@ -731,6 +731,37 @@ class LoRaDemod:
         return (torch.empty((int(cap_packets), int(stride)), dtype=torch.int16, device=dev), torch.empty(int(cap_packets), dtype=torch.int32, device=dev),
                 torch.empty(int(cap_packets), dtype=torch.int32, device=dev))
 
+    def receiver_signal_rows(self, cap, pinned_host=False):
+        """lorahip_demod_receive_signal_rows: with set_signals(True), every receive() / receive_flush() delivers the block's signals
+        (error / power / snr once per packet at DOWNCHIRP1, LoRaDemod.cpp:267-269) of the step whose packets it delivers into these
+        rows, last_signals() of them. Returns the tensors (channel int32, error int32, power float32, snr float32): device memory, or --
+        pinned_host -- numpy arrays over pinned host memory the device writes directly (read them after the stream has passed).
+        cap = 0 unregisters (receiver steps drop the signals again)."""
+        import torch
+        r = _lib.SignalRows()
+        r.struct_size = C.sizeof(_lib.SignalRows)
+        cap = int(cap)
+        if cap == 0:
+            self._sig_rows = None
+            check(self._lib.lorahip_demod_receive_signal_rows(self._h, None), "lorahip_demod_receive_signal_rows")
+            return None
+        if pinned_host:
+            rows = (pinned_empty((cap,), np.int32), pinned_empty((cap,), np.int32), pinned_empty((cap,), np.float32), pinned_empty((cap,), np.float32))
+            r.channel, r.error, r.power, r.snr = (a.ctypes.data for a in rows)
+        else:
+            dev = torch.device("cuda", int(self._device))
+            rows = (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                    torch.empty(cap, dtype=torch.float32, device=dev), torch.empty(cap, dtype=torch.float32, device=dev))
+            r.channel, r.error, r.power, r.snr = (a.data_ptr() for a in rows)
+        r.cap = cap
+        check(self._lib.lorahip_demod_receive_signal_rows(self._h, C.byref(r)), "lorahip_demod_receive_signal_rows")
+        self._sig_rows = rows                                # (kept alive while registered)
+        return rows
+
+    def last_signals(self):
+        """signals the last receive() / receive_flush() delivered into the registered signal rows"""
+        return int(self._lib.lorahip_demod_receive_num_signals(self._h))
+
     def _rows_struct(self, rows, async_):
         syms, nsyms, chan = rows
         r = _lib.PacketRows()

@@ -81,6 +81,9 @@ struct lorahip_demod
     std::vector<int16_t> pktSyms;
     bool wantSignals;                // keep a record per DOWNCHIRP1 call (lorahip_demod_set_signals)
     std::vector<Signal> signals;
+    lorahip_signal_rows sigRows;     // lorahip_demod_receive_signal_rows: where receiver steps deliver the signals (all pointers null: they are dropped)
+    bool sigRowsOn;
+    size_t lastSignals;              // ... how many the last receive / receive_flush delivered there
     // per-round staging (host pinned + device), sized for B windows
     char *h, *d;
     size_t stageBytes;
@@ -993,6 +996,7 @@ struct Pipe
     bool pending[2];                // the set's kernel has been launched, its summary not read yet
     bool held[2];                   // the set's summary has been read, its packets are still in the set (rows too small: nothing is lost)
     size_t nPk[2]; int64_t nCalls[2];   // ... what that summary said
+    size_t nSig[2]; bool sigs[2];       // ... and the signals kept in the set (the step ran with lorahip_demod_set_signals on)
     hipStream_t side;               // step k's packets are packed HERE while step k + 1's kernel runs on the launch stream
     hipEvent_t packDone;            // ... which waits for this before anything later (the next kernel reuses the record set, the caller reads the rows)
     hipEvent_t entry;               // ... and the side stream for this: where the launch stream stood when the call began (the caller's
@@ -1029,6 +1033,7 @@ static int pipeRead(lorahip_demod *dm, const int set)
     dm->lastSum = sum;
     P.nPk[set] = size_t(sum.packets);
     P.nCalls[set] = sum.calls;
+    P.nSig[set] = P.sigs[set] ? size_t(sum.signals) : 0;
     P.held[set] = true;
     return LORAHIP_OK;
 }
@@ -1039,17 +1044,19 @@ static bool rowsHold(const lorahip_packet_rows *rows, const size_t n)
                       rows->cap_packets >= n);
 }
 
-//! the packets held in record set `set` into `rows` from row `firstRow` on (stream-ordered; no wait); the set is free afterwards
-static int pipePack(lorahip_demod *dm, const int set, const lorahip_packet_rows *rows, const size_t firstRow, const bool beside)
+//! do the registered signal rows hold n signals? (nothing registered: the signals are dropped, as the header says)
+static bool sigRowsHold(const lorahip_demod *dm, const size_t n) { return !dm->sigRowsOn || n <= dm->sigRows.cap; }
+
+//! the packets held in record set `set` into `rows` from row `firstRow` on, its signals into the signal rows from `firstSig` on
+//! (stream-ordered; no wait); the set is free afterwards. The scratch (growDense) has been sized by the caller.
+static int pipePack(lorahip_demod *dm, const int set, const lorahip_packet_rows *rows, const size_t firstRow, const size_t firstSig, const bool beside)
 {
     Pipe &P = pipeOf(dm);
     lorahip_ctx *ctx = dm->ctx;
-    const size_t n = P.nPk[set];
-    P.held[set] = false;
-    if (n == 0) return LORAHIP_OK;
+    const size_t n = P.nPk[set], ns = dm->sigRowsOn ? P.nSig[set] : 0;
+    if (n == 0 && ns == 0) { P.held[set] = false; return LORAHIP_OK; }
     const StreamLayout &L = P.lay[set];
     const size_t nbRow = align256(L.B * sizeof(int));
-    { const int grc = growDense(dm, nbRow + n * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
     char *d = P.dev[set];
     // `beside`: packed on the side stream WHILE the step just launched runs (the host has just waited for this step's summary: its
     // kernel is complete). The side stream first waits for where the launch stream stood when this call began -- whatever the caller
@@ -1059,43 +1066,58 @@ static int pipePack(lorahip_demod *dm, const int set, const lorahip_packet_rows 
     // displace workgroups of a streaming grid that exactly fills the device, -5 %).
     hipStream_t packStream = beside ? P.side : ctx->stream;
     if (beside) LORAHIP_TRY(hipStreamWaitEvent(P.side, P.entry, 0));
-    LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(d + L.oPkt), reinterpret_cast<const int *>(d + L.oNPkt),
-                                  reinterpret_cast<const short *>(d + L.oSym), reinterpret_cast<int *>(dm->dDense), L.B, int(L.symStride), int(L.capPkt), n,
-                                  reinterpret_cast<long long *>(dm->dDense + nbRow), rows->syms_dev + firstRow * rows->sym_stride, int(rows->sym_stride),
-                                  rows->nsyms_dev + firstRow, rows->channel_dev ? rows->channel_dev + firstRow : nullptr, packStream));
+    if (n)
+        LORAHIP_TRY(launchPackPackets(reinterpret_cast<const StreamPacket *>(d + L.oPkt), reinterpret_cast<const int *>(d + L.oNPkt),
+                                      reinterpret_cast<const short *>(d + L.oSym), reinterpret_cast<int *>(dm->dDense), L.B, int(L.symStride), int(L.capPkt), n,
+                                      reinterpret_cast<long long *>(dm->dDense + nbRow), rows->syms_dev + firstRow * rows->sym_stride, int(rows->sym_stride),
+                                      rows->nsyms_dev + firstRow, rows->channel_dev ? rows->channel_dev + firstRow : nullptr, packStream));
+    if (ns)
+        LORAHIP_TRY(launchPackSignals(reinterpret_cast<const StreamSignal *>(d + L.oSig), reinterpret_cast<const int *>(d + L.oNSig), L.B, int(L.capPkt),
+                                      dm->sigRows.channel, dm->sigRows.error, dm->sigRows.power, dm->sigRows.snr, firstSig, dm->sigRows.cap, packStream));
     if (beside)
     {
         LORAHIP_TRY(hipEventRecord(P.packDone, P.side));
         LORAHIP_TRY(hipStreamWaitEvent(ctx->stream, P.packDone, 0));
     }
+    P.held[set] = false;                              // only now: a launch that failed above leaves the packets where they are
     return LORAHIP_OK;
 }
 
 /*! Every step whose summary can be read (oldest first) into `rows`, or -- if they do not all fit -- NONE of them: *nPackets = the
  * rows needed, LORAHIP_E_INVALID, the packets stay in their record sets and the next call (with rows that hold them) delivers
- * them. `upTo`: number of record sets to consider, oldest first (1: only the older one). */
+ * them. `sets`: number of record sets to consider, oldest first (1: only the older one). The same holds for the signals and the
+ * rows registered for them (lorahip_demod_receive_signal_rows): all or nothing, lorahip_demod_receive_num_signals() = what is due. */
 static int pipeDeliverHeld(lorahip_demod *dm, const int older, const int sets, const lorahip_packet_rows *rows, size_t *nPackets, int64_t *calls, const bool beside)
 {
     Pipe &P = pipeOf(dm);
-    size_t need = 0;
-    for (int i = 0; i < sets; i++) if (P.held[older ^ i]) need += P.nPk[older ^ i];
+    size_t need = 0, needSig = 0, most = 0;
+    for (int i = 0; i < sets; i++)
+        if (P.held[older ^ i]) { need += P.nPk[older ^ i]; needSig += P.nSig[older ^ i]; if (P.nPk[older ^ i] > most) most = P.nPk[older ^ i]; }
     if (nPackets) *nPackets = need;
+    dm->lastSignals = dm->sigRowsOn ? needSig : 0;
     if (!rowsHold(rows, need))
     {
         setLastError("lorahip_demod_receive (pipelined): the rows cannot hold the packets that are due; they are kept -- call again with rows for *n_packets");
         return LORAHIP_E_INVALID;
     }
-    size_t at = 0;
+    if (!sigRowsHold(dm, needSig))
+    {
+        setLastError("lorahip_demod_receive (pipelined): the signal rows cannot hold the signals that are due; they are kept -- register rows for lorahip_demod_receive_num_signals()");
+        return LORAHIP_E_INVALID;
+    }
+    // the scratch for the largest set, before any state is touched: a failure here delivers nothing and loses nothing
+    if (most) { const int grc = growDense(dm, align256(dm->B * sizeof(int)) + most * sizeof(long long)); if (grc != LORAHIP_OK) return grc; }
+    size_t at = 0, atSig = 0;
     int64_t c = 0;
     for (int i = 0; i < sets; i++)
     {
         const int set = older ^ i;
         if (!P.held[set]) continue;
-        c += P.nCalls[set];
-        const size_t n = P.nPk[set];
-        const int rc = pipePack(dm, set, rows, at, beside);
+        const size_t n = P.nPk[set], ns = dm->sigRowsOn ? P.nSig[set] : 0;
+        const int rc = pipePack(dm, set, rows, at, atSig, beside);
         if (rc != LORAHIP_OK) return rc;
-        at += n;
+        c += P.nCalls[set];
+        at += n; atSig += ns;
     }
     if (calls) *calls = c;
     return LORAHIP_OK;
@@ -1114,6 +1136,7 @@ static int pipeFlush(lorahip_demod *dm, const lorahip_packet_rows *rows, size_t 
         if (P.k > 0 && P.pending[last ^ i]) { const int rc = pipeRead(dm, last ^ i); if (rc != LORAHIP_OK) return rc; }
     size_t n1 = 0;
     int64_t c1 = 0;
+    dm->lastSignals = 0;
     if (rows == nullptr) P.held[0] = P.held[1] = false;                       // dropped on request
     else
     {
@@ -1141,9 +1164,9 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     lorahip_ctx *ctx = dm->ctx;
     const size_t N = dm->N, B = dm->B;
     const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(ctx->sf));
-    // What the pipeline needs in place: the streaming mode, no trace / ports / signals, the state and the open packets on the device
+    // What the pipeline needs in place: the streaming mode, no trace / ports, the state and the open packets on the device
     // with carry rows long enough, a continuing append stream. Anything else takes the ordinary step (which establishes exactly that).
-    const bool compatible = stream && !dm->tracing && !dm->portsOn && !dm->wantSignals && !dm->activatePending && dm->sDev != nullptr &&
+    const bool compatible = stream && !dm->tracing && !dm->portsOn && !dm->activatePending && dm->sDev != nullptr &&
                             dm->append && !dm->appendFresh && dm->uniStride == rowStride && nValid >= dm->appendPrev &&
                             dm->dCarry != nullptr && dm->mtu + 1 <= dm->carryCap;
     const bool ready = compatible && dm->devStateFresh && (dm->devCarryValid || !dm->lastSum.anyOpen) && !pendingOf(dm).valid;
@@ -1170,13 +1193,17 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     // where the launch stream stands now: behind whatever the caller queued to read the rows of the call before (pipePack)
     LORAHIP_TRY(hipEventRecord(P.entry, ctx->stream));
     bool delivered = false;
-    if (P.held[set])
+    dm->lastSignals = 0;
+    if (P.held[set] || P.held[set ^ 1])
     {
-        // The call before could not hand over the packets of the step in THIS record set (rows too small), and the kernel about to be
-        // launched would overwrite them: they are due now, together with the packets of the step launched since -- or nothing is
-        // launched and nothing is lost (the caller comes back with rows for *n_packets; the samples wait in its array).
-        if (P.pending[set ^ 1]) { const int rc = pipeRead(dm, set ^ 1); if (rc != LORAHIP_OK) return rc; }
-        const int rc = pipeDeliverHeld(dm, set, 2, rows, nPackets, calls, false);
+        // A call before could not hand over the packets of a step (rows too small). If they sit in THIS record set the kernel about to
+        // be launched would overwrite them; if in the other one (a flush that failed on small rows left the last step's there) they are
+        // simply older than anything this call produces. Either way they are due now, oldest first, together with the packets of a step
+        // launched since -- or nothing is launched and nothing is lost (the caller comes back with rows for *n_packets; the samples
+        // wait in its array).
+        const int older = P.held[set] ? set : (set ^ 1);
+        if (P.pending[older ^ 1]) { const int rc = pipeRead(dm, older ^ 1); if (rc != LORAHIP_OK) return rc; }
+        const int rc = pipeDeliverHeld(dm, older, 2, rows, nPackets, calls, false);
         if (rc != LORAHIP_OK) return rc;
         delivered = true;
     }
@@ -1184,7 +1211,7 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     size_t cap, capPkt;
     streamCapacity(dm, nValid - dm->appendPrev + 2 * N, cap, capPkt);
     StreamLayout L;
-    L.make(B, cap, capPkt, false, dm->carryCap, false);
+    L.make(B, cap, capPkt, false, dm->carryCap, dm->wantSignals);
     if (L.total > P.bytes[set])
     {
         // (this set's last use, step k - 2, was packed during step k - 1's call, stream-ordered before kernel k - 1: freeing waits for it)
@@ -1206,7 +1233,9 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     a.nCalls = reinterpret_cast<int *>(d + L.oN); a.nSym = reinterpret_cast<int *>(d + L.oNSym); a.nPkt = reinterpret_cast<int *>(d + L.oNPkt);
     a.nSig = reinterpret_cast<int *>(d + L.oNSig); a.end = reinterpret_cast<int2 *>(d + L.oEnd);
     a.pktOut = reinterpret_cast<StreamPacket *>(d + L.oPkt); a.symOut = reinterpret_cast<short *>(d + L.oSym);
-    a.sigOut = nullptr; a.calls = nullptr;
+    // the block's signals (:267-269), kept per step like the packets and delivered with them one step late
+    a.sigOut = dm->wantSignals ? reinterpret_cast<StreamSignal *>(d + L.oSig) : nullptr; a.calls = nullptr;
+    P.sigs[set] = dm->wantSignals;
     a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
     a.fineA = ctx->fineGather ? nullptr : ctx->dFineA; a.fineB = ctx->fineGather ? nullptr : ctx->dFineB;
     a.nChannels = unsigned(B); a.cap = int(cap); a.symStride = int(L.symStride); a.capPkt = int(capPkt);
@@ -1218,7 +1247,7 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     // -- it reads only this record set's counts and end words -- was measured: two more API calls and the hand-over between the streams
     // cost more than the 11 us the next kernel would no longer queue behind, 93 -> 108 us per 8-window step at SF7; profiles/r05/s36_*.)
     LORAHIP_TRY(launchStream(ctx->sf, a, ctx->stream));
-    LORAHIP_TRY(launchStreamSummary(a.end, a.nCalls, a.nSym, a.nPkt, nullptr, B, int(cap), int(capPkt), a.near, dm->dSumScratch, &P.hSum[set], ctx->stream));
+    LORAHIP_TRY(launchStreamSummary(a.end, a.nCalls, a.nSym, a.nPkt, dm->wantSignals ? a.nSig : nullptr, B, int(cap), int(capPkt), a.near, dm->dSumScratch, &P.hSum[set], ctx->stream));
     LORAHIP_TRY(hipEventRecord(P.ev[set], ctx->stream));
     P.pending[set] = true;
     P.k++;
@@ -1446,6 +1475,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->append = false; dm->appendFresh = true; dm->appendPrev = 0; dm->headStale = false; dm->nearSeen[0] = dm->nearSeen[1] = 0;
     std::memset(&dm->lastSum, 0, sizeof(dm->lastSum));
     dm->wantSignals = false;
+    std::memset(&dm->sigRows, 0, sizeof(dm->sigRows)); dm->sigRowsOn = false; dm->lastSignals = 0;
     dm->streamGrid = 0;
     dm->streamCapMax = 0;
     dm->streamLanes = 0;
@@ -2021,6 +2051,60 @@ int lorahip_demod_packets_to_device(lorahip_demod *dm, uint16_t *syms_dev, const
     return packetsToDevice(dm, syms_dev, sym_stride, nsyms_dev, channel_dev, cap_packets, n_packets, true);
 }
 
+/*! The signals of the run just made (an ordinary receiver step) into the registered signal rows from row `first` on: packed on the
+ * device from the last launch's records while they are the only ones (the packets' device path), else from the host queue. Stream
+ * ordered like the packet rows. *n = signals of the run (also when the rows are too small: LORAHIP_E_INVALID, nothing cleared). */
+static int signalsToRows(lorahip_demod *dm, const size_t first, size_t *n, const bool sync)
+{
+    *n = 0;
+    if (!dm->wantSignals || !dm->sigRowsOn) return LORAHIP_OK;
+    const lorahip_signal_rows &R = dm->sigRows;
+    const DeviceGuard guard(dm->ctx->device);
+    hipStream_t st = dm->ctx->stream;
+    PendingLaunch &Q = pendingOf(dm);
+    if (Q.valid && dm->signals.empty())
+    {
+        *n = Q.signals;
+        if (*n == 0) return LORAHIP_OK;
+        if (first + *n > R.cap) { setLastError("lorahip_demod_receive: the signal rows cannot hold the signals that are due"); return LORAHIP_E_INVALID; }
+        const StreamLayout &L = Q.lay;
+        if (!L.signals) { *n = 0; return LORAHIP_OK; }
+        LORAHIP_TRY(launchPackSignals(reinterpret_cast<const StreamSignal *>(dm->sDev + L.oSig), reinterpret_cast<const int *>(dm->sDev + L.oNSig), L.B,
+                                      int(L.capPkt), R.channel, R.error, R.power, R.snr, first, R.cap, st));
+        if (sync) LORAHIP_TRY(hipStreamSynchronize(st));
+        return LORAHIP_OK;
+    }
+    { const int rc = drainPending(dm); if (rc != LORAHIP_OK) return rc; }
+    const size_t S = dm->signals.size();
+    *n = S;
+    if (S == 0) return LORAHIP_OK;
+    if (first + S > R.cap) { setLastError("lorahip_demod_receive: the signal rows cannot hold the signals that are due"); return LORAHIP_E_INVALID; }
+    const size_t nb = align256(S * sizeof(int32_t));
+    { const int grc = growDense(dm, 4 * nb); if (grc != LORAHIP_OK) return grc; }
+    int32_t *hc = reinterpret_cast<int32_t *>(dm->hDense), *he = reinterpret_cast<int32_t *>(dm->hDense + nb);
+    float *hp = reinterpret_cast<float *>(dm->hDense + 2 * nb), *hs = reinterpret_cast<float *>(dm->hDense + 3 * nb);
+    for (size_t i = 0; i < S; i++) { const Signal &g = dm->signals[i]; hc[i] = g.channel; he[i] = g.error; hp[i] = g.power; hs[i] = g.snr; }
+    if (R.channel) LORAHIP_TRY(hipMemcpyAsync(R.channel + first, hc, S * sizeof(int32_t), hipMemcpyDefault, st));
+    if (R.error) LORAHIP_TRY(hipMemcpyAsync(R.error + first, he, S * sizeof(int32_t), hipMemcpyDefault, st));
+    if (R.power) LORAHIP_TRY(hipMemcpyAsync(R.power + first, hp, S * sizeof(float), hipMemcpyDefault, st));
+    if (R.snr) LORAHIP_TRY(hipMemcpyAsync(R.snr + first, hs, S * sizeof(float), hipMemcpyDefault, st));
+    LORAHIP_TRY(hipStreamSynchronize(st));                              // the pinned scratch is reused by the next run
+    return LORAHIP_OK;
+}
+
+int lorahip_demod_receive_signal_rows(lorahip_demod *dm, const lorahip_signal_rows *rows)
+{
+    if (dm == nullptr) return LORAHIP_E_INVALID;
+    if (dm->comp) { setLastError("receiver steps are per part: lorahip_demod_part_handle"); return LORAHIP_E_INVALID; }
+    if (rows == nullptr) { std::memset(&dm->sigRows, 0, sizeof(dm->sigRows)); dm->sigRowsOn = false; return LORAHIP_OK; }
+    if (rows->struct_size != sizeof(lorahip_signal_rows) || rows->cap > 0x7fffffffu) return LORAHIP_E_INVALID;
+    dm->sigRows = *rows;
+    dm->sigRowsOn = rows->cap != 0 && (rows->channel || rows->error || rows->power || rows->snr);
+    return LORAHIP_OK;
+}
+
+size_t lorahip_demod_receive_num_signals(const lorahip_demod *dm) { return dm && !dm->comp ? dm->lastSignals : 0; }
+
 int lorahip_demod_receive(lorahip_demod *dm, const float *iq_dev, const size_t row_stride, const size_t n_valid, const lorahip_packet_rows *rows,
                           size_t *n_packets, int64_t *work_calls)
 {
@@ -2042,9 +2126,12 @@ int lorahip_demod_receive(lorahip_demod *dm, const float *iq_dev, const size_t r
     if (rc != LORAHIP_OK) return rc;
     if (work_calls) *work_calls = dm->workCalls - calls0;
     size_t n = 0;
+    dm->lastSignals = 0;
     rc = packetsToDevice(dm, rows->syms_dev, rows->sym_stride, rows->nsyms_dev, rows->channel_dev, rows->cap_packets, &n, rows->async == 0);
     if (n_packets) *n_packets = n;
     if (rc != LORAHIP_OK) return rc;                                    // (the packets stay queued: a caller with too few rows can fetch them)
+    rc = signalsToRows(dm, 0, &dm->lastSignals, rows->async == 0);      // the block's signals of this step, beside its packets
+    if (rc != LORAHIP_OK) return rc;                                    // (... and so do the signals: lorahip_demod_get_signals)
     lorahip_demod_clear_packets(dm);
     return LORAHIP_OK;
 }
@@ -2077,6 +2164,13 @@ int lorahip_demod_receive_flush(lorahip_demod *dm, const lorahip_packet_rows *ro
                          rows->channel_dev ? rows->channel_dev + n1 : nullptr, rows->cap_packets - n1, &n2, true);
     if (n_packets) *n_packets = n1 + n2;
     if (rc != LORAHIP_OK) return rc;
+    {
+        const size_t s1 = dm->lastSignals;
+        size_t s2 = 0;
+        rc = signalsToRows(dm, s1, &s2, true);
+        dm->lastSignals = s1 + s2;
+        if (rc != LORAHIP_OK) return rc;
+    }
     lorahip_demod_clear_packets(dm);
     return LORAHIP_OK;
 }

@@ -201,6 +201,8 @@ bool streamLanesAvailable(int sf, int log2Lanes);
 int streamLanesChosen(int sf, unsigned nChannels, int forced);
 hipError_t launchStreamLanes(int sf, int log2Lanes, const StreamArgs &s, hipStream_t stream);
 hipError_t launchCompactRows(void *dst, const void *src, size_t rows, size_t srcPitchBytes, size_t rowBytes, hipStream_t stream);
+hipError_t launchPackSignals(const StreamSignal *sigOut, const int *nSig, size_t nChannels, int capPkt, int *channel, int *error, float *power, float *snr,
+                             size_t firstRow, size_t capRows, hipStream_t stream);
 hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const short *symOut, int *rowStart, size_t nChannels, int cap, int capPkt,
                              size_t nPackets, long long *srcOff, unsigned short *symsOut, int stride, int *nsymsOut, int *channelOut, hipStream_t stream);
 hipError_t launchCopySegments(float2 *dst, const float2 *src, const long long *srcOff, const long long *dstOff, const int *len, size_t nSeg,
@@ -263,7 +265,7 @@ int hipFail(hipError_t e, const char *what);
 
 namespace lorahip {
 //! two pinned staging buffers of the host -> device gather (lorahip_upload.cpp)
-struct Uploader { void *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; bool ready = false; };
+struct Uploader { void *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; bool ready = false; void *pool = nullptr; /* CopyPool: lorahip_upload.cpp */ };
 }
 
 struct lorahip_ctx

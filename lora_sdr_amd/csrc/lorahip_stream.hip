@@ -144,6 +144,55 @@ hipError_t launchPackPackets(const StreamPacket *pktOut, const int *nPkt, const 
 }
 
 /***********************************************************************
+ * The signals of a streaming launch (one StreamSignal per DOWNCHIRP1 call, LoRaDemod.cpp:267-269) into dense rows -- channel, error,
+ * power, snr -- in the packets' order: channels ascending, time ascending inside a channel. Same shape as scanDescribe: the row numbers
+ * are an exclusive prefix sum of nSig computed on the device, a lane per channel, no upload and no host synchronisation. The rows may be
+ * device memory or pinned host memory the device writes directly (a host consumer: the block's emitSignal calls).
+ **********************************************************************/
+__global__ void __launch_bounds__(1024) packSignals(const StreamSignal *__restrict__ sigOut, const int *__restrict__ nSig, const unsigned nChannels, const int capPkt,
+                                                    int *__restrict__ channel, int *__restrict__ error, float *__restrict__ power, float *__restrict__ snr,
+                                                    const unsigned firstRow, const unsigned capRows)
+{
+    __shared__ int sWave[16];
+    const unsigned first = blockIdx.x * 1024u, c = first + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int before = 0;
+    for (unsigned i = threadIdx.x; i < first; i += 1024u) before += nSig[i];
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+    if (lane == 0) sWave[w] = before;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < 16; k++) base += sWave[k];
+    __syncthreads();
+    const int mine = c < nChannels ? nSig[c] : 0;
+    int incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) sWave[w] = incl;
+    __syncthreads();
+    for (int k = 0; k < w; k++) base += sWave[k];
+    const unsigned row0 = firstRow + unsigned(base + incl - mine);
+    for (int j = 0; j < mine; j++)
+    {
+        const unsigned r = row0 + unsigned(j);
+        if (r >= capRows) break;                            // (the host checked the capacity before the launch: cannot happen)
+        const StreamSignal q = sigOut[(size_t)c * capPkt + j];
+        if (channel) channel[r] = (int)c;
+        if (error) error[r] = q.error;
+        if (power) power[r] = q.power;
+        if (snr) snr[r] = q.snr;
+    }
+}
+
+hipError_t launchPackSignals(const StreamSignal *sigOut, const int *nSig, const size_t nChannels, const int capPkt, int *channel, int *error, float *power,
+                             float *snr, const size_t firstRow, const size_t capRows, hipStream_t stream)
+{
+    if (nChannels == 0) return hipSuccess;
+    hipLaunchKernelGGL(packSignals, dim3(unsigned((nChannels + 1023) / 1024)), dim3(1024), 0, stream, sigOut, nSig, unsigned(nChannels), capPkt, channel, error, power,
+                       snr, unsigned(firstRow), unsigned(capRows));
+    return hipGetLastError();
+}
+
+/***********************************************************************
  * What the host needs after a streaming launch, reduced on the device: the per-channel counts and end-of-launch words (a few hundred KiB
  * in HBM) become 72 bytes. The per-channel arrays cross PCIe only when an accessor asks for them.
  * ONE workgroup, one launch, up to 32768 channels: five dense arrays (the four counts and StreamArgs::end, which the streaming kernels

@@ -5,8 +5,10 @@
 // pieces that already live in pinned memory (lorahip_host_alloc, or anything hipHostMalloc'ed / hipHostRegister'ed) skip the
 // staging copy and go straight to the DMA engine.
 #include "lorahip_internal.h"
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 namespace lorahip {
@@ -19,7 +21,7 @@ static int uploadThreads()
     static const int n = []() {
         if (const char *e = std::getenv("LORAHIP_UPLOAD_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) return v; }
         const unsigned hw = std::thread::hardware_concurrency();
-        return hw >= 16 ? 6 : (hw >= 4 ? 3 : 1);
+        return hw >= 32 ? 8 : (hw >= 16 ? 6 : (hw >= 4 ? 3 : 1));
     }();
     return n;
 }
@@ -48,36 +50,91 @@ static bool pinnedRange(const void *p, const char *&lo, const char *&hi)
 
 struct Seg { char *dst; const char *src; size_t bytes; };
 
-//! the segments of one staging fill, copied by the calling thread and up to T-1 helpers
-static void copySegments(const std::vector<Seg> &segs, const size_t total)
+//! thread k of T copies bytes [k*share, (k+1)*share) of the concatenation of the segments
+static void copyShare(const std::vector<Seg> &segs, const size_t share, const int k)
+{
+    const size_t lo = size_t(k) * share, hi = lo + share;
+    size_t at = 0;
+    for (const Seg &s : segs)
+    {
+        const size_t a = at > lo ? at : lo, b = (at + s.bytes) < hi ? (at + s.bytes) : hi;
+        if (a < b) std::memcpy(s.dst + (a - at), s.src + (a - at), b - a);
+        at += s.bytes;
+        if (at >= hi) break;
+    }
+}
+
+/*! The helpers of a context's uploads, started once and parked between the staging fills. (Until round 6 every 32 MiB fill started and
+ * joined its helper threads: five thread creations per 0.8 ms of copying, 68 times per 2 GiB at SF7 -- the CPU side of the gather, which
+ * bounds an upload from ordinary memory, ran at 37 GB/s where the DMA engine takes 55.) */
+struct CopyPool
+{
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable go, done;
+    const std::vector<Seg> *segs = nullptr;
+    size_t share = 0;
+    unsigned gen = 0;
+    int running = 0;
+    bool quit = false;
+
+    void worker(const int k)
+    {
+        unsigned seen = 0;
+        for (;;)
+        {
+            const std::vector<Seg> *mine; size_t sh;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                go.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen; mine = segs; sh = share;
+            }
+            copyShare(*mine, sh, k);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--running == 0) done.notify_one();
+            }
+        }
+    }
+    //! helpers 1 .. n-1 (as many as could be started); the caller is thread 0
+    int start(const int n)
+    {
+        try { for (int k = int(th.size()) + 1; k < n; k++) th.emplace_back(&CopyPool::worker, this, k); }
+        catch (...) {}                                    // (no exception may cross the C ABI: fewer helpers, the caller copies their shares)
+        return int(th.size()) + 1;
+    }
+    void run(const std::vector<Seg> &s, const size_t total, const int T)
+    {
+        const int have = start(T);
+        const size_t sh = (total + size_t(T) - 1) / size_t(T);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            segs = &s; share = sh; running = have - 1; gen++;
+        }
+        go.notify_all();
+        copyShare(s, sh, 0);
+        for (int k = have; k < T; k++) copyShare(s, sh, k);   // shares of helpers that could not be started
+        // (helpers beyond T, from an earlier larger T, find their share empty)
+        std::unique_lock<std::mutex> lk(m);
+        done.wait(lk, [&] { return running == 0; });
+    }
+    ~CopyPool(void)
+    {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        go.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+
+//! the segments of one staging fill, copied by the calling thread and up to T-1 parked helpers
+static void copySegments(Uploader &u, const std::vector<Seg> &segs, const size_t total)
 {
     const int T = total >= (size_t(4) << 20) ? uploadThreads() : 1;
     if (T <= 1) { for (const Seg &s : segs) std::memcpy(s.dst, s.src, s.bytes); return; }
-    const size_t share = (total + T - 1) / T;
-    auto work = [&segs, share](const int k)
-    {
-        // thread k copies bytes [k*share, (k+1)*share) of the concatenation of the segments
-        size_t lo = size_t(k) * share, hi = lo + share, at = 0;
-        for (const Seg &s : segs)
-        {
-            const size_t a = at > lo ? at : lo, b = (at + s.bytes) < hi ? (at + s.bytes) : hi;
-            if (a < b) std::memcpy(s.dst + (a - at), s.src + (a - at), b - a);
-            at += s.bytes;
-            if (at >= hi) break;
-        }
-    };
-    // no exception may cross the C ABI: a helper thread that cannot be started (std::system_error) has its share copied here
-    std::vector<std::thread> pool;
-    int started = 1;
-    try
-    {
-        pool.reserve(size_t(T - 1));
-        for (; started < T; started++) pool.emplace_back(work, started);
-    }
-    catch (...) {}
-    work(0);
-    for (int k = started; k < T; k++) work(k);
-    for (auto &t : pool) t.join();
+    if (u.pool == nullptr) u.pool = new (std::nothrow) CopyPool();
+    if (u.pool == nullptr) { for (const Seg &s : segs) std::memcpy(s.dst, s.src, s.bytes); return; }
+    static_cast<CopyPool *>(u.pool)->run(segs, total, T);
 }
 
 int gatherUpload(lorahip_ctx *ctx, void *dDstV, const void *const *src, const size_t *bytes, const size_t n)
@@ -110,7 +167,7 @@ int gatherUpload(lorahip_ctx *ctx, void *dDstV, const void *const *src, const si
     auto flush = [&]() -> int
     {
         if (fill == 0) return LORAHIP_OK;
-        copySegments(segs, fill);
+        copySegments(u, segs, fill);
         LORAHIP_TRY(hipMemcpyAsync(dDst + done, u.buf[k], fill, hipMemcpyHostToDevice, ctx->stream));
         LORAHIP_TRY(hipEventRecord(u.ev[k], ctx->stream));
         u.busy[k] = true;
@@ -176,6 +233,8 @@ void destroyUploader(lorahip_ctx *ctx)
         ctx->up.buf[k] = nullptr; ctx->up.ev[k] = nullptr; ctx->up.busy[k] = false;
     }
     ctx->up.ready = false;
+    delete static_cast<CopyPool *>(ctx->up.pool);         // (parks no thread beyond the context's life)
+    ctx->up.pool = nullptr;
 }
 
 } // namespace lorahip

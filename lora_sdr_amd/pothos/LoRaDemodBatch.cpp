@@ -104,7 +104,7 @@ class LoRaDemodBatch : public Pothos::Block
 public:
     LoRaDemodBatch(const size_t sf, const size_t channels) :
         B(channels), _d(nullptr), _sfs(channels, int32_t(sf)), _devices(1, 0), _sync(0x12), _thresh(-30.0), _mtu(256), _maxWindows(64),
-        _fftCap(128), _fftDropped(0), _pinnedLimitMiB(8192), _debugPorts(false), _signals(true), _active(false)
+        _fftCap(128), _fftDropped(0), _pinnedLimitMiB(12288), _debugPorts(false), _signals(true), _active(false)
     {
         _d = makeDemod(_sfs, _devices);
         this->registerCall(this, POTHOS_FCN_TUPLE(LoRaDemodBatch, setSync));

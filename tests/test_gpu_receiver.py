@@ -233,13 +233,20 @@ def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf)
     iq = gpu.from_numpy(host).cuda()
     d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
     rows = [d.receiver_rows(cap_packets=64, stride=16) for _ in range(2)]
+    # the block's signals (error / power / snr at DOWNCHIRP1, LoRaDemod.cpp:267-269) travel with the packets, one step late like them:
+    # into pinned host rows the device writes directly (what a host consumer -- a block's emitSignal -- reads)
+    d.set_signals(True)
+    sig_rows = d.receiver_signal_rows(64 + B, pinned_host=True)
     got, calls, w, k = [[] for _ in range(B)], 0, 0, 0
+    got_sig = [[] for _ in range(B)]
 
     def take(n, r):
         gpu.cuda.synchronize()
         sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
         for i in range(n):
             got[int(chn[i])].append(sy[i, :ns[i]].copy())
+        for i in range(d.last_signals()):
+            got_sig[int(sig_rows[0][i])].append((int(sig_rows[1][i]), float(sig_rows[2][i]), float(sig_rows[3][i])))
     piped = 0
     while w < cap:
         w = min(cap, w + int(rng.integers(N // 2, 6 * N)))
@@ -265,8 +272,13 @@ def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf)
         assert len(got[c]) == len(r["packets"]) >= 4, "channel %d" % c
         assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
         assert d.consumed(c) == int(sum(q["consumed"] for q in r["calls"]))
+        # every emission of the reference block, in order: error exactly, power / snr within the level-3 tolerance
+        assert len(got_sig[c]) == len(r["signals"]) >= 4, "channel %d" % c
+        assert [g[0] for g in got_sig[c]] == [int(q[0]) for q in r["signals"]]
+        assert np.allclose([g[1:] for g in got_sig[c]], [q[1:] for q in r["signals"]], rtol=0, atol=2e-5)
     assert calls == sum(len(r["calls"]) for r in refs) == d.work_calls()
     assert d.receive_flush() == (0, 0)                                      # nothing in flight: a no-op
+    assert d.last_signals() == 0
     # the flushed object is an ordinary one: a rewound one-shot run gives the same again
     d.rewind(); d.activate()
     refs2 = None
@@ -274,6 +286,123 @@ def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf)
     pk = d.packets()
     assert sum(len(r["packets"]) for r in refs) == len(pk)
     d.close()
+
+
+@pytest.mark.parametrize("async_", [False, True, 2])
+def test_receiver_steps_deliver_the_signals_and_lose_none_on_small_rows(gpu, oracle, async_):
+    """Signals in a running receiver, every kind of step (waiting, stream-ordered, pipelined): device rows this time. Signal rows that
+    cannot hold what is due are an error like packet rows that are too small -- nothing is lost: registering larger rows and calling
+    again delivers everything."""
+    import lora_sdr_amd as L
+    sf, B = 8, 9
+    rng = np.random.default_rng(4242)
+    N = 1 << sf
+    host = _streams(oracle, rng, sf, B, n_frames=3)
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
+    iq = gpu.from_numpy(host).cuda()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
+    d.set_signals(True)
+    rows = d.receiver_rows(cap_packets=64, stride=16)
+    sig = d.receiver_signal_rows(2)                                         # far too small: the first step with > 2 emissions must refuse
+    got, got_sig, refused = [[] for _ in range(B)], [[] for _ in range(B)], 0
+
+    def take(n):
+        gpu.cuda.synchronize()
+        sy, ns, chn = rows[0][:n].cpu().numpy(), rows[1][:n].cpu().numpy(), rows[2][:n].cpu().numpy()
+        for i in range(n):
+            got[int(chn[i])].append(sy[i, :ns[i]].copy())
+        m = d.last_signals()
+        sc, se, sp, ss = (t[:m].cpu().numpy() for t in sig)
+        for i in range(m):
+            got_sig[int(sc[i])].append((int(se[i]), float(sp[i]), float(ss[i])))
+    w = 0
+    while w < cap:
+        w = min(cap, w + 5 * N)
+        try:
+            n, _ = d.receive(iq, w, rows, async_=async_)
+        except L.LoraHipError:
+            refused += 1
+            assert d.last_signals() > 2 or async_ != 2                      # (pipelined: what is due is reported)
+            sig = d.receiver_signal_rows(64 + B)
+            if async_ == 2:
+                n, _ = d.receive(iq, w, rows, async_=2)                     # the held step first, then this one's kernel
+            else:
+                # an ordinary step's packets and signals stayed queued: the accessors still have them
+                pk = d.packets(clear=False)
+                ch_, _, er_, po_, sn_ = d.signals()
+                for c_, _, sy_ in pk:
+                    got[c_].append(np.asarray(sy_))
+                for i in range(len(ch_)):
+                    got_sig[int(ch_[i])].append((int(er_[i]), float(po_[i]), float(sn_[i])))
+                d.clear_packets()
+                continue
+        take(n)
+    if async_ == 2:
+        n, _ = d.receive_flush(rows)
+        take(n)
+    assert refused == 1
+    for c in range(B):
+        r = refs[c]
+        assert len(got[c]) == len(r["packets"]) >= 3 and all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), c
+        assert [g[0] for g in got_sig[c]] == [int(q[0]) for q in r["signals"]] and len(got_sig[c]) >= 3, c
+        assert np.allclose([g[1:] for g in got_sig[c]], [q[1:] for q in r["signals"]], rtol=0, atol=2e-5)
+    d.close()
+
+
+def test_configs3_over_eight_device_entries_equals_six_single_sf_objects(gpu):
+    """BASELINE configs[3] through ONE handle with the device list of an 8-GPU node -- here 0,0,0,0,0,0,0,0: lorahip_shard_plan's split,
+    48 (device, SF) parts, 48 host threads and streams are the real ones, only the GPU is the one a test box has. 16384 channels,
+    SF = 7 + c mod 6, every channel one frame of 16 symbols in one device buffer (lorahip_demod_run_device_segments). Every channel's
+    packets, call count and read position equal what six single-SF objects make of the same samples. A CODE-PATH check of the
+    multi-device object (DeviceGuard, per-part threads, per-device kernel attributes), not a scaling measurement."""
+    import lora_sdr_amd as L
+    from lora_sdr_amd import workloads as WL
+    torch = gpu
+    n_channels, nsyms = 16384, 16
+    sfs = WL.mixed_sf_channels(n_channels)
+    parts, first, cnt, at, per_sf = [], np.zeros(n_channels, np.int64), np.zeros(n_channels, np.uint64), 0, {}
+    for sf in range(7, 13):
+        local = np.nonzero(sfs == sf)[0]
+        ctx = L.Context(sf)
+        iq, _ = WL.frame_streams(ctx, local.size, 1, nsyms, sigma=0.05, seed=3 + sf)
+        ctx.close()
+        n = int(iq.shape[1])
+        first[local] = at + np.arange(local.size, dtype=np.int64) * n
+        cnt[local] = n
+        at += local.size * n
+        parts.append(iq.reshape(-1))
+        per_sf[sf] = (local, iq)
+    buf = torch.cat(parts)
+    del parts
+    m = L.LoRaDemod(channel_sf=sfs, devices=[0] * 8)
+    assert len(m.parts) == 48 and sum(p[2] for p in m.parts) == n_channels
+    m.setMTU(nsyms)
+    m.work_segments_multi([buf] * 8, first, cnt)           # one buffer per entry of the device list (here the same one eight times)
+    ch_, _rd, ln_, sy_ = m.packets_arrays()
+    starts = np.concatenate([[0], np.cumsum(ln_)])[:-1]
+    mine = {}
+    for i in np.argsort(ch_, kind="stable").tolist():
+        mine.setdefault(int(ch_[i]), []).append(sy_[starts[i]:starts[i] + ln_[i]])
+    consumed_m = m.consumed_all()
+    total_calls = 0
+    for sf, (local, iq) in per_sf.items():
+        d = L.LoRaDemod(sf, n_channels=local.size); d.set_mode(1); d.setMTU(nsyms)
+        d.work(iq)
+        total_calls += d.work_calls()
+        c1, _r1, l1, s1 = d.packets_arrays()
+        st1 = np.concatenate([[0], np.cumsum(l1)])[:-1]
+        want = {}
+        for i in np.argsort(c1, kind="stable").tolist():
+            want.setdefault(int(local[c1[i]]), []).append(s1[st1[i]:st1[i] + l1[i]])
+        assert len(want) >= local.size - 2                                        # (practically every channel posts its packet)
+        for g in local.tolist():
+            a, b = mine.get(g, []), want.get(g, [])
+            assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)), "channel %d (SF%d)" % (g, sf)
+        assert np.array_equal(consumed_m[local], d.consumed_all())
+        d.close()
+    assert m.work_calls() == total_calls
+    m.close()
 
 
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])

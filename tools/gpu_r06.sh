@@ -13,6 +13,15 @@ if [[ $what == *tworank* ]]; then
   tail -c 400 $O/${TAG}_bench_two_ranks.err
   python tools/bench_digest.py $O/${TAG}_bench_two_ranks_one_device_gloo.json
 fi
+if [[ $what == *eightrank* ]]; then
+  # the --gpus 8 code path (what the driver's SCALE run launches) on the ONE device of this box over gloo: a code-path check -- the line's
+  # size, its keys and the wall time (rank 0 runs every CPU leg; the driver's limit is 1800 s) -- not a scaling measurement
+  t0=$(date +%s)
+  LORA_BENCH_BACKEND=gloo LORA_BENCH_ONE_DEVICE=1 timeout 1500 python bench.py --gpus 8 --steps 20 --warmup 5 > $O/${TAG}_bench_eight_ranks_one_device_gloo.json 2> $O/${TAG}_bench_eight_ranks.err
+  echo "eight ranks on one device: rc $? wall $(( $(date +%s) - t0 )) s" | tee $O/${TAG}_bench_eight_ranks_wall.txt
+  tail -c 300 $O/${TAG}_bench_eight_ranks.err
+  python tools/bench_digest.py $O/${TAG}_bench_eight_ranks_one_device_gloo.json | head -30
+fi
 if [[ $what == *level3* ]]; then
   for sf in ${L3SFS:-7 8 9 10 11 12}; do
     timeout 200 python tools/bench_demod.py --sf $sf --channels ${L3CH:-$(l3ch $sf)} --modes 1 > $O/${TAG}_level3_sf$sf.txt 2>&1
@@ -97,6 +106,23 @@ if [[ $what == *final* ]]; then
   python tools/pmc_summary.py $O > $O/${TAG}_pmc_summary.txt 2>&1
   tail -25 $O/${TAG}_pmc_summary.txt
   rm -rf $O/pmc_FETCH_SIZE_sf* $O/pmc_WRITE_SIZE_sf*
+fi
+if [[ $what == *counters* ]]; then
+  # north_star's "LDS/VALU utilisation against gfx950 peak" for the batch kernels of THIS tree: two SQ passes per shape
+  # and SF (8 SQ slots per pass), counters only -- no trace domains beside --pmc. -> gpurun_out/counters.json (tools/pmc_counters.py),
+  # installed as profiles/counters.json and replayed by bench.py as roofline.valu_busy / lds_busy / instr_per_sample
+  rm -rf $O/pmc_SQ*_sf*
+  for sf in ${CSF:-7 8 9 10 11 12}; do
+    for shape in steady moving; do
+      mv=""; [[ $shape == moving ]] && mv="--moving"
+      ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES \
+          -d $O/pmc_SQA_${shape}_sf$sf -o pmc --output-format csv -- python $R/bench.py --sf $sf $mv --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $O/pmc_SQA_${shape}_sf$sf.log 2>&1 )
+      ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS \
+          -d $O/pmc_SQB_${shape}_sf$sf -o pmc --output-format csv -- python $R/bench.py --sf $sf $mv --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $O/pmc_SQB_${shape}_sf$sf.log 2>&1 )
+    done
+  done
+  TAG=$TAG python tools/pmc_counters.py $O $TAG | tee $O/${TAG}_sq_counters_batch_kernels.txt
+  rm -rf $O/pmc_SQ*_sf*
 fi
 if [[ $what == *custom* ]]; then
   bash -c "$CUSTOM" > $O/${TAG}_custom.txt 2>&1; tail -${CUSTOM_TAIL:-40} $O/${TAG}_custom.txt
