@@ -148,7 +148,8 @@ def compact_line(full):
                 row["chunk8"] = dict(_pick(c8, "Msym_s", "frac"), pipelined_Msym_s=_get(c8, "pipelined", "Msym_s"),
                                      pipelined_frac=_get(c8, "pipelined", "frac"), with_signals_frac=_get(c8, "with_signals", "frac"),
                                      with_signals_pipelined_frac=_get(c8, "with_signals", "pipelined", "frac"),
-                                     resident_Msym_s=_get(c8, "resident", "Msym_s"), resident_frac=_get(c8, "resident", "frac"))
+                                     resident_Msym_s=_get(c8, "resident", "Msym_s"), resident_frac=_get(c8, "resident", "frac"),
+                                     resident_same_packets=_get(c8, "resident", "same_packets_as_one_shot"))
                 for part in (row["running"], row["chunk8"]):
                     for k in [k for k, v in part.items() if v is None]:
                         part.pop(k)
@@ -207,12 +208,13 @@ def emit(env, line):
         for k in SECTION_KEYS:
             if k in line:
                 print("SECTION %s %s" % (k, json.dumps(line[k], separators=(",", ":"))), flush=True)
-        try:
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, SECTIONS_FILE), "w") as f:
-                json.dump(line, f, indent=1)
-        except OSError:                                   # scratch only: a read-only tree must not cost the line
-            pass
+        if "per_sf" in line or "mixed" in line:           # (the default run and --config mixed: single-shape runs have one section)
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, SECTIONS_FILE), "w") as f:
+                    json.dump(line, f, indent=1)
+            except OSError:                               # scratch only: a read-only tree must not cost the line
+                pass
         print(json.dumps(compact_line(line), separators=(",", ":")), flush=True)
 
 
@@ -829,6 +831,44 @@ def section_level3(env, L, sf, threads=32):
             (running if cw == 128 else running["chunk8"])["pipelined"] = {
                 "ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6),
                 "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)), "packets": int(rb[2])}
+        # RESIDENT steps (async = 3): one kernel launch stays on the device, a step is a 104-byte message and two words back; the kernel packs
+        # the packets itself into the rows that came with the step (two sets, alternating). SF7-10; elsewhere the calls are ordinary steps.
+        rows_b_ = d.receiver_rows(cap_packets=B * (frames + 1), stride=max(8, min(nsyms, 512)))
+
+        def resident_pass(chunk_windows):
+            chunk = chunk_windows << sf
+            d.clear_packets()
+            d.rewind()
+            d.activate()
+            w = n_pk_ = n_work = calls_ = k_ = 0
+            was_ = False
+            env.barrier()
+            t0 = time.perf_counter()
+            while w < cap_:
+                w = min(cap_, w + chunk)
+                n_, c_ = d.receive(iq, w, (rows_, rows_b_)[k_ & 1], async_=3, order_with_torch=False)
+                n_pk_ += n_
+                calls_ += c_
+                n_work += 1
+                k_ += 1
+            was_ = d.resident_active()
+            n_, c_ = d.receive_flush((rows_, rows_b_)[k_ & 1])
+            (dt_,) = env.max_over_ranks(time.perf_counter() - t0)
+            (calls_all_, pk_all_) = env.sum_over_ranks(calls_ + c_, n_pk_ + n_)
+            return dt_, calls_all_, pk_all_, n_work, was_
+        for cw in (128, 8):
+            try:
+                resident_pass(cw)
+                rb = min((resident_pass(cw) for _ in range(3)), key=lambda r_: r_[0])
+                (running if cw == 128 else running["chunk8"])["resident"] = {
+                    "ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6), "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)),
+                    "packets": int(rb[2]), "kernel_resident": bool(rb[4]), "same_packets_as_one_shot": bool(rb[2] == n_dev * env.world)}
+            except Exception as e:
+                (running if cw == 128 else running["chunk8"])["resident"] = {"error": repr(e)[:160]}
+                try:
+                    d.receive_flush(None)
+                except Exception:
+                    pass
         # The same steps delivering what the reference block delivers: packets AND the signals "error" / "power" / "snr" (LoRaDemod.cpp:
         # 267-269), into rows registered with lorahip_demod_receive_signal_rows (device memory: a consumer on the device, like the rows)
         d.set_signals(True)

@@ -67,7 +67,8 @@ int lorahip_version(void);                  /* ABI version, currently 4 (1 -> 2:
                                                3 -> 4, additions only: lorahip_demod_receive_flush, _run_host_rows, _stream_wait / _stream_follow,
                                                _set_stream_lanes / _stream_lanes, _set_stream_grid, _set_variant, _set_record_capacity,
                                                lorahip_decode_packets_host, lorahip_decode_max_symbols, lorahip_decode_max_data_length, lorahip_demod_receive_signal_rows /
-                                               _receive_num_signals: signals in receiver steps, pipelined ones included) */
+                                               _receive_num_signals: signals in receiver steps, pipelined ones included; async = 3: the resident receiver,
+                                               lorahip_demod_resident_active) */
 int lorahip_device_count(void);             /* number of usable gfx950 devices, 0 if none */
 int lorahip_selfcheck(void);                /* host-only: the kernels' compile-time LDS layouts are consistent; no device needed */
 
@@ -386,6 +387,23 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * between (*n_packets and *work_calls then cover both steps; until then no further kernel is launched -- the samples wait in the
  * caller's array, a later call covers them). As with async = 0/1 a packet longer than sym_stride keeps its true length in
  * nsyms_dev and its first sym_stride symbols (the decoder flags it): sym_stride >= the MTU never truncates.
+ * With async = 3 the receiver is RESIDENT (SF7-10, every channel's workgroup on the device at once -- up to the device's resident set,
+ * 16384 channels at SF7 ... 2048 at SF10; otherwise, and until the object is in place for it, the call is an ordinary step): ONE
+ * kernel launch stays on the device across the steps. A call copies a 104-byte message into a ring in device memory (the doorbell) and
+ * returns the counts of the PREVIOUS step; the kernel's wavefronts poll the ring, work through what arrived with the tables they
+ * staged once, pack the step's packets (and signals, lorahip_demod_receive_signal_rows) themselves into the rows that came WITH the
+ * step's call, and the last workgroup reports two words to pinned host memory: no launch, no helper kernel per step. So: the rows
+ * passed to call k are filled by step k and are complete -- in memory, for any stream, a copy engine or, if they are pinned host
+ * memory, the host -- when call k + 1 (or lorahip_demod_receive_flush) returns with their *n_packets; keep two sets of rows and
+ * alternate. Rows are handed out in the order the workgroups finish: a channel's packets of a step are consecutive and in time order,
+ * channels are not sorted (channel_dev says whose a row is). The samples up to n_valid must BE in iq_dev when the call is made (the
+ * kernel reads them on its own, not in the order of any stream). Rows too small for a step: the excess is dropped, counted in
+ * *n_packets, and the call that reports the step returns LORAHIP_E_INVALID -- size the rows for a step (one packet per channel and
+ * frame that can end in it). While the kernel is resident it holds the wavefront slots of its channels -- on a full device nothing else
+ * runs until the flush --, every other entry point that needs the object returns LORAHIP_E_INVALID, and every wait is bounded: a
+ * wavefront that sees no message for 8 s leaves, a host call that sees no report for 5 s tells the kernel to leave and fails (the
+ * object then takes ordinary steps). lorahip_demod_receive_flush(d, rows, ..) reports the last step, ends the kernel and leaves the
+ * object as a streaming run leaves it.
  * Ordering of the rows: a step's packets are written in stream order AFTER everything that was queued on the launch stream when
  * the call began, so a consumer (decoder) of the rows handed out by the call before, queued on that stream (or on a stream the
  * launch stream was told to follow before the call, lorahip_demod_stream_follow), has read them before they are overwritten -- one
@@ -397,7 +415,7 @@ typedef struct lorahip_packet_rows {
     int32_t *nsyms_dev;                          /* [cap_packets] */
     int32_t *channel_dev;                        /* [cap_packets], nullable */
     size_t cap_packets;
-    int32_t async;          /* 0 wait, 1 rows valid in stream order, 2 pipelined (see above) */
+    int32_t async;          /* 0 wait, 1 rows valid in stream order, 2 pipelined, 3 resident (see above) */
     int32_t reserved;
 } lorahip_packet_rows;
 int lorahip_demod_receive(lorahip_demod *d, const float *iq_dev, size_t row_stride, size_t n_valid, const lorahip_packet_rows *rows,
@@ -425,6 +443,7 @@ int lorahip_demod_receive_signal_rows(lorahip_demod *d, const lorahip_signal_row
 size_t lorahip_demod_receive_num_signals(const lorahip_demod *d);
 int lorahip_demod_receive_flush(lorahip_demod *d, const lorahip_packet_rows *rows /* nullable: the last step's packets are dropped */,
                                 size_t *n_packets, int64_t *work_calls);
+int lorahip_demod_resident_active(const lorahip_demod *d);      /* 1 while the resident kernel (async = 3) is on the device */
 
 /* The block's signals "error" (int), "power" (float), "snr" (float), emitted once per packet at DOWNCHIRP1 (LoRaDemod.cpp:85-87,
  * 267-269), WITHOUT a per-call trace: with enable = 1 the following runs keep one record per emission -- the kernels evaluate

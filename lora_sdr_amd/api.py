@@ -758,6 +758,10 @@ class LoRaDemod:
         self._sig_rows = rows                                # (kept alive while registered)
         return rows
 
+    def resident_active(self):
+        """True while the resident kernel of receive(async_=3) is on the device"""
+        return bool(self._lib.lorahip_demod_resident_active(self._h))
+
     def last_signals(self):
         """signals the last receive() / receive_flush() delivered into the registered signal rows"""
         return int(self._lib.lorahip_demod_receive_num_signals(self._h))
@@ -781,8 +785,20 @@ class LoRaDemod:
         (lorahip_demod_stream_wait) -- work queued on it after this call sees the rows. order_with_torch=False leaves both out (two
         event records and two stream waits per step): for a caller that orders its own streams, or times the C entry itself."""
         import torch
-        r = self._rows_struct(rows, 2 if async_ == 2 else int(bool(async_)))
+        r = self._rows_struct(rows, async_ if async_ in (2, 3) else int(bool(async_)))
         n, calls = C.c_size_t(), C.c_int64()
+        if async_ == 3:
+            # RESIDENT: one kernel stays on the device and takes the steps as messages. The rows passed here are filled by THIS step and
+            # are complete when the NEXT receive() / receive_flush() returns (whose counts are this step's). The kernel reads `buf` on its
+            # own: what produced the new samples must have finished (order_with_torch: torch's current stream is waited for).
+            if order_with_torch:
+                torch.cuda.current_stream(buf.device).synchronize()
+            try:
+                check(self._lib.lorahip_demod_receive(self._h, _dptr(buf), int(buf.shape[1]), int(n_valid), C.byref(r), C.byref(n), C.byref(calls)), "lorahip_demod_receive")
+            except Exception as e:
+                e.n_packets = n.value
+                raise
+            return n.value, calls.value
         if async_ == 2:
             if not order_with_torch:
                 check(self._lib.lorahip_demod_receive(self._h, _dptr(buf), int(buf.shape[1]), int(n_valid), C.byref(r), C.byref(n), C.byref(calls)), "lorahip_demod_receive")

@@ -1002,9 +1002,31 @@ struct Pipe
     hipEvent_t entry;               // ... and the side stream for this: where the launch stream stood when the call began (the caller's
                                     // consumer of the rows handed out by the call before, earlier packing on the launch stream)
     const float *iq; size_t rowStride;  // the rows the steps read (a flush that has to resume a full channel continues on them)
+    // ---- the RESIDENT receiver (lorahip_demod_receive, async = 3): one launch across the steps, lorahip_streamkernel.h (RES) ----
+    struct Resident
+    {
+        bool active;                    // the kernel is on the device: only receive (async = 3) / flush may touch the object
+        bool unavailable;               // tried and refused for this object (no instance, the grid not resident at once, a step timed out)
+        unsigned seq;                   // steps rung
+        unsigned reported;              // steps whose report the caller has had
+        ResidentCtl *ctl;               // device
+        ResidentMsg *hMsg;              // [8] pinned: the messages as they are copied into the ring
+        unsigned long long *hSum;       // [4][2] pinned and mapped: the steps' reports
+        char *rec; size_t recBytes;     // the channels' records of a step (a StreamLayout; the state and the carry rows are the object's own)
+        StreamLayout lay;
+        hipStream_t run, bell;          // the kernel's stream; the doorbell copies' stream
+        hipEvent_t ev;
+        unsigned grid;
+        size_t lastValid;
+        bool lastMore;                  // the last reported step left a channel with samples it could not record
+        bool sigs;                      // the launch keeps signal records
+    } res;
 };
 static Pipe &pipeOf(lorahip_demod *dm) { return *static_cast<Pipe *>(dm->pipe); }
-static bool pipeBusy(const lorahip_demod *dm) { return dm->pipe != nullptr && static_cast<const Pipe *>(dm->pipe)->active; }
+static bool pipeBusy(const lorahip_demod *dm)
+{
+    return dm->pipe != nullptr && (static_cast<const Pipe *>(dm->pipe)->active || static_cast<const Pipe *>(dm->pipe)->res.active);
+}
 
 //! per-launch record capacity (work() calls per channel) for streams of at most maxLen samples: see runStream
 static void streamCapacity(const lorahip_demod *dm, const size_t maxLen, size_t &cap, size_t &capPkt)
@@ -1259,6 +1281,244 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     { const int rc = pipeRead(dm, set ^ 1); if (rc != LORAHIP_OK) return rc; }
     const bool shortStep = (nValid - prevValid) <= 48 * N;    // (the step launched above)
     return pipeDeliverHeld(dm, set ^ 1, 1, rows, nPackets, calls, shortStep);
+}
+
+/***********************************************************************
+ * The resident receiver: the host side. A step is a message copied into the ring in device memory (the doorbell) and, one call later,
+ * two words read from pinned memory. Packets and signals are written by the kernel itself into the rows that came WITH the step's
+ * message, i.e. with the call that rang it; they are complete when the next call (or the flush) returns.
+ **********************************************************************/
+static const double kResidentTimeoutS = 5.0;                // host: longest wait for a step's report
+static const unsigned long long kResidentWatchdog = 800000000ull;   // device: 8 s of 100 MHz ticks without a message, then the wavefront leaves
+
+static int residentRing(lorahip_demod *dm, const size_t nValid, const lorahip_packet_rows *rows, const unsigned flags)
+{
+    Pipe::Resident &R = pipeOf(dm).res;
+    const unsigned seq = R.seq + 1;
+    ResidentMsg &m = R.hMsg[seq & 7];
+    std::memset(&m, 0, sizeof(m));
+    m.nValid = nValid;
+    if (rows)
+    {
+        m.syms = rows->syms_dev; m.nsyms = rows->nsyms_dev; m.chan = rows->channel_dev;
+        m.symStride = unsigned(rows->sym_stride); m.capRows = unsigned(rows->cap_packets > 0xffffffu ? 0xffffffu : rows->cap_packets);
+    }
+    if (R.sigs && dm->sigRowsOn)
+    {
+        m.sigCh = dm->sigRows.channel; m.sigErr = dm->sigRows.error; m.sigPow = dm->sigRows.power; m.sigSnr = dm->sigRows.snr;
+        m.capSig = unsigned(dm->sigRows.cap > 0xffffffu ? 0xffffffu : dm->sigRows.cap);
+    }
+    m.flags = flags;
+    m.seq = seq;
+    m.check = residentCheck(m);
+    LORAHIP_TRY(hipMemcpyAsync(&R.ctl->msg[seq & 7], &m, sizeof(m), hipMemcpyHostToDevice, R.bell));
+    R.seq = seq;
+    return LORAHIP_OK;
+}
+
+//! wait for step `k`'s report (bounded); *packets / *signals = what the step produced (dropped ones included), *flags = RES_F_*
+static int residentReport(lorahip_demod *dm, const unsigned k, size_t *packets, size_t *signals, int64_t *calls, unsigned *flags)
+{
+    Pipe::Resident &R = pipeOf(dm).res;
+    volatile unsigned long long *h = R.hSum + 2 * (k & 3);
+    typedef std::chrono::steady_clock Clock;
+    const Clock::time_point t0 = Clock::now();
+    unsigned spins = 0;
+    for (;;)
+    {
+        const unsigned long long w0 = __atomic_load_n(const_cast<unsigned long long *>(h), __ATOMIC_ACQUIRE);
+        const unsigned long long w1 = __atomic_load_n(const_cast<unsigned long long *>(h + 1), __ATOMIC_ACQUIRE);
+        if (unsigned(w0 >> 32) == k && unsigned(w1 >> 56) == (k & 0xffu))
+        {
+            *calls = int64_t(w0 & 0xffffffffull);
+            *packets = size_t(w1 & 0xffffffull);
+            *signals = size_t((w1 >> 24) & 0xffffffull);
+            *flags = unsigned((w1 >> 48) & 0xffull);
+            return LORAHIP_OK;
+        }
+        if ((++spins & 1023u) == 0 && std::chrono::duration<double>(Clock::now() - t0).count() > kResidentTimeoutS) break;
+    }
+    setLastError("lorahip_demod_receive (resident): no report for a step within 5 s -- the kernel is told to leave");
+    return LORAHIP_E_HIP;
+}
+
+//! get the kernel off the device whatever state the steps are in (error paths, destroy)
+static void residentAbort(lorahip_demod *dm)
+{
+    Pipe::Resident &R = pipeOf(dm).res;
+    if (!R.active) return;
+    const unsigned one = 1;
+    (void)hipMemcpyAsync(&R.ctl->abort, &one, sizeof(one), hipMemcpyHostToDevice, R.bell);
+    (void)hipStreamSynchronize(R.bell);
+    (void)hipStreamSynchronize(R.run);
+    R.active = false; R.unavailable = true;
+    dm->devStateFresh = false;                        // the steps' bookkeeping is incomplete: nothing on the device is trusted
+}
+
+static int residentFlush(lorahip_demod *dm, size_t *nPackets, int64_t *calls)
+{
+    Pipe::Resident &R = pipeOf(dm).res;
+    if (nPackets) *nPackets = 0;
+    if (calls) *calls = 0;
+    dm->lastSignals = 0;
+    if (!R.active) return LORAHIP_OK;
+    const DeviceGuard guard(dm->ctx->device);
+    size_t pk = 0, sg = 0;
+    int64_t cl = 0;
+    unsigned fl = 0;
+    bool lost = false;
+    while (R.reported < R.seq)
+    {
+        size_t p1 = 0, s1 = 0; int64_t c1 = 0;
+        const int rc = residentReport(dm, R.reported + 1, &p1, &s1, &c1, &fl);
+        if (rc != LORAHIP_OK) { residentAbort(dm); return rc; }
+        R.reported++;
+        pk += p1; sg += s1; cl += c1;
+        dm->workCalls += c1;
+        lost = lost || (fl & (RES_F_PKT_OVERFLOW | RES_F_SIG_OVERFLOW));
+        R.lastMore = (fl & RES_F_MORE) != 0;
+    }
+    // the quit message, then the kernel's end: the state, the read positions and the open packets are on the device as a streaming run leaves them
+    { const int rc = residentRing(dm, R.lastValid, nullptr, 1u); if (rc != LORAHIP_OK) { residentAbort(dm); return rc; } }
+    LORAHIP_TRY(hipStreamSynchronize(R.bell));
+    LORAHIP_TRY(hipStreamSynchronize(R.run));
+    R.active = false;
+    if (nPackets) *nPackets = pk;
+    if (calls) *calls = cl;
+    dm->lastSignals = dm->sigRowsOn ? sg : 0;
+    dm->kernelMs = 0.0;
+    dm->devStateFresh = true; dm->posOnDevice = true; dm->mirrorsStale = true; dm->headStale = true;
+    dm->devCarryValid = true; dm->hostCarryStale = true;
+    pendingOf(dm).valid = false;
+    std::memset(&dm->lastSum, 0, sizeof(dm->lastSum));
+    dm->lastSum.anyOpen = 1;                          // (not tracked per step: the carry rows are valid, which is all `anyOpen` guards)
+    dm->lastSum.more = R.lastMore ? 1 : 0;
+    {
+        // the kernels' running near-threshold counters
+        const StreamLayout H = headLayout(dm);
+        unsigned near[2] = {0, 0};
+        LORAHIP_TRY(hipMemcpy(near, dm->sDev + H.oNear, sizeof(near), hipMemcpyDeviceToHost));
+        dm->nNearSquelch += int64_t(unsigned(near[0] - dm->nearSeen[0])); dm->nNearStep += int64_t(unsigned(near[1] - dm->nearSeen[1]));
+        dm->nearSeen[0] = near[0]; dm->nearSeen[1] = near[1];
+    }
+    if (lost)
+    {
+        setLastError("lorahip_demod_receive (resident): rows too small for a step's packets or signals -- the excess was dropped (counted in *n_packets)");
+        return LORAHIP_E_INVALID;
+    }
+    return LORAHIP_OK;
+}
+
+/*! One step of the resident receiver. handled = false: the resident mode is not in place (yet) or not to be had for this object -- the
+ * caller takes an ordinary step. *nPackets / *calls / lastSignals are those of the PREVIOUS step (0 for the first), whose rows -- the
+ * ones that came with the previous call -- are complete now. */
+static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowStride, const size_t nValid, const lorahip_packet_rows *rows, size_t *nPackets,
+                        int64_t *calls, bool &handled)
+{
+    handled = false;
+    Pipe &P = pipeOf(dm);
+    Pipe::Resident &R = P.res;
+    lorahip_ctx *ctx = dm->ctx;
+    const size_t N = dm->N, B = dm->B;
+    const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(ctx->sf));
+    const bool compatible = stream && ctx->sf >= 7 && ctx->sf <= 10 && !dm->tracing && !dm->portsOn && !dm->activatePending && dm->sDev != nullptr &&
+                            dm->append && !dm->appendFresh && dm->uniStride == rowStride && nValid >= dm->appendPrev && dm->dCarry != nullptr &&
+                            dm->mtu + 1 <= dm->carryCap && !P.active && rowsHold(rows, 1);
+    if (R.active && (!compatible || iqDev != P.iq))
+    {
+        setLastError("lorahip_demod_receive (resident): a setting or the rows changed under the resident kernel (lorahip_demod_receive_flush first)");
+        return LORAHIP_E_INVALID;
+    }
+    if (!R.active)
+    {
+        const bool ready = compatible && !R.unavailable && dm->devStateFresh && (dm->devCarryValid || !dm->lastSum.anyOpen) && !pendingOf(dm).valid;
+        if (!ready) return LORAHIP_OK;
+        const DeviceGuard guard(ctx->device);
+        if (R.ctl == nullptr)
+        {
+            LORAHIP_TRY(hipMalloc((void **)&R.ctl, sizeof(ResidentCtl)));
+            LORAHIP_TRY(hipHostMalloc((void **)&R.hMsg, 8 * sizeof(ResidentMsg), hipHostMallocDefault));
+            LORAHIP_TRY(hipHostMalloc((void **)&R.hSum, 8 * sizeof(unsigned long long), hipHostMallocMapped));
+            LORAHIP_TRY(hipStreamCreateWithFlags(&R.run, hipStreamNonBlocking));
+            LORAHIP_TRY(hipStreamCreateWithFlags(&R.bell, hipStreamNonBlocking));
+            LORAHIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
+        }
+        // a step's records: sized for a step as long as this one (a longer one fills them, stops the channel and the next step resumes it)
+        size_t cap, capPkt;
+        streamCapacity(dm, nValid - dm->appendPrev + 2 * N, cap, capPkt);
+        StreamLayout L;
+        L.make(B, cap, capPkt, false, dm->carryCap, dm->wantSignals);
+        if (L.total > R.recBytes)
+        {
+            if (R.rec) { (void)hipFree(R.rec); R.rec = nullptr; R.recBytes = 0; }
+            LORAHIP_TRY(hipMalloc((void **)&R.rec, L.total + L.total / 4));
+            R.recBytes = L.total + L.total / 4;
+        }
+        R.lay = L;
+        R.sigs = dm->wantSignals;
+        void *sumDev = nullptr;
+        LORAHIP_TRY(hipHostGetDevicePointer(&sumDev, R.hSum, 0));
+        std::memset(R.hSum, 0, 8 * sizeof(unsigned long long));
+        LORAHIP_TRY(hipMemsetAsync(R.ctl, 0, sizeof(ResidentCtl), ctx->stream));
+        const StreamLayout H = headLayout(dm);
+        char *d = R.rec;
+        StreamArgs a;
+        a.iq = reinterpret_cast<const float2 *>(iqDev);
+        a.base = nullptr; a.len = nullptr;
+        a.uniformLen = 0; a.uniformStride = (long long)rowStride;       // (the length of a step comes with its message)
+        a.flags = 4 | 8;
+        a.carry = dm->dCarry; a.carryCap = int(dm->carryCap); a.maxBlocks = 0; a.lanes = -1; a.lastRoundFrom = 0;
+        a.state = reinterpret_cast<StreamState *>(dm->sDev + H.oState);
+        a.nCalls = reinterpret_cast<int *>(d + L.oN); a.nSym = reinterpret_cast<int *>(d + L.oNSym); a.nPkt = reinterpret_cast<int *>(d + L.oNPkt);
+        a.nSig = reinterpret_cast<int *>(d + L.oNSig); a.end = reinterpret_cast<int2 *>(d + L.oEnd);
+        a.pktOut = reinterpret_cast<StreamPacket *>(d + L.oPkt); a.symOut = reinterpret_cast<short *>(d + L.oSym);
+        a.sigOut = dm->wantSignals ? reinterpret_cast<StreamSignal *>(d + L.oSig) : nullptr; a.calls = nullptr;
+        a.down = ctx->dDown; a.fine = ctx->dFine; a.twStage = ctx->dTwStage;
+        a.fineA = ctx->fineGather ? nullptr : ctx->dFineA; a.fineB = ctx->fineGather ? nullptr : ctx->dFineB;
+        a.nChannels = unsigned(B); a.cap = int(cap); a.symStride = int(L.symStride); a.capPkt = int(capPkt);
+        a.powerScale = ctx->powerScale; a.thresh = dm->thresh; a.sync = dm->sync;
+        a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
+        a.near = reinterpret_cast<unsigned *>(dm->sDev + H.oNear);
+        a.res = R.ctl; a.resSum = static_cast<unsigned long long *>(sumDev); a.resWatchdog = kResidentWatchdog;
+        // behind everything queued on the launch stream (the state of the run before, the cleared control block)
+        LORAHIP_TRY(hipEventRecord(R.ev, ctx->stream));
+        LORAHIP_TRY(hipStreamWaitEvent(R.run, R.ev, 0));
+        LORAHIP_TRY(hipStreamWaitEvent(R.bell, R.ev, 0));
+        const hipError_t le = launchStreamResident(ctx->sf, a, R.run, &R.grid);
+        if (le == hipErrorNotSupported) { (void)hipGetLastError(); R.unavailable = true; return LORAHIP_OK; }     // not for this geometry: ordinary steps
+        LORAHIP_TRY(le);
+        R.active = true; R.seq = 0; R.reported = 0; R.lastMore = false;
+        P.iq = iqDev; P.rowStride = rowStride;
+        dm->devStateFresh = false;                    // until the kernel has left, only it knows where the state stands
+    }
+    handled = true;
+    if (nPackets) *nPackets = 0;
+    if (calls) *calls = 0;
+    dm->lastSignals = 0;
+    const DeviceGuard guard(ctx->device);
+    { const int rc = residentRing(dm, nValid, rows, 0u); if (rc != LORAHIP_OK) { residentAbort(dm); return rc; } }
+    R.lastValid = nValid;
+    dm->uniform = true; dm->uniSpc = nValid; dm->uniStride = rowStride; dm->appendPrev = nValid; dm->geomApplied = false;
+    dm->mirrorsStale = true; dm->headStale = true;
+    if (R.seq < 2) return LORAHIP_OK;
+    // ... and while it runs: the step before
+    size_t pk = 0, sg = 0;
+    int64_t cl = 0;
+    unsigned fl = 0;
+    const int rc = residentReport(dm, R.seq - 1, &pk, &sg, &cl, &fl);
+    if (rc != LORAHIP_OK) { residentAbort(dm); return rc; }
+    R.reported = R.seq - 1;
+    R.lastMore = (fl & RES_F_MORE) != 0;
+    dm->workCalls += cl;
+    if (nPackets) *nPackets = pk;
+    if (calls) *calls = cl;
+    dm->lastSignals = dm->sigRowsOn ? sg : 0;
+    if (fl & (RES_F_PKT_OVERFLOW | RES_F_SIG_OVERFLOW))
+    {
+        setLastError("lorahip_demod_receive (resident): the rows of the call before were too small for its step -- the excess was dropped (counted in *n_packets)");
+        return LORAHIP_E_INVALID;
+    }
+    return LORAHIP_OK;
 }
 
 /***********************************************************************
@@ -1577,6 +1837,14 @@ void lorahip_demod_destroy(lorahip_demod *dm)
     if (dm->pipe)
     {
         Pipe &P = pipeOf(dm);
+        residentAbort(dm);                                        // (a resident kernel must leave before its memory goes)
+        if (P.res.ctl) (void)hipFree(P.res.ctl);
+        if (P.res.hMsg) (void)hipHostFree(P.res.hMsg);
+        if (P.res.hSum) (void)hipHostFree(P.res.hSum);
+        if (P.res.rec) (void)hipFree(P.res.rec);
+        if (P.res.run) (void)hipStreamDestroy(P.res.run);
+        if (P.res.bell) (void)hipStreamDestroy(P.res.bell);
+        if (P.res.ev) (void)hipEventDestroy(P.res.ev);
         for (int i = 0; i < 2; i++)
         {
             if (P.dev[i]) (void)hipFree(P.dev[i]);
@@ -2105,6 +2373,11 @@ int lorahip_demod_receive_signal_rows(lorahip_demod *dm, const lorahip_signal_ro
 
 size_t lorahip_demod_receive_num_signals(const lorahip_demod *dm) { return dm && !dm->comp ? dm->lastSignals : 0; }
 
+int lorahip_demod_resident_active(const lorahip_demod *dm)
+{
+    return dm && !dm->comp && dm->pipe && static_cast<const Pipe *>(dm->pipe)->res.active ? 1 : 0;
+}
+
 int lorahip_demod_receive(lorahip_demod *dm, const float *iq_dev, const size_t row_stride, const size_t n_valid, const lorahip_packet_rows *rows,
                           size_t *n_packets, int64_t *work_calls)
 {
@@ -2112,12 +2385,22 @@ int lorahip_demod_receive(lorahip_demod *dm, const float *iq_dev, const size_t r
     if (n_packets) *n_packets = 0;
     if (work_calls) *work_calls = 0;
     if (dm->comp) { setLastError("append runs are per part: lorahip_demod_part_handle"); return LORAHIP_E_INVALID; }
-    if (rows->async == 2)
+    if (rows->async == 2 || rows->async == 3)
     {
         if (n_valid > row_stride || (n_valid && iq_dev == nullptr)) return LORAHIP_E_INVALID;
         bool handled = false;
-        const int prc = pipeStep(dm, iq_dev, row_stride, n_valid, rows, n_packets, work_calls, handled);
-        if (handled || prc != LORAHIP_OK) return prc;
+        if (rows->async == 3)
+        {
+            if (pipeOf(dm).active) { setLastError("a pipelined step is in flight: lorahip_demod_receive_flush first"); return LORAHIP_E_INVALID; }
+            const int prc = residentStep(dm, iq_dev, row_stride, n_valid, rows, n_packets, work_calls, handled);
+            if (handled || prc != LORAHIP_OK) return prc;
+        }
+        else
+        {
+            if (pipeOf(dm).res.active) { setLastError("the resident kernel is on the device: lorahip_demod_receive_flush first"); return LORAHIP_E_INVALID; }
+            const int prc = pipeStep(dm, iq_dev, row_stride, n_valid, rows, n_packets, work_calls, handled);
+            if (handled || prc != LORAHIP_OK) return prc;
+        }
         // not in place yet (first step, or something else touched the object): an ordinary step, its packets delivered at once
     }
     else { const int frc = refuseWhilePiped(dm); if (frc != LORAHIP_OK) return frc; }
@@ -2142,6 +2425,28 @@ int lorahip_demod_receive_flush(lorahip_demod *dm, const lorahip_packet_rows *ro
     if (n_packets) *n_packets = 0;
     if (work_calls) *work_calls = 0;
     if (dm->comp) return LORAHIP_OK;
+    if (pipeOf(dm).res.active)
+    {
+        // the resident receiver: every step's rows came with its own call; what is left to report are the counts of the last step(s)
+        size_t n0 = 0; int64_t c0 = 0;
+        int rc0 = residentFlush(dm, &n0, &c0);
+        if (n_packets) *n_packets = n0;
+        if (work_calls) *work_calls = c0;
+        if (rc0 != LORAHIP_OK || dm->lastSum.more == 0) return rc0;
+        // a channel still holds samples its last step could not record: an ordinary step over the same rows takes them (as below)
+        const Pipe &P0 = pipeOf(dm);
+        const int64_t calls0 = dm->workCalls;
+        rc0 = lorahip_demod_run_device_append(dm, P0.iq, P0.rowStride, dm->appendPrev, nullptr);
+        if (rc0 != LORAHIP_OK) return rc0;
+        if (work_calls) *work_calls = c0 + (dm->workCalls - calls0);
+        if (rows == nullptr) { lorahip_demod_clear_packets(dm); return LORAHIP_OK; }
+        size_t n2 = 0;
+        rc0 = packetsToDevice(dm, rows->syms_dev, rows->sym_stride, rows->nsyms_dev, rows->channel_dev, rows->cap_packets, &n2, true);
+        if (n_packets) *n_packets = n0 + n2;                  // (n0 of them in the rows of the call before, n2 in these)
+        if (rc0 != LORAHIP_OK) return rc0;
+        lorahip_demod_clear_packets(dm);
+        return LORAHIP_OK;
+    }
     const bool wasPiped = pipeBusy(dm);
     size_t n1 = 0;
     int64_t c1 = 0;

@@ -105,6 +105,45 @@ struct StreamPacket { int callIndex; int len; };
 //! kept only when the caller asked for signals (lorahip_demod_set_signals) -- a receiver without a per-call trace still gets them
 struct StreamSignal { int callIndex; int error; float power; float snr; };
 
+/*! The RESIDENT receiver (lorahip_demod_receive with async = 3; lorahip_streamkernel.h, RES): one launch stays on the device across the
+ * receiver's steps. The host describes a step in a ResidentMsg (copied into the ring in device memory: the "doorbell"), the wavefronts
+ * poll for it, work through what arrived, the last wavefront of every workgroup packs the workgroup's packets / signals into the step's
+ * rows, and the last workgroup of the step reports two words to pinned host memory. No launch, no helper kernel, no API call but the
+ * doorbell's copy per step. */
+struct ResidentMsg
+{
+    unsigned long long nValid;          // samples per channel that are valid now
+    unsigned short *syms; int *nsyms; int *chan;            // this step's packet rows (lorahip_packet_rows)
+    int *sigCh; int *sigErr; float *sigPow; float *sigSnr;  // ... and signal rows (null: signals are not kept)
+    unsigned symStride, capRows, capSig;
+    unsigned flags;                     // bit 0: leave the kernel (no samples with this message)
+    unsigned check;                     // residentCheck() of the fields above and seq: a torn copy is not taken for a message
+    unsigned seq;                       // the step's number (1, 2, ...): written last in the struct
+};
+__host__ __device__ inline unsigned residentCheck(const ResidentMsg &m)
+{
+    unsigned long long h = m.nValid ^ (unsigned long long)(size_t)m.syms ^ ((unsigned long long)(size_t)m.nsyms << 1) ^ ((unsigned long long)(size_t)m.chan << 2) ^
+                           ((unsigned long long)(size_t)m.sigCh << 3) ^ ((unsigned long long)(size_t)m.sigErr << 4) ^ ((unsigned long long)(size_t)m.sigPow << 5) ^
+                           ((unsigned long long)(size_t)m.sigSnr << 6);
+    h ^= (unsigned long long)m.symStride * 0x9E3779B97F4A7C15ull + m.capRows * 0xC2B2AE3D27D4EB4Full + m.capSig * 0x165667B19E3779F9ull + m.flags;
+    return unsigned(h ^ (h >> 32)) ^ (m.seq * 0x85EBCA6Bu) ^ 0x5A5A5A5Au;
+}
+//! device memory shared by the workgroups of a resident launch; the per-step counters exist four times (step & 3): the host never has
+//! more than two steps outstanding, and the last workgroup of step k clears the set of step k + 2
+struct ResidentCtl
+{
+    ResidentMsg msg[8];                 // ring, slot = seq & 7
+    unsigned long long doneCalls[4];    // [63:48] workgroups that finished the step, [47:0] work() calls they made
+    unsigned rowCount[4], sigCount[4];  // rows handed out (may exceed the capacity: the excess was dropped and is reported)
+    unsigned more[4];                   // some channel stopped because a record buffer was full
+    unsigned abort;                     // host: leave now (set before the quit message when a step timed out)
+    unsigned expired;                   // a wavefront gave up waiting for a message (watchdog)
+};
+//! what the last workgroup of a step writes to pinned host memory: two 64-bit words, each carrying (part of) the step number
+//!   w0 = seq << 32 | calls (32 bits)      w1 = (seq & 0xff) << 56 | flags << 48 | signals (24 bits) << 24 | packets (24 bits)
+//!   flags: 1 packets dropped (rows too small), 2 signals dropped, 4 more, 8 expired
+enum { RES_F_PKT_OVERFLOW = 1, RES_F_SIG_OVERFLOW = 2, RES_F_MORE = 4, RES_F_EXPIRED = 8 };
+
 //! argument block of the streaming demod kernel (lorahip_stream.hip); all pointers are device pointers
 struct StreamArgs
 {
@@ -148,6 +187,10 @@ struct StreamArgs
     unsigned lastRoundFrom;     // set by the launcher: workgroups from this blockIdx on are not followed by another one in their slot (lorahip_device.h::rotatePriority)
     unsigned *near;             // [2] decisions float rounding could flip (lorahip_demod_near_threshold): squelch margins, fine-tune steps.
                                 //     Running counters: the kernels only add, the host takes differences
+    // the resident receiver (RES instances only)
+    ResidentCtl *res = nullptr;
+    unsigned long long *resSum = nullptr;      // [4][2] pinned host memory as the device addresses it: the steps' reports
+    unsigned long long resWatchdog = 0;        // 100 MHz ticks a wavefront waits for a message before it gives up
 };
 
 //! what the host needs to know after a streaming launch -- reduced on the device (streamSummary), so that 72 bytes cross PCIe per run
@@ -197,6 +240,9 @@ hipError_t launchWide(int sf, int variant, const DetectArgs &a, const FastTables
 bool streamAvailable(int sf);
 hipError_t launchStream(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchStreamWide(int sf, const StreamArgs &s, hipStream_t stream);
+//! the resident receiver's launch (SF7-10, the 16-points-per-lane geometries): hipErrorNotSupported when there is no such instance or
+//! the grid would not be resident all at once; *grid = workgroups launched
+hipError_t launchStreamResident(int sf, const StreamArgs &s, hipStream_t stream, unsigned *grid);
 bool streamLanesAvailable(int sf, int log2Lanes);
 int streamLanesChosen(int sf, unsigned nChannels, int forced);
 hipError_t launchStreamLanes(int sf, int log2Lanes, const StreamArgs &s, hipStream_t stream);

@@ -23,13 +23,202 @@
 #endif
 namespace lorahip {
 
+/***********************************************************************
+ * The resident receiver (RES instances of demodStream; ResidentMsg / ResidentCtl in lorahip_internal.h)
+ **********************************************************************/
+template <class V> __device__ __forceinline__ void sysStore(V *p, const V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <class V> __device__ __forceinline__ V sysLoad(const V *p) { return __hip_atomic_load(const_cast<V *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <class V> __device__ __forceinline__ V agentLoad(const V *p) { return __hip_atomic_load(const_cast<V *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+//! a step's message as the wavefront holds it (wave-uniform: scalar registers)
+struct ResMsgR
+{
+    unsigned long long nValid;
+    unsigned short *syms; int *nsyms, *chan, *sigCh, *sigErr; float *sigPow, *sigSnr;
+    unsigned symStride, capRows, capSig, flags;
+};
+
+//! the counts the wavefronts of a workgroup leave for the one that arrives last at the end of a step (by step parity: a fast
+//! wavefront may be one step ahead of a slow one, never two -- the host rings step k + 2 only after step k has been reported)
+template <int CH>
+struct ResLds { int nPkt[2][CH], nSig[2][CH]; int calls[2], arrive[2], more[2]; };
+
+__device__ __forceinline__ unsigned long long uni64(const unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+/*! Wait for the message of step `want`. Every wavefront polls for itself (the wavefronts of a workgroup are independent in the loop):
+ * the ring lives in device memory -- the host's doorbell is a small copy into it --, read at system scope, i.e. from memory, so a poll
+ * costs a memory round trip and no PCIe traffic; between polls the wavefront sleeps. A message counts only when its check word fits
+ * its fields (the copy that delivers it is not atomic). false: leave the kernel (quit message, abort flag, or nothing for
+ * s.resWatchdog ticks: every spin is bounded). After a message the wavefront's view of memory is made fresh (agent-scope acquire:
+ * the samples that arrived since the last step must not be served from stale L1 / L2 lines). */
+__device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned want, ResMsgR &m)
+{
+    const ResidentMsg *g = &s.res->msg[want & 7];
+    const unsigned long long t0 = wall_clock64();
+    for (;;)
+    {
+        if (sysLoad(&g->seq) == want)
+        {
+            ResidentMsg c;
+            c.nValid = sysLoad(&g->nValid);
+            c.syms = reinterpret_cast<unsigned short *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->syms)));
+            c.nsyms = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->nsyms)));
+            c.chan = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->chan)));
+            c.sigCh = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigCh)));
+            c.sigErr = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigErr)));
+            c.sigPow = reinterpret_cast<float *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigPow)));
+            c.sigSnr = reinterpret_cast<float *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigSnr)));
+            c.symStride = sysLoad(&g->symStride); c.capRows = sysLoad(&g->capRows); c.capSig = sysLoad(&g->capSig); c.flags = sysLoad(&g->flags);
+            c.seq = want;
+            if (sysLoad(&g->check) == residentCheck(c))
+            {
+                m.nValid = uni64(c.nValid);
+                m.syms = reinterpret_cast<unsigned short *>(uni64((unsigned long long)(size_t)c.syms));
+                m.nsyms = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.nsyms));
+                m.chan = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.chan));
+                m.sigCh = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.sigCh));
+                m.sigErr = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.sigErr));
+                m.sigPow = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)c.sigPow));
+                m.sigSnr = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)c.sigSnr));
+                m.symStride = (unsigned)__builtin_amdgcn_readfirstlane((int)c.symStride); m.capRows = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capRows);
+                m.capSig = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capSig); m.flags = (unsigned)__builtin_amdgcn_readfirstlane((int)c.flags);
+                break;
+            }
+        }
+        if (sysLoad(&s.res->abort) != 0u) return false;
+        if (wall_clock64() - t0 > s.resWatchdog) { sysStore(&s.res->expired, 1u); return false; }
+        __builtin_amdgcn_s_sleep(24);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return (m.flags & 1u) == 0u;
+}
+
+/*! The end of a receiver step for one wavefront. It leaves its channels' counts in the workgroup's slot; the wavefront that arrives LAST
+ * (an LDS counter, no barrier: the others go straight back to polling) takes the rows for all the workgroup's packets and signals with
+ * ONE device-wide atomic each, packs them -- records read at agent scope (they were written through this CU's L1 into L2), rows
+ * written at system scope (through to memory: the consumer is another kernel, a copy engine or the host; no cache has to be written back
+ * for them) -- waits for those stores, and adds the workgroup to the step's count. The workgroup that completes the count reports the
+ * step to the host's pinned memory. Rows are handed out in the order the workgroups finish: a channel's packets of a step are
+ * consecutive and in time order, the channels are not sorted (channel_dev says whose a row is). */
+template <class C>
+__device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMsgR &m, const unsigned step, ResLds<4 * C::WPW> *sR, const StreamOut &o, const bool mine,
+                                                const bool stopped, const int lane, const int wave, const int wsub, const int t)
+{
+    constexpr int WAVES = 4, WPW = C::WPW, CH = WAVES * WPW;
+    static_assert(CH <= 64, "one lane per channel of the workgroup in the scan");
+    const int par = int(step & 1u);
+    const unsigned slot = step & 3u;
+    if (t == 0)
+    {
+        sR->nPkt[par][wave * WPW + wsub] = mine ? o.nPkt : 0;
+        sR->nSig[par][wave * WPW + wsub] = (mine && o.sigOut) ? o.nSig : 0;
+    }
+    int calls = (mine && t == 0) ? o.calls : 0;
+    for (int d = 32; d >= 1; d >>= 1) calls += __shfl_xor(calls, d);
+    const bool anyStopped = __any(stopped);
+    if (lane == 0)
+    {
+        if (calls) atomicAdd(&sR->calls[par], calls);
+        if (anyStopped) sR->more[par] = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the records (through L1 into L2) and the counts before the arrival
+    int arrived = 0;
+    if (lane == 0) arrived = __hip_atomic_fetch_add(&sR->arrive[par], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_readfirstlane(arrived) != WAVES - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    const unsigned first = blockIdx.x * unsigned(CH);               // the workgroup's first channel
+    const int np = lane < CH ? sR->nPkt[par][lane] : 0, ns = lane < CH ? sR->nSig[par][lane] : 0;
+    int ip = np, is = ns;
+    for (int d = 1; d < 64; d <<= 1) { const int a = __shfl_up(ip, d), b = __shfl_up(is, d); if (lane >= d) { ip += a; is += b; } }
+    const int totP = __shfl(ip, 63), totS = __shfl(is, 63);
+    unsigned row0 = 0, sig0 = 0;
+    if (lane == 0)
+    {
+        if (totP) row0 = atomicAdd(&s.res->rowCount[slot], unsigned(totP));
+        if (totS) sig0 = atomicAdd(&s.res->sigCount[slot], unsigned(totS));
+    }
+    row0 = (unsigned)__builtin_amdgcn_readfirstlane((int)row0); sig0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sig0);
+    if (totP)
+        for (int ch = 0; ch < CH; ch++)
+        {
+            const int n = __shfl(np, ch);
+            if (n == 0) continue;
+            const unsigned g = first + unsigned(ch);
+            const StreamPacket *pk = s.pktOut + (size_t)g * s.capPkt;
+            const short *sy = s.symOut + (size_t)g * s.symStride;
+            unsigned r = row0 + unsigned(__shfl(ip, ch) - n);
+            int off = 0;
+            for (int j = 0; j < n; j++, r++)
+            {
+                const int ln = agentLoad(&pk[j].len);
+                if (r < m.capRows)
+                {
+                    const int keep = ln < int(m.symStride) ? ln : int(m.symStride);
+                    unsigned short *dst = m.syms + (size_t)r * m.symStride;
+                    for (int i = lane; i < int(m.symStride); i += 64) sysStore(dst + i, i < keep ? (unsigned short)agentLoad(sy + off + i) : (unsigned short)0);
+                    if (lane == 0) { sysStore(m.nsyms + r, ln); if (m.chan) sysStore(m.chan + r, int(g)); }      // (the true length, as lorahip_demod_packets_to_device)
+                }
+                off += ln;
+            }
+        }
+    if (totS && lane < CH)
+    {
+        const unsigned g = first + unsigned(lane);
+        const StreamSignal *sg = s.sigOut + (size_t)g * s.capPkt;
+        unsigned r = sig0 + unsigned(is - ns);
+        for (int j = 0; j < ns; j++, r++)
+            if (r < m.capSig)
+            {
+                if (m.sigCh) sysStore(m.sigCh + r, int(g));
+                if (m.sigErr) sysStore(m.sigErr + r, agentLoad(&sg[j].error));
+                if (m.sigPow) sysStore(m.sigPow + r, agentLoad(&sg[j].power));
+                if (m.sigSnr) sysStore(m.sigSnr + r, agentLoad(&sg[j].snr));
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the rows are in memory before the workgroup counts as done
+    if (lane == 0)
+    {
+        const unsigned wgCalls = unsigned(sR->calls[par]), wgMore = sR->more[par] ? 1u : 0u;
+        sR->calls[par] = 0; sR->more[par] = 0; sR->arrive[par] = 0;                     // for step + 2
+        // [63:48] workgroups done, [47:36] of them with a channel that stopped for capacity, [35:0] work() calls
+        const unsigned long long add = (1ull << 48) | ((unsigned long long)wgMore << 36) | (unsigned long long)wgCalls;
+        const unsigned long long prev = atomicAdd(&s.res->doneCalls[slot], add);
+        if ((prev >> 48) + 1ull == (unsigned long long)gridDim.x)
+        {
+            const unsigned long long tot = prev + add;
+            const unsigned pkAll = agentLoad(&s.res->rowCount[slot]), sgAll = agentLoad(&s.res->sigCount[slot]);
+            unsigned flags = (pkAll > m.capRows ? unsigned(RES_F_PKT_OVERFLOW) : 0u) | ((m.capSig != 0u && sgAll > m.capSig) ? unsigned(RES_F_SIG_OVERFLOW) : 0u) |
+                             (((tot >> 36) & 0xfffull) ? unsigned(RES_F_MORE) : 0u);
+            // the counters of step + 2: nobody is there yet (the host rings it only after it has seen this report)
+            const unsigned nx = (step + 2u) & 3u;
+            sysStore(&s.res->doneCalls[nx], 0ull); sysStore(&s.res->rowCount[nx], 0u); sysStore(&s.res->sigCount[nx], 0u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long *h = s.resSum + 2 * slot;
+            const unsigned long long w1 = ((unsigned long long)(step & 0xffu) << 56) | ((unsigned long long)flags << 48) | ((unsigned long long)(sgAll & 0xffffffu) << 24) |
+                                          (unsigned long long)(pkAll & 0xffffffu);
+            const unsigned long long w0 = ((unsigned long long)step << 32) | (tot & 0xffffffffull);
+            sysStore(h + 1, w1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sysStore(h, w0);
+        }
+    }
+}
+
 //! PERSIST: a grid of at most s.maxBlocks workgroups, each looping over channel sets -- for launches over more channels than are
 //! resident at once. The loop costs registers (96 / 112 B of scratch at SF7 / SF9 against 20 / 28), so a launch that fits the
 //! device takes the instance without it (one workgroup per channel set).
-template <class C, bool PERSIST>
+//! RES: the resident receiver -- the launch stays, the steps arrive as messages (residentWait / residentStepEnd above). One workgroup
+//! per channel set, all of them resident at once (the launcher checks); s.flags carries the carry bits only.
+template <class C, bool PERSIST, bool RES = false>
 __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD)
 demodStream(const StreamArgs s)
 {
+    static_assert(!(RES && PERSIST), "the resident receiver has one workgroup per channel set");
     typedef FastCore<C> K;
     constexpr int N = C::N, T = C::T, VEC = C::VEC, R = C::R, WPW = C::WPW;
     constexpr int LOG2T = C::LOG2T;
@@ -58,6 +247,9 @@ demodStream(const StreamArgs s)
     typename K::TwM twM;
     K::loadTwM(twM, reinterpret_cast<const v2f *>(s.twStage), t);
     const FineLds fl = fineLoadLds<C::LOG2N>(sFine, s.fineA, s.fineB, threadIdx.x, blockDim.x);
+    typedef ResLds<WAVES * WPW> ResL;
+    ResL *sR = reinterpret_cast<ResL *>(reinterpret_cast<char *>(sFine) + FineDims<C::LOG2N>::BYTES);        // RES only (the launcher adds the bytes)
+    if (RES && threadIdx.x < 2) { sR->calls[threadIdx.x] = 0; sR->arrive[threadIdx.x] = 0; sR->more[threadIdx.x] = 0; }
     __syncthreads();
 
     // With one channel per wavefront (T = 64: SF10) everything the frame machine touches is WAVE-UNIFORM; saying so (v_readfirstlane
@@ -82,10 +274,10 @@ demodStream(const StreamArgs s)
     if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
     if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
     const long long base = s.uniformLen >= 0 ? (long long)cc * s.uniformStride : s.base[cc];
-    const long long len = !mine ? 0 : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]);
+    long long len = !mine ? 0 : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]);             // (RES: what the step's message says)
     StreamOut o;
     o.init(s, cc);
-    if (mine) o.carryIn(s, st, cc, t, T);
+    if (!RES && mine) o.carryIn(s, st, cc, t, T);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
     // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
@@ -296,8 +488,20 @@ demodStream(const StreamArgs s)
     int value0 = 0, fineIdxBefore0 = 0;
     float snr0 = 0.0f, fineErrBefore0 = 0.0f;
     const int slot = wavefrontSlot();
-    const bool lastRound = PERSIST || !LORAHIP_PRIO_HOLD || blockIdx.x >= s.lastRoundFrom;
+    const bool lastRound = RES || PERSIST || !LORAHIP_PRIO_HOLD || blockIdx.x >= s.lastRoundFrom;
     holdPriority<LORAHIP_PRIO_ALTERNATE>(!lastRound);
+    unsigned step = 0;                                      // RES: the last receiver step taken
+    ResMsgR rm;
+    for (;;)                                                // RES: one turn per receiver step; otherwise exactly one turn
+    {
+    if constexpr (RES)
+    {
+        if (!residentWait(s, step + 1u, rm)) break;
+        step++;
+        len = mine ? (long long)rm.nValid : 0;
+        o.init(s, cc);
+        if (mine) o.carryIn(s, st, cc, t, T);           // the packet the channel is inside: its symbols so far, from the carry rows
+    }
     while (true)
     {
         if (lastRound) rotatePriority<2, LORAHIP_PRIO_ALTERNATE>(slot);
@@ -354,6 +558,9 @@ demodStream(const StreamArgs s)
                tsec[0], tsec[1], tsec[2], tsec[3], tsec[6], tsec[7], tsec[4], 0ull, tsec[8], tsec[5], o.calls);
 #endif
     o.carryOut(s, st, cc, t, T, mine);
+    if constexpr (!RES) break;
+    else residentStepEnd<C>(s, rm, step, sR, o, mine, mine && len - st.pos >= 2 * N, lane, wave, wsub, t);     // (stopped with samples left: a record buffer was full)
+    }
     if (mine && t == 0)
     {
         s.state[c] = st;
@@ -392,6 +599,27 @@ static hipError_t launchStreamCfg(const StreamArgs &args, hipStream_t stream)
     if (e != hipSuccess) return e;
     s.lastRoundFrom = lastRoundFrom(grid, residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStream<C, false>), WAVES * 64, smem));
     hipLaunchKernelGGL((demodStream<C, false>), dim3(grid), dim3(WAVES * 64), smem, stream, s);
+    return hipGetLastError();
+}
+
+//! the resident receiver's launch: refused (hipErrorNotSupported) unless every workgroup is resident at once -- a workgroup that had to
+//! wait for a slot would wait for ever, the others never leave
+template <class C>
+static hipError_t launchStreamResidentCfg(const StreamArgs &args, hipStream_t stream, unsigned *gridOut)
+{
+    constexpr int WAVES = 4;
+    const size_t smem = size_t(C::TWN + C::N) * sizeof(float2) + size_t(WAVES) * C::XW * sizeof(float2) + FineDims<C::LOG2N>::BYTES + sizeof(ResLds<WAVES * C::WPW>);
+    static unsigned long long attrDone = 0;
+    static PerDeviceCount resident;
+    const unsigned perBlock = WAVES * C::WPW;
+    const unsigned grid = (args.nChannels + perBlock - 1) / perBlock;
+    if (gridOut) *gridOut = grid;
+    if (grid == 0 || grid > 4095u) return hipErrorNotSupported;
+    const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, false, true>), smem, attrDone);
+    if (e != hipSuccess) return e;
+    const int res = residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStream<C, false, true>), WAVES * 64, smem);
+    if (res <= 0 || grid > unsigned(res)) return hipErrorNotSupported;
+    hipLaunchKernelGGL((demodStream<C, false, true>), dim3(grid), dim3(WAVES * 64), smem, stream, args);
     return hipGetLastError();
 }
 

@@ -241,16 +241,23 @@ public:
         _pkCh.resize(nPackets); _pkLen.resize(nPackets); _pkSyms.resize(nSyms);
         if (nPackets && lorahip_demod_get_packets(_d, _pkCh.data(), nullptr, _pkLen.data(), nPackets, _pkSyms.data(), nSyms) != LORAHIP_OK)
             throw Pothos::Exception("LoRaDemodBatch::work()", lorahip_last_error());
-        size_t at = 0;
-        for (size_t i = 0; i < nPackets; i++)
+        // ONE buffer for all packets of this work(), every payload a view into it (a BufferChunk is a view with shared ownership: the
+        // buffer lives as long as any of the messages) -- not an allocation per packet, of which a work() posts tens of thousands
+        if (nPackets)
         {
-            const size_t len = size_t(_pkLen[i]);
-            Pothos::Packet pkt;
-            pkt.payload = Pothos::BufferChunk(typeid(int16_t), len ? len : 1);
-            pkt.payload.length = len * sizeof(int16_t);
-            if (len) std::memcpy(pkt.payload.template as<int16_t *>(), _pkSyms.data() + at, len * sizeof(int16_t));
-            at += len;
-            _msg[size_t(_pkCh[i])]->postMessage(pkt);
+            Pothos::BufferChunk all(typeid(int16_t), nSyms ? nSyms : 1);
+            if (nSyms) std::memcpy(all.template as<int16_t *>(), _pkSyms.data(), nSyms * sizeof(int16_t));
+            size_t at = 0;
+            for (size_t i = 0; i < nPackets; i++)
+            {
+                const size_t len = size_t(_pkLen[i]);
+                Pothos::Packet pkt;
+                pkt.payload = all;
+                pkt.payload.address = all.address + at * sizeof(int16_t);
+                pkt.payload.length = len * sizeof(int16_t);
+                at += len;
+                _msg[size_t(_pkCh[i])]->postMessage(pkt);
+            }
         }
         lorahip_demod_clear_packets(_d);
         if (_debugPorts) lorahip_demod_set_trace(_d, 0);                                // the next work() starts a fresh trace

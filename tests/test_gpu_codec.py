@@ -174,7 +174,7 @@ def test_longest_packets_and_limits(gpu, oracle):
 
 
 def test_long_encoded_packets_equal_the_verbatim_decoder(gpu, ref):
-    """Real packets longer than 512 symbols: 255 payload bytes through the verbatim LoRaEncoder.cpp at SF7 make 552 (4/7) and 608 (4/8)
+    """Real packets longer than 512 symbols: 255 payload bytes through the verbatim LoRaEncoder.cpp at SF7 make some 550 (4/7) and 600 (4/8)
     symbols. Clean, with symbol errors, and padded by the demodulator's trailing noise symbols up to an MTU of 1024: the batched
     decoder's bytes and drop decisions equal the verbatim LoRaDecoder.cpp's (round 5 reported such packets as out_len = -2)."""
     import lora_sdr_amd as L

@@ -288,6 +288,76 @@ def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf)
     d.close()
 
 
+@pytest.mark.parametrize("sf,B", [(7, 40), (8, 13), (9, 21), (10, 9)])
+def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B):
+    """lorahip_demod_receive with async = 3: ONE kernel launch stays on the device, the steps arrive as messages, the kernel packs every
+    step's packets and signals into the rows that came with the step's call; counts one call late, the flush ends the kernel. All
+    steps together, whatever the chunking (chunks so small that a step posts nothing included): the reference's packets, signals, call
+    counts and read positions. While the kernel is resident everything else is refused; afterwards the object is an ordinary one."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(1300 + sf)
+    N = 1 << sf
+    host = _streams(oracle, rng, sf, B, n_frames=4)
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
+    iq = gpu.from_numpy(host).cuda()
+    gpu.cuda.synchronize()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
+    d.set_signals(True)
+    rows = [d.receiver_rows(cap_packets=4 * B, stride=16) for _ in range(2)]
+    sig = d.receiver_signal_rows(8 * B, pinned_host=True)          # (one set: read before the next step can write -- see take())
+    got, got_sig, calls, w, k = [[] for _ in range(B)], [[] for _ in range(B)], 0, 0, 0
+
+    def take(n, r):
+        # the rows of the call BEFORE the one that returned n (resident steps), or of this call (the ordinary first step)
+        sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
+        for i in range(n):
+            got[int(chn[i])].append(sy[i, :ns[i]].copy())
+        for i in range(d.last_signals()):
+            got_sig[int(sig[0][i])].append((int(sig[1][i]), float(sig[2][i]), float(sig[3][i])))
+    resident = 0
+    while w < cap:
+        w = min(cap, w + int(rng.integers(N // 2, 6 * N)))
+        n, c_ = d.receive(iq, w, rows[k & 1], async_=3)
+        # the first call is an ordinary step (its own rows, at once); from the second on the counts are the previous step's
+        take(n, rows[k & 1] if k == 0 else rows[(k - 1) & 1])
+        calls += c_
+        k += 1
+        if k == 4:
+            for fn in (lambda: d.work(iq), lambda: d.packets(), lambda: d.activate(), lambda: d.receive(iq, w, rows[0], async_=True),
+                       lambda: d.receive(iq, w, rows[0], async_=2)):
+                with pytest.raises(L.LoraHipError):
+                    fn()
+            resident += 1
+        # (the signal rows are one set: the next step may write them as soon as it is rung -- this test waits for a step's report by
+        # ringing an empty step, so that what take() reads next is complete and nothing newer has been written over it)
+        if k >= 2:
+            n, c_ = d.receive(iq, w, rows[k & 1], async_=3)
+            take(n, rows[(k - 1) & 1])
+            calls += c_
+            k += 1
+    n, c_ = d.receive_flush(rows[k & 1])
+    take(n, rows[(k - 1) & 1])
+    calls += c_
+    assert resident == 1 and k > 8
+    for c in range(B):
+        r = refs[c]
+        # a channel's packets arrive in time order (rows of a step are not sorted by channel, the steps are in order)
+        assert len(got[c]) == len(r["packets"]) >= 4, "channel %d" % c
+        assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
+        assert d.consumed(c) == int(sum(q["consumed"] for q in r["calls"]))
+        assert [g[0] for g in got_sig[c]] == [int(q[0]) for q in r["signals"]] and len(got_sig[c]) >= 4, "channel %d" % c
+        assert np.allclose([g[1:] for g in got_sig[c]], [q[1:] for q in r["signals"]], rtol=0, atol=2e-5)
+    assert calls == sum(len(r["calls"]) for r in refs) == d.work_calls()
+    assert d.receive_flush() == (0, 0)
+    # the flushed object is an ordinary one: a rewound one-shot run gives the same again
+    d.set_signals(False); d.receiver_signal_rows(0)
+    d.rewind(); d.activate()
+    d.work_append(iq, cap)
+    assert sum(len(r["packets"]) for r in refs) == len(d.packets())
+    d.close()
+
+
 @pytest.mark.parametrize("async_", [False, True, 2])
 def test_receiver_steps_deliver_the_signals_and_lose_none_on_small_rows(gpu, oracle, async_):
     """Signals in a running receiver, every kind of step (waiting, stream-ordered, pipelined): device rows this time. Signal rows that
