@@ -128,38 +128,37 @@ def compact_line(full):
     if "moving" in full:
         out["moving"] = [dict(_pick(e, "sf", "Msym_s", "frac", "valu_busy", "error"), index_mismatches=_get(e, "oracle", "index_mismatches")) for e in full["moving"]]
     if "level3" in full:
-        rows = []
+        # one row per SF, by columns (the keys once, not six times): rates, roofline fractions, the oracle's verdict, the near-boundary
+        # counters; the receiver steps at 128- and 8-window chunks -- sequential, pipelined, with the block's signals kept, resident
+        cols = (("sf", ("sf",)), ("channels", ("channels",)), ("lanes_log2", ("lanes_log2",)), ("frac_kernel", ("frac_kernel",)),
+                ("frac_kernel_median", ("frac_kernel_median",)), ("with_signals_frac_kernel_median", ("with_signals", "frac_kernel_median")),
+                ("frac_e2e", ("frac_e2e",)), ("near_squelch", ("near_squelch",)), ("near_step", ("near_step",)),
+                ("oracle_channel_mismatches", ("oracle_channel_mismatches",)), ("trace_call_mismatches", ("trace_call_mismatches",)),
+                ("running_Msym_s", ("running", "Msym_s")), ("running_frac", ("running", "frac")), ("running_pipelined_frac", ("running", "pipelined", "frac")),
+                ("running_with_signals_frac", ("running", "with_signals", "frac")), ("running_resident_frac", ("running", "resident", "frac")),
+                ("same_packets_as_one_shot", ("running", "same_packets_as_one_shot")),
+                ("chunk8_Msym_s", ("running", "chunk8", "Msym_s")), ("chunk8_frac", ("running", "chunk8", "frac")),
+                ("chunk8_pipelined_Msym_s", ("running", "chunk8", "pipelined", "Msym_s")), ("chunk8_pipelined_frac", ("running", "chunk8", "pipelined", "frac")),
+                ("chunk8_with_signals_frac", ("running", "chunk8", "with_signals", "frac")),
+                ("chunk8_with_signals_pipelined_frac", ("running", "chunk8", "with_signals", "pipelined", "frac")),
+                ("chunk8_resident_Msym_s", ("running", "chunk8", "resident", "Msym_s")), ("chunk8_resident_frac", ("running", "chunk8", "resident", "frac")),
+                ("chunk8_resident_kernel", ("running", "chunk8", "resident", "kernel_resident")),
+                ("chunk8_resident_same_packets", ("running", "chunk8", "resident", "same_packets_as_one_shot")),
+                ("pothos_ports_off", ("pothos_block", "ports_off", "Msym_s")), ("pothos_pinned_input_slabs", ("pothos_block", "ports_off_pinned_input_slabs", "Msym_s")),
+                ("pothos_ports_on", ("pothos_block", "ports_on", "Msym_s")), ("pothos_vs_cpu_same_threads", ("pothos_block", "vs_cpu_same_threads")))
+        l3 = {"columns": [c for c, _ in cols], "rows": [[_get(e, *path) for _, path in cols] for e in full["level3"]]}
+        errs = {}
         for e in full["level3"]:
-            if "error" in e:
-                rows.append(_pick(e, "sf", "error"))
-                continue
-            run = e.get("running") or {}
-            row = dict(_pick(e, "sf", "channels", "lanes_log2", "frac_kernel", "frac_kernel_median", "frac_e2e", "near_squelch", "near_step",
-                             "oracle_channel_mismatches", "trace_call_mismatches", "parity_error"),
-                       with_signals_frac_kernel_median=_get(e, "with_signals", "frac_kernel_median"))
+            for where, v in (("", e.get("error")), ("parity", e.get("parity_error")), ("running", _get(e, "running", "error")),
+                             ("resident128", _get(e, "running", "resident", "error")), ("resident", _get(e, "running", "chunk8", "resident", "error")),
+                             ("pothos_block", _get(e, "pothos_block", "error"))):
+                if v:
+                    errs["sf%s %s" % (e.get("sf"), where)] = str(v)[:100]
             if e.get("oracle_kind", "reference") != "reference":
-                row["oracle_kind"] = e["oracle_kind"]     # (named only when the pinned restatement stood in for oracle/_ref)
-            if "error" in run:
-                row["running"] = {"error": str(run["error"])[:120]}
-            else:
-                row["running"] = dict(_pick(run, "Msym_s", "frac", "same_packets_as_one_shot"), pipelined_frac=_get(run, "pipelined", "frac"),
-                                      with_signals_frac=_get(run, "with_signals", "frac"), with_signals_pipelined_frac=_get(run, "with_signals", "pipelined", "frac"))
-                c8 = run.get("chunk8") or {}
-                row["chunk8"] = dict(_pick(c8, "Msym_s", "frac"), pipelined_Msym_s=_get(c8, "pipelined", "Msym_s"),
-                                     pipelined_frac=_get(c8, "pipelined", "frac"), with_signals_frac=_get(c8, "with_signals", "frac"),
-                                     with_signals_pipelined_frac=_get(c8, "with_signals", "pipelined", "frac"),
-                                     resident_Msym_s=_get(c8, "resident", "Msym_s"), resident_frac=_get(c8, "resident", "frac"),
-                                     resident_same_packets=_get(c8, "resident", "same_packets_as_one_shot"))
-                for part in (row["running"], row["chunk8"]):
-                    for k in [k for k, v in part.items() if v is None]:
-                        part.pop(k)
-            pb = e.get("pothos_block")
-            if pb:
-                row["pothos_block"] = {"error": pb["error"]} if "error" in pb else {
-                    "ports_off": _get(pb, "ports_off", "Msym_s"), "ports_off_pinned_input_slabs": _get(pb, "ports_off_pinned_input_slabs", "Msym_s"),
-                    "ports_on": _get(pb, "ports_on", "Msym_s"), "vs_cpu_same_threads": pb.get("vs_cpu_same_threads"), "host_threads": pb.get("host_threads")}
-            rows.append(row)
-        out["level3"] = rows
+                errs["sf%s oracle_kind" % e.get("sf")] = e["oracle_kind"]     # (named only when the pinned restatement stood in for oracle/_ref)
+        if errs:
+            l3["errors"] = errs
+        out["level3"] = l3
     if "config5" in full:
         out["config5"] = full["config5"]
     if "mixed" in full:

@@ -1009,12 +1009,11 @@ struct Pipe
         bool unavailable;               // tried and refused for this object (no instance, the grid not resident at once, a step timed out)
         unsigned seq;                   // steps rung
         unsigned reported;              // steps whose report the caller has had
-        ResidentCtl *ctl;               // device
-        ResidentMsg *hMsg;              // [8] pinned: the messages as they are copied into the ring
-        unsigned long long *hSum;       // [4][2] pinned and mapped: the steps' reports
+        ResidentCtl *ctl;               // device: the mirror of the ring, the steps' counters
+        ResidentHost *host;             // pinned and mapped: the ring the host writes, the steps' reports, the abort flag
         char *rec; size_t recBytes;     // the channels' records of a step (a StreamLayout; the state and the carry rows are the object's own)
         StreamLayout lay;
-        hipStream_t run, bell;          // the kernel's stream; the doorbell copies' stream
+        hipStream_t run;                // the kernel's stream
         hipEvent_t ev;
         unsigned grid;
         size_t lastValid;
@@ -1295,7 +1294,7 @@ static int residentRing(lorahip_demod *dm, const size_t nValid, const lorahip_pa
 {
     Pipe::Resident &R = pipeOf(dm).res;
     const unsigned seq = R.seq + 1;
-    ResidentMsg &m = R.hMsg[seq & 7];
+    ResidentMsg m;
     std::memset(&m, 0, sizeof(m));
     m.nValid = nValid;
     if (rows)
@@ -1311,7 +1310,11 @@ static int residentRing(lorahip_demod *dm, const size_t nValid, const lorahip_pa
     m.flags = flags;
     m.seq = seq;
     m.check = residentCheck(m);
-    LORAHIP_TRY(hipMemcpyAsync(&R.ctl->msg[seq & 7], &m, sizeof(m), hipMemcpyHostToDevice, R.bell));
+    // plain stores into pinned memory, the step number last (the kernel verifies the check word whenever it sees the number)
+    ResidentMsg *slot = &R.host->msg[seq & 7];
+    __atomic_store_n(&slot->seq, 0u, __ATOMIC_RELEASE);
+    std::memcpy(slot, &m, offsetof(ResidentMsg, seq));
+    __atomic_store_n(&slot->seq, seq, __ATOMIC_RELEASE);
     R.seq = seq;
     return LORAHIP_OK;
 }
@@ -1320,7 +1323,7 @@ static int residentRing(lorahip_demod *dm, const size_t nValid, const lorahip_pa
 static int residentReport(lorahip_demod *dm, const unsigned k, size_t *packets, size_t *signals, int64_t *calls, unsigned *flags)
 {
     Pipe::Resident &R = pipeOf(dm).res;
-    volatile unsigned long long *h = R.hSum + 2 * (k & 3);
+    volatile unsigned long long *h = R.host->sum + 2 * (k & 3);
     typedef std::chrono::steady_clock Clock;
     const Clock::time_point t0 = Clock::now();
     unsigned spins = 0;
@@ -1347,9 +1350,7 @@ static void residentAbort(lorahip_demod *dm)
 {
     Pipe::Resident &R = pipeOf(dm).res;
     if (!R.active) return;
-    const unsigned one = 1;
-    (void)hipMemcpyAsync(&R.ctl->abort, &one, sizeof(one), hipMemcpyHostToDevice, R.bell);
-    (void)hipStreamSynchronize(R.bell);
+    __atomic_store_n(&R.host->abort, 1u, __ATOMIC_RELEASE);
     (void)hipStreamSynchronize(R.run);
     R.active = false; R.unavailable = true;
     dm->devStateFresh = false;                        // the steps' bookkeeping is incomplete: nothing on the device is trusted
@@ -1380,7 +1381,6 @@ static int residentFlush(lorahip_demod *dm, size_t *nPackets, int64_t *calls)
     }
     // the quit message, then the kernel's end: the state, the read positions and the open packets are on the device as a streaming run leaves them
     { const int rc = residentRing(dm, R.lastValid, nullptr, 1u); if (rc != LORAHIP_OK) { residentAbort(dm); return rc; } }
-    LORAHIP_TRY(hipStreamSynchronize(R.bell));
     LORAHIP_TRY(hipStreamSynchronize(R.run));
     R.active = false;
     if (nPackets) *nPackets = pk;
@@ -1437,10 +1437,8 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         if (R.ctl == nullptr)
         {
             LORAHIP_TRY(hipMalloc((void **)&R.ctl, sizeof(ResidentCtl)));
-            LORAHIP_TRY(hipHostMalloc((void **)&R.hMsg, 8 * sizeof(ResidentMsg), hipHostMallocDefault));
-            LORAHIP_TRY(hipHostMalloc((void **)&R.hSum, 8 * sizeof(unsigned long long), hipHostMallocMapped));
+            LORAHIP_TRY(hipHostMalloc((void **)&R.host, sizeof(ResidentHost), hipHostMallocMapped));
             LORAHIP_TRY(hipStreamCreateWithFlags(&R.run, hipStreamNonBlocking));
-            LORAHIP_TRY(hipStreamCreateWithFlags(&R.bell, hipStreamNonBlocking));
             LORAHIP_TRY(hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
         }
         // a step's records: sized for a step as long as this one (a longer one fills them, stops the channel and the next step resumes it)
@@ -1456,9 +1454,9 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         }
         R.lay = L;
         R.sigs = dm->wantSignals;
-        void *sumDev = nullptr;
-        LORAHIP_TRY(hipHostGetDevicePointer(&sumDev, R.hSum, 0));
-        std::memset(R.hSum, 0, 8 * sizeof(unsigned long long));
+        void *hostDev = nullptr;
+        LORAHIP_TRY(hipHostGetDevicePointer(&hostDev, R.host, 0));
+        std::memset(R.host, 0, sizeof(ResidentHost));
         LORAHIP_TRY(hipMemsetAsync(R.ctl, 0, sizeof(ResidentCtl), ctx->stream));
         const StreamLayout H = headLayout(dm);
         char *d = R.rec;
@@ -1479,15 +1477,27 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         a.powerScale = ctx->powerScale; a.thresh = dm->thresh; a.sync = dm->sync;
         a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
         a.near = reinterpret_cast<unsigned *>(dm->sDev + H.oNear);
-        a.res = R.ctl; a.resSum = static_cast<unsigned long long *>(sumDev); a.resWatchdog = kResidentWatchdog;
+        a.res = R.ctl; a.resHost = static_cast<ResidentHost *>(hostDev); a.resWatchdog = kResidentWatchdog;
         // behind everything queued on the launch stream (the state of the run before, the cleared control block)
         LORAHIP_TRY(hipEventRecord(R.ev, ctx->stream));
         LORAHIP_TRY(hipStreamWaitEvent(R.run, R.ev, 0));
-        LORAHIP_TRY(hipStreamWaitEvent(R.bell, R.ev, 0));
         const hipError_t le = launchStreamResident(ctx->sf, a, R.run, &R.grid);
         if (le == hipErrorNotSupported) { (void)hipGetLastError(); R.unavailable = true; return LORAHIP_OK; }     // not for this geometry: ordinary steps
         LORAHIP_TRY(le);
         R.active = true; R.seq = 0; R.reported = 0; R.lastMore = false;
+        {
+            // the census: every workgroup must be ON the device before a step is rung (bounded wait; otherwise the kernel is told to
+            // leave and the object takes ordinary steps from now on)
+            typedef std::chrono::steady_clock Clock;
+            const Clock::time_point t0 = Clock::now();
+            while (__atomic_load_n(&R.host->arrivedAll, __ATOMIC_ACQUIRE) == 0u && std::chrono::duration<double>(Clock::now() - t0).count() < 2.0) {}
+            if (__atomic_load_n(&R.host->arrivedAll, __ATOMIC_ACQUIRE) == 0u)
+            {
+                residentAbort(dm);
+                dm->devStateFresh = true;             // (no step was taken: the state on the device is what it was)
+                return LORAHIP_OK;
+            }
+        }
         P.iq = iqDev; P.rowStride = rowStride;
         dm->devStateFresh = false;                    // until the kernel has left, only it knows where the state stands
     }
@@ -1839,11 +1849,9 @@ void lorahip_demod_destroy(lorahip_demod *dm)
         Pipe &P = pipeOf(dm);
         residentAbort(dm);                                        // (a resident kernel must leave before its memory goes)
         if (P.res.ctl) (void)hipFree(P.res.ctl);
-        if (P.res.hMsg) (void)hipHostFree(P.res.hMsg);
-        if (P.res.hSum) (void)hipHostFree(P.res.hSum);
+        if (P.res.host) (void)hipHostFree(P.res.host);
         if (P.res.rec) (void)hipFree(P.res.rec);
         if (P.res.run) (void)hipStreamDestroy(P.res.run);
-        if (P.res.bell) (void)hipStreamDestroy(P.res.bell);
         if (P.res.ev) (void)hipEventDestroy(P.res.ev);
         for (int i = 0; i < 2; i++)
         {

@@ -196,12 +196,27 @@ __device__ __forceinline__ int fineChainGroup(const int idx0, const float d, con
 //! LDS copies of the split tables (addresses fixed at compile time); split == false: gather from the table in HBM instead
 struct FineLds { const double2 *A, *B; bool split; };
 
+// A/B switches of the two steps VERDICT r5 item 7 asked to be BUILT and measured (profiles/r06/s*_ab_fine_*; both keep every bit):
+//   LORAHIP_FINEB_SKEW   the B table in LDS skewed by one entry per 16 (entry i at i + i / 16): the 16 lanes of a ds_read_b128 pass whose
+//                        B index runs in an EVEN step no longer fall on the same bank quads; two more address instructions per sample
+//   LORAHIP_FINE_POW2    waves whose windows ALL have a negative or integer step (modulus M = 2^m): the closed-form indices by add + and
+//                        instead of the add / subtract / min of the general modulus
+//! position of B-table entry i in its LDS copy
+__host__ __device__ constexpr unsigned fineBSlot(const unsigned i)
+{
+#ifdef LORAHIP_FINEB_SKEW
+    return i + (i >> 4);
+#else
+    return i;
+#endif
+}
 //! entries of the two split tables for N = 2^LOG2N
 template <int LOG2N> struct FineDims
 {
     static constexpr int LOG2M = LOG2N + 7, LH = fineSplitLog2H(LOG2N);
     static constexpr int NA = 1 << (LOG2M - LH), NB = 1 << LH;
-    static constexpr size_t BYTES = size_t(NA + NB) * sizeof(double2);
+    static constexpr int NB_LDS = int(fineBSlot(unsigned(NB - 1))) + 1;      // entries of the LDS copy of B (skewed: one gap per 16)
+    static constexpr size_t BYTES = size_t(NA + NB_LDS) * sizeof(double2);
 };
 
 //! workgroup copy of the split tables into LDS (call before a __syncthreads())
@@ -213,7 +228,7 @@ __device__ __forceinline__ FineLds fineLoadLds(double2 *dst, const double2 *gA, 
     f.A = dst; f.B = dst + D::NA; f.split = gA != nullptr;
     if (!f.split) return f;
     for (int i = tid; i < D::NA; i += nThreads) dst[i] = gA[i];
-    for (int i = tid; i < D::NB; i += nThreads) dst[D::NA + i] = gB[i];
+    for (int i = tid; i < D::NB; i += nThreads) dst[D::NA + fineBSlot(unsigned(i))] = gB[i];
     return f;
 }
 
@@ -221,7 +236,7 @@ __device__ __forceinline__ FineLds fineLoadLds(double2 *dst, const double2 *gA, 
 template <int LH>
 __device__ __forceinline__ v2f fineEval(const unsigned y, const FineLds &s)
 {
-    const double2 a = s.A[y >> LH], b = s.B[y & ((1u << LH) - 1u)];
+    const double2 a = s.A[y >> LH], b = s.B[fineBSlot(y & ((1u << LH) - 1u))];
     const double re = __builtin_fma(a.x, b.x, -(a.y * b.y));
     const double im = __builtin_fma(a.x, b.y, a.y * b.x);
     return v2f{(float)re, (float)im};
@@ -253,7 +268,7 @@ template <int LH>
 __device__ __forceinline__ void fineIssue(d2v &a, d2v &b, const unsigned y, const unsigned baseA, const unsigned baseB)
 {
     asm volatile("ds_read_b128 %0, %1" : "=v"(a) : "v"(entryAddress16(y >> LH, baseA)));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(b) : "v"(entryAddress16(y & ((1u << LH) - 1u), baseB)));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(b) : "v"(entryAddress16(fineBSlot(y & ((1u << LH) - 1u)), baseB)));
 }
 
 //! CONJ: chirp(i) is the DOWN-chirp table's entry and the window wants the up-chirp table, its conjugate (LoRaDemod.cpp:103): the
@@ -409,6 +424,27 @@ template <int LOG2N, int VEC, int T, int R>
 __device__ __forceinline__ unsigned fineLaneIndices(const int idx0, const FinePlan &p, const int t, unsigned (&y)[R][VEC])
 {
     constexpr int LOG2M = LOG2N + 7;
+#ifdef LORAHIP_FINE_POW2
+    if (__all(p.mod == (1u << LOG2M) && !p.sat))
+    {
+        // every window of the wave steps by an integer or downwards: the modulus is M = 2^m and the wrap is a mask (never the value M)
+        constexpr unsigned MM = (1u << LOG2M) - 1u;
+        const unsigned Qp = (unsigned(VEC * T) * p.q) & MM;
+#pragma unroll
+        for (int u = 0; u < VEC; u++) y[0][u] = (unsigned(idx0) + __umul24(unsigned(VEC * t + u), p.q)) & MM;
+        unsigned Qv = Qp;
+#pragma unroll
+        for (int w = 1; w < R; w <<= 1)
+        {
+#pragma unroll
+            for (int r = 0; r < w && r + w < R; r++)
+#pragma unroll
+                for (int u = 0; u < VEC; u++) y[r + w][u] = (y[r][u] + Qv) & MM;
+            Qv = (Qv + Qv) & MM;
+        }
+        return 0u;
+    }
+#endif
     const unsigned Q = fineReduce(unsigned(VEC * T) * p.q, p, LOG2M);          // VEC*T*q < N*(M+1) < 2^32
     // y[r] = y[0] + r Q (mod M'): by doubling (Q, 2Q, 4Q, ...) instead of one long chain -- log2(R) dependent steps, not R
     unsigned ymax = 0;

@@ -106,10 +106,12 @@ struct StreamPacket { int callIndex; int len; };
 struct StreamSignal { int callIndex; int error; float power; float snr; };
 
 /*! The RESIDENT receiver (lorahip_demod_receive with async = 3; lorahip_streamkernel.h, RES): one launch stays on the device across the
- * receiver's steps. The host describes a step in a ResidentMsg (copied into the ring in device memory: the "doorbell"), the wavefronts
- * poll for it, work through what arrived, the last wavefront of every workgroup packs the workgroup's packets / signals into the step's
- * rows, and the last workgroup of the step reports two words to pinned host memory. No launch, no helper kernel, no API call but the
- * doorbell's copy per step. */
+ * receiver's steps. The host describes a step in a ResidentMsg, written with plain stores into a ring in PINNED HOST memory (the
+ * "doorbell": no API call, and nothing that needs a place on the device -- a copy that the runtime performs with a blit kernel would
+ * wait for ever behind a kernel that fills every SIMD). The wavefronts poll a mirror of the ring in DEVICE memory; a few of them at a
+ * time also look at the host's ring over PCIe, and whoever finds a new message first copies it into the mirror for all. They work
+ * through what arrived, the last wavefront of every workgroup packs the workgroup's packets / signals into the step's rows, and the
+ * last workgroup of the step reports two words to pinned host memory. No launch, no helper kernel, no API call per step. */
 struct ResidentMsg
 {
     unsigned long long nValid;          // samples per channel that are valid now
@@ -136,8 +138,16 @@ struct ResidentCtl
     unsigned long long doneCalls[4];    // [63:48] workgroups that finished the step, [47:0] work() calls they made
     unsigned rowCount[4], sigCount[4];  // rows handed out (may exceed the capacity: the excess was dropped and is reported)
     unsigned more[4];                   // some channel stopped because a record buffer was full
-    unsigned abort;                     // host: leave now (set before the quit message when a step timed out)
+    unsigned arrived;                   // workgroups that have started (the census: all of them must be on the device at once)
     unsigned expired;                   // a wavefront gave up waiting for a message (watchdog)
+};
+//! pinned host memory the device addresses directly: the host's side of the doorbell and the kernel's reports
+struct ResidentHost
+{
+    ResidentMsg msg[8];                 // the ring the host writes (seq last)
+    unsigned long long sum[8];          // [4][2] the steps' reports (below)
+    unsigned abort;                     // host: leave now
+    unsigned arrivedAll;                // kernel: every workgroup has started
 };
 //! what the last workgroup of a step writes to pinned host memory: two 64-bit words, each carrying (part of) the step number
 //!   w0 = seq << 32 | calls (32 bits)      w1 = (seq & 0xff) << 56 | flags << 48 | signals (24 bits) << 24 | packets (24 bits)
@@ -189,7 +199,7 @@ struct StreamArgs
                                 //     Running counters: the kernels only add, the host takes differences
     // the resident receiver (RES instances only)
     ResidentCtl *res = nullptr;
-    unsigned long long *resSum = nullptr;      // [4][2] pinned host memory as the device addresses it: the steps' reports
+    ResidentHost *resHost = nullptr;           // pinned host memory as the device addresses it
     unsigned long long resWatchdog = 0;        // 100 MHz ticks a wavefront waits for a message before it gives up
 };
 

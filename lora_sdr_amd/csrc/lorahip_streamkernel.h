@@ -49,50 +49,77 @@ __device__ __forceinline__ unsigned long long uni64(const unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+//! a ring slot read at system scope (from memory); true if it holds step `want` and its check word fits
+__device__ __forceinline__ bool residentRead(const ResidentMsg *g, const unsigned want, ResidentMsg &c)
+{
+    if (sysLoad(&g->seq) != want) return false;
+    c.nValid = sysLoad(&g->nValid);
+    c.syms = reinterpret_cast<unsigned short *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->syms)));
+    c.nsyms = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->nsyms)));
+    c.chan = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->chan)));
+    c.sigCh = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigCh)));
+    c.sigErr = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigErr)));
+    c.sigPow = reinterpret_cast<float *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigPow)));
+    c.sigSnr = reinterpret_cast<float *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigSnr)));
+    c.symStride = sysLoad(&g->symStride); c.capRows = sysLoad(&g->capRows); c.capSig = sysLoad(&g->capSig); c.flags = sysLoad(&g->flags);
+    c.seq = want;
+    c.check = sysLoad(&g->check);
+    return c.check == residentCheck(c);
+}
+
 /*! Wait for the message of step `want`. Every wavefront polls for itself (the wavefronts of a workgroup are independent in the loop):
- * the ring lives in device memory -- the host's doorbell is a small copy into it --, read at system scope, i.e. from memory, so a poll
- * costs a memory round trip and no PCIe traffic; between polls the wavefront sleeps. A message counts only when its check word fits
- * its fields (the copy that delivers it is not atomic). false: leave the kernel (quit message, abort flag, or nothing for
- * s.resWatchdog ticks: every spin is bounded). After a message the wavefront's view of memory is made fresh (agent-scope acquire:
- * the samples that arrived since the last step must not be served from stale L1 / L2 lines). */
+ * the MIRROR of the ring in device memory, read at system scope, i.e. from memory -- a poll costs a memory round trip and no PCIe
+ * traffic --, and every 16th time the host's own ring over PCIe (the pollers are de-phased: a few of the 2048 wavefronts of a full
+ * device look there at any moment). Whoever finds a message there first copies it into the mirror (several may: they write the same
+ * words). A message counts only when its check word fits its fields (neither the host's stores nor the relay are atomic). Between
+ * polls the wavefront sleeps. false: leave the kernel (quit message, abort flag, or nothing for s.resWatchdog ticks: every spin is
+ * bounded). After a message the wavefront's view of memory is made fresh (agent-scope acquire: the samples that arrived since the last
+ * step must not be served from stale L1 / L2 lines). */
 __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned want, ResMsgR &m)
 {
-    const ResidentMsg *g = &s.res->msg[want & 7];
+    ResidentMsg *g = &s.res->msg[want & 7];
+    const ResidentMsg *h = &s.resHost->msg[want & 7];
     const unsigned long long t0 = wall_clock64();
+    unsigned it = blockIdx.x * 5u + (threadIdx.x >> 6) * 3u;
+    ResidentMsg c;
     for (;;)
     {
-        if (sysLoad(&g->seq) == want)
+        if (residentRead(g, want, c)) break;
+        if ((it++ & 15u) == 0u)
         {
-            ResidentMsg c;
-            c.nValid = sysLoad(&g->nValid);
-            c.syms = reinterpret_cast<unsigned short *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->syms)));
-            c.nsyms = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->nsyms)));
-            c.chan = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->chan)));
-            c.sigCh = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigCh)));
-            c.sigErr = reinterpret_cast<int *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigErr)));
-            c.sigPow = reinterpret_cast<float *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigPow)));
-            c.sigSnr = reinterpret_cast<float *>(sysLoad(reinterpret_cast<const unsigned long long *>(&g->sigSnr)));
-            c.symStride = sysLoad(&g->symStride); c.capRows = sysLoad(&g->capRows); c.capSig = sysLoad(&g->capSig); c.flags = sysLoad(&g->flags);
-            c.seq = want;
-            if (sysLoad(&g->check) == residentCheck(c))
+            if (residentRead(h, want, c))
             {
-                m.nValid = uni64(c.nValid);
-                m.syms = reinterpret_cast<unsigned short *>(uni64((unsigned long long)(size_t)c.syms));
-                m.nsyms = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.nsyms));
-                m.chan = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.chan));
-                m.sigCh = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.sigCh));
-                m.sigErr = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.sigErr));
-                m.sigPow = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)c.sigPow));
-                m.sigSnr = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)c.sigSnr));
-                m.symStride = (unsigned)__builtin_amdgcn_readfirstlane((int)c.symStride); m.capRows = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capRows);
-                m.capSig = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capSig); m.flags = (unsigned)__builtin_amdgcn_readfirstlane((int)c.flags);
+                // relay: the fields, then the check word, then the step number (a reader that sees the number verifies the check)
+                sysStore(&g->nValid, c.nValid);
+                sysStore(reinterpret_cast<unsigned long long *>(&g->syms), (unsigned long long)(size_t)c.syms);
+                sysStore(reinterpret_cast<unsigned long long *>(&g->nsyms), (unsigned long long)(size_t)c.nsyms);
+                sysStore(reinterpret_cast<unsigned long long *>(&g->chan), (unsigned long long)(size_t)c.chan);
+                sysStore(reinterpret_cast<unsigned long long *>(&g->sigCh), (unsigned long long)(size_t)c.sigCh);
+                sysStore(reinterpret_cast<unsigned long long *>(&g->sigErr), (unsigned long long)(size_t)c.sigErr);
+                sysStore(reinterpret_cast<unsigned long long *>(&g->sigPow), (unsigned long long)(size_t)c.sigPow);
+                sysStore(reinterpret_cast<unsigned long long *>(&g->sigSnr), (unsigned long long)(size_t)c.sigSnr);
+                sysStore(&g->symStride, c.symStride); sysStore(&g->capRows, c.capRows); sysStore(&g->capSig, c.capSig); sysStore(&g->flags, c.flags);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sysStore(&g->check, c.check);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sysStore(&g->seq, want);
                 break;
             }
+            if (sysLoad(&s.resHost->abort) != 0u) return false;
         }
-        if (sysLoad(&s.res->abort) != 0u) return false;
         if (wall_clock64() - t0 > s.resWatchdog) { sysStore(&s.res->expired, 1u); return false; }
         __builtin_amdgcn_s_sleep(24);
     }
+    m.nValid = uni64(c.nValid);
+    m.syms = reinterpret_cast<unsigned short *>(uni64((unsigned long long)(size_t)c.syms));
+    m.nsyms = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.nsyms));
+    m.chan = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.chan));
+    m.sigCh = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.sigCh));
+    m.sigErr = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.sigErr));
+    m.sigPow = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)c.sigPow));
+    m.sigSnr = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)c.sigSnr));
+    m.symStride = (unsigned)__builtin_amdgcn_readfirstlane((int)c.symStride); m.capRows = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capRows);
+    m.capSig = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capSig); m.flags = (unsigned)__builtin_amdgcn_readfirstlane((int)c.flags);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return (m.flags & 1u) == 0u;
 }
@@ -198,7 +225,7 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
             const unsigned nx = (step + 2u) & 3u;
             sysStore(&s.res->doneCalls[nx], 0ull); sysStore(&s.res->rowCount[nx], 0u); sysStore(&s.res->sigCount[nx], 0u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned long long *h = s.resSum + 2 * slot;
+            unsigned long long *h = s.resHost->sum + 2 * slot;
             const unsigned long long w1 = ((unsigned long long)(step & 0xffu) << 56) | ((unsigned long long)flags << 48) | ((unsigned long long)(sgAll & 0xffffffu) << 24) |
                                           (unsigned long long)(pkAll & 0xffffffu);
             const unsigned long long w0 = ((unsigned long long)step << 32) | (tot & 0xffffffffull);
@@ -250,6 +277,12 @@ demodStream(const StreamArgs s)
     typedef ResLds<WAVES * WPW> ResL;
     ResL *sR = reinterpret_cast<ResL *>(reinterpret_cast<char *>(sFine) + FineDims<C::LOG2N>::BYTES);        // RES only (the launcher adds the bytes)
     if (RES && threadIdx.x < 2) { sR->calls[threadIdx.x] = 0; sR->arrive[threadIdx.x] = 0; sR->more[threadIdx.x] = 0; }
+    if constexpr (RES)
+    {
+        // the census: the host rings the first step only when every workgroup is on the device (one that had to wait for a slot would wait
+        // for ever: the others never leave)
+        if (threadIdx.x == 0 && atomicAdd(&s.res->arrived, 1u) + 1u == gridDim.x) sysStore(&s.resHost->arrivedAll, 1u);
+    }
     __syncthreads();
 
     // With one channel per wavefront (T = 64: SF10) everything the frame machine touches is WAVE-UNIFORM; saying so (v_readfirstlane

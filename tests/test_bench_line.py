@@ -11,6 +11,11 @@ from conftest import ROOT
 import bench
 
 FULL = [os.path.join(ROOT, "profiles", "r05", n) for n in ("s40_bench_default.json", "s42_bench_two_ranks_one_device_gloo.json")]
+def level3_rows(line):
+    """the level3 section of THE line is columnar (the keys once): back to one dict per SF"""
+    return [dict(zip(line["level3"]["columns"], r)) for r in line["level3"]["rows"]]
+
+
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
             "config", "roofline", "cpu_baseline", "oracle")
 
@@ -29,12 +34,14 @@ def test_compact_line_of_a_full_run_fits_the_reader(path):
         assert line["cpu_baseline"][k] == full["cpu_baseline"][k]
     assert line["config"]["workload"] == full["config"]["workload"]
     # one row per SF in every sweep, with the oracle's verdict in it
-    assert [e["sf"] for e in line["per_sf"]] == [e["sf"] for e in line["moving"]] == [e["sf"] for e in line["level3"]] == list(range(7, 13))
+    l3 = level3_rows(line)
+    assert [e["sf"] for e in line["per_sf"]] == [e["sf"] for e in line["moving"]] == [e["sf"] for e in l3] == list(range(7, 13))
     assert all(e["index_mismatches"] == 0 for e in line["per_sf"] + line["moving"])
-    for row, e in zip(line["level3"], full["level3"]):
+    for row, e in zip(l3, full["level3"]):
         assert row["frac_kernel_median"] == e["frac_kernel_median"] and row["oracle_channel_mismatches"] == e["oracle_channel_mismatches"] == 0
         assert row["trace_call_mismatches"] == 0 and row["near_step"] == e["near_step"]
-        assert row["running"]["frac"] == e["running"]["frac"] and row["chunk8"]["frac"] == e["running"]["chunk8"]["frac"]
+        assert row["running_frac"] == e["running"]["frac"] and row["chunk8_frac"] == e["running"]["chunk8"]["frac"]
+        assert row["chunk8_pipelined_Msym_s"] == e["running"]["chunk8"]["pipelined"]["Msym_s"]
     assert line["config5"] == full["config5"] and line["mixed"]["frac_byte_weighted"] == full["mixed"]["frac_byte_weighted"]
     assert line["mixed_level3"]["oracle_channel_mismatches"] == 0
     assert "SECTION" in line["sections"]

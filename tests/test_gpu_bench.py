@@ -103,15 +103,17 @@ def test_default_line_fits_the_reader_one_rank_and_two(gpu):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         d = the_line(r.stdout)
         assert d["n_gpus"] == n and d["roofline"]["frac"] > 0.3 and d["cpu_baseline"]["value"] > 0 and d["oracle"]["index_mismatches"] == 0
-        for k in ("per_sf", "moving", "level3"):
-            assert [e["sf"] for e in d[k]] == list(range(7, 13)), k
+        l3 = [dict(zip(d["level3"]["columns"], r_)) for r_ in d["level3"]["rows"]]        # (columnar: the keys once)
+        for k, rows_ in (("per_sf", d["per_sf"]), ("moving", d["moving"]), ("level3", l3)):
+            assert [e["sf"] for e in rows_] == list(range(7, 13)), k
         assert all(e["index_mismatches"] == 0 for e in d["per_sf"] + d["moving"])
-        assert all(e["oracle_channel_mismatches"] == 0 and e["trace_call_mismatches"] == 0 for e in d["level3"])
+        assert all(e["oracle_channel_mismatches"] == 0 and e["trace_call_mismatches"] == 0 for e in l3)
+        assert "errors" not in d["level3"], d["level3"]["errors"]
         assert d["config5"]["gpu_vs_cpu_index_mismatches"] == 0 and d["mixed"]["oracle"]["index_mismatches"] == 0
         assert d["mixed_level3"]["oracle_channel_mismatches"] == 0
         full = sections(r.stdout)
         assert set(full) >= {"config", "roofline", "cpu_baseline", "per_sf", "moving", "level3", "config5", "mixed", "mixed_level3"}
-        assert full["level3"][0]["running"]["chunk8"]["frac"] == d["level3"][0]["chunk8"]["frac"]
+        assert full["level3"][0]["running"]["chunk8"]["frac"] == l3[0]["chunk8_frac"]
         saved = json.load(open(os.path.join(ROOT, "gpurun_out", "bench_sections.json")))
         assert saved["level3"] == full["level3"] and saved["value"] == d["value"]
         if n == 2:

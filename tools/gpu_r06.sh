@@ -124,6 +124,49 @@ if [[ $what == *counters* ]]; then
   TAG=$TAG python tools/pmc_counters.py $O $TAG | tee $O/${TAG}_sq_counters_batch_kernels.txt
   rm -rf $O/pmc_SQ*_sf*
 fi
+if [[ $what == *abfine* ]]; then
+  # the two declined micro-steps of the moving-index kernels, BUILT (tools/build_variant.py pow2 / skew) and measured as
+  # in-session A/B pairs: 5 alternations of `bench.py --sf S --moving` per library, the launch time of each; then, per library, the parity
+  # tests that cover the moving index on that build, and the SQ counters of the moving kernel at SF11 / SF12
+  : > $O/${TAG}_ab_fine_moving.txt
+  for rep in 1 2 3 4 5; do
+    for sf in ${ABSF:-10 11 12}; do
+      for lib in ${ABLIBS:-cur pow2 skew}; do
+        path=$R/lora_sdr_amd/liblorahip_$lib.so; [[ $lib == cur ]] && path=$R/lora_sdr_amd/liblorahip.so
+        LORAHIP_LIB=$path timeout 200 python bench.py --sf $sf --no-cpu-baseline --moving 2>/dev/null | python -c "
+import json, sys
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); print('rep %s SF%s %-5s moving %8.1f Msym/s frac %.4f launch %.2f us oracle mismatches %s' % (sys.argv[1], sys.argv[2], sys.argv[3], d['value'], d['roofline']['frac'], d['roofline']['launch_us'], d.get('oracle', {}).get('index_mismatches')))
+" $rep $sf $lib | tee -a $O/${TAG}_ab_fine_moving.txt
+      done
+    done
+  done
+  python - $O/${TAG}_ab_fine_moving.txt <<'EOP' | tee -a $O/${TAG}_ab_fine_moving.txt
+import re, sys, statistics
+rows = {}
+for ln in open(sys.argv[1]):
+    m = re.match(r"rep (\d+) SF(\d+) (\w+)\s+moving\s+([0-9.]+) Msym/s frac ([0-9.]+) launch ([0-9.]+) us", ln)
+    if m:
+        rows.setdefault((int(m.group(2)), m.group(3)), []).append(float(m.group(6)))
+print("median launch us of the 5 alternations, and against cur:")
+for (sf, lib), v in sorted(rows.items()):
+    base = statistics.median(rows.get((sf, "cur"), v))
+    print("  SF%d %-5s %.2f us  (%+.2f %% time vs cur)  [%s]" % (sf, lib, statistics.median(v), (statistics.median(v) / base - 1) * 100, " ".join("%.1f" % x for x in v)))
+EOP
+  for lib in ${ABLIBS:-cur pow2 skew}; do
+    path=$R/lora_sdr_amd/liblorahip_$lib.so; [[ $lib == cur ]] && path=$R/lora_sdr_amd/liblorahip.so
+    LORAHIP_LIB=$path timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_demod.py -m gpu -x -q -k "fine or moving or recurrence" > $O/${TAG}_ab_fine_parity_$lib.txt 2>&1
+    echo "parity [$lib]: $(tail -1 $O/${TAG}_ab_fine_parity_$lib.txt)" | tee -a $O/${TAG}_ab_fine_moving.txt
+    for sf in 11 12; do
+      d=$O/${TAG}_pmc_abfine_${lib}_sf$sf
+      ( cd /tmp && LORAHIP_LIB=$path timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAVES -d $d -o pmc --output-format csv -- \
+          python $R/bench.py --sf $sf --moving --steps 3 --warmup 1 --ramp-seconds 0 --no-cpu-baseline > $d.log 2>&1 )
+      python tools/pmc_kernels.py "$d" detect "moving SF$sf [$lib]" | tee -a $O/${TAG}_ab_fine_moving.txt
+      rm -rf $d
+    done
+  done
+fi
 if [[ $what == *custom* ]]; then
   bash -c "$CUSTOM" > $O/${TAG}_custom.txt 2>&1; tail -${CUSTOM_TAIL:-40} $O/${TAG}_custom.txt
 fi
