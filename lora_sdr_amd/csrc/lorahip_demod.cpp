@@ -1019,6 +1019,7 @@ struct Pipe
         size_t lastValid;
         bool lastMore;                  // the last reported step left a channel with samples it could not record
         bool sigs;                      // the launch keeps signal records
+        bool tail;                      // the last step left fewer than 16 valid samples per row untouched (the flush's ordinary step takes them)
     } res;
 };
 static Pipe &pipeOf(lorahip_demod *dm) { return *static_cast<Pipe *>(dm->pipe); }
@@ -1392,7 +1393,16 @@ static int residentFlush(lorahip_demod *dm, size_t *nPackets, int64_t *calls)
     pendingOf(dm).valid = false;
     std::memset(&dm->lastSum, 0, sizeof(dm->lastSum));
     dm->lastSum.anyOpen = 1;                          // (not tracked per step: the carry rows are valid, which is all `anyOpen` guards)
-    dm->lastSum.more = R.lastMore ? 1 : 0;
+    dm->lastSum.more = (R.lastMore || R.tail) ? 1 : 0;
+    if (std::getenv("LORAHIP_RESIDENT_DEBUG"))
+    {
+        ResidentCtl c;
+        if (hipMemcpy(&c, R.ctl, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int k = 0; k < 8; k++)
+                std::fprintf(stderr, "resident step %d (workgroup 0, wave 0; us): waited %.1f, setup %.1f, windows %.1f, carry out %.1f, step end %.1f; since step 1's wait began %.1f\n", k + 1,
+                             (c.dbg[k][1] - c.dbg[k][0]) / 100.0, (c.dbg[k][2] - c.dbg[k][1]) / 100.0, (c.dbg[k][3] - c.dbg[k][2]) / 100.0, (c.dbg[k][4] - c.dbg[k][3]) / 100.0,
+                             (c.dbg[k][5] - c.dbg[k][4]) / 100.0, (c.dbg[k][0] - c.dbg[0][0]) / 100.0);
+    }
     {
         // the kernels' running near-threshold counters
         const StreamLayout H = headLayout(dm);
@@ -1423,7 +1433,9 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
     const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(ctx->sf));
     const bool compatible = stream && ctx->sf >= 7 && ctx->sf <= 10 && !dm->tracing && !dm->portsOn && !dm->activatePending && dm->sDev != nullptr &&
                             dm->append && !dm->appendFresh && dm->uniStride == rowStride && nValid >= dm->appendPrev && dm->dCarry != nullptr &&
-                            dm->mtu + 1 <= dm->carryCap && !P.active && rowsHold(rows, 1);
+                            dm->mtu + 1 <= dm->carryCap && !P.active && rowsHold(rows, 1) &&
+                            // rows of whole 128-byte lines: a step then never reads a line that holds samples which arrive later (no cache to invalidate)
+                            (rowStride & 15u) == 0 && (reinterpret_cast<uintptr_t>(iqDev) & 127u) == 0;
     if (R.active && (!compatible || iqDev != P.iq))
     {
         setLastError("lorahip_demod_receive (resident): a setting or the rows changed under the resident kernel (lorahip_demod_receive_flush first)");
@@ -1506,8 +1518,10 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
     if (calls) *calls = 0;
     dm->lastSignals = 0;
     const DeviceGuard guard(ctx->device);
-    { const int rc = residentRing(dm, nValid, rows, 0u); if (rc != LORAHIP_OK) { residentAbort(dm); return rc; } }
-    R.lastValid = nValid;
+    // (up to the last whole line of every row: the < 16 samples behind it wait for the next step, or for the flush's ordinary step)
+    { const int rc = residentRing(dm, nValid & ~size_t(15), rows, 0u); if (rc != LORAHIP_OK) { residentAbort(dm); return rc; } }
+    R.lastValid = nValid & ~size_t(15);
+    R.tail = (nValid & 15u) != 0;
     dm->uniform = true; dm->uniSpc = nValid; dm->uniStride = rowStride; dm->appendPrev = nValid; dm->geomApplied = false;
     dm->mirrorsStale = true; dm->headStale = true;
     if (R.seq < 2) return LORAHIP_OK;

@@ -33,7 +33,9 @@ struct StreamOut
         if (!(s.flags & 4) || st.state != ST_DATASYMBOLS) return;
         const int k = st.symCount < s.carryCap ? st.symCount : s.carryCap;
         const short *src = s.carry + (size_t)channel * s.carryCap;
-        for (int i = t; i < k; i += T) symOut[i] = src[i];
+        // (read at agent scope: in the resident receiver the row was written by this compute unit a step ago and an older copy of the
+        // line may still sit in its L1)
+        for (int i = t; i < k; i += T) symOut[i] = __hip_atomic_load(const_cast<short *>(src) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nSym = st.symCount;
     }
     //! ... and a channel that ends the launch inside a packet leaves the packet's symbols -- the last symCount entries of its row,

@@ -73,8 +73,7 @@ __device__ __forceinline__ bool residentRead(const ResidentMsg *g, const unsigne
  * device look there at any moment). Whoever finds a message there first copies it into the mirror (several may: they write the same
  * words). A message counts only when its check word fits its fields (neither the host's stores nor the relay are atomic). Between
  * polls the wavefront sleeps. false: leave the kernel (quit message, abort flag, or nothing for s.resWatchdog ticks: every spin is
- * bounded). After a message the wavefront's view of memory is made fresh (agent-scope acquire: the samples that arrived since the last
- * step must not be served from stale L1 / L2 lines). */
+ * bounded). */
 __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned want, ResMsgR &m)
 {
     ResidentMsg *g = &s.res->msg[want & 7];
@@ -120,7 +119,10 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
     m.sigSnr = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)c.sigSnr));
     m.symStride = (unsigned)__builtin_amdgcn_readfirstlane((int)c.symStride); m.capRows = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capRows);
     m.capSig = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capSig); m.flags = (unsigned)__builtin_amdgcn_readfirstlane((int)c.flags);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // No acquire fence here: at agent scope it invalidates L1 and L2 (buffer_inv sc1), and 2048 wavefronts doing that once per step cost
+    // more than the step. What could be stale is decided by construction instead: a step works up to the last WHOLE 128-byte line of
+    // every row (the host passes n_valid rounded down to 16 samples; rows start on line boundaries), so no line the kernel has ever read
+    // holds samples that arrive later; the records and carry rows a workgroup reads back are its own and are read at agent scope.
     return (m.flags & 1u) == 0u;
 }
 
@@ -527,13 +529,17 @@ demodStream(const StreamArgs s)
     ResMsgR rm;
     for (;;)                                                // RES: one turn per receiver step; otherwise exactly one turn
     {
+    const bool dbgW = RES && blockIdx.x == 0 && threadIdx.x == 0;
     if constexpr (RES)
     {
+        if (dbgW && step < 8u) s.res->dbg[step][0] = wall_clock64();
         if (!residentWait(s, step + 1u, rm)) break;
+        if (dbgW && step < 8u) s.res->dbg[step][1] = wall_clock64();
         step++;
         len = mine ? (long long)rm.nValid : 0;
         o.init(s, cc);
         if (mine) o.carryIn(s, st, cc, t, T);           // the packet the channel is inside: its symbols so far, from the carry rows
+        if (dbgW && step <= 8u) s.res->dbg[step - 1u][2] = wall_clock64();
     }
     while (true)
     {
@@ -590,9 +596,15 @@ demodStream(const StreamArgs s)
                "uniform/epilogue of detect %llu, sync/match logic %llu, frame step+records+loop top %llu; calls %d\n",
                tsec[0], tsec[1], tsec[2], tsec[3], tsec[6], tsec[7], tsec[4], 0ull, tsec[8], tsec[5], o.calls);
 #endif
+    if (dbgW && step <= 8u && step > 0u) s.res->dbg[step - 1u][3] = wall_clock64();
     o.carryOut(s, st, cc, t, T, mine);
     if constexpr (!RES) break;
-    else residentStepEnd<C>(s, rm, step, sR, o, mine, mine && len - st.pos >= 2 * N, lane, wave, wsub, t);     // (stopped with samples left: a record buffer was full)
+    else
+    {
+        if (dbgW && step <= 8u) s.res->dbg[step - 1u][4] = wall_clock64();
+        residentStepEnd<C>(s, rm, step, sR, o, mine, mine && len - st.pos >= 2 * N, lane, wave, wsub, t);     // (stopped with samples left: a record buffer was full)
+        if (dbgW && step <= 8u) s.res->dbg[step - 1u][5] = wall_clock64();
+    }
     }
     if (mine && t == 0)
     {

@@ -298,6 +298,7 @@ def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B):
     rng = np.random.default_rng(1300 + sf)
     N = 1 << sf
     host = _streams(oracle, rng, sf, B, n_frames=4)
+    host = np.pad(host, ((0, 0), (0, -host.shape[1] % 16)))       # rows of whole 128-byte lines: what the resident mode asks for
     cap = host.shape[1]
     refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
     iq = gpu.from_numpy(host).cuda()
@@ -328,6 +329,7 @@ def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B):
                        lambda: d.receive(iq, w, rows[0], async_=2)):
                 with pytest.raises(L.LoraHipError):
                     fn()
+            assert d.resident_active()
             resident += 1
         # (the signal rows are one set: the next step may write them as soon as it is rung -- this test waits for a step's report by
         # ringing an empty step, so that what take() reads next is complete and nothing newer has been written over it)
