@@ -59,6 +59,9 @@ def frame_streams(ctx, n_channels, n_frames=4, nsyms=48, sigma=0.05, sync=0x12, 
     else:
         iq = base.repeat((n_channels + V - 1) // V, 1)[:n_channels].contiguous()
     del base
+    if iq.shape[1] % 16:
+        # rows of whole 128-byte lines (16 samples): what the resident receiver asks of its input (lorahip_demod_receive, async = 3)
+        iq = torch.nn.functional.pad(iq, (0, -iq.shape[1] % 16)).contiguous()
     if sigma:
         ctx.add_awgn(iq, sigma, seed=seed)
     torch.cuda.synchronize(dev)
