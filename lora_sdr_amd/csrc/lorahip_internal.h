@@ -134,7 +134,9 @@ __host__ __device__ inline unsigned residentCheck(const ResidentMsg &m)
 //! more than two steps outstanding, and the last workgroup of step k clears the set of step k + 2
 struct ResidentCtl
 {
-    ResidentMsg msg[8];                 // ring, slot = seq & 7
+    ResidentMsg msg[16][8];             // the ring's mirrors, one per group of workgroups (blockIdx & 15), slot = seq & 7: a thousand
+                                        // wavefronts polling ONE line of memory at system scope queue up behind each other for hundreds of
+                                        // microseconds (measured: profiles/r06); sixteen lines, one poller per workgroup at a time, do not
     unsigned long long doneCalls[4];    // [63:48] workgroups that finished the step, [47:0] work() calls they made
     unsigned rowCount[4], sigCount[4];  // rows handed out (may exceed the capacity: the excess was dropped and is reported)
     unsigned more[4];                   // some channel stopped because a record buffer was full

@@ -41,7 +41,12 @@ struct ResMsgR
 //! the counts the wavefronts of a workgroup leave for the one that arrives last at the end of a step (by step parity: a fast
 //! wavefront may be one step ahead of a slow one, never two -- the host rings step k + 2 only after step k has been reported)
 template <int CH>
-struct ResLds { int nPkt[2][CH], nSig[2][CH]; int calls[2], arrive[2], more[2]; };
+struct ResLds
+{
+    int nPkt[2][CH], nSig[2][CH]; int calls[2], arrive[2], more[2];
+    unsigned msgSeq[2];                 // the step whose message the workgroup holds in msg[step & 1] (whichever wavefront found it first left it there)
+    ResMsgR msg[2];
+};
 
 __device__ __forceinline__ unsigned long long uni64(const unsigned long long v)
 {
@@ -67,59 +72,87 @@ __device__ __forceinline__ bool residentRead(const ResidentMsg *g, const unsigne
     return c.check == residentCheck(c);
 }
 
-/*! Wait for the message of step `want`. Every wavefront polls for itself (the wavefronts of a workgroup are independent in the loop):
- * the MIRROR of the ring in device memory, read at system scope, i.e. from memory -- a poll costs a memory round trip and no PCIe
- * traffic --, and every 16th time the host's own ring over PCIe (the pollers are de-phased: a few of the 2048 wavefronts of a full
- * device look there at any moment). Whoever finds a message there first copies it into the mirror (several may: they write the same
- * words). A message counts only when its check word fits its fields (neither the host's stores nor the relay are atomic). Between
- * polls the wavefront sleeps. false: leave the kernel (quit message, abort flag, or nothing for s.resWatchdog ticks: every spin is
- * bounded). */
-__device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned want, ResMsgR &m)
+/*! Wait for the message of step `want`. The wavefronts of a workgroup are independent in the loop, so each waits for itself -- on a
+ * word in LDS: whichever wavefront of the workgroup finds the message first leaves it there for the others. A waiting wavefront looks
+ * at MEMORY only every fourth turn (the four take turns: about one poll per workgroup and turn): at its group's mirror of the ring in
+ * device memory (read at system scope, i.e. from memory; sixteen mirrors, see ResidentCtl), and every eighth of those polls at the
+ * host's own ring over PCIe instead. Whoever finds a message there copies it into the group's mirror. A message counts only when its
+ * check word fits its fields (neither the host's stores nor the relay are atomic). Between polls the wavefront sleeps. false: leave
+ * the kernel (quit message, abort flag, or nothing for s.resWatchdog ticks: every spin is bounded). */
+template <class RL>
+__device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned want, ResMsgR &m, RL *sR)
 {
-    ResidentMsg *g = &s.res->msg[want & 7];
+    const int par = int(want & 1u);
+    ResidentMsg *g = &s.res->msg[blockIdx.x & 15u][want & 7];
     const ResidentMsg *h = &s.resHost->msg[want & 7];
     const unsigned long long t0 = wall_clock64();
-    unsigned it = blockIdx.x * 5u + (threadIdx.x >> 6) * 3u;
-    ResidentMsg c;
-    for (;;)
+    const unsigned wave = threadIdx.x >> 6;
+    unsigned it = 0;
+    for (;; it++)
     {
-        if (residentRead(g, want, c)) break;
-        if ((it++ & 15u) == 0u)
+        if (__hip_atomic_load(&sR->msgSeq[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want)
         {
-            if (residentRead(h, want, c))
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            break;
+        }
+        if (((it + wave) & 3u) == 0u)
+        {
+            ResidentMsg c;
+            const bool fromHost = (((it >> 2) + blockIdx.x) & 7u) == 0u;
+            bool got = false;
+            if (!fromHost) got = residentRead(g, want, c);
+            else
             {
-                // relay: the fields, then the check word, then the step number (a reader that sees the number verifies the check)
-                sysStore(&g->nValid, c.nValid);
-                sysStore(reinterpret_cast<unsigned long long *>(&g->syms), (unsigned long long)(size_t)c.syms);
-                sysStore(reinterpret_cast<unsigned long long *>(&g->nsyms), (unsigned long long)(size_t)c.nsyms);
-                sysStore(reinterpret_cast<unsigned long long *>(&g->chan), (unsigned long long)(size_t)c.chan);
-                sysStore(reinterpret_cast<unsigned long long *>(&g->sigCh), (unsigned long long)(size_t)c.sigCh);
-                sysStore(reinterpret_cast<unsigned long long *>(&g->sigErr), (unsigned long long)(size_t)c.sigErr);
-                sysStore(reinterpret_cast<unsigned long long *>(&g->sigPow), (unsigned long long)(size_t)c.sigPow);
-                sysStore(reinterpret_cast<unsigned long long *>(&g->sigSnr), (unsigned long long)(size_t)c.sigSnr);
-                sysStore(&g->symStride, c.symStride); sysStore(&g->capRows, c.capRows); sysStore(&g->capSig, c.capSig); sysStore(&g->flags, c.flags);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                sysStore(&g->check, c.check);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                sysStore(&g->seq, want);
+                got = residentRead(h, want, c);
+                if (got)
+                {
+                    // relay: the fields, then the check word, then the step number (a reader that sees the number verifies the check)
+                    sysStore(&g->nValid, c.nValid);
+                    sysStore(reinterpret_cast<unsigned long long *>(&g->syms), (unsigned long long)(size_t)c.syms);
+                    sysStore(reinterpret_cast<unsigned long long *>(&g->nsyms), (unsigned long long)(size_t)c.nsyms);
+                    sysStore(reinterpret_cast<unsigned long long *>(&g->chan), (unsigned long long)(size_t)c.chan);
+                    sysStore(reinterpret_cast<unsigned long long *>(&g->sigCh), (unsigned long long)(size_t)c.sigCh);
+                    sysStore(reinterpret_cast<unsigned long long *>(&g->sigErr), (unsigned long long)(size_t)c.sigErr);
+                    sysStore(reinterpret_cast<unsigned long long *>(&g->sigPow), (unsigned long long)(size_t)c.sigPow);
+                    sysStore(reinterpret_cast<unsigned long long *>(&g->sigSnr), (unsigned long long)(size_t)c.sigSnr);
+                    sysStore(&g->symStride, c.symStride); sysStore(&g->capRows, c.capRows); sysStore(&g->capSig, c.capSig); sysStore(&g->flags, c.flags);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    sysStore(&g->check, c.check);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    sysStore(&g->seq, want);
+                }
+                else if (sysLoad(&s.resHost->abort) != 0u) return false;
+            }
+            if (got)
+            {
+                // for the workgroup's other wavefronts (and this one: it reads it back below like they do)
+                if ((threadIdx.x & 63u) == 0u)
+                {
+                    ResMsgR &d = sR->msg[par];
+                    d.nValid = c.nValid; d.syms = c.syms; d.nsyms = c.nsyms; d.chan = c.chan; d.sigCh = c.sigCh; d.sigErr = c.sigErr; d.sigPow = c.sigPow; d.sigSnr = c.sigSnr;
+                    d.symStride = c.symStride; d.capRows = c.capRows; d.capSig = c.capSig; d.flags = c.flags;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(&sR->msgSeq[par], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 break;
             }
-            if (sysLoad(&s.resHost->abort) != 0u) return false;
         }
-        if (wall_clock64() - t0 > s.resWatchdog) { sysStore(&s.res->expired, 1u); return false; }
-        __builtin_amdgcn_s_sleep(24);
+        if ((it & 63u) == 63u && wall_clock64() - t0 > s.resWatchdog) { sysStore(&s.res->expired, 1u); return false; }
+        __builtin_amdgcn_s_sleep(16);
     }
-    m.nValid = uni64(c.nValid);
-    m.syms = reinterpret_cast<unsigned short *>(uni64((unsigned long long)(size_t)c.syms));
-    m.nsyms = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.nsyms));
-    m.chan = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.chan));
-    m.sigCh = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.sigCh));
-    m.sigErr = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)c.sigErr));
-    m.sigPow = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)c.sigPow));
-    m.sigSnr = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)c.sigSnr));
-    m.symStride = (unsigned)__builtin_amdgcn_readfirstlane((int)c.symStride); m.capRows = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capRows);
-    m.capSig = (unsigned)__builtin_amdgcn_readfirstlane((int)c.capSig); m.flags = (unsigned)__builtin_amdgcn_readfirstlane((int)c.flags);
-    // No acquire fence here: at agent scope it invalidates L1 and L2 (buffer_inv sc1), and 2048 wavefronts doing that once per step cost
+    const ResMsgR &q = sR->msg[par];
+    m.nValid = uni64(q.nValid);
+    m.syms = reinterpret_cast<unsigned short *>(uni64((unsigned long long)(size_t)q.syms));
+    m.nsyms = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)q.nsyms));
+    m.chan = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)q.chan));
+    m.sigCh = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)q.sigCh));
+    m.sigErr = reinterpret_cast<int *>(uni64((unsigned long long)(size_t)q.sigErr));
+    m.sigPow = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)q.sigPow));
+    m.sigSnr = reinterpret_cast<float *>(uni64((unsigned long long)(size_t)q.sigSnr));
+    m.symStride = (unsigned)__builtin_amdgcn_readfirstlane((int)q.symStride); m.capRows = (unsigned)__builtin_amdgcn_readfirstlane((int)q.capRows);
+    m.capSig = (unsigned)__builtin_amdgcn_readfirstlane((int)q.capSig); m.flags = (unsigned)__builtin_amdgcn_readfirstlane((int)q.flags);
+    // No acquire fence at agent scope here: it invalidates L1 and L2 (buffer_inv sc1), and 2048 wavefronts doing that once per step cost
     // more than the step. What could be stale is decided by construction instead: a step works up to the last WHOLE 128-byte line of
     // every row (the host passes n_valid rounded down to 16 samples; rows start on line boundaries), so no line the kernel has ever read
     // holds samples that arrive later; the records and carry rows a workgroup reads back are its own and are read at agent scope.
@@ -278,7 +311,7 @@ demodStream(const StreamArgs s)
     const FineLds fl = fineLoadLds<C::LOG2N>(sFine, s.fineA, s.fineB, threadIdx.x, blockDim.x);
     typedef ResLds<WAVES * WPW> ResL;
     ResL *sR = reinterpret_cast<ResL *>(reinterpret_cast<char *>(sFine) + FineDims<C::LOG2N>::BYTES);        // RES only (the launcher adds the bytes)
-    if (RES && threadIdx.x < 2) { sR->calls[threadIdx.x] = 0; sR->arrive[threadIdx.x] = 0; sR->more[threadIdx.x] = 0; }
+    if (RES && threadIdx.x < 2) { sR->calls[threadIdx.x] = 0; sR->arrive[threadIdx.x] = 0; sR->more[threadIdx.x] = 0; sR->msgSeq[threadIdx.x] = 0u; }
     if constexpr (RES)
     {
         // the census: the host rings the first step only when every workgroup is on the device (one that had to wait for a slot would wait
@@ -533,7 +566,7 @@ demodStream(const StreamArgs s)
     if constexpr (RES)
     {
         if (dbgW && step < 8u) s.res->dbg[step][0] = wall_clock64();
-        if (!residentWait(s, step + 1u, rm)) break;
+        if (!residentWait(s, step + 1u, rm, sR)) break;
         if (dbgW && step < 8u) s.res->dbg[step][1] = wall_clock64();
         step++;
         len = mine ? (long long)rm.nValid : 0;
