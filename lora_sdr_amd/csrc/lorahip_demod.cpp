@@ -1490,6 +1490,7 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
         a.near = reinterpret_cast<unsigned *>(dm->sDev + H.oNear);
         a.res = R.ctl; a.resHost = static_cast<ResidentHost *>(hostDev); a.resWatchdog = kResidentWatchdog;
+        if (const char *e = std::getenv("LORAHIP_RESIDENT_SLEEP")) a.resSleep = std::atoi(e);             // (measurements: profiles/r06)
         // behind everything queued on the launch stream (the state of the run before, the cleared control block)
         LORAHIP_TRY(hipEventRecord(R.ev, ctx->stream));
         LORAHIP_TRY(hipStreamWaitEvent(R.run, R.ev, 0));

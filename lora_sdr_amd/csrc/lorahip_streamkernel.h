@@ -98,7 +98,7 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
         if (((it + wave) & 3u) == 0u)
         {
             ResidentMsg c;
-            const bool fromHost = (((it >> 2) + blockIdx.x) & 7u) == 0u;
+            const bool fromHost = (((it >> 2) + (blockIdx.x >> 4)) & 7u) == 0u;       // (the workgroups of a group look there at different turns)
             bool got = false;
             if (!fromHost) got = residentRead(g, want, c);
             else
@@ -139,7 +139,7 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
             }
         }
         if ((it & 63u) == 63u && wall_clock64() - t0 > s.resWatchdog) { sysStore(&s.res->expired, 1u); return false; }
-        __builtin_amdgcn_s_sleep(16);
+        for (int z = 0; z < s.resSleep; z++) __builtin_amdgcn_s_sleep(8);
     }
     const ResMsgR &q = sR->msg[par];
     m.nValid = uni64(q.nValid);
