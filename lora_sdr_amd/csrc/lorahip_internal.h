@@ -140,6 +140,7 @@ struct ResidentCtl
     unsigned long long doneCalls[4];    // [63:48] workgroups that finished the step, [47:0] work() calls they made
     unsigned rowCount[4], sigCount[4];  // rows handed out (may exceed the capacity: the excess was dropped and is reported)
     unsigned more[4];                   // some channel stopped because a record buffer was full
+    unsigned abortDev;                  // the host's abort flag, relayed (only the relay wavefronts read host memory)
     unsigned arrived;                   // workgroups that have started (the census: all of them must be on the device at once)
     unsigned expired;                   // a wavefront gave up waiting for a message (watchdog)
     unsigned long long dbg[8][6];       // LORAHIP_RESIDENT_DEBUG: workgroup 0, wavefront 0, steps 1..8: 100 MHz ticks at wait start, message seen,

@@ -74,11 +74,13 @@ __device__ __forceinline__ bool residentRead(const ResidentMsg *g, const unsigne
 
 /*! Wait for the message of step `want`. The wavefronts of a workgroup are independent in the loop, so each waits for itself -- on a
  * word in LDS: whichever wavefront of the workgroup finds the message first leaves it there for the others. A waiting wavefront looks
- * at MEMORY only every fourth turn (the four take turns: about one poll per workgroup and turn): at its group's mirror of the ring in
- * device memory (read at system scope, i.e. from memory; sixteen mirrors, see ResidentCtl), and every eighth of those polls at the
- * host's own ring over PCIe instead. Whoever finds a message there copies it into the group's mirror. A message counts only when its
- * check word fits its fields (neither the host's stores nor the relay are atomic). Between polls the wavefront sleeps. false: leave
- * the kernel (quit message, abort flag, or nothing for s.resWatchdog ticks: every spin is bounded). */
+ * at MEMORY only every fourth turn (the four take turns: about one poll per workgroup and turn), at its group's mirror of the ring in
+ * device memory (read at system scope, i.e. from memory; sixteen mirrors, see ResidentCtl). The HOST's ring is read by eight wavefronts
+ * only -- wavefront 0 of workgroups 0..7, whenever they wait: reads of host memory by hundreds of wavefronts (PCIe round trips, address
+ * translation) slowed every memory operation of the kernel by orders of magnitude (profiles/r06) -- and whichever of them finds a
+ * new message copies it into all sixteen mirrors, a lane per mirror. A message counts only when its check word fits its fields (neither
+ * the host's stores nor the relay are atomic). Between polls the wavefront naps. false: leave the kernel (quit message, abort flag,
+ * or nothing for s.resWatchdog ticks: every spin is bounded). */
 template <class RL>
 __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned want, ResMsgR &m, RL *sR)
 {
@@ -86,7 +88,8 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
     ResidentMsg *g = &s.res->msg[blockIdx.x & 15u][want & 7];
     const ResidentMsg *h = &s.resHost->msg[want & 7];
     const unsigned long long t0 = wall_clock64();
-    const unsigned wave = threadIdx.x >> 6;
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const bool relay = blockIdx.x < 8u && wave == 0u;
     unsigned it = 0;
     for (;; it++)
     {
@@ -95,45 +98,52 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             break;
         }
-        if (((it + wave) & 3u) == 0u)
+        if (relay || ((it + wave) & 3u) == 0u)
         {
             ResidentMsg c;
-            const bool fromHost = (((it >> 2) + (blockIdx.x >> 4)) & 7u) == 0u;       // (the workgroups of a group look there at different turns)
             bool got = false;
-            if (!fromHost) got = residentRead(g, want, c);
+            if (!relay)
+            {
+                got = residentRead(g, want, c);
+                if (!got && (it & 127u) == 127u && sysLoad(&s.res->abortDev) != 0u) return false;
+            }
             else
             {
                 got = residentRead(h, want, c);
                 if (got)
                 {
-                    // relay: the fields, then the check word, then the step number (a reader that sees the number verifies the check)
-                    sysStore(&g->nValid, c.nValid);
-                    sysStore(reinterpret_cast<unsigned long long *>(&g->syms), (unsigned long long)(size_t)c.syms);
-                    sysStore(reinterpret_cast<unsigned long long *>(&g->nsyms), (unsigned long long)(size_t)c.nsyms);
-                    sysStore(reinterpret_cast<unsigned long long *>(&g->chan), (unsigned long long)(size_t)c.chan);
-                    sysStore(reinterpret_cast<unsigned long long *>(&g->sigCh), (unsigned long long)(size_t)c.sigCh);
-                    sysStore(reinterpret_cast<unsigned long long *>(&g->sigErr), (unsigned long long)(size_t)c.sigErr);
-                    sysStore(reinterpret_cast<unsigned long long *>(&g->sigPow), (unsigned long long)(size_t)c.sigPow);
-                    sysStore(reinterpret_cast<unsigned long long *>(&g->sigSnr), (unsigned long long)(size_t)c.sigSnr);
-                    sysStore(&g->symStride, c.symStride); sysStore(&g->capRows, c.capRows); sysStore(&g->capSig, c.capSig); sysStore(&g->flags, c.flags);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    sysStore(&g->check, c.check);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    sysStore(&g->seq, want);
+                    if (lane < 16u)
+                    {
+                        // relay, a lane per mirror: the fields, then the check word, then the step number (a reader that sees the number verifies the check)
+                        ResidentMsg *q = &s.res->msg[lane][want & 7];
+                        sysStore(&q->nValid, c.nValid);
+                        sysStore(reinterpret_cast<unsigned long long *>(&q->syms), (unsigned long long)(size_t)c.syms);
+                        sysStore(reinterpret_cast<unsigned long long *>(&q->nsyms), (unsigned long long)(size_t)c.nsyms);
+                        sysStore(reinterpret_cast<unsigned long long *>(&q->chan), (unsigned long long)(size_t)c.chan);
+                        sysStore(reinterpret_cast<unsigned long long *>(&q->sigCh), (unsigned long long)(size_t)c.sigCh);
+                        sysStore(reinterpret_cast<unsigned long long *>(&q->sigErr), (unsigned long long)(size_t)c.sigErr);
+                        sysStore(reinterpret_cast<unsigned long long *>(&q->sigPow), (unsigned long long)(size_t)c.sigPow);
+                        sysStore(reinterpret_cast<unsigned long long *>(&q->sigSnr), (unsigned long long)(size_t)c.sigSnr);
+                        sysStore(&q->symStride, c.symStride); sysStore(&q->capRows, c.capRows); sysStore(&q->capSig, c.capSig); sysStore(&q->flags, c.flags);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        sysStore(&q->check, c.check);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        sysStore(&q->seq, want);
+                    }
                 }
-                else if (sysLoad(&s.resHost->abort) != 0u) return false;
+                else if (sysLoad(&s.resHost->abort) != 0u) { sysStore(&s.res->abortDev, 1u); return false; }
             }
             if (got)
             {
                 // for the workgroup's other wavefronts (and this one: it reads it back below like they do)
-                if ((threadIdx.x & 63u) == 0u)
+                if (lane == 0u)
                 {
                     ResMsgR &d = sR->msg[par];
                     d.nValid = c.nValid; d.syms = c.syms; d.nsyms = c.nsyms; d.chan = c.chan; d.sigCh = c.sigCh; d.sigErr = c.sigErr; d.sigPow = c.sigPow; d.sigSnr = c.sigSnr;
                     d.symStride = c.symStride; d.capRows = c.capRows; d.capSig = c.capSig; d.flags = c.flags;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(&sR->msgSeq[par], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0u) __hip_atomic_store(&sR->msgSeq[par], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 break;
             }
