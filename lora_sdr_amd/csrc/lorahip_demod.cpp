@@ -1399,8 +1399,8 @@ static int residentFlush(lorahip_demod *dm, size_t *nPackets, int64_t *calls)
         ResidentCtl c;
         if (hipMemcpy(&c, R.ctl, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
             for (int k = 0; k < 8; k++)
-                std::fprintf(stderr, "resident step %d (workgroup 0, wave 0; us): waited %.1f, setup %.1f, windows %.1f, carry out %.1f, step end %.1f; since step 1's wait began %.1f\n", k + 1,
-                             (c.dbg[k][1] - c.dbg[k][0]) / 100.0, (c.dbg[k][2] - c.dbg[k][1]) / 100.0, (c.dbg[k][3] - c.dbg[k][2]) / 100.0, (c.dbg[k][4] - c.dbg[k][3]) / 100.0,
+                std::fprintf(stderr, "resident step %d (workgroup 0, wave 0; us): waited %.1f, setup %.1f, windows + records %.1f, look-ahead + step end %.1f; since step 1's wait began %.1f\n", k + 1,
+                             (c.dbg[k][1] - c.dbg[k][0]) / 100.0, (c.dbg[k][2] - c.dbg[k][1]) / 100.0, (c.dbg[k][4] - c.dbg[k][2]) / 100.0,
                              (c.dbg[k][5] - c.dbg[k][4]) / 100.0, (c.dbg[k][0] - c.dbg[0][0]) / 100.0);
     }
     {

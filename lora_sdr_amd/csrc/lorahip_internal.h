@@ -206,7 +206,7 @@ struct StreamArgs
     ResidentCtl *res = nullptr;
     ResidentHost *resHost = nullptr;           // pinned host memory as the device addresses it
     unsigned long long resWatchdog = 0;        // 100 MHz ticks a wavefront waits for a message before it gives up
-    int resSleep = 2;                          // a waiting wavefront's nap between looks, in units of s_sleep 8 (512 clocks); 0: it spins
+    int resSleep = 8;                          // a waiting wavefront's nap between looks, in units of s_sleep 8 (512 clocks); 0: it spins
 };
 
 //! what the host needs to know after a streaming launch -- reduced on the device (streamSummary), so that 72 bytes cross PCIe per run

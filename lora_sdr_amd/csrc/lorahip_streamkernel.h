@@ -40,10 +40,13 @@ struct ResMsgR
 
 //! the counts the wavefronts of a workgroup leave for the one that arrives last at the end of a step (by step parity: a fast
 //! wavefront may be one step ahead of a slow one, never two -- the host rings step k + 2 only after step k has been reported)
+//! (a workgroup of the resident receiver walks up to RES_MAX_SETS channel sets per step when the receiver has more channels than one
+//! resident set of workgroups: 64 / CH at most, the scan of residentStepEnd has one lane per channel)
 template <int CH>
 struct ResLds
 {
-    int nPkt[2][CH], nSig[2][CH]; int calls[2], arrive[2], more[2];
+    static constexpr int SLOTS = 64;
+    int nPkt[2][SLOTS], nSig[2][SLOTS]; int calls[2], arrive[2], more[2];
     unsigned msgSeq[2];                 // the step whose message the workgroup holds in msg[step & 1] (whichever wavefront found it first left it there)
     ResMsgR msg[2];
 };
@@ -70,6 +73,36 @@ __device__ __forceinline__ bool residentRead(const ResidentMsg *g, const unsigne
     c.seq = want;
     c.check = sysLoad(&g->check);
     return c.check == residentCheck(c);
+}
+
+//! a message found in the host's ring into all sixteen mirrors, a lane per mirror: the fields, then the check word, then the step number
+//! (a reader that sees the number verifies the check)
+__device__ __forceinline__ void residentRelay(const StreamArgs &s, const unsigned want, const ResidentMsg &c, const unsigned lane)
+{
+    if (lane >= 16u) return;
+    ResidentMsg *q = &s.res->msg[lane][want & 7];
+    sysStore(&q->nValid, c.nValid);
+    sysStore(reinterpret_cast<unsigned long long *>(&q->syms), (unsigned long long)(size_t)c.syms);
+    sysStore(reinterpret_cast<unsigned long long *>(&q->nsyms), (unsigned long long)(size_t)c.nsyms);
+    sysStore(reinterpret_cast<unsigned long long *>(&q->chan), (unsigned long long)(size_t)c.chan);
+    sysStore(reinterpret_cast<unsigned long long *>(&q->sigCh), (unsigned long long)(size_t)c.sigCh);
+    sysStore(reinterpret_cast<unsigned long long *>(&q->sigErr), (unsigned long long)(size_t)c.sigErr);
+    sysStore(reinterpret_cast<unsigned long long *>(&q->sigPow), (unsigned long long)(size_t)c.sigPow);
+    sysStore(reinterpret_cast<unsigned long long *>(&q->sigSnr), (unsigned long long)(size_t)c.sigSnr);
+    sysStore(&q->symStride, c.symStride); sysStore(&q->capRows, c.capRows); sysStore(&q->capSig, c.capSig); sysStore(&q->flags, c.flags);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sysStore(&q->check, c.check);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sysStore(&q->seq, want);
+}
+
+//! A relay wavefront that has finished a step's windows looks for the NEXT step's message before it reports: the host rings one step
+//! ahead, so it is usually there by then, and the others find it in the mirrors the moment they finish instead of a PCIe round trip later.
+__device__ __forceinline__ void residentLookAhead(const StreamArgs &s, const unsigned next)
+{
+    if (blockIdx.x >= 8u || (threadIdx.x >> 6) != 0u) return;
+    ResidentMsg c;
+    if (residentRead(&s.resHost->msg[next & 7], next, c)) residentRelay(s, next, c, threadIdx.x & 63u);
 }
 
 /*! Wait for the message of step `want`. The wavefronts of a workgroup are independent in the loop, so each waits for itself -- on a
@@ -110,27 +143,7 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
             else
             {
                 got = residentRead(h, want, c);
-                if (got)
-                {
-                    if (lane < 16u)
-                    {
-                        // relay, a lane per mirror: the fields, then the check word, then the step number (a reader that sees the number verifies the check)
-                        ResidentMsg *q = &s.res->msg[lane][want & 7];
-                        sysStore(&q->nValid, c.nValid);
-                        sysStore(reinterpret_cast<unsigned long long *>(&q->syms), (unsigned long long)(size_t)c.syms);
-                        sysStore(reinterpret_cast<unsigned long long *>(&q->nsyms), (unsigned long long)(size_t)c.nsyms);
-                        sysStore(reinterpret_cast<unsigned long long *>(&q->chan), (unsigned long long)(size_t)c.chan);
-                        sysStore(reinterpret_cast<unsigned long long *>(&q->sigCh), (unsigned long long)(size_t)c.sigCh);
-                        sysStore(reinterpret_cast<unsigned long long *>(&q->sigErr), (unsigned long long)(size_t)c.sigErr);
-                        sysStore(reinterpret_cast<unsigned long long *>(&q->sigPow), (unsigned long long)(size_t)c.sigPow);
-                        sysStore(reinterpret_cast<unsigned long long *>(&q->sigSnr), (unsigned long long)(size_t)c.sigSnr);
-                        sysStore(&q->symStride, c.symStride); sysStore(&q->capRows, c.capRows); sysStore(&q->capSig, c.capSig); sysStore(&q->flags, c.flags);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        sysStore(&q->check, c.check);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        sysStore(&q->seq, want);
-                    }
-                }
+                if (got) residentRelay(s, want, c, lane);
                 else if (sysLoad(&s.resHost->abort) != 0u) { sysStore(&s.res->abortDev, 1u); return false; }
             }
             if (got)
@@ -176,20 +189,28 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
  * for them) -- waits for those stores, and adds the workgroup to the step's count. The workgroup that completes the count reports the
  * step to the host's pinned memory. Rows are handed out in the order the workgroups finish: a channel's packets of a step are
  * consecutive and in time order, the channels are not sorted (channel_dev says whose a row is). */
+//! a wavefront's counts of one of its channel sets (the `setIdx`-th of the workgroup in this step), for residentStepEnd
 template <class C>
-__device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMsgR &m, const unsigned step, ResLds<4 * C::WPW> *sR, const StreamOut &o, const bool mine,
-                                                const bool stopped, const int lane, const int wave, const int wsub, const int t)
+__device__ __forceinline__ void residentDeposit(ResLds<4 * C::WPW> *sR, const unsigned step, const int setIdx, const StreamOut &o, const bool mine, const int wave,
+                                                const int wsub, const int t)
+{
+    constexpr int WPW = C::WPW, CH = 4 * WPW;
+    if (t == 0)
+    {
+        sR->nPkt[step & 1u][setIdx * CH + wave * WPW + wsub] = mine ? o.nPkt : 0;
+        sR->nSig[step & 1u][setIdx * CH + wave * WPW + wsub] = (mine && o.sigOut) ? o.nSig : 0;
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMsgR &m, const unsigned step, ResLds<4 * C::WPW> *sR, int calls, const int nSetsMine,
+                                                const bool stopped, const int lane)
 {
     constexpr int WAVES = 4, WPW = C::WPW, CH = WAVES * WPW;
     static_assert(CH <= 64, "one lane per channel of the workgroup in the scan");
     const int par = int(step & 1u);
     const unsigned slot = step & 3u;
-    if (t == 0)
-    {
-        sR->nPkt[par][wave * WPW + wsub] = mine ? o.nPkt : 0;
-        sR->nSig[par][wave * WPW + wsub] = (mine && o.sigOut) ? o.nSig : 0;
-    }
-    int calls = (mine && t == 0) ? o.calls : 0;
+    const int NCH = nSetsMine * CH;                                 // channels (entries) of this workgroup in this step, <= 64
     for (int d = 32; d >= 1; d >>= 1) calls += __shfl_xor(calls, d);
     const bool anyStopped = __any(stopped);
     if (lane == 0)
@@ -203,8 +224,9 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
     if (__builtin_amdgcn_readfirstlane(arrived) != WAVES - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    const unsigned first = blockIdx.x * unsigned(CH);               // the workgroup's first channel
-    const int np = lane < CH ? sR->nPkt[par][lane] : 0, ns = lane < CH ? sR->nSig[par][lane] : 0;
+    // entry e = set index * CH + channel inside the set; the set is blockIdx.x + set index * gridDim.x
+    const auto channelOf = [](const int e) { return (blockIdx.x + unsigned(e / CH) * gridDim.x) * unsigned(CH) + unsigned(e % CH); };
+    const int np = lane < NCH ? sR->nPkt[par][lane] : 0, ns = lane < NCH ? sR->nSig[par][lane] : 0;
     int ip = np, is = ns;
     for (int d = 1; d < 64; d <<= 1) { const int a = __shfl_up(ip, d), b = __shfl_up(is, d); if (lane >= d) { ip += a; is += b; } }
     const int totP = __shfl(ip, 63), totS = __shfl(is, 63);
@@ -216,11 +238,11 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
     }
     row0 = (unsigned)__builtin_amdgcn_readfirstlane((int)row0); sig0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sig0);
     if (totP)
-        for (int ch = 0; ch < CH; ch++)
+        for (int ch = 0; ch < NCH; ch++)
         {
             const int n = __shfl(np, ch);
             if (n == 0) continue;
-            const unsigned g = first + unsigned(ch);
+            const unsigned g = channelOf(ch);
             const StreamPacket *pk = s.pktOut + (size_t)g * s.capPkt;
             const short *sy = s.symOut + (size_t)g * s.symStride;
             unsigned r = row0 + unsigned(__shfl(ip, ch) - n);
@@ -238,9 +260,9 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
                 off += ln;
             }
         }
-    if (totS && lane < CH)
+    if (totS && lane < NCH)
     {
-        const unsigned g = first + unsigned(lane);
+        const unsigned g = channelOf(lane);
         const StreamSignal *sg = s.sigOut + (size_t)g * s.capPkt;
         unsigned r = sig0 + unsigned(is - ns);
         for (int j = 0; j < ns; j++, r++)
@@ -341,6 +363,24 @@ demodStream(const StreamArgs s)
     // after the other -- the tables above are loaded once, and a launch over more channels than fit the device does not run a second,
     // half-empty round of workgroups. From here on the wavefronts of a workgroup are independent (no workgroup barrier below).
     const unsigned nSets = (s.nChannels + WAVES * WPW - 1) / (WAVES * WPW);
+    // RES: one turn of this loop per receiver step (otherwise exactly one turn). In a step the workgroup walks its channel sets --
+    // blockIdx.x, + gridDim.x, ... like a persistent grid -- with the tables it staged once; a channel's state lives in s.state between the
+    // steps (40 bytes per channel and step, against 8 N per window read).
+    unsigned step = 0;                                      // RES: the last receiver step taken
+    ResMsgR rm;
+    int resCalls = 0, setIdx = 0;
+    bool resStopped = false;
+    const bool dbgW = RES && blockIdx.x == 0 && threadIdx.x == 0;
+    for (;;)
+    {
+    if constexpr (RES)
+    {
+        if (dbgW && step < 8u) s.res->dbg[step][0] = wall_clock64();
+        if (!residentWait(s, step + 1u, rm, sR)) break;
+        if (dbgW && step < 8u) s.res->dbg[step][1] = wall_clock64();
+        step++;
+        resCalls = 0; setIdx = 0; resStopped = false;
+    }
     unsigned cset = blockIdx.x;                             // (the grid never exceeds the number of sets)
     do
     {
@@ -348,14 +388,26 @@ demodStream(const StreamArgs s)
     const unsigned c = UNI ? (unsigned)uniI(int((cset * WAVES + wave) * WPW)) : (cset * WAVES + wave) * WPW + wsub;
     const bool mine = c < s.nChannels;
     const unsigned cc = mine ? c : 0;
-    StreamState st = s.state[cc];
+    StreamState st;
+    if constexpr (RES)
+    {
+        // (what this workgroup stored a step ago: read at agent scope, an older copy of the line may still sit in the compute unit's L1)
+        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(&s.state[cc]);
+        unsigned long long w[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = agentLoad(q + i);
+        static_assert(sizeof(StreamState) == 40, "five 64-bit words");
+        __builtin_memcpy(&st, w, sizeof(st));
+    }
+    else st = s.state[cc];
     if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
     if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
     const long long base = s.uniformLen >= 0 ? (long long)cc * s.uniformStride : s.base[cc];
-    long long len = !mine ? 0 : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]);             // (RES: what the step's message says)
+    const long long len = !mine ? 0 : (RES ? (long long)rm.nValid : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]));    // (RES: what the step's message says)
     StreamOut o;
     o.init(s, cc);
-    if (!RES && mine) o.carryIn(s, st, cc, t, T);
+    if (mine) o.carryIn(s, st, cc, t, T);                   // the packet the channel is inside: its symbols so far, from the carry rows
+    if (dbgW && step <= 8u && step > 0u && setIdx == 0) s.res->dbg[step - 1u][2] = wall_clock64();
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
     // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
@@ -568,22 +620,6 @@ demodStream(const StreamArgs s)
     const int slot = wavefrontSlot();
     const bool lastRound = RES || PERSIST || !LORAHIP_PRIO_HOLD || blockIdx.x >= s.lastRoundFrom;
     holdPriority<LORAHIP_PRIO_ALTERNATE>(!lastRound);
-    unsigned step = 0;                                      // RES: the last receiver step taken
-    ResMsgR rm;
-    for (;;)                                                // RES: one turn per receiver step; otherwise exactly one turn
-    {
-    const bool dbgW = RES && blockIdx.x == 0 && threadIdx.x == 0;
-    if constexpr (RES)
-    {
-        if (dbgW && step < 8u) s.res->dbg[step][0] = wall_clock64();
-        if (!residentWait(s, step + 1u, rm, sR)) break;
-        if (dbgW && step < 8u) s.res->dbg[step][1] = wall_clock64();
-        step++;
-        len = mine ? (long long)rm.nValid : 0;
-        o.init(s, cc);
-        if (mine) o.carryIn(s, st, cc, t, T);           // the packet the channel is inside: its symbols so far, from the carry rows
-        if (dbgW && step <= 8u) s.res->dbg[step - 1u][2] = wall_clock64();
-    }
     while (true)
     {
         if (lastRound) rotatePriority<2, LORAHIP_PRIO_ALTERNATE>(slot);
@@ -639,16 +675,7 @@ demodStream(const StreamArgs s)
                "uniform/epilogue of detect %llu, sync/match logic %llu, frame step+records+loop top %llu; calls %d\n",
                tsec[0], tsec[1], tsec[2], tsec[3], tsec[6], tsec[7], tsec[4], 0ull, tsec[8], tsec[5], o.calls);
 #endif
-    if (dbgW && step <= 8u && step > 0u) s.res->dbg[step - 1u][3] = wall_clock64();
     o.carryOut(s, st, cc, t, T, mine);
-    if constexpr (!RES) break;
-    else
-    {
-        if (dbgW && step <= 8u) s.res->dbg[step - 1u][4] = wall_clock64();
-        residentStepEnd<C>(s, rm, step, sR, o, mine, mine && len - st.pos >= 2 * N, lane, wave, wsub, t);     // (stopped with samples left: a record buffer was full)
-        if (dbgW && step <= 8u) s.res->dbg[step - 1u][5] = wall_clock64();
-    }
-    }
     if (mine && t == 0)
     {
         s.state[c] = st;
@@ -658,7 +685,23 @@ demodStream(const StreamArgs s)
         if (s.nSig) s.nSig[c] = o.nSig;
         s.end[c] = make_int2(st.state == ST_DATASYMBOLS ? st.symCount : -1, st.callCount);
     }
-    } while (PERSIST && (cset += gridDim.x) < nSets);       // without PERSIST there is no loop at all (it would cost registers)
+    if constexpr (RES)
+    {
+        residentDeposit<C>(sR, step, setIdx, o, mine, wave, wsub, t);
+        resCalls += (mine && t == 0) ? o.calls : 0;
+        resStopped = resStopped || (mine && len - st.pos >= 2 * N);        // stopped with samples left: a record buffer was full
+        setIdx++;
+    }
+    } while ((PERSIST || RES) && (cset += gridDim.x) < nSets);      // without PERSIST / RES there is no loop at all (it would cost registers)
+    if constexpr (!RES) break;
+    else
+    {
+        if (dbgW && step <= 8u) s.res->dbg[step - 1u][4] = wall_clock64();
+        residentLookAhead(s, step + 1u);
+        residentStepEnd<C>(s, rm, step, sR, resCalls, setIdx, resStopped, lane);
+        if (dbgW && step <= 8u) s.res->dbg[step - 1u][5] = wall_clock64();
+    }
+    }
 }
 
 template <class C>
@@ -700,13 +743,20 @@ static hipError_t launchStreamResidentCfg(const StreamArgs &args, hipStream_t st
     static unsigned long long attrDone = 0;
     static PerDeviceCount resident;
     const unsigned perBlock = WAVES * C::WPW;
-    const unsigned grid = (args.nChannels + perBlock - 1) / perBlock;
-    if (gridOut) *gridOut = grid;
-    if (grid == 0 || grid > 4095u) return hipErrorNotSupported;
+    const unsigned nSets = (args.nChannels + perBlock - 1) / perBlock;
+    if (gridOut) *gridOut = 0;
+    if (nSets == 0) return hipErrorNotSupported;
     const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, false, true>), smem, attrDone);
     if (e != hipSuccess) return e;
     const int res = residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStream<C, false, true>), WAVES * 64, smem);
-    if (res <= 0 || grid > unsigned(res)) return hipErrorNotSupported;
+    if (res <= 0) return hipErrorNotSupported;
+    // more channel sets than the device holds workgroups: every workgroup walks several per step (at most 64 channels per workgroup and
+    // step: residentStepEnd's scan), all workgroups the same number but the last ones
+    const unsigned perWg = (nSets + unsigned(res) - 1) / unsigned(res);
+    if (perWg * perBlock > 64u) return hipErrorNotSupported;
+    const unsigned grid = (nSets + perWg - 1) / perWg;
+    if (grid > 4095u) return hipErrorNotSupported;
+    if (gridOut) *gridOut = grid;
     hipLaunchKernelGGL((demodStream<C, false, true>), dim3(grid), dim3(WAVES * 64), smem, stream, args);
     return hipGetLastError();
 }
