@@ -102,6 +102,7 @@ __device__ __forceinline__ void residentLookAhead(const StreamArgs &s, const uns
 {
     if (blockIdx.x >= 8u || (threadIdx.x >> 6) != 0u) return;
     ResidentMsg c;
+    if (sysLoad(&s.res->msg[blockIdx.x & 15u][next & 7].seq) == next) return;          // another relay wavefront has been there
     if (residentRead(&s.resHost->msg[next & 7], next, c)) residentRelay(s, next, c, threadIdx.x & 63u);
 }
 
