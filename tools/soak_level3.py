@@ -15,7 +15,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 oracle = Oracle()
 t_end = time.time() + budget
-cases = calls_total = packets_total = 0
+cases = calls_total = packets_total = signals_total = 0
+per_how = {}
 per_sf = {}
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
@@ -28,6 +29,7 @@ while time.time() < t_end:
                       sync=sync, lead=int(rng.integers(0, 3 * N)))
         streams.append(s)
     cap = max(s.size for s in streams)
+    cap += -cap % 16                                     # rows of whole 128-byte lines (what the resident receiver asks for)
     host = np.zeros((B, cap), np.complex64)
     for c, s in enumerate(streams): host[c, :s.size] = s
     refs = [oracle.demod_run(sf, host[c], sync=sync, thresh=thresh, mtu=mtu) for c in range(B)]
@@ -36,34 +38,59 @@ while time.time() < t_end:
     d.set_stream_grid(int(rng.choice([0, -1, 1, 2, 5])))
     lanes = int(rng.choice([0, -1, 4, 5, 6])) if os.environ.get("SOAK_LANES", "1") != "0" else 0     # SF7-9: more lanes per channel (lorahip_stream_lanes.hip)
     d.set_stream_lanes(lanes)
-    how = int(rng.integers(0, 3))
+    how = int(rng.integers(0, 4))                        # 0 one shot, 1 sequential steps, 2 pipelined, 3 resident (SF7-10; elsewhere ordinary steps)
+    sigs = rng.random() < 0.5                            # the block's signals (error / power / snr at DOWNCHIRP1) kept and compared too
     got = [[] for _ in range(B)]
+    got_sig = [[] for _ in range(B)]
+    d.set_signals(bool(sigs))
     if how == 0:
         d.work(iq)
+        if sigs:
+            ch_, _rd, er_, po_, sn_ = d.signals()
+            for i in range(len(ch_)): got_sig[int(ch_[i])].append((int(er_[i]), float(po_[i]), float(sn_[i])))
         for ch, _r, q in d.packets(): got[ch].append(q)
         ncalls = d.work_calls()
     else:
         rows = [d.receiver_rows(cap_packets=B * 40, stride=max(mtu, 8)) for _ in range(2)]
+        srow = d.receiver_signal_rows(B * 48, pinned_host=bool(rng.random() < 0.5)) if sigs else None
         w = k = ncalls = 0
         def take(n, r):
             torch.cuda.synchronize()
             sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
             for i in range(n): got[int(chn[i])].append(sy[i, :ns[i]].copy())
+            if sigs:
+                m = d.last_signals()
+                sc, se, sp, ss = (np.asarray(t_[:m].cpu() if hasattr(t_, "cpu") else t_[:m]) for t_ in srow)
+                for i in range(m): got_sig[int(sc[i])].append((int(se[i]), float(sp[i]), float(ss[i])))
         while w < cap:
             w = min(cap, w + int(rng.integers(N // 2, 9 * N)))
-            n, c_ = d.receive(iq, w, rows[k & 1], async_=(2 if how == 2 else True))
-            take(n, rows[k & 1]); ncalls += c_; k += 1
-        if how == 2:
-            n, c_ = d.receive_flush(rows[k & 1]); take(n, rows[k & 1]); ncalls += c_
+            n, c_ = d.receive(iq, w, rows[k & 1], async_=(how if how in (2, 3) else True))
+            # resident steps fill the rows that came with the step and report one call late: the counts returned by call k (k > 0)
+            # belong to the rows of call k - 1. The first call is an ordinary step (its own rows, at once).
+            take(n, rows[(k - 1) & 1] if (how == 3 and k > 0 and d.resident_active()) else rows[k & 1]); ncalls += c_; k += 1
+            if how == 3 and sigs and d.resident_active():
+                # (one set of signal rows: wait for the step's report with an empty step before the next one may write them)
+                n, c_ = d.receive(iq, w, rows[k & 1], async_=3); take(n, rows[(k - 1) & 1]); ncalls += c_; k += 1
+        if how in (2, 3):
+            res_ = how == 3 and d.resident_active()
+            n, c_ = d.receive_flush(rows[k & 1]); take(n, rows[(k - 1) & 1] if res_ else rows[k & 1]); ncalls += c_
+        if sigs:
+            d.receiver_signal_rows(0)
     want_calls = sum(len(r["calls"]) for r in refs)
     assert ncalls == want_calls, ("calls", seed, sf, B, how, ncalls, want_calls)
     for c, r in enumerate(refs):
         assert len(got[c]) == len(r["packets"]), ("packet count", seed, sf, c, how)
         assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), ("packet symbols", seed, sf, c, how)
         assert d.consumed(c) == int(sum(k_["consumed"] for k_ in r["calls"])), ("consumed", seed, sf, c, how)
+        if sigs:
+            assert [g[0] for g in got_sig[c]] == [int(q[0]) for q in r["signals"]], ("signal errors", seed, sf, c, how)
+            assert np.allclose([g[1:] for g in got_sig[c]], [q[1:] for q in r["signals"]], rtol=0, atol=2e-5) if got_sig[c] else True, ("signal values", seed, sf, c, how)
+            signals_total += len(got_sig[c])
     d.close()
     cases += 1; calls_total += want_calls; packets_total += sum(len(r["packets"]) for r in refs)
     per_sf[sf] = per_sf.get(sf, 0) + 1
+    per_how[how] = per_how.get(how, 0) + 1
     seed += 1
-print("level-3 soak: %d random cases (seeds up to %d; per SF %s), %d work() calls, %d packets: every channel's packets, call count and read position equal the reference's"
-      % (cases, seed - 1, dict(sorted(per_sf.items())), calls_total, packets_total))
+print("level-3 soak: %d random cases (seeds up to %d; per SF %s; per mode [one shot, sequential, pipelined, resident] %s), %d work() calls, %d packets, %d signals: every "
+      "channel's packets, call count, read position -- and signals where kept -- equal the reference's"
+      % (cases, seed - 1, dict(sorted(per_sf.items())), [per_how.get(i, 0) for i in range(4)], calls_total, packets_total, signals_total))
