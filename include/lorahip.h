@@ -400,7 +400,8 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * kernel reads them on its own, not in the order of any stream). Rows too small for a step: the excess is dropped, counted in
  * *n_packets, and the call that reports the step returns LORAHIP_E_INVALID -- size the rows for a step (one packet per channel and
  * frame that can end in it). While the kernel is resident it holds the wavefront slots of its channels -- on a full device nothing else
- * runs until the flush --, every other entry point that needs the object returns LORAHIP_E_INVALID, and every wait is bounded: a
+ * runs until the flush, and a DEVICE-wide synchronise (hipDeviceSynchronize) waits for it --, every other entry point that needs the
+ * object returns LORAHIP_E_INVALID, and every wait is bounded: a
  * wavefront that sees no message for 8 s leaves, a host call that sees no report for 5 s tells the kernel to leave and fails (the
  * object then takes ordinary steps). lorahip_demod_receive_flush(d, rows, ..) reports the last step, ends the kernel and leaves the
  * object as a streaming run leaves it.

@@ -151,7 +151,18 @@ int lorahip_create(lorahip_ctx **out, const int device, const int sf)
     do
     {
 #define LORAHIP_CK(expr) { hipError_t _e = (expr); if (_e != hipSuccess) { rc = hipFail(_e, #expr); break; } }
-        LORAHIP_CK(hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking));
+        {
+            // LORAHIP_PART_PRIORITY=1 (a measurement: profiles/r06): the stream of a context at SF11 / 12 above, at SF7 / 8 below the
+            // others -- in a mixed object the long windows' launches then get the device first and their tail starts earliest
+            static const bool byPrio = std::getenv("LORAHIP_PART_PRIORITY") != nullptr;
+            int least = 0, greatest = 0;
+            if (byPrio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            {
+                const int prio = sf >= 11 ? greatest : (sf <= 8 ? least : (least + greatest) / 2);
+                LORAHIP_CK(hipStreamCreateWithPriority(&ctx->ownStream, hipStreamNonBlocking, prio));
+            }
+            else LORAHIP_CK(hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking));
+        }
         ctx->stream = ctx->ownStream;
         LORAHIP_CK(hipEventCreate(&ctx->ev0));
         LORAHIP_CK(hipEventCreate(&ctx->ev1));

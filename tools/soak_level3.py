@@ -55,7 +55,9 @@ while time.time() < t_end:
         srow = d.receiver_signal_rows(B * 48, pinned_host=bool(rng.random() < 0.5)) if sigs else None
         w = k = ncalls = 0
         def take(n, r):
-            torch.cuda.synchronize()
+            # (never a DEVICE-wide synchronise while the resident kernel is on the device: it would wait for the flush -- and the rows of a
+            # resident step are complete in memory when the call that reports them returns)
+            if not (how == 3 and d.resident_active()): torch.cuda.synchronize()
             sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
             for i in range(n): got[int(chn[i])].append(sy[i, :ns[i]].copy())
             if sigs:
@@ -76,6 +78,7 @@ while time.time() < t_end:
             n, c_ = d.receive_flush(rows[k & 1]); take(n, rows[(k - 1) & 1] if res_ else rows[k & 1]); ncalls += c_
         if sigs:
             d.receiver_signal_rows(0)
+    print("case seed %d: SF%d, %d channels, mtu %d, mode %d, signals %s" % (seed, sf, B, mtu, how, bool(sigs)), file=sys.stderr, flush=True) if os.environ.get("SOAK_VERBOSE") else None
     want_calls = sum(len(r["calls"]) for r in refs)
     assert ncalls == want_calls, ("calls", seed, sf, B, how, ncalls, want_calls)
     for c, r in enumerate(refs):
