@@ -51,6 +51,9 @@ struct StreamOut
         // go through one L1 in order: a fence -- the wait for the stores -- orders them, and the loads are made at agent scope (they
         // read L2, where the stores have landed), so no stale L1 line can be hit.
         // An agent-scope FENCE would do too, but it writes the whole L2 back (buffer_wbl2): 90 us per launch at 2048 wavefronts.
+        // (the wait is spelled out: a workgroup-scope fence does not wait for global stores on this target -- the wavefronts of a workgroup
+        // share an L1 --, and the loads below go past the L1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (acrossWaves) __syncthreads();                           // ... and the writer's wavefront has got here: its last symbol is in L2
         if (!mine || st.state != ST_DATASYMBOLS) return;

@@ -219,7 +219,11 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
         if (calls) atomicAdd(&sR->calls[par], calls);
         if (anyStopped) sR->more[par] = 1;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the records (through L1 into L2) and the counts before the arrival
+    // The records must BE in L2 before the arrival counts: the wavefront that packs reads them at agent scope (past the L1), and a
+    // workgroup-scope release does not wait for global stores on this target (the wavefronts of a workgroup share an L1: the compiler emits
+    // no s_waitcnt vmcnt for it) -- found by the randomised soak, a packet's symbols read before they had landed (profiles/r06/s13_*)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // ... and the counts in LDS
     int arrived = 0;
     if (lane == 0) arrived = __hip_atomic_fetch_add(&sR->arrive[par], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (__builtin_amdgcn_readfirstlane(arrived) != WAVES - 1) return;

@@ -13,7 +13,16 @@
 
 namespace lorahip {
 
-static const size_t kStageBytes = size_t(32) << 20;      // per staging buffer
+//! per staging buffer: 32 MiB (LORAHIP_STAGE_MB: measurements, profiles/r06)
+static size_t stageBytes()
+{
+    static const size_t n = []() {
+        if (const char *e = std::getenv("LORAHIP_STAGE_MB")) { const long v = std::atol(e); if (v >= 1 && v <= 1024) return size_t(v) << 20; }
+        return size_t(32) << 20;
+    }();
+    return n;
+}
+#define kStageBytes (stageBytes())
 static const size_t kDirectMin = size_t(1) << 20;         // only pieces this large are asked whether they are pinned (a query per piece costs microseconds); smaller ones are packed
 
 static int uploadThreads()
