@@ -431,7 +431,10 @@ int lorahip_demod_receive(lorahip_demod *d, const float *iq_dev, size_t row_stri
  * packet is still open): cap >= cap_packets + n_channels always suffices. Rows that cannot hold what is due lose nothing: the call
  * returns LORAHIP_E_INVALID exactly as for packet rows that are too small (pipelined: packets and signals stay in the step's record
  * set; ordinary: they stay queued for lorahip_demod_get_packets / _get_signals). rows = NULL (or no rows registered): receiver steps
- * drop the signals, as before version 4. */
+ * drop the signals, as before version 4. The registration may be changed before any call, steps in flight or not (it is two pointers
+ * and a count): a caller that alternates two sets of packet rows alternates two sets of signal rows the same way. The signals a call
+ * delivers go where the registration stood AT that call (ordinary and pipelined steps); a RESIDENT step's signals go, like its packets,
+ * where the registration stood when the step was rung, and are complete when the next call reports them. */
 typedef struct lorahip_signal_rows {
     size_t struct_size;     /* = sizeof(lorahip_signal_rows) */
     int32_t *channel;       /* [cap] */

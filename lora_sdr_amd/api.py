@@ -758,6 +758,19 @@ class LoRaDemod:
         self._sig_rows = rows                                # (kept alive while registered)
         return rows
 
+    def register_signal_rows(self, rows):
+        """register a set made by receiver_signal_rows() again: a caller that alternates two sets of packet rows (pipelined consumers, the
+        resident receiver) alternates two sets of signal rows the same way, one registration before each receive()"""
+        r = _lib.SignalRows()
+        r.struct_size = C.sizeof(_lib.SignalRows)
+        if isinstance(rows[0], np.ndarray):
+            r.channel, r.error, r.power, r.snr = (a.ctypes.data for a in rows)
+        else:
+            r.channel, r.error, r.power, r.snr = (a.data_ptr() for a in rows)
+        r.cap = int(rows[0].shape[0])
+        check(self._lib.lorahip_demod_receive_signal_rows(self._h, C.byref(r)), "lorahip_demod_receive_signal_rows")
+        self._sig_rows = rows
+
     def resident_active(self):
         """True while the resident kernel of receive(async_=3) is on the device"""
         return bool(self._lib.lorahip_demod_resident_active(self._h))

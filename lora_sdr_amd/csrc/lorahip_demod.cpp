@@ -1458,11 +1458,12 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         streamCapacity(dm, nValid - dm->appendPrev + 2 * N, cap, capPkt);
         StreamLayout L;
         L.make(B, cap, capPkt, false, dm->carryCap, dm->wantSignals);
-        if (L.total > R.recBytes)
+        // (two sets of record arrays: a step writes the set of its parity -- StreamArgs::resRecStride)
+        if (2 * L.total > R.recBytes)
         {
             if (R.rec) { (void)hipFree(R.rec); R.rec = nullptr; R.recBytes = 0; }
-            LORAHIP_TRY(hipMalloc((void **)&R.rec, L.total + L.total / 4));
-            R.recBytes = L.total + L.total / 4;
+            LORAHIP_TRY(hipMalloc((void **)&R.rec, 2 * L.total + L.total / 4));
+            R.recBytes = 2 * L.total + L.total / 4;
         }
         R.lay = L;
         R.sigs = dm->wantSignals;
@@ -1489,7 +1490,7 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         a.powerScale = ctx->powerScale; a.thresh = dm->thresh; a.sync = dm->sync;
         a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
         a.near = reinterpret_cast<unsigned *>(dm->sDev + H.oNear);
-        a.res = R.ctl; a.resHost = static_cast<ResidentHost *>(hostDev); a.resWatchdog = kResidentWatchdog;
+        a.res = R.ctl; a.resHost = static_cast<ResidentHost *>(hostDev); a.resWatchdog = kResidentWatchdog; a.resRecStride = L.total;
         if (const char *e = std::getenv("LORAHIP_RESIDENT_SLEEP")) a.resSleep = std::atoi(e);             // (measurements: profiles/r06)
         // behind everything queued on the launch stream (the state of the run before, the cleared control block)
         LORAHIP_TRY(hipEventRecord(R.ev, ctx->stream));

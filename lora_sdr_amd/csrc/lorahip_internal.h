@@ -206,6 +206,9 @@ struct StreamArgs
     ResidentCtl *res = nullptr;
     ResidentHost *resHost = nullptr;           // pinned host memory as the device addresses it
     unsigned long long resWatchdog = 0;        // 100 MHz ticks a wavefront waits for a message before it gives up
+    unsigned long long resRecStride = 0;       // bytes between the two sets of record arrays (symOut / pktOut / sigOut): a step writes the set
+                                               // of its parity, so that a wavefront already in step k + 1 does not write into the rows the
+                                               // workgroup's last wavefront of step k is still packing from (found by the soak: profiles/r06/s15_*)
     int resSleep = 8;                          // a waiting wavefront's nap between looks, in units of s_sleep 8 (512 clocks); 0: it spins
 };
 

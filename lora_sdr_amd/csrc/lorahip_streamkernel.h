@@ -211,6 +211,7 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
     static_assert(CH <= 64, "one lane per channel of the workgroup in the scan");
     const int par = int(step & 1u);
     const unsigned slot = step & 3u;
+    const size_t setOff = par ? size_t(s.resRecStride) : 0;      // the record arrays of this step's parity
     const int NCH = nSetsMine * CH;                                 // channels (entries) of this workgroup in this step, <= 64
     for (int d = 32; d >= 1; d >>= 1) calls += __shfl_xor(calls, d);
     const bool anyStopped = __any(stopped);
@@ -248,8 +249,8 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
             const int n = __shfl(np, ch);
             if (n == 0) continue;
             const unsigned g = channelOf(ch);
-            const StreamPacket *pk = s.pktOut + (size_t)g * s.capPkt;
-            const short *sy = s.symOut + (size_t)g * s.symStride;
+            const StreamPacket *pk = reinterpret_cast<const StreamPacket *>(reinterpret_cast<const char *>(s.pktOut + (size_t)g * s.capPkt) + setOff);
+            const short *sy = reinterpret_cast<const short *>(reinterpret_cast<const char *>(s.symOut + (size_t)g * s.symStride) + setOff);
             unsigned r = row0 + unsigned(__shfl(ip, ch) - n);
             int off = 0;
             for (int j = 0; j < n; j++, r++)
@@ -268,7 +269,7 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
     if (totS && lane < NCH)
     {
         const unsigned g = channelOf(lane);
-        const StreamSignal *sg = s.sigOut + (size_t)g * s.capPkt;
+        const StreamSignal *sg = reinterpret_cast<const StreamSignal *>(reinterpret_cast<const char *>(s.sigOut + (size_t)g * s.capPkt) + setOff);
         unsigned r = sig0 + unsigned(is - ns);
         for (int j = 0; j < ns; j++, r++)
             if (r < m.capSig)
@@ -411,6 +412,14 @@ demodStream(const StreamArgs s)
     const long long len = !mine ? 0 : (RES ? (long long)rm.nValid : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]));    // (RES: what the step's message says)
     StreamOut o;
     o.init(s, cc);
+    if constexpr (RES)
+    {
+        // the record arrays of this step's parity (see StreamArgs::resRecStride)
+        const size_t setOff = (step & 1u) ? size_t(s.resRecStride) : 0;
+        o.symOut = reinterpret_cast<short *>(reinterpret_cast<char *>(o.symOut) + setOff);
+        o.pktOut = reinterpret_cast<StreamPacket *>(reinterpret_cast<char *>(o.pktOut) + setOff);
+        if (o.sigOut) o.sigOut = reinterpret_cast<StreamSignal *>(reinterpret_cast<char *>(o.sigOut) + setOff);
+    }
     if (mine) o.carryIn(s, st, cc, t, T);                   // the packet the channel is inside: its symbols so far, from the carry rows
     if (dbgW && step <= 8u && step > 0u && setIdx == 0) s.res->dbg[step - 1u][2] = wall_clock64();
 

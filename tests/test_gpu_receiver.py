@@ -306,10 +306,11 @@ def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B):
     d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
     d.set_signals(True)
     rows = [d.receiver_rows(cap_packets=4 * B, stride=16) for _ in range(2)]
-    sig = d.receiver_signal_rows(8 * B, pinned_host=True)          # (one set: read before the next step can write -- see take())
+    # two sets of signal rows, alternating with the packet rows (a step's signals go where its packets go: with ITS call's registration)
+    sigs = [d.receiver_signal_rows(8 * B, pinned_host=True) for _ in range(2)]
     got, got_sig, calls, w, k = [[] for _ in range(B)], [[] for _ in range(B)], 0, 0, 0
 
-    def take(n, r):
+    def take(n, r, sig):
         # the rows of the call BEFORE the one that returned n (resident steps), or of this call (the ordinary first step)
         sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
         for i in range(n):
@@ -319,9 +320,10 @@ def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B):
     resident = 0
     while w < cap:
         w = min(cap, w + int(rng.integers(N // 2, 6 * N)))
+        d.register_signal_rows(sigs[k & 1])
         n, c_ = d.receive(iq, w, rows[k & 1], async_=3)
         # the first call is an ordinary step (its own rows, at once); from the second on the counts are the previous step's
-        take(n, rows[k & 1] if k == 0 else rows[(k - 1) & 1])
+        take(n, rows[k & 1], sigs[k & 1]) if k == 0 else take(n, rows[(k - 1) & 1], sigs[(k - 1) & 1])
         calls += c_
         k += 1
         if k == 4:
@@ -331,15 +333,8 @@ def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B):
                     fn()
             assert d.resident_active()
             resident += 1
-        # (the signal rows are one set: the next step may write them as soon as it is rung -- this test waits for a step's report by
-        # ringing an empty step, so that what take() reads next is complete and nothing newer has been written over it)
-        if k >= 2:
-            n, c_ = d.receive(iq, w, rows[k & 1], async_=3)
-            take(n, rows[(k - 1) & 1])
-            calls += c_
-            k += 1
     n, c_ = d.receive_flush(rows[k & 1])
-    take(n, rows[(k - 1) & 1])
+    take(n, rows[(k - 1) & 1], sigs[(k - 1) & 1])
     calls += c_
     assert resident == 1 and k > 8
     for c in range(B):

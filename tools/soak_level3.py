@@ -52,9 +52,10 @@ while time.time() < t_end:
         ncalls = d.work_calls()
     else:
         rows = [d.receiver_rows(cap_packets=B * 40, stride=max(mtu, 8)) for _ in range(2)]
-        srow = d.receiver_signal_rows(B * 48, pinned_host=bool(rng.random() < 0.5)) if sigs else None
+        pin_ = bool(rng.random() < 0.5)
+        srows = [d.receiver_signal_rows(B * 48, pinned_host=pin_) for _ in range(2)] if sigs else None      # two sets, alternating like the packet rows
         w = k = ncalls = 0
-        def take(n, r):
+        def take(n, r, srow=None):
             # (never a DEVICE-wide synchronise while the resident kernel is on the device: it would wait for the flush -- and the rows of a
             # resident step are complete in memory when the call that reports them returns)
             if not (how == 3 and d.resident_active()): torch.cuda.synchronize()
@@ -66,16 +67,16 @@ while time.time() < t_end:
                 for i in range(m): got_sig[int(sc[i])].append((int(se[i]), float(sp[i]), float(ss[i])))
         while w < cap:
             w = min(cap, w + int(rng.integers(N // 2, 9 * N)))
+            if sigs: d.register_signal_rows(srows[k & 1])
             n, c_ = d.receive(iq, w, rows[k & 1], async_=(how if how in (2, 3) else True))
             # resident steps fill the rows that came with the step and report one call late: the counts returned by call k (k > 0)
-            # belong to the rows of call k - 1. The first call is an ordinary step (its own rows, at once).
-            take(n, rows[(k - 1) & 1] if (how == 3 and k > 0 and d.resident_active()) else rows[k & 1]); ncalls += c_; k += 1
-            if how == 3 and sigs and d.resident_active():
-                # (one set of signal rows: wait for the step's report with an empty step before the next one may write them)
-                n, c_ = d.receive(iq, w, rows[k & 1], async_=3); take(n, rows[(k - 1) & 1]); ncalls += c_; k += 1
+            # belong to the rows (packets and signals) of call k - 1. The first call is an ordinary step (its own rows, at once).
+            j = (k - 1) & 1 if (how == 3 and k > 0 and d.resident_active()) else k & 1
+            take(n, rows[j], srows[j] if sigs else None); ncalls += c_; k += 1
         if how in (2, 3):
-            res_ = how == 3 and d.resident_active()
-            n, c_ = d.receive_flush(rows[k & 1]); take(n, rows[(k - 1) & 1] if res_ else rows[k & 1]); ncalls += c_
+            j = (k - 1) & 1 if (how == 3 and d.resident_active()) else k & 1
+            if sigs and not (how == 3 and d.resident_active()): d.register_signal_rows(srows[k & 1])
+            n, c_ = d.receive_flush(rows[k & 1]); take(n, rows[j], srows[j] if sigs else None); ncalls += c_
         if sigs:
             d.receiver_signal_rows(0)
     print("case seed %d: SF%d, %d channels, mtu %d, mode %d, signals %s" % (seed, sf, B, mtu, how, bool(sigs)), file=sys.stderr, flush=True) if os.environ.get("SOAK_VERBOSE") else None
