@@ -30,21 +30,41 @@ print("seed %d: SF%d B %d mtu %d thresh %.1f grid %d lanes %d how %d sigs %s; %d
 iq = torch.from_numpy(host).cuda(); torch.cuda.synchronize()
 d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(mtu); d.setThreshold(thresh); d.setSync(sync); d.set_stream_grid(grid); d.set_stream_lanes(lanes)
 rows = [d.receiver_rows(cap_packets=B * 40, stride=max(mtu, 8)) for _ in range(2)]
+d.set_signals(sigs)
+pin_ = bool(int(ov.get("pin", 0)))
+srows = [d.receiver_signal_rows(B * 48, pinned_host=pin_) for _ in range(2)] if sigs else None
 got = [[] for _ in range(B)]
+got_sig = [[] for _ in range(B)]
 log = []
-def take(n, r, tag):
+def take(n, r, tag, srow=None):
+    if not (how == 3 and d.resident_active()): torch.cuda.synchronize()
     sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
     for i in range(n):
         got[int(chn[i])].append(sy[i, :ns[i]].copy()); log.append((tag, int(chn[i]), int(ns[i])))
+    if sigs:
+        m = d.last_signals()
+        sc, se, sp, ss = (np.asarray(t_[:m].cpu() if hasattr(t_, "cpu") else t_[:m]) for t_ in srow)
+        for i in range(m): got_sig[int(sc[i])].append((int(se[i]), float(sp[i]), float(ss[i]), tag))
 k = 0
 for w in steps:
+    if sigs: d.register_signal_rows(srows[k & 1])
     n, c_ = d.receive(iq, w, rows[k & 1], async_=(how if how in (2, 3) else True))
     res = how == 3 and d.resident_active()
-    take(n, rows[(k - 1) & 1] if (res and k > 0) else rows[k & 1], "call %d (w %d)%s" % (k, w, " resident" if res else "")); k += 1
+    j = (k - 1) & 1 if (res and k > 0) else k & 1
+    take(n, rows[j], "call %d (w %d)%s" % (k, w, " resident" if res else ""), srows[j] if sigs else None); k += 1
 if how in (2, 3):
     res = how == 3 and d.resident_active()
-    n, c_ = d.receive_flush(rows[k & 1]); take(n, rows[(k - 1) & 1] if res else rows[k & 1], "flush")
+    j = (k - 1) & 1 if res else k & 1
+    if sigs and not res: d.register_signal_rows(srows[k & 1])
+    n, c_ = d.receive_flush(rows[k & 1]); take(n, rows[j], "flush", srows[j] if sigs else None)
 bad = 0
+if sigs:
+    for c, r in enumerate(refs):
+        g, wv = got_sig[c], r["signals"]
+        if len(g) != len(wv): print("channel %d: %d signals, reference %d" % (c, len(g), len(wv))); bad += 1; continue
+        for j, (a, b) in enumerate(zip(g, wv)):
+            if a[0] != int(b[0]) or abs(a[1] - b[1]) > 2e-5 or abs(a[2] - b[2]) > 2e-5:
+                bad += 1; print("channel %d signal %d: got error %d power %.6f snr %.6f (%s), want %d %.6f %.6f" % (c, j, a[0], a[1], a[2], a[3], int(b[0]), b[1], b[2]))
 for c, r in enumerate(refs):
     if len(got[c]) != len(r["packets"]): print("channel %d: %d packets, reference %d" % (c, len(got[c]), len(r["packets"]))); bad += 1; continue
     for j, (a, (_, b)) in enumerate(zip(got[c], r["packets"])):
