@@ -89,8 +89,9 @@ while time.time() < t_end:
         if sigs:
             assert [g[0] for g in got_sig[c]] == [int(q[0]) for q in r["signals"]], ("signal errors", seed, sf, c, how)
             if got_sig[c]:
-                dv_ = np.abs(np.array([g[1:] for g in got_sig[c]], np.float64) - np.array([q[1:] for q in r["signals"]], np.float64))
-                assert dv_.max() <= 2e-5, ("signal values", seed, sf, c, how, float(dv_.max()), [g[1:] for g in got_sig[c]], [tuple(q[1:]) for q in r["signals"]])
+                # (a silent window at DOWNCHIRP1 gives power -inf and snr NaN in the reference too: equal non-finite values are equal)
+                assert np.allclose(np.array([g[1:] for g in got_sig[c]], np.float64), np.array([q[1:] for q in r["signals"]], np.float64), rtol=0, atol=2e-5, equal_nan=True), \
+                    ("signal values", seed, sf, c, how, [g[1:] for g in got_sig[c]], [tuple(q[1:]) for q in r["signals"]])
             signals_total += len(got_sig[c])
     d.close()
     cases += 1; calls_total += want_calls; packets_total += sum(len(r["packets"]) for r in refs)
