@@ -12,7 +12,9 @@ With N > 1 every rank demodulates its own channels (independent units, no data-p
 value is the whole-job aggregate. The CPU legs (cpu_baseline, the oracle checks) run on rank 0, on its own shard, after the timed
 regions, while the other ranks wait at a host-side (gloo) barrier; every rank also holds a sample of its shard to the oracle.
 
-Rank 0 prints ONE JSON line. Besides the contract fields it carries
+Rank 0 prints ONE JSON line -- the COMPACT form of the result (compact_line: under LINE_LIMIT = 8000 bytes; round 5's 20.8 KB line was lost by the
+driver's reader): the contract keys, roofline, cpu_baseline and oracle as they are, one short row per SF of every sweep (level3 by columns). The FULL
+sections go out first, one `SECTION <name> {...}` line each, and into gpurun_out/bench_sections.json. Besides the contract fields the result carries
   roofline      HBM roofline of the detect kernel: algorithmic bytes/launch (8*2^SF+14 per window) /
                 average launch duration measured with HIP events on the launch stream inside the C ABI
   cpu_baseline  the reference CPU path (oracle/_ref: the real LoRaDemod.cpp + kissfft compiled in place) timed on this
@@ -20,7 +22,9 @@ Rank 0 prints ONE JSON line. Besides the contract fields it carries
   per_sf        the metric is "per SF": the same measurement at SF7..12 (SF12 = BASELINE configs[2], 1024 channels), each
                 with its roofline fraction, a CPU baseline, and ALL windows of the batch compared with the CPU oracle
   moving        the locked-receiver batch shape (every window its own fine-tune error and start index, LoRaDemod.cpp:160-162)
-  level3        whole LoRaDemod blocks (frame sync, frequency estimate, packets) through the streaming kernel, end to end
+  level3        whole LoRaDemod blocks (frame sync, frequency estimate, packets) through the streaming kernel, end to end; `running`: the same
+                capture arriving in chunks of 128 / 8 windows through lorahip_demod_receive -- sequential, pipelined (async = 2), with the block's
+                signals delivered, and RESIDENT (async = 3: one kernel launch across the steps)
   config5       BASELINE configs[4]: SF10, 8192 channels x 64 windows at -10 dB SNR, symbol error rate GPU and CPU
   mixed         BASELINE configs[3]: 16384 channels, SF = 7 + c mod 6, byte-weighted shards, symbols gathered over RCCL
 Single-shape runs for profiling: --sf S [--moving] [--alias-windows] [--fine-gather]; --config mixed runs configs[3] alone.
