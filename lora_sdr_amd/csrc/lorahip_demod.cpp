@@ -2586,6 +2586,12 @@ int lorahip_demod_consumed_all(const lorahip_demod *dm, int64_t *out)
 {
     if (dm == nullptr || out == nullptr) return LORAHIP_E_INVALID;
     if (dm->comp) return dm->comp->consumedAll(out);
+    // (while the resident kernel is on the device the positions live in its steps; a copy queued behind it could wait for the flush)
+    if (dm->pipe && static_cast<const Pipe *>(dm->pipe)->res.active)
+    {
+        setLastError("the resident kernel is on the device: lorahip_demod_receive_flush first");
+        return LORAHIP_E_INVALID;
+    }
     // the one read that can fail -- the per-channel state back from the device -- up front: an error is the call's, not a negative
     // entry a caller would take for "nothing consumed"
     if (dm->mirrorsStale && dm->posOnDevice && dm->sHost)
