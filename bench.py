@@ -146,6 +146,7 @@ def compact_line(full):
                 ("chunk8_with_signals_frac", ("running", "chunk8", "with_signals", "frac")),
                 ("chunk8_with_signals_pipelined_frac", ("running", "chunk8", "with_signals", "pipelined", "frac")),
                 ("chunk8_resident_Msym_s", ("running", "chunk8", "resident", "Msym_s")), ("chunk8_resident_frac", ("running", "chunk8", "resident", "frac")),
+                ("chunk8_resident_depth3_Msym_s", ("running", "chunk8", "resident_depth3", "Msym_s")), ("chunk8_resident_depth3_frac", ("running", "chunk8", "resident_depth3", "frac")),
                 ("chunk8_resident_kernel", ("running", "chunk8", "resident", "kernel_resident")),
                 ("chunk8_resident_same_packets", ("running", "chunk8", "resident", "same_packets_as_one_shot")),
                 ("pothos_ports_off", ("pothos_block", "ports_off", "Msym_s")), ("pothos_pinned_input_slabs", ("pothos_block", "ports_off_pinned_input_slabs", "Msym_s")),
@@ -155,6 +156,7 @@ def compact_line(full):
         for e in full["level3"]:
             for where, v in (("", e.get("error")), ("parity", e.get("parity_error")), ("running", _get(e, "running", "error")),
                              ("resident128", _get(e, "running", "resident", "error")), ("resident", _get(e, "running", "chunk8", "resident", "error")),
+                             ("resident_depth3", _get(e, "running", "chunk8", "resident_depth3", "error")),
                              ("pothos_block", _get(e, "pothos_block", "error"))):
                 if v:
                     errs["sf%s %s" % (e.get("sf"), where)] = str(v)[:100]
@@ -836,9 +838,11 @@ def section_level3(env, L, sf, threads=32):
                 "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)), "packets": int(rb[2])}
         # RESIDENT steps (async = 3): one kernel launch stays on the device, a step is a 104-byte message and two words back; the kernel packs
         # the packets itself into the rows that came with the step (two sets, alternating). SF7-10; elsewhere the calls are ordinary steps.
-        rows_b_ = d.receiver_rows(cap_packets=B * (frames + 1), stride=max(8, min(nsyms, 512)))
+        # (`depth`: how many steps the receiver may run ahead of the last report -- a step ends with its slowest workgroup, with more steps
+        # in flight the fast ones work ahead; the caller cycles depth + 1 sets of rows)
+        rows_set_ = [rows_] + [d.receiver_rows(cap_packets=B * (frames + 1), stride=max(8, min(nsyms, 512))) for _ in range(3)]
 
-        def resident_pass(chunk_windows):
+        def resident_pass(chunk_windows, depth_):
             chunk = chunk_windows << sf
             d.clear_packets()
             d.rewind()
@@ -849,25 +853,26 @@ def section_level3(env, L, sf, threads=32):
             t0 = time.perf_counter()
             while w < cap_:
                 w = min(cap_, w + chunk)
-                n_, c_ = d.receive(iq, w, (rows_, rows_b_)[k_ & 1], async_=3, order_with_torch=False)
+                n_, c_ = d.receive(iq, w, rows_set_[k_ % (depth_ + 1)], async_=3, order_with_torch=False, depth=depth_)
                 n_pk_ += n_
                 calls_ += c_
                 n_work += 1
                 k_ += 1
             was_ = d.resident_active()
-            n_, c_ = d.receive_flush((rows_, rows_b_)[k_ & 1])
+            n_, c_ = d.receive_flush(rows_set_[k_ % (depth_ + 1)])
             (dt_,) = env.max_over_ranks(time.perf_counter() - t0)
             (calls_all_, pk_all_) = env.sum_over_ranks(calls_ + c_, n_pk_ + n_)
             return dt_, calls_all_, pk_all_, n_work, was_
-        for cw in (128, 8):
+        for cw, depth_, key_ in ((128, 1, "resident"), (8, 1, "resident"), (8, 3, "resident_depth3")):
+            tgt_ = running if cw == 128 else running["chunk8"]
             try:
-                resident_pass(cw)
-                rb = min((resident_pass(cw) for _ in range(3)), key=lambda r_: r_[0])
-                (running if cw == 128 else running["chunk8"])["resident"] = {
-                    "ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6), "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)),
-                    "packets": int(rb[2]), "kernel_resident": bool(rb[4]), "same_packets_as_one_shot": bool(rb[2] == n_dev * env.world)}
+                resident_pass(cw, depth_)
+                rb = min((resident_pass(cw, depth_) for _ in range(3)), key=lambda r_: r_[0])
+                tgt_[key_] = {"ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6),
+                              "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)), "packets": int(rb[2]), "kernel_resident": bool(rb[4]),
+                              "steps_in_flight": depth_, "same_packets_as_one_shot": bool(rb[2] == n_dev * env.world)}
             except Exception as e:
-                (running if cw == 128 else running["chunk8"])["resident"] = {"error": repr(e)[:160]}
+                tgt_[key_] = {"error": repr(e)[:160]}
                 try:
                     d.receive_flush(None)
                 except Exception:

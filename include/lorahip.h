@@ -68,7 +68,7 @@ int lorahip_version(void);                  /* ABI version, currently 4 (1 -> 2:
                                                _set_stream_lanes / _stream_lanes, _set_stream_grid, _set_variant, _set_record_capacity,
                                                lorahip_decode_packets_host, lorahip_decode_max_symbols, lorahip_decode_max_data_length, lorahip_demod_receive_signal_rows /
                                                _receive_num_signals: signals in receiver steps, pipelined ones included; async = 3: the resident receiver,
-                                               lorahip_demod_resident_active) */
+                                               lorahip_demod_resident_active, lorahip_demod_receive_steps) */
 int lorahip_device_count(void);             /* number of usable gfx950 devices, 0 if none */
 int lorahip_selfcheck(void);                /* host-only: the kernels' compile-time LDS layouts are consistent; no device needed */
 
@@ -395,7 +395,7 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * step's call, and the last workgroup reports two words to pinned host memory: no launch, no helper kernel per step. So: the rows
  * passed to call k are filled by step k and are complete -- in memory, for any stream, a copy engine or, if they are pinned host
  * memory, the host -- when call k + 1 (or lorahip_demod_receive_flush) returns with their *n_packets; keep two sets of rows and
- * alternate. Rows are handed out in the order the workgroups finish: a channel's packets of a step are consecutive and in time order,
+ * alternate (with a depth d > 1, `reserved` below: call k + d reports them, d + 1 sets). Rows are handed out in the order the workgroups finish: a channel's packets of a step are consecutive and in time order,
  * channels are not sorted (channel_dev says whose a row is). The samples up to n_valid must BE in iq_dev when the call is made (the
  * kernel reads them on its own, not in the order of any stream). Rows too small for a step: the excess is dropped, counted in
  * *n_packets, and the call that reports the step returns LORAHIP_E_INVALID -- size the rows for a step (one packet per channel and
@@ -417,7 +417,10 @@ typedef struct lorahip_packet_rows {
     int32_t *channel_dev;                        /* [cap_packets], nullable */
     size_t cap_packets;
     int32_t async;          /* 0 wait, 1 rows valid in stream order, 2 pipelined, 3 resident (see above) */
-    int32_t reserved;
+    int32_t reserved;       /* async = 3, at the call that starts the resident kernel: the DEPTH, 0 / 1 (default) .. 3 -- how many steps the
+                               receiver may run ahead of the last report. Call k then reports step k - depth (the rows of call k - depth),
+                               the flush everything left, and the caller cycles depth + 1 sets of rows. A step ends with its slowest
+                               workgroup; with more steps in flight the fast ones work ahead instead of waiting for it. Otherwise 0. */
 } lorahip_packet_rows;
 int lorahip_demod_receive(lorahip_demod *d, const float *iq_dev, size_t row_stride, size_t n_valid, const lorahip_packet_rows *rows,
                           size_t *n_packets, int64_t *work_calls);
@@ -448,6 +451,9 @@ size_t lorahip_demod_receive_num_signals(const lorahip_demod *d);
 int lorahip_demod_receive_flush(lorahip_demod *d, const lorahip_packet_rows *rows /* nullable: the last step's packets are dropped */,
                                 size_t *n_packets, int64_t *work_calls);
 int lorahip_demod_resident_active(const lorahip_demod *d);      /* 1 while the resident kernel (async = 3) is on the device */
+/* The resident steps the LAST receive / flush call reported, oldest first: packets[i] / signals[i] of each (the call's *n_packets is
+ * their sum). A receive call reports at most one; a flush at a depth d > 1 up to d, each in the rows of its own call. Returns how many. */
+size_t lorahip_demod_receive_steps(const lorahip_demod *d, size_t *packets, size_t *signals, size_t cap);
 
 /* The block's signals "error" (int), "power" (float), "snr" (float), emitted once per packet at DOWNCHIRP1 (LoRaDemod.cpp:85-87,
  * 267-269), WITHOUT a per-call trace: with enable = 1 the following runs keep one record per emission -- the kernels evaluate

@@ -137,6 +137,7 @@ SIGNATURES = {
     "lorahip_demod_receive_signal_rows": (C.c_int, [C.c_void_p, C.POINTER(SignalRows)]),
     "lorahip_demod_receive_num_signals": (C.c_size_t, [C.c_void_p]),
     "lorahip_demod_resident_active": (C.c_int, [C.c_void_p]),
+    "lorahip_demod_receive_steps": (C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t]),
     "lorahip_demod_set_signals": (C.c_int, [C.c_void_p, C.c_int]),
     "lorahip_demod_num_signals": (C.c_size_t, [C.c_void_p]),
     "lorahip_demod_get_signals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -771,6 +771,13 @@ class LoRaDemod:
         check(self._lib.lorahip_demod_receive_signal_rows(self._h, C.byref(r)), "lorahip_demod_receive_signal_rows")
         self._sig_rows = rows
 
+    def last_steps(self):
+        """the resident steps the last receive() / receive_flush() reported, oldest first: [(packets, signals)] (a flush at depth > 1
+        reports several, each in the rows of its own call)"""
+        pk, sg = (C.c_size_t * 4)(), (C.c_size_t * 4)()
+        n = int(self._lib.lorahip_demod_receive_steps(self._h, pk, sg, 4))
+        return [(int(pk[i]), int(sg[i])) for i in range(n)]
+
     def resident_active(self):
         """True while the resident kernel of receive(async_=3) is on the device"""
         return bool(self._lib.lorahip_demod_resident_active(self._h))
@@ -779,15 +786,15 @@ class LoRaDemod:
         """signals the last receive() / receive_flush() delivered into the registered signal rows"""
         return int(self._lib.lorahip_demod_receive_num_signals(self._h))
 
-    def _rows_struct(self, rows, async_):
+    def _rows_struct(self, rows, async_, depth=0):
         syms, nsyms, chan = rows
         r = _lib.PacketRows()
         r.struct_size = C.sizeof(_lib.PacketRows)
         r.syms_dev, r.sym_stride, r.nsyms_dev, r.channel_dev = syms.data_ptr(), int(syms.shape[1]), nsyms.data_ptr(), chan.data_ptr()
-        r.cap_packets, r.async_ = int(syms.shape[0]), int(async_)
+        r.cap_packets, r.async_, r.reserved = int(syms.shape[0]), int(async_), int(depth)
         return r
 
-    def receive(self, buf, n_valid, rows, async_=True, order_with_torch=True):
+    def receive(self, buf, n_valid, rows, async_=True, order_with_torch=True, depth=1):
         """lorahip_demod_receive: one receiver step in one call into the library -- the append run, the completed packets packed into
         `rows` (receiver_rows()) on the device, the queue cleared. Returns (n_packets, work_calls). async_: False = wait; True = the
         rows are valid in the order of the stream the object launches on; 2 = PIPELINED: the step is launched and the packets of
@@ -798,11 +805,12 @@ class LoRaDemod:
         (lorahip_demod_stream_wait) -- work queued on it after this call sees the rows. order_with_torch=False leaves both out (two
         event records and two stream waits per step): for a caller that orders its own streams, or times the C entry itself."""
         import torch
-        r = self._rows_struct(rows, async_ if async_ in (2, 3) else int(bool(async_)))
+        r = self._rows_struct(rows, async_ if async_ in (2, 3) else int(bool(async_)), depth if async_ == 3 else 0)
         n, calls = C.c_size_t(), C.c_int64()
         if async_ == 3:
             # RESIDENT: one kernel stays on the device and takes the steps as messages. The rows passed here are filled by THIS step and
-            # are complete when the NEXT receive() / receive_flush() returns (whose counts are this step's). The kernel reads `buf` on its
+            # are complete when the receive() `depth` calls later (default: the NEXT one) or receive_flush() returns (whose counts are this
+            # step's): cycle depth + 1 sets of rows. The kernel reads `buf` on its
             # own: what produced the new samples must have finished (order_with_torch: torch's current stream is waited for).
             if order_with_torch:
                 torch.cuda.current_stream(buf.device).synchronize()

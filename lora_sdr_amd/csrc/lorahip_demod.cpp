@@ -1020,6 +1020,8 @@ struct Pipe
         bool lastMore;                  // the last reported step left a channel with samples it could not record
         bool sigs;                      // the launch keeps signal records
         bool tail;                      // the last step left fewer than 16 valid samples per row untouched (the flush's ordinary step takes them)
+        unsigned nRep; size_t repPk[RES_DEPTH_MAX + 1], repSg[RES_DEPTH_MAX + 1];   // the steps the last call reported, oldest first (lorahip_demod_receive_steps)
+        unsigned depth;                 // steps the caller lets the receiver run ahead of the last report (1 .. RES_DEPTH_MAX): it has depth + 1 sets of rows
     } res;
 };
 static Pipe &pipeOf(lorahip_demod *dm) { return *static_cast<Pipe *>(dm->pipe); }
@@ -1324,7 +1326,7 @@ static int residentRing(lorahip_demod *dm, const size_t nValid, const lorahip_pa
 static int residentReport(lorahip_demod *dm, const unsigned k, size_t *packets, size_t *signals, int64_t *calls, unsigned *flags)
 {
     Pipe::Resident &R = pipeOf(dm).res;
-    volatile unsigned long long *h = R.host->sum + 2 * (k & 3);
+    volatile unsigned long long *h = R.host->sum + 2 * (k & 7);
     typedef std::chrono::steady_clock Clock;
     const Clock::time_point t0 = Clock::now();
     unsigned spins = 0;
@@ -1369,12 +1371,14 @@ static int residentFlush(lorahip_demod *dm, size_t *nPackets, int64_t *calls)
     int64_t cl = 0;
     unsigned fl = 0;
     bool lost = false;
+    R.nRep = 0;
     while (R.reported < R.seq)
     {
         size_t p1 = 0, s1 = 0; int64_t c1 = 0;
         const int rc = residentReport(dm, R.reported + 1, &p1, &s1, &c1, &fl);
         if (rc != LORAHIP_OK) { residentAbort(dm); return rc; }
         R.reported++;
+        if (R.nRep <= RES_DEPTH_MAX) { R.repPk[R.nRep] = p1; R.repSg[R.nRep] = dm->sigRowsOn ? s1 : 0; R.nRep++; }
         pk += p1; sg += s1; cl += c1;
         dm->workCalls += c1;
         lost = lost || (fl & (RES_F_PKT_OVERFLOW | RES_F_SIG_OVERFLOW));
@@ -1458,12 +1462,12 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         streamCapacity(dm, nValid - dm->appendPrev + 2 * N, cap, capPkt);
         StreamLayout L;
         L.make(B, cap, capPkt, false, dm->carryCap, dm->wantSignals);
-        // (two sets of record arrays: a step writes the set of its parity -- StreamArgs::resRecStride)
-        if (2 * L.total > R.recBytes)
+        // (RES_RING sets of record arrays: a step writes set step & 3 -- StreamArgs::resRecStride)
+        if (RES_RING * L.total > R.recBytes)
         {
             if (R.rec) { (void)hipFree(R.rec); R.rec = nullptr; R.recBytes = 0; }
-            LORAHIP_TRY(hipMalloc((void **)&R.rec, 2 * L.total + L.total / 4));
-            R.recBytes = 2 * L.total + L.total / 4;
+            LORAHIP_TRY(hipMalloc((void **)&R.rec, RES_RING * L.total + L.total / 4));
+            R.recBytes = RES_RING * L.total + L.total / 4;
         }
         R.lay = L;
         R.sigs = dm->wantSignals;
@@ -1499,6 +1503,7 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         if (le == hipErrorNotSupported) { (void)hipGetLastError(); R.unavailable = true; return LORAHIP_OK; }     // not for this geometry: ordinary steps
         LORAHIP_TRY(le);
         R.active = true; R.seq = 0; R.reported = 0; R.lastMore = false;
+        R.depth = rows->reserved >= 1 ? (rows->reserved > RES_DEPTH_MAX ? unsigned(RES_DEPTH_MAX) : unsigned(rows->reserved)) : 1u;
         {
             // the census: every workgroup must be ON the device before a step is rung (bounded wait; otherwise the kernel is told to
             // leave and the object takes ordinary steps from now on)
@@ -1519,6 +1524,7 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
     if (nPackets) *nPackets = 0;
     if (calls) *calls = 0;
     dm->lastSignals = 0;
+    R.nRep = 0;
     const DeviceGuard guard(ctx->device);
     // (up to the last whole line of every row: the < 16 samples behind it wait for the next step, or for the flush's ordinary step)
     { const int rc = residentRing(dm, nValid & ~size_t(15), rows, 0u); if (rc != LORAHIP_OK) { residentAbort(dm); return rc; } }
@@ -1526,14 +1532,15 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
     R.tail = (nValid & 15u) != 0;
     dm->uniform = true; dm->uniSpc = nValid; dm->uniStride = rowStride; dm->appendPrev = nValid; dm->geomApplied = false;
     dm->mirrorsStale = true; dm->headStale = true;
-    if (R.seq < 2) return LORAHIP_OK;
-    // ... and while it runs: the step before
+    if (R.seq <= R.depth) return LORAHIP_OK;
+    // ... and while it runs: the step `depth` calls back
     size_t pk = 0, sg = 0;
     int64_t cl = 0;
     unsigned fl = 0;
-    const int rc = residentReport(dm, R.seq - 1, &pk, &sg, &cl, &fl);
+    const int rc = residentReport(dm, R.seq - R.depth, &pk, &sg, &cl, &fl);
     if (rc != LORAHIP_OK) { residentAbort(dm); return rc; }
-    R.reported = R.seq - 1;
+    R.reported = R.seq - R.depth;
+    R.repPk[0] = pk; R.repSg[0] = dm->sigRowsOn ? sg : 0; R.nRep = 1;
     R.lastMore = (fl & RES_F_MORE) != 0;
     dm->workCalls += cl;
     if (nPackets) *nPackets = pk;
@@ -2397,6 +2404,18 @@ int lorahip_demod_receive_signal_rows(lorahip_demod *dm, const lorahip_signal_ro
 
 size_t lorahip_demod_receive_num_signals(const lorahip_demod *dm) { return dm && !dm->comp ? dm->lastSignals : 0; }
 
+size_t lorahip_demod_receive_steps(const lorahip_demod *dm, size_t *packets, size_t *signals, const size_t cap)
+{
+    if (dm == nullptr || dm->comp || dm->pipe == nullptr) return 0;
+    const Pipe::Resident &R = static_cast<const Pipe *>(dm->pipe)->res;
+    for (unsigned i = 0; i < R.nRep && i < cap; i++)
+    {
+        if (packets) packets[i] = R.repPk[i];
+        if (signals) signals[i] = R.repSg[i];
+    }
+    return R.nRep;
+}
+
 int lorahip_demod_resident_active(const lorahip_demod *dm)
 {
     return dm && !dm->comp && dm->pipe && static_cast<const Pipe *>(dm->pipe)->res.active ? 1 : 0;
@@ -2466,8 +2485,15 @@ int lorahip_demod_receive_flush(lorahip_demod *dm, const lorahip_packet_rows *ro
         if (rows == nullptr) { lorahip_demod_clear_packets(dm); return LORAHIP_OK; }
         size_t n2 = 0;
         rc0 = packetsToDevice(dm, rows->syms_dev, rows->sym_stride, rows->nsyms_dev, rows->channel_dev, rows->cap_packets, &n2, true);
-        if (n_packets) *n_packets = n0 + n2;                  // (n0 of them in the rows of the call before, n2 in these)
+        if (n_packets) *n_packets = n0 + n2;                  // (n0 of them in the rows of their own calls, n2 in these)
         if (rc0 != LORAHIP_OK) return rc0;
+        {
+            const size_t s1 = dm->lastSignals;
+            size_t s2 = 0;
+            rc0 = signalsToRows(dm, 0, &s2, true);            // (into the rows registered now, from row 0: the steps' signals are in their own)
+            dm->lastSignals = s1 + s2;
+            if (rc0 != LORAHIP_OK) return rc0;
+        }
         lorahip_demod_clear_packets(dm);
         return LORAHIP_OK;
     }

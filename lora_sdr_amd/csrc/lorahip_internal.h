@@ -130,16 +130,16 @@ __host__ __device__ inline unsigned residentCheck(const ResidentMsg &m)
     h ^= (unsigned long long)m.symStride * 0x9E3779B97F4A7C15ull + m.capRows * 0xC2B2AE3D27D4EB4Full + m.capSig * 0x165667B19E3779F9ull + m.flags;
     return unsigned(h ^ (h >> 32)) ^ (m.seq * 0x85EBCA6Bu) ^ 0x5A5A5A5Au;
 }
-//! device memory shared by the workgroups of a resident launch; the per-step counters exist four times (step & 3): the host never has
-//! more than two steps outstanding, and the last workgroup of step k clears the set of step k + 2
+//! device memory shared by the workgroups of a resident launch; the per-step counters exist eight times (step & 7): the host never has
+//! more than RES_DEPTH_MAX + 1 = 4 steps outstanding, and the last workgroup of step k clears the set of step k + 4
+enum { RES_DEPTH_MAX = 3, RES_RING = 4 };       // steps the host may ring ahead of the last report; LDS / record-array sets per workgroup
 struct ResidentCtl
 {
     ResidentMsg msg[16][8];             // the ring's mirrors, one per group of workgroups (blockIdx & 15), slot = seq & 7: a thousand
                                         // wavefronts polling ONE line of memory at system scope queue up behind each other for hundreds of
                                         // microseconds (measured: profiles/r06); sixteen lines, one poller per workgroup at a time, do not
-    unsigned long long doneCalls[4];    // [63:48] workgroups that finished the step, [47:0] work() calls they made
-    unsigned rowCount[4], sigCount[4];  // rows handed out (may exceed the capacity: the excess was dropped and is reported)
-    unsigned more[4];                   // some channel stopped because a record buffer was full
+    unsigned long long doneCalls[8];    // [63:48] workgroups that finished the step, [47:36] of them with a stopped channel, [35:0] work() calls
+    unsigned rowCount[8], sigCount[8];  // rows handed out (may exceed the capacity: the excess was dropped and is reported)
     unsigned abortDev;                  // the host's abort flag, relayed (only the relay wavefronts read host memory)
     unsigned arrived;                   // workgroups that have started (the census: all of them must be on the device at once)
     unsigned expired;                   // a wavefront gave up waiting for a message (watchdog)
@@ -150,7 +150,7 @@ struct ResidentCtl
 struct ResidentHost
 {
     ResidentMsg msg[8];                 // the ring the host writes (seq last)
-    unsigned long long sum[8];          // [4][2] the steps' reports (below)
+    unsigned long long sum[16];         // [8][2] the steps' reports (below)
     unsigned abort;                     // host: leave now
     unsigned arrivedAll;                // kernel: every workgroup has started
 };
@@ -206,8 +206,8 @@ struct StreamArgs
     ResidentCtl *res = nullptr;
     ResidentHost *resHost = nullptr;           // pinned host memory as the device addresses it
     unsigned long long resWatchdog = 0;        // 100 MHz ticks a wavefront waits for a message before it gives up
-    unsigned long long resRecStride = 0;       // bytes between the two sets of record arrays (symOut / pktOut / sigOut): a step writes the set
-                                               // of its parity, so that a wavefront already in step k + 1 does not write into the rows the
+    unsigned long long resRecStride = 0;       // bytes between the RES_RING sets of record arrays (symOut / pktOut / sigOut): a step writes set
+                                               // step & 3, so that a wavefront already in a later step does not write into the rows the
                                                // workgroup's last wavefront of step k is still packing from (found by the soak: profiles/r06/s15_*)
     int resSleep = 8;                          // a waiting wavefront's nap between looks, in units of s_sleep 8 (512 clocks); 0: it spins
 };

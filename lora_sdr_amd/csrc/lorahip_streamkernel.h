@@ -38,17 +38,17 @@ struct ResMsgR
     unsigned symStride, capRows, capSig, flags;
 };
 
-//! the counts the wavefronts of a workgroup leave for the one that arrives last at the end of a step (by step parity: a fast
-//! wavefront may be one step ahead of a slow one, never two -- the host rings step k + 2 only after step k has been reported)
+//! the counts the wavefronts of a workgroup leave for the one that arrives last at the end of a step (RES_RING sets, by step & 3: a fast
+//! wavefront may be up to RES_DEPTH_MAX steps ahead of a slow one -- the host rings step k + depth + 1 only after step k has been reported)
 //! (a workgroup of the resident receiver walks up to RES_MAX_SETS channel sets per step when the receiver has more channels than one
 //! resident set of workgroups: 64 / CH at most, the scan of residentStepEnd has one lane per channel)
 template <int CH>
 struct ResLds
 {
     static constexpr int SLOTS = 64;
-    int nPkt[2][SLOTS], nSig[2][SLOTS]; int calls[2], arrive[2], more[2];
-    unsigned msgSeq[2];                 // the step whose message the workgroup holds in msg[step & 1] (whichever wavefront found it first left it there)
-    ResMsgR msg[2];
+    int nPkt[RES_RING][SLOTS], nSig[RES_RING][SLOTS]; int calls[RES_RING], arrive[RES_RING], more[RES_RING];
+    unsigned msgSeq[RES_RING];          // the step whose message the workgroup holds in msg[step & 3] (whichever wavefront found it first left it there)
+    ResMsgR msg[RES_RING];
 };
 
 __device__ __forceinline__ unsigned long long uni64(const unsigned long long v)
@@ -118,7 +118,7 @@ __device__ __forceinline__ void residentLookAhead(const StreamArgs &s, const uns
 template <class RL>
 __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned want, ResMsgR &m, RL *sR)
 {
-    const int par = int(want & 1u);
+    const int par = int(want & 3u);
     ResidentMsg *g = &s.res->msg[blockIdx.x & 15u][want & 7];
     const ResidentMsg *h = &s.resHost->msg[want & 7];
     const unsigned long long t0 = wall_clock64();
@@ -198,8 +198,8 @@ __device__ __forceinline__ void residentDeposit(ResLds<4 * C::WPW> *sR, const un
     constexpr int WPW = C::WPW, CH = 4 * WPW;
     if (t == 0)
     {
-        sR->nPkt[step & 1u][setIdx * CH + wave * WPW + wsub] = mine ? o.nPkt : 0;
-        sR->nSig[step & 1u][setIdx * CH + wave * WPW + wsub] = (mine && o.sigOut) ? o.nSig : 0;
+        sR->nPkt[step & 3u][setIdx * CH + wave * WPW + wsub] = mine ? o.nPkt : 0;
+        sR->nSig[step & 3u][setIdx * CH + wave * WPW + wsub] = (mine && o.sigOut) ? o.nSig : 0;
     }
 }
 
@@ -209,9 +209,9 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
 {
     constexpr int WAVES = 4, WPW = C::WPW, CH = WAVES * WPW;
     static_assert(CH <= 64, "one lane per channel of the workgroup in the scan");
-    const int par = int(step & 1u);
-    const unsigned slot = step & 3u;
-    const size_t setOff = par ? size_t(s.resRecStride) : 0;      // the record arrays of this step's parity
+    const int par = int(step & 3u);
+    const unsigned slot = step & 7u;
+    const size_t setOff = size_t(par) * size_t(s.resRecStride);  // the record arrays of this step's set
     const int NCH = nSetsMine * CH;                                 // channels (entries) of this workgroup in this step, <= 64
     for (int d = 32; d >= 1; d >>= 1) calls += __shfl_xor(calls, d);
     const bool anyStopped = __any(stopped);
@@ -284,7 +284,7 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
     if (lane == 0)
     {
         const unsigned wgCalls = unsigned(sR->calls[par]), wgMore = sR->more[par] ? 1u : 0u;
-        sR->calls[par] = 0; sR->more[par] = 0; sR->arrive[par] = 0;                     // for step + 2
+        sR->calls[par] = 0; sR->more[par] = 0; sR->arrive[par] = 0;                     // for step + 4
         // [63:48] workgroups done, [47:36] of them with a channel that stopped for capacity, [35:0] work() calls
         const unsigned long long add = (1ull << 48) | ((unsigned long long)wgMore << 36) | (unsigned long long)wgCalls;
         const unsigned long long prev = atomicAdd(&s.res->doneCalls[slot], add);
@@ -294,8 +294,8 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
             const unsigned pkAll = agentLoad(&s.res->rowCount[slot]), sgAll = agentLoad(&s.res->sigCount[slot]);
             unsigned flags = (pkAll > m.capRows ? unsigned(RES_F_PKT_OVERFLOW) : 0u) | ((m.capSig != 0u && sgAll > m.capSig) ? unsigned(RES_F_SIG_OVERFLOW) : 0u) |
                              (((tot >> 36) & 0xfffull) ? unsigned(RES_F_MORE) : 0u);
-            // the counters of step + 2: nobody is there yet (the host rings it only after it has seen this report)
-            const unsigned nx = (step + 2u) & 3u;
+            // the counters of step + 4: nobody is there yet (the host rings step k + depth + 1, depth <= 3, only after it has seen report k)
+            const unsigned nx = (step + 4u) & 7u;
             sysStore(&s.res->doneCalls[nx], 0ull); sysStore(&s.res->rowCount[nx], 0u); sysStore(&s.res->sigCount[nx], 0u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned long long *h = s.resHost->sum + 2 * slot;
@@ -349,7 +349,7 @@ demodStream(const StreamArgs s)
     const FineLds fl = fineLoadLds<C::LOG2N>(sFine, s.fineA, s.fineB, threadIdx.x, blockDim.x);
     typedef ResLds<WAVES * WPW> ResL;
     ResL *sR = reinterpret_cast<ResL *>(reinterpret_cast<char *>(sFine) + FineDims<C::LOG2N>::BYTES);        // RES only (the launcher adds the bytes)
-    if (RES && threadIdx.x < 2) { sR->calls[threadIdx.x] = 0; sR->arrive[threadIdx.x] = 0; sR->more[threadIdx.x] = 0; sR->msgSeq[threadIdx.x] = 0u; }
+    if (RES && threadIdx.x < RES_RING) { sR->calls[threadIdx.x] = 0; sR->arrive[threadIdx.x] = 0; sR->more[threadIdx.x] = 0; sR->msgSeq[threadIdx.x] = 0u; }
     if constexpr (RES)
     {
         // the census: the host rings the first step only when every workgroup is on the device (one that had to wait for a slot would wait
@@ -415,7 +415,7 @@ demodStream(const StreamArgs s)
     if constexpr (RES)
     {
         // the record arrays of this step's parity (see StreamArgs::resRecStride)
-        const size_t setOff = (step & 1u) ? size_t(s.resRecStride) : 0;
+        const size_t setOff = size_t(step & 3u) * size_t(s.resRecStride);
         o.symOut = reinterpret_cast<short *>(reinterpret_cast<char *>(o.symOut) + setOff);
         o.pktOut = reinterpret_cast<StreamPacket *>(reinterpret_cast<char *>(o.pktOut) + setOff);
         if (o.sigOut) o.sigOut = reinterpret_cast<StreamSignal *>(reinterpret_cast<char *>(o.sigOut) + setOff);

@@ -288,14 +288,15 @@ def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf)
     d.close()
 
 
-@pytest.mark.parametrize("sf,B", [(7, 40), (8, 13), (9, 21), (10, 9)])
-def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B):
+@pytest.mark.parametrize("sf,B,depth", [(7, 40, 1), (8, 13, 1), (9, 21, 2), (10, 9, 3), (7, 70, 3)])
+def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B, depth):
     """lorahip_demod_receive with async = 3: ONE kernel launch stays on the device, the steps arrive as messages, the kernel packs every
-    step's packets and signals into the rows that came with the step's call; counts one call late, the flush ends the kernel. All
-    steps together, whatever the chunking (chunks so small that a step posts nothing included): the reference's packets, signals, call
-    counts and read positions. While the kernel is resident everything else is refused; afterwards the object is an ordinary one."""
+    step's packets and signals into the rows that came with the step's call; a step is reported `depth` calls later (default 1: the
+    caller cycles depth + 1 sets of rows), the flush reports what is left and ends the kernel. All steps together, whatever the chunking
+    (chunks so small that a step posts nothing included): the reference's packets, signals, call counts and read positions. While the
+    kernel is resident everything else is refused; afterwards the object is an ordinary one."""
     import lora_sdr_amd as L
-    rng = np.random.default_rng(1300 + sf)
+    rng = np.random.default_rng(1300 + sf + depth)
     N = 1 << sf
     host = _streams(oracle, rng, sf, B, n_frames=4)
     host = np.pad(host, ((0, 0), (0, -host.shape[1] % 16)))       # rows of whole 128-byte lines: what the resident mode asks for
@@ -305,37 +306,51 @@ def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B):
     gpu.cuda.synchronize()
     d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
     d.set_signals(True)
-    rows = [d.receiver_rows(cap_packets=4 * B, stride=16) for _ in range(2)]
-    # two sets of signal rows, alternating with the packet rows (a step's signals go where its packets go: with ITS call's registration)
-    sigs = [d.receiver_signal_rows(8 * B, pinned_host=True) for _ in range(2)]
+    NS = depth + 1
+    rows = [d.receiver_rows(cap_packets=4 * B, stride=16) for _ in range(NS)]
+    # as many sets of signal rows, cycling with the packet rows (a step's signals go where its packets go: with ITS call's registration)
+    sigs = [d.receiver_signal_rows(8 * B, pinned_host=True) for _ in range(NS)]
     got, got_sig, calls, w, k = [[] for _ in range(B)], [[] for _ in range(B)], 0, 0, 0
+    pending = []                                                 # row sets of the resident steps rung and not yet reported, oldest first
 
-    def take(n, r, sig):
-        # the rows of the call BEFORE the one that returned n (resident steps), or of this call (the ordinary first step)
+    def take(n, r, sig, nsig):
         sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
         for i in range(n):
             got[int(chn[i])].append(sy[i, :ns[i]].copy())
-        for i in range(d.last_signals()):
+        for i in range(nsig):
             got_sig[int(sig[0][i])].append((int(sig[1][i]), float(sig[2][i]), float(sig[3][i])))
     resident = 0
     while w < cap:
         w = min(cap, w + int(rng.integers(N // 2, 6 * N)))
-        d.register_signal_rows(sigs[k & 1])
-        n, c_ = d.receive(iq, w, rows[k & 1], async_=3)
-        # the first call is an ordinary step (its own rows, at once); from the second on the counts are the previous step's
-        take(n, rows[k & 1], sigs[k & 1]) if k == 0 else take(n, rows[(k - 1) & 1], sigs[(k - 1) & 1])
+        j = k % NS
+        d.register_signal_rows(sigs[j])
+        n, c_ = d.receive(iq, w, rows[j], async_=3, depth=depth)
         calls += c_
+        if d.resident_active():
+            pending.append(j)                                    # this call rang a step into rows[j]
+            steps = d.last_steps()
+            assert sum(p for p, _ in steps) == n and len(steps) <= 1
+            for pk_, sg_ in steps:                               # ... and reported the one rung `depth` calls ago
+                jj = pending.pop(0)
+                take(pk_, rows[jj], sigs[jj], sg_)
+        else:
+            take(n, rows[j], sigs[j], d.last_signals())         # an ordinary step (the first): its own rows, at once
         k += 1
         if k == 4:
             for fn in (lambda: d.work(iq), lambda: d.packets(), lambda: d.activate(), lambda: d.receive(iq, w, rows[0], async_=True),
-                       lambda: d.receive(iq, w, rows[0], async_=2)):
+                       lambda: d.receive(iq, w, rows[0], async_=2), lambda: d.consumed_all()):
                 with pytest.raises(L.LoraHipError):
                     fn()
-            assert d.resident_active()
+            assert d.resident_active() and len(pending) == min(depth, 3)
             resident += 1
-    n, c_ = d.receive_flush(rows[k & 1])
-    take(n, rows[(k - 1) & 1], sigs[(k - 1) & 1])
+    n, c_ = d.receive_flush(rows[k % NS])
     calls += c_
+    steps = d.last_steps()
+    assert len(steps) == len(pending) == depth and not d.resident_active()
+    for pk_, sg_ in steps:
+        jj = pending.pop(0)
+        take(pk_, rows[jj], sigs[jj], sg_)
+    take(n - sum(p for p, _ in steps), rows[k % NS], sigs[k % NS], 0)      # (what an ordinary step at the flush added, if any)
     assert resident == 1 and k > 8
     for c in range(B):
         r = refs[c]
@@ -344,7 +359,7 @@ def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B):
         assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], r["packets"])), "channel %d" % c
         assert d.consumed(c) == int(sum(q["consumed"] for q in r["calls"]))
         assert [g[0] for g in got_sig[c]] == [int(q[0]) for q in r["signals"]] and len(got_sig[c]) >= 4, "channel %d" % c
-        assert np.allclose([g[1:] for g in got_sig[c]], [q[1:] for q in r["signals"]], rtol=0, atol=2e-5)
+        assert np.allclose([g[1:] for g in got_sig[c]], [q[1:] for q in r["signals"]], rtol=0, atol=2e-5, equal_nan=True)
     assert calls == sum(len(r["calls"]) for r in refs) == d.work_calls()
     assert d.receive_flush() == (0, 0)
     # the flushed object is an ordinary one: a rewound one-shot run gives the same again

@@ -14,6 +14,7 @@ ap.add_argument("--channels", type=int, default=None)
 ap.add_argument("--chunk", type=int, default=8)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--signals", action="store_true")
+ap.add_argument("--depth", type=int, default=1, help="resident: steps in flight (depth + 1 sets of rows)")
 a = ap.parse_args()
 sf = a.sf
 B = a.channels or WL.LEVEL3_CHANNELS[sf]
@@ -23,7 +24,7 @@ iq, data = WL.frame_streams(ctx, B, frames, nsyms, sigma=0.05)
 torch.cuda.synchronize()
 cap = int(iq.shape[1])
 d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(nsyms)
-rows = [d.receiver_rows(cap_packets=B * (frames + 1), stride=nsyms) for _ in range(2)]
+rows = [d.receiver_rows(cap_packets=B * (frames + 1), stride=nsyms) for _ in range(max(2, a.depth + 1))]
 if a.signals:
     d.set_signals(True); d.receiver_signal_rows(B * (frames + 2))
 chunk = a.chunk << sf
@@ -37,12 +38,13 @@ def one(mode):
     t0 = time.perf_counter()
     while w < cap:
         w = min(cap, w + chunk)
-        n, c = d.receive(iq, w, rows[k & 1], async_=mode, order_with_torch=False) if mode in (2, 3) else d.receive(iq, w, rows[k & 1], async_=True)
+        r_ = rows[k % (a.depth + 1)] if mode == 3 else rows[k & 1]
+        n, c = d.receive(iq, w, r_, async_=mode, order_with_torch=False, depth=a.depth) if mode in (2, 3) else d.receive(iq, w, r_, async_=True)
         pk += n; calls += c; k += 1
     if mode == 3:
         was = d.resident_active()
     if mode in (2, 3):
-        n, c = d.receive_flush(rows[k & 1]); pk += n; calls += c
+        n, c = d.receive_flush(rows[k % (a.depth + 1)] if mode == 3 else rows[k & 1]); pk += n; calls += c
     torch.cuda.synchronize()
     return time.perf_counter() - t0, pk, calls, k, was
 

@@ -51,32 +51,43 @@ while time.time() < t_end:
         for ch, _r, q in d.packets(): got[ch].append(q)
         ncalls = d.work_calls()
     else:
-        rows = [d.receiver_rows(cap_packets=B * 40, stride=max(mtu, 8)) for _ in range(2)]
+        depth = int(rng.integers(1, 4)) if how == 3 else 1  # resident: steps in flight (the caller cycles depth + 1 sets of rows)
+        NS = depth + 1
+        rows = [d.receiver_rows(cap_packets=B * 40, stride=max(mtu, 8)) for _ in range(NS)]
         pin_ = bool(rng.random() < 0.5)
-        srows = [d.receiver_signal_rows(B * 48, pinned_host=pin_) for _ in range(2)] if sigs else None      # two sets, alternating like the packet rows
+        srows = [d.receiver_signal_rows(B * 48, pinned_host=pin_) for _ in range(NS)] if sigs else None      # cycling like the packet rows
         w = k = ncalls = 0
-        def take(n, r, srow=None):
+        pending = []
+        def take(n, r, srow=None, m=0):
             # (never a DEVICE-wide synchronise while the resident kernel is on the device: it would wait for the flush -- and the rows of a
             # resident step are complete in memory when the call that reports them returns)
             if not (how == 3 and d.resident_active()): torch.cuda.synchronize()
             sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
             for i in range(n): got[int(chn[i])].append(sy[i, :ns[i]].copy())
-            if sigs:
-                m = d.last_signals()
+            if sigs and m:
                 sc, se, sp, ss = (np.asarray(t_[:m].cpu() if hasattr(t_, "cpu") else t_[:m]) for t_ in srow)
                 for i in range(m): got_sig[int(sc[i])].append((int(se[i]), float(sp[i]), float(ss[i])))
         while w < cap:
             w = min(cap, w + int(rng.integers(N // 2, 9 * N)))
-            if sigs: d.register_signal_rows(srows[k & 1])
-            n, c_ = d.receive(iq, w, rows[k & 1], async_=(how if how in (2, 3) else True))
-            # resident steps fill the rows that came with the step and report one call late: the counts returned by call k (k > 0)
-            # belong to the rows (packets and signals) of call k - 1. The first call is an ordinary step (its own rows, at once).
-            j = (k - 1) & 1 if (how == 3 and k > 0 and d.resident_active()) else k & 1
-            take(n, rows[j], srows[j] if sigs else None); ncalls += c_; k += 1
+            j = k % NS
+            if sigs: d.register_signal_rows(srows[j])
+            n, c_ = d.receive(iq, w, rows[j], async_=(how if how in (2, 3) else True), depth=depth)
+            ncalls += c_; k += 1
+            if how == 3 and d.resident_active():
+                # a resident step fills the rows that came with ITS call and is reported `depth` calls later
+                pending.append(j)
+                for pk_, sg_ in d.last_steps():
+                    jj = pending.pop(0); take(pk_, rows[jj], srows[jj] if sigs else None, sg_)
+            else:
+                take(n, rows[j], srows[j] if sigs else None, d.last_signals() if sigs else 0)
         if how in (2, 3):
-            j = (k - 1) & 1 if (how == 3 and d.resident_active()) else k & 1
-            if sigs and not (how == 3 and d.resident_active()): d.register_signal_rows(srows[k & 1])
-            n, c_ = d.receive_flush(rows[k & 1]); take(n, rows[j], srows[j] if sigs else None); ncalls += c_
+            j = k % NS
+            if sigs: d.register_signal_rows(srows[j])
+            n, c_ = d.receive_flush(rows[j]); ncalls += c_
+            steps_ = d.last_steps() if pending else []
+            for pk_, sg_ in steps_:
+                jj = pending.pop(0); take(pk_, rows[jj], srows[jj] if sigs else None, sg_)
+            take(n - sum(p_ for p_, _ in steps_), rows[j], srows[j] if sigs else None, (d.last_signals() if sigs else 0) - sum(s_ for _, s_ in steps_))
         if sigs:
             d.receiver_signal_rows(0)
     print("case seed %d: SF%d, %d channels, mtu %d, mode %d, signals %s" % (seed, sf, B, mtu, how, bool(sigs)), file=sys.stderr, flush=True) if os.environ.get("SOAK_VERBOSE") else None
