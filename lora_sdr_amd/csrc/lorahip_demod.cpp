@@ -2468,6 +2468,8 @@ int lorahip_demod_receive_flush(lorahip_demod *dm, const lorahip_packet_rows *ro
     if (n_packets) *n_packets = 0;
     if (work_calls) *work_calls = 0;
     if (dm->comp) return LORAHIP_OK;
+    dm->lastSignals = 0;                                    // (a flush with nothing in flight delivers nothing: not the count of the call before)
+    pipeOf(dm).res.nRep = 0;
     if (pipeOf(dm).res.active)
     {
         // the resident receiver: every step's rows came with its own call; what is left to report are the counts of the last step(s)

@@ -13,12 +13,13 @@
 
 namespace lorahip {
 
-//! per staging buffer: 32 MiB (LORAHIP_STAGE_MB: measurements, profiles/r06)
+//! per staging buffer: 64 MiB (LORAHIP_STAGE_MB: measurements -- profiles/r06/s19_staging_size.txt: from ordinary memory at 8 / 16 / 32 / 64 MiB SF7 43.9 /
+//! 42.6 / 36.8-41.9 / 43.1, SF10 37.3 / 40.7 / 46.6 / 52.4, SF12 43.3 / 47.1 / 50.3 / 52.5 GB/s; two buffers per context that uploads, allocated on first use)
 static size_t stageBytes()
 {
     static const size_t n = []() {
         if (const char *e = std::getenv("LORAHIP_STAGE_MB")) { const long v = std::atol(e); if (v >= 1 && v <= 1024) return size_t(v) << 20; }
-        return size_t(32) << 20;
+        return size_t(64) << 20;
     }();
     return n;
 }
