@@ -14,11 +14,12 @@ ap.add_argument("--channels", type=int, default=None)
 ap.add_argument("--chunk", type=int, default=8)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--signals", action="store_true")
+ap.add_argument("--frames", type=int, default=4, help="frames per channel: the length of the capture (4 = bench.py's level-3 workload, 37 steps of 8 windows)")
 ap.add_argument("--depth", type=int, default=1, help="resident: steps in flight (depth + 1 sets of rows)")
 a = ap.parse_args()
 sf = a.sf
 B = a.channels or WL.LEVEL3_CHANNELS[sf]
-frames, nsyms = 4, 48
+frames, nsyms = a.frames, 48
 ctx = L.Context(sf)
 iq, data = WL.frame_streams(ctx, B, frames, nsyms, sigma=0.05)
 torch.cuda.synchronize()
