@@ -1402,10 +1402,10 @@ static int residentFlush(lorahip_demod *dm, size_t *nPackets, int64_t *calls)
     {
         ResidentCtl c;
         if (hipMemcpy(&c, R.ctl, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
-            for (int k = 0; k < 8; k++)
-                std::fprintf(stderr, "resident step %d (workgroup 0, wave 0; us): waited %.1f, setup %.1f, windows + records %.1f, look-ahead + step end %.1f; since step 1's wait began %.1f\n", k + 1,
+            for (int k = 0; k < 8; k++)                     // (slot k holds the last step with (step - 1) & 7 == k; the wait stamp of slot k is of the step after)
+                std::fprintf(stderr, "resident slot %d (workgroup 0, wave 0; us): waited %.1f, setup %.1f, windows + records %.1f, look-ahead + step end %.1f; since the end of the slot before %.1f\n", k + 1,
                              (c.dbg[k][1] - c.dbg[k][0]) / 100.0, (c.dbg[k][2] - c.dbg[k][1]) / 100.0, (c.dbg[k][4] - c.dbg[k][2]) / 100.0,
-                             (c.dbg[k][5] - c.dbg[k][4]) / 100.0, (c.dbg[k][0] - c.dbg[0][0]) / 100.0);
+                             (c.dbg[k][5] - c.dbg[k][4]) / 100.0, (double(c.dbg[k][5]) - double(c.dbg[(k + 7) & 7][5])) / 100.0);
     }
     {
         // the kernels' running near-threshold counters

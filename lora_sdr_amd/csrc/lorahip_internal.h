@@ -143,7 +143,7 @@ struct ResidentCtl
     unsigned abortDev;                  // the host's abort flag, relayed (only the relay wavefronts read host memory)
     unsigned arrived;                   // workgroups that have started (the census: all of them must be on the device at once)
     unsigned expired;                   // a wavefront gave up waiting for a message (watchdog)
-    unsigned long long dbg[8][6];       // LORAHIP_RESIDENT_DEBUG: workgroup 0, wavefront 0, steps 1..8: 100 MHz ticks at wait start, message seen,
+    unsigned long long dbg[8][6];       // LORAHIP_RESIDENT_DEBUG: workgroup 0, wavefront 0, the LAST eight steps (slot = (step - 1) & 7): 100 MHz ticks at wait start, message seen,
                                         // pass loop entered, pass loop left, records carried out, step end
 };
 //! pinned host memory the device addresses directly: the host's side of the doorbell and the kernel's reports

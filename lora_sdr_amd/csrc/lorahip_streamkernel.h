@@ -381,9 +381,9 @@ demodStream(const StreamArgs s)
     {
     if constexpr (RES)
     {
-        if (dbgW && step < 8u) s.res->dbg[step][0] = wall_clock64();
+        if (dbgW) s.res->dbg[step & 7u][0] = wall_clock64();
         if (!residentWait(s, step + 1u, rm, sR)) break;
-        if (dbgW && step < 8u) s.res->dbg[step][1] = wall_clock64();
+        if (dbgW) s.res->dbg[step & 7u][1] = wall_clock64();
         step++;
         resCalls = 0; setIdx = 0; resStopped = false;
     }
@@ -421,7 +421,7 @@ demodStream(const StreamArgs s)
         if (o.sigOut) o.sigOut = reinterpret_cast<StreamSignal *>(reinterpret_cast<char *>(o.sigOut) + setOff);
     }
     if (mine) o.carryIn(s, st, cc, t, T);                   // the packet the channel is inside: its symbols so far, from the carry rows
-    if (dbgW && step <= 8u && step > 0u && setIdx == 0) s.res->dbg[step - 1u][2] = wall_clock64();
+    if (dbgW && step > 0u && setIdx == 0) s.res->dbg[(step - 1u) & 7u][2] = wall_clock64();
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
     // whose `on` is false run on the head of the buffer and their results are ignored by the caller.
@@ -710,10 +710,10 @@ demodStream(const StreamArgs s)
     if constexpr (!RES) break;
     else
     {
-        if (dbgW && step <= 8u) s.res->dbg[step - 1u][4] = wall_clock64();
+        if (dbgW) s.res->dbg[(step - 1u) & 7u][4] = wall_clock64();
         residentLookAhead(s, step + 1u);
         residentStepEnd<C>(s, rm, step, sR, resCalls, setIdx, resStopped, lane);
-        if (dbgW && step <= 8u) s.res->dbg[step - 1u][5] = wall_clock64();
+        if (dbgW) s.res->dbg[(step - 1u) & 7u][5] = wall_clock64();
     }
     }
 }
