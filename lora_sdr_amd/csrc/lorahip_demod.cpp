@@ -1022,6 +1022,10 @@ struct Pipe
         bool tail;                      // the last step left fewer than 16 valid samples per row untouched (the flush's ordinary step takes them)
         unsigned nRep; size_t repPk[RES_DEPTH_MAX + 1], repSg[RES_DEPTH_MAX + 1];   // the steps the last call reported, oldest first (lorahip_demod_receive_steps)
         unsigned depth;                 // steps the caller lets the receiver run ahead of the last report (1 .. RES_DEPTH_MAX): it has depth + 1 sets of rows
+        // LORAHIP_RESIDENT_DEBUG prints these at the flush: where the host's share of a step goes
+        uint64_t dbgReports, dbgImmediate, dbgCalls;
+        double dbgWaitNs, dbgBetweenNs;
+        std::chrono::steady_clock::time_point dbgLast;
     } res;
 };
 static Pipe &pipeOf(lorahip_demod *dm) { return *static_cast<Pipe *>(dm->pipe); }
@@ -1336,6 +1340,9 @@ static int residentReport(lorahip_demod *dm, const unsigned k, size_t *packets, 
         const unsigned long long w1 = __atomic_load_n(const_cast<unsigned long long *>(h + 1), __ATOMIC_ACQUIRE);
         if (unsigned(w0 >> 32) == k && unsigned(w1 >> 56) == (k & 0xffu))
         {
+            R.dbgReports++;
+            if (spins == 0) R.dbgImmediate++;
+            else R.dbgWaitNs += std::chrono::duration<double, std::nano>(Clock::now() - t0).count();
             *calls = int64_t(w0 & 0xffffffffull);
             *packets = size_t(w1 & 0xffffffull);
             *signals = size_t((w1 >> 24) & 0xffffffull);
@@ -1406,6 +1413,16 @@ static int residentFlush(lorahip_demod *dm, size_t *nPackets, int64_t *calls)
                 std::fprintf(stderr, "resident slot %d (workgroup 0, wave 0; us): waited %.1f, setup %.1f, windows + records %.1f, look-ahead + step end %.1f; since the end of the slot before %.1f\n", k + 1,
                              (c.dbg[k][1] - c.dbg[k][0]) / 100.0, (c.dbg[k][2] - c.dbg[k][1]) / 100.0, (c.dbg[k][4] - c.dbg[k][2]) / 100.0,
                              (c.dbg[k][5] - c.dbg[k][4]) / 100.0, (double(c.dbg[k][5]) - double(c.dbg[(k + 7) & 7][5])) / 100.0);
+        if (hipMemcpy(&c, R.ctl, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int k = 0; k < 8; k++)
+            {
+                const double nw = double(R.grid) * 4.0 * 100.0;
+                std::fprintf(stderr, "resident slot %d, all %u wavefronts (us; max / mean): waited %.1f / %.1f, windows + records %.1f / %.1f, look-ahead + step end %.1f / %.1f\n", k + 1,
+                             R.grid * 4u, c.dbgStat[k][0] / 100.0, c.dbgStat[k][1] / nw, c.dbgStat[k][2] / 100.0, c.dbgStat[k][3] / nw, c.dbgStat[k][4] / 100.0, c.dbgStat[k][5] / nw);
+            }
+        std::fprintf(stderr, "resident host: %llu reports, %llu there at the first look, %.1f us waited per report on average; %.1f us between two receive calls on average\n",
+                     (unsigned long long)R.dbgReports, (unsigned long long)R.dbgImmediate, R.dbgReports ? R.dbgWaitNs / 1e3 / double(R.dbgReports) : 0.0,
+                     R.dbgCalls > 1 ? R.dbgBetweenNs / 1e3 / double(R.dbgCalls - 1) : 0.0);
     }
     {
         // the kernels' running near-threshold counters
@@ -1495,6 +1512,7 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
         a.near = reinterpret_cast<unsigned *>(dm->sDev + H.oNear);
         a.res = R.ctl; a.resHost = static_cast<ResidentHost *>(hostDev); a.resWatchdog = kResidentWatchdog; a.resRecStride = L.total;
+        if (std::getenv("LORAHIP_RESIDENT_DEBUG")) a.resDebug = 1;
         if (const char *e = std::getenv("LORAHIP_RESIDENT_SLEEP")) a.resSleep = std::atoi(e);             // (measurements: profiles/r06)
         // behind everything queued on the launch stream (the state of the run before, the cleared control block)
         LORAHIP_TRY(hipEventRecord(R.ev, ctx->stream));
@@ -1503,6 +1521,7 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         if (le == hipErrorNotSupported) { (void)hipGetLastError(); R.unavailable = true; return LORAHIP_OK; }     // not for this geometry: ordinary steps
         LORAHIP_TRY(le);
         R.active = true; R.seq = 0; R.reported = 0; R.lastMore = false;
+        R.dbgReports = R.dbgImmediate = R.dbgCalls = 0; R.dbgWaitNs = R.dbgBetweenNs = 0.0;
         R.depth = rows->reserved >= 1 ? (rows->reserved > RES_DEPTH_MAX ? unsigned(RES_DEPTH_MAX) : unsigned(rows->reserved)) : 1u;
         {
             // the census: every workgroup must be ON the device before a step is rung (bounded wait; otherwise the kernel is told to
@@ -1521,6 +1540,11 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         dm->devStateFresh = false;                    // until the kernel has left, only it knows where the state stands
     }
     handled = true;
+    {
+        const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
+        if (R.dbgCalls++) R.dbgBetweenNs += std::chrono::duration<double, std::nano>(now - R.dbgLast).count();
+        R.dbgLast = now;
+    }
     if (nPackets) *nPackets = 0;
     if (calls) *calls = 0;
     dm->lastSignals = 0;

@@ -145,6 +145,8 @@ struct ResidentCtl
     unsigned expired;                   // a wavefront gave up waiting for a message (watchdog)
     unsigned long long dbg[8][6];       // LORAHIP_RESIDENT_DEBUG: workgroup 0, wavefront 0, the LAST eight steps (slot = (step - 1) & 7): 100 MHz ticks at wait start, message seen,
                                         // pass loop entered, pass loop left, records carried out, step end
+    unsigned long long dbgStat[8][6];   // ... and over ALL wavefronts of those steps (same slot): max and sum of the ticks waited for the message, spent on the
+                                        // step's windows, spent on the step's end (look-ahead, packing, report)
 };
 //! pinned host memory the device addresses directly: the host's side of the doorbell and the kernel's reports
 struct ResidentHost
@@ -209,6 +211,7 @@ struct StreamArgs
     unsigned long long resRecStride = 0;       // bytes between the RES_RING sets of record arrays (symOut / pktOut / sigOut): a step writes set
                                                // step & 3, so that a wavefront already in a later step does not write into the rows the
                                                // workgroup's last wavefront of step k is still packing from (found by the soak: profiles/r06/s15_*)
+    int resDebug = 0;                          // LORAHIP_RESIDENT_DEBUG: every wavefront adds its step times to ResidentCtl::dbgStat
     int resSleep = 8;                          // a waiting wavefront's nap between looks, in units of s_sleep 8 (512 clocks); 0: it spins
 };
 

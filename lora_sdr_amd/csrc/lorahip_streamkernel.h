@@ -377,13 +377,16 @@ demodStream(const StreamArgs s)
     int resCalls = 0, setIdx = 0;
     bool resStopped = false;
     const bool dbgW = RES && blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long dbgT0 = 0, dbgT1 = 0;
     for (;;)
     {
     if constexpr (RES)
     {
         if (dbgW) s.res->dbg[step & 7u][0] = wall_clock64();
+        if (s.resDebug) dbgT0 = wall_clock64();
         if (!residentWait(s, step + 1u, rm, sR)) break;
         if (dbgW) s.res->dbg[step & 7u][1] = wall_clock64();
+        if (s.resDebug) dbgT1 = wall_clock64();
         step++;
         resCalls = 0; setIdx = 0; resStopped = false;
     }
@@ -711,9 +714,20 @@ demodStream(const StreamArgs s)
     else
     {
         if (dbgW) s.res->dbg[(step - 1u) & 7u][4] = wall_clock64();
+        const unsigned long long dbgT2 = s.resDebug ? wall_clock64() : 0ull;
         residentLookAhead(s, step + 1u);
         residentStepEnd<C>(s, rm, step, sR, resCalls, setIdx, resStopped, lane);
         if (dbgW) s.res->dbg[(step - 1u) & 7u][5] = wall_clock64();
+        if (s.resDebug && lane == 0)
+        {
+            // (the slot of step + 4 is cleared by workgroup 0 when it ends this step: nobody can be in step + 4 before this step is reported)
+            unsigned long long *q = s.res->dbgStat[(step - 1u) & 7u];
+            const unsigned long long t3 = wall_clock64();
+            atomicMax(q + 0, dbgT1 - dbgT0); atomicAdd(q + 1, dbgT1 - dbgT0);
+            atomicMax(q + 2, dbgT2 - dbgT1); atomicAdd(q + 3, dbgT2 - dbgT1);
+            atomicMax(q + 4, t3 - dbgT2); atomicAdd(q + 5, t3 - dbgT2);
+            if (dbgW) { unsigned long long *z = s.res->dbgStat[(step + 3u) & 7u]; for (int i = 0; i < 6; i++) sysStore(z + i, 0ull); }
+        }
     }
     }
 }
