@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 using namespace lorahip;
 
@@ -1407,19 +1408,49 @@ static int residentFlush(lorahip_demod *dm, size_t *nPackets, int64_t *calls)
     dm->lastSum.more = (R.lastMore || R.tail) ? 1 : 0;
     if (std::getenv("LORAHIP_RESIDENT_DEBUG"))
     {
-        ResidentCtl c;
+        std::vector<char> cbuf(sizeof(ResidentCtl));
+        ResidentCtl &c = *reinterpret_cast<ResidentCtl *>(cbuf.data());
         if (hipMemcpy(&c, R.ctl, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
             for (int k = 0; k < 8; k++)                     // (slot k holds the last step with (step - 1) & 7 == k; the wait stamp of slot k is of the step after)
                 std::fprintf(stderr, "resident slot %d (workgroup 0, wave 0; us): waited %.1f, setup %.1f, windows + records %.1f, look-ahead + step end %.1f; since the end of the slot before %.1f\n", k + 1,
                              (c.dbg[k][1] - c.dbg[k][0]) / 100.0, (c.dbg[k][2] - c.dbg[k][1]) / 100.0, (c.dbg[k][4] - c.dbg[k][2]) / 100.0,
                              (c.dbg[k][5] - c.dbg[k][4]) / 100.0, (double(c.dbg[k][5]) - double(c.dbg[(k + 7) & 7][5])) / 100.0);
-        if (hipMemcpy(&c, R.ctl, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
-            for (int k = 0; k < 8; k++)
+        {
+            // every wavefront's stamps of the chosen step: when the step began (the first wavefront that saw the message), and how the
+            // wavefronts' finishing times -- windows done, step end -- are spread behind it
+            const unsigned nw = R.grid * 4u < 16384u ? R.grid * 4u : 16384u;
+            std::vector<double> seen, done, end, busy;
+            unsigned long long first = ~0ull;
+            for (unsigned w = 0; w < nw; w++) if (c.dbgWave[w][1] && c.dbgWave[w][1] < first) first = c.dbgWave[w][1];
+            for (unsigned w = 0; w < nw; w++)
+                if (c.dbgWave[w][1])
+                {
+                    seen.push_back((c.dbgWave[w][1] - first) / 100.0); done.push_back((c.dbgWave[w][2] - first) / 100.0); end.push_back((c.dbgWave[w][3] - first) / 100.0);
+                    busy.push_back((c.dbgWave[w][2] - c.dbgWave[w][1]) / 100.0);
+                }
             {
-                const double nw = double(R.grid) * 4.0 * 100.0;
-                std::fprintf(stderr, "resident slot %d, all %u wavefronts (us; max / mean): waited %.1f / %.1f, windows + records %.1f / %.1f, look-ahead + step end %.1f / %.1f\n", k + 1,
-                             R.grid * 4u, c.dbgStat[k][0] / 100.0, c.dbgStat[k][1] / nw, c.dbgStat[k][2] / 100.0, c.dbgStat[k][3] / nw, c.dbgStat[k][4] / 100.0, c.dbgStat[k][5] / nw);
+                // who the late ones are: the relay wavefronts (wavefront 0 of workgroups 0..7), and the twelve that ended the step last
+                std::vector<std::pair<double, unsigned>> byEnd;
+                for (unsigned w = 0; w < nw; w++) if (c.dbgWave[w][1]) byEnd.push_back(std::make_pair((c.dbgWave[w][3] - first) / 100.0, w));
+                std::sort(byEnd.begin(), byEnd.end());
+                const auto show = [&](const unsigned w, const char *tag)
+                {
+                    size_t rank = 0;
+                    for (; rank < byEnd.size() && byEnd[rank].second != w; rank++) {}
+                    std::fprintf(stderr, "resident wavefront %5u (workgroup %4u wave %u) %s: waiting since %.1f, message seen %.1f, windows + records done %.1f, step end %.1f (rank %zu of %zu)\n", w, w / 4u, w % 4u, tag,
+                                 (double(c.dbgWave[w][0]) - double(first)) / 100.0, (c.dbgWave[w][1] - first) / 100.0, (c.dbgWave[w][2] - first) / 100.0, (c.dbgWave[w][3] - first) / 100.0, rank + 1, byEnd.size());
+                };
+                for (unsigned g = 0; g < 8u && g * 4u < nw; g++) show(g * 4u, "relay");
+                for (size_t i = byEnd.size() > 12 ? byEnd.size() - 12 : 0; i < byEnd.size(); i++) show(byEnd[i].second, "late ");
+                for (size_t i = 0; i < 4 && i < byEnd.size(); i++) show(byEnd[i].second, "early");
             }
+            const auto pct = [](std::vector<double> &v, const double p) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[size_t(p * double(v.size() - 1))]; };
+            const char *what[4] = {"message seen", "windows + records done", "step end", "(windows + records alone)"};
+            std::vector<double> *vs[4] = {&seen, &done, &end, &busy};
+            for (int q = 0; q < 4; q++)
+                std::fprintf(stderr, "resident step of %zu wavefronts, us after the first one saw the message: %-28s min %.1f  10%% %.1f  50%% %.1f  90%% %.1f  99%% %.1f  max %.1f\n", vs[q]->size(),
+                             what[q], pct(*vs[q], 0.0), pct(*vs[q], 0.1), pct(*vs[q], 0.5), pct(*vs[q], 0.9), pct(*vs[q], 0.99), pct(*vs[q], 1.0));
+        }
         std::fprintf(stderr, "resident host: %llu reports, %llu there at the first look, %.1f us waited per report on average; %.1f us between two receive calls on average\n",
                      (unsigned long long)R.dbgReports, (unsigned long long)R.dbgImmediate, R.dbgReports ? R.dbgWaitNs / 1e3 / double(R.dbgReports) : 0.0,
                      R.dbgCalls > 1 ? R.dbgBetweenNs / 1e3 / double(R.dbgCalls - 1) : 0.0);
@@ -1491,7 +1522,7 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         void *hostDev = nullptr;
         LORAHIP_TRY(hipHostGetDevicePointer(&hostDev, R.host, 0));
         std::memset(R.host, 0, sizeof(ResidentHost));
-        LORAHIP_TRY(hipMemsetAsync(R.ctl, 0, sizeof(ResidentCtl), ctx->stream));
+        LORAHIP_TRY(hipMemsetAsync(R.ctl, 0, std::getenv("LORAHIP_RESIDENT_DEBUG") ? sizeof(ResidentCtl) : offsetof(ResidentCtl, dbgWave), ctx->stream));
         const StreamLayout H = headLayout(dm);
         char *d = R.rec;
         StreamArgs a;
@@ -1512,7 +1543,7 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
         a.mtu = dm->mtu > 0xffffffffu ? 0xffffffffu : unsigned(dm->mtu);
         a.near = reinterpret_cast<unsigned *>(dm->sDev + H.oNear);
         a.res = R.ctl; a.resHost = static_cast<ResidentHost *>(hostDev); a.resWatchdog = kResidentWatchdog; a.resRecStride = L.total;
-        if (std::getenv("LORAHIP_RESIDENT_DEBUG")) a.resDebug = 1;
+        if (const char *e = std::getenv("LORAHIP_RESIDENT_DEBUG")) a.resDebug = unsigned(std::atoi(e));     // (the step whose stamps every wavefront leaves)
         if (const char *e = std::getenv("LORAHIP_RESIDENT_SLEEP")) a.resSleep = std::atoi(e);             // (measurements: profiles/r06)
         // behind everything queued on the launch stream (the state of the run before, the cleared control block)
         LORAHIP_TRY(hipEventRecord(R.ev, ctx->stream));

@@ -138,15 +138,17 @@ struct ResidentCtl
     ResidentMsg msg[16][8];             // the ring's mirrors, one per group of workgroups (blockIdx & 15), slot = seq & 7: a thousand
                                         // wavefronts polling ONE line of memory at system scope queue up behind each other for hundreds of
                                         // microseconds (measured: profiles/r06); sixteen lines, one poller per workgroup at a time, do not
-    unsigned long long doneCalls[8];    // [63:48] workgroups that finished the step, [47:36] of them with a stopped channel, [35:0] work() calls
-    unsigned rowCount[8], sigCount[8];  // rows handed out (may exceed the capacity: the excess was dropped and is reported)
+    unsigned long long doneCalls[8][16];    // [k][0] (a 128-byte line per step slot): [63:48] workgroups that finished the step, [47:36] of them with a stopped
+                                        // channel, [35:0] work() calls
+    unsigned long long rowSig[8][16];   // [k][0]: [31:0] packet rows, [63:32] signal rows handed out in the step (may exceed the capacity: the excess was
+                                        // dropped and is reported) -- ONE atomic per wavefront and channel set that has either
     unsigned abortDev;                  // the host's abort flag, relayed (only the relay wavefronts read host memory)
     unsigned arrived;                   // workgroups that have started (the census: all of them must be on the device at once)
     unsigned expired;                   // a wavefront gave up waiting for a message (watchdog)
     unsigned long long dbg[8][6];       // LORAHIP_RESIDENT_DEBUG: workgroup 0, wavefront 0, the LAST eight steps (slot = (step - 1) & 7): 100 MHz ticks at wait start, message seen,
                                         // pass loop entered, pass loop left, records carried out, step end
-    unsigned long long dbgStat[8][6];   // ... and over ALL wavefronts of those steps (same slot): max and sum of the ticks waited for the message, spent on the
-                                        // step's windows, spent on the step's end (look-ahead, packing, report)
+    unsigned long long dbgWave[16384][4];   // ... and EVERY wavefront's stamps of ONE step (LORAHIP_RESIDENT_DEBUG = its number; plain stores, the other steps
+                                        // are not disturbed): wait start, message seen, windows done, step end
 };
 //! pinned host memory the device addresses directly: the host's side of the doorbell and the kernel's reports
 struct ResidentHost
@@ -211,7 +213,7 @@ struct StreamArgs
     unsigned long long resRecStride = 0;       // bytes between the RES_RING sets of record arrays (symOut / pktOut / sigOut): a step writes set
                                                // step & 3, so that a wavefront already in a later step does not write into the rows the
                                                // workgroup's last wavefront of step k is still packing from (found by the soak: profiles/r06/s15_*)
-    int resDebug = 0;                          // LORAHIP_RESIDENT_DEBUG: every wavefront adds its step times to ResidentCtl::dbgStat
+    unsigned resDebug = 0;                     // LORAHIP_RESIDENT_DEBUG: the step whose stamps every wavefront leaves in ResidentCtl::dbgWave
     int resSleep = 8;                          // a waiting wavefront's nap between looks, in units of s_sleep 8 (512 clocks); 0: it spins
 };
 

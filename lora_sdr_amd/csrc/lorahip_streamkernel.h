@@ -38,15 +38,13 @@ struct ResMsgR
     unsigned symStride, capRows, capSig, flags;
 };
 
-//! the counts the wavefronts of a workgroup leave for the one that arrives last at the end of a step (RES_RING sets, by step & 3: a fast
-//! wavefront may be up to RES_DEPTH_MAX steps ahead of a slow one -- the host rings step k + depth + 1 only after step k has been reported)
-//! (a workgroup of the resident receiver walks up to RES_MAX_SETS channel sets per step when the receiver has more channels than one
-//! resident set of workgroups: 64 / CH at most, the scan of residentStepEnd has one lane per channel)
+//! what the wavefronts of a workgroup leave for the one that arrives last at the end of a step (RES_RING sets, by step & 3: a fast
+//! wavefront may be up to RES_DEPTH_MAX steps ahead of a slow one -- the host rings step k + depth + 1 only after step k has been reported),
+//! and the step's message for the workgroup's other wavefronts
 template <int CH>
 struct ResLds
 {
-    static constexpr int SLOTS = 64;
-    int nPkt[RES_RING][SLOTS], nSig[RES_RING][SLOTS]; int calls[RES_RING], arrive[RES_RING], more[RES_RING];
+    int calls[RES_RING], arrive[RES_RING], more[RES_RING];
     unsigned msgSeq[RES_RING];          // the step whose message the workgroup holds in msg[step & 3] (whichever wavefront found it first left it there)
     ResMsgR msg[RES_RING];
 };
@@ -183,36 +181,119 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
     return (m.flags & 1u) == 0u;
 }
 
-/*! The end of a receiver step for one wavefront. It leaves its channels' counts in the workgroup's slot; the wavefront that arrives LAST
- * (an LDS counter, no barrier: the others go straight back to polling) takes the rows for all the workgroup's packets and signals with
- * ONE device-wide atomic each, packs them -- records read at agent scope (they were written through this CU's L1 into L2), rows
- * written at system scope (through to memory: the consumer is another kernel, a copy engine or the host; no cache has to be written back
- * for them) -- waits for those stores, and adds the workgroup to the step's count. The workgroup that completes the count reports the
- * step to the host's pinned memory. Rows are handed out in the order the workgroups finish: a channel's packets of a step are
- * consecutive and in time order, the channels are not sorted (channel_dev says whose a row is). */
-//! a wavefront's counts of one of its channel sets (the `setIdx`-th of the workgroup in this step), for residentStepEnd
+/*! A wavefront's own packets and signals of a step into the step's rows, right after the windows of a channel set (the records are its
+ * own: written through this compute unit's L1 into L2, waited for by carryOut, read back at agent scope; rows written at system scope --
+ * through to memory: the consumer is another kernel, a copy engine or the host, and no cache has to be written back for them).
+ * ONE device-wide atomic per wavefront and channel set that has anything: packet rows in the low word, signal rows in the high word.
+ * Rows are handed out in the order the wavefronts finish: a channel's packets of a step are consecutive and in time order, the channels
+ * are not sorted (channel_dev says whose a row is).
+ * (Until profiles/r06/s24_*: the wavefront that arrived LAST at the end of a step packed for the whole workgroup, one packet after the
+ * other -- 20-30 us behind its own windows, every step, and always the same wavefront, because being last made it later still: the step
+ * rate of the whole receiver was that wavefront's cycle, the others waited ~20 us of every 64.) */
 template <class C>
-__device__ __forceinline__ void residentDeposit(ResLds<4 * C::WPW> *sR, const unsigned step, const int setIdx, const StreamOut &o, const bool mine, const int wave,
-                                                const int wsub, const int t)
+__device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResMsgR &m, const unsigned step, const unsigned chan0, const StreamOut &o, const bool mine,
+                                                const int lane)
 {
-    constexpr int WPW = C::WPW, CH = 4 * WPW;
-    if (t == 0)
+    constexpr int WPW = C::WPW, T = C::T, LOG2T = C::LOG2T;
+    const int wsub = lane >> LOG2T, t = lane & (T - 1);
+    const int np = mine ? o.nPkt : 0, ns = (mine && o.sigOut) ? o.nSig : 0;         // (replicated in the channel's T lanes)
+    int exP = 0, totP = 0, exS = 0, totS = 0, maxP = 0;
+    unsigned hasMask = 0;                                           // bit w: channel w of the wavefront has a packet
+#pragma unroll
+    for (int w = 0; w < WPW; w++)
     {
-        sR->nPkt[step & 3u][setIdx * CH + wave * WPW + wsub] = mine ? o.nPkt : 0;
-        sR->nSig[step & 3u][setIdx * CH + wave * WPW + wsub] = (mine && o.sigOut) ? o.nSig : 0;
+        const int a = __shfl(np, w * T), b = __shfl(ns, w * T);
+        if (w < wsub) { exP += a; exS += b; }
+        totP += a; totS += b;
+        maxP = a > maxP ? a : maxP;
+        hasMask |= a ? (1u << w) : 0u;
+    }
+    if (totP == 0 && totS == 0) return;                             // (wave-uniform)
+    unsigned long long rs = 0;
+    if (lane == 0) rs = atomicAdd(&s.res->rowSig[step & 7u][0], (unsigned long long)unsigned(totP) | ((unsigned long long)unsigned(totS) << 32));
+    // (the atomic is in flight while the lengths are read)
+    const size_t setOff = size_t(step & 3u) * size_t(s.resRecStride);
+    int ln0 = 0;
+    if (np > 0) ln0 = agentLoad(&o.pktOut[0].len);
+    const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rs), sig0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rs >> 32));
+    const unsigned stride = m.symStride;
+    if (totP && maxP == 1)
+    {
+        // at most one packet per channel (every short step): the wavefront's packets as ONE run of totP x stride elements over the 64 lanes
+        const unsigned E = unsigned(totP) * stride;
+        for (unsigned base = 0; base < E; base += 128u)
+        {
+            unsigned short v[2];
+            unsigned short *dst[2];
+            bool put[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+            {
+                const unsigned idx = base + unsigned(u) * 64u + unsigned(lane);
+                const bool valid = idx < E;
+                const unsigned pq = valid ? idx / stride : 0u, i = idx - pq * stride;
+                int wp = 0, cnt = 0;                                // the pq-th channel of the wavefront that has a packet
+#pragma unroll
+                for (int w = 0; w < WPW; w++) { const int a = int((hasMask >> w) & 1u); if (a && cnt == int(pq)) wp = w; cnt += a; }
+                const int lnp = __shfl(ln0, wp * T);
+                const unsigned g = chan0 + unsigned(wp), r = row0 + pq;
+                const short *sy = reinterpret_cast<const short *>(reinterpret_cast<const char *>(s.symOut + (size_t)g * s.symStride) + setOff);
+                const int keep = lnp < int(stride) ? lnp : int(stride);
+                put[u] = valid && r < m.capRows;
+                dst[u] = m.syms + (size_t)r * stride + i;
+                v[u] = (put[u] && int(i) < keep) ? (unsigned short)agentLoad(sy + i) : (unsigned short)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) if (put[u]) sysStore(dst[u], v[u]);
+        }
+        if (np > 0 && t == 0)
+        {
+            const unsigned r = row0 + unsigned(exP);
+            if (r < m.capRows) { sysStore(m.nsyms + r, ln0); if (m.chan) sysStore(m.chan + r, int(chan0 + unsigned(wsub))); }   // (the true length, as lorahip_demod_packets_to_device)
+        }
+    }
+    else if (np > 0)
+    {
+        // a channel with several packets in the step (long steps): its own T lanes copy them one after the other
+        unsigned r = row0 + unsigned(exP);
+        int off = 0;
+        for (int j = 0; j < np; j++, r++)
+        {
+            const int ln = j == 0 ? ln0 : agentLoad(&o.pktOut[j].len);
+            if (r < m.capRows)
+            {
+                const int keep = ln < int(stride) ? ln : int(stride);
+                unsigned short *dst = m.syms + (size_t)r * stride;
+                for (int i = t; i < int(stride); i += T) sysStore(dst + i, i < keep ? (unsigned short)agentLoad(o.symOut + off + i) : (unsigned short)0);
+                if (t == 0) { sysStore(m.nsyms + r, ln); if (m.chan) sysStore(m.chan + r, int(chan0 + unsigned(wsub))); }
+            }
+            off += ln;
+        }
+    }
+    if (ns > 0 && t == 0)
+    {
+        unsigned r = sig0 + unsigned(exS);
+        for (int j = 0; j < ns; j++, r++)
+            if (r < m.capSig)
+            {
+                if (m.sigCh) sysStore(m.sigCh + r, int(chan0 + unsigned(wsub)));
+                if (m.sigErr) sysStore(m.sigErr + r, agentLoad(&o.sigOut[j].error));
+                if (m.sigPow) sysStore(m.sigPow + r, agentLoad(&o.sigOut[j].power));
+                if (m.sigSnr) sysStore(m.sigSnr + r, agentLoad(&o.sigOut[j].snr));
+            }
     }
 }
 
+/*! The end of a receiver step for one wavefront: it waits for its stores (its rows are in memory before it counts as arrived), adds its
+ * work() calls to the workgroup's, and the wavefront that arrives LAST (an LDS counter, no barrier: the others go straight back to
+ * polling) adds the workgroup to the step's count with one device-wide atomic. The workgroup that completes the count reports the step
+ * to the host's pinned memory. */
 template <class C>
-__device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMsgR &m, const unsigned step, ResLds<4 * C::WPW> *sR, int calls, const int nSetsMine,
-                                                const bool stopped, const int lane)
+__device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMsgR &m, const unsigned step, ResLds<4 * C::WPW> *sR, int calls, const bool stopped, const int lane)
 {
-    constexpr int WAVES = 4, WPW = C::WPW, CH = WAVES * WPW;
-    static_assert(CH <= 64, "one lane per channel of the workgroup in the scan");
+    constexpr int WAVES = 4;
     const int par = int(step & 3u);
     const unsigned slot = step & 7u;
-    const size_t setOff = size_t(par) * size_t(s.resRecStride);  // the record arrays of this step's set
-    const int NCH = nSetsMine * CH;                                 // channels (entries) of this workgroup in this step, <= 64
     for (int d = 32; d >= 1; d >>= 1) calls += __shfl_xor(calls, d);
     const bool anyStopped = __any(stopped);
     if (lane == 0)
@@ -220,83 +301,31 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
         if (calls) atomicAdd(&sR->calls[par], calls);
         if (anyStopped) sR->more[par] = 1;
     }
-    // The records must BE in L2 before the arrival counts: the wavefront that packs reads them at agent scope (past the L1), and a
-    // workgroup-scope release does not wait for global stores on this target (the wavefronts of a workgroup share an L1: the compiler emits
-    // no s_waitcnt vmcnt for it) -- found by the randomised soak, a packet's symbols read before they had landed (profiles/r06/s13_*)
+    // (spelled out: a workgroup-scope release does not wait for global stores on this target -- the wavefronts of a workgroup share an L1,
+    // the compiler emits no s_waitcnt vmcnt for it; found by the randomised soak, profiles/r06/s13_*)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // ... and the counts in LDS
     int arrived = 0;
     if (lane == 0) arrived = __hip_atomic_fetch_add(&sR->arrive[par], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (__builtin_amdgcn_readfirstlane(arrived) != WAVES - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-    // entry e = set index * CH + channel inside the set; the set is blockIdx.x + set index * gridDim.x
-    const auto channelOf = [](const int e) { return (blockIdx.x + unsigned(e / CH) * gridDim.x) * unsigned(CH) + unsigned(e % CH); };
-    const int np = lane < NCH ? sR->nPkt[par][lane] : 0, ns = lane < NCH ? sR->nSig[par][lane] : 0;
-    int ip = np, is = ns;
-    for (int d = 1; d < 64; d <<= 1) { const int a = __shfl_up(ip, d), b = __shfl_up(is, d); if (lane >= d) { ip += a; is += b; } }
-    const int totP = __shfl(ip, 63), totS = __shfl(is, 63);
-    unsigned row0 = 0, sig0 = 0;
-    if (lane == 0)
-    {
-        if (totP) row0 = atomicAdd(&s.res->rowCount[slot], unsigned(totP));
-        if (totS) sig0 = atomicAdd(&s.res->sigCount[slot], unsigned(totS));
-    }
-    row0 = (unsigned)__builtin_amdgcn_readfirstlane((int)row0); sig0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sig0);
-    if (totP)
-        for (int ch = 0; ch < NCH; ch++)
-        {
-            const int n = __shfl(np, ch);
-            if (n == 0) continue;
-            const unsigned g = channelOf(ch);
-            const StreamPacket *pk = reinterpret_cast<const StreamPacket *>(reinterpret_cast<const char *>(s.pktOut + (size_t)g * s.capPkt) + setOff);
-            const short *sy = reinterpret_cast<const short *>(reinterpret_cast<const char *>(s.symOut + (size_t)g * s.symStride) + setOff);
-            unsigned r = row0 + unsigned(__shfl(ip, ch) - n);
-            int off = 0;
-            for (int j = 0; j < n; j++, r++)
-            {
-                const int ln = agentLoad(&pk[j].len);
-                if (r < m.capRows)
-                {
-                    const int keep = ln < int(m.symStride) ? ln : int(m.symStride);
-                    unsigned short *dst = m.syms + (size_t)r * m.symStride;
-                    for (int i = lane; i < int(m.symStride); i += 64) sysStore(dst + i, i < keep ? (unsigned short)agentLoad(sy + off + i) : (unsigned short)0);
-                    if (lane == 0) { sysStore(m.nsyms + r, ln); if (m.chan) sysStore(m.chan + r, int(g)); }      // (the true length, as lorahip_demod_packets_to_device)
-                }
-                off += ln;
-            }
-        }
-    if (totS && lane < NCH)
-    {
-        const unsigned g = channelOf(lane);
-        const StreamSignal *sg = reinterpret_cast<const StreamSignal *>(reinterpret_cast<const char *>(s.sigOut + (size_t)g * s.capPkt) + setOff);
-        unsigned r = sig0 + unsigned(is - ns);
-        for (int j = 0; j < ns; j++, r++)
-            if (r < m.capSig)
-            {
-                if (m.sigCh) sysStore(m.sigCh + r, int(g));
-                if (m.sigErr) sysStore(m.sigErr + r, agentLoad(&sg[j].error));
-                if (m.sigPow) sysStore(m.sigPow + r, agentLoad(&sg[j].power));
-                if (m.sigSnr) sysStore(m.sigSnr + r, agentLoad(&sg[j].snr));
-            }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the rows are in memory before the workgroup counts as done
     if (lane == 0)
     {
         const unsigned wgCalls = unsigned(sR->calls[par]), wgMore = sR->more[par] ? 1u : 0u;
         sR->calls[par] = 0; sR->more[par] = 0; sR->arrive[par] = 0;                     // for step + 4
         // [63:48] workgroups done, [47:36] of them with a channel that stopped for capacity, [35:0] work() calls
         const unsigned long long add = (1ull << 48) | ((unsigned long long)wgMore << 36) | (unsigned long long)wgCalls;
-        const unsigned long long prev = atomicAdd(&s.res->doneCalls[slot], add);
+        const unsigned long long prev = atomicAdd(&s.res->doneCalls[slot][0], add);
         if ((prev >> 48) + 1ull == (unsigned long long)gridDim.x)
         {
             const unsigned long long tot = prev + add;
-            const unsigned pkAll = agentLoad(&s.res->rowCount[slot]), sgAll = agentLoad(&s.res->sigCount[slot]);
+            const unsigned long long rs = agentLoad(&s.res->rowSig[slot][0]);
+            const unsigned pkAll = unsigned(rs), sgAll = unsigned(rs >> 32);
             unsigned flags = (pkAll > m.capRows ? unsigned(RES_F_PKT_OVERFLOW) : 0u) | ((m.capSig != 0u && sgAll > m.capSig) ? unsigned(RES_F_SIG_OVERFLOW) : 0u) |
                              (((tot >> 36) & 0xfffull) ? unsigned(RES_F_MORE) : 0u);
             // the counters of step + 4: nobody is there yet (the host rings step k + depth + 1, depth <= 3, only after it has seen report k)
             const unsigned nx = (step + 4u) & 7u;
-            sysStore(&s.res->doneCalls[nx], 0ull); sysStore(&s.res->rowCount[nx], 0u); sysStore(&s.res->sigCount[nx], 0u);
+            sysStore(&s.res->doneCalls[nx][0], 0ull); sysStore(&s.res->rowSig[nx][0], 0ull);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned long long *h = s.resHost->sum + 2 * slot;
             const unsigned long long w1 = ((unsigned long long)(step & 0xffu) << 56) | ((unsigned long long)flags << 48) | ((unsigned long long)(sgAll & 0xffffffu) << 24) |
@@ -383,10 +412,10 @@ demodStream(const StreamArgs s)
     if constexpr (RES)
     {
         if (dbgW) s.res->dbg[step & 7u][0] = wall_clock64();
-        if (s.resDebug) dbgT0 = wall_clock64();
+        if (s.resDebug == step + 1u) dbgT0 = wall_clock64();
         if (!residentWait(s, step + 1u, rm, sR)) break;
         if (dbgW) s.res->dbg[step & 7u][1] = wall_clock64();
-        if (s.resDebug) dbgT1 = wall_clock64();
+        if (s.resDebug == step + 1u) dbgT1 = wall_clock64();
         step++;
         resCalls = 0; setIdx = 0; resStopped = false;
     }
@@ -704,7 +733,7 @@ demodStream(const StreamArgs s)
     }
     if constexpr (RES)
     {
-        residentDeposit<C>(sR, step, setIdx, o, mine, wave, wsub, t);
+        residentPackOwn<C>(s, rm, step, (cset * WAVES + unsigned(wave)) * unsigned(WPW), o, mine, lane);
         resCalls += (mine && t == 0) ? o.calls : 0;
         resStopped = resStopped || (mine && len - st.pos >= 2 * N);        // stopped with samples left: a record buffer was full
         setIdx++;
@@ -714,19 +743,14 @@ demodStream(const StreamArgs s)
     else
     {
         if (dbgW) s.res->dbg[(step - 1u) & 7u][4] = wall_clock64();
-        const unsigned long long dbgT2 = s.resDebug ? wall_clock64() : 0ull;
+        const unsigned long long dbgT2 = s.resDebug == step ? wall_clock64() : 0ull;
         residentLookAhead(s, step + 1u);
-        residentStepEnd<C>(s, rm, step, sR, resCalls, setIdx, resStopped, lane);
+        residentStepEnd<C>(s, rm, step, sR, resCalls, resStopped, lane);
         if (dbgW) s.res->dbg[(step - 1u) & 7u][5] = wall_clock64();
-        if (s.resDebug && lane == 0)
+        if (s.resDebug == step && lane == 0)
         {
-            // (the slot of step + 4 is cleared by workgroup 0 when it ends this step: nobody can be in step + 4 before this step is reported)
-            unsigned long long *q = s.res->dbgStat[(step - 1u) & 7u];
-            const unsigned long long t3 = wall_clock64();
-            atomicMax(q + 0, dbgT1 - dbgT0); atomicAdd(q + 1, dbgT1 - dbgT0);
-            atomicMax(q + 2, dbgT2 - dbgT1); atomicAdd(q + 3, dbgT2 - dbgT1);
-            atomicMax(q + 4, t3 - dbgT2); atomicAdd(q + 5, t3 - dbgT2);
-            if (dbgW) { unsigned long long *z = s.res->dbgStat[(step + 3u) & 7u]; for (int i = 0; i < 6; i++) sysStore(z + i, 0ull); }
+            const unsigned wv = blockIdx.x * 4u + unsigned(wave);
+            if (wv < 16384u) { unsigned long long *q = s.res->dbgWave[wv]; q[0] = dbgT0; q[1] = dbgT1; q[2] = dbgT2; q[3] = wall_clock64(); }
         }
     }
     }
@@ -778,10 +802,9 @@ static hipError_t launchStreamResidentCfg(const StreamArgs &args, hipStream_t st
     if (e != hipSuccess) return e;
     const int res = residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStream<C, false, true>), WAVES * 64, smem);
     if (res <= 0) return hipErrorNotSupported;
-    // more channel sets than the device holds workgroups: every workgroup walks several per step (at most 64 channels per workgroup and
-    // step: residentStepEnd's scan), all workgroups the same number but the last ones
+    // more channel sets than the device holds workgroups: every workgroup walks several per step, all workgroups the same number but
+    // the last ones
     const unsigned perWg = (nSets + unsigned(res) - 1) / unsigned(res);
-    if (perWg * perBlock > 64u) return hipErrorNotSupported;
     const unsigned grid = (nSets + perWg - 1) / perWg;
     if (grid > 4095u) return hipErrorNotSupported;
     if (gridOut) *gridOut = grid;
