@@ -1483,7 +1483,7 @@ static int residentStep(lorahip_demod *dm, const float *iqDev, const size_t rowS
     lorahip_ctx *ctx = dm->ctx;
     const size_t N = dm->N, B = dm->B;
     const bool stream = dm->mode == 1 || (dm->mode == 0 && streamAvailable(ctx->sf));
-    const bool compatible = stream && ctx->sf >= 7 && ctx->sf <= 10 && !dm->tracing && !dm->portsOn && !dm->activatePending && dm->sDev != nullptr &&
+    const bool compatible = stream && ctx->sf >= 7 && ctx->sf <= 12 && !dm->tracing && !dm->portsOn && !dm->activatePending && dm->sDev != nullptr &&
                             dm->append && !dm->appendFresh && dm->uniStride == rowStride && nValid >= dm->appendPrev && dm->dCarry != nullptr &&
                             dm->mtu + 1 <= dm->carryCap && !P.active && rowsHold(rows, 1) &&
                             // rows of whole 128-byte lines: a step then never reads a line that holds samples which arrive later (no cache to invalidate)

@@ -35,6 +35,9 @@ struct StreamOut
         const short *src = s.carry + (size_t)channel * s.carryCap;
         // (read at agent scope: in the resident receiver the row was written by this compute unit a step ago and an older copy of the
         // line may still sit in its L1)
+        // (eight loads in flight per lane before the stores -- instead of a round trip to L2 per element, six per step with 8 lanes per
+        // channel -- was measured in the resident receiver and LOST: 2.36 -> 1.79 Gsym/s at SF7, the registers it takes are spilled in the
+        // window loop; profiles/r06/s26_*)
         for (int i = t; i < k; i += T) symOut[i] = __hip_atomic_load(const_cast<short *>(src) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nSym = st.symCount;
     }

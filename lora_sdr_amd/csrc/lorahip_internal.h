@@ -267,6 +267,7 @@ hipError_t launchStreamWide(int sf, const StreamArgs &s, hipStream_t stream);
 //! the resident receiver's launch (SF7-10, the 16-points-per-lane geometries): hipErrorNotSupported when there is no such instance or
 //! the grid would not be resident all at once; *grid = workgroups launched
 hipError_t launchStreamResident(int sf, const StreamArgs &s, hipStream_t stream, unsigned *grid);
+hipError_t launchStreamResidentWide(int sf, const StreamArgs &s, hipStream_t stream, unsigned *grid);    // SF11 / SF12 (lorahip_wide.hip)
 bool streamLanesAvailable(int sf, int log2Lanes);
 int streamLanesChosen(int sf, unsigned nChannels, int forced);
 hipError_t launchStreamLanes(int sf, int log2Lanes, const StreamArgs &s, hipStream_t stream);

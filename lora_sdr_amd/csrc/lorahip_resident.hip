@@ -14,6 +14,7 @@ hipError_t launchStreamResident(const int sf, const StreamArgs &s, hipStream_t s
     case 8: return launchStreamResidentCfg<Stream8>(s, stream, grid);
     case 9: return launchStreamResidentCfg<Stream9>(s, stream, grid);
     case 10: return launchStreamResidentCfg<Stream10>(s, stream, grid);
+    case 11: case 12: return launchStreamResidentWide(sf, s, stream, grid);
     default: return hipErrorNotSupported;
     }
 }

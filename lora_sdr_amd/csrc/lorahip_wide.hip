@@ -16,6 +16,7 @@
 //   phase 2  bits [B1+4,LOG2N) lane t holds bins t + T*e                                       (registers)
 #include "lorahip_fft.h"
 #include "lorahip_framemachine.h"
+#include "lorahip_residentproto.h"
 
 #ifndef SCAN_CHAINS_WIDE
 #define SCAN_CHAINS_WIDE 1
@@ -671,10 +672,17 @@ extern "C" int lorahip_debug_wg_waves(void *out, const size_t bytes)
 }
 #endif
 
-template <class C, bool PERSIST>
+//! the channel of a demodStreamWide workgroup as residentPackOwn sees it: one channel, packed by the 64 lanes of wavefront 0
+struct ResPackWide { static constexpr int WPW = 1, T = 64, LOG2T = 6; };
+
+//! RES: the resident receiver (see demodStream in lorahip_streamkernel.h, lorahip_residentproto.h): the launch stays, the steps arrive as
+//! messages; a workgroup moves through a step as ONE (its wavefronts share a window), wavefront 0 waits for the message, packs the
+//! channel's packets and signals, and reports
+template <class C, bool PERSIST, bool RES = false>
 __global__ void __launch_bounds__(C::T, 2)
 demodStreamWide(const StreamArgs s)
 {
+    static_assert(!(RES && PERSIST), "the resident receiver walks its channels itself");
 #ifdef LORAHIP_WG_TIMELINE
     const unsigned long long tl0 = wall_clock64();
 #endif
@@ -719,6 +727,13 @@ demodStreamWide(const StreamArgs s)
 #pragma unroll
         for (int u = 0; u < VEC; u++) ch[r][u] = reinterpret_cast<const v2f *>(s.down)[VEC * t + u + VEC * T * r];
     const FineLds fl = fineLoadLds<LOG2N>(sFine, s.fineA, s.fineB, t, T);
+    ResLds *sR = reinterpret_cast<ResLds *>(reinterpret_cast<char *>(sFine) + FineDims<LOG2N>::BYTES);       // RES only (the launcher adds the bytes)
+    if constexpr (RES)
+    {
+        if (t < RES_RING) { sR->calls[t] = 0; sR->arrive[t] = 0; sR->more[t] = 0; sR->msgSeq[t] = 0u; }
+        // the census: the host rings the first step only when every workgroup is on the device
+        if (t == 0 && atomicAdd(&s.res->arrived, 1u) + 1u == gridDim.x) sysStore(&s.resHost->arrivedAll, 1u);
+    }
     __syncthreads();
 
     // One channel per workgroup: everything the frame machine touches is WORKGROUP-UNIFORM. Saying so (v_readfirstlane where a value
@@ -728,16 +743,57 @@ demodStreamWide(const StreamArgs s)
     const auto uniI = [](const int v) { return __builtin_amdgcn_readfirstlane(v); };
     const auto uniF = [](const float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
     // persistent grid (s.maxBlocks workgroups at most), a workgroup takes one channel after the other: see demodStream
+    // RES: one turn of the outer loop per receiver step (otherwise exactly one turn)
+    unsigned step = 0;
+    ResMsgR rm;
+    unsigned resCalls = 0;
+    bool resMore = false;
+    for (;;)
+    {
+    if constexpr (RES)
+    {
+        if (wave == 0)
+        {
+            ResMsgR m0;
+            const bool ok = residentWait(s, step + 1u, m0, sR, true);
+            if (lane == 0) sR->go = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!__builtin_amdgcn_readfirstlane(sR->go)) break;  // (the quit message, the abort flag or the watchdog: the whole workgroup leaves)
+        residentMsgFromLds(sR, int((step + 1u) & 3u), rm);  // (every wavefront from LDS, wavefront 0 too: scalar registers on one path)
+        step++;
+        resCalls = 0; resMore = false;
+    }
     unsigned c = blockIdx.x;                                // (the grid never exceeds the channel count)
     do
     {
-    StreamState st = s.state[c];
+    StreamState st;
+    if constexpr (RES)
+    {
+        // (what this workgroup stored a step ago: read at agent scope -- past the L1 and the scalar cache, which may hold an older copy --
+        // and made scalar again)
+        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(&s.state[c]);
+        unsigned long long w[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = uni64(agentLoad(q + i));
+        static_assert(sizeof(StreamState) == 40, "five 64-bit words");
+        __builtin_memcpy(&st, w, sizeof(st));
+    }
+    else st = s.state[c];
     if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
     if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
     const long long base = s.uniformLen >= 0 ? (long long)c * s.uniformStride : s.base[c];
-    const long long len = s.uniformLen >= 0 ? s.uniformLen : s.len[c];
+    const long long len = RES ? (long long)rm.nValid : (s.uniformLen >= 0 ? s.uniformLen : s.len[c]);         // (RES: what the step's message says)
     StreamOut o;
     o.init(s, c);
+    if constexpr (RES)
+    {
+        // the record arrays of this step's set (StreamArgs::resRecStride)
+        const size_t setOff = size_t(step & 3u) * size_t(s.resRecStride);
+        o.symOut = reinterpret_cast<short *>(reinterpret_cast<char *>(o.symOut) + setOff);
+        o.pktOut = reinterpret_cast<StreamPacket *>(reinterpret_cast<char *>(o.pktOut) + setOff);
+        if (o.sigOut) o.sigOut = reinterpret_cast<StreamSignal *>(reinterpret_cast<char *>(o.sigOut) + setOff);
+    }
     o.carryIn(s, st, c, t, T);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect; every argument is workgroup-uniform
@@ -953,7 +1009,7 @@ demodStreamWide(const StreamArgs s)
     int value0 = 0, fineIdxBefore0 = 0;
     float snr0 = 0.0f, fineErrBefore0 = 0.0f;
     const int slot = wavefrontSlot();
-    const bool lastRound = PERSIST || !LORAHIP_PRIO_HOLD || blockIdx.x >= s.lastRoundFrom;
+    const bool lastRound = PERSIST || RES || !LORAHIP_PRIO_HOLD || blockIdx.x >= s.lastRoundFrom;
     holdPriority<LORAHIP_PRIO_ALTERNATE>(!lastRound);
     while (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt && o.nSig < s.capPkt))          // LoRaDemod.cpp:148
     {
@@ -1013,8 +1069,23 @@ demodStreamWide(const StreamArgs s)
         }
 #endif
     }
-    if (PERSIST) __syncthreads();                           // the next channel reuses the exchange region and the reduction records
-    } while (PERSIST && (c += gridDim.x) < s.nChannels);    // without PERSIST there is no loop at all (it would cost registers)
+    if constexpr (RES)
+    {
+        // the channel's packets and signals of the step into the step's rows (wavefront 0 wrote the records: t == 0 is the writer lane)
+        if (wave == 0) residentPackOwn<ResPackWide>(s, rm, step, c, o, true, lane);
+        resCalls += unsigned(o.calls);
+        resMore = resMore || (len - st.pos >= 2 * N);       // stopped with samples left: a record buffer was full
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the state and the rows are in L2 / in memory before the workgroup moves on
+    }
+    if (PERSIST || RES) __syncthreads();                    // the next channel reuses the exchange region and the reduction records
+    } while ((PERSIST || RES) && (c += gridDim.x) < s.nChannels);    // without PERSIST / RES there is no loop at all (it would cost registers)
+    if constexpr (!RES) break;
+    else
+    {
+        residentLookAhead(s, step + 1u);                    // (the relay wavefronts: the next step's message into the mirrors)
+        if (t == 0) residentWgDone(s, rm, step, resCalls, resMore ? 1u : 0u);
+    }
+    }
 }
 
 
@@ -1054,6 +1125,33 @@ static hipError_t launchStreamWideCfg(const StreamArgs &args, hipStream_t stream
     s.lastRoundFrom = lastRoundFrom(s.nChannels, residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStreamWide<C, false>), C::T, smem));
     hipLaunchKernelGGL((demodStreamWide<C, false>), dim3(s.nChannels), dim3(C::T), smem, stream, s);
     return hipGetLastError();
+}
+
+//! the resident receiver's launch at SF11 / SF12 (see launchStreamResidentCfg in lorahip_streamkernel.h): refused unless every workgroup is
+//! resident at once; with more channels than that every workgroup walks several per step
+template <class C>
+static hipError_t launchStreamResidentWideCfg(const StreamArgs &args, hipStream_t stream, unsigned *gridOut)
+{
+    const size_t smem = size_t(C::TWN + C::XW) * sizeof(float2) + 4 * sizeof(RedRec) + 2 * sizeof(float2) + 12 * sizeof(int) + FineDims<C::LOG2N>::BYTES + sizeof(ResLds);
+    static unsigned long long attrDone = 0;
+    static PerDeviceCount resident;
+    if (gridOut) *gridOut = 0;
+    if (args.nChannels == 0) return hipErrorNotSupported;
+    const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStreamWide<C, false, true>), smem, attrDone);
+    if (e != hipSuccess) return e;
+    const int res = residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStreamWide<C, false, true>), C::T, smem);
+    if (res <= 0) return hipErrorNotSupported;
+    const unsigned perWg = (args.nChannels + unsigned(res) - 1) / unsigned(res);
+    const unsigned grid = (args.nChannels + perWg - 1) / perWg;
+    if (grid > 4095u) return hipErrorNotSupported;
+    if (gridOut) *gridOut = grid;
+    hipLaunchKernelGGL((demodStreamWide<C, false, true>), dim3(grid), dim3(C::T), smem, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launchStreamResidentWide(const int sf, const StreamArgs &s, hipStream_t stream, unsigned *grid)
+{
+    return sf == 11 ? launchStreamResidentWideCfg<StreamWide11>(s, stream, grid) : launchStreamResidentWideCfg<StreamWide12>(s, stream, grid);
 }
 
 hipError_t launchStreamWide(const int sf, const StreamArgs &s, hipStream_t stream)

@@ -288,7 +288,7 @@ def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf)
     d.close()
 
 
-@pytest.mark.parametrize("sf,B,depth", [(7, 40, 1), (8, 13, 1), (9, 21, 2), (10, 9, 3), (7, 70, 3)])
+@pytest.mark.parametrize("sf,B,depth", [(7, 40, 1), (8, 13, 1), (9, 21, 2), (10, 9, 3), (7, 70, 3), (11, 7, 1), (12, 5, 2), (11, 3, 3)])
 def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B, depth):
     """lorahip_demod_receive with async = 3: ONE kernel launch stays on the device, the steps arrive as messages, the kernel packs every
     step's packets and signals into the rows that came with the step's call; a step is reported `depth` calls later (default 1: the

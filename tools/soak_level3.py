@@ -38,7 +38,7 @@ while time.time() < t_end:
     d.set_stream_grid(int(rng.choice([0, -1, 1, 2, 5])))
     lanes = int(rng.choice([0, -1, 4, 5, 6])) if os.environ.get("SOAK_LANES", "1") != "0" else 0     # SF7-9: more lanes per channel (lorahip_stream_lanes.hip)
     d.set_stream_lanes(lanes)
-    how = int(rng.integers(0, 4)) if "SOAK_HOW" not in os.environ else (int(rng.integers(0, 4)), int(os.environ["SOAK_HOW"]))[1]                        # 0 one shot, 1 sequential steps, 2 pipelined, 3 resident (SF7-10; elsewhere ordinary steps)
+    how = int(rng.integers(0, 4)) if "SOAK_HOW" not in os.environ else (int(rng.integers(0, 4)), int(os.environ["SOAK_HOW"]))[1]                        # 0 one shot, 1 sequential steps, 2 pipelined, 3 resident
     sigs = rng.random() < 0.5                            # the block's signals (error / power / snr at DOWNCHIRP1) kept and compared too
     got = [[] for _ in range(B)]
     got_sig = [[] for _ in range(B)]
