@@ -180,7 +180,7 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
  * other -- 20-30 us behind its own windows, every step, and always the same wavefront, because being last made it later still: the step
  * rate of the whole receiver was that wavefront's cycle, the others waited ~20 us of every 64.) */
 template <class C>
-__device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResMsgR &m, const unsigned step, const unsigned chan0, const StreamOut &o, const bool mine,
+__device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResLds *sR, const unsigned step, const unsigned chan0, const StreamOut &o, const bool mine,
                                                 const int lane)
 {
     constexpr int WPW = C::WPW, T = C::T, LOG2T = C::LOG2T;
@@ -198,6 +198,8 @@ __device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResMs
         hasMask |= a ? (1u << w) : 0u;
     }
     if (totP == 0 && totS == 0) return;                             // (wave-uniform)
+    ResMsgR m;                                                      // where the rows are: from the workgroup's copy of the step's message
+    residentMsgFromLds(sR, int(step & 3u), m);
     unsigned long long rs = 0;
     if (lane == 0) rs = atomicAdd(&s.res->rowSig[step & 7u][0], (unsigned long long)unsigned(totP) | ((unsigned long long)unsigned(totS) << 32));
     // (the atomic is in flight while the lengths are read)
@@ -275,7 +277,7 @@ __device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResMs
 
 /*! ONE thread of a workgroup whose wavefronts have all finished the step (their rows are in memory): the workgroup is added to the step's
  * count with one device-wide atomic; the workgroup that completes the count reports the step to the host's pinned memory. */
-__device__ __forceinline__ void residentWgDone(const StreamArgs &s, const ResMsgR &m, const unsigned step, const unsigned wgCalls, const unsigned wgMore)
+__device__ __forceinline__ void residentWgDone(const StreamArgs &s, const ResLds *sR, const unsigned step, const unsigned wgCalls, const unsigned wgMore)
 {
     const unsigned slot = step & 7u;
     // [63:48] workgroups done, [47:36] of them with a channel that stopped for capacity, [35:0] work() calls
@@ -285,6 +287,7 @@ __device__ __forceinline__ void residentWgDone(const StreamArgs &s, const ResMsg
     const unsigned long long tot = prev + add;
     const unsigned long long rs = agentLoad(&s.res->rowSig[slot][0]);
     const unsigned pkAll = unsigned(rs), sgAll = unsigned(rs >> 32);
+    const ResMsgR &m = sR->msg[step & 3u];                          // (one thread: the row capacities straight from the workgroup's copy)
     const unsigned flags = (pkAll > m.capRows ? unsigned(RES_F_PKT_OVERFLOW) : 0u) | ((m.capSig != 0u && sgAll > m.capSig) ? unsigned(RES_F_SIG_OVERFLOW) : 0u) |
                            (((tot >> 36) & 0xfffull) ? unsigned(RES_F_MORE) : 0u);
     // the counters of step + 4: nobody is there yet (the host rings step k + depth + 1, depth <= 3, only after it has seen report k)
@@ -305,7 +308,7 @@ __device__ __forceinline__ void residentWgDone(const StreamArgs &s, const ResMsg
  * polling) adds the workgroup to the step's count with one device-wide atomic. The workgroup that completes the count reports the step
  * to the host's pinned memory. */
 template <class C>
-__device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMsgR &m, const unsigned step, ResLds *sR, int calls, const bool stopped, const int lane)
+__device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const unsigned step, ResLds *sR, int calls, const bool stopped, const int lane)
 {
     constexpr int WAVES = 4;
     const int par = int(step & 3u);
@@ -328,7 +331,7 @@ __device__ __forceinline__ void residentStepEnd(const StreamArgs &s, const ResMs
     {
         const unsigned wgCalls = unsigned(sR->calls[par]), wgMore = sR->more[par] ? 1u : 0u;
         sR->calls[par] = 0; sR->more[par] = 0; sR->arrive[par] = 0;                     // for step + 4
-        residentWgDone(s, m, step, wgCalls, wgMore);
+        residentWgDone(s, sR, step, wgCalls, wgMore);
     }
 }
 

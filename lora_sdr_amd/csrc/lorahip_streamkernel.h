@@ -88,7 +88,7 @@ demodStream(const StreamArgs s)
     // blockIdx.x, + gridDim.x, ... like a persistent grid -- with the tables it staged once; a channel's state lives in s.state between the
     // steps (40 bytes per channel and step, against 8 N per window read).
     unsigned step = 0;                                      // RES: the last receiver step taken
-    ResMsgR rm;
+    unsigned long long resNValid = 0;
     int resCalls = 0, setIdx = 0;
     bool resStopped = false;
     const bool dbgW = RES && blockIdx.x == 0 && threadIdx.x == 0;
@@ -99,7 +99,13 @@ demodStream(const StreamArgs s)
     {
         if (dbgW) s.res->dbg[step & 7u][0] = wall_clock64();
         if (s.resDebug == step + 1u) dbgT0 = wall_clock64();
-        if (!residentWait(s, step + 1u, rm, sR)) break;
+        // (of the step's message only n_valid stays in registers across the windows: what packs and what reports read the rest back from
+        // the workgroup's copy in LDS -- thirteen scalar values kept live took the registers of the window loop into scratch)
+        {
+            ResMsgR m0;
+            if (!residentWait(s, step + 1u, m0, sR)) break;
+            resNValid = m0.nValid;
+        }
         if (dbgW) s.res->dbg[step & 7u][1] = wall_clock64();
         if (s.resDebug == step + 1u) dbgT1 = wall_clock64();
         step++;
@@ -127,7 +133,7 @@ demodStream(const StreamArgs s)
     if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
     if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
     const long long base = s.uniformLen >= 0 ? (long long)cc * s.uniformStride : s.base[cc];
-    const long long len = !mine ? 0 : (RES ? (long long)rm.nValid : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]));    // (RES: what the step's message says)
+    const long long len = !mine ? 0 : (RES ? (long long)resNValid : (s.uniformLen >= 0 ? s.uniformLen : s.len[cc]));    // (RES: what the step's message says)
     StreamOut o;
     o.init(s, cc);
     if constexpr (RES)
@@ -419,7 +425,7 @@ demodStream(const StreamArgs s)
     }
     if constexpr (RES)
     {
-        residentPackOwn<C>(s, rm, step, (cset * WAVES + unsigned(wave)) * unsigned(WPW), o, mine, lane);
+        residentPackOwn<C>(s, sR, step, (cset * WAVES + unsigned(wave)) * unsigned(WPW), o, mine, lane);
         resCalls += (mine && t == 0) ? o.calls : 0;
         resStopped = resStopped || (mine && len - st.pos >= 2 * N);        // stopped with samples left: a record buffer was full
         setIdx++;
@@ -429,15 +435,12 @@ demodStream(const StreamArgs s)
     else
     {
         if (dbgW) s.res->dbg[(step - 1u) & 7u][4] = wall_clock64();
-        const unsigned long long dbgT2 = s.resDebug == step ? wall_clock64() : 0ull;
+        const bool dbgE = s.resDebug == step && lane == 0 && blockIdx.x * 4u + unsigned(wave) < 16384u;
+        if (dbgE) s.res->dbgWave[blockIdx.x * 4u + unsigned(wave)][2] = wall_clock64();
         residentLookAhead(s, step + 1u);
-        residentStepEnd<C>(s, rm, step, sR, resCalls, resStopped, lane);
+        residentStepEnd<C>(s, step, sR, resCalls, resStopped, lane);
         if (dbgW) s.res->dbg[(step - 1u) & 7u][5] = wall_clock64();
-        if (s.resDebug == step && lane == 0)
-        {
-            const unsigned wv = blockIdx.x * 4u + unsigned(wave);
-            if (wv < 16384u) { unsigned long long *q = s.res->dbgWave[wv]; q[0] = dbgT0; q[1] = dbgT1; q[2] = dbgT2; q[3] = wall_clock64(); }
-        }
+        if (dbgE) s.res->dbgWave[blockIdx.x * 4u + unsigned(wave)][3] = wall_clock64();
     }
     }
 }

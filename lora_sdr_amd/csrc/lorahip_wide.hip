@@ -745,7 +745,7 @@ demodStreamWide(const StreamArgs s)
     // persistent grid (s.maxBlocks workgroups at most), a workgroup takes one channel after the other: see demodStream
     // RES: one turn of the outer loop per receiver step (otherwise exactly one turn)
     unsigned step = 0;
-    ResMsgR rm;
+    unsigned long long resNValid = 0;
     unsigned resCalls = 0;
     bool resMore = false;
     for (;;)
@@ -760,7 +760,8 @@ demodStreamWide(const StreamArgs s)
         }
         __syncthreads();
         if (!__builtin_amdgcn_readfirstlane(sR->go)) break;  // (the quit message, the abort flag or the watchdog: the whole workgroup leaves)
-        residentMsgFromLds(sR, int((step + 1u) & 3u), rm);  // (every wavefront from LDS, wavefront 0 too: scalar registers on one path)
+        // (of the message only n_valid stays in registers across the windows; every wavefront from LDS, wavefront 0 too: one path)
+        resNValid = uni64(sR->msg[(step + 1u) & 3u].nValid);
         step++;
         resCalls = 0; resMore = false;
     }
@@ -783,7 +784,7 @@ demodStreamWide(const StreamArgs s)
     if (s.flags & 1) { st.pos = 0; st.callCount = 0; }                        // a new run: every stream from its first sample
     if (s.flags & 2) { st.state = ST_FRAMESYNC; st.downTable = 0; }           // activate() (LoRaDemod.cpp:139-143)
     const long long base = s.uniformLen >= 0 ? (long long)c * s.uniformStride : s.base[c];
-    const long long len = RES ? (long long)rm.nValid : (s.uniformLen >= 0 ? s.uniformLen : s.len[c]);         // (RES: what the step's message says)
+    const long long len = RES ? (long long)resNValid : (s.uniformLen >= 0 ? s.uniformLen : s.len[c]);         // (RES: what the step's message says)
     StreamOut o;
     o.init(s, c);
     if constexpr (RES)
@@ -1072,7 +1073,7 @@ demodStreamWide(const StreamArgs s)
     if constexpr (RES)
     {
         // the channel's packets and signals of the step into the step's rows (wavefront 0 wrote the records: t == 0 is the writer lane)
-        if (wave == 0) residentPackOwn<ResPackWide>(s, rm, step, c, o, true, lane);
+        if (wave == 0) residentPackOwn<ResPackWide>(s, sR, step, c, o, true, lane);
         resCalls += unsigned(o.calls);
         resMore = resMore || (len - st.pos >= 2 * N);       // stopped with samples left: a record buffer was full
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the state and the rows are in L2 / in memory before the workgroup moves on
@@ -1083,7 +1084,7 @@ demodStreamWide(const StreamArgs s)
     else
     {
         residentLookAhead(s, step + 1u);                    // (the relay wavefronts: the next step's message into the mirrors)
-        if (t == 0) residentWgDone(s, rm, step, resCalls, resMore ? 1u : 0u);
+        if (t == 0) residentWgDone(s, sR, step, resCalls, resMore ? 1u : 0u);
     }
     }
 }
