@@ -837,7 +837,7 @@ def section_level3(env, L, sf, threads=32):
                 "ms_per_work": r4(rb[0] / rb[3] * 1e3), "Msym_s": r4(rb[1] / rb[0] / 1e6),
                 "frac": r4(rb[1] * L.bytes_per_symbol(sf) / rb[0] / 1e9 / (HBM_PEAK_GBS * env.world)), "packets": int(rb[2])}
         # RESIDENT steps (async = 3): one kernel launch stays on the device, a step is a 104-byte message and two words back; the kernel packs
-        # the packets itself into the rows that came with the step (two sets, alternating). SF7-10; elsewhere the calls are ordinary steps.
+        # the packets itself into the rows that came with the step (two sets, alternating).
         # (`depth`: how many steps the receiver may run ahead of the last report -- a step ends with its slowest workgroup, with more steps
         # in flight the fast ones work ahead; the caller cycles depth + 1 sets of rows)
         rows_set_ = [rows_] + [d.receiver_rows(cap_packets=B * (frames + 1), stride=max(8, min(nsyms, 512))) for _ in range(3)]

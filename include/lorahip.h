@@ -387,15 +387,15 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * between (*n_packets and *work_calls then cover both steps; until then no further kernel is launched -- the samples wait in the
  * caller's array, a later call covers them). As with async = 0/1 a packet longer than sym_stride keeps its true length in
  * nsyms_dev and its first sym_stride symbols (the decoder flags it): sym_stride >= the MTU never truncates.
- * With async = 3 the receiver is RESIDENT (SF7-10, every channel's workgroup on the device at once -- up to the device's resident set,
- * 16384 channels at SF7 ... 2048 at SF10; otherwise, and until the object is in place for it, the call is an ordinary step): ONE
- * kernel launch stays on the device across the steps. A call copies a 104-byte message into a ring in device memory (the doorbell) and
+ * With async = 3 the receiver is RESIDENT (SF7-12; the grid is at most the device's resident set of workgroups, each taking as many
+ * channel sets per step as it takes to cover the channels; until the object is in place for it -- the first call of a capture -- the
+ * call is an ordinary step): ONE kernel launch stays on the device across the steps. A call copies a 104-byte message into a ring in device memory (the doorbell) and
  * returns the counts of the PREVIOUS step; the kernel's wavefronts poll the ring, work through what arrived with the tables they
- * staged once, pack the step's packets (and signals, lorahip_demod_receive_signal_rows) themselves into the rows that came WITH the
- * step's call, and the last workgroup reports two words to pinned host memory: no launch, no helper kernel per step. So: the rows
+ * staged once, pack their own channels' packets (and signals, lorahip_demod_receive_signal_rows) themselves into the rows that came
+ * WITH the step's call, and the last workgroup reports two words to pinned host memory: no launch, no helper kernel per step. So: the rows
  * passed to call k are filled by step k and are complete -- in memory, for any stream, a copy engine or, if they are pinned host
  * memory, the host -- when call k + 1 (or lorahip_demod_receive_flush) returns with their *n_packets; keep two sets of rows and
- * alternate (with a depth d > 1, `reserved` below: call k + d reports them, d + 1 sets). Rows are handed out in the order the workgroups finish: a channel's packets of a step are consecutive and in time order,
+ * alternate (with a depth d > 1, `reserved` below: call k + d reports them, d + 1 sets). Rows are handed out in the order the wavefronts finish: a channel's packets of a step are consecutive and in time order,
  * channels are not sorted (channel_dev says whose a row is). The samples up to n_valid must BE in iq_dev when the call is made (the
  * kernel reads them on its own, not in the order of any stream). Rows too small for a step: the excess is dropped, counted in
  * *n_packets, and the call that reports the step returns LORAHIP_E_INVALID -- size the rows for a step (one packet per channel and

@@ -190,5 +190,9 @@ if __name__ == "__main__":
         sys.exit(0)
     # --all-variants: also compile the round-1 A/B kernel variants (profiling only; the shipped library carries the default,
     # the generic kernel and one alternative per SF)
-    build_lib(force="--force" in sys.argv, verbose=True, extra=("-DLORAHIP_ALL_VARIANTS",) if "--all-variants" in sys.argv else ())
+    # --define NAME: a measurement build (e.g. LORAHIP_RESIDENT_STAMPS: the resident receiver's per-wavefront time stamps); the shipped
+    # library is the one built WITHOUT it -- build it again afterwards
+    extra = ["-DLORAHIP_ALL_VARIANTS"] if "--all-variants" in sys.argv else []
+    extra += ["-D" + sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--define"]
+    build_lib(force="--force" in sys.argv, verbose=True, extra=tuple(extra))
     print(LIB)

@@ -91,14 +91,22 @@ demodStream(const StreamArgs s)
     unsigned long long resNValid = 0;
     int resCalls = 0, setIdx = 0;
     bool resStopped = false;
+#ifdef LORAHIP_RESIDENT_STAMPS
     const bool dbgW = RES && blockIdx.x == 0 && threadIdx.x == 0;
-    unsigned long long dbgT0 = 0, dbgT1 = 0;
+#else
+    constexpr bool dbgW = false;
+#endif
     for (;;)
     {
     if constexpr (RES)
     {
         if (dbgW) s.res->dbg[step & 7u][0] = wall_clock64();
-        if (s.resDebug == step + 1u) dbgT0 = wall_clock64();
+#ifdef LORAHIP_RESIDENT_STAMPS
+        // (a measurement build, -DLORAHIP_RESIDENT_STAMPS + LORAHIP_RESIDENT_DEBUG=<step>: every wavefront's stamps of ONE step, each stored
+        // at once. Not in the shipped kernel: the few registers it takes moved 80 more bytes per lane into scratch at SF7.)
+        const bool dbgS = s.resDebug == step + 1u && lane == 0 && blockIdx.x * 4u + unsigned(wave) < 16384u;
+        if (dbgS) s.res->dbgWave[blockIdx.x * 4u + unsigned(wave)][0] = wall_clock64();
+#endif
         // (of the step's message only n_valid stays in registers across the windows: what packs and what reports read the rest back from
         // the workgroup's copy in LDS -- thirteen scalar values kept live took the registers of the window loop into scratch)
         {
@@ -107,7 +115,9 @@ demodStream(const StreamArgs s)
             resNValid = m0.nValid;
         }
         if (dbgW) s.res->dbg[step & 7u][1] = wall_clock64();
-        if (s.resDebug == step + 1u) dbgT1 = wall_clock64();
+#ifdef LORAHIP_RESIDENT_STAMPS
+        if (dbgS) s.res->dbgWave[blockIdx.x * 4u + unsigned(wave)][1] = wall_clock64();
+#endif
         step++;
         resCalls = 0; setIdx = 0; resStopped = false;
     }
@@ -435,12 +445,16 @@ demodStream(const StreamArgs s)
     else
     {
         if (dbgW) s.res->dbg[(step - 1u) & 7u][4] = wall_clock64();
+#ifdef LORAHIP_RESIDENT_STAMPS
         const bool dbgE = s.resDebug == step && lane == 0 && blockIdx.x * 4u + unsigned(wave) < 16384u;
         if (dbgE) s.res->dbgWave[blockIdx.x * 4u + unsigned(wave)][2] = wall_clock64();
+#endif
         residentLookAhead(s, step + 1u);
         residentStepEnd<C>(s, step, sR, resCalls, resStopped, lane);
         if (dbgW) s.res->dbg[(step - 1u) & 7u][5] = wall_clock64();
+#ifdef LORAHIP_RESIDENT_STAMPS
         if (dbgE) s.res->dbgWave[blockIdx.x * 4u + unsigned(wave)][3] = wall_clock64();
+#endif
     }
     }
 }
