@@ -28,9 +28,11 @@ struct StreamOut
     }
     //! The packet the channel is inside continues behind the symbols it has already (flag bit 2; `st` with the launch's flags
     //! applied): the channel's lanes (lane `t` of `T`) copy them from the carry rows to the head of the symbol row.
-    __device__ __forceinline__ void carryIn(const StreamArgs &s, const StreamState &st, const unsigned channel, const int t, const int T)
+    //! `copy` false (the resident receiver): they stay where they are -- the symbol row holds only what the launch adds (nSym counts from
+    //! 0), whoever packs the packet takes its first symbols from the carry row (residentPackOwn), and carryOut appends behind them.
+    __device__ __forceinline__ void carryIn(const StreamArgs &s, const StreamState &st, const unsigned channel, const int t, const int T, const bool copy = true)
     {
-        if (!(s.flags & 4) || st.state != ST_DATASYMBOLS) return;
+        if (!copy || !(s.flags & 4) || st.state != ST_DATASYMBOLS) return;
         const int k = st.symCount < s.carryCap ? st.symCount : s.carryCap;
         const short *src = s.carry + (size_t)channel * s.carryCap;
         // (read at agent scope: in the resident receiver the row was written by this compute unit a step ago and an older copy of the
@@ -41,8 +43,10 @@ struct StreamOut
         for (int i = t; i < k; i += T) symOut[i] = __hip_atomic_load(const_cast<short *>(src) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nSym = st.symCount;
     }
-    //! ... and a channel that ends the launch inside a packet leaves the packet's symbols -- the last symCount entries of its row,
-    //! written by the writer lane -- in the carry rows (flag bit 3).
+    //! ... and a channel that ends the launch inside a packet leaves the packet's symbols in the carry rows (flag bit 3): the last
+    //! k = min(symCount, nSym) entries of its row, written by the writer lane, are the packet's LAST k symbols and go to the entries
+    //! symCount - k ... of the carry row. With carryIn's copy k = symCount (the whole packet, from entry 0); without it only what the
+    //! launch added is appended -- with short receiver steps one turn of the loop instead of mtu / T, a round trip to L2 each.
     //! `acrossWaves`: the channel's lanes span several wavefronts (demodStreamWide): the other wavefronts must not load before the
     //! writer's wavefront has waited for its stores -- a workgroup barrier between the two (every thread of the workgroup calls this,
     //! the flags and the loop exit are workgroup-uniform).
@@ -61,8 +65,9 @@ struct StreamOut
         if (acrossWaves) __syncthreads();                           // ... and the writer's wavefront has got here: its last symbol is in L2
         if (!mine || st.state != ST_DATASYMBOLS) return;
         int k = st.symCount < nSym ? st.symCount : nSym;
-        k = k < s.carryCap ? k : s.carryCap;
-        short *dst = s.carry + (size_t)channel * s.carryCap;
+        int at = st.symCount - k;                                   // (0 with carryIn's copy: nSym >= symCount there)
+        if (at + k > s.carryCap) { at = 0; k = k < s.carryCap ? k : s.carryCap; }     // (a packet longer than the carry row: as ever, its last k symbols from entry 0 -- such receivers keep the host path)
+        short *dst = s.carry + (size_t)channel * s.carryCap + at;
         for (int i = t; i < k; i += T) dst[i] = __hip_atomic_load(symOut + (nSym - k + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };

@@ -28,6 +28,8 @@ struct ResMsgR
 struct ResLds
 {
     int calls[RES_RING], arrive[RES_RING], more[RES_RING];
+    short *carry; int carryCap;         // StreamArgs::carry / carryCap for what runs at the end of a step (read from here there: a kernel argument kept in
+                                        // scalar registers across the window loop costs the loop registers)
     int go;                             // demodStreamWide: wavefront 0's verdict on the wait for a step (its workgroup moves in step)
     unsigned msgSeq[RES_RING];          // the step whose message the workgroup holds in msg[step & 3] (whichever wavefront found it first left it there)
     ResMsgR msg[RES_RING];
@@ -170,8 +172,9 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
     return (m.flags & 1u) == 0u;
 }
 
-/*! A wavefront's own packets and signals of a step into the step's rows, right after the windows of a channel set (the records are its
- * own: written through this compute unit's L1 into L2, waited for by carryOut, read back at agent scope; rows written at system scope --
+/*! A wavefront's own packets and signals of a step into the step's rows, right after the windows of a channel set and BEFORE carryOut
+ * (which may overwrite the carry row a packet's first symbols are read from) (the records are its
+ * own: written through this compute unit's L1 into L2, waited for here, read back at agent scope; rows written at system scope --
  * through to memory: the consumer is another kernel, a copy engine or the host, and no cache has to be written back for them).
  * ONE device-wide atomic per wavefront and channel set that has anything: packet rows in the low word, signal rows in the high word.
  * Rows are handed out in the order the wavefronts finish: a channel's packets of a step are consecutive and in time order, the channels
@@ -181,7 +184,7 @@ __device__ __forceinline__ bool residentWait(const StreamArgs &s, const unsigned
  * rate of the whole receiver was that wavefront's cycle, the others waited ~20 us of every 64.) */
 template <class C>
 __device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResLds *sR, const unsigned step, const unsigned chan0, const StreamOut &o, const bool mine,
-                                                const int lane)
+                                                const int lane, const int openSyms = -1)
 {
     constexpr int WPW = C::WPW, T = C::T, LOG2T = C::LOG2T;
     const int wsub = lane >> LOG2T, t = lane & (T - 1);
@@ -198,6 +201,7 @@ __device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResLd
         hasMask |= a ? (1u << w) : 0u;
     }
     if (totP == 0 && totS == 0) return;                             // (wave-uniform)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the writer lanes' records are in L2 (they are read back past the L1)
     ResMsgR m;                                                      // where the rows are: from the workgroup's copy of the step's message
     residentMsgFromLds(sR, int(step & 3u), m);
     unsigned long long rs = 0;
@@ -208,8 +212,12 @@ __device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResLd
     if (np > 0) ln0 = agentLoad(&o.pktOut[0].len);
     const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rs), sig0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rs >> 32));
     const unsigned stride = m.symStride;
+    // openSyms >= 0 (carryIn without the copy): the channel's symbol row holds only what the step ADDED -- the new part of its first packet
+    // (the one it was inside when the step began), the later packets, the symbols of the packet it ends the step inside (openSyms of
+    // them, if that one began in this step: np > 0). The first packet's first `carried` symbols never left the carry row.
     if (totP && maxP == 1)
     {
+        const int carried = (np > 0 && openSyms >= 0) ? ln0 - (o.nSym - openSyms) : 0;
         // at most one packet per channel (every short step): the wavefront's packets as ONE run of totP x stride elements over the 64 lanes
         const unsigned E = unsigned(totP) * stride;
         for (unsigned base = 0; base < E; base += 128u)
@@ -226,13 +234,14 @@ __device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResLd
                 int wp = 0, cnt = 0;                                // the pq-th channel of the wavefront that has a packet
 #pragma unroll
                 for (int w = 0; w < WPW; w++) { const int a = int((hasMask >> w) & 1u); if (a && cnt == int(pq)) wp = w; cnt += a; }
-                const int lnp = __shfl(ln0, wp * T);
+                const int lnp = __shfl(ln0, wp * T), cap_ = __shfl(carried, wp * T);
                 const unsigned g = chan0 + unsigned(wp), r = row0 + pq;
                 const short *sy = reinterpret_cast<const short *>(reinterpret_cast<const char *>(s.symOut + (size_t)g * s.symStride) + setOff);
+                const short *cy = sR->carry + (size_t)g * sR->carryCap;
                 const int keep = lnp < int(stride) ? lnp : int(stride);
                 put[u] = valid && r < m.capRows;
                 dst[u] = m.syms + (size_t)r * stride + i;
-                v[u] = (put[u] && int(i) < keep) ? (unsigned short)agentLoad(sy + i) : (unsigned short)0;
+                v[u] = (put[u] && int(i) < keep) ? (unsigned short)agentLoad(int(i) < cap_ ? cy + i : sy + (int(i) - cap_)) : (unsigned short)0;
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) if (put[u]) sysStore(dst[u], v[u]);
@@ -247,7 +256,14 @@ __device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResLd
     {
         // a channel with several packets in the step (long steps): its own T lanes copy them one after the other
         unsigned r = row0 + unsigned(exP);
-        int off = 0;
+        int carried = 0;
+        if (openSyms >= 0)
+        {
+            int later = 0;
+            for (int j = 1; j < np; j++) later += agentLoad(&o.pktOut[j].len);
+            carried = ln0 - (o.nSym - openSyms - later);
+        }
+        int off = -carried;                                 // (where the first packet would begin in the row if its head were there)
         for (int j = 0; j < np; j++, r++)
         {
             const int ln = j == 0 ? ln0 : agentLoad(&o.pktOut[j].len);
@@ -255,7 +271,9 @@ __device__ __forceinline__ void residentPackOwn(const StreamArgs &s, const ResLd
             {
                 const int keep = ln < int(stride) ? ln : int(stride);
                 unsigned short *dst = m.syms + (size_t)r * stride;
-                for (int i = t; i < int(stride); i += T) sysStore(dst + i, i < keep ? (unsigned short)agentLoad(o.symOut + off + i) : (unsigned short)0);
+                const short *cy = sR->carry + (size_t)(chan0 + unsigned(wsub)) * sR->carryCap;
+                for (int i = t; i < int(stride); i += T)
+                    sysStore(dst + i, i < keep ? (unsigned short)agentLoad((j == 0 && i < carried) ? cy + i : o.symOut + off + i) : (unsigned short)0);
                 if (t == 0) { sysStore(m.nsyms + r, ln); if (m.chan) sysStore(m.chan + r, int(chan0 + unsigned(wsub))); }
             }
             off += ln;

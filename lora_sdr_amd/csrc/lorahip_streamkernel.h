@@ -19,6 +19,9 @@
 #ifndef STREAM_TWLDS9
 #define STREAM_TWLDS9 false
 #endif
+#ifndef LORAHIP_RES_NOCOPY
+#define LORAHIP_RES_NOCOPY 1      // the resident receiver leaves the open packets' symbols in the carry rows (carryIn without the copy; the pack reads them there)
+#endif
 #ifndef STREAM_WPS
 #define STREAM_WPS 2            // wavefronts per SIMD the register budget is set for (3 = 168 VGPRs: A/B builds, profiles/r03)
 #endif
@@ -64,6 +67,7 @@ demodStream(const StreamArgs s)
     const FineLds fl = fineLoadLds<C::LOG2N>(sFine, s.fineA, s.fineB, threadIdx.x, blockDim.x);
     typedef ResLds ResL;
     ResL *sR = reinterpret_cast<ResL *>(reinterpret_cast<char *>(sFine) + FineDims<C::LOG2N>::BYTES);        // RES only (the launcher adds the bytes)
+    if (RES && threadIdx.x == 0) { sR->carry = s.carry; sR->carryCap = s.carryCap; }
     if (RES && threadIdx.x < RES_RING) { sR->calls[threadIdx.x] = 0; sR->arrive[threadIdx.x] = 0; sR->more[threadIdx.x] = 0; sR->msgSeq[threadIdx.x] = 0u; }
     if constexpr (RES)
     {
@@ -154,7 +158,7 @@ demodStream(const StreamArgs s)
         o.pktOut = reinterpret_cast<StreamPacket *>(reinterpret_cast<char *>(o.pktOut) + setOff);
         if (o.sigOut) o.sigOut = reinterpret_cast<StreamSignal *>(reinterpret_cast<char *>(o.sigOut) + setOff);
     }
-    if (mine) o.carryIn(s, st, cc, t, T);                   // the packet the channel is inside: its symbols so far, from the carry rows
+    if (mine) o.carryIn(s, st, cc, t, T, !(RES && LORAHIP_RES_NOCOPY));                 // the packet the channel is inside: its symbols so far, from the carry rows
     if (dbgW && step > 0u && setIdx == 0) s.res->dbg[(step - 1u) & 7u][2] = wall_clock64();
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
@@ -423,6 +427,8 @@ demodStream(const StreamArgs s)
                "uniform/epilogue of detect %llu, sync/match logic %llu, frame step+records+loop top %llu; calls %d\n",
                tsec[0], tsec[1], tsec[2], tsec[3], tsec[6], tsec[7], tsec[4], 0ull, tsec[8], tsec[5], o.calls);
 #endif
+    // (RES: the step's packets leave first -- a packet's first symbols may still be in the carry row carryOut is about to overwrite)
+    if constexpr (RES && LORAHIP_RES_NOCOPY) residentPackOwn<C>(s, sR, step, (cset * WAVES + unsigned(wave)) * unsigned(WPW), o, mine, lane, st.state == ST_DATASYMBOLS ? st.symCount : 0);
     o.carryOut(s, st, cc, t, T, mine);
     if (mine && t == 0)
     {
@@ -435,7 +441,7 @@ demodStream(const StreamArgs s)
     }
     if constexpr (RES)
     {
-        residentPackOwn<C>(s, sR, step, (cset * WAVES + unsigned(wave)) * unsigned(WPW), o, mine, lane);
+        if constexpr (!LORAHIP_RES_NOCOPY) residentPackOwn<C>(s, sR, step, (cset * WAVES + unsigned(wave)) * unsigned(WPW), o, mine, lane);
         resCalls += (mine && t == 0) ? o.calls : 0;
         resStopped = resStopped || (mine && len - st.pos >= 2 * N);        // stopped with samples left: a record buffer was full
         setIdx++;

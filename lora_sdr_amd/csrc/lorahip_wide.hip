@@ -730,6 +730,7 @@ demodStreamWide(const StreamArgs s)
     ResLds *sR = reinterpret_cast<ResLds *>(reinterpret_cast<char *>(sFine) + FineDims<LOG2N>::BYTES);       // RES only (the launcher adds the bytes)
     if constexpr (RES)
     {
+        if (t == 0) { sR->carry = s.carry; sR->carryCap = s.carryCap; }
         if (t < RES_RING) { sR->calls[t] = 0; sR->arrive[t] = 0; sR->more[t] = 0; sR->msgSeq[t] = 0u; }
         // the census: the host rings the first step only when every workgroup is on the device
         if (t == 0 && atomicAdd(&s.res->arrived, 1u) + 1u == gridDim.x) sysStore(&s.resHost->arrivedAll, 1u);
@@ -795,7 +796,7 @@ demodStreamWide(const StreamArgs s)
         o.pktOut = reinterpret_cast<StreamPacket *>(reinterpret_cast<char *>(o.pktOut) + setOff);
         if (o.sigOut) o.sigOut = reinterpret_cast<StreamSignal *>(reinterpret_cast<char *>(o.sigOut) + setOff);
     }
-    o.carryIn(s, st, c, t, T);
+    o.carryIn(s, st, c, t, T, !RES);
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect; every argument is workgroup-uniform
     // What a work() call consumes of the float outputs depends on its state (see demodStream, lorahip_stream.hip): without a
@@ -1049,6 +1050,9 @@ demodStreamWide(const StreamArgs s)
             st.finefreqError = uniF(st.finefreqError);                                  // a float add runs on the vector unit: back to a scalar
         }
     }
+    // (RES: the channel's packets and signals of the step into the step's rows first -- wavefront 0 wrote the records, t == 0 is the writer
+    // lane; a packet's first symbols may still be in the carry row carryOut is about to overwrite)
+    if constexpr (RES) { if (wave == 0) residentPackOwn<ResPackWide>(s, sR, step, c, o, true, lane, st.state == ST_DATASYMBOLS ? st.symCount : 0); }
     o.carryOut(s, st, c, t, T, true, true);             // T > 64: a barrier between the writer's last store and the other wavefronts' loads
 #ifdef LORAHIP_WG_TIMELINE
     if ((t & 63) == 0 && c < 16384) gWgWaveHwId[c][(t >> 6) & 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -1072,8 +1076,6 @@ demodStreamWide(const StreamArgs s)
     }
     if constexpr (RES)
     {
-        // the channel's packets and signals of the step into the step's rows (wavefront 0 wrote the records: t == 0 is the writer lane)
-        if (wave == 0) residentPackOwn<ResPackWide>(s, sR, step, c, o, true, lane);
         resCalls += unsigned(o.calls);
         resMore = resMore || (len - st.pos >= 2 * N);       // stopped with samples left: a record buffer was full
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the state and the rows are in L2 / in memory before the workgroup moves on
