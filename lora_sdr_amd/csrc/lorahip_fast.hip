@@ -454,6 +454,13 @@ static hipError_t launchByShape(const DetectArgs &a, const FastTables &ft, hipSt
     return uni ? launchOne<UNI_CFG, false, true>(a, ft, stream) : launchOne<MOVING_CFG, false, false>(a, ft, stream);
 }
 
+// (the option sets of the per-window-settings instances of SF7 / SF10 as macros: A/B builds, tools/build_variant.py -DLORAHIP_SF10_MOVING=...)
+#ifndef LORAHIP_SF7_MOVING
+#define LORAHIP_SF7_MOVING (CH_REG | NT)
+#endif
+#ifndef LORAHIP_SF10_MOVING
+#define LORAHIP_SF10_MOVING (W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG)
+#endif
 struct FastVariant { int sf, variant; FastLaunch launch; };
 #define V(SF, N, OPTS) { SF, N, &launchCfg<Fast<SF, (OPTS)>> }
 // What ships: per SF the default (0) and ONE alternative -- variant 10, every table (chirp, twiddles) read from LDS, the option
@@ -468,7 +475,7 @@ static const FastVariant kFastVariants[] = {
 #ifndef LORAHIP_FMA      // (the contracted build carries the defaults only)
     { 6, 10, &launchByShape<Fast<6, CH_REG | NT>, Fast<6, CH_REG | NT>, Fast<6, W2 | CH_REG | NT>> },
 #endif
-    { 7, 0, &launchByShape<Fast<7, CH_REG | NT>, Fast<7, CH_REG | NT>, Fast<7, W2 | CH_REG | NT>> },   // default
+    { 7, 0, &launchByShape<Fast<7, CH_REG | NT>, Fast<7, LORAHIP_SF7_MOVING>, Fast<7, W2 | CH_REG | NT>> },   // default
 #ifndef LORAHIP_FMA
     { 7, 10, &launchByShape<Fast<7, 0>, Fast<7, 0>, Fast<7, W2>> },
 #endif
@@ -485,7 +492,7 @@ static const FastVariant kFastVariants[] = {
     { 9, 10, &launchByShape<Fast<9, 0>, Fast<9, W2>, Fast<9, W2>> },
 #endif
     // default SF10: per-window settings at two waves per SIMD with the middle-phase twiddles in registers too
-    { 10, 0, &launchByShape<Fast<10, CH_REG | TW_REG | NT | X1_SWAP>, Fast<10, W2 | CH_REG | TW_REG | NT | X1_SWAP | TWM_REG>, Fast<10, W2>> },   // (debug ports: every table from LDS, no scratch)
+    { 10, 0, &launchByShape<Fast<10, CH_REG | TW_REG | NT | X1_SWAP>, Fast<10, LORAHIP_SF10_MOVING>, Fast<10, W2>> },   // (debug ports: every table from LDS, no scratch)
 #ifndef LORAHIP_FMA
     { 10, 10, &launchByShape<Fast<10, 0>, Fast<10, W2>, Fast<10, W2>> },
 #endif
