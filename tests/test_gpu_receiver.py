@@ -288,6 +288,68 @@ def test_pipelined_receiver_delivers_every_packet_one_step_late(gpu, oracle, sf)
     d.close()
 
 
+@pytest.mark.parametrize("sf,B", [(7, 24), (10, 6), (12, 4)])
+def test_resident_rows_too_small_drop_the_excess_loudly(gpu, oracle, sf, B):
+    """The resident receiver writes a step's packets while the step runs: rows that cannot hold them lose the excess -- counted, and the
+    call that reports the step fails with LORAHIP_E_INVALID and the number of rows the step needed (include/lorahip.h). What DID fit is
+    whole packets of the reference, every later step is unaffected, the counts add up to the reference's, and the flushed object is an
+    ordinary one."""
+    import lora_sdr_amd as L
+    rng = np.random.default_rng(1500 + sf)
+    N = 1 << sf
+    host = _streams(oracle, rng, sf, B, n_frames=3)
+    host = np.pad(host, ((0, 0), (0, -host.shape[1] % 16)))
+    cap = host.shape[1]
+    refs = [oracle.demod_run(sf, host[c], mtu=9) for c in range(B)]
+    total = sum(len(r["packets"]) for r in refs)
+    iq = gpu.from_numpy(host).cuda()
+    gpu.cuda.synchronize()
+    d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(9)
+    small = 2
+    rows = [d.receiver_rows(cap_packets=small, stride=16) for _ in range(2)]
+    reported = failed = kept = 0
+    w = k = 0
+    pending = None
+    step = 40 * N                                                      # long steps: several channels finish a packet in each
+
+    def check_rows(r, n):
+        nonlocal kept
+        sy, ns, chn = r[0][:n].cpu().numpy(), r[1][:n].cpu().numpy(), r[2][:n].cpu().numpy()
+        for i in range(n):
+            assert any(np.array_equal(sy[i, :ns[i]], q) for _, q in refs[int(chn[i])]["packets"]), "row %d is no packet of channel %d" % (i, int(chn[i]))
+            kept += 1
+    while w < cap:
+        w = min(cap, w + (step if k else 2 * N))                        # (the first call is an ordinary step: too short for a packet)
+        try:
+            n, _ = d.receive(iq, w, rows[k & 1], async_=3)
+        except L.LoraHipError as e:
+            n = e.n_packets
+            failed += 1
+            assert n > small and d.resident_active()                    # the step needed more rows than it had; the kernel stays
+        if k == 0:
+            assert n == 0
+        else:
+            assert d.resident_active()
+            if pending is not None: check_rows(rows[pending], min(n, small))
+            pending = k & 1
+        reported += n
+        k += 1
+    try:
+        n, _ = d.receive_flush(rows[k & 1])
+    except L.LoraHipError as e:
+        n = e.n_packets
+        failed += 1
+    st = d.last_steps()
+    if pending is not None and st: check_rows(rows[pending], min(st[0][0], small))
+    reported += n
+    assert not d.resident_active()
+    assert failed >= 1 and reported == total and kept >= failed * small
+    d.rewind(); d.activate()
+    d.work_append(iq, cap)
+    assert len(d.packets()) == total
+    d.close()
+
+
 @pytest.mark.parametrize("sf,B,depth", [(7, 40, 1), (8, 13, 1), (9, 21, 2), (10, 9, 3), (7, 70, 3), (11, 7, 1), (12, 5, 2), (11, 3, 3)])
 def test_resident_receiver_equals_the_reference(gpu, oracle, sf, B, depth):
     """lorahip_demod_receive with async = 3: ONE kernel launch stays on the device, the steps arrive as messages, the kernel packs every
