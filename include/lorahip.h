@@ -403,7 +403,10 @@ int lorahip_demod_rewind(lorahip_demod *d);
  * runs until the flush, and a DEVICE-wide synchronise (hipDeviceSynchronize) waits for it --, every other entry point that needs the
  * object returns LORAHIP_E_INVALID, and every wait is bounded: a
  * wavefront that sees no message for 8 s leaves, a host call that sees no report for 5 s tells the kernel to leave and fails (the
- * object then takes ordinary steps). lorahip_demod_receive_flush(d, rows, ..) reports the last step, ends the kernel and leaves the
+ * object then takes ordinary steps). The launch is sized for an EMPTY device: a second object (another part of a mixed receiver, another
+ * process) asking for a resident kernel while the first holds the device's slots finds its census incomplete after 2 s, ends its launch and
+ * takes ordinary steps from then on -- one resident receiver per device at a time. lorahip_demod_receive_flush(d, rows, ..) reports the
+ * last step, ends the kernel and leaves the
  * object as a streaming run leaves it.
  * Ordering of the rows: a step's packets are written in stream order AFTER everything that was queued on the launch stream when
  * the call began, so a consumer (decoder) of the rows handed out by the call before, queued on that stream (or on a stream the
