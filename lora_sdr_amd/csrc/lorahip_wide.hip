@@ -749,9 +749,9 @@ demodStreamWide(const StreamArgs s)
     unsigned long long resNValid = 0;
     unsigned resCalls = 0;
     bool resMore = false;
-    for (;;)
-    {
-    if constexpr (RES)
+    // (ONE loop over the workgroup's channels, step after step -- the wait for the next step's message sits at the end of the last channel's
+    // turn, not in a loop around this one: the loop nest the compiler sees is the persistent instance's)
+    const auto nextStep = [&]() -> bool
     {
         if (wave == 0)
         {
@@ -760,12 +760,14 @@ demodStreamWide(const StreamArgs s)
             if (lane == 0) sR->go = ok ? 1 : 0;
         }
         __syncthreads();
-        if (!__builtin_amdgcn_readfirstlane(sR->go)) break;  // (the quit message, the abort flag or the watchdog: the whole workgroup leaves)
+        if (!__builtin_amdgcn_readfirstlane(sR->go)) return false;  // (the quit message, the abort flag or the watchdog: the whole workgroup leaves)
         // (of the message only n_valid stays in registers across the windows; every wavefront from LDS, wavefront 0 too: one path)
         resNValid = uni64(sR->msg[(step + 1u) & 3u].nValid);
         step++;
         resCalls = 0; resMore = false;
-    }
+        return true;
+    };
+    if constexpr (RES) { if (!nextStep()) return; }
     unsigned c = blockIdx.x;                                // (the grid never exceeds the channel count)
     do
     {
@@ -1081,14 +1083,19 @@ demodStreamWide(const StreamArgs s)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the state and the rows are in L2 / in memory before the workgroup moves on
     }
     if (PERSIST || RES) __syncthreads();                    // the next channel reuses the exchange region and the reduction records
-    } while ((PERSIST || RES) && (c += gridDim.x) < s.nChannels);    // without PERSIST / RES there is no loop at all (it would cost registers)
-    if constexpr (!RES) break;
-    else
+    if constexpr (RES)
     {
-        residentLookAhead(s, step + 1u);                    // (the relay wavefronts: the next step's message into the mirrors)
-        if (t == 0) residentWgDone(s, sR, step, resCalls, resMore ? 1u : 0u);
+        c += gridDim.x;
+        if (c >= s.nChannels)
+        {
+            // the step's last channel: report, and on to the next step
+            residentLookAhead(s, step + 1u);                // (the relay wavefronts: the next step's message into the mirrors)
+            if (t == 0) residentWgDone(s, sR, step, resCalls, resMore ? 1u : 0u);
+            if (!nextStep()) break;
+            c = blockIdx.x;
+        }
     }
-    }
+    } while (RES || (PERSIST && (c += gridDim.x) < s.nChannels));    // without PERSIST / RES there is no loop at all (it would cost registers)
 }
 
 
