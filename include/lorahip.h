@@ -298,7 +298,12 @@ int lorahip_demod_set_stream_grid(lorahip_demod *d, int max_workgroups);
  * wavefront slots empty, so the library then gives a channel 2x / 4x / 8x the lanes (8 or 4 points per lane: shorter calls, more
  * wavefronts). log2_lanes: 0 = chosen by the channel count (default), < 0 = 16 points per lane always, 4 / 5 / 6 = 16 / 32 / 64 lanes
  * per channel where the build holds that instance (SF7: 4, 5; SF8: 5, 6; SF9: 6), the default geometry elsewhere. For measurements
- * and tests. */
+ * and tests.
+ * 16 | l (l = 3, 4, 5: SF7; 4, 5: SF8; 5: SF9): a channel takes TWO groups of 2^l lanes, and the second evaluates the window the NEXT
+ * work() call will read if this one consumes exactly N samples and leaves the fine-tune state where a plain call leaves it (inside a
+ * packet, on a quiet or aligned FRAMESYNC call, on the first down-chirp); the frame machine makes that second call in the same pass
+ * when it finds the channel exactly there, and drops the window otherwise. Chosen by the library only at SF7 with at most half as many
+ * channels as the device holds wavefronts at two per SIMD (1024 on an MI355X), where it is worth 4 - 8 %. */
 int lorahip_demod_set_stream_lanes(lorahip_demod *d, int log2_lanes);
 /* log2 of the lanes per channel the object's streaming launches run on (the choice above resolved for its channel count and device;
  * SF11 / SF12: 7 / 8, a channel is a workgroup); LORAHIP_E_INVALID for a mixed object (per part: lorahip_demod_part_handle) */

@@ -613,7 +613,8 @@ class LoRaDemod:
 
     def set_stream_lanes(self, log2_lanes):
         """lanes per channel of the streaming kernels at SF7-9 (scheduling only, same results): 0 by channel count (default), < 0
-        always 16 points per lane, 4 / 5 / 6 = 16 / 32 / 64 lanes per channel where the build holds that instance"""
+        always 16 points per lane, 4 / 5 / 6 = 16 / 32 / 64 lanes per channel where the build holds that instance; 16 | l = two groups
+        of 2^l lanes per channel, the second one a window ahead of the call (lorahip.h)"""
         check(self._lib.lorahip_demod_set_stream_lanes(self._h, int(log2_lanes)), "lorahip_demod_set_stream_lanes")
 
     def stream_lanes(self):

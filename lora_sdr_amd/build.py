@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblorahip.so")
-SOURCES = ["lorahip_kernels.hip", "lorahip_fast.hip", "lorahip_wide.hip", "lorahip_stream.hip", "lorahip_stream_lanes.hip", "lorahip_resident.hip", "lorahip_codec.hip", "lorahip_chan.hip", "lorahip_api.cpp", "lorahip_tables.cpp",
+SOURCES = ["lorahip_kernels.hip", "lorahip_fast.hip", "lorahip_wide.hip", "lorahip_stream.hip", "lorahip_stream_lanes.hip", "lorahip_stream_pairs.hip", "lorahip_resident.hip", "lorahip_codec.hip", "lorahip_chan.hip", "lorahip_api.cpp", "lorahip_tables.cpp",
            "lorahip_demod.cpp", "lorahip_mixed.cpp", "lorahip_upload.cpp", "lorahip_rx.cpp", "lorahip_fma_fast.hip", "lorahip_fma_wide.hip"]
 HEADERS = ["lorahip_internal.h", "lorahip_device.h", "lorahip_fft.h", "lorahip_fastcore.h", "lorahip_framemachine.h", "lorahip_streamkernel.h", "lorahip_residentproto.h", "lorahip_streamcfg.h", "lorahip_fine.h", os.path.join("..", "..", "include", "lorahip.h")]
 INCLUDED_SOURCES = {"lorahip_fma_fast.hip": ["lorahip_fast.hip"], "lorahip_fma_wide.hip": ["lorahip_wide.hip"]}

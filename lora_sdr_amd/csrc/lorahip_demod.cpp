@@ -2053,7 +2053,7 @@ int lorahip_demod_set_stream_grid(lorahip_demod *dm, const int max_workgroups)
 
 int lorahip_demod_set_stream_lanes(lorahip_demod *dm, const int log2_lanes)
 {
-    if (dm == nullptr || log2_lanes > 6) return LORAHIP_E_INVALID;
+    if (dm == nullptr || (log2_lanes > 6 && (log2_lanes < (LORAHIP_LANES_AHEAD | 3) || log2_lanes > (LORAHIP_LANES_AHEAD | 5)))) return LORAHIP_E_INVALID;
     if (dm->comp)
     {
         for (size_t i = 0; i < dm->comp->numParts(); i++) { const int rc = lorahip_demod_set_stream_lanes(dm->comp->part(i), log2_lanes); if (rc != LORAHIP_OK) return rc; }

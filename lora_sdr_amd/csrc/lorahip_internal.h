@@ -271,6 +271,11 @@ hipError_t launchStreamResidentWide(int sf, const StreamArgs &s, hipStream_t str
 bool streamLanesAvailable(int sf, int log2Lanes);
 int streamLanesChosen(int sf, unsigned nChannels, int forced);
 hipError_t launchStreamLanes(int sf, int log2Lanes, const StreamArgs &s, hipStream_t stream);
+//! a lanes code with this bit: the AHEAD instance over windows of 2^(code & 15) lanes (lorahip_stream_pairs.hip) -- a channel takes two such
+//! lane groups, the second evaluates the window the NEXT call reads if this one is plain
+constexpr int LORAHIP_LANES_AHEAD = 16;
+bool streamPairsAvailable(int sf, int log2WindowLanes);
+hipError_t launchStreamPairs(int sf, int log2WindowLanes, const StreamArgs &s, hipStream_t stream);
 hipError_t launchCompactRows(void *dst, const void *src, size_t rows, size_t srcPitchBytes, size_t rowBytes, hipStream_t stream);
 hipError_t launchPackSignals(const StreamSignal *sigOut, const int *nSig, size_t nChannels, int capPkt, int *channel, int *error, float *power, float *snr,
                              size_t firstRow, size_t capRows, hipStream_t stream);

@@ -32,11 +32,21 @@ namespace lorahip {
 //! device takes the instance without it (one workgroup per channel set).
 //! RES: the resident receiver -- the launch stays, the steps arrive as messages (residentWait / residentStepEnd above). One workgroup
 //! per channel set, all of them resident at once (the launcher checks); s.flags carries the carry bits only.
-template <class C, bool PERSIST, bool RES = false>
+//! AHEAD: a channel takes TWO lane groups of the wavefront. The first evaluates the call's window as ever; the second, at the same
+//! time, the window the NEXT call will read if this one consumes exactly N samples and leaves the fine-tune state where a plain
+//! call leaves it (DATASYMBOLS inside a packet, a quiet or aligned FRAMESYNC call, the first down-chirp: most calls of a receiver
+//! that is following frames). The frame machine then runs for the first window, looks whether the state it left is the one the
+//! second window was evaluated for -- position, fine-tune index and error, table, state -- and if so runs for the second window
+//! too: two work() calls of the chain in one pass. If not, the second window's results are dropped and nothing of them is kept or
+//! counted. For receivers with fewer channels than the device holds wavefronts (lorahip_stream_pairs.hip): a chain's time is the
+//! time of its passes, and this halves their number where the guess holds. Scheduling only: every call sees the operands it would
+//! have seen alone.
+template <class C, bool PERSIST, bool RES = false, bool AHEAD = false>
 __global__ void __launch_bounds__(256, C::WAVES_PER_SIMD)
 demodStream(const StreamArgs s)
 {
     static_assert(!(RES && PERSIST), "the resident receiver has one workgroup per channel set");
+    static_assert(!AHEAD || (!RES && !PERSIST && C::WPW >= 2 && C::PREFETCH == 0), "the look-ahead instances: one-launch grids, two lane groups per channel");
     typedef FastCore<C> K;
     constexpr int N = C::N, T = C::T, VEC = C::VEC, R = C::R, WPW = C::WPW;
     constexpr int LOG2T = C::LOG2T;
@@ -53,8 +63,11 @@ demodStream(const StreamArgs s)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wsub = lane >> LOG2T;                        // channel inside the wavefront
+    const int wsub = lane >> LOG2T;                        // lane group (window slot) inside the wavefront
     const int t = lane & (T - 1);
+    constexpr int CPW = AHEAD ? WPW / 2 : WPW;              // channels per wavefront
+    const bool roleB = AHEAD ? (wsub & 1) != 0 : false;     // AHEAD: the group that evaluates the window after the call's
+    const int csub = AHEAD ? wsub >> 1 : wsub;              // channel inside the wavefront
     v2f *X = sX + wave * XW;
 
     const v2f *gIq = reinterpret_cast<const v2f *>(s.iq), *gFine = reinterpret_cast<const v2f *>(s.fine);
@@ -87,7 +100,7 @@ demodStream(const StreamArgs s)
     // The grid is PERSISTENT: at most the resident number of workgroups (s.maxBlocks), each walking one set of WAVES * WPW channels
     // after the other -- the tables above are loaded once, and a launch over more channels than fit the device does not run a second,
     // half-empty round of workgroups. From here on the wavefronts of a workgroup are independent (no workgroup barrier below).
-    const unsigned nSets = (s.nChannels + WAVES * WPW - 1) / (WAVES * WPW);
+    const unsigned nSets = (s.nChannels + WAVES * CPW - 1) / (WAVES * CPW);
     // RES: one turn of this loop per receiver step (otherwise exactly one turn). In a step the workgroup walks its channel sets --
     // blockIdx.x, + gridDim.x, ... like a persistent grid -- with the tables it staged once; a channel's state lives in s.state between the
     // steps (40 bytes per channel and step, against 8 N per window read).
@@ -129,7 +142,7 @@ demodStream(const StreamArgs s)
     do
     {
     // ---- this lane group's channel and its state (replicated in the T lanes) ----------------------
-    const unsigned c = UNI ? (unsigned)uniI(int((cset * WAVES + wave) * WPW)) : (cset * WAVES + wave) * WPW + wsub;
+    const unsigned c = UNI ? (unsigned)uniI(int((cset * WAVES + wave) * WPW)) : (cset * WAVES + wave) * CPW + csub;
     const bool mine = c < s.nChannels;
     const unsigned cc = mine ? c : 0;
     StreamState st;
@@ -158,7 +171,9 @@ demodStream(const StreamArgs s)
         o.pktOut = reinterpret_cast<StreamPacket *>(reinterpret_cast<char *>(o.pktOut) + setOff);
         if (o.sigOut) o.sigOut = reinterpret_cast<StreamSignal *>(reinterpret_cast<char *>(o.sigOut) + setOff);
     }
-    if (mine) o.carryIn(s, st, cc, t, T, !(RES && LORAHIP_RES_NOCOPY));                 // the packet the channel is inside: its symbols so far, from the carry rows
+    const int tc = AHEAD ? t + (roleB ? T : 0) : t;         // lane inside the channel's lanes, TC of them
+    constexpr int TC = AHEAD ? 2 * T : T;
+    if (mine) o.carryIn(s, st, cc, tc, TC, !(RES && LORAHIP_RES_NOCOPY));                 // the packet the channel is inside: its symbols so far, from the carry rows
     if (dbgW && step > 0u && setIdx == 0) s.res->dbg[(step - 1u) & 7u][2] = wall_clock64();
 
     // one window: LoRaDemod.cpp:157-166 + LoRaDetector::detect. Every lane of the wavefront takes part; groups
@@ -188,6 +203,13 @@ demodStream(const StreamArgs s)
     constexpr bool PF = C::PREFETCH != 0;
     v2f xp[PF ? R : 1][PF ? VEC : 1];
     long long pfOff = -1;
+    // the near-threshold counters (StreamArgs::near): a window evaluated ahead is counted when -- and only if -- its call is made
+    int nearAhead = 0;
+    const auto noteNear = [&](const int which, const bool yes)
+    {
+        if (AHEAD && roleB) nearAhead |= yes ? 1 << which : 0;
+        else if (yes) atomicAdd(s.near + which, 1u);
+    };
     auto detect = [&](const bool full, const bool on, const bool wantSq, const bool wantLogs, const int wantFi, const long long off, const bool downTable, const int idx0, const float err,
                       int &value, float &power, float &powerAvg, float &fIndex, int &idxEnd, bool &squelched)
     {
@@ -231,7 +253,7 @@ demodStream(const StreamArgs s)
                 __builtin_amdgcn_wave_barrier();
             }
             if (moving) idxEnd = e;
-            if (moving && t == 0 && nearStep(d)) atomicAdd(s.near + 1, 1u);          // counted, not changed (lorahip_internal.h)
+            noteNear(1, moving && t == 0 && nearStep(d));                            // counted, not changed (lorahip_internal.h)
         }
         TMARK_NOWAIT(0);
         TMARK(1);
@@ -309,7 +331,7 @@ demodStream(const StreamArgs s)
             __builtin_amdgcn_wave_barrier();
             tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
             squelched = (power - powerAvg) < s.thresh;                                   // :173-174
-            if (on && wantSq && t == 0 && nearSquelch(power - powerAvg, s.thresh)) atomicAdd(s.near, 1u);
+            noteNear(0, on && wantSq && t == 0 && nearSquelch(power - powerAvg, s.thresh));
         }
         else
         {
@@ -345,7 +367,7 @@ demodStream(const StreamArgs s)
                     }
                     tailValuesPaired(s.powerScale, bestV, tot, l, r, lane, power, powerAvg, fIndex);
                     squelched = (power - powerAvg) < s.thresh;                           // the quick decision where it was sure, by construction
-                    if (exact && t == 0 && nearSquelch(power - powerAvg, s.thresh)) atomicAdd(s.near, 1u);
+                    noteNear(0, exact && t == 0 && nearSquelch(power - powerAvg, s.thresh));
                     power = logs ? power : 0.0f; powerAvg = logs ? powerAvg : 0.0f;     // (what the signal record takes; nobody else reads them)
                 }
                 else fIndex = fIndexPaired(bestV, l, r, lane);
@@ -360,6 +382,8 @@ demodStream(const StreamArgs s)
 
 #ifdef LORAHIP_STREAM_TIMING
     tlast = __builtin_amdgcn_s_memtime();
+    int tPasses = 0;
+    const unsigned long long tBegin = tlast;
 #endif
     // A FRAMESYNC call that is sync'd and matches the first sync word looks at a SECOND window (LoRaDemod.cpp:183-206). The wave's
     // channels run in lock step, so a second detect() inside the pass would be paid by all of them; instead the call is split over
@@ -367,6 +391,9 @@ demodStream(const StreamArgs s)
     // slot of the next pass -- while the other channels do their next calls -- and completes the frame machine step. Nothing is
     // written and nothing is consumed in between, and the limits checked for the first pass cover the whole call.
     bool pend = false;
+    bool fsPlain = false;                                   // AHEAD: the channel's last FRAMESYNC call consumed N and left the fine-tune state alone
+    float planErr = __uint_as_float(0x7fc00000u);           // AHEAD: the error planStepN / planMod were derived from (NaN: none yet)
+    unsigned planStepN = 0u, planMod = 0u;                  //        N q mod M' and M' of lorahip_fine.h's closed form (planMod 0: the form does not apply)
     int value0 = 0, fineIdxBefore0 = 0;
     float snr0 = 0.0f, fineErrBefore0 = 0.0f;
     const int slot = wavefrontSlot();
@@ -377,60 +404,173 @@ demodStream(const StreamArgs s)
         if (lastRound) rotatePriority<2, LORAHIP_PRIO_ALTERNATE>(slot);
         const bool live = mine && (pend || ((len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt && o.nSig < s.capPkt));   // LoRaDemod.cpp:148
         if (!__any(live)) break;
+#ifdef LORAHIP_STREAM_TIMING
+        tPasses++;
+#endif
 
         // ---- this pass's window: window 0 of a call (:157-172), or window 1 of a parked one (:189-206) ----
         const bool second = pend;
         int value, idxEnd;
         float power, powerAvg, fIndex;
-        const int fineIdxBefore = second ? fineIdxBefore0 : st.fineTuneIndex;
-        const float fineErrBefore = second ? fineErrBefore0 : st.finefreqError;
         const long long here = base + st.pos + (second ? N : 0);
         const bool fs = st.state == ST_FRAMESYNC;
         bool squelched;
+        // AHEAD: what the call after this one reads and is, IF this one turns out plain -- N samples on (:320 with total = N), the index
+        // where this window's N steps leave it (:160-162; lorahip_fine.h's closed form, checked against the committed index below), the
+        // same error and table, DATASYMBOLS / FRAMESYNC again or the second down-chirp after the first (:243). Not tried from the other
+        // states (the calls around the quarter chirp move by something else, :278), nor while a sync check is parked.
+        const int stateAhead = st.state == ST_DOWNCHIRP0 ? ST_DOWNCHIRP1 : st.state;
+        const long long posAhead = st.pos + N;
+        const float errAhead = st.finefreqError;
+        const int tableAhead = st.downTable;
+        int idxAhead = st.fineTuneIndex;
+        bool tryAhead = false;
+        if constexpr (AHEAD)
+        {
+            // (the index after N steps of the closed form, lorahip_fine.h: (idx + N q) mod M' -- N q mod M' kept per channel for as long as
+            // the error stays, which inside a packet is the whole packet; a window where the form does not hold, or lands on M', ends on
+            // another index than this and the second call is simply not made)
+            if (__any(live && errAhead != planErr))
+            {
+                const FinePlan pa = finePlan(errAhead * (float)LORAHIP_FINE_STEPS, K::M);   // (d = 0: q = 0, the index stays)
+                planErr = errAhead;
+                // (0 < d < 1, `sat`: the index walks down by one per sample and stays at 0 -- marked by a modulus no sum reaches)
+                planMod = pa.regular ? (pa.sat ? 0x80000000u : pa.mod) : 0u;
+                planStepN = pa.sat ? 0u : fineReduce(pa.q << C::LOG2N, pa, C::LOG2N + 7);
+            }
+            {
+                const unsigned sum = unsigned(st.fineTuneIndex) + planStepN, wrapped = sum - planMod;
+                const int down = st.fineTuneIndex - N;
+                idxAhead = planMod == 0x80000000u ? (down > 0 ? down : 0) : int(sum < wrapped ? sum : wrapped);
+            }
+            // (FRAMESYNC: only while the channel's last FRAMESYNC call was a plain one -- on noise above the threshold every call moves the
+            // window, :219, and a window evaluated ahead there is work for nothing in every pass)
+            tryAhead = live && !second && planMod != 0u && errAhead == planErr && ((fs && fsPlain) || st.state == ST_DATASYMBOLS || st.state == ST_DOWNCHIRP0);
+            nearAhead = 0;
+        }
+        const bool onG = roleB ? tryAhead : live;
+        const int stG = roleB ? stateAhead : st.state;
+        const bool firstG = roleB || !second;                   // this group's window is window 0 of its call
         // Signals without a trace: the one call per packet that emits them evaluates power and snr through the exact chain of the
         // untraced path (the same operations on the same operands as the traced path's: the same bits) -- for the channels that are in
         // that call, not, as the traced path would, the fp64 scan and both logarithms for every channel of the wavefront whenever one
         // of them is there (SF7: 8 channels per wavefront, 0.378 -> of the roofline with signals kept against 0.442 without, round 5)
-        detect(all, live, !second && (fs || st.state == ST_DATASYMBOLS), sig && live && !second && st.state == ST_DOWNCHIRP1, second ? 2 : (fs ? 1 : 0), here, st.downTable != 0, st.fineTuneIndex,
+        detect(all, onG, firstG && (stG == ST_FRAMESYNC || stG == ST_DATASYMBOLS), sig && onG && firstG && stG == ST_DOWNCHIRP1, firstG ? (stG == ST_FRAMESYNC ? 1 : 0) : 2,
+               roleB ? base + posAhead : here, st.downTable != 0, roleB ? idxAhead : st.fineTuneIndex,
                st.finefreqError, value, power, powerAvg, fIndex, idxEnd, squelched);
+        // AHEAD: the two groups of a channel tell each other what they found (the channel's state is replicated in both)
+        int valueB = 0, idxEndB = 0;
+        float powerB = 0.0f, powerAvgB = 0.0f, fIndexB = 0.0f;
+        bool squelchedB = false;
+        if constexpr (AHEAD)
+        {
+            // (one word: value < N <= 2^9, the squelch bit, the index < 128 N <= 2^16)
+            static_assert(C::LOG2N <= 9, "the packed exchange");
+            const int mineW = value | (squelched ? 1 << 12 : 0) | (idxEnd << 13);
+            const int otherW = __shfl_xor(mineW, T);
+            const int aW = roleB ? otherW : mineW, bW = roleB ? mineW : otherW;
+            value = aW & 0xfff; squelched = (aW & (1 << 12)) != 0; idxEnd = int(unsigned(aW) >> 13);
+            valueB = bW & 0xfff; squelchedB = (bW & (1 << 12)) != 0; idxEndB = int(unsigned(bW) >> 13);
+            // (the float outputs reach the frame machine from FRAMESYNC windows, the signals' call and a trace only)
+            if (all || __any(live && st.state != ST_DATASYMBOLS))
+            {
+                const float oP = __shfl_xor(power, T), oA = __shfl_xor(powerAvg, T), oF = __shfl_xor(fIndex, T);
+                powerB = roleB ? power : oP; power = roleB ? oP : power;
+                powerAvgB = roleB ? powerAvg : oA; powerAvg = roleB ? oA : powerAvg;
+                fIndexB = roleB ? fIndex : oF; fIndex = roleB ? oF : fIndex;
+            }
+            else power = powerAvg = fIndex = 0.0f;              // (what detect() leaves there on the untraced path)
+        }
+
+        // one call after its window: returns whether the frame machine stepped (false: idle, or parked for its second window)
+        const auto finish = [&](const bool liveX, const bool secondX, int value, float power, const float powerAvg, const float fIndex, const int idxEnd, bool squelched) -> bool
+        {
+        const int fineIdxBefore = secondX ? fineIdxBefore0 : st.fineTuneIndex;
+        const float fineErrBefore = secondX ? fineErrBefore0 : st.finefreqError;
+        const bool fs = st.state == ST_FRAMESYNC;
         float snr = power - powerAvg;                                                   // :173 (squelched = snr < thresh, :174, comes from detect)
         // window 0: the loop commits the member (:160-162); window 1: `int ft = _fineTuneIndex` (:191) starts from the committed
         // index and is not committed itself
-        if (live && !second) st.fineTuneIndex = idxEnd;
+        if (liveX && !secondX) st.fineTuneIndex = idxEnd;
 
         // (selects, not branches: the wave's channels are in different states at once, see frameStep)
         const bool syncdW = !squelched && (st.prevValue + 4) / 8 == 0;                 // :183
         const int word = (value + 4) / 8;
         // window 0 of a sync'd FRAMESYNC call that matches the first sync word: park it, its window 1 comes in the next pass
-        const bool park = live && !second && fs && syncdW && word == (s.sync >> 4);    // :184
-        const bool match1 = second && word == (s.sync & 0xf);                          // :205
+        const bool park = liveX && !secondX && fs && syncdW && word == (s.sync >> 4);  // :184
+        const bool match1 = secondX && word == (s.sync & 0xf);                         // :205
         // detect() of window 1 overwrote power / powerAvg / fIndex (:203); value, snr and what follows from them are window 0's
         value0 = park ? value : value0; snr0 = park ? snr : snr0;
         fineIdxBefore0 = park ? fineIdxBefore : fineIdxBefore0; fineErrBefore0 = park ? fineErrBefore : fineErrBefore0;
-        value = second ? value0 : value; snr = second ? snr0 : snr;
-        squelched = second ? false : squelched;
-        const bool syncd = second || syncdW, match0 = second || word == (s.sync >> 4);
-        pend = park;
-        const bool step = live && !park;
+        value = secondX ? value0 : value; snr = secondX ? snr0 : snr;
+        squelched = secondX ? false : squelched;
+        const bool syncd = secondX || syncdW, match0 = secondX || word == (s.sync >> 4);
+        pend = AHEAD ? (liveX ? park : pend) : park;            // (not live: nothing is parked -- but AHEAD's second call must not un-park the first)
+        const bool step = liveX && !park;
 
         // ---- the frame machine (:176-312) ----
         TMARK(8);
         if (step)
         {
-            frameStep<N>(st, s, o, t == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
+            frameStep<N>(st, s, o, tc == 0, value, power, powerAvg, snr, fIndex, squelched, syncd, match0, match1, fineIdxBefore, fineErrBefore);
             st.finefreqError = uniF(st.finefreqError);          // a float add runs on the vector unit: back to a scalar where uniform
         }
+        return step;
+        };
+        const bool stepped = finish(live, second, value, power, powerAvg, fIndex, idxEnd, squelched);
+        if constexpr (AHEAD)
+        {
+            if (live && !second && fs)
+                fsPlain = stepped && st.state == ST_FRAMESYNC && int(st.pos) == int(posAhead) && st.fineTuneIndex == idxAhead && st.finefreqError == errAhead;
+            // the call after: is the channel where the second group's window was evaluated for? (every input of that window's
+            // detect() and the state its wants were derived from; then :148's conditions for a call)
+            const bool live2 = tryAhead && stepped && st.state == stateAhead && int(st.pos) == int(posAhead) && st.fineTuneIndex == idxAhead && st.finefreqError == errAhead    // (positions: a call moves by less than 2^31)
+                               && st.downTable == tableAhead && (len - st.pos >= 2 * N) && o.calls < s.cap && o.nPkt < s.capPkt && o.nSig < s.capPkt;
+            if (__any(live2))
+            {
+                if (!all && __all(!live2 || st.state == ST_DATASYMBOLS))
+                {
+                    // every second call of the wavefront is inside a packet: the DATASYMBOLS arm alone (:160-162, :290-300, :320, :326), as
+                    // frameStep takes it -- a twentieth of the machine written as selects over all five states
+                    if (live2)
+                    {
+                        st.fineTuneIndex = idxEndB;                                                          // :160-162
+                        const int symCount = st.symCount + 1;
+                        const bool post = (unsigned)symCount >= s.mtu || squelchedB;                         // :291
+#ifndef LORAHIP_TIMING_NO_RECORD_STORES
+                        if (tc == 0) o.symOut[o.nSym] = (short)valueB;                                       // out[_symCount++] = value  :290
+#endif
+                        if (tc == 0 && post) { StreamPacket q; q.callIndex = st.callCount; q.len = symCount; o.pktOut[o.nPkt] = q; }   // :295-298
+                        o.nSym++; o.nPkt += post ? 1 : 0; o.calls++;
+                        st.finefreqError = post ? 0.0f : st.finefreqError;                                   // :299
+                        st.state = post ? ST_FRAMESYNC : ST_DATASYMBOLS;                                     // :300
+                        st.symCount = symCount;
+                        st.prevValue = (short)valueB;                                                        // :326
+                        st.pos += N;                                                                         // :320
+                        st.callCount++;
+                    }
+                }
+                else (void)finish(live2, false, valueB, powerB, powerAvgB, fIndexB, idxEndB, squelchedB);
+                if (live2 && roleB && t == 0 && nearAhead != 0)
+                {
+                    if (nearAhead & 1) atomicAdd(s.near, 1u);
+                    if (nearAhead & 2) atomicAdd(s.near + 1, 1u);
+                }
+            }
+        }
+        else (void)stepped;
+        TMARK(9);
     }
 #ifdef LORAHIP_STREAM_TIMING
     if (blockIdx.x == 7 && threadIdx.x == 0)
         printf("stream timing (s_memtime ticks): index math %llu, load wait %llu, chirp+dechirp %llu, fft %llu, scan+reductions %llu, squelch estimate %llu, neighbours+fIndex+exact tail %llu, "
-               "uniform/epilogue of detect %llu, sync/match logic %llu, frame step+records+loop top %llu; calls %d\n",
-               tsec[0], tsec[1], tsec[2], tsec[3], tsec[6], tsec[7], tsec[4], 0ull, tsec[8], tsec[5], o.calls);
+               "uniform/epilogue of detect %llu, sync/match logic %llu, frame step(s)+records %llu, loop top %llu; calls %d in %d passes of the wavefront, %llu ticks\n",
+               tsec[0], tsec[1], tsec[2], tsec[3], tsec[6], tsec[7], tsec[4], 0ull, tsec[8], tsec[9], tsec[5], o.calls, tPasses, (unsigned long long)__builtin_amdgcn_s_memtime() - tBegin);
 #endif
     // (RES: the step's packets leave first -- a packet's first symbols may still be in the carry row carryOut is about to overwrite)
     if constexpr (RES && LORAHIP_RES_NOCOPY) residentPackOwn<C>(s, sR, step, (cset * WAVES + unsigned(wave)) * unsigned(WPW), o, mine, lane, st.state == ST_DATASYMBOLS ? st.symCount : 0);
-    o.carryOut(s, st, cc, t, T, mine);
-    if (mine && t == 0)
+    o.carryOut(s, st, cc, tc, TC, mine);
+    if (mine && tc == 0)
     {
         s.state[c] = st;
         s.nCalls[c] = o.calls;
@@ -465,7 +605,7 @@ demodStream(const StreamArgs s)
     }
 }
 
-template <class C>
+template <class C, bool AHEAD = false>
 static hipError_t launchStreamCfg(const StreamArgs &args, hipStream_t stream)
 {
     constexpr int WAVES = 4;
@@ -473,11 +613,11 @@ static hipError_t launchStreamCfg(const StreamArgs &args, hipStream_t stream)
     static unsigned long long attrDone = 0, attrDoneP = 0;
     static PerDeviceCount resident;
     StreamArgs s = args;
-    const unsigned perBlock = WAVES * C::WPW;
+    const unsigned perBlock = WAVES * (AHEAD ? C::WPW / 2 : C::WPW);
     const unsigned grid = (s.nChannels + perBlock - 1) / perBlock;
     if (grid == 0) return hipSuccess;
 #if defined(LORAHIP_ALL_VARIANTS) || defined(LORAHIP_STREAM_PERSIST)      // the persistent grid: profiling builds only (lorahip_demod.cpp::runStream)
-    if (s.maxBlocks > 0 && grid > unsigned(s.maxBlocks))
+    if (!AHEAD && s.maxBlocks > 0 && grid > unsigned(s.maxBlocks))
     {
         const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, true>), smem, attrDoneP);
         if (e != hipSuccess) return e;
@@ -487,10 +627,10 @@ static hipError_t launchStreamCfg(const StreamArgs &args, hipStream_t stream)
     }
 #endif
     (void)attrDoneP;
-    const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, false>), smem, attrDone);
+    const hipError_t e = ensureDynamicLds(reinterpret_cast<const void *>(demodStream<C, false, false, AHEAD>), smem, attrDone);
     if (e != hipSuccess) return e;
-    s.lastRoundFrom = lastRoundFrom(grid, residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStream<C, false>), WAVES * 64, smem));
-    hipLaunchKernelGGL((demodStream<C, false>), dim3(grid), dim3(WAVES * 64), smem, stream, s);
+    s.lastRoundFrom = lastRoundFrom(grid, residentWorkgroupsCached(resident, reinterpret_cast<const void *>(demodStream<C, false, false, AHEAD>), WAVES * 64, smem));
+    hipLaunchKernelGGL((demodStream<C, false, false, AHEAD>), dim3(grid), dim3(WAVES * 64), smem, stream, s);
     return hipGetLastError();
 }
 

@@ -9,7 +9,9 @@ from test_gpu_demod import frames, compare_channel
 
 pytestmark = pytest.mark.gpu
 
-INSTANCES = [(7, 4), (7, 5), (8, 5), (8, 6), (9, 6)]        # (SF, log2 lanes per channel)
+AHEAD = 16                                                  # lorahip.h: LORAHIP_LANES_AHEAD | log2 lanes of one window -- two windows per channel and pass
+INSTANCES = [(7, 4), (7, 5), (8, 5), (8, 6), (9, 6),        # (SF, log2 lanes per channel)
+             (7, AHEAD | 3), (7, AHEAD | 4), (7, AHEAD | 5), (8, AHEAD | 4), (8, AHEAD | 5), (9, AHEAD | 5)]
 
 
 def _host(oracle, rng, sf, B, n_frames, nsyms):
@@ -32,6 +34,7 @@ def test_traces_packets_and_signals_equal_the_reference(gpu, oracle, sf, lanes):
     refs = [oracle.demod_run(sf, host[c], mtu=10) for c in range(B)]
     iq = gpu.from_numpy(host).cuda()
     d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(10); d.set_stream_lanes(lanes); d.set_trace(True)
+    assert d.stream_lanes() == lanes                          # the build holds the instance
     d.work(iq)
     pk = d.packets()
     for c in range(B):
@@ -134,3 +137,9 @@ def test_the_choice_follows_the_channel_count(gpu):
         few.set_stream_lanes(6)
         assert few.stream_lanes() == (6 if sf in (8, 9) else base)
         few.close()
+    # a sixteenth of the slots at SF7: two groups of 32 lanes per channel, the second a window ahead (lorahip_stream_pairs.hip)
+    fewer = L.LoRaDemod(7, n_channels=slots // 2)
+    assert fewer.stream_lanes() == (AHEAD | 5)
+    fewer.set_stream_lanes(5)
+    assert fewer.stream_lanes() == 5
+    fewer.close()

@@ -9,13 +9,13 @@ from lora_sdr_amd import workloads as WL
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sf", type=int, nargs="+", default=[7, 8, 9])
-ap.add_argument("--lanes", type=int, nargs="+", default=[-1, 4, 5, 6, 0])
+ap.add_argument("--lanes", type=int, nargs="+", default=[-1, 4, 5, 6, 19, 20, 21, 0])   # 16 | l: the AHEAD instances (lorahip_stream_pairs.hip)
 ap.add_argument("--counts", type=int, nargs="+", default=None)
 ap.add_argument("--passes", type=int, default=5)
 a = ap.parse_args()
 DEF = {7: (1024, 2048, 4096, 8192, 12288, 16384), 8: (512, 1024, 2048, 4096, 8192), 9: (256, 512, 1024, 2048, 4096), 10: (512, 1024, 2048),
        11: (256, 512, 1024, 2048), 12: (128, 256, 512, 1024)}
-AVAIL = {7: (4, 5), 8: (5, 6), 9: (6,)}
+AVAIL = {7: (4, 5, 19, 20, 21), 8: (5, 6, 20, 21), 9: (6, 21)}
 for sf in a.sf:
     ctx = L.Context(sf)
     for B in (a.counts or DEF[sf]):

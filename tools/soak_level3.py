@@ -21,6 +21,7 @@ per_sf = {}
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     sf = int(rng.integers(7, 13)); N = 1 << sf
+    if "SOAK_SFS" in os.environ: sf = int(rng.choice([int(x) for x in os.environ["SOAK_SFS"].split(",")])); N = 1 << sf      # e.g. SOAK_SFS=7,8,9 with SOAK_LANES_SET=19,20,21
     B = int(rng.integers(1, 24 if sf < 11 else 10))
     mtu = int(rng.integers(3, 40)); thresh = float(rng.uniform(-40, -5)); sync = int(rng.integers(0, 256)) if rng.random() < 0.3 else 0x12
     streams = []
@@ -36,7 +37,9 @@ while time.time() < t_end:
     iq = torch.from_numpy(host).cuda()
     d = L.LoRaDemod(sf, n_channels=B); d.set_mode(1); d.setMTU(mtu); d.setThreshold(thresh); d.setSync(sync)
     d.set_stream_grid(int(rng.choice([0, -1, 1, 2, 5])))
-    lanes = int(rng.choice([0, -1, 4, 5, 6])) if os.environ.get("SOAK_LANES", "1") != "0" else 0     # SF7-9: more lanes per channel (lorahip_stream_lanes.hip)
+    # SF7-9: more lanes per channel (lorahip_stream_lanes.hip), and 16 | l: two windows of 2^l lanes per channel, the second one ahead (lorahip_stream_pairs.hip)
+    lanes_set = [int(x) for x in os.environ["SOAK_LANES_SET"].split(",")] if "SOAK_LANES_SET" in os.environ else [0, -1, 4, 5, 6, 19, 20, 21]
+    lanes = int(rng.choice(lanes_set)) if os.environ.get("SOAK_LANES", "1") != "0" else 0
     d.set_stream_lanes(lanes)
     how = int(rng.integers(0, 4)) if "SOAK_HOW" not in os.environ else (int(rng.integers(0, 4)), int(os.environ["SOAK_HOW"]))[1]                        # 0 one shot, 1 sequential steps, 2 pipelined, 3 resident
     sigs = rng.random() < 0.5                            # the block's signals (error / power / snr at DOWNCHIRP1) kept and compared too
