@@ -350,7 +350,7 @@ static int streamLanesFor(const int sf, const unsigned nChannels)
     for (int l = base + 1; l <= 6; l++)
         if (streamLanesAvailable(sf, l) && (unsigned long long)nChannels << l <= (unsigned long long)slots * 64u) best = l;
     // Where even 32 lanes per channel leave half of the slots empty, SF7 takes two such lane groups per channel, the second one a
-    // window ahead (lorahip_stream_pairs.hip): measured +8 % at 512 channels, +4 % at 1024, -1 % at 2048 (profiles/r06/a7_*). The other
+    // window ahead (lorahip_stream_pairs.hip): measured +8 % at 512 channels, +4 % at 1024, -1 % at 2048 (profiles/r06/s37_ahead_*). The other
     // AHEAD instances never won against the lanes instance that fills the same slots and run only when asked for.
     if (sf == 7 && best == 5 && (unsigned long long)nChannels * 128u <= (unsigned long long)slots * 64u && streamLanesAvailable(sf, LORAHIP_LANES_AHEAD | 5))
         best = LORAHIP_LANES_AHEAD | 5;
