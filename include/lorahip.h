@@ -303,7 +303,9 @@ int lorahip_demod_set_stream_grid(lorahip_demod *d, int max_workgroups);
  * work() call will read if this one consumes exactly N samples and leaves the fine-tune state where a plain call leaves it (inside a
  * packet, on a quiet or aligned FRAMESYNC call, on the first down-chirp); the frame machine makes that second call in the same pass
  * when it finds the channel exactly there, and drops the window otherwise. Chosen by the library only at SF7 with at most half as many
- * channels as the device holds wavefronts at two per SIMD (1024 on an MI355X), where it is worth 4 - 8 %. */
+ * channels as the device holds wavefronts at two per SIMD (1024 on an MI355X), where it is worth 4 - 8 %.
+ * The parts of a mixed object (lorahip_demod_create_mixed) run side by side on their device: where the choice is the library's, a
+ * part counts the wavefronts its sibling parts bring (at 16 points per lane) as taken, and widens only into what is left. */
 int lorahip_demod_set_stream_lanes(lorahip_demod *d, int log2_lanes);
 /* log2 of the lanes per channel the object's streaming launches run on (the choice above resolved for its channel count and device;
  * SF11 / SF12: 7 / 8, a channel is a workgroup); LORAHIP_E_INVALID for a mixed object (per part: lorahip_demod_part_handle) */

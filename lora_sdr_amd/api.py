@@ -617,6 +617,18 @@ class LoRaDemod:
         of 2^l lanes per channel, the second one a window ahead of the call (lorahip.h)"""
         check(self._lib.lorahip_demod_set_stream_lanes(self._h, int(log2_lanes)), "lorahip_demod_set_stream_lanes")
 
+    def part_stream_lanes(self):
+        """mixed form: log2 of the lanes per channel each part's streaming launches run on, in the order of `parts` (a part counts the
+        wavefronts its sibling parts put on the same device: lorahip.h, lorahip_demod_create_mixed)"""
+        out = []
+        for i in range(len(self.parts)):
+            h = self._lib.lorahip_demod_part_handle(self._h, i)
+            v = int(self._lib.lorahip_demod_stream_lanes(C.c_void_p(h)))
+            if v < 0:
+                raise _lib.LoraHipError(v, "lorahip_demod_stream_lanes")
+            out.append(v)
+        return out
+
     def stream_lanes(self):
         """log2 of the lanes per channel the streaming launches of this object run on"""
         v = int(self._lib.lorahip_demod_stream_lanes(self._h))

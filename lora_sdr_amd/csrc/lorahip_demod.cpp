@@ -69,6 +69,7 @@ struct lorahip_demod
     int streamGrid;                  // lorahip_demod_set_stream_grid: 0 default, < 0 one workgroup per channel set, > 0 at most that many workgroups
     size_t streamCapMax;             // lorahip_demod_set_record_capacity: 0 = no bound beyond the library's own
     int streamLanes;                 // lorahip_demod_set_stream_lanes: 0 by channel count, < 0 always 16 points per lane, else log2 of the lanes per channel
+    unsigned coWaves;                // a part of a mixed object: the wavefronts its sibling parts put on the same device (the automatic choice counts them)
     lorahip::Composite *comp;        // non-null: the handle is a container of (device, SF) parts (lorahip_rx.cpp); nothing below is used then
     lorahip_ctx *ctx;
     size_t N, B;
@@ -683,6 +684,15 @@ static int syncMirrors(lorahip_demod *dm)
     return LORAHIP_OK;
 }
 
+//! StreamArgs::lanes of this object's launches: what was asked for; where nothing was and sibling parts share the device (a mixed
+//! object), the automatic choice made HERE with their wavefronts counted -- as an explicit choice for launchStream
+static int lanesArg(const lorahip_demod *dm)
+{
+    if (dm->streamLanes != 0 || dm->coWaves == 0) return dm->streamLanes;
+    const int l = streamLanesChosen(dm->ctx->sf, unsigned(dm->B), 0, dm->coWaves);
+    return l == dm->ctx->sf - 4 ? -1 : l;
+}
+
 static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 {
     lorahip_ctx *ctx = dm->ctx;
@@ -850,7 +860,7 @@ static int runStream(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
     // looping over sets) lost there even with the alternating priority (profiles/r04/s22_*: SF7 32768 channels 0.34 against 0.44,
     // SF9 0.36 against 0.40; SF8 / 10 / 12 equal) -- the loop costs the wave-per-channel-set kernels registers -- and is the default
     // only where one-by-one placement leaves slots unusable: SF11 (lorahip_wide.hip::launchStreamWideCfg).
-    a.maxBlocks = dm->streamGrid; a.lanes = dm->streamLanes; a.lastRoundFrom = 0;
+    a.maxBlocks = dm->streamGrid; a.lanes = lanesArg(dm); a.lastRoundFrom = 0;
 #if defined(LORAHIP_ALL_VARIANTS) || defined(LORAHIP_STREAM_PERSIST)
     if (const char *e = std::getenv("LORAHIP_STREAM_BLOCKS")) a.maxBlocks = std::atoi(e);        // e.g. 512: two workgroups of 256 threads per CU
 #endif
@@ -1257,7 +1267,7 @@ static int pipeStep(lorahip_demod *dm, const float *iqDev, const size_t rowStrid
     a.base = nullptr; a.len = nullptr;
     a.uniformLen = (long long)nValid; a.uniformStride = (long long)rowStride;
     a.flags = 4 | 8;                                  // continue the streams; open packets in from / out to the carry rows
-    a.carry = dm->dCarry; a.carryCap = int(dm->carryCap); a.maxBlocks = dm->streamGrid; a.lanes = dm->streamLanes; a.lastRoundFrom = 0;
+    a.carry = dm->dCarry; a.carryCap = int(dm->carryCap); a.maxBlocks = dm->streamGrid; a.lanes = lanesArg(dm); a.lastRoundFrom = 0;
     a.state = reinterpret_cast<StreamState *>(dm->sDev + H.oState);          // the object's own: every launch continues it
     a.nCalls = reinterpret_cast<int *>(d + L.oN); a.nSym = reinterpret_cast<int *>(d + L.oNSym); a.nPkt = reinterpret_cast<int *>(d + L.oNPkt);
     a.nSig = reinterpret_cast<int *>(d + L.oNSig); a.end = reinterpret_cast<int2 *>(d + L.oEnd);
@@ -1791,6 +1801,10 @@ static int runAny(lorahip_demod *dm, const float *iqDev, int64_t *roundsOut)
 
 } // namespace
 
+namespace lorahip {
+void demodSetCoResidentWaves(lorahip_demod *dm, const unsigned waves) { if (dm != nullptr && dm->comp == nullptr) dm->coWaves = waves; }
+}
+
 extern "C" {
 
 int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, const size_t n_channels)
@@ -1827,6 +1841,7 @@ int lorahip_demod_create(lorahip_demod **out, const int device, const int sf, co
     dm->streamGrid = 0;
     dm->streamCapMax = 0;
     dm->streamLanes = 0;
+    dm->coWaves = 0;
     dm->lastLaunches = 0;
     dm->dCarry = nullptr; dm->carryCap = 0; dm->devCarryValid = false; dm->hostCarryStale = false;
     dm->callsPerWindowQ8 = 288;                                 // 1.125 calls per N samples to begin with
@@ -2068,7 +2083,7 @@ int lorahip_demod_stream_lanes(const lorahip_demod *dm)
 {
     if (dm == nullptr || dm->comp) return LORAHIP_E_INVALID;
     const DeviceGuard guard(dm->ctx->device);
-    return streamLanesChosen(dm->ctx->sf, unsigned(dm->B), dm->streamLanes);
+    return streamLanesChosen(dm->ctx->sf, unsigned(dm->B), dm->streamLanes, dm->coWaves);
 }
 
 int lorahip_demod_set_record_capacity(lorahip_demod *dm, const size_t max_calls_per_launch)

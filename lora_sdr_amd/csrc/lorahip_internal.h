@@ -269,7 +269,9 @@ hipError_t launchStreamWide(int sf, const StreamArgs &s, hipStream_t stream);
 hipError_t launchStreamResident(int sf, const StreamArgs &s, hipStream_t stream, unsigned *grid);
 hipError_t launchStreamResidentWide(int sf, const StreamArgs &s, hipStream_t stream, unsigned *grid);    // SF11 / SF12 (lorahip_wide.hip)
 bool streamLanesAvailable(int sf, int log2Lanes);
-int streamLanesChosen(int sf, unsigned nChannels, int forced);
+int streamLanesChosen(int sf, unsigned nChannels, int forced, unsigned otherWaves = 0);
+//! wavefronts the other parts of a mixed object put on this part's device at 16 points per lane (lorahip_rx.cpp -> lorahip_demod.cpp)
+void demodSetCoResidentWaves(lorahip_demod *dm, unsigned waves);
 hipError_t launchStreamLanes(int sf, int log2Lanes, const StreamArgs &s, hipStream_t stream);
 //! a lanes code with this bit: the AHEAD instance over windows of 2^(code & 15) lanes (lorahip_stream_pairs.hip) -- a channel takes two such
 //! lane groups, the second evaluates the window the NEXT call reads if this one is plain

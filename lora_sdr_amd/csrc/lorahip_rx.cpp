@@ -145,6 +145,17 @@ int Composite::create(Composite **out, const int *devices, const size_t nDev, co
                 if (rc != LORAHIP_OK) { const std::string e = lorahip_last_error(); delete k; setLastError(e); return rc; }
                 for (size_t j = 0; j < slot.chan.size(); j++) { I.partOf[slot.chan[j]] = uint32_t(I.parts.size() - 1); I.localOf[slot.chan[j]] = uint32_t(j); }
             }
+        // The parts of one device run side by side (runSegments: a stream and a host thread each), so a part's launch does not have the
+        // device to itself: tell each how many wavefronts its siblings bring (at 16 points per lane: 2^(sf - 4) lanes per channel),
+        // and its choice of a wider geometry (lorahip_stream_lanes.hip) is made into the slots that are left. BASELINE configs[3]:
+        // 2731 channels per SF fill the device several times over -- every part on 16 points per lane, +2 % (profiles/r06/s40_*).
+        for (Impl::Part &part : I.parts)
+        {
+            unsigned long long others = 0;
+            for (const Impl::Part &q : I.parts)
+                if (&q != &part && q.device == part.device) others += ((unsigned long long)q.chan.size() << (q.sf - 4)) / 64u + 1u;
+            demodSetCoResidentWaves(part.d, others > 0xffffffffull ? 0xffffffffu : unsigned(others));
+        }
         if (I.parts.size() > 1)
             for (Impl::Part &part : I.parts)
             {

@@ -336,7 +336,7 @@ bool streamAvailable(const int sf) { return sf >= 6 && sf <= 12; }
 //! log2 of the lanes a channel gets when nobody forces a choice: the 16-points-per-lane geometry unless the launch has so few
 //! channels that a wider one still fits the device's wavefront slots (two per SIMD: lorahip_stream_lanes.hip; thresholds measured,
 //! profiles/r05)
-static int streamLanesFor(const int sf, const unsigned nChannels)
+static int streamLanesFor(const int sf, const unsigned nChannels, const unsigned otherWaves)
 {
     static int slots = 0;                                   // wavefronts the device holds at two per SIMD
     if (slots == 0)
@@ -348,21 +348,24 @@ static int streamLanesFor(const int sf, const unsigned nChannels)
     const int base = sf - 4 > 6 ? 6 : sf - 4;               // SF6: 4 lanes ... SF10: 64
     int best = base;
     for (int l = base + 1; l <= 6; l++)
-        if (streamLanesAvailable(sf, l) && (unsigned long long)nChannels << l <= (unsigned long long)slots * 64u) best = l;
+        if (streamLanesAvailable(sf, l) && ((unsigned long long)nChannels << l) + (unsigned long long)otherWaves * 64u <= (unsigned long long)slots * 64u) best = l;
     // Where even 32 lanes per channel leave half of the slots empty, SF7 takes two such lane groups per channel, the second one a
     // window ahead (lorahip_stream_pairs.hip): measured +8 % at 512 channels, +4 % at 1024, -1 % at 2048 (profiles/r06/s37_ahead_*). The other
     // AHEAD instances never won against the lanes instance that fills the same slots and run only when asked for.
-    if (sf == 7 && best == 5 && (unsigned long long)nChannels * 128u <= (unsigned long long)slots * 64u && streamLanesAvailable(sf, LORAHIP_LANES_AHEAD | 5))
+    if (sf == 7 && best == 5 && (unsigned long long)nChannels * 128u + (unsigned long long)otherWaves * 64u <= (unsigned long long)slots * 64u && streamLanesAvailable(sf, LORAHIP_LANES_AHEAD | 5))
         best = LORAHIP_LANES_AHEAD | 5;
     return best;
 }
 
-//! log2 of the lanes per channel a launch over nChannels channels runs on (the current device's size decides where nobody forces it)
-int streamLanesChosen(const int sf, const unsigned nChannels, const int forced)
+//! log2 of the lanes per channel a launch over nChannels channels runs on (the current device's size decides where nobody forces it;
+//! otherWaves: wavefronts that launches running BESIDE this one put on the device -- the other parts of a mixed object, lorahip_rx.cpp:
+//! slots they take are not empty, and a wider geometry pays more slot-time per call than the 16-point one, so it is chosen only into
+//! slots nobody else wants)
+int streamLanesChosen(const int sf, const unsigned nChannels, const int forced, const unsigned otherWaves)
 {
     const int base = sf <= 10 ? sf - 4 : sf - 4;            // SF6: 4 lanes ... SF10: 64; SF11 / SF12: a workgroup of 128 / 256
     if (sf < 7 || sf > 9) return base;
-    const int lanes = forced > 0 ? forced : (forced < 0 ? base : streamLanesFor(sf, nChannels));
+    const int lanes = forced > 0 ? forced : (forced < 0 ? base : streamLanesFor(sf, nChannels, otherWaves));
     return lanes != base && streamLanesAvailable(sf, lanes) ? lanes : base;
 }
 

@@ -143,3 +143,25 @@ def test_the_choice_follows_the_channel_count(gpu):
     fewer.set_stream_lanes(5)
     assert fewer.stream_lanes() == 5
     fewer.close()
+
+
+def test_the_parts_of_a_mixed_object_count_their_siblings(gpu):
+    """a part of lorahip_demod_create_mixed shares the device with the other parts: wider lanes only into slots nobody else takes"""
+    import lora_sdr_amd as L
+    import torch
+    slots = torch.cuda.get_device_properties(0).multi_processor_count * 8
+    # BASELINE configs[3]: 16384 channels, SF = 7 + c mod 6 -- the SF10-12 parts alone fill the device several times over
+    big = L.LoRaDemod(channel_sf=(7 + np.arange(16384) % 6).astype(np.int32), devices=[0])
+    assert [p[1] for p in big.parts] == [7, 8, 9, 10, 11, 12]
+    assert big.part_stream_lanes() == [3, 4, 5, 6, 7, 8]
+    big.set_stream_lanes(5)                                              # asked for: as asked
+    assert big.part_stream_lanes()[0] == 5
+    big.set_stream_lanes(0)
+    assert big.part_stream_lanes()[0] == 3
+    big.close()
+    # a handful of channels per SF: every part as wide as it would be alone
+    n = max(6, slots // 64 * 6)
+    small = L.LoRaDemod(channel_sf=(7 + np.arange(n) % 3).astype(np.int32), devices=[0])
+    assert small.part_stream_lanes() == [AHEAD | 5, 6, 6]
+    small.close()
+    # the same results either way (scheduling only): the mixed object against its parts alone is tests/test_gpu_mixed.py
