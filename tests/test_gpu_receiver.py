@@ -859,3 +859,12 @@ def test_summary_and_row_numbers_over_several_workgroups(gpu, oracle, sf, B):
     for c in range(0, B, 37):
         assert all(np.array_equal(a, b) for a, (_, b) in zip(got[c], refs[kind_of[c]]["packets"])) and len(got[c]) == len(refs[kind_of[c]]["packets"])
     d.close()
+
+
+def test_random_mixed_objects_equal_their_reference_blocks(gpu):
+    """a few seconds of tools/soak_mixed.py (fixed seeds): random SF mixes, device lists, segment placements, settings, lanes, signals --
+    every channel of the mixed object equal to its own reference block (LoRaDemod.cpp:119-122: one block per channel)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_mixed.py"), "5", "424200"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "equal the reference's" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
