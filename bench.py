@@ -952,7 +952,7 @@ def section_level3(env, L, sf, threads=32):
     return res
 
 
-def section_level3_scaling(env, L, sweeps=((7, (2048, 4096, 8192, 16384, 24576, 32768)), (8, (2048, 4096)), (9, (1024, 2048)), (10, (512, 1024)), (11, (1024, 2048, 4096)),
+def section_level3_scaling(env, L, sweeps=((7, (1024, 2048, 4096, 8192, 16384, 24576, 32768)), (8, (2048, 4096)), (9, (1024, 2048)), (10, (512, 1024)), (11, (1024, 2048, 4096)),
                                            (12, (256, 512, 1024, 2048, 4096))), both_grids=False, passes=4):
     """The streaming kernels against the channel count (whole LoRaDemod blocks, the level-3 workload): below the resident set (two
     wavefronts per SIMD: 16384 channels at SF7, 1024 at SF11, 512 at SF12) the device is not full; above it the dispatcher hands every
